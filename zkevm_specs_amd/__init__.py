@@ -1,0 +1,1 @@
+"""zkevm_specs_amd — MI355X-native constraint-evaluation engine for the zkEVM spec circuits."""

@@ -1,0 +1,75 @@
+// Shared definitions for the constraint kernels: status codes, the pass/fail tally, the
+// open-addressing row index used by every lookup table, and cell accessors.
+#pragma once
+#include "fr.hpp"
+
+#if defined(ZK_HOSTSIM)
+#include <string.h>
+#endif
+
+// ---------------------------------------------------------------------------------------
+// Status code of one evaluated row / step:  0 = all constraints satisfied, otherwise
+// (kind << 24) | site.  `kind` is the Python exception class the reference raises at the
+// first failing check of that row; `site` identifies the check in
+// source order (kernel-specific numbering, documented next to each kernel).
+// ---------------------------------------------------------------------------------------
+enum ZkKind : u32 {
+    ZK_OK = 0,
+    ZK_ASSERT = 1,            // AssertionError (constrain_*, plain assert)
+    ZK_CONSTRAINT = 2,        // ConstraintUnsatFailure *raised* (range_check, word_to_fq)
+    ZK_LOOKUP_UNSAT = 3,      // LookupUnsatFailure (table.py:688,880)
+    ZK_LOOKUP_AMBIGUOUS = 4,  // LookupAmbiguousFailure (table.py:882)
+    ZK_WRONG_QUERY_KEY = 5,   // WrongQueryKey (table.py:387) - unreachable from fixed call sites
+    ZK_NOT_IMPLEMENTED = 6,   // NotImplementedError (main.py:63)
+    ZK_TYPE_ERROR = 7,        // TypeError
+    ZK_OVERFLOW_ERROR = 8,    // OverflowError (int.to_bytes on an over-wide / negative value)
+    ZK_VALUE_ERROR = 9,       // ValueError (enum ctor, bytes() out of range)
+    ZK_ZERO_DIVISION = 10,    // ZeroDivisionError
+    ZK_UNSUPPORTED = 15,      // engine limitation: state/gadget not implemented on device
+};
+#define ZK_CODE(kind, site) ((((u32)(kind)) << 24) | ((u32)(site) & 0xffffffu))
+
+struct ZkTally {
+    unsigned long long fail_count;       // rows with status != 0
+    unsigned long long first_fail;       // min over failing rows of (row << 32 | code); ~0 = none
+};
+
+#define ZK_EMPTY_SLOT 0xffffffffu
+
+// 64-bit mixer (splitmix64 finaliser) used to spread keys over the open-addressing index.
+ZK_HD u64 zk_mix64(u64 x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+ZK_HD u64 zk_hash_cell(u64 h, const Fr& c) {
+    u64 a = ((u64)c.v[0] | ((u64)c.v[1] << 32)) ^ (((u64)c.v[2] | ((u64)c.v[3] << 32)) * 0x9e3779b97f4a7c15ull);
+    u64 b = ((u64)c.v[4] | ((u64)c.v[5] << 32)) ^ (((u64)c.v[6] | ((u64)c.v[7] << 32)) * 0xc2b2ae3d27d4eb4full);
+    return zk_mix64(h ^ a ^ (b << 1) ^ (b >> 63)) + 0x632be59bd9b4e019ull;
+}
+
+// Row-major lookup table resident in HBM: n rows of `ncells` canonical cells (32 B each),
+// one u32 of per-row type bits (is_word flags of WordOrValue columns), and an
+// open-addressing index (slot -> row id) keyed on a fixed subset of the cells.
+struct ZkTable {
+    const u64* cells;   // [n][ncells][4]
+    const u32* flags;   // [n] or nullptr
+    const u32* slots;   // [mask + 1], ZK_EMPTY_SLOT = empty
+    u32 n;
+    u32 ncells;
+    u32 mask;
+};
+ZK_HD Fr zk_table_cell(const ZkTable& t, u32 row, u32 c) {
+    return fr_load(t.cells + ((u64)row * t.ncells + c) * 4);
+}
+
+// Column-major witness: cell c of row i at cells[(c * n + i) * 4].
+struct ZkCols {
+    const u64* cells;
+    const u32* flags;
+    u64 n;
+};
+ZK_HD Fr zk_col(const ZkCols& w, u32 c, u64 i) { return fr_load(w.cells + ((u64)c * w.n + i) * 4); }

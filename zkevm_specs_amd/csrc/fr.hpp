@@ -1,0 +1,309 @@
+// BN254 scalar field (Fr) + 256-bit integer helpers for the constraint kernels.
+//
+// Semantics follow the reference's field type `FQ` (src/zkevm_specs/util/arithmetic.py:41-63,
+// a py_ecc.bn128.FQ with field_modulus = curve_order): every cell is a canonical integer in
+// [0, p).  Wire/HBM format is 4 x u64 little-endian canonical (bit-comparable with `FQ.n`);
+// in registers a cell is 8 x u32 (gfx950 VGPRs are 32-bit and the multiplier is
+// v_mad_u64_u32, so the Montgomery CIOS inner product runs on 32-bit limbs).
+//
+// Multiplication is Montgomery (R = 2^256): mont(a, b) = a*b*R^-1.  Cells stay canonical in
+// registers (range checks / comparisons read `.n` directly, like the reference does), so
+//   fr_mul(a, b)   = mont(mont(a, b), R^2)      (canonical x canonical -> canonical)
+//   fr_mulc(a, cM) = mont(a, cM)                 (cM = constant pre-converted to Montgomery form)
+//
+// The same source is compiled by hipcc for gfx950 (product) and by g++ with -DZK_HOSTSIM for
+// the CPU logic tests under tests/hostsim (test infrastructure, never loaded by the package).
+#pragma once
+#include <stdint.h>
+#include "fr_constants.h"
+
+#if defined(ZK_HOSTSIM)
+#define ZK_HD static inline
+#define ZK_CONST static const
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+#else
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_CONST __device__ static const
+#endif
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct Fr {
+    u32 v[8];
+};
+
+#define FR_CONST_ARR(name, limbs) ZK_HD Fr name() { Fr r = {limbs}; return r; }
+FR_CONST_ARR(fr_modulus, FR_P_LIMBS)
+FR_CONST_ARR(frm_one, FR_R_LIMBS)
+FR_CONST_ARR(frm_r2, FR_R2_LIMBS)
+FR_CONST_ARR(frm_2p16, FRM_2P16_LIMBS)
+FR_CONST_ARR(frm_2p64, FRM_2P64_LIMBS)
+FR_CONST_ARR(frm_2p128, FRM_2P128_LIMBS)
+FR_CONST_ARR(frm_256, FRM_256_LIMBS)
+FR_CONST_ARR(frm_inv_2p128, FRM_INV_2P128_LIMBS)
+FR_CONST_ARR(frm_inv2, FRM_INV2_LIMBS)
+FR_CONST_ARR(frm_inv4, FRM_INV4_LIMBS)
+FR_CONST_ARR(frm_inv8, FRM_INV8_LIMBS)
+
+ZK_HD Fr fr_zero() {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    return r;
+}
+ZK_HD Fr fr_from_u64(u64 x) {
+    Fr r = fr_zero();
+    r.v[0] = (u32)x;
+    r.v[1] = (u32)(x >> 32);
+    return r;
+}
+ZK_HD Fr fr_from_u128(u64 lo, u64 hi) {
+    Fr r = fr_zero();
+    r.v[0] = (u32)lo;
+    r.v[1] = (u32)(lo >> 32);
+    r.v[2] = (u32)hi;
+    r.v[3] = (u32)(hi >> 32);
+    return r;
+}
+// Load one canonical cell (4 x u64 LE = 8 x u32 LE on a little-endian machine).
+ZK_HD Fr fr_load(const u64* p) {
+    Fr r;
+    const uint4* q = (const uint4*)p;
+    uint4 a = q[0], b = q[1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+ZK_HD bool fr_is_zero(const Fr& a) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+ZK_HD bool fr_eq(const Fr& a, const Fr& b) {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// value fits in 64 / 128 bits (upper limbs zero)
+ZK_HD bool fr_fits64(const Fr& a) { return (a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0; }
+ZK_HD bool fr_fits128(const Fr& a) { return (a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0; }
+ZK_HD bool fr_fits32(const Fr& a) { return (a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0; }
+ZK_HD u64 fr_lo64(const Fr& a) { return (u64)a.v[0] | ((u64)a.v[1] << 32); }
+ZK_HD u64 fr_hi64of128(const Fr& a) { return (u64)a.v[2] | ((u64)a.v[3] << 32); }
+ZK_HD bool fr_eq_u64(const Fr& a, u64 x) { return fr_fits64(a) && fr_lo64(a) == x; }
+// a <= x as integers (x: u64)
+ZK_HD bool fr_le_u64(const Fr& a, u64 x) { return fr_fits64(a) && fr_lo64(a) <= x; }
+// number of significant bytes of the canonical integer (0 for zero)
+ZK_HD int fr_byte_len(const Fr& a) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 w = a.v[i];
+        if (w) n = 4 * i + (w >> 24 ? 4 : (w >> 16 ? 3 : (w >> 8 ? 2 : 1)));
+    }
+    return n;
+}
+ZK_HD u32 fr_byte(const Fr& a, int i) { return (a.v[i >> 2] >> (8 * (i & 3))) & 0xff; }
+
+// integer compare of canonical values: a < b
+ZK_HD bool fr_lt(const Fr& a, const Fr& b) {
+    bool lt = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        lt = (a.v[i] < b.v[i]) || (a.v[i] == b.v[i] && lt);
+    }
+    return lt;
+}
+// raw 256-bit add/sub with carry/borrow out
+ZK_HD u32 u256_add(Fr& r, const Fr& a, const Fr& b) {
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)a.v[i] + b.v[i];
+        r.v[i] = (u32)c;
+        c >>= 32;
+    }
+    return (u32)c;
+}
+ZK_HD u32 u256_sub(Fr& r, const Fr& a, const Fr& b) {
+    u64 bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - b.v[i] - bw;
+        r.v[i] = (u32)t;
+        bw = (t >> 32) & 1;
+    }
+    return (u32)bw;
+}
+ZK_HD bool fr_geq_p(const Fr& a) {
+    Fr p = fr_modulus();
+    return !fr_lt(a, p);
+}
+ZK_HD Fr fr_add(const Fr& a, const Fr& b) {
+    Fr s, t;
+    u256_add(s, a, b);  // a,b < p < 2^254: no carry out
+    Fr p = fr_modulus();
+    u32 bw = u256_sub(t, s, p);
+    return bw ? s : t;
+}
+ZK_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    Fr d, t;
+    u32 bw = u256_sub(d, a, b);
+    Fr p = fr_modulus();
+    u256_add(t, d, p);
+    return bw ? t : d;
+}
+ZK_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
+ZK_HD Fr fr_add_u64(const Fr& a, u64 x) { return fr_add(a, fr_from_u64(x)); }
+ZK_HD Fr fr_sub_u64(const Fr& a, u64 x) { return fr_sub(a, fr_from_u64(x)); }
+
+// Montgomery product a*b*R^-1 mod p (CIOS on 8 x 32-bit limbs); inputs < p.
+ZK_HD Fr fr_mont(const Fr& a, const Fr& b) {
+    const Fr p = fr_modulus();
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+        const u32 bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * bi + t[j];
+            t[j] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (u32)c;
+        t[9] = (u32)(c >> 32);
+        const u32 m = t[0] * FR_INV32;
+        c = (u64)m * p.v[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (u64)m * p.v[j] + t[j];
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (u32)c;
+        t[8] = t[9] + (u32)(c >> 32);
+    }
+    Fr r, s;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    u32 bw = u256_sub(s, r, p);
+    return (t[8] || !bw) ? s : r;
+}
+ZK_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_mont(fr_mont(a, b), frm_r2()); }
+ZK_HD Fr fr_mulc(const Fr& a, const Fr& cM) { return fr_mont(a, cM); }
+ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont(a, frm_r2()); }
+// small-constant multiply by repeated doubling is avoided: use integer path when it fits.
+ZK_HD Fr fr_mul_u64(const Fr& a, u64 k) { return fr_mulc(a, fr_to_mont(fr_from_u64(k))); }
+
+// ---------------------------------------------------------------------------------------
+// 256-bit unsigned integer helpers (EVM words). U256 reuses the Fr limb container but the
+// value is a plain integer in [0, 2^256).
+// ---------------------------------------------------------------------------------------
+typedef Fr U256;
+
+ZK_HD U256 u256_from_lo_hi(const Fr& lo, const Fr& hi) {  // lo, hi < 2^128 (caller-checked)
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r.v[i] = lo.v[i];
+        r.v[4 + i] = hi.v[i];
+    }
+    return r;
+}
+ZK_HD Fr u256_lo(const U256& a) {
+    Fr r = fr_zero();
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = a.v[i];
+    return r;
+}
+ZK_HD Fr u256_hi(const U256& a) {
+    Fr r = fr_zero();
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.v[i] = a.v[4 + i];
+    return r;
+}
+ZK_HD u64 u256_limb64(const U256& a, int i) { return (u64)a.v[2 * i] | ((u64)a.v[2 * i + 1] << 32); }
+
+struct U512 {
+    u32 v[16];
+};
+ZK_HD U512 u256_mul_full(const U256& a, const U256& b) {
+    U512 r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.v[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * b.v[i] + r.v[i + j];
+            r.v[i + j] = (u32)c;
+            c >>= 32;
+        }
+        r.v[i + 8] = (u32)c;
+    }
+    return r;
+}
+ZK_HD U256 u512_lo(const U512& a) {
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
+    return r;
+}
+ZK_HD U256 u512_hi(const U512& a) {
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[8 + i];
+    return r;
+}
+ZK_HD U512 u512_from(const U256& lo, const U256& hi) {
+    U512 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i] = lo.v[i];
+        r.v[8 + i] = hi.v[i];
+    }
+    return r;
+}
+ZK_HD int u256_bit(const U256& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1; }
+ZK_HD int u512_bit(const U512& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1; }
+
+// Restoring shift-subtract division of a 512-bit numerator by a 256-bit divisor (d != 0).
+// q receives the low 512 bits of the quotient, r the remainder.  Used for the witness
+// values the reference computes with Python big-int // and % (e.g. mul_div_mod.py:23-41,
+// addmod.py:32-41, mulmod.py:41-50).  `nbits` = number of numerator bits to process.
+ZK_HD void u512_divmod(const U512& n, const U256& d, U512& q, U256& r, int nbits) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) q.v[i] = 0;
+    r = fr_zero();
+    for (int i = nbits - 1; i >= 0; i--) {
+        // r = (r << 1) | bit
+        u32 top = r.v[7] >> 31;
+#pragma unroll
+        for (int k = 7; k > 0; k--) r.v[k] = (r.v[k] << 1) | (r.v[k - 1] >> 31);
+        r.v[0] = (r.v[0] << 1) | (u32)u512_bit(n, i);
+        U256 t;
+        u32 bw = u256_sub(t, r, d);
+        if (top || !bw) {
+            r = t;
+            q.v[i >> 5] |= 1u << (i & 31);
+        }
+    }
+}
+ZK_HD void u256_divmod(const U256& n, const U256& d, U256& q, U256& r) {
+    U512 nn = u512_from(n, fr_zero()), qq;
+    u512_divmod(nn, d, qq, r, 256);
+    q = u512_lo(qq);
+}

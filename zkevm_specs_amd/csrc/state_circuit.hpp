@@ -1,0 +1,359 @@
+// State (RW-consistency) circuit: per-row constraint evaluation.
+//
+// Reference: src/zkevm_specs/state_circuit.py — `check_state_row` :492-613, per-tag checks
+// :216-488, `LowerThanGadget` :195-207, `all_keys_eq` :188, `Tables.mpt_lookup` :165-184;
+// the row loop with wrap-around neighbours lives in tests/test_state_circuit.py:26-30.
+//
+// Witness layout (column-major, 57 cells per row, 32 B per cell):
+//   0 rw_counter | 1 is_write | 2 tag | 3 id | 4 address | 5 field_tag | 6,7 storage_key lo,hi
+//   8..17 address limbs (16-bit, LE) | 18..49 storage-key bytes (LE)
+//   50,51 value lo,hi | 52,53 initial_value lo,hi | 54,55 root lo,hi | 56 lexicographic selector
+// flags bit0 = value.is_word, bit1 = initial_value.is_word (WordOrValue, util/arithmetic.py:171).
+// MPT table row (row-major, 12 cells): address, proof_type, storage_key lo,hi, root lo,hi,
+//   root_prev lo,hi, value lo,hi, value_prev lo,hi  (evm_circuit/table.py:461-468).
+//
+// Site numbers (low 24 bits of the status code) are listed beside each check; they follow the
+// reference's evaluation order, so the first failing site is the one Python would raise at.
+#pragma once
+#include "common.hpp"
+
+enum {
+    ST_RWC = 0, ST_IS_WRITE = 1, ST_TAG = 2, ST_ID = 3, ST_ADDR = 4, ST_FIELD_TAG = 5,
+    ST_KEY_LO = 6, ST_KEY_HI = 7, ST_LIMB0 = 8, ST_BYTE0 = 18, ST_VAL_LO = 50, ST_VAL_HI = 51,
+    ST_INIT_LO = 52, ST_INIT_HI = 53, ST_ROOT_LO = 54, ST_ROOT_HI = 55, ST_LEX = 56,
+    ST_NCELLS = 57,
+};
+enum { MPT_NCELLS = 12 };
+
+struct StateArgs {
+    ZkCols rows;
+    ZkTable mpt;
+};
+
+// 576-bit accumulator for the lexicographic key packing of state_circuit.py:552-565.
+struct Big18 {
+    u32 v[18];
+};
+ZK_HD void big_shl_add(Big18& a, int shift_words, int shift_bits, const Fr& x) {
+    // a = (a << (32*shift_words + shift_bits)) + x, truncated to 576 bits (the reference
+    // keeps only the low 31 16-bit limbs = 496 bits afterwards).
+    if (shift_bits) {
+        for (int k = 17; k > 0; k--) a.v[k] = (a.v[k] << shift_bits) | (a.v[k - 1] >> (32 - shift_bits));
+        a.v[0] <<= shift_bits;
+    }
+    if (shift_words) {
+        for (int k = 17; k >= 0; k--) a.v[k] = (k >= shift_words) ? a.v[k - shift_words] : 0;
+    }
+    u64 c = 0;
+    for (int k = 0; k < 18; k++) {
+        c += (u64)a.v[k] + (k < 8 ? x.v[k] : 0u);
+        a.v[k] = (u32)c;
+        c >>= 32;
+    }
+}
+
+// Packs (tag, id, address, field_tag, storage_key_bytes, rw_counter) exactly like
+// keys_rwc_to_limbs_in_order (state_circuit.py:552-565) using the raw `.n` of every cell.
+// Returns false if a storage-key byte is >= 256 (Python: bytes() raises ValueError).
+ZK_HD bool state_pack_keys(const ZkCols& w, u64 i, Big18& out) {
+    for (int k = 0; k < 18; k++) out.v[k] = 0;
+    U256 key = fr_zero();
+    bool ok = true;
+    for (int b = 0; b < 32; b++) {
+        Fr c = zk_col(w, ST_BYTE0 + b, i);
+        if (!fr_le_u64(c, 255)) ok = false;
+        key.v[b >> 2] |= (c.v[0] & 0xff) << (8 * (b & 3));
+    }
+    if (!ok) return false;
+    big_shl_add(out, 0, 0, zk_col(w, ST_TAG, i));
+    big_shl_add(out, 0, 28, zk_col(w, ST_ID, i));         // v * 2^ID_BITS + id
+    big_shl_add(out, 5, 0, zk_col(w, ST_ADDR, i));        // v * 2^160 + address
+    big_shl_add(out, 0, 16, zk_col(w, ST_FIELD_TAG, i));  // v * 2^16 + field_tag
+    big_shl_add(out, 1, 0, key);                          // v * 2^32 + storage key (256-bit)
+    big_shl_add(out, 1, 0, zk_col(w, ST_RWC, i));         // v * 2^32 + rw_counter
+    // keep 31 limbs of 16 bits = 496 bits
+    out.v[15] &= 0xffffu;
+    out.v[16] = 0;
+    out.v[17] = 0;
+    return true;
+}
+ZK_HD bool big_lt(const Big18& a, const Big18& b) {
+    bool lt = false;
+    for (int k = 0; k < 16; k++) lt = (a.v[k] < b.v[k]) || (a.v[k] == b.v[k] && lt);
+    return lt;
+}
+
+ZK_HD bool state_keys_eq(const ZkCols& w, u64 i, u64 j) {
+    bool eq = true;
+    for (int c = ST_TAG; c <= ST_KEY_HI; c++) eq = eq && fr_eq(zk_col(w, c, i), zk_col(w, c, j));
+    return eq;
+}
+ZK_HD bool state_pair_eq(const ZkCols& w, int c, u64 i, u64 j) {
+    return fr_eq(zk_col(w, c, i), zk_col(w, c, j)) && fr_eq(zk_col(w, c + 1, i), zk_col(w, c + 1, j));
+}
+ZK_HD bool state_pair_zero(const ZkCols& w, int c, u64 i) {
+    return fr_is_zero(zk_col(w, c, i)) && fr_is_zero(zk_col(w, c + 1, i));
+}
+
+// MPT lookup with every field given (state_circuit.py:165-184 -> table.py:864-884): since
+// the query covers all 12 cells and the table is a set, 0 or 1 distinct rows can match.
+ZK_HD bool state_mpt_lookup(const ZkTable& t, const Fr q[MPT_NCELLS]) {
+    if (t.n == 0) return false;
+    u64 h = 0x5bd1e995u;
+    h = zk_hash_cell(h, q[0]);
+    h = zk_hash_cell(h, q[2]);
+    h = zk_hash_cell(h, q[3]);
+    u32 slot = (u32)h & t.mask;
+    for (u32 probes = 0; probes <= t.mask; probes++) {
+        u32 r = t.slots[slot];
+        if (r == ZK_EMPTY_SLOT) return false;
+        bool m = true;
+        for (int c = 0; c < MPT_NCELLS; c++) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
+        if (m) return true;
+        slot = (slot + 1) & t.mask;
+    }
+    return false;
+}
+ZK_HD u64 state_mpt_key_hash(const ZkTable& t, u32 r) {
+    u64 h = 0x5bd1e995u;
+    h = zk_hash_cell(h, zk_table_cell(t, r, 0));
+    h = zk_hash_cell(h, zk_table_cell(t, r, 2));
+    h = zk_hash_cell(h, zk_table_cell(t, r, 3));
+    return h;
+}
+
+#define ST_FAIL(kind, site) return ZK_CODE(kind, site)
+#define ST_ASSERT(cond, site) do { if (!(cond)) ST_FAIL(ZK_ASSERT, site); } while (0)
+
+// Evaluate row i against prev = (i-1) mod n and next = (i+1) mod n.
+ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
+    const ZkCols& w = a.rows;
+    const u64 n = w.n;
+    const u64 ip = (i + n - 1) % n;
+    const u64 in = (i + 1) % n;
+    const u32 fl = w.flags ? w.flags[i] : 0u;
+    const bool val_is_word = fl & 1u, init_is_word = fl & 2u;
+
+    const Fr rwc = zk_col(w, ST_RWC, i);
+    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
+    const Fr tag = zk_col(w, ST_TAG, i);
+    const Fr id = zk_col(w, ST_ID, i);
+    const Fr addr = zk_col(w, ST_ADDR, i);
+    const Fr ftag = zk_col(w, ST_FIELD_TAG, i);
+
+    // 0.0 tag, id, field_tag ranges (:498-502)
+    ST_ASSERT(fr_fits64(tag) && fr_lo64(tag) >= 1 && fr_lo64(tag) <= 12, 1);
+    ST_ASSERT(fr_le_u64(id, (1ull << 28) - 1), 2);
+    ST_ASSERT(fr_le_u64(ftag, 24), 3);
+    const u32 tagv = tag.v[0];
+
+    // 0.1 address limbs are 16-bit and recompose to address in Fr (:505-509)
+    {
+        U256 lc = fr_zero();
+        for (int k = 0; k < 10; k++) {
+            Fr limb = zk_col(w, ST_LIMB0 + k, i);
+            ST_ASSERT(fr_le_u64(limb, 65535), 4);
+            lc.v[k >> 1] |= (limb.v[0] & 0xffffu) << (16 * (k & 1));
+        }
+        ST_ASSERT(fr_eq(addr, lc), 5);  // sum < 2^160 < p: integer value == field value
+    }
+    // 0.2 storage-key bytes are bytes and recompose to (lo, hi) (:512-517)
+    {
+        Fr lo = fr_zero(), hi = fr_zero();
+        for (int b = 0; b < 32; b++) {
+            Fr c = zk_col(w, ST_BYTE0 + b, i);
+            ST_ASSERT(fr_le_u64(c, 255), 6);
+            u32 byte = c.v[0] & 0xff;
+            if (b < 16) lo.v[b >> 2] |= byte << (8 * (b & 3));
+            else hi.v[(b - 16) >> 2] |= byte << (8 * (b & 3));
+        }
+        ST_ASSERT(fr_eq(zk_col(w, ST_KEY_LO, i), lo) && fr_eq(zk_col(w, ST_KEY_HI, i), hi), 7);
+    }
+    // 0.3 is_write boolean (:520)
+    ST_ASSERT(fr_le_u64(is_write, 1), 8);
+    const bool is_read = fr_is_zero(is_write);
+
+    // 0.4 lexicographic ordering (:552-570).  Both limb vectors are built unconditionally.
+    {
+        Big18 kp, kc;
+        if (!state_pack_keys(w, ip, kp)) ST_FAIL(ZK_VALUE_ERROR, 9);
+        state_pack_keys(w, i, kc);
+        if (tagv != 1) ST_ASSERT(big_lt(kp, kc), 10);
+    }
+    const bool keys_eq_prev = state_keys_eq(w, i, ip);
+    // 0.5 read consistency (:577-581)
+    if (is_read && keys_eq_prev) ST_ASSERT(state_pair_eq(w, ST_VAL_LO, i, ip), 11);
+    if (keys_eq_prev) ST_ASSERT(state_pair_eq(w, ST_INIT_LO, i, ip), 12);
+    // 8. rw_counter != 0 except Start (:584-585)
+    if (tagv != 1) ST_ASSERT(!fr_is_zero(rwc), 13);
+
+    const Fr val_lo = zk_col(w, ST_VAL_LO, i), val_hi = zk_col(w, ST_VAL_HI, i);
+    const Fr init_lo = zk_col(w, ST_INIT_LO, i), init_hi = zk_col(w, ST_INIT_HI, i);
+    const bool key_zero = state_pair_zero(w, ST_KEY_LO, i);
+    const bool root_same = state_pair_eq(w, ST_ROOT_LO, i, ip);
+    const bool val_zero = fr_is_zero(val_lo) && fr_is_zero(val_hi);
+    const bool init_zero = fr_is_zero(init_lo) && fr_is_zero(init_hi);
+
+    switch (tagv) {
+    case 1:  // Start (:216-236)
+        ST_ASSERT(fr_is_zero(ftag), 20);
+        ST_ASSERT(fr_is_zero(addr), 21);
+        ST_ASSERT(fr_is_zero(id), 22);
+        ST_ASSERT(key_zero, 23);
+        ST_ASSERT(fr_is_zero(val_hi), 24);
+        ST_ASSERT(fr_is_zero(init_hi), 25);
+        {
+            Fr lex = zk_col(w, ST_LEX, i);
+            Fr d = fr_sub_u64(fr_sub(rwc, zk_col(w, ST_RWC, ip)), 1);
+            ST_ASSERT(fr_is_zero(lex) || fr_is_zero(d), 26);  // p prime: product zero iff a factor is
+            ST_ASSERT(!val_is_word, 27);
+            ST_ASSERT(fr_is_zero(val_lo), 28);
+            ST_ASSERT(!init_is_word, 29);
+            ST_ASSERT(fr_is_zero(init_lo), 30);
+            if (!fr_is_zero(lex)) ST_ASSERT(root_same, 31);
+        }
+        break;
+    case 2:  // Memory (:240-266)
+        ST_ASSERT(fr_is_zero(ftag), 40);
+        ST_ASSERT(key_zero, 41);
+        ST_ASSERT(fr_is_zero(val_hi), 42);
+        ST_ASSERT(fr_is_zero(init_hi), 43);
+        if (!keys_eq_prev && is_read) {
+            ST_ASSERT(!val_is_word, 44);
+            ST_ASSERT(fr_is_zero(val_lo), 45);
+        }
+        ST_ASSERT(fr_le_u64(addr, 0xffffffffull), 46);
+        ST_ASSERT(!val_is_word, 47);
+        ST_ASSERT(fr_le_u64(val_lo, 255), 48);
+        ST_ASSERT(!init_is_word, 49);
+        ST_ASSERT(fr_is_zero(init_lo), 50);
+        ST_ASSERT(root_same, 51);
+        break;
+    case 3:  // Stack (:270-301)
+        ST_ASSERT(fr_is_zero(ftag), 60);
+        ST_ASSERT(key_zero, 61);
+        if (!keys_eq_prev) ST_ASSERT(fr_eq_u64(is_write, 1), 62);
+        ST_ASSERT(fr_le_u64(addr, 1023), 63);
+        if (fr_eq(tag, zk_col(w, ST_TAG, ip)) && fr_eq(id, zk_col(w, ST_ID, ip))) {
+            Fr d = fr_sub(addr, zk_col(w, ST_ADDR, ip));
+            ST_ASSERT(fr_le_u64(d, 1), 64);
+        }
+        ST_ASSERT(init_zero, 65);
+        ST_ASSERT(root_same, 66);
+        break;
+    case 4:    // Storage (:305-324)
+    case 6: {  // Account (:349-380)
+        u64 proof_type;
+        if (tagv == 4) {
+            ST_ASSERT(fr_is_zero(ftag), 70);
+            proof_type = (val_zero && init_zero) ? 4 : 6;  // NonExistingAccountProof : StorageMod
+        } else {
+            // AccountFieldTag(field_tag.n) raises ValueError outside 1..4 (:350)
+            if (!(fr_lo64(ftag) >= 1 && fr_lo64(ftag) <= 4)) ST_FAIL(ZK_VALUE_ERROR, 90);
+            ST_ASSERT(fr_is_zero(id), 91);
+            ST_ASSERT(key_zero, 92);
+            if (fr_eq_u64(ftag, 1)) {
+                ST_ASSERT(fr_is_zero(val_hi), 93);
+                ST_ASSERT(fr_is_zero(init_hi), 94);
+            }
+            bool non_exist = val_zero && init_zero && fr_eq_u64(ftag, 3);
+            proof_type = non_exist ? 4 : fr_lo64(ftag);  // from_account_field_tag: tag k -> proof k
+        }
+        if (!state_keys_eq(w, i, in)) {
+            Fr q[MPT_NCELLS];
+            q[0] = addr;
+            q[1] = fr_from_u64(proof_type);
+            q[2] = zk_col(w, ST_KEY_LO, i);
+            q[3] = zk_col(w, ST_KEY_HI, i);
+            q[4] = zk_col(w, ST_ROOT_LO, i);
+            q[5] = zk_col(w, ST_ROOT_HI, i);
+            q[6] = zk_col(w, ST_ROOT_LO, ip);
+            q[7] = zk_col(w, ST_ROOT_HI, ip);
+            q[8] = val_lo;
+            q[9] = val_hi;
+            q[10] = init_lo;
+            q[11] = init_hi;
+            if (!state_mpt_lookup(a.mpt, q)) ST_FAIL(ZK_LOOKUP_UNSAT, tagv == 4 ? 71 : 95);
+        } else {
+            ST_ASSERT(root_same, tagv == 4 ? 73 : 97);
+        }
+        break;
+    }
+    case 5:  // CallContext (:328-345)
+        ST_ASSERT(fr_is_zero(addr), 80);
+        ST_ASSERT(key_zero, 81);
+        ST_ASSERT(fr_le_u64(ftag, 24), 82);
+        if (!keys_eq_prev && is_read) {
+            ST_ASSERT(!val_is_word, 83);
+            ST_ASSERT(fr_is_zero(val_lo), 84);
+        }
+        ST_ASSERT(init_zero, 85);
+        ST_ASSERT(root_same, 86);
+        break;
+    case 7:  // TxRefund (:387-402)
+        ST_ASSERT(fr_is_zero(addr), 100);
+        ST_ASSERT(fr_is_zero(ftag), 101);
+        ST_ASSERT(key_zero, 102);
+        ST_ASSERT(root_same, 103);
+        ST_ASSERT(init_zero, 104);
+        if (!keys_eq_prev && is_read) ST_ASSERT(val_zero, 105);
+        break;
+    case 8:  // TxAccessListAccount (:406-419)
+        ST_ASSERT(fr_is_zero(ftag), 110);
+        ST_ASSERT(key_zero, 111);
+        ST_ASSERT(fr_is_zero(val_hi), 112);
+        ST_ASSERT(fr_is_zero(init_hi), 113);
+        ST_ASSERT(root_same, 114);
+        if (!keys_eq_prev && is_read) {
+            ST_ASSERT(!val_is_word, 115);
+            ST_ASSERT(fr_is_zero(val_lo), 116);
+        }
+        break;
+    case 9:  // TxAccessListAccountStorage (:423-435)
+        ST_ASSERT(fr_is_zero(ftag), 120);
+        ST_ASSERT(fr_is_zero(val_hi), 121);
+        ST_ASSERT(fr_is_zero(init_hi), 122);
+        ST_ASSERT(root_same, 123);
+        if (!keys_eq_prev && is_read) {
+            ST_ASSERT(!val_is_word, 124);
+            ST_ASSERT(fr_is_zero(val_lo), 125);
+        }
+        break;
+    case 10:  // TxLog (:439-453)
+        if (!fr_eq_u64(ftag, 2)) {  // TxLogFieldTag.Topic
+            ST_ASSERT(fr_is_zero(val_hi), 130);
+            ST_ASSERT(fr_is_zero(init_hi), 131);
+        }
+        ST_ASSERT(fr_eq_u64(is_write, 1), 132);
+        ST_ASSERT(root_same, 133);
+        break;
+    case 11: {  // TxReceipt (:460-488)
+        ST_ASSERT(fr_is_zero(addr), 140);
+        ST_ASSERT(key_zero, 141);
+        ST_ASSERT(fr_is_zero(val_hi), 142);
+        ST_ASSERT(fr_is_zero(init_hi), 143);
+        if (fr_eq_u64(ftag, 1)) {  // PostStateOrStatus
+            ST_ASSERT(!val_is_word, 144);
+            ST_ASSERT(fr_le_u64(val_lo, 1), 145);
+        }
+        const Fr pid = zk_col(w, ST_ID, ip);
+        const bool same_tag = fr_eq(tag, zk_col(w, ST_TAG, ip));
+        if (!fr_eq(id, pid) && same_tag) {
+            ST_ASSERT(fr_eq(id, fr_add_u64(pid, 1)), 146);
+            if (fr_eq_u64(ftag, 2)) {  // CumulativeGasUsed
+                ST_ASSERT(!val_is_word, 147);
+                const u32 pfl = w.flags ? w.flags[ip] : 0u;
+                ST_ASSERT(!(pfl & 1u), 148);
+                ST_ASSERT(fr_lt(zk_col(w, ST_VAL_LO, ip), val_lo), 149);
+            }
+        }
+        if (!same_tag) ST_ASSERT(fr_eq_u64(id, 1), 150);
+        ST_ASSERT(fr_lo64(id) >= 1 && fr_le_u64(id, 1ull << 11), 151);
+        ST_ASSERT(root_same, 152);
+        break;
+    }
+    default:  // tag 12: passes 0.0 but is no Tag variant -> ValueError("Unreachable") (:613)
+        ST_FAIL(ZK_VALUE_ERROR, 160);
+    }
+    return ZK_OK;
+}
