@@ -1,0 +1,93 @@
+/* zkevm_hip.h — C ABI of the MI355X constraint-evaluation engine (libzkevm_hip.so).
+ *
+ * The reference (privacy-scaling-explorations/zkevm-specs, pure Python) has no FFI: its seam
+ * is the set of module-level callables its tests import by name.  Each entry
+ * point below replaces the per-row Python loop of one of them; INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Wire format: one field cell = 4 x uint64 little-endian canonical (== `FQ.n`,
+ * src/zkevm_specs/util/arithmetic.py:41-63).  Witness rows are column-major
+ * uint64[n_cells][n_rows][4]; lookup tables are row-major uint64[n_rows][n_cells][4];
+ * per-row type bits (is_word of WordOrValue cells, util/arithmetic.py:171-195) are uint32[n_rows].
+ *
+ * Ownership: the caller owns every buffer for the duration of the call (or of the session
+ * for zk_*_open); nothing is retained after zk_*_close / after a one-shot call returns.
+ * Errors: every function returns 0 on success and a negative code on infrastructure errors
+ * (bad arguments, HIP failures — text via zk_last_error()); constraint failures are NOT
+ * errors, they are reported in zk_result.  Nothing throws across this boundary.
+ * Threading: one engine per process/device, calls from one thread at a time.
+ */
+#ifndef ZKEVM_HIP_H
+#define ZKEVM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status code of one row/step: 0 = satisfied, else (kind << 24) | site.  `kind` is the Python
+ * exception class the reference raises at the first failing check of that row. */
+enum zk_kind {
+    ZK_KIND_OK = 0,
+    ZK_KIND_ASSERTION_ERROR = 1,      /* constrain_* / assert (caught by verify_steps, main.py:36) */
+    ZK_KIND_CONSTRAINT_UNSAT = 2,     /* ConstraintUnsatFailure raised (instruction.py:483,534) */
+    ZK_KIND_LOOKUP_UNSAT = 3,         /* LookupUnsatFailure (table.py:688,880) */
+    ZK_KIND_LOOKUP_AMBIGUOUS = 4,     /* LookupAmbiguousFailure (table.py:882) */
+    ZK_KIND_WRONG_QUERY_KEY = 5,
+    ZK_KIND_NOT_IMPLEMENTED = 6,      /* NotImplementedError (main.py:63) */
+    ZK_KIND_TYPE_ERROR = 7,
+    ZK_KIND_OVERFLOW_ERROR = 8,
+    ZK_KIND_VALUE_ERROR = 9,
+    ZK_KIND_ZERO_DIVISION = 10,
+    ZK_KIND_UNSUPPORTED = 15          /* gadget not implemented by this engine */
+};
+
+typedef struct zk_result {
+    uint64_t fail_count;       /* rows whose status != 0 */
+    uint64_t first_fail_row;   /* smallest failing row index, UINT64_MAX if none */
+    uint32_t first_fail_code;  /* status code of that row */
+    uint32_t launches;         /* kernel launches covered by this result */
+    uint64_t rows_evaluated;   /* rows per launch */
+    double kernel_ms;          /* mean device time of the evaluation kernel per launch (HIP events) */
+} zk_result;
+
+#define ZK_OPT_DEVICE_PTRS 1u  /* every data pointer is a device (HBM) pointer */
+
+/* Select the GPU (HIP ordinal) and create the engine's stream/events.  Idempotent. */
+int zk_init(int device);
+void zk_shutdown(void);
+/* Launch on the caller's HIP stream (e.g. torch's current stream); NULL = engine's own. */
+int zk_set_stream(void* hip_stream);
+const char* zk_last_error(void);
+/* BN254-Fr vector ops on the device for tests: op 0 add, 1 sub, 2 mul, 3 montmul, 4 neg.
+ * (reference: FQ.__add__/__sub__/__mul__/__neg__ via py_ecc, util/arithmetic.py:41) */
+int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts);
+
+/* ---- State circuit: replaces the `for row: check_state_row(row, prev, next, tables)` loop
+ *      (src/zkevm_specs/state_circuit.py:492; loop tests/test_state_circuit.py:26-30).
+ *      rows: uint64[57][n][4] + flags uint32[n] (bit0 value.is_word, bit1 initial.is_word);
+ *      mpt: uint64[n_mpt][12][4] (MPTTableRow, evm_circuit/table.py:461-468). */
+typedef struct zk_session zk_session;
+int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n,
+                  const uint64_t* mpt, uint64_t n_mpt, uint32_t opts, zk_session** out);
+/* One-shot convenience: open + launch + collect (+ copy per-row status to host) + close. */
+int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n,
+                    const uint64_t* mpt, uint64_t n_mpt, uint32_t opts,
+                    uint32_t* status_out /* nullable, n entries, host unless DEVICE_PTRS */,
+                    zk_result* result);
+
+/* ---- Session protocol shared by every circuit.
+ * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
+ *         n uint32 receiving the per-row status codes.
+ * collect: wait for all enqueued passes, return the tally of the LAST pass and the mean kernel
+ *         time over the passes since the previous collect. */
+int zk_launch(zk_session* s, uint32_t* status_dev);
+int zk_collect(zk_session* s, zk_result* result);
+/* Copy the per-row status of the last pass into a HOST buffer (n entries). */
+int zk_read_status(zk_session* s, uint32_t* status_host);
+int zk_close(zk_session* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

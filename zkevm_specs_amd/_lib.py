@@ -1,0 +1,89 @@
+"""ctypes binding of libzkevm_hip.so (C ABI: include/zkevm_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is usable the
+engine raises — the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
+
+EXPORTED_SYMBOLS = [
+    "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
+    "zk_state_open", "zk_state_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+]
+
+OPT_DEVICE_PTRS = 1
+
+
+class ZkResult(ctypes.Structure):
+    _fields_ = [
+        ("fail_count", ctypes.c_uint64),
+        ("first_fail_row", ctypes.c_uint64),
+        ("first_fail_code", ctypes.c_uint32),
+        ("launches", ctypes.c_uint32),
+        ("rows_evaluated", ctypes.c_uint64),
+        ("kernel_ms", ctypes.c_double),
+    ]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+_inited_device = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(zkevm_specs_amd/csrc/build.sh). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+    lib.zk_init.argtypes = [ctypes.c_int]
+    lib.zk_set_stream.argtypes = [vp]
+    lib.zk_last_error.restype = ctypes.c_char_p
+    lib.zk_fr_op.argtypes = [ctypes.c_int, vp, vp, vp, u64, u32]
+    lib.zk_state_open.argtypes = [vp, vp, u64, vp, u64, u32, ctypes.POINTER(vp)]
+    lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_launch.argtypes = [vp, vp]
+    lib.zk_collect.argtypes = [vp, ctypes.POINTER(ZkResult)]
+    lib.zk_read_status.argtypes = [vp, vp]
+    lib.zk_close.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().zk_last_error().decode(errors="replace")
+        raise EngineError(f"{what} failed (rc={rc}): {msg}")
+
+
+def init(device=None):
+    """Initialise the engine on a HIP device (default: LOCAL_RANK or 0)."""
+    global _inited_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _inited_device != device:
+        check(lib.zk_init(int(device)), "zk_init")
+        _inited_device = device
+    return lib
+
+
+def ptr(x):
+    """void* of a numpy array (host) or a torch tensor (device / host)."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.ctypes.data)

@@ -122,8 +122,11 @@ ZK_HD u64 state_mpt_key_hash(const ZkTable& t, u32 r) {
     return h;
 }
 
-#define ST_FAIL(kind, site) return ZK_CODE(kind, site)
-#define ST_ASSERT(cond, site) do { if (!(cond)) ST_FAIL(ZK_ASSERT, site); } while (0)
+// Checks are accumulated branch-free ("first failure wins") instead of returning early, so the
+// witness loads of later checks are not control-dependent on earlier ones and the compiler can
+// keep many 32-byte cell loads in flight per lane (the kernel is HBM-latency/bandwidth bound).
+#define ST_FAIL(kind, site) code = (code == 0u) ? ZK_CODE(kind, site) : code
+#define ST_ASSERT(cond, site) code = (code == 0u && !(cond)) ? ZK_CODE(ZK_ASSERT, site) : code
 
 // Evaluate row i against prev = (i-1) mod n and next = (i+1) mod n.
 ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
@@ -133,6 +136,7 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
     const u64 in = (i + 1) % n;
     const u32 fl = w.flags ? w.flags[i] : 0u;
     const bool val_is_word = fl & 1u, init_is_word = fl & 2u;
+    u32 code = 0;
 
     const Fr rwc = zk_col(w, ST_RWC, i);
     const Fr is_write = zk_col(w, ST_IS_WRITE, i);
@@ -178,14 +182,14 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
         Big18 kp, kc;
         if (!state_pack_keys(w, ip, kp)) ST_FAIL(ZK_VALUE_ERROR, 9);
         state_pack_keys(w, i, kc);
-        if (tagv != 1) ST_ASSERT(big_lt(kp, kc), 10);
+        ST_ASSERT(tagv == 1 || big_lt(kp, kc), 10);
     }
     const bool keys_eq_prev = state_keys_eq(w, i, ip);
     // 0.5 read consistency (:577-581)
-    if (is_read && keys_eq_prev) ST_ASSERT(state_pair_eq(w, ST_VAL_LO, i, ip), 11);
-    if (keys_eq_prev) ST_ASSERT(state_pair_eq(w, ST_INIT_LO, i, ip), 12);
+    ST_ASSERT(!(is_read && keys_eq_prev) || state_pair_eq(w, ST_VAL_LO, i, ip), 11);
+    ST_ASSERT(!keys_eq_prev || state_pair_eq(w, ST_INIT_LO, i, ip), 12);
     // 8. rw_counter != 0 except Start (:584-585)
-    if (tagv != 1) ST_ASSERT(!fr_is_zero(rwc), 13);
+    ST_ASSERT(tagv == 1 || !fr_is_zero(rwc), 13);
 
     const Fr val_lo = zk_col(w, ST_VAL_LO, i), val_hi = zk_col(w, ST_VAL_HI, i);
     const Fr init_lo = zk_col(w, ST_INIT_LO, i), init_hi = zk_col(w, ST_INIT_HI, i);
@@ -273,7 +277,7 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
             q[9] = val_hi;
             q[10] = init_lo;
             q[11] = init_hi;
-            if (!state_mpt_lookup(a.mpt, q)) ST_FAIL(ZK_LOOKUP_UNSAT, tagv == 4 ? 71 : 95);
+            if (code == 0u && !state_mpt_lookup(a.mpt, q)) ST_FAIL(ZK_LOOKUP_UNSAT, tagv == 4 ? 71 : 95);
         } else {
             ST_ASSERT(root_same, tagv == 4 ? 73 : 97);
         }
@@ -355,5 +359,5 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
     default:  // tag 12: passes 0.0 but is no Tag variant -> ValueError("Unreachable") (:613)
         ST_FAIL(ZK_VALUE_ERROR, 160);
     }
-    return ZK_OK;
+    return code;
 }

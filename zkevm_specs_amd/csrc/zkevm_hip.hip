@@ -1,0 +1,326 @@
+// libzkevm_hip.so — HIP kernels (gfx950) + C ABI (include/zkevm_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/zkevm_hip.h"
+#include "state_circuit.hpp"
+
+// ---------------------------------------------------------------------------------------
+// engine state
+// ---------------------------------------------------------------------------------------
+static int g_device = -1;
+static hipStream_t g_own_stream = nullptr;
+static hipStream_t g_stream = nullptr;
+static std::string g_err;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            char buf_[512];                                                                   \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                     \
+            g_err = buf_;                                                                     \
+            return -(int)e_ - 1000;                                                           \
+        }                                                                                     \
+    } while (0)
+#define ARG_TRY(cond, msg)  \
+    do {                    \
+        if (!(cond)) {      \
+            g_err = msg;    \
+            return -1;      \
+        }                   \
+    } while (0)
+
+extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
+
+extern "C" int zk_init(int device) {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    ARG_TRY(device >= 0 && device < count, "zk_init: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (g_device != device || !g_own_stream) {
+        if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
+        HIP_TRY(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking));
+        g_device = device;
+    }
+    if (!g_stream) g_stream = g_own_stream;
+    return 0;
+}
+extern "C" void zk_shutdown(void) {
+    if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
+    g_own_stream = nullptr;
+    g_stream = nullptr;
+    g_device = -1;
+}
+extern "C" int zk_set_stream(void* s) {
+    ARG_TRY(g_device >= 0, "zk_set_stream: call zk_init first");
+    g_stream = s ? (hipStream_t)s : g_own_stream;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// tally + index kernels
+// ---------------------------------------------------------------------------------------
+__global__ void tally_reset_kernel(ZkTally* t) {
+    t->fail_count = 0ull;
+    t->first_fail = ~0ull;
+}
+
+// One wave-level ballot, then at most one counter atomic per wave and one atomicMin per
+// failing lane (failures are rare on real witnesses; the hot path issues no atomics at all).
+__device__ __forceinline__ void tally_commit(ZkTally* tally, u64 row, u32 code) {
+    const unsigned long long ballot = __ballot(code != 0u);
+    if (ballot != 0ull) {
+        if (code != 0u) atomicMin(&tally->first_fail, (row << 32) | (unsigned long long)code);
+        const int lane = threadIdx.x & 63;
+        if (lane == __ffsll((long long)ballot) - 1) atomicAdd(&tally->fail_count, (unsigned long long)__popcll(ballot));
+    }
+}
+
+__global__ void slots_fill_kernel(u32* slots, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = ZK_EMPTY_SLOT;
+}
+
+template <u64 (*HASH)(const ZkTable&, u32)>
+__global__ void index_build_kernel(ZkTable t, u32* slots) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.n) return;
+    u32 s = (u32)HASH(t, r) & t.mask;
+    while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
+}
+
+// ---------------------------------------------------------------------------------------
+// State circuit kernel: one lane per row; column-major cells make every cell load a fully
+// coalesced 32 B/lane access (2 x dwordx4); neighbours (i-1, i+1) are re-read through L1/L2.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.rows.n) {
+        code = state_check_row(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
+
+__global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr x = fr_load(a + 4 * i), y = fr_load(b + 4 * i), r;
+    switch (op) {
+    case 0: r = fr_add(x, y); break;
+    case 1: r = fr_sub(x, y); break;
+    case 2: r = fr_mul(x, y); break;
+    case 3: r = fr_mont(x, y); break;
+    case 4: r = fr_neg(x); break;
+    default: r = fr_zero();
+    }
+    for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
+}
+
+// ---------------------------------------------------------------------------------------
+// sessions
+// ---------------------------------------------------------------------------------------
+enum SessionKind { SESSION_STATE = 1 };
+
+struct zk_session {
+    SessionKind kind;
+    u64 n = 0;                      // rows per pass
+    std::vector<void*> owned;       // device allocations to free at close
+    ZkTally* d_tally = nullptr;
+    u32* d_status = nullptr;        // internal per-row status (always kept for zk_read_status)
+    std::vector<hipEvent_t> ev;     // start/stop pairs
+    u32 launches = 0;               // since last collect
+    StateArgs state;
+};
+
+static const int MAX_EVENT_PAIRS = 256;
+
+static int dev_alloc(zk_session* s, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    s->owned.push_back(*p);
+    return 0;
+}
+// Bring a buffer to the device unless the caller already handed a device pointer.
+static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs, const void** out) {
+    if (device_ptrs || bytes == 0 || !src) {
+        *out = src;
+        return 0;
+    }
+    void* d = nullptr;
+    int rc = dev_alloc(s, &d, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, g_stream));
+    *out = d;
+    return 0;
+}
+
+template <u64 (*HASH)(const ZkTable&, u32)>
+static int build_index(zk_session* s, ZkTable& t) {
+    u32 cap = 16;
+    while (cap < 2 * t.n + 2) cap <<= 1;
+    u32* slots = nullptr;
+    int rc = dev_alloc(s, (void**)&slots, (size_t)cap * sizeof(u32));
+    if (rc) return rc;
+    t.mask = cap - 1;
+    t.slots = slots;
+    hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, g_stream, slots, cap);
+    if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, g_stream, t, slots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int session_common_init(zk_session* s) {
+    int rc = dev_alloc(s, (void**)&s->d_tally, sizeof(ZkTally));
+    if (rc) return rc;
+    rc = dev_alloc(s, (void**)&s->d_status, (size_t)s->n * sizeof(u32));
+    return rc;
+}
+
+extern "C" int zk_close(zk_session* s) {
+    if (!s) return 0;
+    (void)hipStreamSynchronize(g_stream);
+    for (void* p : s->owned) (void)hipFree(p);
+    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    delete s;
+    return 0;
+}
+
+extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n, const uint64_t* mpt,
+                             uint64_t n_mpt, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_state_open: call zk_init first");
+    ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_state_open: bad arguments");
+    ARG_TRY(n_mpt < (1ull << 31), "zk_state_open: MPT table too large");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_STATE;
+    s->n = n;
+    int rc = 0;
+    const void* p = nullptr;
+    if ((rc = stage(s, rows, (size_t)n * ST_NCELLS * 32, dev, &p))) goto fail;
+    s->state.rows.cells = (const u64*)p;
+    if ((rc = stage(s, flags, (size_t)n * 4, dev, &p))) goto fail;
+    s->state.rows.flags = (const u32*)p;
+    s->state.rows.n = n;
+    if ((rc = stage(s, mpt, (size_t)n_mpt * MPT_NCELLS * 32, dev, &p))) goto fail;
+    s->state.mpt.cells = (const u64*)p;
+    s->state.mpt.flags = nullptr;
+    s->state.mpt.n = (u32)n_mpt;
+    s->state.mpt.ncells = MPT_NCELLS;
+    if ((rc = build_index<state_mpt_key_hash>(s, s->state.mpt))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+
+extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
+    ARG_TRY(s, "zk_launch: null session");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = s->launches < (u32)MAX_EVENT_PAIRS;
+    if (timed) {
+        if (s->ev.size() < 2 * (size_t)(s->launches + 1)) {
+            HIP_TRY(hipEventCreate(&e0));
+            s->ev.push_back(e0);
+            HIP_TRY(hipEventCreate(&e1));
+            s->ev.push_back(e1);
+        }
+        e0 = s->ev[2 * s->launches];
+        e1 = s->ev[2 * s->launches + 1];
+    }
+    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
+    u32* status = status_dev ? status_dev : s->d_status;
+    if (timed) HIP_TRY(hipEventRecord(e0, g_stream));
+    switch (s->kind) {
+    case SESSION_STATE: {
+        const int block = 256;
+        const u32 grid = (u32)((s->n + block - 1) / block);
+        hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, s->d_tally);
+        break;
+    }
+    }
+    if (timed) HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipGetLastError());
+    s->launches++;
+    return 0;
+}
+
+extern "C" int zk_collect(zk_session* s, zk_result* r) {
+    ARG_TRY(s && r, "zk_collect: bad arguments");
+    ZkTally t;
+    HIP_TRY(hipMemcpyAsync(&t, s->d_tally, sizeof t, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    double ms = 0;
+    u32 timed = s->launches < (u32)MAX_EVENT_PAIRS ? s->launches : (u32)MAX_EVENT_PAIRS;
+    for (u32 k = 0; k < timed; k++) {
+        float f = 0;
+        HIP_TRY(hipEventElapsedTime(&f, s->ev[2 * k], s->ev[2 * k + 1]));
+        ms += f;
+    }
+    r->fail_count = t.fail_count;
+    r->first_fail_row = t.first_fail == ~0ull ? UINT64_MAX : (t.first_fail >> 32);
+    r->first_fail_code = t.first_fail == ~0ull ? 0u : (u32)(t.first_fail & 0xffffffffull);
+    r->launches = s->launches;
+    r->rows_evaluated = s->n;
+    r->kernel_ms = timed ? ms / timed : 0.0;
+    s->launches = 0;
+    return 0;
+}
+
+extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
+    ARG_TRY(s && status_host, "zk_read_status: bad arguments");
+    HIP_TRY(hipMemcpyAsync(status_host, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+extern "C" int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n, const uint64_t* mpt,
+                               uint64_t n_mpt, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_state_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_state_open(rows, flags, n, mpt, n_mpt, opts, &s);
+    if (rc) return rc;
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
+extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts) {
+    ARG_TRY(g_device >= 0, "zk_fr_op: call zk_init first");
+    ARG_TRY(a && b && out, "zk_fr_op: null pointer");
+    if (n == 0) return 0;
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    const u64 *da = a, *db = b;
+    u64* dout = out;
+    void *ta = nullptr, *tb = nullptr, *to = nullptr;
+    if (!dev) {
+        HIP_TRY(hipMalloc(&ta, n * 32));
+        HIP_TRY(hipMalloc(&tb, n * 32));
+        HIP_TRY(hipMalloc(&to, n * 32));
+        HIP_TRY(hipMemcpyAsync(ta, a, n * 32, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(tb, b, n * 32, hipMemcpyHostToDevice, g_stream));
+        da = (const u64*)ta;
+        db = (const u64*)tb;
+        dout = (u64*)to;
+    }
+    hipLaunchKernelGGL(fr_op_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, g_stream, op, da, db, dout, n);
+    HIP_TRY(hipGetLastError());
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(out, to, n * 32, hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        (void)hipFree(ta);
+        (void)hipFree(tb);
+        (void)hipFree(to);
+    }
+    return 0;
+}

@@ -1,0 +1,115 @@
+"""Session objects over the C ABI: upload once, launch many passes, collect the tally."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import OPT_DEVICE_PTRS, ZkResult, check
+
+
+class Result:
+    """Outcome of one evaluation pass over all rows (mirrors zk_result)."""
+
+    def __init__(self, r: ZkResult):
+        self.fail_count = int(r.fail_count)
+        self.first_fail_row = None if r.first_fail_row == 0xFFFFFFFFFFFFFFFF else int(r.first_fail_row)
+        self.first_fail_code = int(r.first_fail_code)
+        self.first_fail_kind = self.first_fail_code >> 24
+        self.first_fail_site = self.first_fail_code & 0xFFFFFF
+        self.launches = int(r.launches)
+        self.rows_evaluated = int(r.rows_evaluated)
+        self.kernel_ms = float(r.kernel_ms)
+
+    @property
+    def ok(self):
+        return self.fail_count == 0
+
+    def __repr__(self):
+        return (f"Result(ok={self.ok}, fail_count={self.fail_count}, first_fail_row={self.first_fail_row}, "
+                f"kind={self.first_fail_kind}, site={self.first_fail_site}, kernel_ms={self.kernel_ms:.4f})")
+
+
+def _is_device(x):
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
+class Session:
+    """RAII wrapper of zk_session*.  Inputs may be numpy arrays (staged to HBM by the library)
+    or torch CUDA tensors (used in place; the caller keeps them alive)."""
+
+    def __init__(self, handle, n, keepalive):
+        self._h = handle
+        self.n = n
+        self._keep = keepalive
+
+    def launch(self, status_dev=None):
+        check(_lib.load().zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch")
+
+    def collect(self):
+        r = ZkResult()
+        check(_lib.load().zk_collect(self._h, ctypes.byref(r)), "zk_collect")
+        return Result(r)
+
+    def run(self):
+        self.launch()
+        return self.collect()
+
+    def read_status(self):
+        out = np.empty(self.n, dtype=np.uint32)
+        check(_lib.load().zk_read_status(self._h, _lib.ptr(out)), "zk_read_status")
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.load().zk_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _prep(arrs):
+    dev = [_is_device(a) for a in arrs if a is not None]
+    if any(dev) and not all(dev):
+        raise ValueError("mix of host and device buffers")
+    is_dev = bool(dev) and all(dev)
+    out = []
+    for a in arrs:
+        if a is None:
+            out.append(None)
+        elif is_dev:
+            out.append(a.contiguous())
+        else:
+            out.append(np.ascontiguousarray(a))
+    return out, (OPT_DEVICE_PTRS if is_dev else 0)
+
+
+def open_state(rows, flags, mpt, device=None):
+    """rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4] -> Session"""
+    lib = _lib.init(device)
+    (rows, flags, mpt), opts = _prep([rows, flags, mpt])
+    n = rows.shape[1]
+    m = mpt.shape[0] if mpt is not None else 0
+    h = ctypes.c_void_p()
+    check(lib.zk_state_open(_lib.ptr(rows), _lib.ptr(flags), n, _lib.ptr(mpt) if m else None, m, opts,
+                            ctypes.byref(h)), "zk_state_open")
+    return Session(h, n, (rows, flags, mpt))
+
+
+def fr_op(op, a, b):
+    """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
+    lib = _lib.init()
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    check(lib.zk_fr_op(int(op), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.shape[0], 0), "zk_fr_op")
+    return out

@@ -1,0 +1,271 @@
+"""Synthetic witness generators for the BASELINE.json configurations (numpy, seeded).
+
+Witnesses are produced directly in the C-ABI wire format (see wire.py) because building
+2^16..2^20 rows out of Python `FQ`/`Word` objects is itself Python-bound (SURVEY.md §7
+"hard parts").  Every generator yields a *valid* witness (all constraints satisfied); tests
+tamper cells afterwards to exercise failures.
+"""
+import numpy as np
+
+# ---- State circuit (config 2) ------------------------------------------
+# Tag numbering: reference state_circuit.py:42-60.
+T_START, T_MEMORY, T_STACK, T_STORAGE, T_CALLCTX, T_ACCOUNT, T_REFUND, T_AL_ACC, T_AL_STOR, T_LOG, T_RECEIPT = range(1, 12)
+
+_STATE_MIX = [  # (tag, share of rows, mean rows per key group)
+    (T_MEMORY, 0.35, 3.0),
+    (T_STACK, 0.30, 2.5),
+    (T_CALLCTX, 0.12, 1.5),
+    (T_STORAGE, 0.06, 2.0),
+    (T_ACCOUNT, 0.05, 2.0),
+    (T_AL_ACC, 0.02, 2.0),
+    (T_AL_STOR, 0.02, 2.0),
+    (T_REFUND, 0.03, 4.0),
+    (T_LOG, 0.03, 1.0),
+    (T_RECEIPT, 0.02, 1.0),
+]
+
+
+def _u64s(rng, shape):
+    return rng.integers(0, 2**63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)
+
+
+def synth_state_witness(n, seed=2):
+    """Return (rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4]) for an n-row State
+    circuit: row 0 is the Start row (lexicographic selector 0), the rest follows _STATE_MIX in
+    strict lexicographic key order with unique rw_counters 1..n-1."""
+    assert n >= 64
+    rng = np.random.default_rng(seed)
+    m = n - 1
+    # --- decide per-tag row counts and key groups -------------------------------------
+    shares = np.array([s for _, s, _ in _STATE_MIX])
+    counts = np.floor(shares / shares.sum() * m).astype(np.int64)
+    counts[-1] = min(counts[-1], 3 * 2048)  # TxReceipt: tx_id must stay within [1, 2^11] (11.3)
+    counts[-2] = min(counts[-2], 1 << 20)
+    counts[0] += m - counts.sum()
+    tag = np.empty(m, dtype=np.int64)
+    gid = np.empty(m, dtype=np.int64)     # global group id (unique key tuple)
+    pos = np.empty(m, dtype=np.int64)     # position inside the group
+    g_tag, g_size = [], []
+    off = 0
+    for (t, _, mean), c in zip(_STATE_MIX, counts):
+        if c == 0:
+            continue
+        sizes = []
+        left = int(c)
+        while left > 0:
+            s = 1 if mean <= 1.0 else int(min(left, 1 + rng.poisson(mean - 1.0)))
+            if t == T_RECEIPT:
+                s = min(left, 1)
+            sizes.append(s)
+            left -= s
+        sizes = np.array(sizes, dtype=np.int64)
+        ng = len(sizes)
+        base = len(g_tag)
+        g_tag += [t] * ng
+        g_size += sizes.tolist()
+        idx = np.repeat(np.arange(ng), sizes)
+        tag[off : off + c] = t
+        gid[off : off + c] = base + idx
+        starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        pos[off : off + c] = np.arange(c) - np.repeat(starts, sizes)
+        off += c
+    g_tag = np.array(g_tag)
+    g_size = np.array(g_size)
+    G = len(g_tag)
+
+    # --- per-group keys (id, address[3 limbs], field_tag, storage_key[4 limbs]) -----------
+    g_id = np.zeros(G, dtype=np.uint64)
+    g_addr = np.zeros((G, 3), dtype=np.uint64)  # 160-bit: limbs 0,1 full, limb 2 = 32 bits
+    g_ft = np.zeros(G, dtype=np.uint64)
+    g_key = np.zeros((G, 4), dtype=np.uint64)
+
+    def sel(t):
+        return np.nonzero(g_tag == t)[0]
+
+    def rand_addr160(k):
+        a = np.zeros((k, 3), dtype=np.uint64)
+        a[:, 0] = _u64s(rng, k)
+        a[:, 1] = _u64s(rng, k)
+        a[:, 2] = rng.integers(0, 2**32, size=k, dtype=np.uint64)
+        return a
+
+    # unique composite keys per tag are obtained by drawing from spaces where collisions are
+    # resolved by construction (dense counters) or are astronomically unlikely (160/256-bit).
+    s_ = sel(T_MEMORY)
+    if len(s_):
+        g_id[s_] = 1 + (np.arange(len(s_)) % 64).astype(np.uint64)
+        g_addr[s_, 0] = (np.arange(len(s_)) // 64).astype(np.uint64)
+    s_ = sel(T_STACK)
+    if len(s_):  # per call: contiguous stack slots 1023 downwards (diff in {0,1} when sorted)
+        per_call = 64
+        g_id[s_] = 1 + (np.arange(len(s_)) // per_call).astype(np.uint64)
+        g_addr[s_, 0] = (1023 - (per_call - 1) + (np.arange(len(s_)) % per_call)).astype(np.uint64)
+    s_ = sel(T_CALLCTX)
+    if len(s_):
+        g_id[s_] = 1 + (np.arange(len(s_)) // 24).astype(np.uint64)
+        g_ft[s_] = 1 + (np.arange(len(s_)) % 24).astype(np.uint64)
+    s_ = sel(T_STORAGE)
+    if len(s_):
+        g_id[s_] = 1 + rng.integers(0, 16, size=len(s_)).astype(np.uint64)
+        g_addr[s_] = rand_addr160(len(s_))
+        g_key[s_] = _u64s(rng, (len(s_), 4))
+    s_ = sel(T_ACCOUNT)
+    if len(s_):
+        a = rand_addr160((len(s_) + 3) // 4)
+        g_addr[s_] = np.repeat(a, 4, axis=0)[: len(s_)]
+        g_ft[s_] = 1 + (np.arange(len(s_)) % 4).astype(np.uint64)
+    s_ = sel(T_REFUND)
+    if len(s_):
+        g_id[s_] = 1 + np.arange(len(s_)).astype(np.uint64)
+    s_ = sel(T_AL_ACC)
+    if len(s_):
+        g_id[s_] = 1 + rng.integers(0, 16, size=len(s_)).astype(np.uint64)
+        g_addr[s_] = rand_addr160(len(s_))
+    s_ = sel(T_AL_STOR)
+    if len(s_):
+        g_id[s_] = 1 + rng.integers(0, 16, size=len(s_)).astype(np.uint64)
+        g_addr[s_] = rand_addr160(len(s_))
+        g_key[s_] = _u64s(rng, (len(s_), 4))
+    s_ = sel(T_LOG)
+    if len(s_):  # id=tx_id, address=log_id, field_tag in {1 Address, 2 Topic, 3 Data}, key=index
+        k = np.arange(len(s_))
+        g_id[s_] = 1 + (k // 96).astype(np.uint64)
+        g_addr[s_, 0] = ((k // 12) % 8).astype(np.uint64)
+        g_ft[s_] = 1 + ((k // 4) % 3).astype(np.uint64)
+        g_key[s_, 0] = (k % 4).astype(np.uint64)
+    s_ = sel(T_RECEIPT)
+    if len(s_):  # tx ids 1.. with field tags 1,2,3 in order
+        k = np.arange(len(s_))
+        g_id[s_] = 1 + (k // 3).astype(np.uint64)
+        g_ft[s_] = 1 + (k % 3).astype(np.uint64)
+
+    # --- order groups the way the reference's gadget really compares them --------------------
+    # keys_rwc_to_limbs_in_order (state_circuit.py:552-565) packs
+    #   v = ((((tag*2^28 + id)*2^160 + address)*2^16 + field_tag)*2^32 + storage_key)*2^32 + rwc
+    # i.e. the 256-bit storage key is shifted by only 32 bits and *adds into* the field_tag and
+    # address limbs.  A valid witness must therefore be sorted by S = address*2^48 +
+    # field_tag*2^32 + storage_key inside one (tag, id); keys stay < 2^200 and addresses
+    # < 2^159 here so S never carries into id/tag.
+    big = np.nonzero(g_key.any(axis=1))[0]
+    g_key[big, 3] &= np.uint64(0xFF)
+    g_addr[big, 2] &= np.uint64(0x7FFFFFFF)
+    S = np.zeros((G, 4), dtype=np.uint64)
+    S[:, 0] = (g_addr[:, 0] << np.uint64(48)) | (g_ft << np.uint64(32))
+    S[:, 1] = (g_addr[:, 0] >> np.uint64(16)) | (g_addr[:, 1] << np.uint64(48))
+    S[:, 2] = (g_addr[:, 1] >> np.uint64(16)) | (g_addr[:, 2] << np.uint64(48))
+    S[:, 3] = g_addr[:, 2] >> np.uint64(16)
+    for g in big.tolist():
+        v = sum(int(S[g, k]) << (64 * k) for k in range(4)) + sum(int(g_key[g, k]) << (64 * k) for k in range(4))
+        for k in range(4):
+            S[g, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    order = np.lexsort((S[:, 0], S[:, 1], S[:, 2], S[:, 3], g_id, g_tag))
+    rank = np.empty(G, dtype=np.int64)
+    rank[order] = np.arange(G)
+    row_order = np.lexsort((pos, rank[gid]))
+    tag, gid, pos = tag[row_order], gid[row_order], pos[row_order]
+    first = pos == 0
+    last = np.concatenate([gid[1:] != gid[:-1], [True]])
+
+    # rw_counters: unique 1..m, ascending inside each group
+    rwc = (1 + rng.permutation(m)).astype(np.uint64)
+    grp_sorted = np.lexsort((rwc, rank[gid]))
+    rwc = rwc[grp_sorted]  # rows are already grouped contiguously in rank order
+
+    # --- is_write / values ---------------------------------------------------------------
+    is_write = rng.integers(0, 2, size=m).astype(np.uint64)
+    is_write[first & (tag == T_STACK)] = 1
+    is_write[tag == T_LOG] = 1
+    is_write[(tag == T_RECEIPT)] = 0
+    cand = np.zeros((m, 4), dtype=np.uint64)  # value lo[0:2], hi[2:4] as 64-bit limbs
+    wide = np.isin(tag, [T_STACK, T_STORAGE, T_REFUND])
+    cand[wide] = _u64s(rng, (int(wide.sum()), 4))
+    mem = tag == T_MEMORY
+    cand[mem, 0] = rng.integers(0, 256, size=int(mem.sum()), dtype=np.uint64)
+    cc = tag == T_CALLCTX
+    cand[cc, 0] = _u64s(rng, int(cc.sum()))
+    acc = tag == T_ACCOUNT
+    ft_row = g_ft[gid]
+    cand[acc, 0] = _u64s(rng, int(acc.sum()))
+    acc_wide = acc & (ft_row != 1)
+    cand[acc_wide] = _u64s(rng, (int(acc_wide.sum()), 4))
+    al = np.isin(tag, [T_AL_ACC, T_AL_STOR])
+    cand[al, 0] = rng.integers(0, 2, size=int(al.sum()), dtype=np.uint64)
+    lg = tag == T_LOG
+    cand[lg, 0] = _u64s(rng, int(lg.sum()))
+    lg_topic = lg & (ft_row == 2)
+    cand[lg_topic] = _u64s(rng, (int(lg_topic.sum()), 4))
+    rc = tag == T_RECEIPT
+    cand[rc & (ft_row == 1), 0] = 1
+    cand[rc & (ft_row == 2), 0] = (g_id[gid][rc & (ft_row == 2)] * np.uint64(21000))
+    cand[rc & (ft_row == 3), 0] = 0
+    # first access that is a read must see 0 (2.1, 5.2, 7.3, 8.2, 9.2); storage/account reads
+    # see the committed value.
+    first_read = first & (is_write == 0)
+    zero_first = first_read & np.isin(tag, [T_MEMORY, T_CALLCTX, T_REFUND, T_AL_ACC, T_AL_STOR])
+    cand[zero_first] = 0
+    # committed (initial) value per group for Storage/Account
+    g_init = np.zeros((G, 4), dtype=np.uint64)
+    sa = np.isin(g_tag, [T_STORAGE, T_ACCOUNT])
+    g_init[sa] = _u64s(rng, (int(sa.sum()), 4))
+    nonce_g = (g_tag == T_ACCOUNT) & (g_ft == 1)
+    g_init[nonce_g, 1:] = 0
+    init = g_init[gid]
+    sa_row = np.isin(tag, [T_STORAGE, T_ACCOUNT])
+    fr_sa = first_read & sa_row
+    cand[fr_sa] = init[fr_sa]
+    # value of a read = value of the latest defining row (write, or first row) of its group
+    defining = (is_write == 1) | first
+    didx = np.maximum.accumulate(np.where(defining, np.arange(m), 0))
+    value = cand[didx]
+
+    # --- roots: +5 at every last access of a Storage/Account group (mock MPT, :903-933) ---
+    upd = last & sa_row
+    root = (3 + 5 * np.cumsum(upd)).astype(np.uint64)
+    root_prev = np.concatenate([[3], root[:-1]]).astype(np.uint64)
+
+    # --- assemble wire cells ------------------------------------------------------------
+    cols = np.zeros((57, n, 4), dtype=np.uint64)
+    R = slice(1, n)
+    cols[0, R, 0] = rwc
+    cols[1, R, 0] = is_write
+    cols[2, 0, 0] = T_START
+    cols[2, R, 0] = tag.astype(np.uint64)
+    cols[3, R, 0] = g_id[gid]
+    addr = g_addr[gid]
+    cols[4, R, 0:3] = addr
+    cols[5, R, 0] = ft_row
+    key = g_key[gid]
+    cols[6, R, 0:2] = key[:, 0:2]
+    cols[7, R, 0:2] = key[:, 2:4]
+    for k in range(10):  # 16-bit address limbs
+        cols[8 + k, R, 0] = (addr[:, k // 4] >> np.uint64(16 * (k % 4))) & np.uint64(0xFFFF)
+    for b in range(32):  # storage-key bytes
+        cols[18 + b, R, 0] = (key[:, b // 8] >> np.uint64(8 * (b % 8))) & np.uint64(0xFF)
+    cols[50, R, 0:2] = value[:, 0:2]
+    cols[51, R, 0:2] = value[:, 2:4]
+    cols[52, R, 0:2] = init[:, 0:2]
+    cols[53, R, 0:2] = init[:, 2:4]
+    cols[54, 0, 0] = 3
+    cols[54, R, 0] = root
+    cols[56, R, 0] = 1
+    flags = np.zeros(n, dtype=np.uint32)
+    word_valued = np.isin(tag, [T_STACK, T_STORAGE, T_REFUND]) | acc_wide | lg_topic
+    flags[1:] = np.where(word_valued, 1, 0) | np.where(sa_row & word_valued, 2, 0)
+
+    # --- MPT table rows for the updating rows -------------------------------------------
+    ui = np.nonzero(upd)[0]
+    mpt = np.zeros((len(ui), 12, 4), dtype=np.uint64)
+    mpt[:, 0, 0:3] = addr[ui]
+    u_tag, u_ft = tag[ui], ft_row[ui]
+    vz = (value[ui] == 0).all(axis=1) & (init[ui] == 0).all(axis=1)
+    proof = np.where(u_tag == T_STORAGE, np.where(vz, 4, 6), np.where(vz & (u_ft == 3), 4, u_ft))
+    mpt[:, 1, 0] = proof.astype(np.uint64)
+    mpt[:, 2, 0:2] = key[ui][:, 0:2]
+    mpt[:, 3, 0:2] = key[ui][:, 2:4]
+    mpt[:, 4, 0] = root[ui]
+    mpt[:, 6, 0] = root_prev[ui]
+    mpt[:, 8, 0:2] = value[ui][:, 0:2]
+    mpt[:, 9, 0:2] = value[ui][:, 2:4]
+    mpt[:, 10, 0:2] = init[ui][:, 0:2]
+    mpt[:, 11, 0:2] = init[ui][:, 2:4]
+    return cols, flags, mpt
