@@ -46,6 +46,11 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(zkevm_specs_amd/csrc/build.sh). There is no CPU fallback."
         )
+    # torch ships its own libamdhip64.so.7; importing it first makes the dynamic loader bind
+    # this library to the SAME HIP runtime instance (one runtime per process: device pointers,
+    # streams and events are then interchangeable with torch's).
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
     lib.zk_init.argtypes = [ctypes.c_int]
