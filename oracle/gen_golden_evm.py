@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""EVM-circuit golden vectors from the UNMODIFIED reference (build container only).
+
+Replays the reference's own opcode tests (tests/evm/test_*.py) under pytest with
+`verify_steps` intercepted: for every call we record the flattened witness and, per step pair,
+the exception class the reference's `verify_step` raises on that pair alone (0 = pass).
+A second pass fuzzes the recorded witnesses at the cell level, rebuilds reference objects from
+the wire cells and records the reference's outcome again (tampered-witness parity).
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_TESTS = "/root/reference/tests/evm"
+
+from oracle.gen_golden import kind_of_exception  # noqa: E402
+
+TEST_FILES = """add_sub mul_div_mod comparator slt_sgt iszero not bitwise byte signextend push pop shl_shr addmod
+mulmod memory caller callvalue address calldatasize returndatasize origin gasprice selfbalance block_ctx gas
+msize codesize jump jumpi sload sstore sar sdiv_smod""".split()
+MAX_CASES_PER_FILE = 48
+
+
+def ref_step_outcomes(tables, steps, begin, end):
+    from zkevm_specs.evm_circuit.instruction import Instruction
+    from zkevm_specs.evm_circuit.main import verify_step
+
+    out = []
+    n = len(steps)
+    for idx in range(n - 1):
+        try:
+            verify_step(Instruction(tables=tables, curr=steps[idx], next=steps[idx + 1],
+                                    is_first_step=begin and idx == 0, is_last_step=end and idx == n - 2))
+            out.append(0)
+        except Exception as e:  # noqa: BLE001
+            out.append(kind_of_exception(e))
+    return out
+
+
+class Harvest:
+    def __init__(self):
+        self.cases = []
+        self.current = None
+
+    def pytest_runtest_setup(self, item):
+        self.current = item.nodeid.split("/")[-1]
+        real = sys.modules["zkevm_specs.evm_circuit.main"].verify_steps
+        harvest = self
+
+        def capture(tables, steps, begin_with_first_step=False, end_with_last_step=False, success=True):
+            from zkevm_specs.evm_circuit.main import DUMMY_STEP_STATE
+
+            steps_l = list(steps) + ([DUMMY_STEP_STATE] if end_with_last_step else [])
+            harvest.cases.append((harvest.current, tables, steps_l, begin_with_first_step, end_with_last_step, success))
+            return real(tables, steps, begin_with_first_step, end_with_last_step, success)
+
+        item.module.verify_steps = capture
+
+
+def unflatten(wire):
+    """wire dict -> reference (Tables, steps): used to ask the reference about fuzzed cells."""
+    from zkevm_specs.evm_circuit import (BlockTableRow, BytecodeTableRow, ExecutionState, RWTableRow, StepState,
+                                         Tables, TxTableRow)
+    from zkevm_specs.util import FQ, Word, WordOrValue
+
+    from oracle.wire import colmajor_to_rows, rowmajor_to_rows
+
+    def wov(lo, hi, is_word):
+        if is_word:
+            return WordOrValue(Word((FQ(lo), FQ(hi)), check=False))
+        v = WordOrValue(FQ(lo))
+        v.hi = FQ(hi)
+        return v
+
+    W = lambda lo, hi: Word((FQ(lo), FQ(hi)), check=False)  # noqa: E731
+    steps = []
+    for c in colmajor_to_rows(wire["steps"]):
+        s = StepState(ExecutionState(c[0]), 0, code_hash=W(c[5], c[6]))
+        s.rw_counter, s.call_id = FQ(c[1]), FQ(c[2])
+        s.is_root, s.is_create = bool(c[3]), bool(c[4])
+        s.program_counter, s.stack_pointer, s.gas_left = FQ(c[7]), FQ(c[8]), FQ(c[9])
+        s.memory_word_size, s.reversible_write_counter, s.log_id = FQ(c[10]), FQ(c[11]), FQ(c[12])
+        steps.append(s)
+    rw = set()
+    for c, f in zip(rowmajor_to_rows(wire["rw"]), wire["rw_flags"]):
+        rw.add(RWTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), W(c[6], c[7]),
+                          wov(c[8], c[9], f & 1), wov(c[10], c[11], f & 2), W(c[12], c[13])))
+    bc = set(BytecodeTableRow(W(c[0], c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5])) for c in rowmajor_to_rows(wire["bytecode"]))
+    tx = set(TxTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), wov(c[3], c[4], f & 1))
+             for c, f in zip(rowmajor_to_rows(wire["tx"]), wire["tx_flags"]))
+    blk = set(BlockTableRow(FQ(c[0]), FQ(c[1]), wov(c[2], c[3], f & 1))
+              for c, f in zip(rowmajor_to_rows(wire["block"]), wire["block_flags"]))
+    return Tables(block_table=blk, tx_table=tx, withdrawal_table=set(), bytecode_table=bc, rw_table=rw), steps
+
+
+def fuzz_wire(wire, rng):
+    """Overwrite 1..3 random cells of the steps / rw / bytecode tables (canonical values)."""
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    w = {k: v.copy() for k, v in wire.items()}
+
+    def put(arr, idx, val):
+        arr[idx] = np.frombuffer(int(val % P).to_bytes(32, "little"), dtype="<u8")
+
+    def cur(arr, idx):
+        return int.from_bytes(arr[idx].tobytes(), "little")
+
+    for _ in range(rng.choice([1, 1, 2, 3])):
+        which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
+        if which == "steps":
+            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[1])
+            if c in (3, 4):
+                put(w["steps"], (c, i), rng.randrange(2))
+            else:
+                old = cur(w["steps"], (c, i))
+                put(w["steps"], (c, i), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
+        elif which == "rw" and w["rw"].shape[0]:
+            i, c = rng.randrange(w["rw"].shape[0]), rng.randrange(14)
+            old = cur(w["rw"], (i, c))
+            put(w["rw"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(128)),
+                                              2**128, 2**255 % P, old + 2**128, rng.randrange(2**128)]))
+        elif which == "bytecode" and w["bytecode"].shape[0]:
+            i, c = rng.randrange(w["bytecode"].shape[0]), rng.randrange(2, 6)
+            old = cur(w["bytecode"], (i, c))
+            put(w["bytecode"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(256), rng.randrange(P)]))
+        elif w["rw_flags"].shape[0]:
+            i = rng.randrange(w["rw_flags"].shape[0])
+            w["rw_flags"][i] ^= np.uint32(rng.choice([1, 2]))
+    return w
+
+
+def main():
+    from zkevm_specs_amd.flatten import flatten_evm
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    total = 0
+    only = sys.argv[1:] if len(sys.argv) > 1 and sys.argv[0].endswith("gen_golden_evm.py") else None
+    for name in TEST_FILES:
+        if only and name not in only:
+            continue
+        rng = random.Random(hash(name) % 1000 + 20240807) if False else random.Random(sum(map(ord, name)) + 20240807)
+        path = os.path.join(REF_TESTS, f"test_{name}.py")
+        h = Harvest()
+        rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null", path], plugins=[h])
+        assert rc == 0, (name, rc)
+        cases = h.cases
+        if len(cases) > MAX_CASES_PER_FILE:
+            cases = rng.sample(cases, MAX_CASES_PER_FILE)
+        out, names = {}, []
+        n_fuzz_fail = 0
+        for tid, tables, steps, begin, end, success in cases:
+            wire = flatten_evm(tables, steps)
+            kinds = ref_step_outcomes(tables, steps, begin, end)
+            assert success and not any(kinds), (tid, kinds)  # the reference's EVM tests are positive-only
+            # sanity: the unflattened witness behaves identically
+            t2, s2 = unflatten(wire)
+            assert ref_step_outcomes(t2, s2, begin, end) == kinds, tid
+            variants = [("", wire, kinds)]
+            for k in range(3):
+                fw = fuzz_wire(wire, rng)
+                t3, s3 = unflatten(fw)
+                fk = ref_step_outcomes(t3, s3, begin, end)
+                n_fuzz_fail += any(fk)
+                variants.append((f"#fuzz{k}", fw, fk))
+            for suffix, w, kd in variants:
+                key = f"c{len(names):04d}"
+                names.append(tid + suffix)
+                for k, v in w.items():
+                    out[f"{key}_{k}"] = v
+                out[f"{key}_opts"] = np.array([int(begin), int(end)], dtype=np.uint8)
+                out[f"{key}_ref_kind"] = np.array(kd, dtype=np.uint8)
+        out["names"] = np.array(names)
+        fn = os.path.join(GOLDEN, f"evm_{name}.npz")
+        np.savez_compressed(fn, **out)
+        total += len(names)
+        print(f"evm/{name}: {len(names)} cases ({n_fuzz_fail} fuzzed with failures) -> {os.path.getsize(fn)//1024} KiB", flush=True)
+    print("total evm cases", total)
+
+
+if __name__ == "__main__":
+    main()

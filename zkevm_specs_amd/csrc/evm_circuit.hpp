@@ -1,0 +1,1272 @@
+// EVM circuit: per-step constraint evaluation (one execution step pair (curr, next) per lane).
+//
+// Reference: src/zkevm_specs/evm_circuit/main.py:14-63 (`verify_steps` / `verify_step`), the
+// `Instruction` toolbox in evm_circuit/instruction.py and the execution-state gadgets in
+// evm_circuit/execution/*.py; lookup semantics evm_circuit/table.py:864-884.
+//
+// Wire layouts (all cells canonical 4xu64):
+//   steps   column-major [13][n_steps]: execution_state, rw_counter, call_id, is_root, is_create,
+//           code_hash lo,hi, program_counter, stack_pointer, gas_left, memory_word_size,
+//           reversible_write_counter, log_id                      (evm_circuit/step.py:16-75)
+//   rw      row-major [n][14]: rw_counter, rw, key0(Target), id, address, field_tag, storage_key lo,hi,
+//           value lo,hi, value_prev lo,hi, aux0 lo,hi; flags bit0 value.is_word bit1 value_prev.is_word
+//                                                                  (evm_circuit/table.py:447-457)
+//   bytecode row-major [n][6]: hash lo,hi, field_tag, index, is_code, value   (table.py:438-443)
+//   tx      row-major [n][5]: tx_id, field_tag, index, value lo,hi; flags bit0 value.is_word (:421-426)
+//   block   row-major [n][4]: field_tag, block_number, value lo,hi; flags bit0 value.is_word (:413-417)
+//
+// Status code of a step = (kind << 24) | seq: `seq` is the ordinal of the failing *checkpoint*
+// (every primitive that can raise counts one, in the reference's evaluation order) — the same
+// numbering oracle/evm_oracle.py uses, so complete codes are comparable in the parity tests.
+#pragma once
+#include "common.hpp"
+#include "evm_tables.h"
+
+enum { S_STATE = 0, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, S_PC, S_SP, S_GAS, S_MWS, S_REV, S_LOG, STEP_NCELLS };
+enum { R_RWC = 0, R_RW, R_TAG, R_ID, R_ADDR, R_FT, R_KEY_LO, R_KEY_HI, R_VAL_LO, R_VAL_HI, R_PREV_LO, R_PREV_HI, R_AUX_LO, R_AUX_HI, RW_NCELLS };
+enum { B_HASH_LO = 0, B_HASH_HI, B_TAG, B_INDEX, B_IS_CODE, B_VALUE, BYTECODE_NCELLS };
+enum { TX_NCELLS = 5, BLOCK_NCELLS = 4 };
+
+struct EvmArgs {
+    ZkCols steps;
+    ZkTable rw, bytecode, tx, block;
+    const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
+    u32 n_pairs;      // n_steps - 1
+    u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
+};
+
+struct Word {
+    Fr lo, hi;
+};
+struct WordOrValue {
+    Word w;
+    bool is_word;
+};
+
+struct Ins {
+    const EvmArgs* a;
+    u64 idx;   // pair index: curr = idx, next = idx + 1
+    u32 err;   // first failure's status code (0 = none yet)
+    u32 seq;   // checkpoint counter
+    u32 rw_off, pc_off;
+    int sp_off;
+};
+
+// ---- checkpoints --------------------------------------------------------------------------
+ZK_HD void ev_fail(Ins& I, u32 kind) {
+    if (I.err == 0u) I.err = ZK_CODE(kind, I.seq);
+}
+ZK_HD void ev_require(Ins& I, bool cond, u32 kind = ZK_ASSERT) {
+    I.seq++;
+    if (!cond) ev_fail(I, kind);
+}
+#define EV_TRY(stmt) do { stmt; if (I.err) return; } while (0)
+#define EV_TRYV(stmt, ret) do { stmt; if (I.err) return ret; } while (0)
+
+ZK_HD Fr ev_curr(const Ins& I, int c) { return zk_col(I.a->steps, c, I.idx); }
+ZK_HD Fr ev_next(const Ins& I, int c) { return zk_col(I.a->steps, c, I.idx + 1); }
+ZK_HD Fr fr_u(u64 x) { return fr_from_u64(x); }
+ZK_HD Word word_of(const Fr& lo, const Fr& hi) {
+    Word w;
+    w.lo = lo;
+    w.hi = hi;
+    return w;
+}
+ZK_HD Word word_zero() { return word_of(fr_zero(), fr_zero()); }
+ZK_HD bool word_eq(const Word& a, const Word& b) { return fr_eq(a.lo, b.lo) && fr_eq(a.hi, b.hi); }
+
+ZK_HD void constrain_zero(Ins& I, const Fr& v) { ev_require(I, fr_is_zero(v)); }
+ZK_HD void constrain_equal(Ins& I, const Fr& a, const Fr& b) { ev_require(I, fr_eq(a, b)); }
+ZK_HD void constrain_equal_word(Ins& I, const Word& a, const Word& b) { ev_require(I, word_eq(a, b)); }
+// range_check (instruction.py:529-534): value fits n_bytes, else ConstraintUnsatFailure is raised
+ZK_HD void range_check(Ins& I, const Fr& v, int n_bytes) { ev_require(I, fr_byte_len(v) <= n_bytes, ZK_CONSTRAINT); }
+// WordOrValue.value() (util/arithmetic.py:186-189)
+ZK_HD Fr value_of(Ins& I, const WordOrValue& v) {
+    ev_require(I, !v.is_word);
+    return v.w.lo;
+}
+ZK_HD bool word_cells_fit(const Word& w) { return fr_fits128(w.lo) && fr_fits128(w.hi); }
+// Word.to_le_bytes / to_64s (util/arithmetic.py:155-168): int.to_bytes(16) raises OverflowError
+ZK_HD U256 to_u256(Ins& I, const Word& w) {
+    ev_require(I, word_cells_fit(w), ZK_OVERFLOW_ERROR);
+    return u256_from_lo_hi(w.lo, w.hi);
+}
+// Integer value of a word for the witness computations the reference does with Python big
+// ints (`Word.int_value`, util/arithmetic.py:127-129).  Cells >= 2^128 would need unbounded
+// integers here; such malformed word cells are reported as ZK_UNSUPPORTED (no checkpoint).
+ZK_HD U256 int_value(Ins& I, const Word& w) {
+    if (!word_cells_fit(w) && I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+    return u256_from_lo_hi(w.lo, w.hi);
+}
+ZK_HD Word word_from_u256(const U256& v) { return word_of(u256_lo(v), u256_hi(v)); }
+// Word(int) (util/arithmetic.py:115-122): `neg` -> OverflowError, `too_big` (>= 2^256) -> AssertionError
+ZK_HD Word word_from_int(Ins& I, const U256& v, bool neg = false, bool too_big = false) {
+    I.seq++;
+    if (too_big) ev_fail(I, ZK_ASSERT);
+    else if (neg) ev_fail(I, ZK_OVERFLOW_ERROR);
+    return word_from_u256(v);
+}
+// Word((lo, hi)) with check=True (util/arithmetic.py:110-114)
+ZK_HD Word word_checked(Ins& I, const Fr& lo, const Fr& hi) {
+    ev_require(I, fr_fits128(lo) && fr_fits128(hi));
+    return word_of(lo, hi);
+}
+// Instruction.compare (instruction.py:447-451): both operands must fit n_bytes
+ZK_HD void ev_compare(Ins& I, const Fr& lhs, const Fr& rhs, int n_bytes, u32& lt, u32& eq) {
+    ev_require(I, fr_byte_len(lhs) <= n_bytes && fr_byte_len(rhs) <= n_bytes);
+    lt = fr_lt(lhs, rhs);
+    eq = fr_eq(lhs, rhs);
+}
+// compare_word (instruction.py:453-463): hi first, then lo
+ZK_HD void compare_word(Ins& I, const Word& a, const Word& b, u32& lt, u32& eq) {
+    u32 hl, he, ll, le;
+    ev_compare(I, a.hi, b.hi, 16, hl, he);
+    ev_compare(I, a.lo, b.lo, 16, ll, le);
+    lt = hl + he * ll;
+    eq = he * le;
+}
+// Instruction.select asserts the condition is boolean (instruction.py:419-423)
+ZK_HD bool ev_select(Ins& I, const Fr& cond) {
+    ev_require(I, fr_le_u64(cond, 1));
+    return fr_eq_u64(cond, 1);
+}
+ZK_HD bool ev_select_b(Ins& I, u32 cond01) {  // structurally boolean condition: checkpoint only
+    I.seq++;
+    return cond01 == 1u;
+}
+ZK_HD u32 is_zero_word(const Word& w) { return fr_is_zero(fr_add(w.lo, w.hi)); }  // instruction.py:489
+ZK_HD u32 is_equal_word(const Word& a, const Word& b) {
+    return fr_is_zero(fr_add(fr_sub(a.lo, b.lo), fr_sub(a.hi, b.hi)));
+}
+// word_to_fq (instruction.py:480-484)
+ZK_HD Fr word_to_fq(Ins& I, const Word& w, int n_bytes) {
+    U256 v = to_u256(I, w);
+    bool hi_zero = true;
+    for (int b = n_bytes; b < 32; b++) hi_zero = hi_zero && fr_byte(v, b) == 0;
+    ev_require(I, hi_zero, ZK_CONSTRAINT);
+    Fr r = fr_zero();
+    for (int b = 0; b < n_bytes; b++) r.v[b >> 2] |= fr_byte(v, b) << (8 * (b & 3));
+    return r;
+}
+
+// ---- lookups ------------------------------------------------------------------------------
+ZK_HD u64 rw_key_hash_cell(const Fr& rwc) { return zk_hash_cell(0x51ed27u, rwc); }
+ZK_HD u64 rw_key_hash(const ZkTable& t, u32 r) { return rw_key_hash_cell(zk_table_cell(t, r, R_RWC)); }
+ZK_HD u64 bc_key_hash_cells(const Fr& lo, const Fr& hi, const Fr& tag, const Fr& index) {
+    return zk_hash_cell(zk_hash_cell(zk_hash_cell(zk_hash_cell(0xb7e15u, lo), hi), tag), index);
+}
+ZK_HD u64 bc_key_hash(const ZkTable& t, u32 r) {
+    return bc_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1), zk_table_cell(t, r, 2), zk_table_cell(t, r, 3));
+}
+ZK_HD u64 tx_key_hash_cells(const Fr& a, const Fr& b, const Fr& c) {
+    return zk_hash_cell(zk_hash_cell(zk_hash_cell(0x7f4a7u, a), b), c);
+}
+ZK_HD u64 tx_key_hash(const ZkTable& t, u32 r) {
+    return tx_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1), zk_table_cell(t, r, 2));
+}
+ZK_HD u64 blk_key_hash_cells(const Fr& a, const Fr& b) { return zk_hash_cell(zk_hash_cell(0x3c6efu, a), b); }
+ZK_HD u64 blk_key_hash(const ZkTable& t, u32 r) { return blk_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1)); }
+
+ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
+    bool same = true;
+    for (u32 c = 0; c < t.ncells; c++) same = same && fr_eq(zk_table_cell(t, r0, c), zk_table_cell(t, r1, c));
+    return same;
+}
+
+// Generic "exactly one distinct matching row" lookup (table.py:864-884) over the open-addressing
+// index: `q` holds ncells query cells, bit c of `mask` says cell c is part of the query.
+template <int NCELLS>
+ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32 mask) {
+    I.seq++;
+    u32 found = ZK_EMPTY_SLOT;
+    bool ambiguous = false;
+    if (t.n != 0) {
+        u32 slot = (u32)h & t.mask;
+        for (u32 probes = 0; probes <= t.mask; probes++) {
+            const u32 r = t.slots[slot];
+            if (r == ZK_EMPTY_SLOT) break;
+            bool m = true;
+            for (int c = 0; c < NCELLS; c++)
+                if ((mask >> c) & 1u) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
+            if (m) {
+                if (found == ZK_EMPTY_SLOT) found = r;
+                else if (!rows_identical(t, found, r)) ambiguous = true;
+            }
+            slot = (slot + 1) & t.mask;
+        }
+    }
+    if (found == ZK_EMPTY_SLOT) {
+        ev_fail(I, ZK_LOOKUP_UNSAT);
+        return 0;
+    }
+    if (ambiguous) ev_fail(I, ZK_LOOKUP_AMBIGUOUS);
+    return found;
+}
+
+struct RwQ {
+    Fr q[RW_NCELLS];
+    u32 mask;
+};
+ZK_HD void rwq_init(RwQ& Q, u32 rw, u32 tag) {
+    Q.mask = (1u << R_RWC) | (1u << R_RW) | (1u << R_TAG);
+    Q.q[R_RW] = fr_u(rw);
+    Q.q[R_TAG] = fr_u(tag);
+}
+ZK_HD void rwq_set(RwQ& Q, int c, const Fr& v) {
+    Q.q[c] = v;
+    Q.mask |= 1u << c;
+}
+ZK_HD void rwq_set_word(RwQ& Q, int c, const Word& w) {
+    rwq_set(Q, c, w.lo);
+    rwq_set(Q, c + 1, w.hi);
+}
+// Instruction.rw_lookup (instruction.py:792-824); rw_counter = curr.rw_counter + offset unless given
+ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
+    if (rw_counter) {
+        Q.q[R_RWC] = *rw_counter;
+    } else {
+        Q.q[R_RWC] = fr_add_u64(ev_curr(I, S_RWC), I.rw_off);
+        I.rw_off++;
+    }
+    return table_lookup<RW_NCELLS>(I, I.a->rw, rw_key_hash_cell(Q.q[R_RWC]), Q.q, Q.mask);
+}
+ZK_HD Fr rw_cell(const Ins& I, u32 row, int c) { return zk_table_cell(I.a->rw, row, c); }
+ZK_HD Word rw_word(const Ins& I, u32 row, int c) { return word_of(rw_cell(I, row, c), rw_cell(I, row, c + 1)); }
+ZK_HD WordOrValue rw_value(const Ins& I, u32 row) {
+    WordOrValue v;
+    v.w = rw_word(I, row, R_VAL_LO);
+    v.is_word = I.a->rw.flags ? (I.a->rw.flags[row] & 1u) : true;
+    return v;
+}
+ZK_HD WordOrValue rw_value_prev(const Ins& I, u32 row) {
+    WordOrValue v;
+    v.w = rw_word(I, row, R_PREV_LO);
+    v.is_word = I.a->rw.flags ? (I.a->rw.flags[row] & 2u) : true;
+    return v;
+}
+
+// Tables.bytecode_lookup (table.py:718-731); is_code < 0 = not part of the query
+ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& index, int is_code) {
+    Fr q[BYTECODE_NCELLS];
+    q[B_HASH_LO] = code_hash.lo;
+    q[B_HASH_HI] = code_hash.hi;
+    q[B_TAG] = fr_u(tag);
+    q[B_INDEX] = index;
+    q[B_IS_CODE] = fr_u(is_code > 0 ? 1 : 0);
+    q[B_VALUE] = fr_zero();
+    u32 mask = 0xfu | (is_code >= 0 ? (1u << B_IS_CODE) : 0u);
+    return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
+}
+ZK_HD Word curr_code_hash(const Ins& I) { return word_of(ev_curr(I, S_CH_LO), ev_curr(I, S_CH_HI)); }
+ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instruction.py:789-790
+    u32 r = bytecode_lookup(I, curr_code_hash(I), 2, index, is_code ? 1 : 0);
+    if (I.err) return fr_zero();
+    return zk_table_cell(I.a->bytecode, r, B_VALUE);
+}
+ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
+    Fr index = fr_add_u64(ev_curr(I, S_PC), I.pc_off);
+    I.pc_off++;
+    return opcode_lookup_at(I, index, is_code);
+}
+ZK_HD Fr bytecode_length(Ins& I, const Word& code_hash) {  // instruction.py:771-774
+    u32 r = bytecode_lookup(I, code_hash, 1, fr_zero(), 0);
+    if (I.err) return fr_zero();
+    return zk_table_cell(I.a->bytecode, r, B_VALUE);
+}
+ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag) {  // table.py:697-706 (index 0)
+    Fr q[TX_NCELLS];
+    q[0] = tx_id;
+    q[1] = fr_u(field_tag);
+    q[2] = fr_zero();
+    q[3] = fr_zero();
+    q[4] = fr_zero();
+    u32 r = table_lookup<TX_NCELLS>(I, I.a->tx, tx_key_hash_cells(q[0], q[1], q[2]), q, 0x7u);
+    WordOrValue v;
+    v.w = word_zero();
+    v.is_word = true;
+    if (I.err) return v;
+    v.w = word_of(zk_table_cell(I.a->tx, r, 3), zk_table_cell(I.a->tx, r, 4));
+    v.is_word = I.a->tx.flags ? (I.a->tx.flags[r] & 1u) : true;
+    return v;
+}
+ZK_HD WordOrValue block_lookup(Ins& I, u32 field_tag) {  // table.py:690-695 (block number 0)
+    Fr q[BLOCK_NCELLS];
+    q[0] = fr_u(field_tag);
+    q[1] = fr_zero();
+    q[2] = fr_zero();
+    q[3] = fr_zero();
+    u32 r = table_lookup<BLOCK_NCELLS>(I, I.a->block, blk_key_hash_cells(q[0], q[1]), q, 0x3u);
+    WordOrValue v;
+    v.w = word_zero();
+    v.is_word = true;
+    if (I.err) return v;
+    v.w = word_of(zk_table_cell(I.a->block, r, 2), zk_table_cell(I.a->block, r, 3));
+    v.is_word = I.a->block.flags ? (I.a->block.flags[r] & 1u) : true;
+    return v;
+}
+
+// Fixed-table membership in closed form (table.py:37-103, 673-688): exact 4-tuple semantics,
+// operands are field elements (anything >= 256 / >= range is simply not in the table).
+ZK_HD void fixed_lookup(Ins& I, u32 tag, const Fr& v0, const Fr& v1, const Fr& v2) {
+    I.seq++;
+    bool ok = false;
+    const bool b0 = fr_le_u64(v0, 255), b1 = fr_le_u64(v1, 255);
+    const u32 x = v0.v[0], y = v1.v[0];
+    switch (tag) {
+    case FX_Range5: ok = fr_le_u64(v0, 4) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range16: ok = fr_le_u64(v0, 15) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range32: ok = fr_le_u64(v0, 31) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range64: ok = fr_le_u64(v0, 63) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range256: ok = b0 && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range512: ok = fr_le_u64(v0, 511) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range1024: ok = fr_le_u64(v0, 1023) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_Range24_576: ok = fr_le_u64(v0, 24575) && fr_is_zero(v1) && fr_is_zero(v2); break;
+    case FX_SignByte: ok = b0 && fr_eq_u64(v1, (x >> 7) * 0xffu) && fr_is_zero(v2); break;
+    case FX_BitwiseAnd: ok = b0 && b1 && fr_eq_u64(v2, x & y); break;
+    case FX_BitwiseOr: ok = b0 && b1 && fr_eq_u64(v2, x | y); break;
+    case FX_BitwiseXor: ok = b0 && b1 && fr_eq_u64(v2, x ^ y); break;
+    case FX_ResponsibleOpcode: {
+        static const uint8_t resp[256] = ZK_OPCODE_RESP_STATE_INIT;
+        ok = fr_is_zero(v2) && b1 && fr_le_u64(v0, 255) && x != 0 && resp[y] == x;
+        if (!ok && (fr_eq_u64(v0, ES_ErrorInvalidOpcode) || fr_eq_u64(v0, ES_ErrorStack) || fr_eq_u64(v0, ES_ErrorWriteProtection))) {
+            if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+            return;
+        }
+        break;
+    }
+    case FX_Pow2: {
+        if (b0) {
+            Fr p = fr_zero();
+            p.v[(x & 127u) >> 5] = 1u << (x & 31u);
+            ok = x < 128 ? (fr_eq(v1, p) && fr_is_zero(v2)) : (fr_is_zero(v1) && fr_eq(v2, p));
+        }
+        break;
+    }
+    default:
+        if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+        return;
+    }
+    if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
+}
+
+// ---- stack / memory / call context (instruction.py:866-935) --------------------------------
+ZK_HD Word stack_lookup(Ins& I, u32 rw, int off) {
+    RwQ Q;
+    rwq_init(Q, rw, TG_Stack);
+    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
+    Fr sp = ev_curr(I, S_SP);
+    rwq_set(Q, R_ADDR, off >= 0 ? fr_add_u64(sp, (u64)off) : fr_sub_u64(sp, (u64)(-off)));
+    u32 r = rw_lookup(I, Q);
+    if (I.err) return word_zero();
+    return rw_word(I, r, R_VAL_LO);
+}
+ZK_HD Word stack_pop(Ins& I) {
+    int off = I.sp_off;
+    I.sp_off++;
+    return stack_lookup(I, 0, off);
+}
+ZK_HD Word stack_push(Ins& I) {
+    I.sp_off--;
+    return stack_lookup(I, 1, I.sp_off);
+}
+ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr) {
+    RwQ Q;
+    rwq_init(Q, rw, TG_Memory);
+    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
+    rwq_set(Q, R_ADDR, addr);
+    u32 r = rw_lookup(I, Q);
+    if (I.err) return fr_zero();
+    return value_of(I, rw_value(I, r));
+}
+ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag) {
+    RwQ Q;
+    rwq_init(Q, 0, TG_CallContext);
+    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
+    rwq_set(Q, R_ADDR, fr_u(field_tag));
+    u32 r = rw_lookup(I, Q);
+    WordOrValue v;
+    v.w = word_zero();
+    v.is_word = true;
+    if (I.err) return v;
+    return rw_value(I, r);
+}
+ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag) {
+    WordOrValue v = call_context_lookup_word(I, field_tag);
+    if (I.err) return fr_zero();
+    return value_of(I, v);
+}
+struct Reversion {
+    Fr end, persistent, rwc;
+};
+ZK_HD Reversion reversion_info(Ins& I) {  // instruction.py:901-913
+    Reversion rv;
+    rv.end = call_context_lookup(I, CC_RwCounterEndOfReversion);
+    rv.persistent = call_context_lookup(I, CC_IsPersistent);
+    rv.rwc = ev_curr(I, S_REV);
+    return rv;
+}
+// state_write (instruction.py:826-863): the write plus, when not persistent, its reversion row
+ZK_HD u32 state_write(Ins& I, RwQ& Q, Reversion& rv) {
+    const u32 tag = Q.q[R_TAG].v[0];
+    u32 r = rw_lookup(I, Q);
+    if (I.err) return 0;
+    if (fr_is_zero(rv.persistent)) {
+        Fr rwc = fr_sub(rv.end, rv.rwc);
+        rv.rwc = fr_add_u64(rv.rwc, 1);
+        RwQ R;
+        rwq_init(R, 1, tag);
+        rwq_set(R, R_ID, rw_cell(I, r, R_ID));
+        rwq_set(R, R_ADDR, rw_cell(I, r, R_ADDR));
+        rwq_set(R, R_FT, rw_cell(I, r, R_FT));
+        rwq_set_word(R, R_KEY_LO, rw_word(I, r, R_KEY_LO));
+        rwq_set_word(R, R_VAL_LO, rw_word(I, r, R_PREV_LO));
+        rwq_set_word(R, R_PREV_LO, rw_word(I, r, R_VAL_LO));
+        rwq_set_word(R, R_AUX_LO, rw_word(I, r, R_AUX_LO));
+        rw_lookup(I, R, &rwc);
+    }
+    return r;
+}
+
+// ---- 256-bit word arithmetic ------------------------------------------------------------------
+// add_words (util/arithmetic.py:236-242) for two addends
+ZK_HD Word add_words2(Ins& I, const Word& x, const Word& y, Fr& carry_hi) {
+    Fr slo = fr_add(x.lo, y.lo);  // FQ sum, then divmod by 2^128 on its canonical integer
+    Fr sum_lo = slo, c_lo = fr_zero();
+    for (int k = 4; k < 8; k++) { c_lo.v[k - 4] = slo.v[k]; sum_lo.v[k] = 0; }
+    Fr shi = fr_add(fr_add(x.hi, y.hi), c_lo);
+    Fr sum_hi = shi;
+    carry_hi = fr_zero();
+    for (int k = 4; k < 8; k++) { carry_hi.v[k - 4] = shi.v[k]; sum_hi.v[k] = 0; }
+    return word_checked(I, sum_lo, sum_hi);
+}
+
+struct Limbs64 {
+    u64 v[4];
+};
+ZK_HD Limbs64 to_64s(Ins& I, const Word& w) {
+    U256 x = to_u256(I, w);
+    Limbs64 l;
+    for (int k = 0; k < 4; k++) l.v[k] = u256_limb64(x, k);
+    return l;
+}
+// 64x64 -> 128 accumulate into a 256-bit integer at a 64-bit limb offset
+ZK_HD void acc_mul64(U256& acc, u64 a, u64 b, int limb_off) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0, p01 = (u64)a0 * b1, p10 = (u64)a1 * b0, p11 = (u64)a1 * b1;
+    u32 w[4];
+    u64 c = p00;
+    w[0] = (u32)c;
+    c = (c >> 32) + (u32)p01 + (u32)p10;
+    w[1] = (u32)c;
+    c = (c >> 32) + (p01 >> 32) + (p10 >> 32) + (u32)p11;
+    w[2] = (u32)c;
+    c = (c >> 32) + (p11 >> 32);
+    w[3] = (u32)c;
+    u64 carry = 0;
+    for (int k = 0; k < 8 - 2 * limb_off; k++) {
+        carry += (u64)acc.v[2 * limb_off + k] + (k < 4 ? w[k] : 0u);
+        acc.v[2 * limb_off + k] = (u32)carry;
+        carry >>= 32;
+    }
+}
+// t-values of mul_add_words* (instruction.py:604-611 / 643-652): plain integers < 2^196
+struct MulT {
+    U256 lo;    // t0 + t1 * 2^64
+    U256 mid;   // t2 + t3 * 2^64
+    U256 hi;    // t4 + t5 * 2^64
+    U256 t6;
+    U256 ovf;   // a1b3 + a2b2 + a3b1 + a2b3 + a3b2 + a3b3 (mul_add_words' overflow terms)
+};
+ZK_HD MulT mul_terms(const Limbs64& a, const Limbs64& b) {
+    MulT t;
+    t.lo = fr_zero(); t.mid = fr_zero(); t.hi = fr_zero(); t.t6 = fr_zero(); t.ovf = fr_zero();
+    acc_mul64(t.lo, a.v[0], b.v[0], 0);
+    acc_mul64(t.lo, a.v[0], b.v[1], 1);
+    acc_mul64(t.lo, a.v[1], b.v[0], 1);
+    acc_mul64(t.mid, a.v[0], b.v[2], 0);
+    acc_mul64(t.mid, a.v[1], b.v[1], 0);
+    acc_mul64(t.mid, a.v[2], b.v[0], 0);
+    acc_mul64(t.mid, a.v[0], b.v[3], 1);
+    acc_mul64(t.mid, a.v[1], b.v[2], 1);
+    acc_mul64(t.mid, a.v[2], b.v[1], 1);
+    acc_mul64(t.mid, a.v[3], b.v[0], 1);
+    acc_mul64(t.hi, a.v[1], b.v[3], 0);
+    acc_mul64(t.hi, a.v[2], b.v[2], 0);
+    acc_mul64(t.hi, a.v[3], b.v[1], 0);
+    acc_mul64(t.hi, a.v[2], b.v[3], 1);
+    acc_mul64(t.hi, a.v[3], b.v[2], 1);
+    acc_mul64(t.t6, a.v[3], b.v[3], 0);
+    acc_mul64(t.ovf, a.v[1], b.v[3], 0);
+    acc_mul64(t.ovf, a.v[2], b.v[2], 0);
+    acc_mul64(t.ovf, a.v[3], b.v[1], 0);
+    acc_mul64(t.ovf, a.v[2], b.v[3], 0);
+    acc_mul64(t.ovf, a.v[3], b.v[2], 0);
+    acc_mul64(t.ovf, a.v[3], b.v[3], 0);
+    return t;
+}
+// mul_add_words (instruction.py:599-632): constrains a*b + c == d (mod 2^256), returns overflow.
+// The two constrain_equal calls (:629-630) are identities of the field (carry is *defined* as
+// (lhs - d)/2^128), so they only advance the checkpoint counter.
+ZK_HD Fr mul_add_words(Ins& I, const Word& a, const Word& b, const Word& c, const Word& d) {
+    Limbs64 a64 = to_64s(I, a);
+    Limbs64 b64 = to_64s(I, b);
+    MulT t = mul_terms(a64, b64);
+    Fr carry_lo = fr_mulc(fr_sub(fr_add(t.lo, c.lo), d.lo), frm_inv_2p128());
+    Fr carry_hi = fr_mulc(fr_sub(fr_add(fr_add(t.mid, c.hi), carry_lo), d.hi), frm_inv_2p128());
+    Fr overflow = fr_add(carry_hi, t.ovf);
+    range_check(I, carry_lo, 9);
+    range_check(I, carry_hi, 9);
+    I.seq += 2;
+    return overflow;
+}
+// mul_add_words_512 (instruction.py:634-665): a*b + c == d*2^256 + e
+ZK_HD void mul_add_words_512(Ins& I, const Word& a, const Word& b, const Word& c, const Word& d, const Word& e) {
+    Limbs64 a64 = to_64s(I, a);
+    Limbs64 b64 = to_64s(I, b);
+    MulT t = mul_terms(a64, b64);
+    Fr c0 = fr_mulc(fr_sub(fr_add(t.lo, c.lo), e.lo), frm_inv_2p128());
+    Fr c1 = fr_mulc(fr_sub(fr_add(fr_add(t.mid, c.hi), c0), e.hi), frm_inv_2p128());
+    Fr c2 = fr_mulc(fr_sub(fr_add(t.hi, c1), d.lo), frm_inv_2p128());
+    range_check(I, c0, 9);
+    range_check(I, c1, 9);
+    range_check(I, c2, 9);
+    I.seq += 3;  // three identities (:660-662)
+    constrain_equal(I, fr_add(t.t6, c2), d.hi);
+}
+
+// ---- step-state transition (instruction.py:206-264, 365-394) ----------------------------------
+struct Trans {
+    u32 kind;  // 0 same, 1 delta, 2 to
+    Fr value;
+};
+ZK_HD Trans t_same() { Trans t; t.kind = 0; t.value = fr_zero(); return t; }
+ZK_HD Trans t_delta(const Fr& v) { Trans t; t.kind = 1; t.value = v; return t; }
+ZK_HD Trans t_delta_i(long long v) { return t_delta(v >= 0 ? fr_u((u64)v) : fr_neg(fr_u((u64)(-v)))); }
+ZK_HD Trans t_to(const Fr& v) { Trans t; t.kind = 2; t.value = v; return t; }
+ZK_HD void transition(Ins& I, int cell, const Trans& t) {
+    Fr c = ev_curr(I, cell), n = ev_next(I, cell);
+    Fr expect = t.kind == 0 ? c : (t.kind == 1 ? fr_add(c, t.value) : t.value);
+    ev_require(I, fr_eq(n, expect));
+}
+ZK_HD void same_context(Ins& I, const Fr& opcode, const Trans& rw_counter, const Trans& program_counter,
+                        const Trans& stack_pointer, const Trans& memory_word_size, const Trans& rev_wc,
+                        const Fr& dynamic_gas_cost) {
+    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero());
+    static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
+    static const uint16_t cgas[256] = ZK_OPCODE_CONST_GAS_INIT;
+    const bool op_ok = fr_le_u64(opcode, 255) && valid[opcode.v[0] & 0xff];
+    ev_require(I, op_ok, ZK_VALUE_ERROR);  // Opcode(opcode.n)
+    Fr gas_cost = fr_add(fr_u(op_ok ? cgas[opcode.v[0] & 0xff] : 0), dynamic_gas_cost);
+    range_check(I, fr_sub(ev_curr(I, S_GAS), gas_cost), 8);
+    transition(I, S_RWC, rw_counter);
+    transition(I, S_PC, program_counter);
+    transition(I, S_SP, stack_pointer);
+    transition(I, S_GAS, t_delta(fr_neg(gas_cost)));
+    transition(I, S_MWS, memory_word_size);
+    transition(I, S_REV, rev_wc);
+    transition(I, S_LOG, t_same());
+    transition(I, S_CALL_ID, t_same());
+    transition(I, S_IS_ROOT, t_same());
+    transition(I, S_IS_CREATE, t_same());
+    ev_require(I, fr_eq(ev_next(I, S_CH_LO), ev_curr(I, S_CH_LO)) && fr_eq(ev_next(I, S_CH_HI), ev_curr(I, S_CH_HI)));
+}
+ZK_HD void same_context3(Ins& I, const Fr& opcode, long long rwc, long long pc, long long sp) {
+    same_context(I, opcode, t_delta_i(rwc), t_delta_i(pc), sp == 0 ? t_same() : t_delta_i(sp), t_same(), t_same(), fr_zero());
+}
+
+// constant_divmod (instruction.py:440-445) with a small constant denominator (power of two here)
+ZK_HD Fr constant_divmod_shift(Ins& I, const Fr& num, int shift, int n_bytes) {
+    Fr q = fr_zero();
+    for (int k = 0; k < 8; k++) {
+        u32 lo = num.v[k] >> shift;
+        u32 hi = (k + 1 < 8) ? (num.v[k + 1] << (32 - shift)) : 0u;
+        q.v[k] = lo | hi;
+    }
+    range_check(I, q, n_bytes);
+    return q;
+}
+ZK_HD Fr memory_gas_cost(Ins& I, const Fr& size) {  // instruction.py:1122-1129
+    Fr q = constant_divmod_shift(I, fr_mul(size, size), 9, 8);
+    return fr_add(q, fr_add(fr_add(size, size), size));
+}
+ZK_HD void memory_expansion(Ins& I, const Fr& offset, const Fr& length, Fr& next_size, Fr& gas) {  // :1131-1148
+    Fr mws = ev_curr(I, S_MWS);
+    Fr mem_size = fr_zero();
+    if (!fr_is_zero(length)) mem_size = constant_divmod_shift(I, fr_add_u64(fr_add(length, offset), 31), 5, 4);
+    u32 lt, eq;
+    ev_compare(I, mws, mem_size, 4, lt, eq);
+    next_size = ev_select_b(I, lt) ? mem_size : mws;
+    Fr g0 = memory_gas_cost(I, mws);
+    Fr g1 = memory_gas_cost(I, next_size);
+    gas = fr_sub(g1, g0);
+}
+
+// ---- gadgets (evm_circuit/execution/*.py) --------------------------------------------------------
+ZK_HD void g_add_sub(Ins& I) {  // add_sub.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    const bool is_sub = fr_eq_u64(opcode, OP_SUB);
+    Word a, b, c;
+    EV_TRY(a = stack_pop(I));
+    EV_TRY(b = stack_pop(I));
+    EV_TRY(c = stack_push(I));
+    Word x = ev_select_b(I, is_sub) ? c : a;
+    Fr carry;
+    Word res = add_words2(I, x, b, carry);
+    Word y = ev_select_b(I, is_sub) ? a : c;
+    constrain_equal_word(I, res, y);
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_mul_div_mod(Ins& I) {  // mul_div_mod.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    // is_mul/is_div/is_mod are field expressions of the opcode (:14-16)
+    Fr op_m2 = fr_sub_u64(opcode, 2), op_m4 = fr_sub_u64(opcode, 4);
+    Fr f4_op = fr_sub(fr_u(4), opcode), f6_op = fr_sub(fr_u(6), opcode);
+    Fr is_mul = fr_mulc(fr_mul(f4_op, f6_op), frm_inv8());
+    Fr is_div = fr_mulc(fr_mul(op_m2, f6_op), frm_inv4());
+    Fr is_mod = fr_mulc(fr_mul(op_m2, op_m4), frm_inv8());
+    Word pop1, pop2, push;
+    EV_TRY(pop1 = stack_pop(I));
+    EV_TRY(pop2 = stack_pop(I));
+    EV_TRY(push = stack_push(I));
+    Word a, b, c, d;
+    if (fr_eq_u64(is_mul, 1)) {
+        a = pop1; b = pop2; c = word_from_int(I, fr_zero()); d = push;
+    } else if (fr_eq_u64(is_div, 1)) {
+        d = pop1; b = pop2; a = push;
+        U256 dv, bv, av;
+        EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b)); EV_TRY(av = int_value(I, a));
+        U512 prod = u256_mul_full(bv, av);
+        U256 plo = u512_lo(prod), rem;
+        bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, plo);
+        EV_TRY(c = word_from_int(I, rem, neg));
+    } else {
+        d = pop1; b = pop2;
+        U256 dv, bv;
+        EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b));
+        if (fr_is_zero(bv)) {
+            c = d; a = word_from_int(I, fr_zero());
+        } else {
+            c = push;
+            U256 cv; EV_TRY(cv = int_value(I, c));
+            U256 diff, q, r;
+            bool neg = u256_sub(diff, dv, cv);
+            u256_divmod(diff, bv, q, r);
+            EV_TRY(a = word_from_int(I, q, neg));
+        }
+    }
+    const u32 dz = is_zero_word(b);
+    Fr overflow; EV_TRY(overflow = mul_add_words(I, a, b, c, d));
+    bool sel = ev_select(I, is_mul); if (I.err) return;
+    constrain_equal_word(I, pop1, sel ? a : d);
+    constrain_equal_word(I, pop2, b);
+    Fr nz = fr_u(1 - dz);
+    Fr s1 = fr_mul(is_div, nz), s2 = fr_mul(is_mod, nz);
+    Word w1 = word_checked(I, fr_mul(d.lo, is_mul), fr_mul(d.hi, is_mul));
+    Word w2 = word_checked(I, fr_mul(a.lo, s1), fr_mul(a.hi, s1));
+    Word w12 = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
+    Word w3 = word_checked(I, fr_mul(c.lo, s2), fr_mul(c.hi, s2));
+    Word rhs = word_checked(I, fr_add(w12.lo, w3.lo), fr_add(w12.hi, w3.hi));
+    constrain_equal_word(I, push, rhs);
+    U256 cb = to_u256(I, c); if (I.err) return;
+    u32 csum = 0;
+    for (int k = 0; k < 32; k++) csum += fr_byte(cb, k);
+    constrain_zero(I, fr_mul(is_mul, fr_u(csum)));
+    u32 lt, eq; compare_word(I, c, b, lt, eq); if (I.err) return;
+    Fr one_m_mul = fr_sub(fr_u(1), is_mul);
+    constrain_zero(I, fr_mul(fr_mul(one_m_mul, nz), fr_u(1 - lt)));
+    constrain_zero(I, fr_mul(one_m_mul, overflow));
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_cmp(Ins& I) {  // comparator.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    const bool is_eq = fr_eq_u64(opcode, OP_EQ), is_gt = fr_eq_u64(opcode, OP_GT);
+    Word a, b, c;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    Word aa = is_gt ? b : a, bb = is_gt ? a : b;
+    u32 lt_lo, eq_lo, lt_hi, eq_hi;
+    ev_compare(I, aa.lo, bb.lo, 16, lt_lo, eq_lo);
+    ev_compare(I, aa.hi, bb.hi, 16, lt_hi, eq_hi);
+    u32 lt = ev_select_b(I, lt_hi) ? 1u : eq_hi * lt_lo;
+    u32 eq = eq_lo * eq_hi;
+    u32 result = is_eq ? eq : lt;
+    Word rw = word_checked(I, fr_u(result), fr_zero());
+    constrain_equal_word(I, rw, c);
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+// slt_sgt.py:31-36 / addmod.py:7-19: lo compare, hi compare, inner select, outer select
+ZK_HD u32 lt_u256_sel(Ins& I, const Word& a, const Word& b) {
+    u32 lt_lo, eq_lo, lt_hi, eq_hi;
+    ev_compare(I, a.lo, b.lo, 16, lt_lo, eq_lo);
+    ev_compare(I, a.hi, b.hi, 16, lt_hi, eq_hi);
+    u32 inner = ev_select_b(I, eq_hi * lt_lo) ? 1u : 0u;
+    return ev_select_b(I, lt_hi) ? 1u : inner;
+}
+
+ZK_HD void g_scmp(Ins& I) {  // slt_sgt.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    const bool is_sgt = fr_eq_u64(opcode, OP_SGT);
+    Word a, b, c;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    Word aa = is_sgt ? b : a, bb = is_sgt ? a : b;
+    U256 a8, b8, c8;
+    EV_TRY(a8 = to_u256(I, aa)); EV_TRY(b8 = to_u256(I, bb)); EV_TRY(c8 = to_u256(I, c));
+    ev_require(I, fr_byte(c8, 31) == 0); if (I.err) return;
+    Fr cc = c8;  // low 31 bytes (byte 31 is zero) as a field element
+    u32 a_lt_b; EV_TRY(a_lt_b = lt_u256_sel(I, aa, bb));
+    const u32 am = fr_byte(a8, 31), bm = fr_byte(b8, 31);
+    if (am >= 128 && bm < 128) constrain_equal(I, cc, fr_u(1));
+    else if (bm >= 128 && am < 128) constrain_equal(I, cc, fr_zero());
+    else constrain_equal(I, cc, fr_u(a_lt_b));
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_iszero(Ins& I) {  // iszero.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word value; EV_TRY(value = stack_pop(I));
+    Word z = word_checked(I, fr_u(is_zero_word(value)), fr_zero());
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, z, push);
+    same_context3(I, opcode, 2, 1, 0);
+}
+
+ZK_HD void g_not(Ins& I) {  // not_.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word a; EV_TRY(a = stack_pop(I));
+    U256 a8; EV_TRY(a8 = to_u256(I, a));
+    Word b; EV_TRY(b = stack_push(I));
+    U256 b8; EV_TRY(b8 = to_u256(I, b));
+    for (int k = 0; k < 32; k++) fixed_lookup(I, FX_BitwiseXor, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(255));
+    if (I.err) return;
+    same_context3(I, opcode, 2, 1, 0);
+}
+
+ZK_HD void g_bitwise(Ins& I) {  // bitwise.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word a, b, c;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    U256 a8, b8, c8;
+    EV_TRY(a8 = to_u256(I, a)); EV_TRY(b8 = to_u256(I, b)); EV_TRY(c8 = to_u256(I, c));
+    // tag = BitwiseAnd + (opcode.n - AND) as a Python int, then FixedTableTag(tag)
+    Fr tagf = fr_zero();
+    bool tag_ok;
+    {
+        // opcode.n - 0x16 + 10 = opcode.n - 12 (integer arithmetic on the canonical value)
+        Fr twelve = fr_u(12);
+        bool neg = u256_sub(tagf, opcode, twelve);
+        tag_ok = !neg && fr_lo64(tagf) >= 1 && fr_le_u64(tagf, 16);
+    }
+    ev_require(I, tag_ok, ZK_VALUE_ERROR); if (I.err) return;
+    const u32 tag = tagf.v[0];
+    for (int k = 0; k < 32; k++) fixed_lookup(I, tag, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(fr_byte(c8, k)));
+    if (I.err) return;
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_byte(Ins& I) {  // byte.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word a, b, c;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    U256 index, value;
+    EV_TRY(index = to_u256(I, a)); EV_TRY(value = to_u256(I, b));
+    bool msb_zero = true;
+    for (int k = 1; k < 32; k++) msb_zero = msb_zero && fr_byte(index, k) == 0;
+    const u32 i0 = fr_byte(index, 0);
+    u32 selected = 0;
+    for (int k = 0; k < 32; k++) selected += (i0 == (u32)(31 - k) && msb_zero) ? fr_byte(value, k) : 0u;
+    Word sw = word_checked(I, fr_u(selected), fr_zero());
+    constrain_equal_word(I, sw, c);
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_signextend(Ins& I) {  // signextend.py (is_equal results are discarded there)
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word index, value, result;
+    EV_TRY(index = stack_pop(I)); EV_TRY(value = stack_pop(I)); EV_TRY(result = stack_push(I));
+    U256 ib, vb, rb;
+    EV_TRY(ib = to_u256(I, index)); EV_TRY(vb = to_u256(I, value)); EV_TRY(rb = to_u256(I, result));
+    bool msb_zero = true;
+    for (int k = 1; k < 32; k++) msb_zero = msb_zero && fr_byte(ib, k) == 0;
+    const u32 i0 = fr_byte(ib, 0);
+    const u32 sign_byte = i0 < 31 ? (fr_byte(vb, (int)i0) >> 7) * 0xffu : 0u;
+    u32 selected = 0;
+    for (int k = 0; k < 31; k++) selected += (i0 == (u32)k && msb_zero) ? fr_byte(vb, k) : 0u;
+    fixed_lookup(I, FX_SignByte, fr_u(selected), fr_u(sign_byte), fr_zero()); if (I.err) return;
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+ZK_HD void g_push(Ins& I) {  // push.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr num_pushed = fr_sub_u64(opcode, OP_PUSH0);
+    Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
+    Fr pc = ev_curr(I, S_PC);
+    Fr left = fr_sub_u64(fr_sub(code_length, pc), 1);
+    u32 oob, eq; ev_compare(I, left, num_pushed, 8, oob, eq); if (I.err) return;
+    Fr num_padding = oob ? fr_sub(num_pushed, left) : fr_zero();
+    Word value; EV_TRY(value = stack_push(I));
+    U256 vb; EV_TRY(vb = to_u256(I, value));
+    for (int k = 0; k < 32; k++) {
+        const bool pushed = fr_lt(fr_u((u64)k), num_pushed), padding = fr_lt(fr_u((u64)k), num_padding);
+        if (pushed && !padding) {
+            Fr index = fr_sub_u64(fr_add(pc, num_pushed), (u64)k);
+            Fr byte; EV_TRY(byte = opcode_lookup_at(I, index, false));
+            constrain_equal(I, fr_u(fr_byte(vb, k)), byte);
+        } else {
+            constrain_zero(I, fr_u(fr_byte(vb, k)));
+        }
+    }
+    same_context(I, opcode, t_delta_i(1), t_delta(fr_add_u64(num_pushed, 1)), t_delta_i(-1), t_same(), t_same(), fr_zero());
+}
+
+ZK_HD void g_pop(Ins& I) {  // pop.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    EV_TRY(stack_pop(I));
+    same_context3(I, opcode, 1, 1, 1);
+}
+
+ZK_HD void g_shl_shr(Ins& I) {  // shl_shr.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word pop1, pop2, push;
+    EV_TRY(pop1 = stack_pop(I)); EV_TRY(pop2 = stack_pop(I)); EV_TRY(push = stack_push(I));
+    // gen_witness (:103-127)
+    Fr is_shl = fr_sub(fr_u(OP_SHR), opcode);
+    Word shift = pop1;
+    U256 sb; EV_TRY(sb = to_u256(I, shift));
+    const u32 shf0 = fr_byte(sb, 0);
+    bool rest_zero = true;
+    for (int k = 1; k < 32; k++) rest_zero = rest_zero && fr_byte(sb, k) == 0;
+    U256 dvs = fr_zero();
+    if (rest_zero) dvs.v[shf0 >> 5] = 1u << (shf0 & 31u);
+    Word divisor = word_from_int(I, dvs);
+    Word dividend, quotient, remainder;
+    if (fr_eq_u64(is_shl, 1)) {
+        dividend = push; quotient = pop2; remainder = word_from_int(I, fr_zero());
+    } else {
+        dividend = pop2; quotient = push;
+        U256 dv, qv;
+        EV_TRY(dv = int_value(I, dividend)); EV_TRY(qv = int_value(I, quotient));
+        U512 prod = u256_mul_full(qv, dvs);
+        U256 rem;
+        bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, u512_lo(prod));
+        EV_TRY(remainder = word_from_int(I, rem, neg));
+    }
+    // check_witness (:35-100)
+    Fr is_shr = fr_sub(fr_u(1), is_shl);
+    EV_TRY(sb = to_u256(I, shift));
+    const u32 shf_lt256 = rest_zero ? 1u : 0u;
+    const u32 dz = is_zero_word(divisor);
+    constrain_equal_word(I, pop1, shift);
+    {
+        Word w1 = word_checked(I, fr_mul(quotient.lo, is_shl), fr_mul(quotient.hi, is_shl));
+        Word w2 = word_checked(I, fr_mul(dividend.lo, is_shr), fr_mul(dividend.hi, is_shr));
+        Word s = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
+        constrain_equal_word(I, pop2, s);
+    }
+    {
+        Fr s = fr_mul(is_shr, fr_u(1 - dz));
+        Word w1 = word_checked(I, fr_mul(dividend.lo, is_shl), fr_mul(dividend.hi, is_shl));
+        Word w2 = word_checked(I, fr_mul(quotient.lo, s), fr_mul(quotient.hi, s));
+        Word sum = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
+        constrain_equal_word(I, push, sum);
+    }
+    constrain_zero(I, fr_zero());  // shf0 - shift_le_bytes[0]: same byte by construction (:67)
+    {
+        Word lhs = dz ? word_checked(I, fr_zero(), fr_zero()) : word_checked(I, shift.lo, shift.hi);
+        word_checked(I, fr_u(shf0), fr_zero());
+        Word rhs = word_checked(I, dz ? fr_zero() : fr_u(shf0), fr_zero());
+        constrain_equal_word(I, lhs, rhs);
+    }
+    ev_require(I, (1 - (int)dz - (int)shf_lt256) == 0);
+    u32 rlt, req; compare_word(I, remainder, divisor, rlt, req);
+    ev_require(I, dz == 1 || rlt == 1);
+    constrain_zero(I, is_zero_word(remainder) ? fr_zero() : is_shl);
+    if (I.err) return;
+    Fr overflow; EV_TRY(overflow = mul_add_words(I, quotient, divisor, remainder, dividend));
+    constrain_zero(I, fr_mul(is_shr, overflow));
+    if (dz == 0) fixed_lookup(I, FX_Pow2, fr_u(shf0), divisor.lo, divisor.hi);
+    if (I.err) return;
+    same_context3(I, opcode, 3, 1, 1);
+}
+
+// 512-bit / 256-bit helpers for ADDMOD / MULMOD witness values
+ZK_HD void divmod_512(const U512& num, const U256& den, U512& q, U256& r) { u512_divmod(num, den, q, r, 512); }
+
+ZK_HD void g_addmod(Ins& I) {  // addmod.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_ADDMOD));
+    Word a, b, n, pushed_r;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(n = stack_pop(I)); EV_TRY(pushed_r = stack_push(I));
+    U256 av, bv, nv;
+    EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n));
+    const bool n_zero = fr_is_zero(nv);
+    U256 a_red, k = fr_zero(), d = fr_zero();
+    Word r;
+    if (n_zero) {
+        a_red = av;
+        U256 s; u256_add(s, a_red, bv);  // (a_red + b) % 2^256
+        r = word_from_int(I, s);
+    } else {
+        u256_divmod(av, nv, k, a_red);
+        U256 s; u32 carry = u256_add(s, a_red, bv);
+        U512 num = u512_from(s, fr_u(carry)), q; U256 rem;
+        divmod_512(num, nv, q, rem);
+        d = u512_lo(q);
+        r = pushed_r;
+    }
+    Word kw = word_from_int(I, k);
+    Word arw = word_from_int(I, a_red);
+    Fr overflow; EV_TRY(overflow = mul_add_words(I, kw, n, arw, a));
+    constrain_zero(I, overflow);
+    Word arw2 = word_from_int(I, a_red);
+    Fr carry_hi;
+    Word a_red_plus_b = add_words2(I, arw2, b, carry_hi);
+    Word dw = word_from_int(I, d);
+    Word ow = n_zero ? word_from_int(I, fr_zero()) : word_checked(I, carry_hi, fr_zero());
+    EV_TRY(mul_add_words_512(I, dw, n, r, ow, a_red_plus_b));
+    const u32 nz = is_zero_word(n);
+    u32 r_lt_n; EV_TRY(r_lt_n = lt_u256_sel(I, r, n));
+    Word arw3 = word_from_int(I, a_red);
+    u32 a_lt_n; EV_TRY(a_lt_n = lt_u256_sel(I, arw3, n));
+    ev_require(I, 2 == a_lt_n + r_lt_n + 2 * nz);
+    // pushed_r.int_value() == FQ(r.int_value() * (1 - n_is_zero)).n  (reduction mod p, addmod.py:61)
+    {
+        U256 pv; EV_TRY(pv = int_value(I, pushed_r));
+        U256 rv; EV_TRY(rv = int_value(I, r));
+        U256 rhs = fr_zero();
+        if (!nz) {  // r_int mod p: r_int < 2^256 < 6p
+            rhs = rv;
+            Fr p = fr_modulus();
+            for (int t = 0; t < 6; t++) { U256 s; if (!u256_sub(s, rhs, p)) rhs = s; }
+        }
+        ev_require(I, fr_eq(pv, rhs));
+    }
+    same_context3(I, opcode, 4, 1, 2);
+}
+
+ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r) {  // mulmod.py:6-29
+    U256 av = u256_from_lo_hi(a.lo, a.hi), nv = u256_from_lo_hi(n.lo, n.hi);
+    Word a_or_zero;
+    U256 k = fr_zero();
+    if (fr_is_zero(nv)) {
+        a_or_zero = word_from_int(I, fr_zero());
+    } else {
+        a_or_zero = a;
+        U256 rem; u256_divmod(av, nv, k, rem);
+    }
+    Word kw = word_from_int(I, k);
+    EV_TRY(mul_add_words(I, kw, n, r, a_or_zero));
+    const u32 eq = is_equal_word(a, a_or_zero);
+    u32 lt, e2; compare_word(I, r, n, lt, e2);
+    const u32 nz = is_zero_word(n), aoz = is_zero_word(a_or_zero);
+    ev_require(I, (1 - eq) * (1 - nz * aoz) == 0);
+    ev_require(I, (1 - (int)lt - (int)nz) == 0);
+}
+
+ZK_HD void g_mulmod(Ins& I) {  // mulmod.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_MULMOD));
+    Word a, b, n, r;
+    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(n = stack_pop(I)); EV_TRY(r = stack_push(I));
+    U256 av, bv, nv, rv;
+    EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
+    U256 a_red = fr_zero(), k = fr_zero();
+    U512 prod;
+    bool safety;
+    if (fr_is_zero(nv)) {
+        prod = u256_mul_full(a_red, bv);  // 0
+        safety = fr_is_zero(rv);          // 0 == 0*0 + r
+    } else {
+        U256 q0; u256_divmod(av, nv, q0, a_red);
+        prod = u256_mul_full(a_red, bv);
+        U512 q; U256 rem; divmod_512(prod, nv, q, rem);
+        k = u512_lo(q);      // k < b < 2^256
+        safety = fr_eq(rem, rv);  // prod == k*n + r  <=>  r == prod mod n
+    }
+    Word e = word_from_int(I, u512_lo(prod));
+    Word d = word_from_int(I, u512_hi(prod));
+    ev_require(I, safety);
+    Word arw = word_from_int(I, a_red);
+    EV_TRY(mulmod_mod(I, a, n, arw));
+    Word arw2 = word_from_int(I, a_red);
+    Word zero = word_from_int(I, fr_zero());
+    EV_TRY(mul_add_words_512(I, arw2, b, zero, d, e));
+    Word kw = word_from_int(I, k);
+    EV_TRY(mul_add_words_512(I, kw, n, r, d, e));
+    const u32 nz = is_zero_word(n);
+    u32 lt, eq; compare_word(I, r, n, lt, eq);
+    ev_require(I, (1 - (int)lt - (int)nz) == 0);
+    same_context3(I, opcode, 4, 1, 2);
+}
+
+ZK_HD void g_memory(Ins& I) {  // memory.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Word aw; EV_TRY(aw = stack_pop(I));
+    Fr address; EV_TRY(address = word_to_fq(I, aw, 20));
+    const bool is_mload = fr_eq_u64(opcode, OP_MLOAD), is_mstore8 = fr_eq_u64(opcode, OP_MSTORE8);
+    const bool is_store = !is_mload, is_not8 = !is_mstore8;
+    Word value;
+    if (is_mload) { EV_TRY(value = stack_push(I)); } else { EV_TRY(value = stack_pop(I)); }
+    EV_TRY(to_u256(I, value));
+    Fr next_size, gas;
+    EV_TRY(memory_expansion(I, ev_curr(I, S_MWS), fr_add_u64(address, 1 + (is_not8 ? 31 : 0)), next_size, gas));
+    if (is_mstore8) EV_TRY(memory_lookup(I, 1, address));
+    if (is_not8)
+        for (int k = 0; k < 32; k++) EV_TRY(memory_lookup(I, is_store ? 1 : 0, fr_add_u64(address, (u64)k)));
+    same_context(I, opcode, t_delta_i(34 - (is_mstore8 ? 31 : 0)), t_delta_i(1), t_delta_i(is_store ? 2 : 0),
+                 t_to(next_size), t_same(), gas);
+}
+
+ZK_HD void ctx_push_word(Ins& I, const Fr& opcode, const Word& w) {
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, w, push);
+    same_context3(I, opcode, 2, 1, -1);
+}
+ZK_HD void g_ctx_word(Ins& I, u32 expected_opcode, u32 field_tag) {  // caller.py / callvalue.py / address.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(expected_opcode));
+    WordOrValue v; EV_TRY(v = call_context_lookup_word(I, field_tag));
+    ctx_push_word(I, opcode, v.w);
+}
+ZK_HD void g_ctx_value(Ins& I, u32 expected_opcode, u32 field_tag) {  // calldatasize.py / returndatasize.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(expected_opcode));
+    Fr v; EV_TRY(v = call_context_lookup(I, field_tag));
+    Word w = word_checked(I, v, fr_zero());
+    ctx_push_word(I, opcode, w);
+}
+ZK_HD void g_tx_word(Ins& I, u32 expected_opcode, u32 tx_field_tag) {  // origin.py / gasprice.py
+    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(expected_opcode));
+    WordOrValue v; EV_TRY(v = tx_lookup(I, tx_id, tx_field_tag));
+    ctx_push_word(I, opcode, v.w);
+}
+ZK_HD void g_selfbalance(Ins& I) {  // selfbalance.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_SELFBALANCE));
+    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
+    RwQ Q;
+    rwq_init(Q, 0, TG_Account);
+    rwq_set(Q, R_ADDR, callee);
+    rwq_set(Q, R_FT, fr_u(ACC_Balance));
+    u32 r; EV_TRY(r = rw_lookup(I, Q));
+    Word bal = rw_word(I, r, R_VAL_LO);
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, push, bal);
+    same_context3(I, opcode, 3, 1, -1);
+}
+ZK_HD void g_blockctx(Ins& I) {  // block_ctx.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    u32 tag = 0;
+    if (fr_eq_u64(opcode, OP_COINBASE)) tag = BLK_Coinbase;
+    else if (fr_eq_u64(opcode, OP_TIMESTAMP)) tag = BLK_Timestamp;
+    else if (fr_eq_u64(opcode, OP_NUMBER)) tag = BLK_Number;
+    else if (fr_eq_u64(opcode, OP_GASLIMIT)) tag = BLK_GasLimit;
+    else if (fr_eq_u64(opcode, OP_PREVRANDAO)) tag = BLK_PrevRandao;
+    else if (fr_eq_u64(opcode, OP_BASEFEE)) tag = BLK_BaseFee;
+    else if (fr_eq_u64(opcode, OP_CHAINID)) tag = BLK_ChainId;
+    ev_require(I, tag != 0, ZK_NAME_ERROR); if (I.err) return;  // `op` unbound (:24)
+    WordOrValue v; EV_TRY(v = block_lookup(I, tag));
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, v.w, push);
+    same_context3(I, opcode, 1, 1, -1);
+}
+ZK_HD void g_push_lo(Ins& I, const Fr& opcode, const Fr& lo) {  // Word.from_lo(x) == stack_push()
+    Word w = word_checked(I, lo, fr_zero());
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, w, push);
+    same_context3(I, opcode, 1, 1, -1);
+}
+ZK_HD void g_gas(Ins& I) {  // gas.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_GAS));
+    g_push_lo(I, opcode, fr_sub_u64(ev_curr(I, S_GAS), 2));
+}
+ZK_HD void g_msize(Ins& I) {  // msize.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    g_push_lo(I, opcode, fr_mulc(ev_curr(I, S_MWS), fr_to_mont(fr_u(32))));
+}
+ZK_HD void g_codesize(Ins& I) {  // codesize.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_CODESIZE));
+    Fr size; EV_TRY(size = bytecode_length(I, curr_code_hash(I)));
+    g_push_lo(I, opcode, size);
+}
+ZK_HD void g_jump(Ins& I) {  // jump.py
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_JUMP));
+    Word dest; EV_TRY(dest = stack_pop(I));
+    constrain_zero(I, dest.hi);
+    Fr byte; EV_TRY(byte = opcode_lookup_at(I, dest.lo, true));
+    constrain_equal(I, fr_u(OP_JUMPDEST), byte);
+    same_context(I, opcode, t_delta_i(1), t_to(dest.lo), t_delta_i(1), t_same(), t_same(), fr_zero());
+}
+ZK_HD void g_jumpi(Ins& I) {  // jumpi.py: `if is_zero_word(cond)` is always truthy (FQ has no __bool__)
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_JUMPI));
+    Word dest; EV_TRY(dest = stack_pop(I));
+    constrain_zero(I, dest.hi);
+    EV_TRY(stack_pop(I));
+    same_context3(I, opcode, 2, 1, 2);
+}
+
+ZK_HD void g_sload(Ins& I) {  // storage.py:15-47
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_SLOAD));
+    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
+    Reversion rv; EV_TRY(rv = reversion_info(I));
+    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
+    Word key; EV_TRY(key = stack_pop(I));
+    RwQ Q;
+    rwq_init(Q, 0, TG_AccountStorage);
+    rwq_set(Q, R_ID, tx_id);
+    rwq_set(Q, R_ADDR, callee);
+    rwq_set_word(Q, R_KEY_LO, key);
+    u32 r; EV_TRY(r = rw_lookup(I, Q));
+    Word val = rw_word(I, r, R_VAL_LO);
+    Word push; EV_TRY(push = stack_push(I));
+    constrain_equal_word(I, val, push);
+    RwQ W;
+    rwq_init(W, 1, TG_TxAccessListAccountStorage);
+    rwq_set(W, R_ID, tx_id);
+    rwq_set(W, R_ADDR, callee);
+    rwq_set_word(W, R_KEY_LO, key);
+    rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+    u32 wr; EV_TRY(wr = state_write(I, W, rv));
+    Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
+    bool warm = ev_select(I, is_warm); if (I.err) return;
+    same_context(I, opcode, t_delta_i(8), t_delta_i(1), t_delta_i(0), t_same(), t_delta_i(1), fr_u(warm ? 100 : 2100));
+}
+
+ZK_HD void g_sstore(Ins& I) {  // storage.py:50-153
+    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    constrain_equal(I, opcode, fr_u(OP_SSTORE));
+    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
+    Fr is_static; EV_TRY(is_static = call_context_lookup(I, CC_IsStatic));
+    constrain_equal(I, fr_zero(), is_static);
+    Reversion rv; EV_TRY(rv = reversion_info(I));
+    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
+    Word key, sval;
+    EV_TRY(key = stack_pop(I)); EV_TRY(sval = stack_pop(I));
+    RwQ Q;
+    rwq_init(Q, 1, TG_AccountStorage);
+    rwq_set(Q, R_ID, tx_id);
+    rwq_set(Q, R_ADDR, callee);
+    rwq_set_word(Q, R_KEY_LO, key);
+    u32 r; EV_TRY(r = state_write(I, Q, rv));
+    Word value = rw_word(I, r, R_VAL_LO), value_prev = rw_word(I, r, R_PREV_LO), original = rw_word(I, r, R_AUX_LO);
+    constrain_equal_word(I, sval, value);
+    RwQ W;
+    rwq_init(W, 1, TG_TxAccessListAccountStorage);
+    rwq_set(W, R_ID, tx_id);
+    rwq_set(W, R_ADDR, callee);
+    rwq_set_word(W, R_KEY_LO, key);
+    rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+    u32 wr; EV_TRY(wr = state_write(I, W, rv));
+    Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
+    RwQ Rf;
+    rwq_init(Rf, 1, TG_TxRefund);
+    rwq_set(Rf, R_ID, tx_id);
+    u32 rr; EV_TRY(rr = state_write(I, Rf, rv));
+    Fr gas_refund; EV_TRY(gas_refund = value_of(I, rw_value(I, rr)));
+    Fr refund_prev; EV_TRY(refund_prev = value_of(I, rw_value_prev(I, rr)));
+    const u64 CLEARS = 4800, SET = 20000, RESET = 2900, SLOAD = 100;
+    // eager nested selects in the reference's evaluation order (storage.py:84-123)
+    const u32 vz = is_zero_word(value), pz = is_zero_word(value_prev), oz = is_zero_word(original);
+    const u32 o_eq_v = is_equal_word(original, value), o_eq_p = is_equal_word(original, value_prev);
+    const u32 p_eq_v = is_equal_word(value_prev, value), p_eq_o = is_equal_word(value_prev, original);
+    Fr inner = ev_select_b(I, vz) ? fr_add_u64(refund_prev, CLEARS) : refund_prev;
+    Fr nz_allne = ev_select_b(I, pz) ? fr_sub_u64(refund_prev, CLEARS) : inner;
+    Fr nz_ne_ne = ev_select_b(I, 1 - o_eq_v) ? nz_allne : fr_sub_u64(fr_add_u64(nz_allne, RESET), SLOAD);
+    Fr inner2 = ev_select_b(I, o_eq_v) ? fr_sub_u64(fr_add_u64(refund_prev, SET), SLOAD) : refund_prev;
+    Fr ne_ne = ev_select_b(I, 1 - oz) ? nz_ne_ne : inner2;
+    Fr inner3 = ev_select_b(I, (1 - oz) * vz) ? fr_add_u64(refund_prev, CLEARS) : refund_prev;
+    Fr inner4 = ev_select_b(I, o_eq_p) ? inner3 : ne_ne;
+    Fr refund_new = ev_select_b(I, p_eq_v) ? refund_prev : inner4;
+    constrain_equal(I, gas_refund, refund_new);
+    const u32 eq_prev = p_eq_v, prev_ne_orig = 1 - p_eq_o;
+    const u64 inner5 = ev_select_b(I, oz) ? SET : RESET;
+    const u64 warm_case = ev_select_b(I, eq_prev + prev_ne_orig - eq_prev * prev_ne_orig) ? SLOAD : inner5;
+    bool warm = ev_select(I, is_warm); if (I.err) return;
+    same_context(I, opcode, t_delta_i(10), t_delta_i(1), t_delta_i(2), t_same(), t_delta_i(3),
+                 fr_u(warm ? warm_case : warm_case + 2100));
+}
+
+// ExecutionState transition constraint (instruction.py:189-204)
+ZK_HD bool state_transition_ok(u32 curr, u32 next) {
+    static const uint8_t halts[] = ZK_STATE_HALTS_INIT;
+    if (curr == ES_EndTx && !(next == ES_BeginTx || next == ES_EndBlock)) return false;
+    if (curr == ES_EndBlock && next != ES_EndBlock) return false;
+    if (next == ES_BeginTx) return curr == ES_EndTx;
+    if (next == ES_EndTx) return (curr < ES_COUNT && halts[curr]) || curr == ES_BeginTx;
+    if (next == ES_EndBlock) return curr == ES_EndTx || curr == ES_EndBlock;
+    return true;
+}
+
+// verify_step (main.py:47-63) for pair `idx`
+ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
+    Ins I;
+    I.a = &a;
+    I.idx = idx;
+    I.err = 0;
+    I.seq = 0;
+    I.rw_off = I.pc_off = 0;
+    I.sp_off = 0;
+    const bool is_first = (a.opts & 1u) && idx == 0;
+    const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
+    const Fr statef = ev_curr(I, S_STATE);
+    const u32 state = statef.v[0];
+    if (is_first) {
+        ev_require(I, state == ES_BeginTx || state == ES_EndBlock);
+        constrain_equal(I, ev_curr(I, S_RWC), fr_u(1));
+    }
+    if (is_last) ev_require(I, state == ES_EndBlock);
+    else ev_require(I, state_transition_ok(state, ev_next(I, S_STATE).v[0]));
+    if (I.err) return I.err;
+    I.seq++;
+    static const uint8_t ref_impl[] = ZK_STATE_REF_IMPLEMENTED_INIT;
+    if (state >= ES_COUNT || !ref_impl[state]) {
+        ev_fail(I, ZK_NOT_IMPLEMENTED);
+        return I.err;
+    }
+    switch (state) {
+    case ES_ADD: g_add_sub(I); break;
+    case ES_MUL: g_mul_div_mod(I); break;
+    case ES_CMP: g_cmp(I); break;
+    case ES_SCMP: g_scmp(I); break;
+    case ES_ISZERO: g_iszero(I); break;
+    case ES_NOT: g_not(I); break;
+    case ES_BITWISE: g_bitwise(I); break;
+    case ES_BYTE: g_byte(I); break;
+    case ES_SIGNEXTEND: g_signextend(I); break;
+    case ES_PUSH: g_push(I); break;
+    case ES_POP: g_pop(I); break;
+    case ES_SHL_SHR: g_shl_shr(I); break;
+    case ES_ADDMOD: g_addmod(I); break;
+    case ES_MULMOD: g_mulmod(I); break;
+    case ES_MEMORY: g_memory(I); break;
+    case ES_CALLER: g_ctx_word(I, OP_CALLER, CC_CallerAddress); break;
+    case ES_CALLVALUE: g_ctx_word(I, OP_CALLVALUE, CC_Value); break;
+    case ES_ADDRESS: g_ctx_word(I, OP_ADDRESS, CC_CalleeAddress); break;
+    case ES_CALLDATASIZE: g_ctx_value(I, OP_CALLDATASIZE, CC_CallDataLength); break;
+    case ES_RETURNDATASIZE: g_ctx_value(I, OP_RETURNDATASIZE, CC_LastCalleeReturnDataLength); break;
+    case ES_ORIGIN: g_tx_word(I, OP_ORIGIN, TXC_CallerAddress); break;
+    case ES_GASPRICE: g_tx_word(I, OP_GASPRICE, TXC_GasPrice); break;
+    case ES_SELFBALANCE: g_selfbalance(I); break;
+    case ES_BlockCtx: g_blockctx(I); break;
+    case ES_GAS: g_gas(I); break;
+    case ES_MSIZE: g_msize(I); break;
+    case ES_CODESIZE: g_codesize(I); break;
+    case ES_JUMP: g_jump(I); break;
+    case ES_JUMPI: g_jumpi(I); break;
+    case ES_SLOAD: g_sload(I); break;
+    case ES_SSTORE: g_sstore(I); break;
+    default: ev_fail(I, ZK_UNSUPPORTED); break;
+    }
+    return I.err;
+}

@@ -31,12 +31,12 @@ class UnsupportedOnDevice(Exception):
 
 KIND_OK, KIND_ASSERT, KIND_CONSTRAINT, KIND_LOOKUP_UNSAT, KIND_LOOKUP_AMBIGUOUS = 0, 1, 2, 3, 4
 KIND_WRONG_QUERY_KEY, KIND_NOT_IMPLEMENTED, KIND_TYPE_ERROR, KIND_OVERFLOW_ERROR = 5, 6, 7, 8
-KIND_VALUE_ERROR, KIND_ZERO_DIVISION, KIND_UNSUPPORTED = 9, 10, 15
+KIND_VALUE_ERROR, KIND_ZERO_DIVISION, KIND_NAME_ERROR, KIND_UNSUPPORTED = 9, 10, 11, 15
 
 KIND_NAMES = {
     0: "ok", 1: "AssertionError", 2: "ConstraintUnsatFailure", 3: "LookupUnsatFailure",
     4: "LookupAmbiguousFailure", 5: "WrongQueryKey", 6: "NotImplementedError", 7: "TypeError",
-    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 15: "UnsupportedOnDevice",
+    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 11: "UnboundLocalError", 15: "UnsupportedOnDevice",
 }
 
 
@@ -63,6 +63,8 @@ def exception_for_code(code, where=""):
         return ValueError(msg)
     if kind == KIND_ZERO_DIVISION:
         return ZeroDivisionError(msg)
+    if kind == KIND_NAME_ERROR:
+        return UnboundLocalError(msg)
     if kind == KIND_UNSUPPORTED:
         return UnsupportedOnDevice(msg)
     return RuntimeError(f"{msg} (unknown kind {kind})")

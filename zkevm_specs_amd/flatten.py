@@ -56,3 +56,100 @@ def mpt_row_cells(m):
 def flatten_mpt_table(mpt_table):
     rows = sorted(set(tuple(mpt_row_cells(m)) for m in mpt_table))
     return rows_to_rowmajor(rows, MPT_NCELLS)
+
+
+# ---- EVM circuit ------------------------------------------------------------------------
+STEP_NCELLS = 13
+RW_NCELLS = 14
+BYTECODE_NCELLS = 6
+TX_NCELLS = 5
+BLOCK_NCELLS = 4
+
+
+def _word_cells(x):
+    """(lo, hi, is_word) of a Word / WordOrValue / bare FQ field"""
+    if hasattr(x, "lo"):
+        return _n(x.lo), _n(x.hi), _is_word(x)
+    return _n(x), 0, False
+
+
+def step_cells(s):
+    """StepState (evm_circuit/step.py:6-75) -> 13 ints"""
+    return [int(s.execution_state), _n(s.rw_counter), _n(s.call_id), int(bool(s.is_root)), int(bool(s.is_create)),
+            _n(s.code_hash.lo), _n(s.code_hash.hi), _n(s.program_counter), _n(s.stack_pointer), _n(s.gas_left),
+            _n(s.memory_word_size), _n(s.reversible_write_counter), _n(s.log_id)]
+
+
+def flatten_steps(steps):
+    return rows_to_colmajor([step_cells(s) for s in steps], STEP_NCELLS)
+
+
+def rw_row_cells(r):
+    """RWTableRow (evm_circuit/table.py:447-457) -> 14 ints + flags"""
+    vlo, vhi, vw = _word_cells(r.value)
+    plo, phi, pw = _word_cells(r.value_prev)
+    cells = [_n(r.rw_counter), _n(r.rw), _n(r.key0), _n(r.id), _n(r.address), _n(r.field_tag),
+             _n(r.storage_key.lo), _n(r.storage_key.hi), vlo, vhi, plo, phi, _n(r.aux0.lo), _n(r.aux0.hi)]
+    return cells, (1 if vw else 0) | (2 if pw else 0)
+
+
+def _dedup(pairs):
+    """Tables are sets keyed on the cells (type bits do not take part in hashing/equality,
+    util/arithmetic.py:133-141): keep the first occurrence, sorted for determinism."""
+    seen = {}
+    for cells, flag in pairs:
+        seen.setdefault(tuple(cells), flag)
+    keys = sorted(seen)
+    return [list(k) for k in keys], [seen[k] for k in keys]
+
+
+def _iter_table(t):
+    """A table argument may be a set/list of rows or a witness object with table_assignments()."""
+    if t is None:
+        return []
+    if hasattr(t, "table_assignments"):
+        return list(t.table_assignments())
+    return list(t)
+
+
+def flatten_rw_table(rw_table):
+    rows, flags = _dedup([rw_row_cells(r) for r in _iter_table(rw_table)])
+    return rows_to_rowmajor(rows, RW_NCELLS), np.array(flags, dtype=np.uint32)
+
+
+def flatten_bytecode_table(bytecode_table):
+    rows, _ = _dedup([([_n(r.bytecode_hash.lo), _n(r.bytecode_hash.hi), _n(r.field_tag), _n(r.index),
+                        _n(r.is_code), _n(r.value)], 0) for r in _iter_table(bytecode_table)])
+    return rows_to_rowmajor(rows, BYTECODE_NCELLS)
+
+
+def flatten_tx_table(tx_table):
+    pairs = []
+    for r in _iter_table(tx_table):
+        lo, hi, w = _word_cells(r.value)
+        pairs.append(([_n(r.tx_id), _n(r.field_tag), _n(r.call_data_index_or_zero), lo, hi], 1 if w else 0))
+    rows, flags = _dedup(pairs)
+    return rows_to_rowmajor(rows, TX_NCELLS), np.array(flags, dtype=np.uint32)
+
+
+def flatten_block_table(block_table):
+    pairs = []
+    for r in _iter_table(block_table):
+        lo, hi, w = _word_cells(r.value)
+        pairs.append(([_n(r.field_tag), _n(r.block_number_or_zero), lo, hi], 1 if w else 0))
+    rows, flags = _dedup(pairs)
+    return rows_to_rowmajor(rows, BLOCK_NCELLS), np.array(flags, dtype=np.uint32)
+
+
+def flatten_evm(tables, steps):
+    """reference `Tables` (evm_circuit/table.py:578-671) + list of StepState -> dict of wire arrays"""
+    rw, rw_flags = flatten_rw_table(tables.rw_table)
+    tx, tx_flags = flatten_tx_table(tables.tx_table)
+    blk, blk_flags = flatten_block_table(tables.block_table)
+    return {
+        "steps": flatten_steps(steps),
+        "rw": rw, "rw_flags": rw_flags,
+        "bytecode": flatten_bytecode_table(tables.bytecode_table),
+        "tx": tx, "tx_flags": tx_flags,
+        "block": blk, "block_flags": blk_flags,
+    }
