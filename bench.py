@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="state", choices=["state"])
-    ap.add_argument("--log-rows", type=int, default=16)
+    ap.add_argument("--workload", default="evm", choices=["evm", "state"])
+    ap.add_argument("--log-rows", type=int, default=None, help="log2 rows per GPU (default: 18 evm, 16 state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -42,16 +42,36 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from zkevm_specs_amd import _lib, engine
-    from zkevm_specs_amd.synth import synth_state_witness
 
-    n = 1 << args.log_rows
-    cols, flags, mpt = synth_state_witness(n, seed=2 + rank)
-    bytes_per_row = 57 * 32  # every witness cell counted once
+    log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "evm" else 16)
+    n = 1 << log_rows
     to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
-    d_cols, d_flags, d_mpt = to_dev(cols), to_dev(flags), to_dev(mpt)
     _lib.init(local_rank)
     _lib.check(_lib.load().zk_set_stream(torch.cuda.current_stream().cuda_stream), "zk_set_stream")
-    sess = engine.open_state(d_cols, d_flags, d_mpt, device=local_rank)
+    if args.workload == "evm":
+        from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+        wire_h = synth_evm_trace(n, seed=3 + rank)
+        meta = wire_h.pop("meta")
+        wire_d = {k: to_dev(v) for k, v in wire_h.items()}
+        sess = engine.open_evm(wire_d, device=local_rank)
+        units = n - 1
+        algo_bytes = meta["algorithmic_bytes"]
+        kernel_name = "evm_steps_kernel"
+        workload = (f"EVM circuit, 2^{log_rows} execution steps per GPU, mixed-opcode synthetic trace "
+                    f"(BASELINE configs[2]); RW table {meta['n_rw']} rows, bytecode table {meta['n_bytecode']} rows")
+        extra_cfg = {"steps_per_gpu": n, "rw_rows": meta["n_rw"], "bytecode_rows": meta["n_bytecode"]}
+    else:
+        from zkevm_specs_amd.synth import synth_state_witness
+
+        cols, flags, mpt = synth_state_witness(n, seed=2 + rank)
+        d_cols, d_flags, d_mpt = to_dev(cols), to_dev(flags), to_dev(mpt)
+        sess = engine.open_state(d_cols, d_flags, d_mpt, device=local_rank)
+        units = n
+        algo_bytes = n * 57 * 32  # every witness cell counted once
+        kernel_name = "state_rows_kernel"
+        workload = f"State circuit, 2^{log_rows} RW rows per GPU (BASELINE configs[1])"
+        extra_cfg = {"rows_per_gpu": n, "mpt_rows": int(mpt.shape[0])}
 
     def barrier():
         if world > 1:
@@ -69,7 +89,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    tally = torch.tensor([res.fail_count, (res.first_fail_row + rank * n) if res.first_fail_row is not None else 2**62],
+    tally = torch.tensor([res.fail_count, (res.first_fail_row + rank * units) if res.first_fail_row is not None else 2**62],
                          dtype=torch.int64, device="cuda")
     t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -80,9 +100,9 @@ def main():
     assert int(tally[0].item()) == 0, "synthetic witness must satisfy every constraint"
 
     if rank == 0:
-        rows_total = n * args.steps * world
+        rows_total = units * args.steps * world
         kernel_s = res.kernel_ms / 1e3
-        achieved = n * bytes_per_row / kernel_s / 1e9
+        achieved = algo_bytes / kernel_s / 1e9
         out = {
             "metric": "BN254 constraint-rows/sec",
             "value": rows_total / dt,
@@ -96,14 +116,27 @@ def main():
             "vs_baseline": None,
             "dtype": "u256 (BN254 Fr, 4xu64 canonical cells; u32-limb Montgomery multiply)",
             "data": "synthetic",
-            "config": {"workload": f"State circuit, 2^{args.log_rows} RW rows per GPU (BASELINE configs[1])",
-                       "rows_per_gpu": n, "mpt_rows": int(mpt.shape[0]), "sharding": f"rows x{world}, tally all-reduce"},
+            "config": dict({"workload": workload, "sharding": f"rows x{world}, tally all-reduce"}, **extra_cfg),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "state_rows_kernel", "kernel_ms": res.kernel_ms,
-                         "algorithmic_bytes_per_launch": n * bytes_per_row},
+                         "kernel": kernel_name, "kernel_ms": res.kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "evm":
+            from oracle import evm_oracle, wire
+
+            sample = min(units, 1 << 17)
+            W = evm_oracle.EvmWitness(wire.colmajor_to_rows(wire_h["steps"][:, : sample + 1]), wire.rowmajor_to_rows(wire_h["rw"]),
+                                      wire_h["rw_flags"], wire.rowmajor_to_rows(wire_h["bytecode"]))
+            tc = time.perf_counter()
+            st = evm_oracle.verify_steps(W)
+            tc = time.perf_counter() - tc
+            assert not any(st)
+            out["cpu_baseline"] = {"value": sample / tc, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {sample} step pairs of the same trace, pure-Python oracle with dict-indexed "
+                                             "lookups (oracle/evm_oracle.py), 1 thread; the reference's own linear-scan lookups "
+                                             "are quadratic (0.33 steps/s at 257 steps, BASELINE.md)"}
+        elif not args.no_cpu_baseline:
             from oracle import state_oracle, wire
 
             sample = min(n, 1 << 16)

@@ -77,6 +77,28 @@ int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n,
                     uint32_t* status_out /* nullable, n entries, host unless DEVICE_PTRS */,
                     zk_result* result);
 
+/* ---- EVM circuit: replaces the `for (curr, next) in zip(steps, steps[1:]): verify_step(...)` loop of
+ *      verify_steps (src/zkevm_specs/evm_circuit/main.py:14-44): one status per step PAIR
+ *      (n_steps - 1 of them).  steps: uint64[13][n_steps][4] (StepState, step.py:16-75; the dummy
+ *      EndBlock step of main.py:21-22 is appended by the caller when end_with_last_step);
+ *      rw uint64[n][14][4] + flags (bit0 value.is_word, bit1 value_prev.is_word) — RWTableRow,
+ *      table.py:447-457; bytecode uint64[n][6][4] (:438-443); tx uint64[n][5][4] + flags (:421-426);
+ *      block uint64[n][4][4] + flags (:413-417).  Fixed-table lookups (table.py:14-103) are
+ *      evaluated in closed form on the device.  Tables are sets: callers de-duplicate rows. */
+typedef struct zk_evm_tables {
+    const uint64_t* steps;      uint64_t n_steps;
+    const uint64_t* rw;         const uint32_t* rw_flags;    uint64_t n_rw;
+    const uint64_t* bytecode;   uint64_t n_bytecode;
+    const uint64_t* tx;         const uint32_t* tx_flags;    uint64_t n_tx;
+    const uint64_t* block;      const uint32_t* block_flags; uint64_t n_block;
+    uint32_t begin_with_first_step;
+    uint32_t end_with_last_step;
+} zk_evm_tables;
+#define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
+int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
+int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
+                  uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

@@ -943,6 +943,55 @@ def g_sstore(i):  # storage.py:50-153
                    reversible_write_counter=D(3), dynamic_gas_cost=dyn)
 
 
+def _restore_context(i, rw_counter_delta, gas_left):  # instruction.py:292-363 (caller_id=None form)
+    rw_counter_delta += 12
+    caller_id = i.call_context_lookup(CC.CallerId)
+    saved = [i.call_context_lookup_word(t, call_id=caller_id) for t in (
+        CC.IsRoot, CC.IsCreate, CC.CodeHash, CC.ProgramCounter, CC.StackPointer, CC.GasLeft, CC.MemorySize,
+        CC.ReversibleWriteCounter)]
+    for tag, expected in ((CC.LastCalleeId, i.curr[S_CALL_ID]), (CC.LastCalleeReturnDataOffset, 0),
+                          (CC.LastCalleeReturnDataLength, 0)):
+        v = i.call_context_lookup(tag, rw=1, call_id=caller_id)
+        i.constrain_equal(v, expected)
+    rev = i.curr[S_REV] if ES(i.curr[S_STATE]).name in T.HALTS_IN_SUCCESS else 0
+    is_root = i.value_of(saved[0])
+    is_create = i.value_of(saved[1])
+    code_hash = saved[2][0]
+    pc = i.value_of(saved[3])
+    sp = i.value_of(saved[4])
+    gas = i.value_of(saved[5])
+    mem = i.value_of(saved[6])
+    rwc = i.value_of(saved[7])
+    i.transition(S_RWC, "delta", rw_counter_delta)
+    i.transition(S_CALL_ID, "to", caller_id)
+    i.transition(S_IS_ROOT, "to", is_root)
+    i.transition(S_IS_CREATE, "to", is_create)
+    i.require(i.next[S_CH_LO] == code_hash[0] % P and i.next[S_CH_HI] == code_hash[1] % P)
+    i.transition(S_PC, "to", pc)
+    i.transition(S_SP, "to", sp)
+    i.transition(S_GAS, "to", gas + gas_left)
+    i.transition(S_MWS, "to", mem)
+    i.transition(S_REV, "to", rwc + rev)
+
+
+def g_stop(i):  # stop.py
+    code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
+    code_length = i.bytecode_length(code_hash)
+    lt, eq = i.compare(code_length, i.curr[S_PC], 8)
+    if lt + eq == 0:
+        opcode = i.opcode_lookup(True)
+        i.fixed_lookup(T.FixedTableTag.ResponsibleOpcode, i.curr[S_STATE], opcode, 0)
+    is_success = i.call_context_lookup(CC.IsSuccess)
+    i.constrain_equal(is_success, 1)
+    is_to_end_tx = int(i.next[S_STATE] == ES.EndTx)
+    i.constrain_equal(i.curr[S_IS_ROOT], is_to_end_tx)
+    if i.curr[S_IS_ROOT]:
+        i.transition(S_RWC, "delta", 1)
+        i.transition(S_CALL_ID, "same")
+    else:
+        _restore_context(i, 1, i.curr[S_GAS])
+
+
 GADGETS = {
     ES.ADD: g_add_sub, ES.MUL: g_mul_div_mod, ES.CMP: g_cmp, ES.SCMP: g_scmp, ES.ISZERO: g_iszero,
     ES.NOT: g_not, ES.BITWISE: g_bitwise, ES.BYTE: g_byte, ES.SIGNEXTEND: g_signextend, ES.PUSH: g_push,
@@ -950,7 +999,7 @@ GADGETS = {
     ES.CALLER: g_caller, ES.CALLVALUE: g_callvalue, ES.ADDRESS: g_address, ES.CALLDATASIZE: g_calldatasize,
     ES.RETURNDATASIZE: g_returndatasize, ES.ORIGIN: g_origin, ES.GASPRICE: g_gasprice,
     ES.SELFBALANCE: g_selfbalance, ES.BlockCtx: g_blockctx, ES.GAS: g_gas, ES.MSIZE: g_msize,
-    ES.CODESIZE: g_codesize, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
+    ES.CODESIZE: g_codesize, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }
 SUPPORTED_STATES = sorted(int(s) for s in GADGETS)
 

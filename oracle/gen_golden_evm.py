@@ -24,7 +24,7 @@ from oracle.gen_golden import kind_of_exception  # noqa: E402
 
 TEST_FILES = """add_sub mul_div_mod comparator slt_sgt iszero not bitwise byte signextend push pop shl_shr addmod
 mulmod memory caller callvalue address calldatasize returndatasize origin gasprice selfbalance block_ctx gas
-msize codesize jump jumpi sload sstore sar sdiv_smod""".split()
+msize codesize jump jumpi sload sstore stop sar sdiv_smod""".split()
 MAX_CASES_PER_FILE = 48
 
 

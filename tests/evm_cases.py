@@ -1,0 +1,80 @@
+"""Shared helpers for the EVM-circuit tests: golden-case loading and oracle / hostsim drivers."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+
+from oracle import evm_oracle as eo, wire
+
+FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags")
+
+
+def golden_files(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, "evm_*.npz")))
+
+
+def load_cases(fn):
+    g = np.load(fn)
+    for i, nm in enumerate(g["names"]):
+        k = f"c{i:04d}"
+        w = {f: g[f"{k}_{f}"] for f in FIELDS}
+        yield str(nm), w, g[k + "_opts"], g[k + "_ref_kind"]
+
+
+def to_witness(w):
+    return eo.EvmWitness(wire.colmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
+                         wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
+                         wire.rowmajor_to_rows(w["block"]), w["block_flags"])
+
+
+def oracle_status(w, opts=(0, 0)):
+    return eo.verify_steps(to_witness(w), bool(opts[0]), bool(opts[1]))
+
+
+def hostsim_status(lib, w, opts=(0, 0)):
+    a = {k: np.ascontiguousarray(w[k]) for k in FIELDS}
+    n = a["steps"].shape[1]
+    st = np.zeros(max(n - 1, 1), dtype=np.uint32)
+    vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+    u64 = ctypes.c_uint64
+    lib.sim_evm_verify(vp(a["steps"]), u64(n), vp(a["rw"]), vp(a["rw_flags"]), u64(a["rw"].shape[0]),
+                       vp(a["bytecode"]), u64(a["bytecode"].shape[0]), vp(a["tx"]), vp(a["tx_flags"]),
+                       u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
+                       ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1)), vp(st))
+    return st[: n - 1].tolist()
+
+
+def fuzz_wire(w, rng):
+    """Overwrite 1..3 random cells of the steps / rw / bytecode tables (canonical values)."""
+    P = wire.P
+    w = {k: v.copy() for k, v in w.items() if k in FIELDS}
+
+    def put(arr, idx, val):
+        arr[idx] = np.frombuffer(int(val % P).to_bytes(32, "little"), dtype="<u8")
+
+    def cur(arr, idx):
+        return int.from_bytes(arr[idx].tobytes(), "little")
+
+    for _ in range(rng.choice([1, 1, 2, 3])):
+        which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
+        if which == "steps":
+            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[1])
+            if c in (3, 4):
+                put(w["steps"], (c, i), rng.randrange(2))
+            else:
+                old = cur(w["steps"], (c, i))
+                put(w["steps"], (c, i), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
+        elif which == "rw" and w["rw"].shape[0]:
+            i, c = rng.randrange(w["rw"].shape[0]), rng.randrange(14)
+            old = cur(w["rw"], (i, c))
+            put(w["rw"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(128)),
+                                              2**128, 2**255 % P, old + 2**128, rng.randrange(2**128)]))
+        elif which == "bytecode" and w["bytecode"].shape[0]:
+            i, c = rng.randrange(w["bytecode"].shape[0]), rng.randrange(2, 6)
+            old = cur(w["bytecode"], (i, c))
+            put(w["bytecode"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(256), rng.randrange(P)]))
+        elif w["rw_flags"].shape[0]:
+            i = rng.randrange(w["rw_flags"].shape[0])
+            w["rw_flags"][i] ^= np.uint32(rng.choice([1, 2]))
+    return w

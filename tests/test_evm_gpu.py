@@ -1,0 +1,108 @@
+"""GPU parity tests of the EVM-circuit kernel, through the C ABI."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import codes
+from tests.evm_cases import fuzz_wire, golden_files, load_cases, oracle_status
+from zkevm_specs_amd import engine
+from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(w, opts=(0, 0), state_sort=True):
+    with engine.open_evm(w, bool(opts[0]), bool(opts[1]), state_sort=state_sort) as s:
+        res = s.run()
+        return res, s.read_status().tolist()
+
+
+def _check_tally(res, exp):
+    fails = [j for j, c in enumerate(exp) if c]
+    assert res.fail_count == len(fails)
+    if fails:
+        assert res.first_fail_row == fails[0] and res.first_fail_code == exp[fails[0]]
+    else:
+        assert res.first_fail_row is None
+
+
+def test_golden_cases_match_reference_and_oracle(golden_dir):
+    """Every golden case (the reference's own opcode tests + reference-labelled fuzz): device
+    status == oracle status (kind and checkpoint), and the kind equals the reference's."""
+    n = 0
+    for fn in golden_files(golden_dir):
+        for name, w, opts, ref_kind in load_cases(fn):
+            res, status = _run(w, opts)
+            exp = oracle_status(w, opts)
+            assert status == exp, (os.path.basename(fn), name)
+            _check_tally(res, exp)
+            for c, rk in zip(status, ref_kind.tolist()):
+                if codes.kind_of(c) != codes.UNSUPPORTED:
+                    assert codes.kind_of(c) == rk, (os.path.basename(fn), name)
+            n += 1
+    assert n > 2000
+
+
+def test_fuzzed_cases_match_oracle(golden_dir):
+    rng = random.Random(4242)
+    for fn in golden_files(golden_dir):
+        cases = [c for c in load_cases(fn) if "#fuzz" not in c[0]][:6]
+        for name, w, opts, _ in cases:
+            for _ in range(6):
+                fw = fuzz_wire(w, rng)
+                res, status = _run(fw, opts)
+                exp = oracle_status(fw, opts)
+                assert status == exp, (os.path.basename(fn), name)
+                _check_tally(res, exp)
+
+
+@pytest.mark.parametrize("state_sort", [True, False])
+def test_synthetic_trace_matches_oracle(state_sort):
+    """2^13-step mixed-opcode trace, valid and with tampered cells, vs the oracle on every pair."""
+    w = synth_evm_trace(1 << 13, seed=21)
+    w = {k: v for k, v in w.items() if k != "meta"}
+    res, status = _run(w, state_sort=state_sort)
+    assert res.ok and not any(status)
+    rng = random.Random(5)
+    for _ in range(40):
+        w = fuzz_wire(w, rng)
+    res, status = _run(w, state_sort=state_sort)
+    exp = oracle_status(w)
+    assert status == exp
+    _check_tally(res, exp)
+    assert res.fail_count >= 10
+
+
+def test_full_size_trace_properties():
+    """BASELINE config 3 size (2^18 steps): the valid trace passes; tampering k cells makes exactly
+    the pairs that look at those cells fail (oracle evaluated on the affected pairs only);
+    state-sorted and trace-order evaluation agree (permutation invariance)."""
+    n = 1 << 18
+    w = synth_evm_trace(n, seed=3)
+    meta = w.pop("meta")
+    assert meta["n_pairs"] == n - 1
+    res, status = _run(w)
+    assert res.ok and res.rows_evaluated == n - 1 and not any(status)
+    # tamper stack values of 64 random RW rows
+    rng = np.random.default_rng(8)
+    rows = rng.integers(0, w["rw"].shape[0], size=64)
+    w["rw"][rows, 8, 0] ^= np.uint64(1)
+    res1, st1 = _run(w)
+    res2, st2 = _run(w, state_sort=False)
+    assert st1 == st2 and (res1.fail_count, res1.first_fail_row, res1.first_fail_code) == (res2.fail_count, res2.first_fail_row, res2.first_fail_code)
+    from oracle import evm_oracle as eo
+    from tests.evm_cases import to_witness
+    W = to_witness(w)
+    fails = [j for j, c in enumerate(st1) if c]
+    assert 1 <= len(fails) <= 64 * 2
+    for j in fails + [max(0, fails[0] - 1), fails[-1] + 1 if fails[-1] + 1 < n - 1 else 0]:
+        assert eo.verify_step(W, j) == st1[j]
+    # every tampered row belongs to a step whose status we can predict with the oracle
+    rwc = [int(w["rw"][r, 0, 0]) for r in rows]
+    step_rwc = w["steps"][1, :, 0].astype(np.int64)
+    for c in rwc:
+        j = int(np.searchsorted(step_rwc, c, side="right") - 1)
+        if j < n - 1:
+            assert eo.verify_step(W, j) == st1[j]

@@ -1,0 +1,58 @@
+"""CPU tests of the EVM circuit: oracle vs the reference's recorded outcomes (golden vectors
+generated from the unmodified reference by oracle/gen_golden_evm.py), and the kernels' gadget
+logic (hostsim build of csrc/evm_circuit.hpp) vs the oracle, including cell-level fuzz."""
+import os
+import random
+
+import pytest
+
+from oracle import codes
+from tests.evm_cases import fuzz_wire, golden_files, hostsim_status, load_cases, oracle_status
+from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+
+def test_golden_files_present(golden_dir):
+    assert len(golden_files(golden_dir)) >= 30
+
+
+def test_oracle_matches_reference_outcomes(golden_dir):
+    n = n_fail = 0
+    for fn in golden_files(golden_dir):
+        for name, w, opts, ref_kind in load_cases(fn):
+            got = oracle_status(w, opts)
+            for j, (c, rk) in enumerate(zip(got, ref_kind.tolist())):
+                if codes.kind_of(c) == codes.UNSUPPORTED:
+                    continue  # states / malformed-cell cases outside the engine's domain
+                assert codes.kind_of(c) == rk, (os.path.basename(fn), name, j)
+                n += 1
+                n_fail += rk != 0
+    assert n > 1500 and n_fail > 500
+
+
+def test_kernel_logic_matches_oracle_on_goldens(golden_dir, hostsim):
+    for fn in golden_files(golden_dir):
+        for name, w, opts, _ in load_cases(fn):
+            assert hostsim_status(hostsim, w, opts) == oracle_status(w, opts), (os.path.basename(fn), name)
+
+
+def test_kernel_logic_matches_oracle_under_fuzz(golden_dir, hostsim):
+    rng = random.Random(99)
+    n = n_fail = 0
+    for fn in golden_files(golden_dir):
+        cases = [c for c in load_cases(fn) if "#fuzz" not in c[0]][:8]
+        for name, w, opts, _ in cases:
+            for _ in range(12):
+                fw = fuzz_wire(w, rng)
+                exp = oracle_status(fw, opts)
+                assert hostsim_status(hostsim, fw, opts) == exp, (os.path.basename(fn), name)
+                n += len(exp)
+                n_fail += sum(1 for e in exp if e)
+    assert n > 2000 and n_fail > 800
+
+
+@pytest.mark.parametrize("n,seed", [(700, 3), (2600, 5)])
+def test_synthetic_trace_is_valid(n, seed, hostsim):
+    w = synth_evm_trace(n, seed=seed)
+    exp = oracle_status(w)
+    assert not any(exp)
+    assert hostsim_status(hostsim, w) == exp

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+    "zk_state_open", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -26,6 +26,20 @@ class ZkResult(ctypes.Structure):
         ("rows_evaluated", ctypes.c_uint64),
         ("kernel_ms", ctypes.c_double),
     ]
+
+
+class ZkEvmTables(ctypes.Structure):
+    _fields_ = [
+        ("steps", ctypes.c_void_p), ("n_steps", ctypes.c_uint64),
+        ("rw", ctypes.c_void_p), ("rw_flags", ctypes.c_void_p), ("n_rw", ctypes.c_uint64),
+        ("bytecode", ctypes.c_void_p), ("n_bytecode", ctypes.c_uint64),
+        ("tx", ctypes.c_void_p), ("tx_flags", ctypes.c_void_p), ("n_tx", ctypes.c_uint64),
+        ("block", ctypes.c_void_p), ("block_flags", ctypes.c_void_p), ("n_block", ctypes.c_uint64),
+        ("begin_with_first_step", ctypes.c_uint32), ("end_with_last_step", ctypes.c_uint32),
+    ]
+
+
+OPT_NO_STATE_SORT = 2
 
 
 class EngineError(RuntimeError):
@@ -59,6 +73,8 @@ def load():
     lib.zk_fr_op.argtypes = [ctypes.c_int, vp, vp, vp, u64, u32]
     lib.zk_state_open.argtypes = [vp, vp, u64, vp, u64, u32, ctypes.POINTER(vp)]
     lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_evm_open.argtypes = [ctypes.POINTER(ZkEvmTables), u32, ctypes.POINTER(vp)]
+    lib.zk_evm_verify.argtypes = [ctypes.POINTER(ZkEvmTables), u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_launch.argtypes = [vp, vp]
     lib.zk_collect.argtypes = [vp, ctypes.POINTER(ZkResult)]
     lib.zk_read_status.argtypes = [vp, vp]

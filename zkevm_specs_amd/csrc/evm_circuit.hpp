@@ -378,10 +378,10 @@ ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr) {
     if (I.err) return fr_zero();
     return value_of(I, rw_value(I, r));
 }
-ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag) {
+ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
     RwQ Q;
-    rwq_init(Q, 0, TG_CallContext);
-    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
+    rwq_init(Q, rw, TG_CallContext);
+    rwq_set(Q, R_ID, call_id ? *call_id : ev_curr(I, S_CALL_ID));
     rwq_set(Q, R_ADDR, fr_u(field_tag));
     u32 r = rw_lookup(I, Q);
     WordOrValue v;
@@ -390,8 +390,8 @@ ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag) {
     if (I.err) return v;
     return rw_value(I, r);
 }
-ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag) {
-    WordOrValue v = call_context_lookup_word(I, field_tag);
+ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
+    WordOrValue v = call_context_lookup_word(I, field_tag, rw, call_id);
     if (I.err) return fr_zero();
     return value_of(I, v);
 }
@@ -1197,6 +1197,65 @@ ZK_HD void g_sstore(Ins& I) {  // storage.py:50-153
                  fr_u(warm ? warm_case : warm_case + 2100));
 }
 
+// step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
+ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
+    rw_counter_delta += 12;
+    Fr caller_id; EV_TRY(caller_id = call_context_lookup(I, CC_CallerId));
+    const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
+                         CC_MemorySize, CC_ReversibleWriteCounter};
+    WordOrValue saved[8];
+    for (int k = 0; k < 8; k++) EV_TRY(saved[k] = call_context_lookup_word(I, tags[k], 0, &caller_id));
+    {
+        Fr v; EV_TRY(v = call_context_lookup(I, CC_LastCalleeId, 1, &caller_id));
+        constrain_equal(I, v, ev_curr(I, S_CALL_ID));
+        EV_TRY(v = call_context_lookup(I, CC_LastCalleeReturnDataOffset, 1, &caller_id));
+        constrain_equal(I, v, fr_zero());
+        EV_TRY(v = call_context_lookup(I, CC_LastCalleeReturnDataLength, 1, &caller_id));
+        constrain_equal(I, v, fr_zero());
+    }
+    const u32 st = ev_curr(I, S_STATE).v[0];
+    const bool halts_ok = st == ES_STOP || st == ES_RETURN || st == ES_SELFDESTRUCT;
+    Fr rev = halts_ok ? ev_curr(I, S_REV) : fr_zero();
+    Fr is_root = value_of(I, saved[0]);
+    Fr is_create = value_of(I, saved[1]);
+    Fr pc = value_of(I, saved[3]);
+    Fr sp = value_of(I, saved[4]);
+    Fr gas = value_of(I, saved[5]);
+    Fr mem = value_of(I, saved[6]);
+    Fr rwc = value_of(I, saved[7]);
+    transition(I, S_RWC, t_delta(fr_u(rw_counter_delta)));
+    transition(I, S_CALL_ID, t_to(caller_id));
+    transition(I, S_IS_ROOT, t_to(is_root));
+    transition(I, S_IS_CREATE, t_to(is_create));
+    ev_require(I, fr_eq(ev_next(I, S_CH_LO), saved[2].w.lo) && fr_eq(ev_next(I, S_CH_HI), saved[2].w.hi));
+    transition(I, S_PC, t_to(pc));
+    transition(I, S_SP, t_to(sp));
+    transition(I, S_GAS, t_to(fr_add(gas, gas_left)));
+    transition(I, S_MWS, t_to(mem));
+    transition(I, S_REV, t_to(fr_add(rwc, rev)));
+}
+
+ZK_HD void g_stop(Ins& I) {  // stop.py
+    Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
+    u32 lt, eq; ev_compare(I, code_length, ev_curr(I, S_PC), 8, lt, eq); if (I.err) return;
+    if (lt + eq == 0) {
+        Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+        fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
+    }
+    Fr is_success; EV_TRY(is_success = call_context_lookup(I, CC_IsSuccess));
+    constrain_equal(I, is_success, fr_u(1));
+    const u32 to_end_tx = ev_next(I, S_STATE).v[0] == ES_EndTx ? 1u : 0u;
+    Fr is_root = ev_curr(I, S_IS_ROOT);
+    constrain_equal(I, is_root, fr_u(to_end_tx));
+    if (I.err) return;
+    if (!fr_is_zero(is_root)) {
+        transition(I, S_RWC, t_delta_i(1));
+        transition(I, S_CALL_ID, t_same());
+    } else {
+        restore_context(I, 1, ev_curr(I, S_GAS));
+    }
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_transition_ok(u32 curr, u32 next) {
     static const uint8_t halts[] = ZK_STATE_HALTS_INIT;
@@ -1262,6 +1321,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_GAS: g_gas(I); break;
     case ES_MSIZE: g_msize(I); break;
     case ES_CODESIZE: g_codesize(I); break;
+    case ES_STOP: g_stop(I); break;
     case ES_JUMP: g_jump(I); break;
     case ES_JUMPI: g_jumpi(I); break;
     case ES_SLOAD: g_sload(I); break;

@@ -7,6 +7,7 @@
 
 #include "../../include/zkevm_hip.h"
 #include "state_circuit.hpp"
+#include "evm_circuit.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -108,6 +109,68 @@ __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* statu
     tally_commit(tally, i, code);
 }
 
+// ---------------------------------------------------------------------------------------
+// EVM circuit kernel: one lane per step pair (curr, next).  Lanes are assigned through a
+// state-sorted permutation so that a 64-lane wavefront runs ONE gadget body instead of
+// serialising the ~10 different execution states a window of consecutive steps contains.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void evm_steps_kernel(EvmArgs a, u32* status, ZkTally* tally) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    u64 idx = t;
+    if (t < a.n_pairs) {
+        idx = a.perm ? a.perm[t] : t;
+        code = evm_check_step(a, idx);
+        if (status) status[idx] = code;
+    }
+    tally_commit(tally, idx, code);
+}
+
+// Counting sort of the step pairs by execution state (stable): histogram, scan, scatter.
+__global__ void evm_state_hist_kernel(ZkCols steps, u32 n_pairs, u32* hist) {
+    __shared__ u32 local[128];
+    for (u32 k = threadIdx.x; k < 128; k += blockDim.x) local[k] = 0;
+    __syncthreads();
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) {
+        u32 st = (u32)steps.cells[((u64)S_STATE * steps.n + i) * 4] & 127u;
+        atomicAdd(&local[st], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < 128; k += blockDim.x)
+        if (local[k]) atomicAdd(&hist[k], local[k]);
+}
+// Exclusive scan of the 128 state bins (turns the histogram into per-state cursors).
+__global__ void evm_state_scan_kernel(u32* hist) {
+    if (threadIdx.x == 0) {
+        u32 acc = 0;
+        for (int k = 0; k < 128; k++) {
+            u32 c = hist[k];
+            hist[k] = acc;
+            acc += c;
+        }
+    }
+}
+// Scatter with block-level aggregation: ranks inside a block come from LDS atomics, one global
+// atomic per (block, state present).  Order inside a state bucket is irrelevant for correctness.
+__global__ void evm_state_scatter_kernel(ZkCols steps, u32 n_pairs, u32* cursor, u32* perm) {
+    __shared__ u32 local[128];
+    __shared__ u32 base[128];
+    for (u32 k = threadIdx.x; k < 128; k += blockDim.x) local[k] = 0;
+    __syncthreads();
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 st = 0, rank = 0;
+    if (i < n_pairs) {
+        st = (u32)steps.cells[((u64)S_STATE * steps.n + i) * 4] & 127u;
+        rank = atomicAdd(&local[st], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < 128; k += blockDim.x)
+        if (local[k]) base[k] = atomicAdd(&cursor[k], local[k]);
+    __syncthreads();
+    if (i < n_pairs) perm[base[st] + rank] = i;
+}
+
 __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -126,7 +189,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2 };
 
 struct zk_session {
     SessionKind kind;
@@ -137,6 +200,9 @@ struct zk_session {
     std::vector<hipEvent_t> ev;     // start/stop pairs
     u32 launches = 0;               // since last collect
     StateArgs state;
+    EvmArgs evm;
+    u32* d_hist = nullptr;   // EVM: 128 state bins (histogram -> cursors)
+    u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
 };
 
 static const int MAX_EVENT_PAIRS = 256;
@@ -221,6 +287,80 @@ fail:
     return rc;
 }
 
+static int table_stage(zk_session* s, ZkTable& t, const uint64_t* cells, const uint32_t* flags, uint64_t n,
+                       u32 ncells, bool dev) {
+    const void* p = nullptr;
+    int rc;
+    if ((rc = stage(s, cells, (size_t)n * ncells * 32, dev, &p))) return rc;
+    t.cells = (const u64*)p;
+    if ((rc = stage(s, flags, (size_t)n * 4, dev, &p))) return rc;
+    t.flags = (n && flags) ? (const u32*)p : nullptr;
+    t.n = (u32)n;
+    t.ncells = ncells;
+    return 0;
+}
+
+// (Re)build the state-sorted permutation of the step pairs.
+static int evm_build_perm(zk_session* s) {
+    const u32 n = s->evm.n_pairs;
+    HIP_TRY(hipMemsetAsync(s->d_hist, 0, 128 * sizeof(u32), g_stream));
+    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist);
+    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(64), 0, g_stream, s->d_hist);
+    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist, s->d_perm);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_evm_open: call zk_init first");
+    ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
+    ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31),
+            "zk_evm_open: table too large");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_EVM;
+    s->n = t->n_steps - 1;
+    int rc = 0;
+    const void* p = nullptr;
+    if ((rc = stage(s, t->steps, (size_t)t->n_steps * STEP_NCELLS * 32, dev, &p))) goto fail;
+    s->evm.steps.cells = (const u64*)p;
+    s->evm.steps.flags = nullptr;
+    s->evm.steps.n = t->n_steps;
+    if ((rc = table_stage(s, s->evm.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.block, t->block, t->block_flags, t->n_block, BLOCK_NCELLS, dev))) goto fail;
+    if ((rc = build_index<rw_key_hash>(s, s->evm.rw))) goto fail;
+    if ((rc = build_index<bc_key_hash>(s, s->evm.bytecode))) goto fail;
+    if ((rc = build_index<tx_key_hash>(s, s->evm.tx))) goto fail;
+    if ((rc = build_index<blk_key_hash>(s, s->evm.block))) goto fail;
+    s->evm.n_pairs = (u32)(t->n_steps - 1);
+    s->evm.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
+    if ((rc = dev_alloc(s, (void**)&s->d_hist, 128 * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
+    s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
+    if (s->evm.perm && (rc = evm_build_perm(s))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+
+extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_evm_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_evm_open(t, opts, &s);
+    if (rc) return rc;
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -243,6 +383,12 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
         hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, s->d_tally);
+        break;
+    }
+    case SESSION_EVM: {
+        const int block = 256;
+        const u32 grid = (u32)((s->n + block - 1) / block);
+        hipLaunchKernelGGL(evm_steps_kernel, dim3(grid), dim3(block), 0, g_stream, s->evm, status, s->d_tally);
         break;
     }
     }

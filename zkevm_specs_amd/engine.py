@@ -105,6 +105,35 @@ def open_state(rows, flags, mpt, device=None):
     return Session(h, n, (rows, flags, mpt))
 
 
+def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True):
+    """wire: dict with steps uint64[13, n, 4], rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
+    (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
+    lib = _lib.init(device)
+    names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags"]
+    arrs, opts = _prep([wire.get(k) for k in names])
+    a = dict(zip(names, arrs))
+
+    def rows(x):
+        return 0 if x is None else int(x.shape[0])
+
+    def p(x):
+        v = _lib.ptr(x)
+        return v.value if v is not None else None
+
+    t = _lib.ZkEvmTables(
+        p(a["steps"]), int(a["steps"].shape[1]),
+        p(a["rw"]) if rows(a["rw"]) else None, p(a["rw_flags"]) if rows(a["rw"]) else None, rows(a["rw"]),
+        p(a["bytecode"]) if rows(a["bytecode"]) else None, rows(a["bytecode"]),
+        p(a["tx"]) if rows(a["tx"]) else None, p(a["tx_flags"]) if rows(a["tx"]) else None, rows(a["tx"]),
+        p(a["block"]) if rows(a["block"]) else None, p(a["block_flags"]) if rows(a["block"]) else None, rows(a["block"]),
+        int(bool(begin_with_first_step)), int(bool(end_with_last_step)))
+    if not state_sort:
+        opts |= _lib.OPT_NO_STATE_SORT
+    h = ctypes.c_void_p()
+    check(lib.zk_evm_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_evm_open")
+    return Session(h, int(a["steps"].shape[1]) - 1, arrs)
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

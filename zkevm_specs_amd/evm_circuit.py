@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's EVM-circuit driver, evaluated on the MI355X.
+
+Reference seam: `zkevm_specs.evm_circuit.verify_steps(tables, steps, begin_with_first_step=False,
+end_with_last_step=False, success=True)` (evm_circuit/main.py:14-44), which loops
+`verify_step(Instruction(tables, curr, next, ...))` over consecutive step pairs.  Here the loop
+is one device pass; arguments, the dummy EndBlock step and the error behaviour are the same:
+the first failing pair decides — an AssertionError there is swallowed and re-raised iff `success`
+(main.py:36-44), any other exception class propagates as is.
+"""
+from . import engine
+from .errors import KIND_ASSERT, exception_for_code
+from .evm_tables import ExecutionState
+from .flatten import flatten_evm
+
+
+class Word:
+    """256-bit word as lo/hi 128-bit halves (util/arithmetic.py:99-123), enough for step fields."""
+
+    def __init__(self, value=0):
+        if isinstance(value, tuple):
+            self.lo, self.hi = value
+        else:
+            self.lo, self.hi = value & ((1 << 128) - 1), value >> 128
+
+
+class StepState:
+    """Same constructor as the reference's StepState (evm_circuit/step.py:47-75)."""
+
+    def __init__(self, execution_state, rw_counter, call_id=0, is_root=False, is_create=False, code_hash=None,
+                 program_counter=0, stack_pointer=1024, gas_left=0, memory_word_size=0,
+                 reversible_write_counter=0, log_id=0, aux_data=None):
+        self.execution_state = execution_state
+        self.rw_counter = rw_counter
+        self.call_id = call_id
+        self.is_root = is_root
+        self.is_create = is_create
+        self.code_hash = code_hash if code_hash is not None else Word(0)
+        self.program_counter = program_counter
+        self.stack_pointer = stack_pointer
+        self.gas_left = gas_left
+        self.memory_word_size = memory_word_size
+        self.reversible_write_counter = reversible_write_counter
+        self.log_id = log_id
+        self.aux_data = aux_data
+
+
+def _dummy_step():
+    return StepState(ExecutionState.EndBlock, rw_counter=-1)  # main.py:11
+
+
+def verify_steps(tables, steps, begin_with_first_step=False, end_with_last_step=False, success=True):
+    if end_with_last_step:
+        steps.append(_dummy_step())  # the reference mutates the caller's list too (main.py:21-22)
+    wire = flatten_evm(tables, steps)
+    with engine.open_evm(wire, begin_with_first_step, end_with_last_step) as s:
+        res = s.run()
+    exception = None
+    if not res.ok:
+        exc = exception_for_code(res.first_fail_code, f"EVM circuit step {res.first_fail_row}")
+        if res.first_fail_kind != KIND_ASSERT:
+            raise exc
+        exception = exc
+    if success:
+        if exception:
+            raise exception
+    else:
+        assert exception is not None
+    return res
+
+
+def verify_steps_status(tables, steps, begin_with_first_step=False, end_with_last_step=False):
+    """Diagnostic form: per-pair status codes of every step pair (no early stop)."""
+    if end_with_last_step:
+        steps = list(steps) + [_dummy_step()]
+    wire = flatten_evm(tables, steps)
+    with engine.open_evm(wire, begin_with_first_step, end_with_last_step) as s:
+        res = s.run()
+        return res, s.read_status()

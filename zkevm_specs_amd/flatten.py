@@ -4,7 +4,7 @@ Duck-typed: works on the reference's own objects (`zkevm_specs.state_circuit.Row
 `MPTTableRow`, `StepState`, `RWTableRow`, ...) or on this package's mirrors — only attribute
 names are used, nothing is imported from the reference.
 """
-from .wire import rows_to_colmajor, rows_to_rowmajor
+from .wire import FR_MODULUS, rows_to_colmajor, rows_to_rowmajor
 import numpy as np
 
 
@@ -14,7 +14,7 @@ def _n(x):
         return x.expr().n
     if hasattr(x, "n"):
         return x.n
-    return int(x)
+    return int(x) % FR_MODULUS  # plain ints behave like FQ(int) (reduction mod p, e.g. rw_counter=-1)
 
 
 def _is_word(x):
