@@ -126,7 +126,7 @@ def main():
             from oracle import evm_oracle, wire
 
             sample = min(units, 1 << 17)
-            W = evm_oracle.EvmWitness(wire.colmajor_to_rows(wire_h["steps"][:, : sample + 1]), wire.rowmajor_to_rows(wire_h["rw"]),
+            W = evm_oracle.EvmWitness(wire.rowmajor_to_rows(wire_h["steps"][: sample + 1]), wire.rowmajor_to_rows(wire_h["rw"]),
                                       wire_h["rw_flags"], wire.rowmajor_to_rows(wire_h["bytecode"]))
             tc = time.perf_counter()
             st = evm_oracle.verify_steps(W)

@@ -79,7 +79,8 @@ int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n,
 
 /* ---- EVM circuit: replaces the `for (curr, next) in zip(steps, steps[1:]): verify_step(...)` loop of
  *      verify_steps (src/zkevm_specs/evm_circuit/main.py:14-44): one status per step PAIR
- *      (n_steps - 1 of them).  steps: uint64[13][n_steps][4] (StepState, step.py:16-75; the dummy
+ *      (n_steps - 1 of them).  steps: ROW-major uint64[n_steps][13][4] (StepState, step.py:16-75 —
+ *      lanes visit steps in state-sorted order, so each step's cells stay contiguous; the dummy
  *      EndBlock step of main.py:21-22 is appended by the caller when end_with_last_step);
  *      rw uint64[n][14][4] + flags (bit0 value.is_word, bit1 value_prev.is_word) — RWTableRow,
  *      table.py:447-457; bytecode uint64[n][6][4] (:438-443); tx uint64[n][5][4] + flags (:421-426);
@@ -95,6 +96,7 @@ typedef struct zk_evm_tables {
     uint32_t end_with_last_step;
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
+#define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */
 int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
 int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
                   uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);

@@ -81,7 +81,7 @@ def unflatten(wire):
 
     W = lambda lo, hi: Word((FQ(lo), FQ(hi)), check=False)  # noqa: E731
     steps = []
-    for c in colmajor_to_rows(wire["steps"]):
+    for c in rowmajor_to_rows(wire["steps"]):
         s = StepState(ExecutionState(c[0]), 0, code_hash=W(c[5], c[6]))
         s.rw_counter, s.call_id = FQ(c[1]), FQ(c[2])
         s.is_root, s.is_create = bool(c[3]), bool(c[4])
@@ -114,12 +114,12 @@ def fuzz_wire(wire, rng):
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
         if which == "steps":
-            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[1])
+            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[0])
             if c in (3, 4):
-                put(w["steps"], (c, i), rng.randrange(2))
+                put(w["steps"], (i, c), rng.randrange(2))
             else:
-                old = cur(w["steps"], (c, i))
-                put(w["steps"], (c, i), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
+                old = cur(w["steps"], (i, c))
+                put(w["steps"], (i, c), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
         elif which == "rw" and w["rw"].shape[0]:
             i, c = rng.randrange(w["rw"].shape[0]), rng.randrange(14)
             old = cur(w["rw"], (i, c))

@@ -23,7 +23,7 @@ def load_cases(fn):
 
 
 def to_witness(w):
-    return eo.EvmWitness(wire.colmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
+    return eo.EvmWitness(wire.rowmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"])
 
@@ -32,16 +32,16 @@ def oracle_status(w, opts=(0, 0)):
     return eo.verify_steps(to_witness(w), bool(opts[0]), bool(opts[1]))
 
 
-def hostsim_status(lib, w, opts=(0, 0)):
+def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
     a = {k: np.ascontiguousarray(w[k]) for k in FIELDS}
-    n = a["steps"].shape[1]
+    n = a["steps"].shape[0]
     st = np.zeros(max(n - 1, 1), dtype=np.uint32)
     vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
     u64 = ctypes.c_uint64
     lib.sim_evm_verify(vp(a["steps"]), u64(n), vp(a["rw"]), vp(a["rw_flags"]), u64(a["rw"].shape[0]),
                        vp(a["bytecode"]), u64(a["bytecode"].shape[0]), vp(a["tx"]), vp(a["tx_flags"]),
                        u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
-                       ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1)), vp(st))
+                       ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1) | (4 if generic_index else 0)), vp(st))
     return st[: n - 1].tolist()
 
 
@@ -59,12 +59,12 @@ def fuzz_wire(w, rng):
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
         if which == "steps":
-            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[1])
+            c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[0])
             if c in (3, 4):
-                put(w["steps"], (c, i), rng.randrange(2))
+                put(w["steps"], (i, c), rng.randrange(2))
             else:
-                old = cur(w["steps"], (c, i))
-                put(w["steps"], (c, i), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
+                old = cur(w["steps"], (i, c))
+                put(w["steps"], (i, c), rng.choice([old + 1, old - 1, 0, rng.randrange(P), old ^ 1, 2**64, 2**128 + old]))
         elif which == "rw" and w["rw"].shape[0]:
             i, c = rng.randrange(w["rw"].shape[0]), rng.randrange(14)
             old = cur(w["rw"], (i, c))

@@ -13,8 +13,8 @@ from zkevm_specs_amd.synth_evm import synth_evm_trace
 pytestmark = pytest.mark.gpu
 
 
-def _run(w, opts=(0, 0), state_sort=True):
-    with engine.open_evm(w, bool(opts[0]), bool(opts[1]), state_sort=state_sort) as s:
+def _run(w, opts=(0, 0), state_sort=True, generic_index=False):
+    with engine.open_evm(w, bool(opts[0]), bool(opts[1]), state_sort=state_sort, generic_index=generic_index) as s:
         res = s.run()
         return res, s.read_status().tolist()
 
@@ -38,6 +38,8 @@ def test_golden_cases_match_reference_and_oracle(golden_dir):
             exp = oracle_status(w, opts)
             assert status == exp, (os.path.basename(fn), name)
             _check_tally(res, exp)
+            if n % 7 == 0:  # the generic open-addressing index must give the same answers
+                assert _run(w, opts, generic_index=True)[1] == exp, (os.path.basename(fn), name)
             for c, rk in zip(status, ref_kind.tolist()):
                 if codes.kind_of(c) != codes.UNSUPPORTED:
                     assert codes.kind_of(c) == rk, (os.path.basename(fn), name)
@@ -58,17 +60,17 @@ def test_fuzzed_cases_match_oracle(golden_dir):
                 _check_tally(res, exp)
 
 
-@pytest.mark.parametrize("state_sort", [True, False])
-def test_synthetic_trace_matches_oracle(state_sort):
+@pytest.mark.parametrize("state_sort,generic_index", [(True, False), (False, False), (True, True)])
+def test_synthetic_trace_matches_oracle(state_sort, generic_index):
     """2^13-step mixed-opcode trace, valid and with tampered cells, vs the oracle on every pair."""
     w = synth_evm_trace(1 << 13, seed=21)
     w = {k: v for k, v in w.items() if k != "meta"}
-    res, status = _run(w, state_sort=state_sort)
+    res, status = _run(w, state_sort=state_sort, generic_index=generic_index)
     assert res.ok and not any(status)
     rng = random.Random(5)
     for _ in range(40):
         w = fuzz_wire(w, rng)
-    res, status = _run(w, state_sort=state_sort)
+    res, status = _run(w, state_sort=state_sort, generic_index=generic_index)
     exp = oracle_status(w)
     assert status == exp
     _check_tally(res, exp)
@@ -101,7 +103,7 @@ def test_full_size_trace_properties():
         assert eo.verify_step(W, j) == st1[j]
     # every tampered row belongs to a step whose status we can predict with the oracle
     rwc = [int(w["rw"][r, 0, 0]) for r in rows]
-    step_rwc = w["steps"][1, :, 0].astype(np.int64)
+    step_rwc = w["steps"][:, 1, 0].astype(np.int64)
     for c in rwc:
         j = int(np.searchsorted(step_rwc, c, side="right") - 1)
         if j < n - 1:

@@ -32,7 +32,9 @@ def test_oracle_matches_reference_outcomes(golden_dir):
 def test_kernel_logic_matches_oracle_on_goldens(golden_dir, hostsim):
     for fn in golden_files(golden_dir):
         for name, w, opts, _ in load_cases(fn):
-            assert hostsim_status(hostsim, w, opts) == oracle_status(w, opts), (os.path.basename(fn), name)
+            exp = oracle_status(w, opts)
+            assert hostsim_status(hostsim, w, opts) == exp, (os.path.basename(fn), name)
+            assert hostsim_status(hostsim, w, opts, generic_index=True) == exp, (os.path.basename(fn), name)
 
 
 def test_kernel_logic_matches_oracle_under_fuzz(golden_dir, hostsim):
@@ -45,6 +47,7 @@ def test_kernel_logic_matches_oracle_under_fuzz(golden_dir, hostsim):
                 fw = fuzz_wire(w, rng)
                 exp = oracle_status(fw, opts)
                 assert hostsim_status(hostsim, fw, opts) == exp, (os.path.basename(fn), name)
+                assert hostsim_status(hostsim, fw, opts, generic_index=True) == exp, (os.path.basename(fn), name)
                 n += len(exp)
                 n_fail += sum(1 for e in exp if e)
     assert n > 2000 and n_fail > 800
@@ -56,3 +59,4 @@ def test_synthetic_trace_is_valid(n, seed, hostsim):
     exp = oracle_status(w)
     assert not any(exp)
     assert hostsim_status(hostsim, w) == exp
+    assert hostsim_status(hostsim, w, generic_index=True) == exp

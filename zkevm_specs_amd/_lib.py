@@ -40,6 +40,7 @@ class ZkEvmTables(ctypes.Structure):
 
 
 OPT_NO_STATE_SORT = 2
+OPT_GENERIC_INDEX = 4
 
 
 class EngineError(RuntimeError):

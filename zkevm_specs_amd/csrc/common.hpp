@@ -67,6 +67,34 @@ ZK_HD Fr zk_table_cell(const ZkTable& t, u32 row, u32 c) {
     return fr_load(t.cells + ((u64)row * t.ncells + c) * 4);
 }
 
+// Direct-index metadata built when a session is opened (the analogue of the reference building
+// its `Tables` sets, evm_circuit/table.py:592-625, before verify_steps runs):
+//  * RW table: when the rows are sorted with consecutive rw_counters (rw[i].rw_counter == base + i,
+//    what RWDictionary produces, evm_circuit/typing.py:813-845) a lookup by rw_counter is the row
+//    `rw_counter - base`; otherwise the generic open-addressing index is used.
+struct ZkRwMeta {
+    u32 dense;
+    u32 pad;
+    u64 base;
+};
+//  * Bytecode table: one directory entry per distinct code hash whose rows are "regular" (one
+//    Header row + Byte rows with indices 0..n-1, contiguous, no duplicates): a lookup by
+//    (hash, tag, index) is then header_row / byte_base + index.
+struct ZkCodeEntry {
+    u64 hash[8];  // lo cell (4 x u64) then hi cell
+    u32 header_row;
+    u32 byte_base;
+    u32 n_bytes;
+    u32 regular;
+};
+struct ZkCodeDir {
+    const ZkCodeEntry* entries;
+    const u32* slots;  // open addressing over entries, keyed on the hash cells
+    u32 mask;
+    u32 n;
+};
+ZK_HD u64 zk_code_hash_key(const Fr& lo, const Fr& hi) { return zk_hash_cell(zk_hash_cell(0xc0de5u, lo), hi); }
+
 // Column-major witness: cell c of row i at cells[(c * n + i) * 4].
 struct ZkCols {
     const u64* cells;

@@ -5,7 +5,9 @@
 // evm_circuit/execution/*.py; lookup semantics evm_circuit/table.py:864-884.
 //
 // Wire layouts (all cells canonical 4xu64):
-//   steps   column-major [13][n_steps]: execution_state, rw_counter, call_id, is_root, is_create,
+//   steps   ROW-major [n_steps][13] (lanes evaluate steps in state-sorted order, so a step's 13
+//           cells are kept contiguous - 416 B, 4 cache lines - instead of 13 strided columns):
+//           execution_state, rw_counter, call_id, is_root, is_create,
 //           code_hash lo,hi, program_counter, stack_pointer, gas_left, memory_word_size,
 //           reversible_write_counter, log_id                      (evm_circuit/step.py:16-75)
 //   rw      row-major [n][14]: rw_counter, rw, key0(Target), id, address, field_tag, storage_key lo,hi,
@@ -28,8 +30,11 @@ enum { B_HASH_LO = 0, B_HASH_HI, B_TAG, B_INDEX, B_IS_CODE, B_VALUE, BYTECODE_NC
 enum { TX_NCELLS = 5, BLOCK_NCELLS = 4 };
 
 struct EvmArgs {
-    ZkCols steps;
+    const u64* steps;  // [n_steps][13][4]
+    u64 n_steps;
     ZkTable rw, bytecode, tx, block;
+    const ZkRwMeta* rw_meta;  // nullptr = generic index only
+    ZkCodeDir codes;          // n == 0 = generic index only
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
     u32 n_pairs;      // n_steps - 1
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
@@ -50,6 +55,7 @@ struct Ins {
     u32 seq;   // checkpoint counter
     u32 rw_off, pc_off;
     int sp_off;
+    Fr rwc, call_id, sp, pc;  // curr step cells every lookup needs (loaded once)
 };
 
 // ---- checkpoints --------------------------------------------------------------------------
@@ -63,8 +69,9 @@ ZK_HD void ev_require(Ins& I, bool cond, u32 kind = ZK_ASSERT) {
 #define EV_TRY(stmt) do { stmt; if (I.err) return; } while (0)
 #define EV_TRYV(stmt, ret) do { stmt; if (I.err) return ret; } while (0)
 
-ZK_HD Fr ev_curr(const Ins& I, int c) { return zk_col(I.a->steps, c, I.idx); }
-ZK_HD Fr ev_next(const Ins& I, int c) { return zk_col(I.a->steps, c, I.idx + 1); }
+ZK_HD Fr ev_step_cell(const EvmArgs& a, u64 step, int c) { return fr_load(a.steps + (step * STEP_NCELLS + c) * 4); }
+ZK_HD Fr ev_curr(const Ins& I, int c) { return ev_step_cell(*I.a, I.idx, c); }
+ZK_HD Fr ev_next(const Ins& I, int c) { return ev_step_cell(*I.a, I.idx + 1, c); }
 ZK_HD Fr fr_u(u64 x) { return fr_from_u64(x); }
 ZK_HD Word word_of(const Fr& lo, const Fr& hi) {
     Word w;
@@ -174,10 +181,9 @@ ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
 }
 
 // Generic "exactly one distinct matching row" lookup (table.py:864-884) over the open-addressing
-// index: `q` holds ncells query cells, bit c of `mask` says cell c is part of the query.
-template <int NCELLS>
-ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32 mask) {
-    I.seq++;
+// index: `q` holds the query cells, bit c of `mask` says cell c is part of the query.  Out of
+// line; returns row | (kind << 32) with kind 0 / ZK_LOOKUP_UNSAT / ZK_LOOKUP_AMBIGUOUS.
+ZK_NOINLINE u64 table_probe_generic(ZkTable t, u64 h, const Fr* q, u32 mask) {
     u32 found = ZK_EMPTY_SLOT;
     bool ambiguous = false;
     if (t.n != 0) {
@@ -186,7 +192,7 @@ ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u
             const u32 r = t.slots[slot];
             if (r == ZK_EMPTY_SLOT) break;
             bool m = true;
-            for (int c = 0; c < NCELLS; c++)
+            for (u32 c = 0; c < t.ncells; c++)
                 if ((mask >> c) & 1u) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
             if (m) {
                 if (found == ZK_EMPTY_SLOT) found = r;
@@ -195,12 +201,18 @@ ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u
             slot = (slot + 1) & t.mask;
         }
     }
-    if (found == ZK_EMPTY_SLOT) {
-        ev_fail(I, ZK_LOOKUP_UNSAT);
-        return 0;
-    }
-    if (ambiguous) ev_fail(I, ZK_LOOKUP_AMBIGUOUS);
-    return found;
+    if (found == ZK_EMPTY_SLOT) return (u64)ZK_LOOKUP_UNSAT << 32;
+    return (u64)found | (ambiguous ? ((u64)ZK_LOOKUP_AMBIGUOUS << 32) : 0ull);
+}
+template <int NCELLS>
+ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32 mask) {
+    I.seq++;
+    Fr tmp[NCELLS];  // private copy: only this cold path's array escapes to the out-of-line probe
+    for (int c = 0; c < NCELLS; c++) tmp[c] = ((mask >> c) & 1u) ? q[c] : fr_zero();
+    const u64 res = table_probe_generic(t, h, tmp, mask);
+    const u32 kind = (u32)(res >> 32);
+    if (kind) ev_fail(I, kind);
+    return kind == ZK_LOOKUP_UNSAT ? 0u : (u32)res;
 }
 
 struct RwQ {
@@ -225,8 +237,23 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
     if (rw_counter) {
         Q.q[R_RWC] = *rw_counter;
     } else {
-        Q.q[R_RWC] = fr_add_u64(ev_curr(I, S_RWC), I.rw_off);
+        Q.q[R_RWC] = fr_add_u64(I.rwc, I.rw_off);
         I.rw_off++;
+    }
+    const ZkRwMeta* m = I.a->rw_meta;
+    if (m && m->dense) {
+        // direct index: the only row with this rw_counter is row (rw_counter - base)
+        I.seq++;
+        const Fr& rwc = Q.q[R_RWC];
+        const u64 off = fr_lo64(rwc) - m->base;
+        bool ok = fr_fits64(rwc) && fr_lo64(rwc) >= m->base && off < (u64)I.a->rw.n;
+        const u32 r = ok ? (u32)off : 0u;  // row 0 always exists (tables keep one zero row when empty)
+        // branch-free compare: the row loads do not depend on earlier lookups' outcomes, so the
+        // loads of consecutive lookups (MLOAD: 32 rows, PUSH32: 33 rows) overlap in flight
+        for (int c = 1; c < RW_NCELLS; c++)
+            if ((Q.mask >> c) & 1u) ok = ok & fr_eq(zk_table_cell(I.a->rw, r, c), Q.q[c]);
+        if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
+        return r;
     }
     return table_lookup<RW_NCELLS>(I, I.a->rw, rw_key_hash_cell(Q.q[R_RWC]), Q.q, Q.mask);
 }
@@ -255,16 +282,43 @@ ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& inde
     q[B_IS_CODE] = fr_u(is_code > 0 ? 1 : 0);
     q[B_VALUE] = fr_zero();
     u32 mask = 0xfu | (is_code >= 0 ? (1u << B_IS_CODE) : 0u);
+    const ZkCodeDir& dir = I.a->codes;
+    if (dir.n != 0) {
+        // directory probe on the code hash, then a direct row index for regular codes
+        u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
+        const ZkCodeEntry* e = nullptr;
+        for (u32 probes = 0; probes <= dir.mask; probes++) {
+            const u32 k = dir.slots[slot];
+            if (k == ZK_EMPTY_SLOT) break;
+            const ZkCodeEntry* c = dir.entries + k;
+            if (fr_eq(fr_load(c->hash), code_hash.lo) && fr_eq(fr_load(c->hash + 4), code_hash.hi)) { e = c; break; }
+            slot = (slot + 1) & dir.mask;
+        }
+        if (e == nullptr) {  // no row carries this hash
+            I.seq++;
+            ev_fail(I, ZK_LOOKUP_UNSAT);
+            return 0;
+        }
+        if (e->regular) {
+            I.seq++;
+            bool ok;
+            u32 r = 0;
+            if (tag == 1) { ok = fr_is_zero(index); r = e->header_row; }
+            else { ok = tag == 2 && fr_fits64(index) && fr_lo64(index) < (u64)e->n_bytes; r = ok ? e->byte_base + (u32)fr_lo64(index) : 0u; }
+            if (is_code >= 0) ok = ok & fr_eq(zk_table_cell(I.a->bytecode, r, B_IS_CODE), q[B_IS_CODE]);
+            if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
+            return r;
+        }
+    }
     return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
 }
 ZK_HD Word curr_code_hash(const Ins& I) { return word_of(ev_curr(I, S_CH_LO), ev_curr(I, S_CH_HI)); }
 ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instruction.py:789-790
     u32 r = bytecode_lookup(I, curr_code_hash(I), 2, index, is_code ? 1 : 0);
-    if (I.err) return fr_zero();
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
 }
 ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
-    Fr index = fr_add_u64(ev_curr(I, S_PC), I.pc_off);
+    Fr index = fr_add_u64(I.pc, I.pc_off);
     I.pc_off++;
     return opcode_lookup_at(I, index, is_code);
 }
@@ -353,8 +407,8 @@ ZK_HD void fixed_lookup(Ins& I, u32 tag, const Fr& v0, const Fr& v1, const Fr& v
 ZK_HD Word stack_lookup(Ins& I, u32 rw, int off) {
     RwQ Q;
     rwq_init(Q, rw, TG_Stack);
-    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
-    Fr sp = ev_curr(I, S_SP);
+    rwq_set(Q, R_ID, I.call_id);
+    const Fr& sp = I.sp;
     rwq_set(Q, R_ADDR, off >= 0 ? fr_add_u64(sp, (u64)off) : fr_sub_u64(sp, (u64)(-off)));
     u32 r = rw_lookup(I, Q);
     if (I.err) return word_zero();
@@ -372,16 +426,15 @@ ZK_HD Word stack_push(Ins& I) {
 ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr) {
     RwQ Q;
     rwq_init(Q, rw, TG_Memory);
-    rwq_set(Q, R_ID, ev_curr(I, S_CALL_ID));
+    rwq_set(Q, R_ID, I.call_id);
     rwq_set(Q, R_ADDR, addr);
     u32 r = rw_lookup(I, Q);
-    if (I.err) return fr_zero();
     return value_of(I, rw_value(I, r));
 }
 ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
     RwQ Q;
     rwq_init(Q, rw, TG_CallContext);
-    rwq_set(Q, R_ID, call_id ? *call_id : ev_curr(I, S_CALL_ID));
+    rwq_set(Q, R_ID, call_id ? *call_id : I.call_id);
     rwq_set(Q, R_ADDR, fr_u(field_tag));
     u32 r = rw_lookup(I, Q);
     WordOrValue v;
@@ -548,30 +601,54 @@ ZK_HD void transition(Ins& I, int cell, const Trans& t) {
     Fr expect = t.kind == 0 ? c : (t.kind == 1 ? fr_add(c, t.value) : t.value);
     ev_require(I, fr_eq(n, expect));
 }
-ZK_HD void same_context(Ins& I, const Fr& opcode, const Trans& rw_counter, const Trans& program_counter,
-                        const Trans& stack_pointer, const Trans& memory_word_size, const Trans& rev_wc,
-                        const Fr& dynamic_gas_cost) {
+// The step-state transition every same-context gadget ends with (instruction.py:365-394) is
+// evaluated ONCE after the gadget dispatch: gadgets only record its parameters here.
+struct Tail {
+    Fr opcode, pc_val, mws_val, dyn_gas;
+    int rw_delta, sp_delta, rev_delta;
+    u32 pc_kind, mws_kind;  // Trans kinds: 0 same, 1 delta, 2 to
+    bool enabled;
+};
+ZK_HD void set_tail(Tail& T, const Fr& opcode, int rw_delta, const Trans& pc, int sp_delta, const Trans& mws,
+                    int rev_delta, const Fr& dyn_gas) {
+    T.opcode = opcode;
+    T.rw_delta = rw_delta;
+    T.pc_kind = pc.kind;
+    T.pc_val = pc.value;
+    T.sp_delta = sp_delta;
+    T.mws_kind = mws.kind;
+    T.mws_val = mws.value;
+    T.rev_delta = rev_delta;
+    T.dyn_gas = dyn_gas;
+    T.enabled = true;
+}
+ZK_HD void set_tail3(Tail& T, const Fr& opcode, int rwc, int pc, int sp) {
+    set_tail(T, opcode, rwc, t_delta_i(pc), sp, t_same(), 0, fr_zero());
+}
+ZK_HD Trans t_int(int d) { return d == 0 ? t_same() : t_delta_i(d); }
+ZK_HD void same_context(Ins& I, const Tail& T) {
+    const Fr& opcode = T.opcode;
     fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero());
     static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
     static const uint16_t cgas[256] = ZK_OPCODE_CONST_GAS_INIT;
     const bool op_ok = fr_le_u64(opcode, 255) && valid[opcode.v[0] & 0xff];
     ev_require(I, op_ok, ZK_VALUE_ERROR);  // Opcode(opcode.n)
-    Fr gas_cost = fr_add(fr_u(op_ok ? cgas[opcode.v[0] & 0xff] : 0), dynamic_gas_cost);
+    Fr gas_cost = fr_add(fr_u(op_ok ? cgas[opcode.v[0] & 0xff] : 0), T.dyn_gas);
     range_check(I, fr_sub(ev_curr(I, S_GAS), gas_cost), 8);
-    transition(I, S_RWC, rw_counter);
-    transition(I, S_PC, program_counter);
-    transition(I, S_SP, stack_pointer);
+    Trans pc, mws;
+    pc.kind = T.pc_kind; pc.value = T.pc_val;
+    mws.kind = T.mws_kind; mws.value = T.mws_val;
+    transition(I, S_RWC, t_delta_i(T.rw_delta));  // Transition.delta(0) == same
+    transition(I, S_PC, pc);
+    transition(I, S_SP, t_int(T.sp_delta));
     transition(I, S_GAS, t_delta(fr_neg(gas_cost)));
-    transition(I, S_MWS, memory_word_size);
-    transition(I, S_REV, rev_wc);
+    transition(I, S_MWS, mws);
+    transition(I, S_REV, t_int(T.rev_delta));
     transition(I, S_LOG, t_same());
     transition(I, S_CALL_ID, t_same());
     transition(I, S_IS_ROOT, t_same());
     transition(I, S_IS_CREATE, t_same());
     ev_require(I, fr_eq(ev_next(I, S_CH_LO), ev_curr(I, S_CH_LO)) && fr_eq(ev_next(I, S_CH_HI), ev_curr(I, S_CH_HI)));
-}
-ZK_HD void same_context3(Ins& I, const Fr& opcode, long long rwc, long long pc, long long sp) {
-    same_context(I, opcode, t_delta_i(rwc), t_delta_i(pc), sp == 0 ? t_same() : t_delta_i(sp), t_same(), t_same(), fr_zero());
 }
 
 // constant_divmod (instruction.py:440-445) with a small constant denominator (power of two here)
@@ -602,7 +679,7 @@ ZK_HD void memory_expansion(Ins& I, const Fr& offset, const Fr& length, Fr& next
 }
 
 // ---- gadgets (evm_circuit/execution/*.py) --------------------------------------------------------
-ZK_HD void g_add_sub(Ins& I) {  // add_sub.py
+ZK_HD void g_add_sub(Ins& I, Tail& T) {  // add_sub.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     const bool is_sub = fr_eq_u64(opcode, OP_SUB);
     Word a, b, c;
@@ -614,10 +691,10 @@ ZK_HD void g_add_sub(Ins& I) {  // add_sub.py
     Word res = add_words2(I, x, b, carry);
     Word y = ev_select_b(I, is_sub) ? a : c;
     constrain_equal_word(I, res, y);
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_mul_div_mod(Ins& I) {  // mul_div_mod.py
+ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     // is_mul/is_div/is_mod are field expressions of the opcode (:14-16)
     Fr op_m2 = fr_sub_u64(opcode, 2), op_m4 = fr_sub_u64(opcode, 4);
@@ -676,10 +753,10 @@ ZK_HD void g_mul_div_mod(Ins& I) {  // mul_div_mod.py
     Fr one_m_mul = fr_sub(fr_u(1), is_mul);
     constrain_zero(I, fr_mul(fr_mul(one_m_mul, nz), fr_u(1 - lt)));
     constrain_zero(I, fr_mul(one_m_mul, overflow));
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_cmp(Ins& I) {  // comparator.py
+ZK_HD void g_cmp(Ins& I, Tail& T) {  // comparator.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     const bool is_eq = fr_eq_u64(opcode, OP_EQ), is_gt = fr_eq_u64(opcode, OP_GT);
     Word a, b, c;
@@ -693,7 +770,7 @@ ZK_HD void g_cmp(Ins& I) {  // comparator.py
     u32 result = is_eq ? eq : lt;
     Word rw = word_checked(I, fr_u(result), fr_zero());
     constrain_equal_word(I, rw, c);
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
 // slt_sgt.py:31-36 / addmod.py:7-19: lo compare, hi compare, inner select, outer select
@@ -705,7 +782,7 @@ ZK_HD u32 lt_u256_sel(Ins& I, const Word& a, const Word& b) {
     return ev_select_b(I, lt_hi) ? 1u : inner;
 }
 
-ZK_HD void g_scmp(Ins& I) {  // slt_sgt.py
+ZK_HD void g_scmp(Ins& I, Tail& T) {  // slt_sgt.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     const bool is_sgt = fr_eq_u64(opcode, OP_SGT);
     Word a, b, c;
@@ -720,19 +797,19 @@ ZK_HD void g_scmp(Ins& I) {  // slt_sgt.py
     if (am >= 128 && bm < 128) constrain_equal(I, cc, fr_u(1));
     else if (bm >= 128 && am < 128) constrain_equal(I, cc, fr_zero());
     else constrain_equal(I, cc, fr_u(a_lt_b));
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_iszero(Ins& I) {  // iszero.py
+ZK_HD void g_iszero(Ins& I, Tail& T) {  // iszero.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word value; EV_TRY(value = stack_pop(I));
     Word z = word_checked(I, fr_u(is_zero_word(value)), fr_zero());
     Word push; EV_TRY(push = stack_push(I));
     constrain_equal_word(I, z, push);
-    same_context3(I, opcode, 2, 1, 0);
+    set_tail3(T, opcode, 2, 1, 0);
 }
 
-ZK_HD void g_not(Ins& I) {  // not_.py
+ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word a; EV_TRY(a = stack_pop(I));
     U256 a8; EV_TRY(a8 = to_u256(I, a));
@@ -740,10 +817,10 @@ ZK_HD void g_not(Ins& I) {  // not_.py
     U256 b8; EV_TRY(b8 = to_u256(I, b));
     for (int k = 0; k < 32; k++) fixed_lookup(I, FX_BitwiseXor, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(255));
     if (I.err) return;
-    same_context3(I, opcode, 2, 1, 0);
+    set_tail3(T, opcode, 2, 1, 0);
 }
 
-ZK_HD void g_bitwise(Ins& I) {  // bitwise.py
+ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word a, b, c;
     EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
@@ -762,10 +839,10 @@ ZK_HD void g_bitwise(Ins& I) {  // bitwise.py
     const u32 tag = tagf.v[0];
     for (int k = 0; k < 32; k++) fixed_lookup(I, tag, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(fr_byte(c8, k)));
     if (I.err) return;
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_byte(Ins& I) {  // byte.py
+ZK_HD void g_byte(Ins& I, Tail& T) {  // byte.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word a, b, c;
     EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
@@ -778,10 +855,10 @@ ZK_HD void g_byte(Ins& I) {  // byte.py
     for (int k = 0; k < 32; k++) selected += (i0 == (u32)(31 - k) && msb_zero) ? fr_byte(value, k) : 0u;
     Word sw = word_checked(I, fr_u(selected), fr_zero());
     constrain_equal_word(I, sw, c);
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_signextend(Ins& I) {  // signextend.py (is_equal results are discarded there)
+ZK_HD void g_signextend(Ins& I, Tail& T) {  // signextend.py (is_equal results are discarded there)
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word index, value, result;
     EV_TRY(index = stack_pop(I)); EV_TRY(value = stack_pop(I)); EV_TRY(result = stack_push(I));
@@ -794,14 +871,14 @@ ZK_HD void g_signextend(Ins& I) {  // signextend.py (is_equal results are discar
     u32 selected = 0;
     for (int k = 0; k < 31; k++) selected += (i0 == (u32)k && msb_zero) ? fr_byte(vb, k) : 0u;
     fixed_lookup(I, FX_SignByte, fr_u(selected), fr_u(sign_byte), fr_zero()); if (I.err) return;
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
-ZK_HD void g_push(Ins& I) {  // push.py
+ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Fr num_pushed = fr_sub_u64(opcode, OP_PUSH0);
     Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
-    Fr pc = ev_curr(I, S_PC);
+    const Fr& pc = I.pc;
     Fr left = fr_sub_u64(fr_sub(code_length, pc), 1);
     u32 oob, eq; ev_compare(I, left, num_pushed, 8, oob, eq); if (I.err) return;
     Fr num_padding = oob ? fr_sub(num_pushed, left) : fr_zero();
@@ -811,22 +888,22 @@ ZK_HD void g_push(Ins& I) {  // push.py
         const bool pushed = fr_lt(fr_u((u64)k), num_pushed), padding = fr_lt(fr_u((u64)k), num_padding);
         if (pushed && !padding) {
             Fr index = fr_sub_u64(fr_add(pc, num_pushed), (u64)k);
-            Fr byte; EV_TRY(byte = opcode_lookup_at(I, index, false));
+            Fr byte = opcode_lookup_at(I, index, false);
             constrain_equal(I, fr_u(fr_byte(vb, k)), byte);
         } else {
             constrain_zero(I, fr_u(fr_byte(vb, k)));
         }
     }
-    same_context(I, opcode, t_delta_i(1), t_delta(fr_add_u64(num_pushed, 1)), t_delta_i(-1), t_same(), t_same(), fr_zero());
+    set_tail(T, opcode, 1, t_delta(fr_add_u64(num_pushed, 1)), -1, t_same(), 0, fr_zero());
 }
 
-ZK_HD void g_pop(Ins& I) {  // pop.py
+ZK_HD void g_pop(Ins& I, Tail& T) {  // pop.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     EV_TRY(stack_pop(I));
-    same_context3(I, opcode, 1, 1, 1);
+    set_tail3(T, opcode, 1, 1, 1);
 }
 
-ZK_HD void g_shl_shr(Ins& I) {  // shl_shr.py
+ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word pop1, pop2, push;
     EV_TRY(pop1 = stack_pop(I)); EV_TRY(pop2 = stack_pop(I)); EV_TRY(push = stack_push(I));
@@ -887,13 +964,13 @@ ZK_HD void g_shl_shr(Ins& I) {  // shl_shr.py
     constrain_zero(I, fr_mul(is_shr, overflow));
     if (dz == 0) fixed_lookup(I, FX_Pow2, fr_u(shf0), divisor.lo, divisor.hi);
     if (I.err) return;
-    same_context3(I, opcode, 3, 1, 1);
+    set_tail3(T, opcode, 3, 1, 1);
 }
 
 // 512-bit / 256-bit helpers for ADDMOD / MULMOD witness values
 ZK_HD void divmod_512(const U512& num, const U256& den, U512& q, U256& r) { u512_divmod(num, den, q, r, 512); }
 
-ZK_HD void g_addmod(Ins& I) {  // addmod.py
+ZK_HD void g_addmod(Ins& I, Tail& T) {  // addmod.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_ADDMOD));
     Word a, b, n, pushed_r;
@@ -942,18 +1019,18 @@ ZK_HD void g_addmod(Ins& I) {  // addmod.py
         }
         ev_require(I, fr_eq(pv, rhs));
     }
-    same_context3(I, opcode, 4, 1, 2);
+    set_tail3(T, opcode, 4, 1, 2);
 }
 
-ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r) {  // mulmod.py:6-29
-    U256 av = u256_from_lo_hi(a.lo, a.hi), nv = u256_from_lo_hi(n.lo, n.hi);
+ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r, const U256& a_div_n) {  // mulmod.py:6-29
+    U256 nv = u256_from_lo_hi(n.lo, n.hi);
     Word a_or_zero;
     U256 k = fr_zero();
     if (fr_is_zero(nv)) {
         a_or_zero = word_from_int(I, fr_zero());
     } else {
         a_or_zero = a;
-        U256 rem; u256_divmod(av, nv, k, rem);
+        k = a_div_n;  // a // n, computed once by the caller together with a % n
     }
     Word kw = word_from_int(I, k);
     EV_TRY(mul_add_words(I, kw, n, r, a_or_zero));
@@ -964,21 +1041,21 @@ ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r) {  //
     ev_require(I, (1 - (int)lt - (int)nz) == 0);
 }
 
-ZK_HD void g_mulmod(Ins& I) {  // mulmod.py
+ZK_HD void g_mulmod(Ins& I, Tail& T) {  // mulmod.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_MULMOD));
     Word a, b, n, r;
     EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(n = stack_pop(I)); EV_TRY(r = stack_push(I));
     U256 av, bv, nv, rv;
     EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
-    U256 a_red = fr_zero(), k = fr_zero();
+    U256 a_red = fr_zero(), k = fr_zero(), q0 = fr_zero();
     U512 prod;
     bool safety;
     if (fr_is_zero(nv)) {
         prod = u256_mul_full(a_red, bv);  // 0
         safety = fr_is_zero(rv);          // 0 == 0*0 + r
     } else {
-        U256 q0; u256_divmod(av, nv, q0, a_red);
+        u256_divmod(av, nv, q0, a_red);
         prod = u256_mul_full(a_red, bv);
         U512 q; U256 rem; divmod_512(prod, nv, q, rem);
         k = u512_lo(q);      // k < b < 2^256
@@ -988,7 +1065,7 @@ ZK_HD void g_mulmod(Ins& I) {  // mulmod.py
     Word d = word_from_int(I, u512_hi(prod));
     ev_require(I, safety);
     Word arw = word_from_int(I, a_red);
-    EV_TRY(mulmod_mod(I, a, n, arw));
+    EV_TRY(mulmod_mod(I, a, n, arw, q0));
     Word arw2 = word_from_int(I, a_red);
     Word zero = word_from_int(I, fr_zero());
     EV_TRY(mul_add_words_512(I, arw2, b, zero, d, e));
@@ -997,10 +1074,10 @@ ZK_HD void g_mulmod(Ins& I) {  // mulmod.py
     const u32 nz = is_zero_word(n);
     u32 lt, eq; compare_word(I, r, n, lt, eq);
     ev_require(I, (1 - (int)lt - (int)nz) == 0);
-    same_context3(I, opcode, 4, 1, 2);
+    set_tail3(T, opcode, 4, 1, 2);
 }
 
-ZK_HD void g_memory(Ins& I) {  // memory.py
+ZK_HD void g_memory(Ins& I, Tail& T) {  // memory.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     Word aw; EV_TRY(aw = stack_pop(I));
     Fr address; EV_TRY(address = word_to_fq(I, aw, 20));
@@ -1011,39 +1088,39 @@ ZK_HD void g_memory(Ins& I) {  // memory.py
     EV_TRY(to_u256(I, value));
     Fr next_size, gas;
     EV_TRY(memory_expansion(I, ev_curr(I, S_MWS), fr_add_u64(address, 1 + (is_not8 ? 31 : 0)), next_size, gas));
-    if (is_mstore8) EV_TRY(memory_lookup(I, 1, address));
+    if (is_mstore8) memory_lookup(I, 1, address);
     if (is_not8)
-        for (int k = 0; k < 32; k++) EV_TRY(memory_lookup(I, is_store ? 1 : 0, fr_add_u64(address, (u64)k)));
-    same_context(I, opcode, t_delta_i(34 - (is_mstore8 ? 31 : 0)), t_delta_i(1), t_delta_i(is_store ? 2 : 0),
-                 t_to(next_size), t_same(), gas);
+        for (int k = 0; k < 32; k++) memory_lookup(I, is_store ? 1 : 0, fr_add_u64(address, (u64)k));
+    if (I.err) return;
+    set_tail(T, opcode, 34 - (is_mstore8 ? 31 : 0), t_delta_i(1), is_store ? 2 : 0, t_to(next_size), 0, gas);
 }
 
-ZK_HD void ctx_push_word(Ins& I, const Fr& opcode, const Word& w) {
+ZK_HD void ctx_push_word(Ins& I, Tail& T, const Fr& opcode, const Word& w) {
     Word push; EV_TRY(push = stack_push(I));
     constrain_equal_word(I, w, push);
-    same_context3(I, opcode, 2, 1, -1);
+    set_tail3(T, opcode, 2, 1, -1);
 }
-ZK_HD void g_ctx_word(Ins& I, u32 expected_opcode, u32 field_tag) {  // caller.py / callvalue.py / address.py
+ZK_HD void g_ctx_word(Ins& I, Tail& T, u32 expected_opcode, u32 field_tag) {  // caller.py / callvalue.py / address.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(expected_opcode));
     WordOrValue v; EV_TRY(v = call_context_lookup_word(I, field_tag));
-    ctx_push_word(I, opcode, v.w);
+    ctx_push_word(I, T, opcode, v.w);
 }
-ZK_HD void g_ctx_value(Ins& I, u32 expected_opcode, u32 field_tag) {  // calldatasize.py / returndatasize.py
+ZK_HD void g_ctx_value(Ins& I, Tail& T, u32 expected_opcode, u32 field_tag) {  // calldatasize.py / returndatasize.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(expected_opcode));
     Fr v; EV_TRY(v = call_context_lookup(I, field_tag));
     Word w = word_checked(I, v, fr_zero());
-    ctx_push_word(I, opcode, w);
+    ctx_push_word(I, T, opcode, w);
 }
-ZK_HD void g_tx_word(Ins& I, u32 expected_opcode, u32 tx_field_tag) {  // origin.py / gasprice.py
+ZK_HD void g_tx_word(Ins& I, Tail& T, u32 expected_opcode, u32 tx_field_tag) {  // origin.py / gasprice.py
     Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(expected_opcode));
     WordOrValue v; EV_TRY(v = tx_lookup(I, tx_id, tx_field_tag));
-    ctx_push_word(I, opcode, v.w);
+    ctx_push_word(I, T, opcode, v.w);
 }
-ZK_HD void g_selfbalance(Ins& I) {  // selfbalance.py
+ZK_HD void g_selfbalance(Ins& I, Tail& T) {  // selfbalance.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_SELFBALANCE));
     WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
@@ -1056,9 +1133,9 @@ ZK_HD void g_selfbalance(Ins& I) {  // selfbalance.py
     Word bal = rw_word(I, r, R_VAL_LO);
     Word push; EV_TRY(push = stack_push(I));
     constrain_equal_word(I, push, bal);
-    same_context3(I, opcode, 3, 1, -1);
+    set_tail3(T, opcode, 3, 1, -1);
 }
-ZK_HD void g_blockctx(Ins& I) {  // block_ctx.py
+ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     u32 tag = 0;
     if (fr_eq_u64(opcode, OP_COINBASE)) tag = BLK_Coinbase;
@@ -1072,48 +1149,48 @@ ZK_HD void g_blockctx(Ins& I) {  // block_ctx.py
     WordOrValue v; EV_TRY(v = block_lookup(I, tag));
     Word push; EV_TRY(push = stack_push(I));
     constrain_equal_word(I, v.w, push);
-    same_context3(I, opcode, 1, 1, -1);
+    set_tail3(T, opcode, 1, 1, -1);
 }
-ZK_HD void g_push_lo(Ins& I, const Fr& opcode, const Fr& lo) {  // Word.from_lo(x) == stack_push()
+ZK_HD void g_push_lo(Ins& I, Tail& T, const Fr& opcode, const Fr& lo) {  // Word.from_lo(x) == stack_push()
     Word w = word_checked(I, lo, fr_zero());
     Word push; EV_TRY(push = stack_push(I));
     constrain_equal_word(I, w, push);
-    same_context3(I, opcode, 1, 1, -1);
+    set_tail3(T, opcode, 1, 1, -1);
 }
-ZK_HD void g_gas(Ins& I) {  // gas.py
+ZK_HD void g_gas(Ins& I, Tail& T) {  // gas.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_GAS));
-    g_push_lo(I, opcode, fr_sub_u64(ev_curr(I, S_GAS), 2));
+    g_push_lo(I, T, opcode, fr_sub_u64(ev_curr(I, S_GAS), 2));
 }
-ZK_HD void g_msize(Ins& I) {  // msize.py
+ZK_HD void g_msize(Ins& I, Tail& T) {  // msize.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
-    g_push_lo(I, opcode, fr_mulc(ev_curr(I, S_MWS), fr_to_mont(fr_u(32))));
+    g_push_lo(I, T, opcode, fr_mulc(ev_curr(I, S_MWS), fr_to_mont(fr_u(32))));
 }
-ZK_HD void g_codesize(Ins& I) {  // codesize.py
+ZK_HD void g_codesize(Ins& I, Tail& T) {  // codesize.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_CODESIZE));
     Fr size; EV_TRY(size = bytecode_length(I, curr_code_hash(I)));
-    g_push_lo(I, opcode, size);
+    g_push_lo(I, T, opcode, size);
 }
-ZK_HD void g_jump(Ins& I) {  // jump.py
+ZK_HD void g_jump(Ins& I, Tail& T) {  // jump.py
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_JUMP));
     Word dest; EV_TRY(dest = stack_pop(I));
     constrain_zero(I, dest.hi);
     Fr byte; EV_TRY(byte = opcode_lookup_at(I, dest.lo, true));
     constrain_equal(I, fr_u(OP_JUMPDEST), byte);
-    same_context(I, opcode, t_delta_i(1), t_to(dest.lo), t_delta_i(1), t_same(), t_same(), fr_zero());
+    set_tail(T, opcode, 1, t_to(dest.lo), 1, t_same(), 0, fr_zero());
 }
-ZK_HD void g_jumpi(Ins& I) {  // jumpi.py: `if is_zero_word(cond)` is always truthy (FQ has no __bool__)
+ZK_HD void g_jumpi(Ins& I, Tail& T) {  // jumpi.py: `if is_zero_word(cond)` is always truthy (FQ has no __bool__)
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_JUMPI));
     Word dest; EV_TRY(dest = stack_pop(I));
     constrain_zero(I, dest.hi);
     EV_TRY(stack_pop(I));
-    same_context3(I, opcode, 2, 1, 2);
+    set_tail3(T, opcode, 2, 1, 2);
 }
 
-ZK_HD void g_sload(Ins& I) {  // storage.py:15-47
+ZK_HD void g_sload(Ins& I, Tail& T) {  // storage.py:15-47
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_SLOAD));
     Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
@@ -1139,10 +1216,10 @@ ZK_HD void g_sload(Ins& I) {  // storage.py:15-47
     u32 wr; EV_TRY(wr = state_write(I, W, rv));
     Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
     bool warm = ev_select(I, is_warm); if (I.err) return;
-    same_context(I, opcode, t_delta_i(8), t_delta_i(1), t_delta_i(0), t_same(), t_delta_i(1), fr_u(warm ? 100 : 2100));
+    set_tail(T, opcode, 8, t_delta_i(1), 0, t_same(), 1, fr_u(warm ? 100 : 2100));
 }
 
-ZK_HD void g_sstore(Ins& I) {  // storage.py:50-153
+ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
     Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
     constrain_equal(I, opcode, fr_u(OP_SSTORE));
     Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
@@ -1193,8 +1270,7 @@ ZK_HD void g_sstore(Ins& I) {  // storage.py:50-153
     const u64 inner5 = ev_select_b(I, oz) ? SET : RESET;
     const u64 warm_case = ev_select_b(I, eq_prev + prev_ne_orig - eq_prev * prev_ne_orig) ? SLOAD : inner5;
     bool warm = ev_select(I, is_warm); if (I.err) return;
-    same_context(I, opcode, t_delta_i(10), t_delta_i(1), t_delta_i(2), t_same(), t_delta_i(3),
-                 fr_u(warm ? warm_case : warm_case + 2100));
+    set_tail(T, opcode, 10, t_delta_i(1), 2, t_same(), 3, fr_u(warm ? warm_case : warm_case + 2100));
 }
 
 // step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
@@ -1235,7 +1311,7 @@ ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
     transition(I, S_REV, t_to(fr_add(rwc, rev)));
 }
 
-ZK_HD void g_stop(Ins& I) {  // stop.py
+ZK_HD void g_stop(Ins& I, Tail& T) {  // stop.py
     Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
     u32 lt, eq; ev_compare(I, code_length, ev_curr(I, S_PC), 8, lt, eq); if (I.err) return;
     if (lt + eq == 0) {
@@ -1267,7 +1343,56 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
     return true;
 }
 
-// verify_step (main.py:47-63) for pair `idx`
+#define GROUP_OF_ES_ADD 0
+#define GROUP_OF_ES_ADDMOD 1
+#define GROUP_OF_ES_ADDRESS 0
+#define GROUP_OF_ES_BITWISE 0
+#define GROUP_OF_ES_BYTE 0
+#define GROUP_OF_ES_BlockCtx 0
+#define GROUP_OF_ES_CALLDATASIZE 0
+#define GROUP_OF_ES_CALLER 0
+#define GROUP_OF_ES_CALLVALUE 0
+#define GROUP_OF_ES_CMP 0
+#define GROUP_OF_ES_CODESIZE 0
+#define GROUP_OF_ES_GAS 0
+#define GROUP_OF_ES_GASPRICE 0
+#define GROUP_OF_ES_ISZERO 0
+#define GROUP_OF_ES_JUMP 0
+#define GROUP_OF_ES_JUMPI 0
+#define GROUP_OF_ES_MEMORY 2
+#define GROUP_OF_ES_MSIZE 0
+#define GROUP_OF_ES_MUL 1
+#define GROUP_OF_ES_MULMOD 1
+#define GROUP_OF_ES_NOT 0
+#define GROUP_OF_ES_ORIGIN 0
+#define GROUP_OF_ES_POP 0
+#define GROUP_OF_ES_PUSH 0
+#define GROUP_OF_ES_RETURNDATASIZE 0
+#define GROUP_OF_ES_SCMP 0
+#define GROUP_OF_ES_SELFBALANCE 0
+#define GROUP_OF_ES_SHL_SHR 1
+#define GROUP_OF_ES_SIGNEXTEND 0
+#define GROUP_OF_ES_SLOAD 2
+#define GROUP_OF_ES_SSTORE 2
+#define GROUP_OF_ES_STOP 2
+
+// Kernel specialisation groups: the step pairs are sorted by (group, state) and each group is
+// evaluated by its own kernel instantiation, which contains only that group's gadget bodies
+// (smaller instruction footprint, fewer live registers -> more resident wavefronts).
+enum { EVM_GROUP_LIGHT = 0, EVM_GROUP_MUL = 1, EVM_GROUP_MEM = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
+ZK_HD int evm_state_group(u32 state) {
+    switch (state) {
+    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
+    case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: return EVM_GROUP_MEM;
+    default: return EVM_GROUP_LIGHT;
+    }
+}
+// sort bin of a state: group-major, state-minor (128 bins per group)
+ZK_HD u32 evm_state_bin(u32 state) { return (u32)evm_state_group(state) * 128u + (state & 127u); }
+#define EVM_N_BINS (EVM_N_GROUPS * 128)
+
+// verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
+template <int G>
 ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     Ins I;
     I.a = &a;
@@ -1276,6 +1401,10 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     I.seq = 0;
     I.rw_off = I.pc_off = 0;
     I.sp_off = 0;
+    I.rwc = ev_curr(I, S_RWC);
+    I.call_id = ev_curr(I, S_CALL_ID);
+    I.sp = ev_curr(I, S_SP);
+    I.pc = ev_curr(I, S_PC);
     const bool is_first = (a.opts & 1u) && idx == 0;
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
     const Fr statef = ev_curr(I, S_STATE);
@@ -1293,40 +1422,47 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
         ev_fail(I, ZK_NOT_IMPLEMENTED);
         return I.err;
     }
+    Tail T;
+    T.enabled = false;
+    if (G != EVM_GROUP_ALL && evm_state_group(state) != G) {  // cannot happen with a correct lane mapping
+        ev_fail(I, ZK_UNSUPPORTED);
+        return I.err;
+    }
     switch (state) {
-    case ES_ADD: g_add_sub(I); break;
-    case ES_MUL: g_mul_div_mod(I); break;
-    case ES_CMP: g_cmp(I); break;
-    case ES_SCMP: g_scmp(I); break;
-    case ES_ISZERO: g_iszero(I); break;
-    case ES_NOT: g_not(I); break;
-    case ES_BITWISE: g_bitwise(I); break;
-    case ES_BYTE: g_byte(I); break;
-    case ES_SIGNEXTEND: g_signextend(I); break;
-    case ES_PUSH: g_push(I); break;
-    case ES_POP: g_pop(I); break;
-    case ES_SHL_SHR: g_shl_shr(I); break;
-    case ES_ADDMOD: g_addmod(I); break;
-    case ES_MULMOD: g_mulmod(I); break;
-    case ES_MEMORY: g_memory(I); break;
-    case ES_CALLER: g_ctx_word(I, OP_CALLER, CC_CallerAddress); break;
-    case ES_CALLVALUE: g_ctx_word(I, OP_CALLVALUE, CC_Value); break;
-    case ES_ADDRESS: g_ctx_word(I, OP_ADDRESS, CC_CalleeAddress); break;
-    case ES_CALLDATASIZE: g_ctx_value(I, OP_CALLDATASIZE, CC_CallDataLength); break;
-    case ES_RETURNDATASIZE: g_ctx_value(I, OP_RETURNDATASIZE, CC_LastCalleeReturnDataLength); break;
-    case ES_ORIGIN: g_tx_word(I, OP_ORIGIN, TXC_CallerAddress); break;
-    case ES_GASPRICE: g_tx_word(I, OP_GASPRICE, TXC_GasPrice); break;
-    case ES_SELFBALANCE: g_selfbalance(I); break;
-    case ES_BlockCtx: g_blockctx(I); break;
-    case ES_GAS: g_gas(I); break;
-    case ES_MSIZE: g_msize(I); break;
-    case ES_CODESIZE: g_codesize(I); break;
-    case ES_STOP: g_stop(I); break;
-    case ES_JUMP: g_jump(I); break;
-    case ES_JUMPI: g_jumpi(I); break;
-    case ES_SLOAD: g_sload(I); break;
-    case ES_SSTORE: g_sstore(I); break;
+    case ES_ADD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADD) { g_add_sub(I, T); } break;
+    case ES_MUL: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MUL) { g_mul_div_mod(I, T); } break;
+    case ES_CMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CMP) { g_cmp(I, T); } break;
+    case ES_SCMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SCMP) { g_scmp(I, T); } break;
+    case ES_ISZERO: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ISZERO) { g_iszero(I, T); } break;
+    case ES_NOT: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_NOT) { g_not(I, T); } break;
+    case ES_BITWISE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_BITWISE) { g_bitwise(I, T); } break;
+    case ES_BYTE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_BYTE) { g_byte(I, T); } break;
+    case ES_SIGNEXTEND: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SIGNEXTEND) { g_signextend(I, T); } break;
+    case ES_PUSH: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_PUSH) { g_push(I, T); } break;
+    case ES_POP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_POP) { g_pop(I, T); } break;
+    case ES_SHL_SHR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SHL_SHR) { g_shl_shr(I, T); } break;
+    case ES_ADDMOD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADDMOD) { g_addmod(I, T); } break;
+    case ES_MULMOD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MULMOD) { g_mulmod(I, T); } break;
+    case ES_MEMORY: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MEMORY) { g_memory(I, T); } break;
+    case ES_CALLER: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CALLER) { g_ctx_word(I, T, OP_CALLER, CC_CallerAddress); } break;
+    case ES_CALLVALUE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CALLVALUE) { g_ctx_word(I, T, OP_CALLVALUE, CC_Value); } break;
+    case ES_ADDRESS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADDRESS) { g_ctx_word(I, T, OP_ADDRESS, CC_CalleeAddress); } break;
+    case ES_CALLDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CALLDATASIZE) { g_ctx_value(I, T, OP_CALLDATASIZE, CC_CallDataLength); } break;
+    case ES_RETURNDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_RETURNDATASIZE) { g_ctx_value(I, T, OP_RETURNDATASIZE, CC_LastCalleeReturnDataLength); } break;
+    case ES_ORIGIN: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ORIGIN) { g_tx_word(I, T, OP_ORIGIN, TXC_CallerAddress); } break;
+    case ES_GASPRICE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_GASPRICE) { g_tx_word(I, T, OP_GASPRICE, TXC_GasPrice); } break;
+    case ES_SELFBALANCE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SELFBALANCE) { g_selfbalance(I, T); } break;
+    case ES_BlockCtx: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_BlockCtx) { g_blockctx(I, T); } break;
+    case ES_GAS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_GAS) { g_gas(I, T); } break;
+    case ES_MSIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MSIZE) { g_msize(I, T); } break;
+    case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
+    case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
+    case ES_JUMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMP) { g_jump(I, T); } break;
+    case ES_JUMPI: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMPI) { g_jumpi(I, T); } break;
+    case ES_SLOAD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SLOAD) { g_sload(I, T); } break;
+    case ES_SSTORE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SSTORE) { g_sstore(I, T); } break;
     default: ev_fail(I, ZK_UNSUPPORTED); break;
     }
+    if (I.err == 0u && T.enabled) same_context(I, T);
     return I.err;
 }

@@ -19,13 +19,18 @@
 
 #if defined(ZK_HOSTSIM)
 #define ZK_HD static inline
+#define ZK_NOINLINE static
 #define ZK_CONST static const
 struct uint4 {
     uint32_t x, y, z, w;
 };
 #else
 #include <hip/hip_runtime.h>
-#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_HD __device__ __forceinline__
+// Out-of-line device functions (arguments and results by value = in VGPRs): keeps the EVM kernel's
+// instruction footprint inside the instruction cache instead of inlining ~300-instruction bodies
+// at hundreds of call sites.
+#define ZK_NOINLINE __device__ __noinline__
 #define ZK_CONST __device__ static const
 #endif
 
@@ -164,7 +169,7 @@ ZK_HD Fr fr_add_u64(const Fr& a, u64 x) { return fr_add(a, fr_from_u64(x)); }
 ZK_HD Fr fr_sub_u64(const Fr& a, u64 x) { return fr_sub(a, fr_from_u64(x)); }
 
 // Montgomery product a*b*R^-1 mod p (CIOS on 8 x 32-bit limbs); inputs < p.
-ZK_HD Fr fr_mont(const Fr& a, const Fr& b) {
+ZK_NOINLINE Fr fr_mont(Fr a, Fr b) {
     const Fr p = fr_modulus();
     u32 t[10];
 #pragma unroll
@@ -280,30 +285,130 @@ ZK_HD U512 u512_from(const U256& lo, const U256& hi) {
 ZK_HD int u256_bit(const U256& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1; }
 ZK_HD int u512_bit(const U512& a, int i) { return (a.v[i >> 5] >> (i & 31)) & 1; }
 
-// Restoring shift-subtract division of a 512-bit numerator by a 256-bit divisor (d != 0).
-// q receives the low 512 bits of the quotient, r the remainder.  Used for the witness
-// values the reference computes with Python big-int // and % (e.g. mul_div_mod.py:23-41,
-// addmod.py:32-41, mulmod.py:41-50).  `nbits` = number of numerator bits to process.
-ZK_HD void u512_divmod(const U512& n, const U256& d, U512& q, U256& r, int nbits) {
+// Long division (Knuth, TAOCP vol.2 4.3.1 algorithm D) of an NL-limb numerator by a non-zero
+// 256-bit divisor on 32-bit limbs.  The divisor is normalised by a left shift of s = clz256(d)
+// bits so that it always occupies 8 limbs with the top bit set: every array index below is then a
+// compile-time constant after unrolling (no private-memory arrays on the GPU).  Used for the
+// witness values the reference computes with Python big-int // and % (mul_div_mod.py:23-41,
+// addmod.py:32-41, mulmod.py:41-50).
+struct DivRes {
+    U512 q;
+    U256 r;
+};
+ZK_HD u32 zk_clz32(u32 x) {
+#if defined(ZK_HOSTSIM)
+    return x ? (u32)__builtin_clz(x) : 32u;
+#else
+    return (u32)__clz((int)x);
+#endif
+}
+template <int NL>  // NL = numerator limbs (8 or 16)
+ZK_HD void zk_divmod_limbs(const u32* n, const U256& d, u32* q /*NL limbs*/, U256& rem) {
+    // s = leading zero bits of d
+    u32 s = 0;
+    bool seen = false;
 #pragma unroll
-    for (int i = 0; i < 16; i++) q.v[i] = 0;
-    r = fr_zero();
-    for (int i = nbits - 1; i >= 0; i--) {
-        // r = (r << 1) | bit
-        u32 top = r.v[7] >> 31;
-#pragma unroll
-        for (int k = 7; k > 0; k--) r.v[k] = (r.v[k] << 1) | (r.v[k - 1] >> 31);
-        r.v[0] = (r.v[0] << 1) | (u32)u512_bit(n, i);
-        U256 t;
-        u32 bw = u256_sub(t, r, d);
-        if (top || !bw) {
-            r = t;
-            q.v[i >> 5] |= 1u << (i & 31);
+    for (int k = 7; k >= 0; k--) {
+        if (!seen) {
+            if (d.v[k]) { s += zk_clz32(d.v[k]); seen = true; }
+            else s += 32;
         }
     }
+    const u32 bs = s & 31u, ws = s >> 5;
+    // v = d << s (8 limbs), u = n << s (NL + 8 limbs, plus a zero guard limb)
+    u32 v[8], u[NL + 9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = bs ? ((d.v[k] << bs) | (k ? (d.v[k - 1] >> (32 - bs)) : 0u)) : d.v[k];
+#pragma unroll
+    for (int k = 0; k < NL + 9; k++) {
+        const u32 lo = k < NL ? n[k] : 0u, prev = (k >= 1 && k - 1 < NL) ? n[k - 1] : 0u;
+        u[k] = bs ? ((lo << bs) | (prev >> (32 - bs))) : lo;
+    }
+#pragma unroll
+    for (int st = 2; st >= 0; st--) {  // word shift by ws in {0..7}: 4, 2, 1
+        const int w = 1 << st;
+        const bool on = (ws >> st) & 1u;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) v[k] = on ? (k >= w ? v[k - w] : 0u) : v[k];
+#pragma unroll
+        for (int k = NL + 8; k >= 0; k--) u[k] = on ? (k >= w ? u[k - w] : 0u) : u[k];
+    }
+    const u64 vtop = v[7], vsec = v[6];
+#pragma unroll
+    for (int j = NL - 1; j >= 0; j--) {
+        const u64 num = ((u64)u[j + 8] << 32) | u[j + 7];
+        u64 qhat = num / vtop, rhat = num - qhat * vtop;
+        // at most two corrections (Knuth D3)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (qhat >> 32 || (rhat >> 32 == 0 && qhat * vsec > ((rhat << 32) | u[j + 6]))) {
+                qhat--;
+                rhat += vtop;
+            }
+        }
+        // multiply and subtract: u[j..j+8] -= qhat * v
+        u64 borrow = 0, carry = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u64 p = (u64)(u32)qhat * v[k] + carry;
+            carry = p >> 32;
+            const u64 t = (u64)u[j + k] - (u32)p - borrow;
+            u[j + k] = (u32)t;
+            borrow = (t >> 32) & 1u;
+        }
+        const u64 t = (u64)u[j + 8] - carry - borrow;
+        u[j + 8] = (u32)t;
+        if ((t >> 32) & 1u) {  // qhat was one too large: add the divisor back (D6)
+            qhat--;
+            u64 c2 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                c2 += (u64)u[j + k] + v[k];
+                u[j + k] = (u32)c2;
+                c2 >>= 32;
+            }
+            u[j + 8] += (u32)c2;
+        }
+        q[j] = (u32)qhat;
+    }
+    // remainder = u[0..7] >> s  (word shift then bit shift)
+    u32 r8[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r8[k] = u[k];
+    r8[8] = 0;
+    // undo: the remainder of n<<s by d<<s is (n mod d) << s, still below d << s: it lives in the
+    // low 8 + ws limbs... after the word shift it occupies limbs ws..7, so shift back down.
+#pragma unroll
+    for (int st = 2; st >= 0; st--) {
+        const int w = 1 << st;
+        const bool on = (ws >> st) & 1u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r8[k] = on ? (k + w < 8 ? r8[k + w] : 0u) : r8[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) rem.v[k] = bs ? ((r8[k] >> bs) | (k + 1 < 8 ? (r8[k + 1] << (32 - bs)) : 0u)) : r8[k];
+}
+ZK_NOINLINE DivRes u512_divmod_v(U512 n, U256 d, int nbits) {
+    DivRes o;
+    (void)nbits;
+    zk_divmod_limbs<16>(n.v, d, o.q.v, o.r);
+    return o;
+}
+struct DivRes256 {
+    U256 q, r;
+};
+ZK_NOINLINE DivRes256 u256_divmod_v(U256 n, U256 d) {
+    DivRes256 o;
+    zk_divmod_limbs<8>(n.v, d, o.q.v, o.r);
+    return o;
+}
+ZK_HD void u512_divmod(const U512& n, const U256& d, U512& q, U256& r, int nbits) {
+    DivRes o = u512_divmod_v(n, d, nbits);
+    q = o.q;
+    r = o.r;
 }
 ZK_HD void u256_divmod(const U256& n, const U256& d, U256& q, U256& r) {
-    U512 nn = u512_from(n, fr_zero()), qq;
-    u512_divmod(nn, d, qq, r, 256);
-    q = u512_lo(qq);
+    DivRes256 o = u256_divmod_v(n, d);
+    q = o.q;
+    r = o.r;
 }

@@ -8,6 +8,7 @@
 #include "../../include/zkevm_hip.h"
 #include "state_circuit.hpp"
 #include "evm_circuit.hpp"
+#include "host_index.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -110,65 +111,89 @@ __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* statu
 }
 
 // ---------------------------------------------------------------------------------------
-// EVM circuit kernel: one lane per step pair (curr, next).  Lanes are assigned through a
-// state-sorted permutation so that a 64-lane wavefront runs ONE gadget body instead of
-// serialising the ~10 different execution states a window of consecutive steps contains.
+// EVM circuit kernels: one lane per step pair (curr, next).  Lanes are assigned through a
+// permutation sorted by (kernel group, execution state) so that a 64-lane wavefront runs ONE
+// gadget body instead of serialising the ~10 different execution states a window of consecutive
+// steps contains; each group has its own kernel instantiation (evm_circuit.hpp).
+// group_start[g] .. group_start[g+1] is the lane range of group g inside `perm`.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void evm_steps_kernel(EvmArgs a, u32* status, ZkTally* tally) {
+template <int G>
+__global__ __launch_bounds__(256, (G == EVM_GROUP_LIGHT ? 4 : (G == EVM_GROUP_MUL ? 2 : 1))) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     u64 idx = t;
-    if (t < a.n_pairs) {
-        idx = a.perm ? a.perm[t] : t;
-        code = evm_check_step(a, idx);
+    bool active;
+    if (G == EVM_GROUP_ALL) {
+        active = t < a.n_pairs;
+    } else {
+        const u32 lo = group_start[G], hi = group_start[G + 1];
+        active = t < (u64)(hi - lo);
+        if (active) idx = a.perm[lo + t];
+    }
+    if (active) {
+        code = evm_check_step<G>(a, idx);
         if (status) status[idx] = code;
     }
     tally_commit(tally, idx, code);
 }
 
-// Counting sort of the step pairs by execution state (stable): histogram, scan, scatter.
-__global__ void evm_state_hist_kernel(ZkCols steps, u32 n_pairs, u32* hist) {
-    __shared__ u32 local[128];
-    for (u32 k = threadIdx.x; k < 128; k += blockDim.x) local[k] = 0;
+// RW-table density check (see ZkRwMeta): meta->dense must be pre-set to 1.
+__global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.n) return;
+    const u64* p = t.cells + (u64)r * RW_NCELLS * 4;
+    const u64* p0 = t.cells;
+    const u64 base = p0[0];
+    const bool ok = (p0[1] | p0[2] | p0[3]) == 0 && (p[1] | p[2] | p[3]) == 0 && p[0] == base + r && base + r >= base;
+    if (r == 0) meta->base = base;
+    if (!ok) atomicAnd(&meta->dense, 0u);
+}
+
+// Counting sort of the step pairs by (group, state): histogram, scan, scatter.
+__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist) {
+    __shared__ u32 local[EVM_N_BINS];
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
     __syncthreads();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pairs) {
-        u32 st = (u32)steps.cells[((u64)S_STATE * steps.n + i) * 4] & 127u;
-        atomicAdd(&local[st], 1u);
+        u32 st = (u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4];
+        atomicAdd(&local[evm_state_bin(st)], 1u);
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < 128; k += blockDim.x)
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
         if (local[k]) atomicAdd(&hist[k], local[k]);
 }
-// Exclusive scan of the 128 state bins (turns the histogram into per-state cursors).
-__global__ void evm_state_scan_kernel(u32* hist) {
+// Exclusive scan of the bins (histogram -> per-bin cursors) + the group boundaries.
+__global__ void evm_state_scan_kernel(u32* hist, u32* group_start) {
     if (threadIdx.x == 0) {
         u32 acc = 0;
-        for (int k = 0; k < 128; k++) {
+        for (int k = 0; k < EVM_N_BINS; k++) {
+            if ((k & 127) == 0) group_start[k >> 7] = acc;
             u32 c = hist[k];
             hist[k] = acc;
             acc += c;
         }
+        group_start[EVM_N_GROUPS] = acc;
     }
 }
 // Scatter with block-level aggregation: ranks inside a block come from LDS atomics, one global
-// atomic per (block, state present).  Order inside a state bucket is irrelevant for correctness.
-__global__ void evm_state_scatter_kernel(ZkCols steps, u32 n_pairs, u32* cursor, u32* perm) {
-    __shared__ u32 local[128];
-    __shared__ u32 base[128];
-    for (u32 k = threadIdx.x; k < 128; k += blockDim.x) local[k] = 0;
+// atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
+__global__ void evm_state_scatter_kernel(const u64* steps, u32 n_pairs, u32* cursor, u32* perm) {
+    __shared__ u32 local[EVM_N_BINS];
+    __shared__ u32 base[EVM_N_BINS];
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
     __syncthreads();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 st = 0, rank = 0;
+    u32 bin = 0, rank = 0;
     if (i < n_pairs) {
-        st = (u32)steps.cells[((u64)S_STATE * steps.n + i) * 4] & 127u;
-        rank = atomicAdd(&local[st], 1u);
+        bin = evm_state_bin((u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4]);
+        rank = atomicAdd(&local[bin], 1u);
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < 128; k += blockDim.x)
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
         if (local[k]) base[k] = atomicAdd(&cursor[k], local[k]);
     __syncthreads();
-    if (i < n_pairs) perm[base[st] + rank] = i;
+    if (i < n_pairs) perm[base[bin] + rank] = i;
 }
 
 __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
@@ -201,7 +226,10 @@ struct zk_session {
     u32 launches = 0;               // since last collect
     StateArgs state;
     EvmArgs evm;
-    u32* d_hist = nullptr;   // EVM: 128 state bins (histogram -> cursors)
+    u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
+    u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
+    hipStream_t side[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};  // EVM: group kernels run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
 };
 
@@ -214,7 +242,16 @@ static int dev_alloc(zk_session* s, void** p, size_t bytes) {
 }
 // Bring a buffer to the device unless the caller already handed a device pointer.
 static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs, const void** out) {
-    if (device_ptrs || bytes == 0 || !src) {
+    if (bytes == 0 || !src) {
+        // empty table: keep one zeroed row so that "row 0" is always readable on the device
+        void* z = nullptr;
+        int rc0 = dev_alloc(s, &z, 512);
+        if (rc0) return rc0;
+        HIP_TRY(hipMemsetAsync(z, 0, 512, g_stream));
+        *out = z;
+        return 0;
+    }
+    if (device_ptrs) {
         *out = src;
         return 0;
     }
@@ -253,6 +290,11 @@ extern "C" int zk_close(zk_session* s) {
     (void)hipStreamSynchronize(g_stream);
     for (void* p : s->owned) (void)hipFree(p);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    for (int g = 0; g < EVM_N_GROUPS; g++) {
+        if (s->side[g]) { (void)hipStreamSynchronize(s->side[g]); (void)hipStreamDestroy(s->side[g]); }
+        if (s->ev_join[g]) (void)hipEventDestroy(s->ev_join[g]);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     delete s;
     return 0;
 }
@@ -303,9 +345,9 @@ static int table_stage(zk_session* s, ZkTable& t, const uint64_t* cells, const u
 // (Re)build the state-sorted permutation of the step pairs.
 static int evm_build_perm(zk_session* s) {
     const u32 n = s->evm.n_pairs;
-    HIP_TRY(hipMemsetAsync(s->d_hist, 0, 128 * sizeof(u32), g_stream));
+    HIP_TRY(hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream));
     hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist);
-    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(64), 0, g_stream, s->d_hist);
+    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(64), 0, g_stream, s->d_hist, s->d_group_start);
     hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist, s->d_perm);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -323,9 +365,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     int rc = 0;
     const void* p = nullptr;
     if ((rc = stage(s, t->steps, (size_t)t->n_steps * STEP_NCELLS * 32, dev, &p))) goto fail;
-    s->evm.steps.cells = (const u64*)p;
-    s->evm.steps.flags = nullptr;
-    s->evm.steps.n = t->n_steps;
+    s->evm.steps = (const u64*)p;
+    s->evm.n_steps = t->n_steps;
     if ((rc = table_stage(s, s->evm.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
@@ -334,12 +375,56 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = build_index<bc_key_hash>(s, s->evm.bytecode))) goto fail;
     if ((rc = build_index<tx_key_hash>(s, s->evm.tx))) goto fail;
     if ((rc = build_index<blk_key_hash>(s, s->evm.block))) goto fail;
+    s->evm.rw_meta = nullptr;
+    s->evm.codes.n = 0;
+    if (!(opts & ZK_OPT_GENERIC_INDEX)) {
+        // dense RW index: verified on the device (the table can be hundreds of MB)
+        ZkRwMeta* d_meta = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_meta, sizeof(ZkRwMeta)))) goto fail;
+        ZkRwMeta init;
+        init.dense = t->n_rw ? 1u : 0u;
+        init.pad = 0;
+        init.base = 0;
+        if (hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, g_stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
+        if (t->n_rw)
+            hipLaunchKernelGGL(rw_dense_check_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, g_stream, s->evm.rw, d_meta);
+        s->evm.rw_meta = d_meta;
+        // bytecode directory: built on the host (the table is small), then uploaded
+        if (t->n_bytecode) {
+            std::vector<u64> host_rows;
+            const u64* rows = t->bytecode;
+            if (dev) {
+                host_rows.resize((size_t)t->n_bytecode * BYTECODE_NCELLS * 4);
+                if (hipMemcpy(host_rows.data(), t->bytecode, host_rows.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "bytecode download failed"; goto fail; }
+                rows = host_rows.data();
+            }
+            HostCodeDir dir;
+            build_code_dir(rows, t->n_bytecode, dir);
+            ZkCodeEntry* d_entries = nullptr;
+            u32* d_slots = nullptr;
+            if ((rc = dev_alloc(s, (void**)&d_entries, dir.entries.size() * sizeof(ZkCodeEntry)))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d_slots, dir.slots.size() * sizeof(u32)))) goto fail;
+            if (hipMemcpy(d_entries, dir.entries.data(), dir.entries.size() * sizeof(ZkCodeEntry), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_slots, dir.slots.data(), dir.slots.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; g_err = "directory upload failed"; goto fail; }
+            s->evm.codes.entries = d_entries;
+            s->evm.codes.slots = d_slots;
+            s->evm.codes.mask = dir.mask;
+            s->evm.codes.n = (u32)dir.entries.size();
+        }
+    }
     s->evm.n_pairs = (u32)(t->n_steps - 1);
     s->evm.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
-    if ((rc = dev_alloc(s, (void**)&s->d_hist, 128 * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_hist, EVM_N_BINS * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
     s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
-    if (s->evm.perm && (rc = evm_build_perm(s))) goto fail;
+    if (s->evm.perm) {
+        if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "event create failed"; goto fail; }
+        for (int g = 1; g < EVM_N_GROUPS; g++) {
+            if (hipStreamCreateWithFlags(&s->side[g], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_join[g], hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "stream create failed"; goto fail; }
+        }
+    }
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
@@ -386,9 +471,24 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         break;
     }
     case SESSION_EVM: {
+        // the state-sorted lane mapping is derived from the step column on every pass
+        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed) HIP_TRY(hipEventRecord(e0, g_stream)); }
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
-        hipLaunchKernelGGL(evm_steps_kernel, dim3(grid), dim3(block), 0, g_stream, s->evm, status, s->d_tally);
+        if (s->evm.perm) {
+            // fork: the heavy groups run on side streams concurrently with the light group
+            HIP_TRY(hipEventRecord(s->ev_fork, g_stream));
+            for (int g = 1; g < EVM_N_GROUPS; g++) HIP_TRY(hipStreamWaitEvent(s->side[g], s->ev_fork, 0));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MEM], s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MUL], s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            for (int g = 1; g < EVM_N_GROUPS; g++) {
+                HIP_TRY(hipEventRecord(s->ev_join[g], s->side[g]));
+                HIP_TRY(hipStreamWaitEvent(g_stream, s->ev_join[g], 0));
+            }
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        }
         break;
     }
     }

@@ -105,8 +105,9 @@ def open_state(rows, flags, mpt, device=None):
     return Session(h, n, (rows, flags, mpt))
 
 
-def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True):
-    """wire: dict with steps uint64[13, n, 4], rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
+def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
+             generic_index=False):
+    """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
     (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
     lib = _lib.init(device)
     names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags"]
@@ -121,7 +122,7 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         return v.value if v is not None else None
 
     t = _lib.ZkEvmTables(
-        p(a["steps"]), int(a["steps"].shape[1]),
+        p(a["steps"]), int(a["steps"].shape[0]),
         p(a["rw"]) if rows(a["rw"]) else None, p(a["rw_flags"]) if rows(a["rw"]) else None, rows(a["rw"]),
         p(a["bytecode"]) if rows(a["bytecode"]) else None, rows(a["bytecode"]),
         p(a["tx"]) if rows(a["tx"]) else None, p(a["tx_flags"]) if rows(a["tx"]) else None, rows(a["tx"]),
@@ -129,9 +130,11 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         int(bool(begin_with_first_step)), int(bool(end_with_last_step)))
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
+    if generic_index:
+        opts |= _lib.OPT_GENERIC_INDEX
     h = ctypes.c_void_p()
     check(lib.zk_evm_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_evm_open")
-    return Session(h, int(a["steps"].shape[1]) - 1, arrs)
+    return Session(h, int(a["steps"].shape[0]) - 1, arrs)
 
 
 def fr_op(op, a, b):

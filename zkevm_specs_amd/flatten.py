@@ -81,7 +81,8 @@ def step_cells(s):
 
 
 def flatten_steps(steps):
-    return rows_to_colmajor([step_cells(s) for s in steps], STEP_NCELLS)
+    """row-major uint64[n_steps, 13, 4] (see include/zkevm_hip.h: the EVM kernel gathers steps)"""
+    return rows_to_rowmajor([step_cells(s) for s in steps], STEP_NCELLS)
 
 
 def rw_row_cells(r):

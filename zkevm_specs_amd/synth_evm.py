@@ -45,15 +45,19 @@ def _signed(x):
 
 
 class _Contract:
-    def __init__(self, rng, n_ops):
+    def __init__(self, rng, n_ops, mix=None):
         self.ops = []  # (opcode name, pc, push bytes)
         code = bytearray()
-        weights = [w for w, _ in _MIX]
-        kinds = [k for _, k in _MIX]
+        mix = mix or _MIX
+        weights = [w for w, _ in mix]
+        kinds = [k for _, k in mix]
         for _ in range(n_ops):
             kind = rng.choices(kinds, weights)[0]
             data = b""
-            if kind == "PUSH":
+            if kind.startswith("PUSH") and kind != "PUSH":
+                n = int(kind[4:])
+                name, data = kind, bytes(rng.getrandbits(8) for _ in range(n))
+            elif kind == "PUSH":
                 n = rng.choice(_PUSH_SIZES)
                 name, data = f"PUSH{n}", bytes(rng.getrandbits(8) for _ in range(n))
             elif kind == "ADDSUB":
@@ -107,11 +111,11 @@ for _st, _ops in T.RESPONSIBLE.items():
         _STATE_OF[_o] = int(ES[_st])
 
 
-def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True):
+def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True, mix=None):
     """Build an n_steps-step trace (n_steps - 1 evaluated pairs).  Returns a dict with the wire
     arrays `steps, rw, rw_flags, bytecode, tx, tx_flags, block, block_flags` plus `meta`."""
     rng = random.Random(seed)
-    contracts = [_Contract(rng, seg_len - 1) for _ in range(n_contracts)]
+    contracts = [_Contract(rng, seg_len - 1, mix) for _ in range(n_contracts)]
     steps, rw, rw_flags = [], [], []
     looked_up_cells = 0  # algorithmic-bytes accounting: cells of rows the step pairs look up
     tx_id = 1
@@ -119,7 +123,7 @@ def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True):
     rwc = 1
     seg = 0
     gas_left, rev_wc = 10**9, 0
-    SP0, GAS_REFILL = 400, 10**7
+    SP0, GAS_REFILL = (400 if mix is None else 512), 10**7
 
     def add_rw(rw_, tag, id_=0, addr=0, ft=0, key=0, value=0, prev=0, aux=0, vw=True, pw=True):
         nonlocal rwc
@@ -337,7 +341,7 @@ def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True):
     if not as_wire:
         return steps, rw, rw_flags, bytecode_rows, meta
     return {
-        "steps": rows_to_colmajor(steps, 13),
+        "steps": rows_to_rowmajor(steps, 13),
         "rw": rows_to_rowmajor(rw, 14), "rw_flags": np.array(rw_flags, dtype=np.uint32),
         "bytecode": rows_to_rowmajor(bytecode_rows, 6),
         "tx": np.zeros((0, 5, 4), dtype=np.uint64), "tx_flags": np.zeros(0, dtype=np.uint32),
