@@ -89,15 +89,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    tally = torch.tensor([res.fail_count, (res.first_fail_row + rank * units) if res.first_fail_row is not None else 2**62],
-                         dtype=torch.int64, device="cuda")
+    from zkevm_specs_amd.distributed import reduce_tally
+
+    total_fail, first_row, first_code = reduce_tally(res.fail_count, res.first_fail_row, res.first_fail_code,
+                                                     rank * units, device="cuda")
     t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(tally[0:1], op=dist.ReduceOp.SUM)
-        dist.all_reduce(tally[1:2], op=dist.ReduceOp.MIN)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
-    assert int(tally[0].item()) == 0, "synthetic witness must satisfy every constraint"
+    assert total_fail == 0 and first_row is None, "synthetic witness must satisfy every constraint"
 
     if rank == 0:
         rows_total = units * args.steps * world

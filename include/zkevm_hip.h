@@ -71,6 +71,10 @@ int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64
 typedef struct zk_session zk_session;
 int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n,
                   const uint64_t* mpt, uint64_t n_mpt, uint32_t opts, zk_session** out);
+/* Multi-GPU row sharding: evaluate only rows [row_lo, row_hi) of the uploaded block; the rows
+ * outside the range are a read-only halo (prev/next of the boundary rows).  Default: all rows,
+ * neighbours wrapping modulo n as in the reference's driver. */
+int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi);
 /* One-shot convenience: open + launch + collect (+ copy per-row status to host) + close. */
 int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n,
                     const uint64_t* mpt, uint64_t n_mpt, uint32_t opts,

@@ -20,8 +20,14 @@ static void build_index(std::vector<u32>& slots, u32& mask, u32 n, u64 (*hash_of
     }
 }
 
+extern "C" int sim_state_verify_range(const u64* cells, const u32* flags, u64 n, const u64* mpt, u64 n_mpt,
+                                      u64 lo, u64 hi, u32* status);
 extern "C" int sim_state_verify(const u64* cells, const u32* flags, u64 n, const u64* mpt, u64 n_mpt,
                                 u32* status) {
+    return sim_state_verify_range(cells, flags, n, mpt, n_mpt, 0, n, status);
+}
+extern "C" int sim_state_verify_range(const u64* cells, const u32* flags, u64 n, const u64* mpt, u64 n_mpt,
+                                      u64 lo, u64 hi, u32* status) {
     StateArgs a;
     a.rows.cells = cells;
     a.rows.flags = flags;
@@ -33,7 +39,9 @@ extern "C" int sim_state_verify(const u64* cells, const u32* flags, u64 n, const
     std::vector<u32> slots;
     u32 mask = 0;
     build_index(slots, mask, (u32)n_mpt, state_mpt_key_hash, a.mpt);
-    for (u64 i = 0; i < n; i++) status[i] = state_check_row(a, i);
+    a.eval_lo = lo;
+    a.eval_hi = hi;
+    for (u64 i = lo; i < hi; i++) status[i] = state_check_row(a, i);
     return 0;
 }
 

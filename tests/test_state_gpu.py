@@ -91,3 +91,27 @@ def test_device_pointer_path_and_idempotence():
     assert r1.launches == 2 and r2.launches == 1
     assert (r1.fail_count, r1.first_fail_row, r1.first_fail_code) == (r2.fail_count, r2.first_fail_row, r2.first_fail_code)
     assert r1.fail_count >= 1 and r1.first_fail_row <= 78
+
+
+def test_sharded_ranges_with_halo_match_full_pass():
+    """Multi-GPU sharding on one GPU: two row ranges with halos give the full pass's statuses."""
+    from zkevm_specs_amd import distributed
+
+    n = 1 << 13
+    cols, flags, mpt = synth_state_witness(n, seed=6)
+    cols[1, 5000, 0] = np.uint64(2)
+    cols[50, n // 2 - 1, 0] ^= np.uint64(1)
+    cols[0, n // 2, 0] = np.uint64(0)
+    _, full = _run(cols, flags, mpt)
+    got = np.zeros(n, dtype=np.uint32)
+    total = 0
+    for rank in range(2):
+        lc, lf, lo, hi, off = distributed.shard_state(cols, flags, rank, 2)
+        with engine.open_state(lc, lf, mpt) as s:
+            s.set_range(lo, hi)
+            res = s.run()
+            st = s.read_status()
+        assert res.rows_evaluated == hi - lo
+        got[off:off + hi - lo] = st[lo:hi]
+        total += res.fail_count
+    assert np.array_equal(got, full) and total == int((full != 0).sum()) >= 3

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -73,6 +73,7 @@ def load():
     lib.zk_last_error.restype = ctypes.c_char_p
     lib.zk_fr_op.argtypes = [ctypes.c_int, vp, vp, vp, u64, u32]
     lib.zk_state_open.argtypes = [vp, vp, u64, vp, u64, u32, ctypes.POINTER(vp)]
+    lib.zk_state_set_range.argtypes = [vp, u64, u64]
     lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_evm_open.argtypes = [ctypes.POINTER(ZkEvmTables), u32, ctypes.POINTER(vp)]
     lib.zk_evm_verify.argtypes = [ctypes.POINTER(ZkEvmTables), u32, vp, ctypes.POINTER(ZkResult)]

@@ -28,6 +28,7 @@ enum { MPT_NCELLS = 12 };
 struct StateArgs {
     ZkCols rows;
     ZkTable mpt;
+    u64 eval_lo, eval_hi;  // rows [eval_lo, eval_hi) are evaluated; the others are read-only halo
 };
 
 // 576-bit accumulator for the lexicographic key packing of state_circuit.py:552-565.

@@ -101,9 +101,9 @@ __global__ void index_build_kernel(ZkTable t, u32* slots) {
 // coalesced 32 B/lane access (2 x dwordx4); neighbours (i-1, i+1) are re-read through L1/L2.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = a.eval_lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.rows.n) {
+    if (i < a.eval_hi) {
         code = state_check_row(a, i);
         if (status) status[i] = code;
     }
@@ -315,6 +315,8 @@ extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64
     if ((rc = stage(s, flags, (size_t)n * 4, dev, &p))) goto fail;
     s->state.rows.flags = (const u32*)p;
     s->state.rows.n = n;
+    s->state.eval_lo = 0;
+    s->state.eval_hi = n;
     if ((rc = stage(s, mpt, (size_t)n_mpt * MPT_NCELLS * 32, dev, &p))) goto fail;
     s->state.mpt.cells = (const u64*)p;
     s->state.mpt.flags = nullptr;
@@ -446,6 +448,15 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     return rc;
 }
 
+extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
+    ARG_TRY(s && s->kind == SESSION_STATE, "zk_state_set_range: not a State session");
+    ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_state_set_range: bad range");
+    s->state.eval_lo = row_lo;
+    s->state.eval_hi = row_hi;
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, (size_t)s->n * sizeof(u32), g_stream));
+    return 0;
+}
+
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -466,7 +477,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     switch (s->kind) {
     case SESSION_STATE: {
         const int block = 256;
-        const u32 grid = (u32)((s->n + block - 1) / block);
+        const u32 grid = (u32)((s->state.eval_hi - s->state.eval_lo + block - 1) / block);
         hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, s->d_tally);
         break;
     }
@@ -514,7 +525,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     r->first_fail_row = t.first_fail == ~0ull ? UINT64_MAX : (t.first_fail >> 32);
     r->first_fail_code = t.first_fail == ~0ull ? 0u : (u32)(t.first_fail & 0xffffffffull);
     r->launches = s->launches;
-    r->rows_evaluated = s->n;
+    r->rows_evaluated = s->kind == SESSION_STATE ? s->state.eval_hi - s->state.eval_lo : s->n;
     r->kernel_ms = timed ? ms / timed : 0.0;
     s->launches = 0;
     return 0;

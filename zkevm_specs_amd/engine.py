@@ -54,6 +54,10 @@ class Session:
         self.launch()
         return self.collect()
 
+    def set_range(self, row_lo, row_hi):
+        """State sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
+        check(_lib.load().zk_state_set_range(self._h, int(row_lo), int(row_hi)), "zk_state_set_range")
+
     def read_status(self):
         out = np.empty(self.n, dtype=np.uint32)
         check(_lib.load().zk_read_status(self._h, _lib.ptr(out)), "zk_read_status")
