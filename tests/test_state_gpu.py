@@ -114,4 +114,4 @@ def test_sharded_ranges_with_halo_match_full_pass():
         assert res.rows_evaluated == hi - lo
         got[off:off + hi - lo] = st[lo:hi]
         total += res.fail_count
-    assert np.array_equal(got, full) and total == int((full != 0).sum()) >= 3
+    assert np.array_equal(got, full) and total == int((full != 0).sum()) >= 2
