@@ -97,6 +97,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     a.tx = ttx.t;
     a.block = tblk.t;
     a.perm = nullptr;
+    a.prof = nullptr;
     a.n_pairs = (u32)(n_steps - 1);
     a.opts = opts & 3u;
     // bit 2 of opts: generic open-addressing indices only (no dense RW index / code directory)

@@ -13,7 +13,7 @@ from zkevm_specs_amd.synth_evm import synth_evm_trace
 
 KINDS = sys.argv[1:] or ["PUSH1", "PUSH32", "POP", "ADDSUB", "MULDIVMOD", "CMP", "SCMP", "BITWISE", "NOT", "ISZERO", "BYTE",
                          "SIGNEXTEND", "SHIFT", "ADDMOD", "MULMOD", "MEMORY", "SLOAD", "SSTORE", "READER"]
-n = 1 << 16
+n = 1 << int(os.environ.get("LOGN", "16"))
 to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
 _lib.init(0)
 out = {}

@@ -35,6 +35,7 @@ struct EvmArgs {
     ZkTable rw, bytecode, tx, block;
     const ZkRwMeta* rw_meta;  // nullptr = generic index only
     ZkCodeDir codes;          // n == 0 = generic index only
+    unsigned long long* prof;  // optional phase timestamps (tuning aid): [block][8]
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
     u32 n_pairs;      // n_steps - 1
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
@@ -56,7 +57,17 @@ struct Ins {
     u32 rw_off, pc_off;
     int sp_off;
     Fr rwc, call_id, sp, pc;  // curr step cells every lookup needs (loaded once)
+    // bytecode-directory entry of curr.code_hash, probed once per step (every opcode/push-data
+    // lookup of the step goes to the same code): state 0 = not probed, 1 = regular entry cached,
+    // 2 = hash absent from the table, 3 = use the generic index
+    u32 code_state, code_header_row, code_byte_base, code_n_bytes;
 };
+
+#if defined(ZK_HOSTSIM)
+#define EV_PROF(I, k) do { } while (0)
+#else
+#define EV_PROF(I, k) do { if ((I).a->prof && (threadIdx.x & 63) == 0 && blockIdx.x < 512) (I).a->prof[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#endif
 
 // ---- checkpoints --------------------------------------------------------------------------
 ZK_HD void ev_fail(Ins& I, u32 kind) {
@@ -282,33 +293,42 @@ ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& inde
     q[B_IS_CODE] = fr_u(is_code > 0 ? 1 : 0);
     q[B_VALUE] = fr_zero();
     u32 mask = 0xfu | (is_code >= 0 ? (1u << B_IS_CODE) : 0u);
-    const ZkCodeDir& dir = I.a->codes;
-    if (dir.n != 0) {
-        // directory probe on the code hash, then a direct row index for regular codes
-        u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
-        const ZkCodeEntry* e = nullptr;
-        for (u32 probes = 0; probes <= dir.mask; probes++) {
-            const u32 k = dir.slots[slot];
-            if (k == ZK_EMPTY_SLOT) break;
-            const ZkCodeEntry* c = dir.entries + k;
-            if (fr_eq(fr_load(c->hash), code_hash.lo) && fr_eq(fr_load(c->hash + 4), code_hash.hi)) { e = c; break; }
-            slot = (slot + 1) & dir.mask;
+    // every bytecode lookup of the implemented gadgets queries curr.code_hash: probe once per step
+    if (I.code_state == 0) {
+        const ZkCodeDir& dir = I.a->codes;
+        I.code_state = 3;
+        if (dir.n != 0) {
+            u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
+            I.code_state = 2;
+            for (u32 probes = 0; probes <= dir.mask; probes++) {
+                const u32 k = dir.slots[slot];
+                if (k == ZK_EMPTY_SLOT) break;
+                const ZkCodeEntry* c = dir.entries + k;
+                if (fr_eq(fr_load(c->hash), code_hash.lo) && fr_eq(fr_load(c->hash + 4), code_hash.hi)) {
+                    I.code_state = c->regular ? 1 : 3;
+                    I.code_header_row = c->header_row;
+                    I.code_byte_base = c->byte_base;
+                    I.code_n_bytes = c->n_bytes;
+                    break;
+                }
+                slot = (slot + 1) & dir.mask;
+            }
         }
-        if (e == nullptr) {  // no row carries this hash
-            I.seq++;
-            ev_fail(I, ZK_LOOKUP_UNSAT);
-            return 0;
-        }
-        if (e->regular) {
-            I.seq++;
-            bool ok;
-            u32 r = 0;
-            if (tag == 1) { ok = fr_is_zero(index); r = e->header_row; }
-            else { ok = tag == 2 && fr_fits64(index) && fr_lo64(index) < (u64)e->n_bytes; r = ok ? e->byte_base + (u32)fr_lo64(index) : 0u; }
-            if (is_code >= 0) ok = ok & fr_eq(zk_table_cell(I.a->bytecode, r, B_IS_CODE), q[B_IS_CODE]);
-            if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
-            return r;
-        }
+    }
+    if (I.code_state == 2) {  // no row carries this hash
+        I.seq++;
+        ev_fail(I, ZK_LOOKUP_UNSAT);
+        return 0;
+    }
+    if (I.code_state == 1) {
+        I.seq++;
+        bool ok;
+        u32 r = 0;
+        if (tag == 1) { ok = fr_is_zero(index); r = I.code_header_row; }
+        else { ok = tag == 2 && fr_fits64(index) && fr_lo64(index) < (u64)I.code_n_bytes; r = ok ? I.code_byte_base + (u32)fr_lo64(index) : 0u; }
+        if (is_code >= 0) ok = ok & fr_eq(zk_table_cell(I.a->bytecode, r, B_IS_CODE), q[B_IS_CODE]);
+        if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
+        return r;
     }
     return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
 }
@@ -324,7 +344,6 @@ ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
 }
 ZK_HD Fr bytecode_length(Ins& I, const Word& code_hash) {  // instruction.py:771-774
     u32 r = bytecode_lookup(I, code_hash, 1, fr_zero(), 0);
-    if (I.err) return fr_zero();
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
 }
 ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag) {  // table.py:697-706 (index 0)
@@ -336,9 +355,6 @@ ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag) {  // table.
     q[4] = fr_zero();
     u32 r = table_lookup<TX_NCELLS>(I, I.a->tx, tx_key_hash_cells(q[0], q[1], q[2]), q, 0x7u);
     WordOrValue v;
-    v.w = word_zero();
-    v.is_word = true;
-    if (I.err) return v;
     v.w = word_of(zk_table_cell(I.a->tx, r, 3), zk_table_cell(I.a->tx, r, 4));
     v.is_word = I.a->tx.flags ? (I.a->tx.flags[r] & 1u) : true;
     return v;
@@ -351,9 +367,6 @@ ZK_HD WordOrValue block_lookup(Ins& I, u32 field_tag) {  // table.py:690-695 (bl
     q[3] = fr_zero();
     u32 r = table_lookup<BLOCK_NCELLS>(I, I.a->block, blk_key_hash_cells(q[0], q[1]), q, 0x3u);
     WordOrValue v;
-    v.w = word_zero();
-    v.is_word = true;
-    if (I.err) return v;
     v.w = word_of(zk_table_cell(I.a->block, r, 2), zk_table_cell(I.a->block, r, 3));
     v.is_word = I.a->block.flags ? (I.a->block.flags[r] & 1u) : true;
     return v;
@@ -411,7 +424,6 @@ ZK_HD Word stack_lookup(Ins& I, u32 rw, int off) {
     const Fr& sp = I.sp;
     rwq_set(Q, R_ADDR, off >= 0 ? fr_add_u64(sp, (u64)off) : fr_sub_u64(sp, (u64)(-off)));
     u32 r = rw_lookup(I, Q);
-    if (I.err) return word_zero();
     return rw_word(I, r, R_VAL_LO);
 }
 ZK_HD Word stack_pop(Ins& I) {
@@ -437,15 +449,10 @@ ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag, u32 rw = 0, co
     rwq_set(Q, R_ID, call_id ? *call_id : I.call_id);
     rwq_set(Q, R_ADDR, fr_u(field_tag));
     u32 r = rw_lookup(I, Q);
-    WordOrValue v;
-    v.w = word_zero();
-    v.is_word = true;
-    if (I.err) return v;
     return rw_value(I, r);
 }
 ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
     WordOrValue v = call_context_lookup_word(I, field_tag, rw, call_id);
-    if (I.err) return fr_zero();
     return value_of(I, v);
 }
 struct Reversion {
@@ -462,7 +469,7 @@ ZK_HD Reversion reversion_info(Ins& I) {  // instruction.py:901-913
 ZK_HD u32 state_write(Ins& I, RwQ& Q, Reversion& rv) {
     const u32 tag = Q.q[R_TAG].v[0];
     u32 r = rw_lookup(I, Q);
-    if (I.err) return 0;
+    if (I.err) return r;
     if (fr_is_zero(rv.persistent)) {
         Fr rwc = fr_sub(rv.end, rv.rwc);
         rv.rwc = fr_add_u64(rv.rwc, 1);
@@ -680,12 +687,12 @@ ZK_HD void memory_expansion(Ins& I, const Fr& offset, const Fr& length, Fr& next
 
 // ---- gadgets (evm_circuit/execution/*.py) --------------------------------------------------------
 ZK_HD void g_add_sub(Ins& I, Tail& T) {  // add_sub.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_sub = fr_eq_u64(opcode, OP_SUB);
     Word a, b, c;
-    EV_TRY(a = stack_pop(I));
-    EV_TRY(b = stack_pop(I));
-    EV_TRY(c = stack_push(I));
+    a = stack_pop(I);
+    b = stack_pop(I);
+    c = stack_push(I);
     Word x = ev_select_b(I, is_sub) ? c : a;
     Fr carry;
     Word res = add_words2(I, x, b, carry);
@@ -695,7 +702,7 @@ ZK_HD void g_add_sub(Ins& I, Tail& T) {  // add_sub.py
 }
 
 ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     // is_mul/is_div/is_mod are field expressions of the opcode (:14-16)
     Fr op_m2 = fr_sub_u64(opcode, 2), op_m4 = fr_sub_u64(opcode, 4);
     Fr f4_op = fr_sub(fr_u(4), opcode), f6_op = fr_sub(fr_u(6), opcode);
@@ -703,9 +710,9 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
     Fr is_div = fr_mulc(fr_mul(op_m2, f6_op), frm_inv4());
     Fr is_mod = fr_mulc(fr_mul(op_m2, op_m4), frm_inv8());
     Word pop1, pop2, push;
-    EV_TRY(pop1 = stack_pop(I));
-    EV_TRY(pop2 = stack_pop(I));
-    EV_TRY(push = stack_push(I));
+    pop1 = stack_pop(I);
+    pop2 = stack_pop(I);
+    push = stack_push(I);
     Word a, b, c, d;
     if (fr_eq_u64(is_mul, 1)) {
         a = pop1; b = pop2; c = word_from_int(I, fr_zero()); d = push;
@@ -757,10 +764,10 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
 }
 
 ZK_HD void g_cmp(Ins& I, Tail& T) {  // comparator.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_eq = fr_eq_u64(opcode, OP_EQ), is_gt = fr_eq_u64(opcode, OP_GT);
     Word a, b, c;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
     Word aa = is_gt ? b : a, bb = is_gt ? a : b;
     u32 lt_lo, eq_lo, lt_hi, eq_hi;
     ev_compare(I, aa.lo, bb.lo, 16, lt_lo, eq_lo);
@@ -783,10 +790,10 @@ ZK_HD u32 lt_u256_sel(Ins& I, const Word& a, const Word& b) {
 }
 
 ZK_HD void g_scmp(Ins& I, Tail& T) {  // slt_sgt.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_sgt = fr_eq_u64(opcode, OP_SGT);
     Word a, b, c;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
     Word aa = is_sgt ? b : a, bb = is_sgt ? a : b;
     U256 a8, b8, c8;
     EV_TRY(a8 = to_u256(I, aa)); EV_TRY(b8 = to_u256(I, bb)); EV_TRY(c8 = to_u256(I, c));
@@ -801,19 +808,19 @@ ZK_HD void g_scmp(Ins& I, Tail& T) {  // slt_sgt.py
 }
 
 ZK_HD void g_iszero(Ins& I, Tail& T) {  // iszero.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
-    Word value; EV_TRY(value = stack_pop(I));
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word value; value = stack_pop(I);
     Word z = word_checked(I, fr_u(is_zero_word(value)), fr_zero());
-    Word push; EV_TRY(push = stack_push(I));
+    Word push; push = stack_push(I);
     constrain_equal_word(I, z, push);
     set_tail3(T, opcode, 2, 1, 0);
 }
 
 ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
-    Word a; EV_TRY(a = stack_pop(I));
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word a; a = stack_pop(I);
     U256 a8; EV_TRY(a8 = to_u256(I, a));
-    Word b; EV_TRY(b = stack_push(I));
+    Word b; b = stack_push(I);
     U256 b8; EV_TRY(b8 = to_u256(I, b));
     for (int k = 0; k < 32; k++) fixed_lookup(I, FX_BitwiseXor, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(255));
     if (I.err) return;
@@ -821,9 +828,9 @@ ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
 }
 
 ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     Word a, b, c;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
     U256 a8, b8, c8;
     EV_TRY(a8 = to_u256(I, a)); EV_TRY(b8 = to_u256(I, b)); EV_TRY(c8 = to_u256(I, c));
     // tag = BitwiseAnd + (opcode.n - AND) as a Python int, then FixedTableTag(tag)
@@ -843,9 +850,9 @@ ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
 }
 
 ZK_HD void g_byte(Ins& I, Tail& T) {  // byte.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     Word a, b, c;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(c = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
     U256 index, value;
     EV_TRY(index = to_u256(I, a)); EV_TRY(value = to_u256(I, b));
     bool msb_zero = true;
@@ -859,9 +866,9 @@ ZK_HD void g_byte(Ins& I, Tail& T) {  // byte.py
 }
 
 ZK_HD void g_signextend(Ins& I, Tail& T) {  // signextend.py (is_equal results are discarded there)
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     Word index, value, result;
-    EV_TRY(index = stack_pop(I)); EV_TRY(value = stack_pop(I)); EV_TRY(result = stack_push(I));
+    index = stack_pop(I); value = stack_pop(I); result = stack_push(I);
     U256 ib, vb, rb;
     EV_TRY(ib = to_u256(I, index)); EV_TRY(vb = to_u256(I, value)); EV_TRY(rb = to_u256(I, result));
     bool msb_zero = true;
@@ -875,14 +882,14 @@ ZK_HD void g_signextend(Ins& I, Tail& T) {  // signextend.py (is_equal results a
 }
 
 ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     Fr num_pushed = fr_sub_u64(opcode, OP_PUSH0);
-    Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
+    Fr code_length; code_length = bytecode_length(I, curr_code_hash(I));
     const Fr& pc = I.pc;
     Fr left = fr_sub_u64(fr_sub(code_length, pc), 1);
     u32 oob, eq; ev_compare(I, left, num_pushed, 8, oob, eq); if (I.err) return;
     Fr num_padding = oob ? fr_sub(num_pushed, left) : fr_zero();
-    Word value; EV_TRY(value = stack_push(I));
+    Word value; value = stack_push(I);
     U256 vb; EV_TRY(vb = to_u256(I, value));
     for (int k = 0; k < 32; k++) {
         const bool pushed = fr_lt(fr_u((u64)k), num_pushed), padding = fr_lt(fr_u((u64)k), num_padding);
@@ -898,15 +905,15 @@ ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
 }
 
 ZK_HD void g_pop(Ins& I, Tail& T) {  // pop.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
-    EV_TRY(stack_pop(I));
+    Fr opcode; opcode = opcode_lookup(I, true);
+    stack_pop(I);
     set_tail3(T, opcode, 1, 1, 1);
 }
 
 ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     Word pop1, pop2, push;
-    EV_TRY(pop1 = stack_pop(I)); EV_TRY(pop2 = stack_pop(I)); EV_TRY(push = stack_push(I));
+    pop1 = stack_pop(I); pop2 = stack_pop(I); push = stack_push(I);
     // gen_witness (:103-127)
     Fr is_shl = fr_sub(fr_u(OP_SHR), opcode);
     Word shift = pop1;
@@ -971,10 +978,10 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
 ZK_HD void divmod_512(const U512& num, const U256& den, U512& q, U256& r) { u512_divmod(num, den, q, r, 512); }
 
 ZK_HD void g_addmod(Ins& I, Tail& T) {  // addmod.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_ADDMOD));
     Word a, b, n, pushed_r;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(n = stack_pop(I)); EV_TRY(pushed_r = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); n = stack_pop(I); pushed_r = stack_push(I);
     U256 av, bv, nv;
     EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n));
     const bool n_zero = fr_is_zero(nv);
@@ -1042,10 +1049,10 @@ ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r, const
 }
 
 ZK_HD void g_mulmod(Ins& I, Tail& T) {  // mulmod.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_MULMOD));
     Word a, b, n, r;
-    EV_TRY(a = stack_pop(I)); EV_TRY(b = stack_pop(I)); EV_TRY(n = stack_pop(I)); EV_TRY(r = stack_push(I));
+    a = stack_pop(I); b = stack_pop(I); n = stack_pop(I); r = stack_push(I);
     U256 av, bv, nv, rv;
     EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
     U256 a_red = fr_zero(), k = fr_zero(), q0 = fr_zero();
@@ -1078,13 +1085,13 @@ ZK_HD void g_mulmod(Ins& I, Tail& T) {  // mulmod.py
 }
 
 ZK_HD void g_memory(Ins& I, Tail& T) {  // memory.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
-    Word aw; EV_TRY(aw = stack_pop(I));
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word aw; aw = stack_pop(I);
     Fr address; EV_TRY(address = word_to_fq(I, aw, 20));
     const bool is_mload = fr_eq_u64(opcode, OP_MLOAD), is_mstore8 = fr_eq_u64(opcode, OP_MSTORE8);
     const bool is_store = !is_mload, is_not8 = !is_mstore8;
     Word value;
-    if (is_mload) { EV_TRY(value = stack_push(I)); } else { EV_TRY(value = stack_pop(I)); }
+    if (is_mload) { value = stack_push(I); } else { value = stack_pop(I); }
     EV_TRY(to_u256(I, value));
     Fr next_size, gas;
     EV_TRY(memory_expansion(I, ev_curr(I, S_MWS), fr_add_u64(address, 1 + (is_not8 ? 31 : 0)), next_size, gas));
@@ -1096,47 +1103,47 @@ ZK_HD void g_memory(Ins& I, Tail& T) {  // memory.py
 }
 
 ZK_HD void ctx_push_word(Ins& I, Tail& T, const Fr& opcode, const Word& w) {
-    Word push; EV_TRY(push = stack_push(I));
+    Word push; push = stack_push(I);
     constrain_equal_word(I, w, push);
     set_tail3(T, opcode, 2, 1, -1);
 }
 ZK_HD void g_ctx_word(Ins& I, Tail& T, u32 expected_opcode, u32 field_tag) {  // caller.py / callvalue.py / address.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(expected_opcode));
-    WordOrValue v; EV_TRY(v = call_context_lookup_word(I, field_tag));
+    WordOrValue v; v = call_context_lookup_word(I, field_tag);
     ctx_push_word(I, T, opcode, v.w);
 }
 ZK_HD void g_ctx_value(Ins& I, Tail& T, u32 expected_opcode, u32 field_tag) {  // calldatasize.py / returndatasize.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(expected_opcode));
-    Fr v; EV_TRY(v = call_context_lookup(I, field_tag));
+    Fr v; v = call_context_lookup(I, field_tag);
     Word w = word_checked(I, v, fr_zero());
     ctx_push_word(I, T, opcode, w);
 }
 ZK_HD void g_tx_word(Ins& I, Tail& T, u32 expected_opcode, u32 tx_field_tag) {  // origin.py / gasprice.py
-    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(expected_opcode));
-    WordOrValue v; EV_TRY(v = tx_lookup(I, tx_id, tx_field_tag));
+    WordOrValue v; v = tx_lookup(I, tx_id, tx_field_tag);
     ctx_push_word(I, T, opcode, v.w);
 }
 ZK_HD void g_selfbalance(Ins& I, Tail& T) {  // selfbalance.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_SELFBALANCE));
-    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
     Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
     RwQ Q;
     rwq_init(Q, 0, TG_Account);
     rwq_set(Q, R_ADDR, callee);
     rwq_set(Q, R_FT, fr_u(ACC_Balance));
-    u32 r; EV_TRY(r = rw_lookup(I, Q));
+    u32 r; r = rw_lookup(I, Q);
     Word bal = rw_word(I, r, R_VAL_LO);
-    Word push; EV_TRY(push = stack_push(I));
+    Word push; push = stack_push(I);
     constrain_equal_word(I, push, bal);
     set_tail3(T, opcode, 3, 1, -1);
 }
 ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     u32 tag = 0;
     if (fr_eq_u64(opcode, OP_COINBASE)) tag = BLK_Coinbase;
     else if (fr_eq_u64(opcode, OP_TIMESTAMP)) tag = BLK_Timestamp;
@@ -1146,66 +1153,66 @@ ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
     else if (fr_eq_u64(opcode, OP_BASEFEE)) tag = BLK_BaseFee;
     else if (fr_eq_u64(opcode, OP_CHAINID)) tag = BLK_ChainId;
     ev_require(I, tag != 0, ZK_NAME_ERROR); if (I.err) return;  // `op` unbound (:24)
-    WordOrValue v; EV_TRY(v = block_lookup(I, tag));
-    Word push; EV_TRY(push = stack_push(I));
+    WordOrValue v; v = block_lookup(I, tag);
+    Word push; push = stack_push(I);
     constrain_equal_word(I, v.w, push);
     set_tail3(T, opcode, 1, 1, -1);
 }
 ZK_HD void g_push_lo(Ins& I, Tail& T, const Fr& opcode, const Fr& lo) {  // Word.from_lo(x) == stack_push()
     Word w = word_checked(I, lo, fr_zero());
-    Word push; EV_TRY(push = stack_push(I));
+    Word push; push = stack_push(I);
     constrain_equal_word(I, w, push);
     set_tail3(T, opcode, 1, 1, -1);
 }
 ZK_HD void g_gas(Ins& I, Tail& T) {  // gas.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_GAS));
     g_push_lo(I, T, opcode, fr_sub_u64(ev_curr(I, S_GAS), 2));
 }
 ZK_HD void g_msize(Ins& I, Tail& T) {  // msize.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     g_push_lo(I, T, opcode, fr_mulc(ev_curr(I, S_MWS), fr_to_mont(fr_u(32))));
 }
 ZK_HD void g_codesize(Ins& I, Tail& T) {  // codesize.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_CODESIZE));
-    Fr size; EV_TRY(size = bytecode_length(I, curr_code_hash(I)));
+    Fr size; size = bytecode_length(I, curr_code_hash(I));
     g_push_lo(I, T, opcode, size);
 }
 ZK_HD void g_jump(Ins& I, Tail& T) {  // jump.py
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_JUMP));
-    Word dest; EV_TRY(dest = stack_pop(I));
+    Word dest; dest = stack_pop(I);
     constrain_zero(I, dest.hi);
-    Fr byte; EV_TRY(byte = opcode_lookup_at(I, dest.lo, true));
+    Fr byte; byte = opcode_lookup_at(I, dest.lo, true);
     constrain_equal(I, fr_u(OP_JUMPDEST), byte);
     set_tail(T, opcode, 1, t_to(dest.lo), 1, t_same(), 0, fr_zero());
 }
 ZK_HD void g_jumpi(Ins& I, Tail& T) {  // jumpi.py: `if is_zero_word(cond)` is always truthy (FQ has no __bool__)
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_JUMPI));
-    Word dest; EV_TRY(dest = stack_pop(I));
+    Word dest; dest = stack_pop(I);
     constrain_zero(I, dest.hi);
-    EV_TRY(stack_pop(I));
+    stack_pop(I);
     set_tail3(T, opcode, 2, 1, 2);
 }
 
 ZK_HD void g_sload(Ins& I, Tail& T) {  // storage.py:15-47
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_SLOAD));
-    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
     Reversion rv; EV_TRY(rv = reversion_info(I));
-    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
     Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
-    Word key; EV_TRY(key = stack_pop(I));
+    Word key; key = stack_pop(I);
     RwQ Q;
     rwq_init(Q, 0, TG_AccountStorage);
     rwq_set(Q, R_ID, tx_id);
     rwq_set(Q, R_ADDR, callee);
     rwq_set_word(Q, R_KEY_LO, key);
-    u32 r; EV_TRY(r = rw_lookup(I, Q));
+    u32 r; r = rw_lookup(I, Q);
     Word val = rw_word(I, r, R_VAL_LO);
-    Word push; EV_TRY(push = stack_push(I));
+    Word push; push = stack_push(I);
     constrain_equal_word(I, val, push);
     RwQ W;
     rwq_init(W, 1, TG_TxAccessListAccountStorage);
@@ -1213,29 +1220,29 @@ ZK_HD void g_sload(Ins& I, Tail& T) {  // storage.py:15-47
     rwq_set(W, R_ADDR, callee);
     rwq_set_word(W, R_KEY_LO, key);
     rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
-    u32 wr; EV_TRY(wr = state_write(I, W, rv));
+    u32 wr; wr = state_write(I, W, rv);
     Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
     bool warm = ev_select(I, is_warm); if (I.err) return;
     set_tail(T, opcode, 8, t_delta_i(1), 0, t_same(), 1, fr_u(warm ? 100 : 2100));
 }
 
 ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
-    Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+    Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_SSTORE));
-    Fr tx_id; EV_TRY(tx_id = call_context_lookup(I, CC_TxId));
-    Fr is_static; EV_TRY(is_static = call_context_lookup(I, CC_IsStatic));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Fr is_static; is_static = call_context_lookup(I, CC_IsStatic);
     constrain_equal(I, fr_zero(), is_static);
     Reversion rv; EV_TRY(rv = reversion_info(I));
-    WordOrValue cw; EV_TRY(cw = call_context_lookup_word(I, CC_CalleeAddress));
+    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
     Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
     Word key, sval;
-    EV_TRY(key = stack_pop(I)); EV_TRY(sval = stack_pop(I));
+    key = stack_pop(I); sval = stack_pop(I);
     RwQ Q;
     rwq_init(Q, 1, TG_AccountStorage);
     rwq_set(Q, R_ID, tx_id);
     rwq_set(Q, R_ADDR, callee);
     rwq_set_word(Q, R_KEY_LO, key);
-    u32 r; EV_TRY(r = state_write(I, Q, rv));
+    u32 r; r = state_write(I, Q, rv);
     Word value = rw_word(I, r, R_VAL_LO), value_prev = rw_word(I, r, R_PREV_LO), original = rw_word(I, r, R_AUX_LO);
     constrain_equal_word(I, sval, value);
     RwQ W;
@@ -1244,12 +1251,12 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
     rwq_set(W, R_ADDR, callee);
     rwq_set_word(W, R_KEY_LO, key);
     rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
-    u32 wr; EV_TRY(wr = state_write(I, W, rv));
+    u32 wr; wr = state_write(I, W, rv);
     Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
     RwQ Rf;
     rwq_init(Rf, 1, TG_TxRefund);
     rwq_set(Rf, R_ID, tx_id);
-    u32 rr; EV_TRY(rr = state_write(I, Rf, rv));
+    u32 rr; rr = state_write(I, Rf, rv);
     Fr gas_refund; EV_TRY(gas_refund = value_of(I, rw_value(I, rr)));
     Fr refund_prev; EV_TRY(refund_prev = value_of(I, rw_value_prev(I, rr)));
     const u64 CLEARS = 4800, SET = 20000, RESET = 2900, SLOAD = 100;
@@ -1276,17 +1283,17 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
 // step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
 ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
     rw_counter_delta += 12;
-    Fr caller_id; EV_TRY(caller_id = call_context_lookup(I, CC_CallerId));
+    Fr caller_id; caller_id = call_context_lookup(I, CC_CallerId);
     const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
                          CC_MemorySize, CC_ReversibleWriteCounter};
     WordOrValue saved[8];
     for (int k = 0; k < 8; k++) EV_TRY(saved[k] = call_context_lookup_word(I, tags[k], 0, &caller_id));
     {
-        Fr v; EV_TRY(v = call_context_lookup(I, CC_LastCalleeId, 1, &caller_id));
+        Fr v; v = call_context_lookup(I, CC_LastCalleeId, 1, &caller_id);
         constrain_equal(I, v, ev_curr(I, S_CALL_ID));
-        EV_TRY(v = call_context_lookup(I, CC_LastCalleeReturnDataOffset, 1, &caller_id));
+        v = call_context_lookup(I, CC_LastCalleeReturnDataOffset, 1, &caller_id);
         constrain_equal(I, v, fr_zero());
-        EV_TRY(v = call_context_lookup(I, CC_LastCalleeReturnDataLength, 1, &caller_id));
+        v = call_context_lookup(I, CC_LastCalleeReturnDataLength, 1, &caller_id);
         constrain_equal(I, v, fr_zero());
     }
     const u32 st = ev_curr(I, S_STATE).v[0];
@@ -1312,13 +1319,13 @@ ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
 }
 
 ZK_HD void g_stop(Ins& I, Tail& T) {  // stop.py
-    Fr code_length; EV_TRY(code_length = bytecode_length(I, curr_code_hash(I)));
+    Fr code_length; code_length = bytecode_length(I, curr_code_hash(I));
     u32 lt, eq; ev_compare(I, code_length, ev_curr(I, S_PC), 8, lt, eq); if (I.err) return;
     if (lt + eq == 0) {
-        Fr opcode; EV_TRY(opcode = opcode_lookup(I, true));
+        Fr opcode; opcode = opcode_lookup(I, true);
         fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
     }
-    Fr is_success; EV_TRY(is_success = call_context_lookup(I, CC_IsSuccess));
+    Fr is_success; is_success = call_context_lookup(I, CC_IsSuccess);
     constrain_equal(I, is_success, fr_u(1));
     const u32 to_end_tx = ev_next(I, S_STATE).v[0] == ES_EndTx ? 1u : 0u;
     Fr is_root = ev_curr(I, S_IS_ROOT);
@@ -1343,43 +1350,45 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
     return true;
 }
 
-#define GROUP_OF_ES_ADD 0
+#define GROUP_OF_ES_ADD 2
 #define GROUP_OF_ES_ADDMOD 1
-#define GROUP_OF_ES_ADDRESS 0
-#define GROUP_OF_ES_BITWISE 0
-#define GROUP_OF_ES_BYTE 0
-#define GROUP_OF_ES_BlockCtx 0
-#define GROUP_OF_ES_CALLDATASIZE 0
-#define GROUP_OF_ES_CALLER 0
-#define GROUP_OF_ES_CALLVALUE 0
-#define GROUP_OF_ES_CMP 0
-#define GROUP_OF_ES_CODESIZE 0
-#define GROUP_OF_ES_GAS 0
-#define GROUP_OF_ES_GASPRICE 0
-#define GROUP_OF_ES_ISZERO 0
-#define GROUP_OF_ES_JUMP 0
-#define GROUP_OF_ES_JUMPI 0
-#define GROUP_OF_ES_MEMORY 2
-#define GROUP_OF_ES_MSIZE 0
+#define GROUP_OF_ES_ADDRESS 2
+#define GROUP_OF_ES_BITWISE 2
+#define GROUP_OF_ES_BYTE 2
+#define GROUP_OF_ES_BlockCtx 2
+#define GROUP_OF_ES_CALLDATASIZE 2
+#define GROUP_OF_ES_CALLER 2
+#define GROUP_OF_ES_CALLVALUE 2
+#define GROUP_OF_ES_CMP 2
+#define GROUP_OF_ES_CODESIZE 2
+#define GROUP_OF_ES_GAS 2
+#define GROUP_OF_ES_GASPRICE 2
+#define GROUP_OF_ES_ISZERO 2
+#define GROUP_OF_ES_JUMP 2
+#define GROUP_OF_ES_JUMPI 2
+#define GROUP_OF_ES_MEMORY 0
+#define GROUP_OF_ES_MSIZE 2
 #define GROUP_OF_ES_MUL 1
 #define GROUP_OF_ES_MULMOD 1
-#define GROUP_OF_ES_NOT 0
-#define GROUP_OF_ES_ORIGIN 0
-#define GROUP_OF_ES_POP 0
-#define GROUP_OF_ES_PUSH 0
-#define GROUP_OF_ES_RETURNDATASIZE 0
-#define GROUP_OF_ES_SCMP 0
-#define GROUP_OF_ES_SELFBALANCE 0
+#define GROUP_OF_ES_NOT 2
+#define GROUP_OF_ES_ORIGIN 2
+#define GROUP_OF_ES_POP 2
+#define GROUP_OF_ES_PUSH 2
+#define GROUP_OF_ES_RETURNDATASIZE 2
+#define GROUP_OF_ES_SCMP 2
+#define GROUP_OF_ES_SELFBALANCE 2
 #define GROUP_OF_ES_SHL_SHR 1
-#define GROUP_OF_ES_SIGNEXTEND 0
-#define GROUP_OF_ES_SLOAD 2
-#define GROUP_OF_ES_SSTORE 2
-#define GROUP_OF_ES_STOP 2
+#define GROUP_OF_ES_SIGNEXTEND 2
+#define GROUP_OF_ES_SLOAD 0
+#define GROUP_OF_ES_SSTORE 0
+#define GROUP_OF_ES_STOP 0
 
 // Kernel specialisation groups: the step pairs are sorted by (group, state) and each group is
 // evaluated by its own kernel instantiation, which contains only that group's gadget bodies
 // (smaller instruction footprint, fewer live registers -> more resident wavefronts).
-enum { EVM_GROUP_LIGHT = 0, EVM_GROUP_MUL = 1, EVM_GROUP_MEM = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
+// numbered in launch order: the long-running gadgets get the first lanes so that their wavefronts start
+// first and the short ones fill in behind them (no long tail at the end of the kernel)
+enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
     case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
@@ -1401,6 +1410,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     I.seq = 0;
     I.rw_off = I.pc_off = 0;
     I.sp_off = 0;
+    I.code_state = 0;
+    EV_PROF(I, 0);
     I.rwc = ev_curr(I, S_RWC);
     I.call_id = ev_curr(I, S_CALL_ID);
     I.sp = ev_curr(I, S_SP);
@@ -1422,6 +1433,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
         ev_fail(I, ZK_NOT_IMPLEMENTED);
         return I.err;
     }
+    EV_PROF(I, 1);
     Tail T;
     T.enabled = false;
     if (G != EVM_GROUP_ALL && evm_state_group(state) != G) {  // cannot happen with a correct lane mapping
@@ -1463,6 +1475,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_SSTORE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SSTORE) { g_sstore(I, T); } break;
     default: ev_fail(I, ZK_UNSUPPORTED); break;
     }
+    EV_PROF(I, 2);
     if (I.err == 0u && T.enabled) same_context(I, T);
+    EV_PROF(I, 3);
     return I.err;
 }

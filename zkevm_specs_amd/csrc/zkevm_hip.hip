@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -117,14 +118,15 @@ __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* statu
 // steps contains; each group has its own kernel instantiation (evm_circuit.hpp).
 // group_start[g] .. group_start[g+1] is the lane range of group g inside `perm`.
 // ---------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256, (G == EVM_GROUP_LIGHT ? 4 : (G == EVM_GROUP_MUL ? 2 : 1))) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
+template <int G, int OCC>
+__global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     u64 idx = t;
     bool active;
     if (G == EVM_GROUP_ALL) {
         active = t < a.n_pairs;
+        if (active && a.perm) idx = a.perm[t];
     } else {
         const u32 lo = group_start[G], hi = group_start[G + 1];
         active = t < (u64)(hi - lo);
@@ -150,8 +152,12 @@ __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
 }
 
 // Counting sort of the step pairs by (group, state): histogram, scan, scatter.
-__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist) {
+__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, ZkTally* tally) {
     __shared__ u32 local[EVM_N_BINS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
+        tally->fail_count = 0ull;
+        tally->first_fail = ~0ull;
+    }
     for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
     __syncthreads();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,18 +169,26 @@ __global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist) 
     for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
         if (local[k]) atomicAdd(&hist[k], local[k]);
 }
-// Exclusive scan of the bins (histogram -> per-bin cursors) + the group boundaries.
-__global__ void evm_state_scan_kernel(u32* hist, u32* group_start) {
-    if (threadIdx.x == 0) {
-        u32 acc = 0;
-        for (int k = 0; k < EVM_N_BINS; k++) {
-            if ((k & 127) == 0) group_start[k >> 7] = acc;
-            u32 c = hist[k];
-            hist[k] = acc;
-            acc += c;
-        }
-        group_start[EVM_N_GROUPS] = acc;
+// Exclusive scan of the bins (histogram -> per-bin cursors) + the group boundaries; one block of
+// EVM_N_BINS threads, Hillis-Steele in LDS.  Also clears the histogram copy for the next pass.
+__global__ void evm_state_scan_kernel(u32* hist, u32* cursor, u32* group_start) {
+    __shared__ u32 a[EVM_N_BINS], b[EVM_N_BINS];
+    const u32 k = threadIdx.x;
+    const u32 c = hist[k];
+    hist[k] = 0;  // ready for the next pass's histogram
+    a[k] = c;
+    __syncthreads();
+    u32* src = a;
+    u32* dst = b;
+    for (u32 off = 1; off < EVM_N_BINS; off <<= 1) {
+        dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
+        __syncthreads();
+        u32* t = src; src = dst; dst = t;
     }
+    const u32 excl = src[k] - c;
+    cursor[k] = excl;
+    if ((k & 127u) == 0) group_start[k >> 7] = excl;
+    if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
 }
 // Scatter with block-level aggregation: ranks inside a block come from LDS atomics, one global
 // atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
@@ -227,10 +241,12 @@ struct zk_session {
     StateArgs state;
     EvmArgs evm;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
+    u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
-    hipStream_t side[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};  // EVM: group kernels run concurrently
+    hipStream_t side[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};  // indexed by group; the LIGHT group uses the main stream  // EVM: group kernels run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
+    u32 evm_strategy = 1;    // launch strategy: 1 = one state-sorted kernel (default), 0 = concurrent group kernels, 2 = sequential group kernels, 3 = one kernel at 4 waves/SIMD (tuning knob, ZK_EVM_STRATEGY env)
 };
 
 static const int MAX_EVENT_PAIRS = 256;
@@ -347,10 +363,10 @@ static int table_stage(zk_session* s, ZkTable& t, const uint64_t* cells, const u
 // (Re)build the state-sorted permutation of the step pairs.
 static int evm_build_perm(zk_session* s) {
     const u32 n = s->evm.n_pairs;
-    HIP_TRY(hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream));
-    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist);
-    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(64), 0, g_stream, s->d_hist, s->d_group_start);
-    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, s->evm.steps, n, s->d_hist, s->d_perm);
+    // d_hist is zero on entry (cleared at open and by every scan)
+    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->evm.steps, n, s->d_hist, s->d_tally);
+    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(EVM_N_BINS), 0, g_stream, s->d_hist, s->d_cursor, s->d_group_start);
+    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->evm.steps, n, s->d_cursor, s->d_perm);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -417,12 +433,20 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     s->evm.n_pairs = (u32)(t->n_steps - 1);
     s->evm.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
     if ((rc = dev_alloc(s, (void**)&s->d_hist, EVM_N_BINS * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
+    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess) { rc = -2; goto fail; }
     if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
+    s->evm.prof = nullptr;
+    if (getenv("ZK_EVM_PROF")) {
+        if ((rc = dev_alloc(s, (void**)&s->evm.prof, 512 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
+        if (hipMemset(s->evm.prof, 0, 512 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) { rc = -2; goto fail; }
+    }
     s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
+    if (const char* e = getenv("ZK_EVM_STRATEGY")) s->evm_strategy = (u32)atoi(e);
     if (s->evm.perm) {
         if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "event create failed"; goto fail; }
-        for (int g = 1; g < EVM_N_GROUPS; g++) {
+        for (int g = 0; g < EVM_N_GROUPS - 1; g++) {
             if (hipStreamCreateWithFlags(&s->side[g], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&s->ev_join[g], hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "stream create failed"; goto fail; }
         }
@@ -457,6 +481,14 @@ extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_h
     return 0;
 }
 
+// tuning aid (not part of the public ABI): copy the phase timestamps of the last pass
+extern "C" int zk_debug_read_prof(zk_session* s, unsigned long long* out) {
+    if (!s || !s->evm.prof) return -1;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(out, s->evm.prof, 512 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -471,7 +503,8 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         e0 = s->ev[2 * s->launches];
         e1 = s->ev[2 * s->launches + 1];
     }
-    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
+    if (!(s->kind == SESSION_EVM && s->evm.perm))
+        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
     u32* status = status_dev ? status_dev : s->d_status;
     if (timed) HIP_TRY(hipEventRecord(e0, g_stream));
     switch (s->kind) {
@@ -486,19 +519,28 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed) HIP_TRY(hipEventRecord(e0, g_stream)); }
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
-        if (s->evm.perm) {
+        const u32 strat = s->evm_strategy;
+        if (s->evm.perm && strat == 1) {  // one kernel with every gadget, state-sorted lanes
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        } else if (s->evm.perm && strat == 2) {  // group kernels back to back on one stream
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM, 1>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        } else if (s->evm.perm && strat == 3) {  // one kernel, tighter register budget
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        } else if (s->evm.perm) {
             // fork: the heavy groups run on side streams concurrently with the light group
             HIP_TRY(hipEventRecord(s->ev_fork, g_stream));
-            for (int g = 1; g < EVM_N_GROUPS; g++) HIP_TRY(hipStreamWaitEvent(s->side[g], s->ev_fork, 0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MEM], s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MUL], s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-            for (int g = 1; g < EVM_N_GROUPS; g++) {
+            for (int g = 0; g < EVM_N_GROUPS - 1; g++) HIP_TRY(hipStreamWaitEvent(s->side[g], s->ev_fork, 0));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM, 1>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MEM], s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL, 2>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MUL], s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            for (int g = 0; g < EVM_N_GROUPS - 1; g++) {
                 HIP_TRY(hipEventRecord(s->ev_join[g], s->side[g]));
                 HIP_TRY(hipStreamWaitEvent(g_stream, s->ev_join[g], 0));
             }
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 1>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
         }
         break;
     }
