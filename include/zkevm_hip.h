@@ -105,6 +105,24 @@ int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
 int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
                   uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);
 
+/* ---- Bytecode circuit: replaces the `for row: check_bytecode_row(row, next, push_table, keccak_table, r)`
+ *      loop (src/zkevm_specs/bytecode_circuit.py:37-100; loop tests/test_bytecode_circuit.py:26-47, next row
+ *      wraps modulo n).  rows: column-major uint64[12][n][4] (Row, bytecode_circuit.py:15-26: q_first,
+ *      q_last, hash lo, hi, tag, index, value, is_code, push_data_left, value_rlc, length,
+ *      push_data_size); keccak: uint64[m][5][4] (KeccakTableRow, table.py:511-515); randomness: one
+ *      cell (keccak_randomness).  The push table (:174-179) is evaluated in closed form. */
+int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak,
+                     const uint64_t* randomness, uint32_t opts, zk_session** out);
+int zk_bytecode_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak,
+                       const uint64_t* randomness, uint32_t opts, uint32_t* status_out, zk_result* result);
+
+/* ---- Exp circuit: replaces the loop of verify_exp_circuit (src/zkevm_specs/exp_circuit.py:88-97,
+ *      verify_step :14-85; next row wraps).  rows: column-major uint64[21][n][4] (ExpCircuitRow,
+ *      table.py:519-535: q_usable, is_step, identifier, is_last, base, exponent, exponentiation,
+ *      a, b, c, d, q as lo/hi pairs, r). */
+int zk_exp_open(const uint64_t* rows, uint64_t n, uint32_t opts, zk_session** out);
+int zk_exp_verify(const uint64_t* rows, uint64_t n, uint32_t opts, uint32_t* status_out, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

@@ -134,3 +134,27 @@ extern "C" void sim_divmod(int wide, const u64* n, const u64* d, u64* q, u64* r,
         for (int k = 0; k < 4; k++) r[4 * i + k] = (u64)rr.v[2 * k] | ((u64)rr.v[2 * k + 1] << 32);
     }
 }
+
+// ---- Bytecode / Exp circuits -------------------------------------------------------------------
+#include "../../zkevm_specs_amd/csrc/row_circuits.hpp"
+
+extern "C" int sim_bytecode_verify(const u64* cells, u64 n, const u64* keccak, u64 n_keccak, const u64* r, u32* status) {
+    BytecodeArgs a;
+    a.rows.cells = cells;
+    a.rows.flags = nullptr;
+    a.rows.n = n;
+    HostTable kt;
+    host_table(kt, keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    a.keccak = kt.t;
+    a.r = fr_load(r);
+    for (u64 i = 0; i < n; i++) status[i] = bytecode_check_row(a, i);
+    return 0;
+}
+extern "C" int sim_exp_verify(const u64* cells, u64 n, u32* status) {
+    ExpArgs a;
+    a.rows.cells = cells;
+    a.rows.flags = nullptr;
+    a.rows.n = n;
+    for (u64 i = 0; i < n; i++) status[i] = exp_check_row(a, i);
+    return 0;
+}

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -77,6 +77,10 @@ def load():
     lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_evm_open.argtypes = [ctypes.POINTER(ZkEvmTables), u32, ctypes.POINTER(vp)]
     lib.zk_evm_verify.argtypes = [ctypes.POINTER(ZkEvmTables), u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_bytecode_open.argtypes = [vp, u64, vp, u64, vp, u32, ctypes.POINTER(vp)]
+    lib.zk_bytecode_verify.argtypes = [vp, u64, vp, u64, vp, u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_exp_open.argtypes = [vp, u64, u32, ctypes.POINTER(vp)]
+    lib.zk_exp_verify.argtypes = [vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_launch.argtypes = [vp, vp]
     lib.zk_collect.argtypes = [vp, ctypes.POINTER(ZkResult)]
     lib.zk_read_status.argtypes = [vp, vp]

@@ -1,0 +1,39 @@
+"""Host-side mirror of the reference's Bytecode-circuit interface, evaluated on the MI355X.
+
+Reference seam (src/zkevm_specs/bytecode_circuit.py): `check_bytecode_row(cur, next, push_table,
+keccak_table, keccak_randomness)` :37 is called per row by the driver loop of the reference's
+tests (tests/test_bytecode_circuit.py:26-47, next row wraps modulo n).  `verify_bytecode_rows` is
+that loop as one device pass.  A failing row raises AssertionError like the reference.
+"""
+from . import engine
+from .errors import KIND_ASSERT, exception_for_code, raise_for_code
+from .flatten import _n, flatten_bytecode_rows, flatten_keccak_table
+
+
+def verify_bytecode_rows(rows, keccak_table, keccak_randomness, success=True):
+    cols = flatten_bytecode_rows(rows)
+    kt = flatten_keccak_table(keccak_table)
+    with engine.open_bytecode(cols, kt, _n(keccak_randomness)) as s:
+        res = s.run()
+    exception = None
+    if not res.ok:
+        exc = exception_for_code(res.first_fail_code, f"Bytecode circuit row {res.first_fail_row}")
+        if res.first_fail_kind != KIND_ASSERT:
+            raise exc
+        exception = exc
+    if success:
+        if exception:
+            raise exception
+    else:
+        assert exception is not None
+    return res
+
+
+def check_bytecode_row(cur, next, push_table, keccak_table, keccak_randomness):
+    """Single-row form with the reference's signature (`push_table` is implied: opcode.py:432)."""
+    cols = flatten_bytecode_rows([cur, next])
+    kt = flatten_keccak_table(keccak_table)
+    with engine.open_bytecode(cols, kt, _n(keccak_randomness)) as s:
+        s.run()
+        status = s.read_status()
+    raise_for_code(int(status[0]), "Bytecode circuit row")

@@ -10,6 +10,7 @@
 #include "state_circuit.hpp"
 #include "evm_circuit.hpp"
 #include "host_index.hpp"
+#include "row_circuits.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -210,6 +211,29 @@ __global__ void evm_state_scatter_kernel(const u64* steps, u32 n_pairs, u32* cur
     if (i < n_pairs) perm[base[bin] + rank] = i;
 }
 
+// ---------------------------------------------------------------------------------------
+// Bytecode / Exp circuit kernels: one lane per row, column-major witness (coalesced), next row
+// re-read through L1/L2 (wraps modulo n).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.rows.n) {
+        code = bytecode_check_row(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
+__global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.rows.n) {
+        code = exp_check_row(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
+
 __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -228,7 +252,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4 };
 
 struct zk_session {
     SessionKind kind;
@@ -240,6 +264,8 @@ struct zk_session {
     u32 launches = 0;               // since last collect
     StateArgs state;
     EvmArgs evm;
+    BytecodeArgs bytecode;
+    ExpArgs exp;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -472,6 +498,81 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     return rc;
 }
 
+extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak,
+                                const uint64_t* randomness, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_bytecode_open: call zk_init first");
+    ARG_TRY(out && rows && randomness && n > 0 && n < (1ull << 32) && n_keccak < (1ull << 31), "zk_bytecode_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_BYTECODE;
+    s->n = n;
+    int rc = 0;
+    const void* p = nullptr;
+    u64 rh[4];
+    if ((rc = stage(s, rows, (size_t)n * BC_NCELLS * 32, dev, &p))) goto fail;
+    s->bytecode.rows.cells = (const u64*)p;
+    s->bytecode.rows.flags = nullptr;
+    s->bytecode.rows.n = n;
+    if ((rc = table_stage(s, s->bytecode.keccak, keccak, nullptr, n_keccak, KECCAK_NCELLS, dev))) goto fail;
+    if ((rc = build_index<keccak_key_hash>(s, s->bytecode.keccak))) goto fail;
+    if (dev) {
+        if (hipMemcpy(rh, randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, randomness, 32);
+    }
+    for (int k = 0; k < 4; k++) { s->bytecode.r.v[2 * k] = (u32)rh[k]; s->bytecode.r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+
+extern "C" int zk_exp_open(const uint64_t* rows, uint64_t n, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_exp_open: call zk_init first");
+    ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_exp_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_EXP;
+    s->n = n;
+    int rc = 0;
+    const void* p = nullptr;
+    if ((rc = stage(s, rows, (size_t)n * EX_NCELLS * 32, dev, &p))) goto fail;
+    s->exp.rows.cells = (const u64*)p;
+    s->exp.rows.flags = nullptr;
+    s->exp.rows.n = n;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+
+static int one_shot(zk_session* s, bool dev, uint32_t* status_out, zk_result* result) {
+    int rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_bytecode_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak,
+                                  const uint64_t* randomness, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_bytecode_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_bytecode_open(rows, n, keccak, n_keccak, randomness, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+extern "C" int zk_exp_verify(const uint64_t* rows, uint64_t n, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_exp_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_exp_open(rows, n, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+
 extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
     ARG_TRY(s && s->kind == SESSION_STATE, "zk_state_set_range: not a State session");
     ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_state_set_range: bad range");
@@ -512,6 +613,16 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const int block = 256;
         const u32 grid = (u32)((s->state.eval_hi - s->state.eval_lo + block - 1) / block);
         hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, s->d_tally);
+        break;
+    }
+    case SESSION_BYTECODE: {
+        const u32 grid = (u32)((s->n + 255) / 256);
+        hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->bytecode, status, s->d_tally);
+        break;
+    }
+    case SESSION_EXP: {
+        const u32 grid = (u32)((s->n + 255) / 256);
+        hipLaunchKernelGGL(exp_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->exp, status, s->d_tally);
         break;
     }
     case SESSION_EVM: {

@@ -141,6 +141,29 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
     return Session(h, int(a["steps"].shape[0]) - 1, arrs)
 
 
+def open_bytecode(rows, keccak, randomness, device=None):
+    """rows uint64[12, n, 4], keccak uint64[m, 5, 4], randomness uint64[4] (or an int) -> Session"""
+    lib = _lib.init(device)
+    if isinstance(randomness, int):
+        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    (rows, keccak, randomness), opts = _prep([rows, keccak, randomness])
+    n = rows.shape[1]
+    m = keccak.shape[0] if keccak is not None else 0
+    h = ctypes.c_void_p()
+    check(lib.zk_bytecode_open(_lib.ptr(rows), n, _lib.ptr(keccak) if m else None, m, _lib.ptr(randomness), opts,
+                               ctypes.byref(h)), "zk_bytecode_open")
+    return Session(h, n, (rows, keccak, randomness))
+
+
+def open_exp(rows, device=None):
+    """rows uint64[21, n, 4] -> Session"""
+    lib = _lib.init(device)
+    (rows,), opts = _prep([rows])
+    h = ctypes.c_void_p()
+    check(lib.zk_exp_open(_lib.ptr(rows), rows.shape[1], opts, ctypes.byref(h)), "zk_exp_open")
+    return Session(h, rows.shape[1], (rows,))
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

@@ -154,3 +154,35 @@ def flatten_evm(tables, steps):
         "tx": tx, "tx_flags": tx_flags,
         "block": blk, "block_flags": blk_flags,
     }
+
+
+# ---- Bytecode / Exp circuits ------------------------------------------------------------------------
+BYTECODE_ROW_NCELLS = 12
+KECCAK_NCELLS = 5
+EXP_NCELLS = 21
+
+
+def flatten_bytecode_rows(rows):
+    """bytecode_circuit.Row (bytecode_circuit.py:15-26) -> uint64[12, n, 4] column-major"""
+    cells = [[_n(r.q_first), _n(r.q_last), _n(r.hash.lo), _n(r.hash.hi), _n(r.tag), _n(r.index), _n(r.value),
+              _n(r.is_code), _n(r.push_data_left), _n(r.value_rlc), _n(r.length), _n(r.push_data_size)] for r in rows]
+    return rows_to_colmajor(cells, BYTECODE_ROW_NCELLS)
+
+
+def flatten_keccak_table(keccak_table):
+    """set of KeccakTableRow (evm_circuit/table.py:511-515) -> uint64[m, 5, 4]"""
+    rows = sorted(set((_n(k.state_tag), _n(k.input_rlc), _n(k.input_len), _n(k.output.lo), _n(k.output.hi))
+                      for k in _iter_table(keccak_table)))
+    return rows_to_rowmajor([list(r) for r in rows], KECCAK_NCELLS)
+
+
+def flatten_exp_rows(rows):
+    """ExpCircuitRow (evm_circuit/table.py:519-535) -> uint64[21, n, 4] column-major"""
+    cells = []
+    for r in rows:
+        c = [_n(r.q_usable), _n(r.is_step), _n(r.identifier), _n(r.is_last)]
+        for w in (r.base, r.exponent, r.exponentiation, r.a, r.b, r.c, r.d, r.q):
+            c += [_n(w.lo), _n(w.hi)]
+        c.append(_n(r.r))
+        cells.append(c)
+    return rows_to_colmajor(cells, EXP_NCELLS)

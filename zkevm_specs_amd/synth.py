@@ -269,3 +269,94 @@ def synth_state_witness(n, seed=2):
     mpt[:, 10, 0:2] = init[ui][:, 0:2]
     mpt[:, 11, 0:2] = init[ui][:, 2:4]
     return cols, flags, mpt
+
+
+# ---- Bytecode circuit (config 1) ---------------------------------------------------------------
+EMPTY_HASH = 0xC5D2460186F7233C927E7DB2DCC703C0E500B653CA82273B7BFAD8045D85A470  # keccak256("")
+_FR_P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def synth_bytecode_witness(codes, k, r, digest=None):
+    """Witness of the Bytecode circuit for the byte strings `codes` padded to 2^k rows, following
+    the row semantics of assign_bytecode_circuit (bytecode_circuit.py:104-167): one Header row
+    + one Byte row per byte, value_rlc' = value_rlc * r + byte, push-data tracking, EMPTY_HASH
+    padding headers.  Returns (rows uint64[12, 2^k, 4], keccak uint64[m, 5, 4]).
+
+    `digest(code) -> int` supplies the code hash; the circuit only checks that (rlc, length, hash)
+    is a keccak-table row, so the default is a synthetic 256-bit digest (no keccak needed here)."""
+    import hashlib
+
+    from .wire import rows_to_colmajor, rows_to_rowmajor
+
+    if digest is None:
+        digest = lambda c: int.from_bytes(hashlib.blake2b(c, digest_size=32).digest(), "big")  # noqa: E731
+    n = 1 << k
+    rows, keccak = [], set()
+    for code in codes:
+        h = digest(code)
+        lo, hi = h & ((1 << 128) - 1), h >> 128
+        if len(rows) < n:
+            rows.append([0, 0, lo, hi, 1, 0, len(code), 0, 0, 0, len(code), 0])
+        rlc, left = 0, 0
+        for idx, b in enumerate(code):
+            is_code = left == 0
+            size = b - 0x5F if 0x60 <= b <= 0x7F else 0
+            rlc = (rlc * r + b) % _FR_P
+            if len(rows) < n:
+                rows.append([0, 0, lo, hi, 2, idx, b, int(is_code), left, rlc, len(code), size])
+            left = size if is_code else left - 1
+        keccak.add((2, rlc, len(code), lo, hi))
+    e_lo, e_hi = EMPTY_HASH & ((1 << 128) - 1), EMPTY_HASH >> 128
+    while len(rows) < n:
+        rows.append([0, 0, e_lo, e_hi, 1, 0, 0, 0, 0, 0, 0, 0])
+    rows[0][0] = 1
+    rows[n - 1][1] = 1
+    return rows_to_colmajor(rows, 12), rows_to_rowmajor([list(x) for x in sorted(keccak)], 5)
+
+
+# ---- Exp circuit ------------------------------------------------------------------------------------
+def synth_exp_witness(n_rows, seed=5):
+    """Square-and-multiply traces (ExpCircuit.add_event semantics, evm_circuit/typing.py:880-939)
+    for random (base, exponent) events, padded with dummy rows (:941-962) to n_rows."""
+    import random
+
+    from .wire import rows_to_colmajor
+
+    rng = random.Random(seed)
+    M = (1 << 256) - 1
+    lo_hi = lambda v: [v & ((1 << 128) - 1), v >> 128]  # noqa: E731
+    rows = []
+    ident = 1
+    while True:
+        base = rng.getrandbits(rng.choice([8, 64, 160, 256]))
+        exponent = rng.getrandbits(rng.choice([2, 5, 16, 64, 256])) + 2
+        steps = []
+
+        def rec(e):
+            if e == 0:
+                return 1
+            if e == 1:
+                return base
+            e1 = rec(e // 2)
+            e2 = (e1 * e1) & M
+            steps.append((e1, e1, e2))
+            if e % 2 == 0:
+                return e2
+            ex = (base * e2) & M
+            steps.append((e2, base, ex))
+            return ex
+
+        rec(exponent)
+        steps.reverse()
+        if len(rows) + len(steps) > n_rows:
+            break
+        e = exponent
+        for i, (a, b, d) in enumerate(steps):
+            q, odd = divmod(e, 2)
+            rows.append([1, 1, ident, int(i == len(steps) - 1)] + lo_hi(base) + lo_hi(e) + lo_hi(d) + lo_hi(a) + lo_hi(b)
+                        + [0, 0] + lo_hi(d) + lo_hi(q) + [odd])
+            e = e // 2 if odd == 0 else e - 1
+        ident += rng.randrange(1, 50)
+    while len(rows) < n_rows:
+        rows.append([1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1])
+    return rows_to_colmajor(rows, 21)
