@@ -123,6 +123,22 @@ int zk_bytecode_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak,
 int zk_exp_open(const uint64_t* rows, uint64_t n, uint32_t opts, zk_session** out);
 int zk_exp_verify(const uint64_t* rows, uint64_t n, uint32_t opts, uint32_t* status_out, zk_result* result);
 
+/* ---- Copy circuit: replaces the loop of verify_copy_table (src/zkevm_specs/copy_circuit.py:92-130:
+ *      verify_row :23-59 + verify_step :62-89 on the window (i, i+1, i+2) mod n, then the RW / bytecode /
+ *      tx lookups of row i).  rows: column-major uint64[20][n][4] (CopyCircuitRow, table.py:472-491: q_step,
+ *      is_first, is_last, id lo, hi, tag, addr, src_addr_end, bytes_left, value, rlc_acc, is_code, is_pad,
+ *      rw_counter, rwc_inc_left, is_memory, is_bytecode, is_tx_calldata, is_tx_log, is_rlc_acc) + row_flags
+ *      (bit0 id.is_word); randomness: one cell; tables as for the EVM circuit. */
+typedef struct zk_copy_tables {
+    const uint64_t* rows;       const uint32_t* row_flags;   uint64_t n_rows;
+    const uint64_t* randomness;
+    const uint64_t* rw;         const uint32_t* rw_flags;    uint64_t n_rw;
+    const uint64_t* bytecode;   uint64_t n_bytecode;
+    const uint64_t* tx;         const uint32_t* tx_flags;    uint64_t n_tx;
+} zk_copy_tables;
+int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session** out);
+int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

@@ -158,3 +158,27 @@ extern "C" int sim_exp_verify(const u64* cells, u64 n, u32* status) {
     for (u64 i = 0; i < n; i++) status[i] = exp_check_row(a, i);
     return 0;
 }
+
+// ---- Copy circuit ------------------------------------------------------------------------------
+#include "../../zkevm_specs_amd/csrc/copy_circuit.hpp"
+
+extern "C" int sim_copy_verify(const u64* cells, const u32* flags, u64 n, const u64* r, const u64* rw, const u32* rw_flags,
+                               u64 n_rw, const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
+                               u32 generic_index, u32* status) {
+    CopyArgs a;
+    a.rows.cells = cells;
+    a.rows.flags = flags;
+    a.rows.n = n;
+    HostTable trw, tbc, ttx;
+    host_table(trw, rw, rw_flags, n_rw, RW_NCELLS, rw_key_hash);
+    host_table(tbc, bytecode, nullptr, n_bc, BYTECODE_NCELLS, bc_key_hash);
+    host_table(ttx, tx, tx_flags, n_tx, TX_NCELLS, tx_key_hash);
+    a.rw = trw.t;
+    a.bytecode = tbc.t;
+    a.tx = ttx.t;
+    ZkRwMeta meta = rw_dense_meta_host(rw, n_rw);
+    a.rw_meta = generic_index ? nullptr : &meta;
+    a.r = fr_load(r);
+    for (u64 i = 0; i < n; i++) status[i] = copy_check_row(a, i);
+    return 0;
+}

@@ -11,6 +11,7 @@
 #include "evm_circuit.hpp"
 #include "host_index.hpp"
 #include "row_circuits.hpp"
+#include "copy_circuit.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -224,6 +225,15 @@ __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32*
     }
     tally_commit(tally, i, code);
 }
+__global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.rows.n) {
+        code = copy_check_row(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 __global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
@@ -252,7 +262,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5 };
 
 struct zk_session {
     SessionKind kind;
@@ -266,6 +276,7 @@ struct zk_session {
     EvmArgs evm;
     BytecodeArgs bytecode;
     ExpArgs exp;
+    CopyArgs copy;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -550,6 +561,69 @@ fail:
     return rc;
 }
 
+// dense RW-index metadata (see ZkRwMeta), verified on the device
+static int build_rw_meta(zk_session* s, const ZkTable& rw, const ZkRwMeta** out) {
+    ZkRwMeta* d_meta = nullptr;
+    int rc = dev_alloc(s, (void**)&d_meta, sizeof(ZkRwMeta));
+    if (rc) return rc;
+    ZkRwMeta init;
+    init.dense = rw.n ? 1u : 0u;
+    init.pad = 0;
+    init.base = 0;
+    HIP_TRY(hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));  // `init` lives on this stack frame
+    if (rw.n) hipLaunchKernelGGL(rw_dense_check_kernel, dim3((rw.n + 255) / 256), dim3(256), 0, g_stream, rw, d_meta);
+    *out = d_meta;
+    return 0;
+}
+
+extern "C" int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_copy_open: call zk_init first");
+    ARG_TRY(t && out && t->rows && t->randomness && t->n_rows > 0 && t->n_rows < (1ull << 32), "zk_copy_open: bad arguments");
+    ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31), "zk_copy_open: table too large");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_COPY;
+    s->n = t->n_rows;
+    int rc = 0;
+    const void* p = nullptr;
+    u64 rh[4];
+    if ((rc = stage(s, t->rows, (size_t)t->n_rows * CP_NCELLS * 32, dev, &p))) goto fail;
+    s->copy.rows.cells = (const u64*)p;
+    if ((rc = stage(s, t->row_flags, (size_t)t->n_rows * 4, dev, &p))) goto fail;
+    s->copy.rows.flags = t->row_flags ? (const u32*)p : nullptr;
+    s->copy.rows.n = t->n_rows;
+    if ((rc = table_stage(s, s->copy.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->copy.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->copy.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
+    if ((rc = build_index<rw_key_hash>(s, s->copy.rw))) goto fail;
+    if ((rc = build_index<bc_key_hash>(s, s->copy.bytecode))) goto fail;
+    if ((rc = build_index<tx_key_hash>(s, s->copy.tx))) goto fail;
+    s->copy.rw_meta = nullptr;
+    if (!(opts & ZK_OPT_GENERIC_INDEX) && (rc = build_rw_meta(s, s->copy.rw, &s->copy.rw_meta))) goto fail;
+    if (dev) {
+        if (hipMemcpy(rh, t->randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, t->randomness, 32);
+    }
+    for (int k = 0; k < 4; k++) { s->copy.r.v[2 * k] = (u32)rh[k]; s->copy.r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+
+static int one_shot(zk_session* s, bool dev, uint32_t* status_out, zk_result* result);
+extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_copy_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_copy_open(t, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+
 static int one_shot(zk_session* s, bool dev, uint32_t* status_out, zk_result* result) {
     int rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
     if (!rc) rc = zk_collect(s, result);
@@ -618,6 +692,11 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_BYTECODE: {
         const u32 grid = (u32)((s->n + 255) / 256);
         hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->bytecode, status, s->d_tally);
+        break;
+    }
+    case SESSION_COPY: {
+        const u32 grid = (u32)((s->n + 255) / 256);
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->copy, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

@@ -164,6 +164,31 @@ def open_exp(rows, device=None):
     return Session(h, rows.shape[1], (rows,))
 
 
+def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags, device=None, generic_index=False):
+    """Copy circuit session: rows uint64[20, n, 4] + flags, randomness (int or uint64[4]), EVM-format tables."""
+    lib = _lib.init(device)
+    if isinstance(randomness, int):
+        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    arrs, opts = _prep([rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags])
+    rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags = arrs
+
+    def nrows(x):
+        return 0 if x is None else int(x.shape[0])
+
+    def p(x, n=1):
+        v = _lib.ptr(x) if n else None
+        return v.value if v is not None else None
+
+    t = _lib.ZkCopyTables(p(rows), p(row_flags), int(rows.shape[1]), p(randomness),
+                          p(rw, nrows(rw)), p(rw_flags, nrows(rw)), nrows(rw), p(bytecode, nrows(bytecode)), nrows(bytecode),
+                          p(tx, nrows(tx)), p(tx_flags, nrows(tx)), nrows(tx))
+    if generic_index:
+        opts |= _lib.OPT_GENERIC_INDEX
+    h = ctypes.c_void_p()
+    check(lib.zk_copy_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_copy_open")
+    return Session(h, int(rows.shape[1]), arrs)
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

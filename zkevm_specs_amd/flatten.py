@@ -186,3 +186,20 @@ def flatten_exp_rows(rows):
         c.append(_n(r.r))
         cells.append(c)
     return rows_to_colmajor(cells, EXP_NCELLS)
+
+
+# ---- Copy circuit --------------------------------------------------------------------------------------
+COPY_NCELLS = 20
+
+
+def flatten_copy_rows(rows):
+    """CopyCircuitRow (evm_circuit/table.py:472-491) -> (uint64[20, n, 4] column-major, uint32 flags[n])"""
+    cells, flags = [], []
+    for r in rows:
+        lo, hi, w = _word_cells(r.id)
+        cells.append([_n(r.q_step), _n(r.is_first), _n(r.is_last), lo, hi, _n(r.tag), _n(r.addr), _n(r.src_addr_end),
+                      _n(r.bytes_left), _n(r.value), _n(r.rlc_acc), _n(r.is_code), _n(r.is_pad), _n(r.rw_counter),
+                      _n(r.rwc_inc_left), _n(r.is_memory), _n(r.is_bytecode), _n(r.is_tx_calldata), _n(r.is_tx_log),
+                      _n(r.is_rlc_acc)])
+        flags.append(1 if w else 0)
+    return rows_to_colmajor(cells, COPY_NCELLS), np.array(flags, dtype=np.uint32)
