@@ -39,6 +39,7 @@ enum zk_kind {
     ZK_KIND_OVERFLOW_ERROR = 8,
     ZK_KIND_VALUE_ERROR = 9,
     ZK_KIND_ZERO_DIVISION = 10,
+    ZK_KIND_INDEX_ERROR = 12,
     ZK_KIND_NAME_ERROR = 11,          /* UnboundLocalError (execution/block_ctx.py:24) */
     ZK_KIND_UNSUPPORTED = 15          /* gadget not implemented by this engine */
 };
@@ -138,6 +139,25 @@ typedef struct zk_copy_tables {
 } zk_copy_tables;
 int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session** out);
 int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result);
+
+/* ---- Tx and Sig circuits: replace the per-tx loop of tx_circuit.verify_circuit (src/zkevm_specs/tx_circuit.py:
+ *      253-291: SignVerifyChip.verify :205-243 + the copy constraints to the tx-table rows) and the per-row
+ *      loop of sig_circuit.verify_circuit (sig_circuit.py:113-122: Row.verify :64-104).  One unit = one tx
+ *      slot / one signature row.  bytes: uint8[n][9][32] (pk_x, pk_y, ecdsa pk_x, pk_y, msg_hash_bytes, ecdsa
+ *      msg_hash_bytes, pub_key_hash, ecdsa sig_r LE, ecdsa sig_s LE); cells: column-major uint64[8][n][4]
+ *      (address, msg_hash lo, hi, sig_v, sig_r lo, hi, sig_s lo, hi); meta: uint32[n][4] (ecdsa_status: 0
+ *      verified / 1 not verified / (kind<<24) exception of the third-party secp256k1 call, expected is_valid,
+ *      malformed-attribute mask, 0); keccak: uint64[m][5][4] (is_enabled, input_rlc, input_len, output lo, hi;
+ *      tx_circuit.py:38-61); tx_rows: uint64[rows][5][4] + flags (Tx circuit only). */
+typedef struct zk_sign_units {
+    const uint8_t* bytes;       const uint64_t* cells;       const uint32_t* meta;      uint64_t n_units;
+    const uint64_t* randomness;
+    const uint64_t* keccak;     uint64_t n_keccak;
+    const uint64_t* tx_rows;    const uint32_t* tx_flags;    uint64_t n_tx_rows;
+    uint32_t is_sig;            /* 0 = Tx circuit semantics, 1 = Sig circuit semantics */
+} zk_sign_units;
+int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** out);
+int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* status_out, zk_result* result);
 
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of

@@ -11,6 +11,7 @@ OVERFLOW_ERROR = 8
 VALUE_ERROR = 9
 ZERO_DIVISION = 10
 NAME_ERROR = 11
+INDEX_ERROR = 12
 UNSUPPORTED = 15
 
 KIND_NAMES = {
@@ -18,7 +19,7 @@ KIND_NAMES = {
     LOOKUP_UNSAT: "LookupUnsatFailure", LOOKUP_AMBIGUOUS: "LookupAmbiguousFailure",
     WRONG_QUERY_KEY: "WrongQueryKey", NOT_IMPLEMENTED: "NotImplementedError",
     TYPE_ERROR: "TypeError", OVERFLOW_ERROR: "OverflowError", VALUE_ERROR: "ValueError",
-    ZERO_DIVISION: "ZeroDivisionError", NAME_ERROR: "NameError", UNSUPPORTED: "Unsupported",
+    ZERO_DIVISION: "ZeroDivisionError", NAME_ERROR: "NameError", INDEX_ERROR: "IndexError", UNSUPPORTED: "Unsupported",
 }
 NAME_TO_KIND = {v: k for k, v in KIND_NAMES.items()}
 

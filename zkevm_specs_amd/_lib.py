@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -46,6 +46,16 @@ class ZkCopyTables(ctypes.Structure):
         ("rw", ctypes.c_void_p), ("rw_flags", ctypes.c_void_p), ("n_rw", ctypes.c_uint64),
         ("bytecode", ctypes.c_void_p), ("n_bytecode", ctypes.c_uint64),
         ("tx", ctypes.c_void_p), ("tx_flags", ctypes.c_void_p), ("n_tx", ctypes.c_uint64),
+    ]
+
+
+class ZkSignUnits(ctypes.Structure):
+    _fields_ = [
+        ("bytes", ctypes.c_void_p), ("cells", ctypes.c_void_p), ("meta", ctypes.c_void_p), ("n_units", ctypes.c_uint64),
+        ("randomness", ctypes.c_void_p),
+        ("keccak", ctypes.c_void_p), ("n_keccak", ctypes.c_uint64),
+        ("tx_rows", ctypes.c_void_p), ("tx_flags", ctypes.c_void_p), ("n_tx_rows", ctypes.c_uint64),
+        ("is_sig", ctypes.c_uint32),
     ]
 
 
@@ -93,6 +103,8 @@ def load():
     lib.zk_exp_verify.argtypes = [vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_copy_open.argtypes = [ctypes.POINTER(ZkCopyTables), u32, ctypes.POINTER(vp)]
     lib.zk_copy_verify.argtypes = [ctypes.POINTER(ZkCopyTables), u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_sign_open.argtypes = [ctypes.POINTER(ZkSignUnits), u32, ctypes.POINTER(vp)]
+    lib.zk_sign_verify.argtypes = [ctypes.POINTER(ZkSignUnits), u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_launch.argtypes = [vp, vp]
     lib.zk_collect.argtypes = [vp, ctypes.POINTER(ZkResult)]
     lib.zk_read_status.argtypes = [vp, vp]

@@ -12,6 +12,7 @@
 #include "host_index.hpp"
 #include "row_circuits.hpp"
 #include "copy_circuit.hpp"
+#include "sign_circuit.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -234,6 +235,16 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status,
     }
     tally_commit(tally, i, code);
 }
+// Tx / Sig circuits: one lane per tx slot / signature row (units are independent: no halo).
+__global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.cells.n) {
+        code = sign_check_unit(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 __global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
@@ -262,7 +273,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6 };
 
 struct zk_session {
     SessionKind kind;
@@ -277,6 +288,7 @@ struct zk_session {
     BytecodeArgs bytecode;
     ExpArgs exp;
     CopyArgs copy;
+    SignArgs sign;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -616,6 +628,53 @@ fail:
 }
 
 static int one_shot(zk_session* s, bool dev, uint32_t* status_out, zk_result* result);
+extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_sign_open: call zk_init first");
+    ARG_TRY(t && out && t->bytes && t->cells && t->meta && t->randomness && t->n_units > 0 && t->n_units < (1ull << 32),
+            "zk_sign_open: bad arguments");
+    ARG_TRY(t->n_keccak < (1ull << 31) && t->n_tx_rows < (1ull << 32), "zk_sign_open: table too large");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_SIGN;
+    s->n = t->n_units;
+    int rc = 0;
+    const void* p = nullptr;
+    u64 rh[4];
+    if ((rc = stage(s, t->bytes, (size_t)t->n_units * SG_NBYTES_ROWS * 32, dev, &p))) goto fail;
+    s->sign.bytes = (const uint8_t*)p;
+    if ((rc = stage(s, t->cells, (size_t)t->n_units * SG_NCELLS * 32, dev, &p))) goto fail;
+    s->sign.cells.cells = (const u64*)p;
+    s->sign.cells.flags = nullptr;
+    s->sign.cells.n = t->n_units;
+    if ((rc = stage(s, t->meta, (size_t)t->n_units * 16, dev, &p))) goto fail;
+    s->sign.meta = (const u32*)p;
+    if ((rc = table_stage(s, s->sign.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
+    if ((rc = build_index<keccak_key_hash>(s, s->sign.keccak))) goto fail;
+    if ((rc = table_stage(s, s->sign.tx_rows, t->tx_rows, t->tx_flags, t->n_tx_rows, TX_NCELLS, dev))) goto fail;
+    s->sign.tx_rows.slots = nullptr;
+    s->sign.tx_rows.mask = 0;
+    s->sign.is_sig = t->is_sig ? 1u : 0u;
+    if (dev) {
+        if (hipMemcpy(rh, t->randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, t->randomness, 32);
+    }
+    for (int k = 0; k < 4; k++) { s->sign.r.v[2 * k] = (u32)rh[k]; s->sign.r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_sign_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_sign_open(t, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -697,6 +756,11 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_COPY: {
         const u32 grid = (u32)((s->n + 255) / 256);
         hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->copy, status, s->d_tally);
+        break;
+    }
+    case SESSION_SIGN: {
+        const u32 grid = (u32)((s->n + 255) / 256);
+        hipLaunchKernelGGL(sign_units_kernel, dim3(grid), dim3(256), 0, g_stream, s->sign, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

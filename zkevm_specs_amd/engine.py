@@ -189,6 +189,31 @@ def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags,
     return Session(h, int(rows.shape[1]), arrs)
 
 
+def open_sign(wire, randomness, is_sig, device=None):
+    """Tx / Sig circuit session over `wire` = dict(bytes, cells, meta, keccak, tx_rows, tx_flags)."""
+    lib = _lib.init(device)
+    if isinstance(randomness, int):
+        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    names = ["bytes", "cells", "meta", "keccak", "tx_rows", "tx_flags"]
+    arrs, opts = _prep([wire.get(k) for k in names] + [randomness])
+    a = dict(zip(names + ["r"], arrs))
+
+    def nrows(x):
+        return 0 if x is None else int(x.shape[0])
+
+    def p(x, n=1):
+        v = _lib.ptr(x) if n else None
+        return v.value if v is not None else None
+
+    n = int(a["bytes"].shape[0])
+    t = _lib.ZkSignUnits(p(a["bytes"]), p(a["cells"]), p(a["meta"]), n, p(a["r"]), p(a["keccak"], nrows(a["keccak"])),
+                         nrows(a["keccak"]), p(a["tx_rows"], nrows(a["tx_rows"])), p(a["tx_flags"], nrows(a["tx_rows"])),
+                         nrows(a["tx_rows"]), int(bool(is_sig)))
+    h = ctypes.c_void_p()
+    check(lib.zk_sign_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_sign_open")
+    return Session(h, n, arrs)
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

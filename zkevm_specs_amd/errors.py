@@ -31,12 +31,12 @@ class UnsupportedOnDevice(Exception):
 
 KIND_OK, KIND_ASSERT, KIND_CONSTRAINT, KIND_LOOKUP_UNSAT, KIND_LOOKUP_AMBIGUOUS = 0, 1, 2, 3, 4
 KIND_WRONG_QUERY_KEY, KIND_NOT_IMPLEMENTED, KIND_TYPE_ERROR, KIND_OVERFLOW_ERROR = 5, 6, 7, 8
-KIND_VALUE_ERROR, KIND_ZERO_DIVISION, KIND_NAME_ERROR, KIND_UNSUPPORTED = 9, 10, 11, 15
+KIND_VALUE_ERROR, KIND_ZERO_DIVISION, KIND_NAME_ERROR, KIND_INDEX_ERROR, KIND_UNSUPPORTED = 9, 10, 11, 12, 15
 
 KIND_NAMES = {
     0: "ok", 1: "AssertionError", 2: "ConstraintUnsatFailure", 3: "LookupUnsatFailure",
     4: "LookupAmbiguousFailure", 5: "WrongQueryKey", 6: "NotImplementedError", 7: "TypeError",
-    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 11: "UnboundLocalError", 15: "UnsupportedOnDevice",
+    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 11: "UnboundLocalError", 12: "IndexError", 15: "UnsupportedOnDevice",
 }
 
 
@@ -65,6 +65,8 @@ def exception_for_code(code, where=""):
         return ZeroDivisionError(msg)
     if kind == KIND_NAME_ERROR:
         return UnboundLocalError(msg)
+    if kind == KIND_INDEX_ERROR:
+        return IndexError(msg)
     if kind == KIND_UNSUPPORTED:
         return UnsupportedOnDevice(msg)
     return RuntimeError(f"{msg} (unknown kind {kind})")
@@ -73,3 +75,13 @@ def exception_for_code(code, where=""):
 def raise_for_code(code, where=""):
     if code != 0:
         raise exception_for_code(code, where)
+
+
+def kind_for_exception(e):
+    """Status-code kind of a Python exception instance (inverse of exception_for_code)."""
+    names = {v: k for k, v in KIND_NAMES.items()}
+    names["NameError"] = KIND_NAME_ERROR
+    for cls in type(e).__mro__:
+        if cls.__name__ in names:
+            return names[cls.__name__]
+    return KIND_UNSUPPORTED

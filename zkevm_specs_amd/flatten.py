@@ -203,3 +203,92 @@ def flatten_copy_rows(rows):
                       _n(r.is_rlc_acc)])
         flags.append(1 if w else 0)
     return rows_to_colmajor(cells, COPY_NCELLS), np.array(flags, dtype=np.uint32)
+
+
+# ---- Tx / Sig circuits ------------------------------------------------------------------------------------
+SIGN_NBYTES_ROWS = 9
+SIGN_NCELLS = 8
+
+
+def _b32(x):
+    """32 byte values, or None when the attribute is not a 32-byte bytes object (the reference's tests
+    assign e.g. `Word(1)` to such attributes: every use then fails a type assert -> `malformed` bit)."""
+    if not isinstance(x, (bytes, bytearray)) or len(x) != 32:
+        return None
+    return list(bytes(x))
+
+
+def _byte_rows(fields):
+    rows, malformed = [], 0
+    for k, f in enumerate(fields):
+        b = _b32(f)
+        if b is None:
+            malformed |= 1 << k
+            b = [0] * 32
+        rows.append(b)
+    return rows, malformed
+
+
+def _ecdsa_status(call, returns_bool):
+    """Outcome of the reference-style ECDSA chip's verify(): 0 verified, 1 not verified (returned False /
+    asserted), otherwise (kind << 24) of the exception it raised — the pre-computed `ecdsa_status` column."""
+    from .errors import kind_for_exception
+
+    try:
+        ok = call()
+        return 0 if (ok or not returns_bool) else 1
+    except AssertionError:
+        return 1
+    except Exception as e:  # noqa: BLE001 - third-party signature errors are data here
+        return kind_for_exception(e) << 24
+
+
+def flatten_keccak_tuples(table):
+    """tx_circuit.KeccakTable.table: set of (is_enabled, input_rlc, input_len, output Word) -> uint64[m, 5, 4]"""
+    rows = sorted(set((_n(t[0]), _n(t[1]), _n(t[2]), _n(t[3].lo), _n(t[3].hi)) for t in table))
+    return rows_to_rowmajor([list(r) for r in rows], KECCAK_NCELLS)
+
+
+def flatten_tx_witness(witness, max_txs):
+    """tx_circuit.Witness (rows, keccak_table, sign_verifications) -> dict of wire arrays"""
+    bts, cells, meta = [], [], []
+    for sv in witness.sign_verifications[:max_txs]:
+        e = sv.ecdsa_chip
+        rows_, bad = _byte_rows([sv.pub_key_x_bytes, sv.pub_key_y_bytes, e.pub_key_x_bytes, e.pub_key_y_bytes,
+                                 sv.msg_hash_bytes, e.msg_hash_bytes, sv.pub_key_hash, bytes(32), bytes(32)])
+        bts.append(rows_)
+        cells.append([_n(sv.address), _n(sv.msg_hash.lo), _n(sv.msg_hash.hi), 0, 0, 0, 0, 0])
+        meta.append([_ecdsa_status(lambda e=e: e.verify(""), False), 1, bad, 0])
+    pairs = []
+    for r in witness.rows:
+        lo, hi, w = _word_cells(r.value)
+        pairs.append(([_n(r.tx_id), _n(r.tag), _n(r.index), lo, hi], 1 if w else 0))
+    return {
+        "bytes": np.array(bts, dtype=np.uint8).reshape(-1, SIGN_NBYTES_ROWS, 32),
+        "cells": rows_to_colmajor(cells, SIGN_NCELLS),
+        "meta": np.array(meta, dtype=np.uint32).reshape(-1, 4),
+        "keccak": flatten_keccak_tuples(witness.keccak_table.table),
+        "tx_rows": rows_to_rowmajor([c for c, _ in pairs], TX_NCELLS),
+        "tx_flags": np.array([f for _, f in pairs], dtype=np.uint32),
+    }
+
+
+def flatten_sig_witness(witness):
+    """sig_circuit.Witness (rows, keccak_table) -> dict of wire arrays"""
+    bts, cells, meta = [], [], []
+    for row in witness.rows:
+        e = row.ecdsa_chip
+        rows_, bad = _byte_rows([row.pub_key_x_bytes, row.pub_key_y_bytes, e.pub_key_x_bytes, e.pub_key_y_bytes,
+                                 row.msg_hash_bytes, e.msg_hash_bytes, row.pub_key_hash, e.sig_r.le_bytes, e.sig_s.le_bytes])
+        bts.append(rows_)
+        cells.append([_n(row.recovered_addr), _n(row.msg_hash.lo), _n(row.msg_hash.hi), _n(row.sig_v), _n(row.sig_r.lo),
+                      _n(row.sig_r.hi), _n(row.sig_s.lo), _n(row.sig_s.hi)])
+        meta.append([_ecdsa_status(lambda e=e: e.verify(), True), int(bool(row.is_valid)), bad, 0])
+    return {
+        "bytes": np.array(bts, dtype=np.uint8).reshape(-1, SIGN_NBYTES_ROWS, 32),
+        "cells": rows_to_colmajor(cells, SIGN_NCELLS),
+        "meta": np.array(meta, dtype=np.uint32).reshape(-1, 4),
+        "keccak": flatten_keccak_tuples(witness.keccak_table.table),
+        "tx_rows": np.zeros((0, TX_NCELLS, 4), dtype=np.uint64),
+        "tx_flags": np.zeros(0, dtype=np.uint32),
+    }

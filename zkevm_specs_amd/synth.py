@@ -360,3 +360,53 @@ def synth_exp_witness(n_rows, seed=5):
     while len(rows) < n_rows:
         rows.append([1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1])
     return rows_to_colmajor(rows, 21)
+
+
+# ---- Tx circuit (config 4) ------------------------------------------------------------------------
+def synth_tx_witness(n_txs, r, seed=4, padding=0):
+    """n_txs transaction slots (+ `padding` zero slots) for the Tx circuit's SignVerify path: random
+    64-byte public keys, a synthetic 32-byte digest as pub_key_hash (the circuit checks keccak-table
+    membership of (RLC(pk), 64, hash), not the hash function), address = low 20 bytes, random message
+    hashes, ecdsa_status = 0 (the secp256k1 verdict is a pre-computed input column).  Returns the wire dict."""
+    import hashlib
+    import random
+
+    from .wire import rows_to_colmajor, rows_to_rowmajor
+
+    rng = random.Random(seed)
+    bts, cells, meta, rows, flags = [], [], [], [], []
+    keccak = {(0, 0, 0, 0, 0)}
+    for i in range(n_txs + padding):
+        if i < n_txs:
+            pk_x = bytes(rng.getrandbits(8) for _ in range(32))  # little-endian limbs, as in the chip
+            pk_y = bytes(rng.getrandbits(8) for _ in range(32))
+            h = hashlib.blake2b(pk_x + pk_y, digest_size=32).digest()
+            msg = bytes(rng.getrandbits(8) for _ in range(32))
+            acc = 0
+            for b in reversed(pk_y + pk_x):
+                acc = (acc * r + b) % _FR_P
+            h_lo, h_hi = int.from_bytes(h[:16], "little"), int.from_bytes(h[16:], "little")
+            keccak.add((1, acc, 64, h_lo, h_hi))
+            addr = int.from_bytes(h[-20:], "big")
+            m_lo, m_hi = int.from_bytes(msg[:16], "little"), int.from_bytes(msg[16:], "little")
+        else:
+            pk_x = pk_y = h = msg = bytes(32)
+            addr = m_lo = m_hi = 0
+        bts.append([list(pk_x), list(pk_y), list(pk_x), list(pk_y), list(msg), list(msg), list(h), [0] * 32, [0] * 32])
+        cells.append([addr, m_lo, m_hi, 0, 0, 0, 0, 0])
+        meta.append([0, 1, 0, 0])
+        for tag in range(1, 13):  # Nonce .. TxSignHash (TxContextFieldTag, table.py:147-166)
+            lo, hi, w = 0, 0, 0
+            if tag == 4:
+                lo = addr
+            elif tag == 12:
+                lo, hi, w = m_lo, m_hi, 1
+            elif tag in (3, 7):
+                w = 1
+            rows.append([i + 1, tag, 0, lo, hi])
+            flags.append(w)
+    return {
+        "bytes": np.array(bts, dtype=np.uint8), "cells": rows_to_colmajor(cells, 8),
+        "meta": np.array(meta, dtype=np.uint32), "keccak": rows_to_rowmajor([list(k) for k in sorted(keccak)], 5),
+        "tx_rows": rows_to_rowmajor(rows, 5), "tx_flags": np.array(flags, dtype=np.uint32),
+    }
