@@ -55,7 +55,7 @@ ZK_HD u32 copy_rw_lookup(const CopyArgs& a, const Fr& rwc, const Fr& rw, u32 tag
 
 ZK_HD u32 copy_check_row(const CopyArgs& a, u64 i) {
     const ZkCols& w = a.rows;
-    const u64 n = w.n, i1 = (i + 1) % n, i2 = (i + 2) % n;
+    const u64 n = w.n, i1 = i + 1 >= n ? i + 1 - n : i + 1, i2 = i + 2 >= n ? (i + 2 - n) % n : i + 2;
     u32 code = 0;
     const Fr one = fr_from_u64(1);
     const Fr q_step = zk_col(w, CP_Q_STEP, i), is_first = zk_col(w, CP_IS_FIRST, i), is_last = zk_col(w, CP_IS_LAST, i);

@@ -50,7 +50,7 @@ ZK_HD bool keccak_contains(const ZkTable& t, const Fr q[KECCAK_NCELLS]) {
 
 ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
     const ZkCols& w = a.rows;
-    const u64 in = (i + 1) % w.n;
+    const u64 in = i + 1 == w.n ? 0 : i + 1;
     u32 code = 0;
     const Fr q_first = zk_col(w, BC_Q_FIRST, i), q_last = zk_col(w, BC_Q_LAST, i);
     const Fr tag = zk_col(w, BC_TAG, i), ntag = zk_col(w, BC_TAG, in);
@@ -188,7 +188,7 @@ ZK_HD void ex_mul_add_carries(const ExWord& a, const ExWord& b, const ExWord& c,
 
 ZK_HD u32 exp_check_row(const ExpArgs& a, u64 i) {
     const ZkCols& w = a.rows;
-    const u64 in = (i + 1) % w.n;
+    const u64 in = i + 1 == w.n ? 0 : i + 1;
     u32 code = 0;
     const Fr is_step = zk_col(w, EX_IS_STEP, i), is_last = zk_col(w, EX_IS_LAST, i), r = zk_col(w, EX_R, i);
     const ExWord base = ex_word(w, EX_BASE, i), exponent = ex_word(w, EX_EXPONENT, i);

@@ -133,8 +133,8 @@ ZK_HD u64 state_mpt_key_hash(const ZkTable& t, u32 r) {
 ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
     const ZkCols& w = a.rows;
     const u64 n = w.n;
-    const u64 ip = (i + n - 1) % n;
-    const u64 in = (i + 1) % n;
+    const u64 ip = i == 0 ? n - 1 : i - 1;   // (i - 1) mod n without a 64-bit division
+    const u64 in = i + 1 == n ? 0 : i + 1;
     const u32 fl = w.flags ? w.flags[i] : 0u;
     const bool val_is_word = fl & 1u, init_is_word = fl & 2u;
     u32 code = 0;
