@@ -103,6 +103,14 @@ def main():
         rows_total = units * args.steps * world
         kernel_s = res.kernel_ms / 1e3
         achieved = algo_bytes / kernel_s / 1e9
+        # HBM traffic comes from separate rocprofv3 --pmc passes over this same command
+        # (tools/profile_bench.sh); the committed per-dispatch summary is attached when it matches
+        traffic, traffic_src = None, None
+        import glob
+        here = os.path.dirname(os.path.abspath(__file__))
+        for f in sorted(glob.glob(os.path.join(here, "profiles", f"r*_{args.workload}_2p{log_rows}_traffic.json"))):
+            t = json.load(open(f))
+            traffic, traffic_src = t["traffic_bytes_per_dispatch"], "profiles/" + os.path.basename(f)
         out = {
             "metric": "BN254 constraint-rows/sec",
             "value": rows_total / dt,
@@ -118,7 +126,7 @@ def main():
             "data": "synthetic",
             "config": dict({"workload": workload, "sharding": f"rows x{world}, tally all-reduce"}, **extra_cfg),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": res.kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }

@@ -723,6 +723,44 @@ extern "C" int zk_debug_read_prof(zk_session* s, unsigned long long* out) {
     return 0;
 }
 
+// profiling aid (not part of the public ABI): read `nbytes` exactly once in the EVM kernel's
+// access pattern -- every lane walks its own `lane_bytes`-byte record with 16-byte loads -- so the
+// FETCH_SIZE counter can be calibrated against a known byte count (MI355X guide, HBM section).
+__global__ void __launch_bounds__(256) calib_gather_kernel(const uint4* __restrict__ buf, u64 n_rec, u32 vec_per_rec,
+                                                           u32* __restrict__ sink) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const uint4* p = buf + i * vec_per_rec;
+    u32 acc = 0;
+    for (u32 k = 0; k < vec_per_rec; ++k) {
+        const uint4 v = p[k];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // keeps the loads alive
+}
+extern "C" int zk_debug_calib_gather(uint64_t nbytes, uint32_t lane_bytes, float* ms_out) {
+    ARG_TRY(lane_bytes && lane_bytes % 16 == 0 && nbytes >= lane_bytes, "zk_debug_calib_gather: bad sizes");
+    const u64 n_rec = nbytes / lane_bytes;
+    uint4* buf = nullptr;
+    u32* sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, n_rec * lane_bytes));
+    HIP_TRY(hipMalloc(&sink, 64));
+    HIP_TRY(hipMemsetAsync(buf, 0x5a, n_rec * lane_bytes, g_stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, g_stream));
+    calib_gather_kernel<<<dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, g_stream>>>(buf, n_rec, lane_bytes / 16, sink);
+    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (ms_out) HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(buf);
+    hipFree(sink);
+    return 0;
+}
+
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
     hipEvent_t e0 = nullptr, e1 = nullptr;
