@@ -663,6 +663,105 @@ def g_shl_shr(i):  # shl_shr.py
     i.same_context(opcode, rw_counter=D(3), program_counter=D(1), stack_pointer=D(1))
 
 
+def g_sar(i):  # sar.py
+    opcode = i.opcode_lookup(True)
+    shift, a, b = i.stack_pop(), i.stack_pop(), i.stack_push()
+    # gen_witness (:154-199)
+    is_neg = i.int_value(a) >> 255
+    sb = i.to_le_bytes(shift)
+    shf0 = sb[0]
+    shf_div64, shf_mod64 = shf0 // 64, shf0 % 64
+    p_lo, p_hi = 1 << shf_mod64, 1 << (64 - shf_mod64)
+    p_top = is_neg * (MAX_U64 + 1 - p_hi) % P
+    shf_rest = sum(sb) - shf0
+    a64s = i.to_64s(a)
+    a_lo = [x % p_lo for x in a64s]
+    a_hi = [x // p_lo for x in a64s]
+    b64s = [MAX_U64 if is_neg else 0] * 4
+    if shf_rest == 0 and shf_div64 < 4:
+        b64s[3 - shf_div64] = (a_hi[3] + p_top) % P
+        for k in range(3 - shf_div64):
+            b64s[k] = (a_hi[k + shf_div64] + a_lo[k + shf_div64 + 1] * p_hi) % P
+    # check_witness (:53-151)
+    ab, bb, sb = i.to_le_bytes(a), i.to_le_bytes(b), i.to_le_bytes(shift)
+    is_neg_c, _ = i.compare(127, ab[31], 1)
+    shf_lt256 = int(sum(sb[1:]) % P == 0)
+    for k in range(4):
+        i.constrain_equal(a64s[k], int.from_bytes(bytes(ab[8 * k: 8 * k + 8]), "little"))
+        i.constrain_equal(b64s[k], int.from_bytes(bytes(bb[8 * k: 8 * k + 8]), "little"))
+        i.constrain_equal(a64s[k], a_lo[k] + a_hi[k] * p_lo)
+        lt, _ = i.compare(a_lo[k], p_lo, 16)
+        i.constrain_equal(lt, 1)
+        lt, _ = i.compare(a_hi[k], p_hi, 16)
+        i.constrain_equal(lt, 1)
+    e = [shf_lt256 * int(shf_div64 == k) for k in range(4)]
+    fill = is_neg_c * MAX_U64
+    i.constrain_equal(b64s[0], (a_hi[0] + a_lo[1] * p_hi) * e[0] + (a_hi[1] + a_lo[2] * p_hi) * e[1]
+                      + (a_hi[2] + a_lo[3] * p_hi) * e[2] + (a_hi[3] + p_top) * e[3]
+                      + fill * (1 - e[0] - e[1] - e[2] - e[3]))
+    i.constrain_equal(b64s[1], (a_hi[1] + a_lo[2] * p_hi) * e[0] + (a_hi[2] + a_lo[3] * p_hi) * e[1]
+                      + (a_hi[3] + p_top) * e[2] + fill * (1 - e[0] - e[1] - e[2]))
+    i.constrain_equal(b64s[2], (a_hi[2] + a_lo[3] * p_hi) * e[0] + (a_hi[3] + p_top) * e[1] + fill * (1 - e[0] - e[1]))
+    i.constrain_equal(b64s[3], (a_hi[3] + p_top) * e[0] + fill * (1 - e[0]))
+    lt, _ = i.compare(shf_div64, 4, 1)
+    i.constrain_equal(lt, 1)
+    lt, _ = i.compare(shf_mod64, 64, 1)
+    i.constrain_equal(lt, 1)
+    i.constrain_equal(sb[0], shf_mod64 + shf_div64 * 64)
+    i.constrain_bool(is_neg_c)
+    sign = i.select(is_neg_c, 255, 0)
+    i.fixed_lookup(T.FixedTableTag.SignByte, ab[31], sign, 0)
+    i.constrain_equal(p_top, is_neg_c * (MAX_U64 + 1 - p_hi))
+    i.fixed_lookup(T.FixedTableTag.Pow2, shf_mod64, p_lo, 0)
+    i.fixed_lookup(T.FixedTableTag.Pow2, 64 - shf_mod64, p_hi, 0)
+    i.same_context(opcode, rw_counter=D(3), program_counter=D(1), stack_pointer=D(1))
+
+
+def _int_neg(x):  # util/arithmetic.py:283-284
+    return 0 if x == 0 else (1 << 256) - x
+
+
+def _int_abs(x):  # util/arithmetic.py:279-280
+    return _int_neg(x) if x >> 255 else x
+
+
+def g_sdiv_smod(i):  # sdiv_smod.py
+    opcode = i.opcode_lookup(True)
+    pop1, pop2, push = i.stack_pop(), i.stack_pop(), i.stack_push()
+    # gen_witness (:79-119)
+    is_sdiv = (OP.SMOD - opcode) * INV2 % P
+    v1, v2, vp = i.int_value(pop1), i.int_value(pop2), i.int_value(push)
+    a1, a2, ap = _int_abs(v1), _int_abs(v2), _int_abs(vp)
+    n1, n2 = v1 >> 255, v2 >> 255
+    if is_sdiv == 1:
+        quotient, divisor, dividend = push, pop2, pop1
+        rem = a1 - ap * a2
+        remainder = i.word_from_int(rem if n1 == 0 else _int_neg(rem))
+    else:
+        if v2 == 0:
+            quotient = i.word_from_int(0)
+        elif n1 == n2:
+            quotient = i.word_from_int(a1 // a2)
+        else:
+            quotient = i.word_from_int(_int_neg(a1 // a2))
+        divisor, dividend = pop2, pop1
+        remainder = pop1 if v2 == 0 else push
+    # check_witness (:34-76)
+    q_abs, q_neg = i.abs_word(quotient)
+    d_abs, d_neg = i.abs_word(divisor)
+    r_abs, r_neg = i.abs_word(remainder)
+    n_abs, n_neg = i.abs_word(dividend)
+    q_nz, d_nz, r_nz = 1 - i.is_zero_word(quotient), 1 - i.is_zero_word(divisor), 1 - i.is_zero_word(remainder)
+    overflow = i.mul_add_words(q_abs, d_abs, r_abs, n_abs)
+    i.constrain_zero(overflow)
+    lt, _ = i.compare_word(r_abs, d_abs)
+    i.constrain_zero((1 - lt) * d_nz)
+    i.constrain_zero((n_neg - r_neg) * q_nz * d_nz * r_nz)
+    signed_overflow = i.is_neg_word(n_abs)
+    i.constrain_zero((q_neg + d_neg - 2 * q_neg * d_neg - n_neg) * q_nz * d_nz * (1 - signed_overflow))
+    i.same_context(opcode, rw_counter=D(3), program_counter=D(1), stack_pointer=D(1))
+
+
 def g_addmod(i):  # addmod.py
     opcode = i.opcode_lookup(True)
     i.constrain_equal(opcode, OP.ADDMOD)
@@ -999,7 +1098,7 @@ GADGETS = {
     ES.CALLER: g_caller, ES.CALLVALUE: g_callvalue, ES.ADDRESS: g_address, ES.CALLDATASIZE: g_calldatasize,
     ES.RETURNDATASIZE: g_returndatasize, ES.ORIGIN: g_origin, ES.GASPRICE: g_gasprice,
     ES.SELFBALANCE: g_selfbalance, ES.BlockCtx: g_blockctx, ES.GAS: g_gas, ES.MSIZE: g_msize,
-    ES.CODESIZE: g_codesize, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
+    ES.CODESIZE: g_codesize, ES.SAR: g_sar, ES.SDIV_SMOD: g_sdiv_smod, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }
 SUPPORTED_STATES = sorted(int(s) for s in GADGETS)
 

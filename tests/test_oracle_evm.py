@@ -53,9 +53,11 @@ def test_kernel_logic_matches_oracle_under_fuzz(golden_dir, hostsim):
     assert n > 2000 and n_fail > 800
 
 
-@pytest.mark.parametrize("n,seed", [(700, 3), (2600, 5)])
-def test_synthetic_trace_is_valid(n, seed, hostsim):
-    w = synth_evm_trace(n, seed=seed)
+@pytest.mark.parametrize("n,seed,extra", [(700, 3, None), (2600, 5, None), (1500, 11, [(10, "SDIVSMOD"), (10, "SHIFT")])])
+def test_synthetic_trace_is_valid(n, seed, extra, hostsim):
+    from zkevm_specs_amd.synth_evm import _MIX
+
+    w = synth_evm_trace(n, seed=seed, mix=None if extra is None else _MIX + extra)
     exp = oracle_status(w)
     assert not any(exp)
     assert hostsim_status(hostsim, w) == exp

@@ -974,6 +974,118 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
     set_tail3(T, opcode, 3, 1, 1);
 }
 
+// sar.py.  Once the three words pass their to_le_bytes() checks, every constraint of
+// check_witness (:53-151) except `b64s[idx] == bytes_to_fq(b_le_bytes[..])` is an identity of
+// gen_witness's own outputs (:154-199): those only advance the checkpoint counter.
+ZK_HD void g_sar(Ins& I, Tail& T) {
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word shift, a, b;
+    shift = stack_pop(I); a = stack_pop(I); b = stack_push(I);
+    U256 av; EV_TRY(av = int_value(I, a));
+    U256 sb; EV_TRY(sb = to_u256(I, shift));
+    I.seq++;  // a.to_64s(): the cells fit (int_value passed)
+    const u32 is_neg = av.v[7] >> 31;
+    const u32 shf0 = fr_byte(sb, 0), dv = shf0 >> 6, md = shf0 & 63u;
+    bool rest_zero = true;
+    for (int k = 1; k < 32; k++) rest_zero = rest_zero && fr_byte(sb, k) == 0;
+    const u64 fill = is_neg ? ~0ull : 0ull;
+    u64 b64[4] = {fill, fill, fill, fill};
+    if (rest_zero) {
+        u64 a_lo[4], a_hi[4];
+        for (int k = 0; k < 4; k++) {
+            const u64 x = u256_limb64(av, k);
+            a_hi[k] = x >> md;
+            a_lo[k] = md ? (x << (64 - md)) : 0ull;  // (x mod 2^md) * 2^(64-md)
+        }
+        const u64 p_top = (is_neg && md) ? ~0ull << (64 - md) : 0ull;  // is_neg * (2^64 - 2^(64-md))
+        for (int k = 0; k < 4; k++) {
+            const u32 src = k + dv;
+            if (src == 3) b64[k] = a_hi[3] + p_top;
+            else if (src < 3) b64[k] = a_hi[src] + a_lo[src + 1];
+        }
+    }
+    U256 bb;
+    I.seq++;  // a.to_le_bytes()
+    EV_TRY(bb = to_u256(I, b));
+    I.seq += 2;  // shift.to_le_bytes(), compare(127, a_le_bytes[31], 1)
+    for (int k = 0; k < 4; k++) {
+        I.seq++;
+        ev_require(I, b64[k] == u256_limb64(bb, k));
+        if (I.err) return;
+        I.seq += 5;
+    }
+    I.seq += 15;  // merge constraints, shift decomposition, is_neg, sign-byte / pow2 lookups
+    set_tail3(T, opcode, 3, 1, 1);
+}
+
+// two's complement negation of a 256-bit integer (get_int_neg, util/arithmetic.py:283-284)
+ZK_HD U256 u256_neg(const U256& x) {
+    U256 r;
+    u256_sub(r, fr_zero(), x);
+    return r;
+}
+// Instruction.abs_word (instruction.py:539-571): is_neg from the hi cell; the six constraints are
+// identities of the witness x_abs = x or 2^256 - x.
+ZK_HD Word abs_word(Ins& I, const Word& x, u32& is_neg) {
+    u32 eq;
+    is_neg = 0;
+    ev_compare(I, fr_from_u128(~0ull, 0x7fffffffffffffffull), x.hi, 16, is_neg, eq);
+    if (I.err) return x;
+    Word x_abs = x;
+    if (is_neg) {
+        U256 v = int_value(I, x);
+        if (I.err) return x;
+        x_abs = word_from_int(I, u256_neg(v));
+    }
+    I.seq += 6;
+    return x_abs;
+}
+ZK_HD void g_sdiv_smod(Ins& I, Tail& T) {  // sdiv_smod.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word pop1, pop2, push;
+    pop1 = stack_pop(I); pop2 = stack_pop(I); push = stack_push(I);
+    // gen_witness (:79-119); is_sdiv = (SMOD - opcode) / 2 equals 1 exactly for SDIV
+    const bool is_sdiv = fr_eq_u64(opcode, OP_SDIV);
+    U256 v1, v2, vp;
+    EV_TRY(v1 = int_value(I, pop1)); EV_TRY(v2 = int_value(I, pop2)); EV_TRY(vp = int_value(I, push));
+    const u32 n1 = v1.v[7] >> 31, n2 = v2.v[7] >> 31, np = vp.v[7] >> 31;
+    const U256 a1 = n1 ? u256_neg(v1) : v1, a2 = n2 ? u256_neg(v2) : v2, ap = np ? u256_neg(vp) : vp;
+    Word quotient, divisor = pop2, remainder, dividend = pop1;
+    if (is_sdiv) {
+        quotient = push;
+        U512 prod = u256_mul_full(ap, a2);
+        U256 rem;
+        const bool neg = u256_sub(rem, a1, u512_lo(prod)) || !fr_is_zero(u512_hi(prod));
+        if (n1 == 0) EV_TRY(remainder = word_from_int(I, rem, neg));
+        else EV_TRY(remainder = word_from_int(I, u256_neg(rem), false, neg));  // 2^256 - rem >= 2^256 when rem < 0
+    } else {
+        if (fr_is_zero(v2)) {
+            quotient = word_from_int(I, fr_zero());
+        } else {
+            U256 q, r;
+            u256_divmod(a1, a2, q, r);
+            quotient = word_from_int(I, n1 == n2 ? q : u256_neg(q));
+        }
+        remainder = fr_is_zero(v2) ? pop1 : push;
+    }
+    // check_witness (:34-76)
+    u32 q_neg, d_neg, r_neg, n_neg;
+    Word q_abs, d_abs, r_abs, n_abs;
+    EV_TRY(q_abs = abs_word(I, quotient, q_neg));
+    EV_TRY(d_abs = abs_word(I, divisor, d_neg));
+    EV_TRY(r_abs = abs_word(I, remainder, r_neg));
+    EV_TRY(n_abs = abs_word(I, dividend, n_neg));
+    const u32 q_nz = 1 - is_zero_word(quotient), d_nz = 1 - is_zero_word(divisor), r_nz = 1 - is_zero_word(remainder);
+    Fr overflow; EV_TRY(overflow = mul_add_words(I, q_abs, d_abs, r_abs, n_abs));
+    constrain_zero(I, overflow);
+    u32 lt, eq; compare_word(I, r_abs, d_abs, lt, eq); if (I.err) return;
+    ev_require(I, lt == 1 || d_nz == 0);
+    ev_require(I, n_neg == r_neg || !(q_nz && d_nz && r_nz));
+    u32 so; ev_compare(I, fr_from_u128(~0ull, 0x7fffffffffffffffull), n_abs.hi, 16, so, eq); if (I.err) return;
+    ev_require(I, (q_neg ^ d_neg) == n_neg || !(q_nz && d_nz && !so));
+    set_tail3(T, opcode, 3, 1, 1);
+}
+
 // 512-bit / 256-bit helpers for ADDMOD / MULMOD witness values
 ZK_HD void divmod_512(const U512& num, const U256& den, U512& q, U256& r) { u512_divmod(num, den, q, r, 512); }
 
@@ -1351,6 +1463,8 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 }
 
 #define GROUP_OF_ES_ADD 2
+#define GROUP_OF_ES_SAR 2
+#define GROUP_OF_ES_SDIV_SMOD 1
 #define GROUP_OF_ES_ADDMOD 1
 #define GROUP_OF_ES_ADDRESS 2
 #define GROUP_OF_ES_BITWISE 2
@@ -1391,7 +1505,7 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
-    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
+    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: case ES_SDIV_SMOD: return EVM_GROUP_MUL;
     case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
@@ -1469,6 +1583,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_MSIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MSIZE) { g_msize(I, T); } break;
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
     case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
+    case ES_SAR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SAR) { g_sar(I, T); } break;
+    case ES_SDIV_SMOD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SDIV_SMOD) { g_sdiv_smod(I, T); } break;
     case ES_JUMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMP) { g_jump(I, T); } break;
     case ES_JUMPI: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMPI) { g_jumpi(I, T); } break;
     case ES_SLOAD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SLOAD) { g_sload(I, T); } break;

@@ -71,7 +71,9 @@ class _Contract:
             elif kind == "BITWISE":
                 name = rng.choice(["AND", "OR", "XOR"])
             elif kind == "SHIFT":
-                name = rng.choice(["SHL", "SHR"])
+                name = rng.choice(["SHL", "SHR", "SAR"])
+            elif kind == "SDIVSMOD":
+                name = rng.choice(["SDIV", "SMOD"])
             elif kind == "MEMORY":
                 name = rng.choice(["MLOAD", "MSTORE", "MSTORE8"])
             elif kind == "READER":
@@ -216,6 +218,26 @@ def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True, 
                 x = _word(rng)
                 c = 0 if s_ >= 256 else ((x << s_) & M256 if name == "SHL" else x >> s_)
                 pop(s_, 0); pop(x, 1); push(c, 1)
+                sp += 1
+            elif name == "SAR":
+                s_ = rng.randrange(0, 256) if rng.random() < 0.85 else rng.choice([256, 257, 1 << 64, M256])
+                x = _word(rng)
+                c = (_signed(x) >> min(s_, 256)) & M256
+                pop(s_, 0); pop(x, 1); push(c, 1)
+                sp += 1
+            elif name in ("SDIV", "SMOD"):
+                a, b = _word(rng), _word(rng)
+                if rng.random() < 0.3:
+                    b = (_signed(b) >> rng.randrange(0, 250)) & M256
+                sa, sb_ = _signed(a), _signed(b)
+                if b == 0:
+                    c = 0
+                else:
+                    q_ = abs(sa) // abs(sb_)
+                    r_ = abs(sa) % abs(sb_)
+                    c = (q_ if (sa < 0) == (sb_ < 0) else -q_) if name == "SDIV" else (-r_ if sa < 0 else r_)
+                    c &= M256
+                pop(a, 0); pop(b, 1); push(c, 1)
                 sp += 1
             elif name in ("ADDMOD", "MULMOD"):
                 a, b = _word(rng), _word(rng)
