@@ -34,6 +34,9 @@ TG = T.Target
 CC = T.CallContextFieldTag
 _VALID_OPCODES = {int(o) for o in OP}
 _CONST_GAS = {int(OP[k]): v[1] for k, v in T.OPCODES.items()}
+_DYNAMIC_GAS = {int(OP[k]): v[2] for k, v in T.OPCODES.items()}
+_STACK_BOUNDS = {int(OP[k]): v for k, v in T.STACK_BOUNDS.items()}
+_STATE_WRITE_OPCODES = {int(OP[k]) for k in "SSTORE LOG0 LOG1 LOG2 LOG3 LOG4 CREATE CALL CREATE2 SELFDESTRUCT".split()}
 _RESP = {}
 for _s, _ops in T.RESPONSIBLE.items():
     for _o in _ops:
@@ -276,9 +279,16 @@ class Ins:
         elif tag == F.BitwiseXor:
             ok = v0 < 256 and v1 < 256 and v2 == (v0 ^ v1)
         elif tag == F.ResponsibleOpcode:
-            ok = v2 == 0 and (v0, v1) in _RESP  # success-case states only (aux == 0)
-            if not ok and v0 in (int(ES.ErrorInvalidOpcode), int(ES.ErrorStack), int(ES.ErrorWriteProtection)):
-                raise Fail(UNSUPPORTED, self.seq)
+            ok = v2 == 0 and (v0, v1) in _RESP  # success-case states (aux == 0)
+            if v0 == ES.ErrorInvalidOpcode:  # execution_state.py:355-356: every byte that is not an opcode
+                ok = v2 == 0 and v1 < 256 and v1 not in _VALID_OPCODES
+            elif v0 == ES.ErrorStack and v1 in _STACK_BOUNDS:  # opcode.py:369-384: (opcode, stack_pointer) pairs
+                mn, mx = _STACK_BOUNDS[v1]
+                ok = v2 < mn or mx + 1 <= v2 <= 1024
+            elif v0 == ES.ErrorWriteProtection:  # opcode.py:395-407
+                ok = v2 == 0 and v1 in _STATE_WRITE_OPCODES
+        elif tag == F.OpcodeConstantGas:  # opcode.py:387-392
+            ok = v2 == 0 and v0 in _VALID_OPCODES and not _DYNAMIC_GAS[v0] and _CONST_GAS[v0] > 0 and v1 == _CONST_GAS[v0]
         elif tag == F.Pow2:
             ok = v0 < 256 and ((v0 < 128 and v1 == 1 << v0 and v2 == 0) or (v0 >= 128 and v1 == 0 and v2 == 1 << (v0 - 128)))
         else:
@@ -937,6 +947,120 @@ def g_blockctx(i):  # block_ctx.py (unknown opcode -> `op` unbound -> UnboundLoc
     i.same_context(opcode, rw_counter=D(1), program_counter=D(1), stack_pointer=D(-1))
 
 
+ACC = T.AccountFieldTag
+COLD_ACCOUNT_EXTRA = 2500  # EXTRA_GAS_COST_ACCOUNT_COLD_ACCESS (util/param.py:72)
+
+
+def _account_access(i, opcode_expected):
+    """Common head of balance.py / extcodesize.py / extcodehash.py: opcode, address, access-list write."""
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, opcode_expected)
+    address = i.word_to_fq(i.stack_pop(), 20)
+    tx_id = i.call_context_lookup(CC.TxId)
+    rev = i.reversion_info()
+    rowf = i.state_write(TG.TxAccessListAccount, tx_id, address, value=(1, 0), reversion_info=rev)  # instruction.py:1044-1057
+    is_warm = i.value_of(i.row_value_prev(rowf))
+    return opcode, address, is_warm
+
+
+def _account_read_word(i, address, field_tag):  # instruction.py:957-962
+    return i.row_value(i.rw_lookup(0, TG.Account, address=address, field_tag=int(field_tag)))[0]
+
+
+def g_balance(i):  # balance.py
+    opcode, address, is_warm = _account_access(i, OP.BALANCE)
+    exists = 1 - i.is_zero_word(_account_read_word(i, address, ACC.CodeHash))
+    balance = _account_read_word(i, address, ACC.Balance) if exists == 1 else i.word_from_int(0)
+    zero = i.word_from_int(0)
+    sel = balance if i.select(exists, 1, 0) else zero
+    push = i.stack_push()
+    i.constrain_equal_word(sel, push)
+    dyn = i.select(is_warm, 0, COLD_ACCOUNT_EXTRA)
+    i.same_context(opcode, rw_counter=D(7 + exists), program_counter=D(1), stack_pointer=D(0), dynamic_gas_cost=dyn)
+
+
+def g_extcodesize(i):  # extcodesize.py
+    opcode, address, is_warm = _account_access(i, OP.EXTCODESIZE)
+    code_hash = _account_read_word(i, address, ACC.CodeHash)
+    exists = 1 - i.is_zero_word(code_hash)
+    code_size = i.bytecode_length(code_hash) if exists == 1 else 0
+    w = i.word_checked(i.select(exists, code_size, 0), 0)
+    push = i.stack_push()
+    i.constrain_equal_word(w, push)
+    dyn = i.select(is_warm, 0, COLD_ACCOUNT_EXTRA)
+    i.same_context(opcode, rw_counter=D(7), program_counter=D(1), stack_pointer=D(0), dynamic_gas_cost=dyn,
+                   reversible_write_counter=D(1))
+
+
+def g_extcodehash(i):  # extcodehash.py
+    opcode, address, is_warm = _account_access(i, OP.EXTCODEHASH)
+    code_hash = _account_read_word(i, address, ACC.CodeHash)
+    push = i.stack_push()
+    i.constrain_equal_word(code_hash, push)
+    dyn = i.select(is_warm, 0, COLD_ACCOUNT_EXTRA)
+    i.same_context(opcode, rw_counter=D(7), program_counter=D(1), stack_pointer=D(0), dynamic_gas_cost=dyn)
+
+
+def g_blockhash(i):  # blockhash.py
+    opcode = i.opcode_lookup(True)
+    block_number = i.word_to_fq(i.stack_pop(), 8)
+    current = i.value_of(i.block_lookup(int(T.BlockContextFieldTag.Number)))
+    block_hash = i.stack_push()
+    block_lt, _ = i.compare(block_number, current, 8)
+    diff_lt, _ = i.compare(current, 256 + block_number, 2)
+    if block_lt * diff_lt == 1:
+        expected, _ = i.block_lookup(int(T.BlockContextFieldTag.HistoryHash), block_number)
+    else:
+        expected = (0, 0)
+    i.constrain_equal_word(block_hash, expected)
+    i.same_context(opcode, rw_counter=D(2), program_counter=D(1), stack_pointer=D(0))
+
+
+def _buffer_reader(i, addr_start, addr_end):  # util/__init__.py BufferReaderGadget (max_bytes = bytes_left = 32)
+    bound = [max(0, addr_end - addr_start - k) for k in range(32)]
+    lt, _ = i.compare(addr_end, addr_start, 5)  # Instruction.min (instruction.py:472-474)
+    mn = i.select(lt, addr_end, addr_start)
+    i.constrain_equal(bound[0], addr_end - mn)
+    for k in range(1, 32):
+        d = i.select(int(bound[k - 1] == 0), 0, 1)
+        i.constrain_equal(bound[k - 1] - bound[k], d)
+    return [int(b != 0) for b in bound]  # read_flag (selectors are all 1)
+
+
+def g_calldataload(i):  # calldataload.py
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.CALLDATALOAD)
+    offset = i.word_to_fq(i.stack_pop(), 8)
+    is_root = i.curr[S_IS_ROOT] != 0
+    if is_root:
+        src_id = i.call_context_lookup(CC.TxId)
+        length = i.call_context_lookup(CC.CallDataLength)
+        cd_offset = 0
+    else:
+        src_id = i.call_context_lookup(CC.CallerId)
+        length = i.call_context_lookup(CC.CallDataLength)
+        cd_offset = i.call_context_lookup(CC.CallDataOffset)
+    src_addr = (offset + cd_offset) % P
+    src_end = (length + cd_offset) % P
+    flags = _buffer_reader(i, src_addr, src_end)
+    data = []
+    for k in range(32):
+        if flags[k]:
+            if is_root:
+                b = i.value_of(i.tx_lookup(src_id, int(T.TxContextFieldTag.CallData), src_addr + k))
+            else:
+                b = i.memory_lookup(0, src_addr + k, src_id)
+            i.cp(); i.cp()  # constrain_byte: both products vanish by construction
+            data.append(b)
+        else:
+            data.append(0)
+    i.require(all(b < 256 for b in data), VALUE_ERROR)  # bytes(calldata_word)
+    v = int.from_bytes(bytes(data), "little")  # Word(bytes): lo = bytes[0:16], hi = bytes[16:32], little-endian
+    push = i.stack_push()
+    i.constrain_equal_word((v & M128, v >> 128), push)
+    i.same_context(opcode, rw_counter=D(i.rw_off), program_counter=D(1), stack_pointer=D(0))
+
+
 def g_gas(i):  # gas.py
     opcode = i.opcode_lookup(True)
     i.constrain_equal(opcode, OP.GAS)
@@ -1073,6 +1197,57 @@ def _restore_context(i, rw_counter_delta, gas_left):  # instruction.py:292-363 (
     i.transition(S_REV, "to", rwc + rev)
 
 
+def _constrain_error_state(i, rw_counter_delta):  # instruction.py:1426-1452
+    rw_counter_delta = (rw_counter_delta + 1) % P
+    is_success = i.call_context_lookup(CC.IsSuccess)
+    i.constrain_equal(is_success, 0)
+    i.constrain_equal(i.curr[S_IS_ROOT], int(i.next[S_STATE] == ES.EndTx))
+    if i.curr[S_IS_ROOT]:
+        i.transition(S_RWC, "delta", rw_counter_delta)
+        i.transition(S_CALL_ID, "same")
+    else:
+        _restore_context(i, rw_counter_delta, 0)
+
+
+def g_error_invalid_opcode(i):  # error_invalid_opcode.py
+    opcode = i.opcode_lookup(True)
+    i.fixed_lookup(T.FixedTableTag.ResponsibleOpcode, i.curr[S_STATE], opcode, 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_error_stack(i):  # error_stack.py
+    opcode = i.opcode_lookup(True)
+    i.fixed_lookup(T.FixedTableTag.ResponsibleOpcode, i.curr[S_STATE], opcode, i.curr[S_SP])
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_error_oog_constant(i):  # error_oog_constant.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode % P in _VALID_OPCODES, VALUE_ERROR)  # Opcode(opcode.n)
+    gas = _CONST_GAS[opcode % P]
+    i.fixed_lookup(T.FixedTableTag.OpcodeConstantGas, opcode, gas, 0)
+    lt, _ = i.compare(i.curr[S_GAS], gas, 8)
+    i.constrain_equal(lt, 1)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_error_invalid_jump(i):  # error_invalid_jump.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.JUMP, OP.JUMPI))
+    code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
+    code_length = i.bytecode_length(code_hash)
+    dest = i.stack_pop()
+    if opcode == OP.JUMPI:
+        cond = i.stack_pop()
+        i.require(cond[0] % P != 0 or cond[1] % P != 0)
+    dest_value = i.word_to_fq(dest, 8)
+    within, _ = i.compare(dest_value, code_length, 8)
+    if within == 1:  # out-of-range destinations get no further constraint (indentation of :25-33)
+        row = i.bytecode_lookup(code_hash, 2, dest_value)
+        i.constrain_zero(row[B_IS_CODE] * int(row[B_VALUE] == OP.JUMPDEST))
+        _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1098,7 +1273,10 @@ GADGETS = {
     ES.CALLER: g_caller, ES.CALLVALUE: g_callvalue, ES.ADDRESS: g_address, ES.CALLDATASIZE: g_calldatasize,
     ES.RETURNDATASIZE: g_returndatasize, ES.ORIGIN: g_origin, ES.GASPRICE: g_gasprice,
     ES.SELFBALANCE: g_selfbalance, ES.BlockCtx: g_blockctx, ES.GAS: g_gas, ES.MSIZE: g_msize,
-    ES.CODESIZE: g_codesize, ES.SAR: g_sar, ES.SDIV_SMOD: g_sdiv_smod, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
+    ES.CODESIZE: g_codesize, ES.SAR: g_sar, ES.SDIV_SMOD: g_sdiv_smod, ES.BALANCE: g_balance, ES.EXTCODESIZE: g_extcodesize,
+    ES.EXTCODEHASH: g_extcodehash, ES.BLOCKHASH: g_blockhash, ES.CALLDATALOAD: g_calldataload,
+    ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
+    ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }
 SUPPORTED_STATES = sorted(int(s) for s in GADGETS)
 

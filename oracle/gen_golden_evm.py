@@ -24,7 +24,8 @@ from oracle.gen_golden import kind_of_exception  # noqa: E402
 
 TEST_FILES = """add_sub mul_div_mod comparator slt_sgt iszero not bitwise byte signextend push pop shl_shr addmod
 mulmod memory caller callvalue address calldatasize returndatasize origin gasprice selfbalance block_ctx gas
-msize codesize jump jumpi sload sstore stop sar sdiv_smod""".split()
+msize codesize jump jumpi sload sstore stop sar sdiv_smod balance extcodesize extcodehash blockhash
+calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_jump""".split()
 MAX_CASES_PER_FILE = 48
 
 
@@ -135,10 +136,38 @@ def fuzz_wire(wire, rng):
     return w
 
 
+def check_tables_against_reference():
+    """zkevm_specs_amd/evm_tables.py restates the reference's enum numberings and opcode metadata as
+    data; assert every entry against the imported reference so a drift fails golden generation."""
+    from zkevm_specs.evm_circuit import execution_state as res, opcode as rop, table as rt
+    from zkevm_specs.evm_circuit.execution import EXECUTION_STATE_IMPL
+    from zkevm_specs_amd import evm_tables as T
+
+    assert {s.name: int(s) for s in res.ExecutionState} == {s.name: int(s) for s in T.ExecutionState}
+    assert {o.name: int(o) for o in rop.Opcode} == {o.name: int(o) for o in T.Opcode}
+    for o in rop.valid_opcodes():
+        info = rop.OPCODE_INFO_MAP[o]
+        assert T.OPCODES[o.name][1:] == (info.constant_gas_cost, int(info.has_dynamic_gas)), o
+        assert T.STACK_BOUNDS[o.name] == (info.min_stack_pointer, info.max_stack_pointer), o
+    assert sorted(s.name for s in res.ExecutionState if s not in EXECUTION_STATE_IMPL) == sorted(T.REFERENCE_UNIMPLEMENTED)
+    for st, ops in T.RESPONSIBLE.items():
+        got = res.ExecutionState[st].responsible_opcode()
+        assert sorted(int(o) for o in got) == sorted(int(T.Opcode[o]) for o in ops), st
+    for mine, ref in [(T.Target, rt.Target), (T.CallContextFieldTag, rt.CallContextFieldTag),
+                      (T.AccountFieldTag, rt.AccountFieldTag), (T.TxContextFieldTag, rt.TxContextFieldTag),
+                      (T.BlockContextFieldTag, rt.BlockContextFieldTag), (T.BytecodeFieldTag, rt.BytecodeFieldTag),
+                      (T.FixedTableTag, rt.FixedTableTag), (T.RW, rt.RW)]:
+        assert {e.name: int(e) for e in mine} == {e.name: int(e) for e in ref}, mine
+    assert [s.name for s in res.ExecutionState if s.halts_in_success()] == T.HALTS_IN_SUCCESS or \
+        sorted(s.name for s in res.ExecutionState if s.halts_in_success()) == sorted(T.HALTS_IN_SUCCESS)
+    assert sorted(s.name for s in res.ExecutionState if s.halts_in_exception()) == sorted(T.HALTS_IN_EXCEPTION)
+
+
 def main():
     from zkevm_specs_amd.flatten import flatten_evm
 
     os.makedirs(GOLDEN, exist_ok=True)
+    check_tables_against_reference()
     total = 0
     only = sys.argv[1:] if len(sys.argv) > 1 and sys.argv[0].endswith("gen_golden_evm.py") else None
     for name in TEST_FILES:

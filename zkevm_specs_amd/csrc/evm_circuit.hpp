@@ -284,7 +284,7 @@ ZK_HD WordOrValue rw_value_prev(const Ins& I, u32 row) {
 }
 
 // Tables.bytecode_lookup (table.py:718-731); is_code < 0 = not part of the query
-ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& index, int is_code) {
+ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& index, int is_code, bool foreign = false) {
     Fr q[BYTECODE_NCELLS];
     q[B_HASH_LO] = code_hash.lo;
     q[B_HASH_HI] = code_hash.hi;
@@ -293,7 +293,9 @@ ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& inde
     q[B_IS_CODE] = fr_u(is_code > 0 ? 1 : 0);
     q[B_VALUE] = fr_zero();
     u32 mask = 0xfu | (is_code >= 0 ? (1u << B_IS_CODE) : 0u);
-    // every bytecode lookup of the implemented gadgets queries curr.code_hash: probe once per step
+    // a hash other than curr.code_hash (EXTCODESIZE, ...) goes through the generic index
+    if (foreign) return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
+    // all other bytecode lookups of a step query curr.code_hash: probe the directory once per step
     if (I.code_state == 0) {
         const ZkCodeDir& dir = I.a->codes;
         I.code_state = 3;
@@ -342,15 +344,15 @@ ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
     I.pc_off++;
     return opcode_lookup_at(I, index, is_code);
 }
-ZK_HD Fr bytecode_length(Ins& I, const Word& code_hash) {  // instruction.py:771-774
-    u32 r = bytecode_lookup(I, code_hash, 1, fr_zero(), 0);
+ZK_HD Fr bytecode_length(Ins& I, const Word& code_hash, bool foreign = false) {  // instruction.py:771-774
+    u32 r = bytecode_lookup(I, code_hash, 1, fr_zero(), 0, foreign);
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
 }
-ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag) {  // table.py:697-706 (index 0)
+ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag, const Fr* index = nullptr) {  // table.py:697-706
     Fr q[TX_NCELLS];
     q[0] = tx_id;
     q[1] = fr_u(field_tag);
-    q[2] = fr_zero();
+    q[2] = index ? *index : fr_zero();
     q[3] = fr_zero();
     q[4] = fr_zero();
     u32 r = table_lookup<TX_NCELLS>(I, I.a->tx, tx_key_hash_cells(q[0], q[1], q[2]), q, 0x7u);
@@ -359,10 +361,10 @@ ZK_HD WordOrValue tx_lookup(Ins& I, const Fr& tx_id, u32 field_tag) {  // table.
     v.is_word = I.a->tx.flags ? (I.a->tx.flags[r] & 1u) : true;
     return v;
 }
-ZK_HD WordOrValue block_lookup(Ins& I, u32 field_tag) {  // table.py:690-695 (block number 0)
+ZK_HD WordOrValue block_lookup(Ins& I, u32 field_tag, const Fr* number = nullptr) {  // table.py:690-695
     Fr q[BLOCK_NCELLS];
     q[0] = fr_u(field_tag);
-    q[1] = fr_zero();
+    q[1] = number ? *number : fr_zero();
     q[2] = fr_zero();
     q[3] = fr_zero();
     u32 r = table_lookup<BLOCK_NCELLS>(I, I.a->block, blk_key_hash_cells(q[0], q[1]), q, 0x3u);
@@ -394,11 +396,27 @@ ZK_HD void fixed_lookup(Ins& I, u32 tag, const Fr& v0, const Fr& v1, const Fr& v
     case FX_BitwiseXor: ok = b0 && b1 && fr_eq_u64(v2, x ^ y); break;
     case FX_ResponsibleOpcode: {
         static const uint8_t resp[256] = ZK_OPCODE_RESP_STATE_INIT;
+        static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
         ok = fr_is_zero(v2) && b1 && fr_le_u64(v0, 255) && x != 0 && resp[y] == x;
-        if (!ok && (fr_eq_u64(v0, ES_ErrorInvalidOpcode) || fr_eq_u64(v0, ES_ErrorStack) || fr_eq_u64(v0, ES_ErrorWriteProtection))) {
-            if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
-            return;
+        if (fr_eq_u64(v0, ES_ErrorInvalidOpcode)) {  // execution_state.py:355-356
+            ok = fr_is_zero(v2) && b1 && !valid[y];
+        } else if (fr_eq_u64(v0, ES_ErrorStack) && b1 && valid[y]) {  // opcode.py:369-384: (opcode, stack_pointer)
+            static const int16_t mn[256] = ZK_OPCODE_MIN_SP_INIT;
+            static const int16_t mx[256] = ZK_OPCODE_MAX_SP_INIT;
+            const bool small = fr_le_u64(v2, 1024);
+            const int sp = (int)v2.v[0];
+            ok = small && (sp < mn[y] || sp >= mx[y] + 1);
+        } else if (fr_eq_u64(v0, ES_ErrorWriteProtection)) {  // opcode.py:395-407
+            ok = fr_is_zero(v2) && b1 && (y == OP_SSTORE || (y >= OP_LOG0 && y <= OP_LOG4) || y == OP_CREATE || y == OP_CALL ||
+                                          y == OP_CREATE2 || y == OP_SELFDESTRUCT);
         }
+        break;
+    }
+    case FX_OpcodeConstantGas: {  // opcode.py:387-392
+        static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
+        static const uint8_t dyn[256] = ZK_OPCODE_DYNAMIC_GAS_INIT;
+        static const uint16_t cgas[256] = ZK_OPCODE_CONST_GAS_INIT;
+        ok = b0 && valid[x] && !dyn[x] && cgas[x] > 0 && fr_eq_u64(v1, cgas[x]) && fr_is_zero(v2);
         break;
     }
     case FX_Pow2: {
@@ -435,10 +453,10 @@ ZK_HD Word stack_push(Ins& I) {
     I.sp_off--;
     return stack_lookup(I, 1, I.sp_off);
 }
-ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr) {
+ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr, const Fr* call_id = nullptr) {
     RwQ Q;
     rwq_init(Q, rw, TG_Memory);
-    rwq_set(Q, R_ID, I.call_id);
+    rwq_set(Q, R_ID, call_id ? *call_id : I.call_id);
     rwq_set(Q, R_ADDR, addr);
     u32 r = rw_lookup(I, Q);
     return value_of(I, rw_value(I, r));
@@ -1254,6 +1272,142 @@ ZK_HD void g_selfbalance(Ins& I, Tail& T) {  // selfbalance.py
     constrain_equal_word(I, push, bal);
     set_tail3(T, opcode, 3, 1, -1);
 }
+// Common head of balance.py / extcodesize.py / extcodehash.py: opcode check, address from the
+// stack, TxId, reversion info and the access-list write (instruction.py:1044-1057).
+struct AccountAccess {
+    Fr opcode, address;
+    bool warm, warm_is_bool;
+};
+ZK_HD AccountAccess account_access(Ins& I, u32 expected_opcode) {
+    AccountAccess A;
+    A.warm = false;
+    A.warm_is_bool = true;
+    A.address = fr_zero();
+    A.opcode = opcode_lookup(I, true);
+    constrain_equal(I, A.opcode, fr_u(expected_opcode));
+    Word aw; aw = stack_pop(I);
+    EV_TRYV(A.address = word_to_fq(I, aw, 20), A);
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Reversion rv; EV_TRYV(rv = reversion_info(I), A);
+    RwQ W;
+    rwq_init(W, 1, TG_TxAccessListAccount);
+    rwq_set(W, R_ID, tx_id);
+    rwq_set(W, R_ADDR, A.address);
+    rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+    u32 wr; wr = state_write(I, W, rv);
+    Fr is_warm; EV_TRYV(is_warm = value_of(I, rw_value_prev(I, wr)), A);
+    A.warm = fr_eq_u64(is_warm, 1);
+    A.warm_is_bool = fr_le_u64(is_warm, 1);  // checked by the later select
+    return A;
+}
+ZK_HD Word account_read_word(Ins& I, const Fr& address, u32 field_tag) {  // instruction.py:957-962
+    RwQ Q;
+    rwq_init(Q, 0, TG_Account);
+    rwq_set(Q, R_ADDR, address);
+    rwq_set(Q, R_FT, fr_u(field_tag));
+    u32 r; r = rw_lookup(I, Q);
+    return rw_word(I, r, R_VAL_LO);
+}
+// the trailing `select(is_warm, 0, EXTRA_GAS_COST_ACCOUNT_COLD_ACCESS)` (asserts a boolean)
+ZK_HD Fr account_access_gas(Ins& I, const AccountAccess& A) {
+    ev_require(I, A.warm_is_bool);
+    return fr_u(A.warm ? 0 : 2500);
+}
+ZK_HD void g_balance(Ins& I, Tail& T) {  // balance.py
+    AccountAccess A; EV_TRY(A = account_access(I, OP_BALANCE));
+    Word ch; ch = account_read_word(I, A.address, ACC_CodeHash);
+    if (I.err) return;
+    const u32 exists = 1 - is_zero_word(ch);
+    Word bal = word_zero();
+    if (exists) bal = account_read_word(I, A.address, ACC_Balance);
+    else I.seq++;  // Word(0)
+    I.seq += 2;  // Word(0), select_word(exists, ..)
+    Word push; push = stack_push(I);
+    constrain_equal_word(I, bal, push);
+    Fr dyn; EV_TRY(dyn = account_access_gas(I, A));
+    set_tail(T, A.opcode, 7 + (int)exists, t_delta_i(1), 0, t_same(), 0, dyn);
+}
+ZK_HD void g_extcodesize(Ins& I, Tail& T) {  // extcodesize.py
+    AccountAccess A; EV_TRY(A = account_access(I, OP_EXTCODESIZE));
+    Word ch; ch = account_read_word(I, A.address, ACC_CodeHash);
+    if (I.err) return;
+    const u32 exists = 1 - is_zero_word(ch);
+    Fr size = fr_zero();
+    if (exists) size = bytecode_length(I, ch, true);
+    I.seq++;  // select(exists, code_size, 0)
+    Word w; w = word_checked(I, size, fr_zero());
+    Word push; push = stack_push(I);
+    constrain_equal_word(I, w, push);
+    Fr dyn; EV_TRY(dyn = account_access_gas(I, A));
+    set_tail(T, A.opcode, 7, t_delta_i(1), 0, t_same(), 1, dyn);
+}
+ZK_HD void g_extcodehash(Ins& I, Tail& T) {  // extcodehash.py
+    AccountAccess A; EV_TRY(A = account_access(I, OP_EXTCODEHASH));
+    Word ch; ch = account_read_word(I, A.address, ACC_CodeHash);
+    Word push; push = stack_push(I);
+    constrain_equal_word(I, ch, push);
+    Fr dyn; EV_TRY(dyn = account_access_gas(I, A));
+    set_tail(T, A.opcode, 7, t_delta_i(1), 0, t_same(), 0, dyn);
+}
+ZK_HD void g_blockhash(Ins& I, Tail& T) {  // blockhash.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word nw; nw = stack_pop(I);
+    Fr number; EV_TRY(number = word_to_fq(I, nw, 8));
+    WordOrValue cur; cur = block_lookup(I, BLK_Number);
+    Fr current; EV_TRY(current = value_of(I, cur));
+    Word hash; hash = stack_push(I);
+    u32 block_lt, diff_lt, eq;
+    EV_TRY(ev_compare(I, number, current, 8, block_lt, eq));
+    EV_TRY(ev_compare(I, current, fr_add_u64(number, 256), 2, diff_lt, eq));
+    Word expected = word_zero();
+    if (block_lt * diff_lt == 1u) {
+        WordOrValue h; h = block_lookup(I, BLK_HistoryHash, &number);
+        expected = h.w;
+    }
+    constrain_equal_word(I, hash, expected);
+    set_tail3(T, opcode, 2, 1, 0);
+}
+ZK_HD void g_calldataload(Ins& I, Tail& T) {  // calldataload.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_CALLDATALOAD));
+    Word ow; ow = stack_pop(I);
+    Fr offset; EV_TRY(offset = word_to_fq(I, ow, 8));
+    const bool is_root = !fr_is_zero(ev_curr(I, S_IS_ROOT));
+    Fr src_id, length, cd_offset = fr_zero();
+    src_id = call_context_lookup(I, is_root ? CC_TxId : CC_CallerId);
+    length = call_context_lookup(I, CC_CallDataLength);
+    if (!is_root) cd_offset = call_context_lookup(I, CC_CallDataOffset);
+    if (I.err) return;
+    const Fr src_addr = fr_add(offset, cd_offset), src_end = fr_add(length, cd_offset);
+    // BufferReaderGadget (util/__init__.py:131-166) with max_bytes = bytes_left = 32: only
+    // Instruction.min's 5-byte compare can fail, the bound_dist constraints are identities
+    u32 lt, eq;
+    EV_TRY(ev_compare(I, src_end, src_addr, 5, lt, eq));
+    I.seq += 2 + 62;
+    const u64 avail = lt ? 0ull : fr_lo64(src_end) - fr_lo64(src_addr);  // both < 2^40
+    U256 data = fr_zero();
+    bool bytes_ok = true;
+    for (int k = 0; k < 32; k++) {
+        if ((u64)k < avail) {
+            Fr idx = fr_add_u64(src_addr, (u64)k), b;
+            if (is_root) {
+                WordOrValue v; v = tx_lookup(I, src_id, TXC_CallData, &idx);
+                b = value_of(I, v);
+            } else {
+                b = memory_lookup(I, 0, idx, &src_id);
+            }
+            if (I.err) return;
+            I.seq += 2;  // constrain_byte
+            bytes_ok = bytes_ok && fr_le_u64(b, 255);
+            data.v[k >> 2] |= (b.v[0] & 0xffu) << (8 * (k & 3));
+        }
+    }
+    ev_require(I, bytes_ok, ZK_VALUE_ERROR);  // bytes(calldata_word)
+    if (I.err) return;
+    Word push; push = stack_push(I);
+    constrain_equal_word(I, word_from_u256(data), push);
+    set_tail3(T, opcode, (int)I.rw_off, 1, 0);
+}
 ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
     Fr opcode; opcode = opcode_lookup(I, true);
     u32 tag = 0;
@@ -1393,8 +1547,8 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
 }
 
 // step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
-ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
-    rw_counter_delta += 12;
+ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_left) {
+    const Fr rw_counter_delta = fr_add_u64(rw_counter_delta_in, 12);
     Fr caller_id; caller_id = call_context_lookup(I, CC_CallerId);
     const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
                          CC_MemorySize, CC_ReversibleWriteCounter};
@@ -1418,7 +1572,7 @@ ZK_HD void restore_context(Ins& I, u64 rw_counter_delta, const Fr& gas_left) {
     Fr gas = value_of(I, saved[5]);
     Fr mem = value_of(I, saved[6]);
     Fr rwc = value_of(I, saved[7]);
-    transition(I, S_RWC, t_delta(fr_u(rw_counter_delta)));
+    transition(I, S_RWC, t_delta(rw_counter_delta));
     transition(I, S_CALL_ID, t_to(caller_id));
     transition(I, S_IS_ROOT, t_to(is_root));
     transition(I, S_IS_CREATE, t_to(is_create));
@@ -1447,7 +1601,68 @@ ZK_HD void g_stop(Ins& I, Tail& T) {  // stop.py
         transition(I, S_RWC, t_delta_i(1));
         transition(I, S_CALL_ID, t_same());
     } else {
-        restore_context(I, 1, ev_curr(I, S_GAS));
+        restore_context(I, fr_u(1), ev_curr(I, S_GAS));
+    }
+}
+
+// constrain_error_state (instruction.py:1426-1452)
+ZK_HD void constrain_error_state(Ins& I) {
+    const Fr delta = fr_add_u64(fr_add_u64(ev_curr(I, S_REV), I.rw_off), 1);  // rw_counter_offset + reversible_write_counter + 1
+    Fr is_success; is_success = call_context_lookup(I, CC_IsSuccess);
+    constrain_equal(I, is_success, fr_zero());
+    const u32 to_end_tx = ev_next(I, S_STATE).v[0] == ES_EndTx ? 1u : 0u;
+    Fr is_root = ev_curr(I, S_IS_ROOT);
+    constrain_equal(I, is_root, fr_u(to_end_tx));
+    if (I.err) return;
+    if (!fr_is_zero(is_root)) {
+        transition(I, S_RWC, t_delta(delta));
+        transition(I, S_CALL_ID, t_same());
+    } else {
+        restore_context(I, delta, fr_zero());
+    }
+}
+ZK_HD void g_error_invalid_opcode(Ins& I, Tail& T) {  // error_invalid_opcode.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
+    constrain_error_state(I);
+}
+ZK_HD void g_error_stack(Ins& I, Tail& T) {  // error_stack.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, I.sp); if (I.err) return;
+    constrain_error_state(I);
+}
+ZK_HD void g_error_oog_constant(Ins& I, Tail& T) {  // error_oog_constant.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
+    static const uint16_t cgas[256] = ZK_OPCODE_CONST_GAS_INIT;
+    const bool op_ok = fr_le_u64(opcode, 255) && valid[opcode.v[0] & 0xff];
+    ev_require(I, op_ok, ZK_VALUE_ERROR);  // Opcode(opcode.n)
+    if (I.err) return;
+    const Fr gas = fr_u(cgas[opcode.v[0] & 0xff]);
+    fixed_lookup(I, FX_OpcodeConstantGas, opcode, gas, fr_zero()); if (I.err) return;
+    u32 lt, eq; ev_compare(I, ev_curr(I, S_GAS), gas, 8, lt, eq); if (I.err) return;
+    ev_require(I, lt == 1u); if (I.err) return;
+    constrain_error_state(I);
+}
+ZK_HD void g_error_invalid_jump(Ins& I, Tail& T) {  // error_invalid_jump.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const bool is_jumpi = fr_eq_u64(opcode, OP_JUMPI);
+    ev_require(I, is_jumpi || fr_eq_u64(opcode, OP_JUMP)); if (I.err) return;
+    Fr code_length; code_length = bytecode_length(I, curr_code_hash(I));
+    Word dest; dest = stack_pop(I);
+    if (is_jumpi) {
+        Word cond; cond = stack_pop(I);
+        ev_require(I, !fr_is_zero(cond.lo) || !fr_is_zero(cond.hi));
+    }
+    if (I.err) return;
+    Fr dest_value; EV_TRY(dest_value = word_to_fq(I, dest, 8));
+    u32 within, eq; ev_compare(I, dest_value, code_length, 8, within, eq); if (I.err) return;
+    if (within == 1u) {  // out-of-range destinations get no further constraint (:25-33)
+        u32 r; r = bytecode_lookup(I, curr_code_hash(I), 2, dest_value, -1); if (I.err) return;
+        const bool is_code = !fr_is_zero(zk_table_cell(I.a->bytecode, r, B_IS_CODE));
+        const bool is_dest = fr_eq_u64(zk_table_cell(I.a->bytecode, r, B_VALUE), OP_JUMPDEST);
+        ev_require(I, !(is_code && is_dest)); if (I.err) return;
+        constrain_error_state(I);
     }
 }
 
@@ -1506,7 +1721,9 @@ enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_N_GROUPS =
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
     case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: case ES_SDIV_SMOD: return EVM_GROUP_MUL;
-    case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: return EVM_GROUP_MEM;
+    case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: case ES_BALANCE: case ES_EXTCODESIZE:
+    case ES_EXTCODEHASH: case ES_BLOCKHASH: case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack:
+    case ES_ErrorOutOfGasConstant: case ES_ErrorInvalidJump: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -1584,6 +1801,15 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
     case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
     case ES_SAR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SAR) { g_sar(I, T); } break;
+    case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_opcode(I, T); } break;
+    case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
+    case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
+    case ES_ErrorInvalidJump: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_jump(I, T); } break;
+    case ES_BALANCE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_balance(I, T); } break;
+    case ES_EXTCODESIZE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodesize(I, T); } break;
+    case ES_EXTCODEHASH: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodehash(I, T); } break;
+    case ES_BLOCKHASH: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_blockhash(I, T); } break;
+    case ES_CALLDATALOAD: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_calldataload(I, T); } break;
     case ES_SDIV_SMOD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SDIV_SMOD) { g_sdiv_smod(I, T); } break;
     case ES_JUMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMP) { g_jump(I, T); } break;
     case ES_JUMPI: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMPI) { g_jumpi(I, T); } break;

@@ -66,6 +66,27 @@ for _i in range(1, 17):
 
 Opcode = IntEnum("Opcode", {k: v[0] for k, v in OPCODES.items()})
 
+# (min_stack_pointer, max_stack_pointer) of OPCODE_INFO_MAP (opcode.py:213-362), grouped
+_STACK_BOUNDS = {
+    (-6, 1017): "CALL CALLCODE", (-6, 1018): "LOG4", (-5, 1018): "DELEGATECALL STATICCALL", (-5, 1019): "LOG3",
+    (-4, 1020): "EXTCODECOPY LOG2", (-3, 1020): "CREATE2", (-3, 1021): "CALLDATACOPY CODECOPY RETURNDATACOPY LOG1",
+    (-2, 1021): "ADDMOD MULMOD CREATE", (-2, 1022): "MSTORE MSTORE8 SSTORE JUMPI LOG0 RETURN REVERT",
+    (-1, 1022): "ADD MUL SUB DIV SDIV MOD SMOD EXP SIGNEXTEND LT GT SLT SGT EQ AND OR XOR BYTE SHL SHR SAR SHA3",
+    (-1, 1023): "POP JUMP SELFDESTRUCT",
+    (0, 1023): "ISZERO NOT BALANCE CALLDATALOAD EXTCODESIZE EXTCODEHASH BLOCKHASH MLOAD SLOAD",
+    (0, 1024): "STOP JUMPDEST",
+    (1, 1024): "ADDRESS ORIGIN CALLER CALLVALUE CALLDATASIZE CODESIZE GASPRICE RETURNDATASIZE COINBASE TIMESTAMP "
+               "NUMBER PREVRANDAO GASLIMIT CHAINID SELFBALANCE BASEFEE PC MSIZE GAS PUSH0",
+}
+STACK_BOUNDS = {name: b for b, names in _STACK_BOUNDS.items() for name in names.split()}
+for _i in range(1, 33):
+    STACK_BOUNDS[f"PUSH{_i}"] = (1, 1024)
+for _i in range(1, 17):
+    STACK_BOUNDS[f"DUP{_i}"] = (1, 1024 - _i)
+    STACK_BOUNDS[f"SWAP{_i}"] = (0, 1023 - _i)
+assert set(STACK_BOUNDS) == set(OPCODES)
+
+
 # success-case state -> responsible opcodes (execution_state.py:143-362); aux is 0 for all of them
 RESPONSIBLE = {
     "STOP": ["STOP"], "ADD": ["ADD", "SUB"], "MUL": ["MUL", "DIV", "MOD"], "SDIV_SMOD": ["SDIV", "SMOD"],
@@ -155,6 +176,13 @@ def gen_header():
     arr("ZK_OPCODE_VALID", "uint8_t", valid)
     arr("ZK_OPCODE_CONST_GAS", "uint16_t", gas)
     arr("ZK_OPCODE_RESP_STATE", "uint8_t", resp)
+    dyn, mn, mx = [0] * 256, [0] * 256, [0] * 256
+    for name, (v, g, d) in OPCODES.items():
+        dyn[v] = d
+        mn[v], mx[v] = STACK_BOUNDS[name]
+    arr("ZK_OPCODE_DYNAMIC_GAS", "uint8_t", dyn)
+    arr("ZK_OPCODE_MIN_SP", "int16_t", mn)
+    arr("ZK_OPCODE_MAX_SP", "int16_t", mx)
     impl = [0] * (len(ExecutionState) + 1)
     for s in ExecutionState:
         impl[int(s)] = 0 if s.name in REFERENCE_UNIMPLEMENTED else 1
