@@ -99,6 +99,15 @@ typedef struct zk_evm_tables {
     const uint64_t* block;      const uint32_t* block_flags; uint64_t n_block;
     uint32_t begin_with_first_step;
     uint32_t end_with_last_step;
+    /* tables only the copy / SHA3 / EXP gadgets look up (Tables.copy_table / keccak_table / exp_table,
+     * table.py:614-619); n == 0 when absent.  copy uint64[n][14][4] (CopyTableRow :494-507: is_first,
+     * src_id lo/hi, src_tag, dst_id lo/hi, dst_tag, src_addr, src_addr_end, dst_addr, length, rlc_acc,
+     * rw_counter, rwc_inc); keccak uint64[n][5][4] (KeccakTableRow :511-515); exp uint64[n][11][4]
+     * (ExpTableRow :538-548: is_step, identifier, is_last, base_limb0..3, exponent lo/hi,
+     * exponentiation lo/hi). */
+    const uint64_t* copy;       uint64_t n_copy;
+    const uint64_t* keccak;     uint64_t n_keccak;
+    const uint64_t* exp;        uint64_t n_exp;
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
 #define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */

@@ -51,7 +51,8 @@ MAX_U64 = (1 << 64) - 1
 class EvmWitness:
     """Flattened tables as Python ints + the indices the lookups use."""
 
-    def __init__(self, steps, rw, rw_flags, bytecode, tx=(), tx_flags=(), block=(), block_flags=()):
+    def __init__(self, steps, rw, rw_flags, bytecode, tx=(), tx_flags=(), block=(), block_flags=(), copy=(),
+                 keccak=(), exp=()):
         self.steps = steps
         self.rw = [tuple(r) for r in rw]
         self.rw_flags = list(rw_flags)
@@ -72,6 +73,17 @@ class EvmWitness:
         self.blk_idx = {}
         for i, r in enumerate(self.block):
             self.blk_idx.setdefault(r[:2], []).append(i)
+        # copy table (14 cells, table.py:494-507), keccak table (5, :511-515), exp table (11, :538-548)
+        self.copy = [tuple(r) for r in copy]
+        self.keccak = [tuple(r) for r in keccak]
+        self.exp = [tuple(r) for r in exp]
+        self.copy_idx, self.keccak_idx, self.exp_idx = {}, {}, {}
+        for i, r in enumerate(self.copy):
+            self.copy_idx.setdefault(r[12], []).append(i)
+        for i, r in enumerate(self.keccak):
+            self.keccak_idx.setdefault((r[2], r[1]), []).append(i)
+        for i, r in enumerate(self.exp):
+            self.exp_idx.setdefault(r[1], []).append(i)
 
 
 def _distinct_match(rows, cands, query):
@@ -295,6 +307,50 @@ class Ins:
             raise Fail(UNSUPPORTED, self.seq)
         if not ok:
             self.fail(LOOKUP_UNSAT)
+
+    # ---- copy / keccak / exp tables (table.py:760-814) -------------------------------------
+    def copy_lookup(self, src_id, src_tag, dst_id, dst_tag, src_addr, src_addr_end, dst_addr, length, rw_counter):
+        """ids are (lo, hi) pairs (a field value v travels as (v, 0), WordOrValue(FQ)); non-TxLog destinations"""
+        q = [(1, src_id[0] % P), (2, src_id[1] % P), (3, int(src_tag)), (4, dst_id[0] % P), (5, dst_id[1] % P),
+             (6, int(dst_tag)), (7, src_addr % P), (8, src_addr_end % P), (9, dst_addr % P), (10, length % P),
+             (12, rw_counter % P)]
+        r = self.w.copy[self._lookup(self.w.copy, self.w.copy_idx.get(rw_counter % P, ()), q)]
+        return r[13], r[11]  # rwc_inc, rlc_acc
+
+    def keccak_lookup(self, length, value_rlc):
+        q = [(0, 2), (2, length % P), (1, value_rlc % P)]
+        r = self.w.keccak[self._lookup(self.w.keccak, self.w.keccak_idx.get((length % P, value_rlc % P), ()), q)]
+        return (r[3], r[4])
+
+    def exp_lookup(self, identifier, is_last, base_limbs, exponent):
+        q = [(0, 1), (1, identifier % P), (2, is_last % P)] + [(3 + k, base_limbs[k] % P) for k in range(4)] + \
+            [(7, exponent[0] % P), (8, exponent[1] % P)]
+        r = self.w.exp[self._lookup(self.w.exp, self.w.exp_idx.get(identifier % P, ()), q)]
+        return (r[9], r[10])
+
+    # ---- memory helpers of the copy gadgets (instruction.py:1122-1192) -----------------------
+    def memory_offset_and_length(self, offset_word, length_word):
+        length = self.word_to_fq(length_word, 5)
+        if length == 0:
+            return 0, 0
+        return self.word_to_fq(offset_word, 5), length
+
+    def max_(self, lhs, rhs, n_bytes):  # instruction.py:476-478
+        lt, _ = self.compare(lhs, rhs, n_bytes)
+        return self.select(lt, rhs, lhs)
+
+    def memory_expansion_dynamic_length(self, cd_offset, cd_length):  # (rd_* = None form)
+        cd_size, _ = self.constant_divmod(cd_offset + cd_length + 31, 32, 4)
+        nxt = self.max_(self.curr[S_MWS], cd_size, 4)
+        g0 = self.memory_gas_cost(self.curr[S_MWS])
+        g1 = self.memory_gas_cost(nxt)
+        return nxt, (g1 - g0) % P
+
+    def memory_copier_gas_cost(self, length, expansion_gas, per_word=3):
+        words, _ = self.constant_divmod(length + 31, 32, 4)
+        gas = (words * per_word + expansion_gas) % P
+        self.range_check(gas, 8)
+        return gas
 
     # ---- stack / memory / call context (instruction.py:866-935) --------------------------
     def stack_pop(self):
@@ -1061,6 +1117,136 @@ def g_calldataload(i):  # calldataload.py
     i.same_context(opcode, rw_counter=D(i.rw_off), program_counter=D(1), stack_pointer=D(0))
 
 
+CDT_BYTECODE, CDT_MEMORY, CDT_TXCALLDATA, CDT_TXLOG, CDT_RLCACC = 1, 2, 3, 4, 5  # CopyDataTypeTag (table.py:306-323)
+
+
+def g_sha3(i):  # sha3.py
+    opcode = i.opcode_lookup(True)
+    offset, size, sha3_value = i.stack_pop(), i.stack_pop(), i.stack_push()
+    mem_off, length = i.memory_offset_and_length(offset, size)
+    call_id = (i.curr[S_CALL_ID], 0)
+    if length != 0:
+        rwc_inc, rlc_acc = i.copy_lookup(call_id, CDT_MEMORY, call_id, CDT_RLCACC, mem_off, mem_off + length, 0, length,
+                                         i.curr[S_RWC] + i.rw_off)
+    else:
+        rwc_inc, rlc_acc = 0, 0
+    out = i.keccak_lookup(length, rlc_acc)
+    i.constrain_equal_word(out, sha3_value)
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mem_off, length)
+    gas = i.memory_copier_gas_cost(length, exp_gas, 6)
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(1),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=gas)
+
+
+def g_codecopy(i):  # codecopy.py
+    opcode = i.opcode_lookup(True)
+    mem_w, code_w, size_w = i.stack_pop(), i.stack_pop(), i.stack_pop()
+    mem_off, size = i.memory_offset_and_length(mem_w, size_w)
+    code_off = i.word_to_fq(code_w, 5)
+    code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
+    code_size = i.bytecode_length(code_hash)
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mem_off, size)
+    gas = i.memory_copier_gas_cost(size, exp_gas)
+    rwc_inc = 0
+    if size != 0:
+        rwc_inc, _ = i.copy_lookup(code_hash, CDT_BYTECODE, (i.curr[S_CALL_ID], 0), CDT_MEMORY, code_off, code_size, mem_off,
+                                   size, i.curr[S_RWC] + i.rw_off)
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(3),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=gas)
+
+
+def g_calldatacopy(i):  # calldatacopy.py
+    opcode = i.opcode_lookup(True)
+    mem_w, data_w, len_w = i.stack_pop(), i.stack_pop(), i.stack_pop()
+    mem_off, length = i.memory_offset_and_length(mem_w, len_w)
+    data_off = i.word_to_fq(data_w, 5)
+    is_root = i.curr[S_IS_ROOT] != 0
+    if is_root:
+        src_id = i.call_context_lookup(CC.TxId)
+        cd_length = i.call_context_lookup(CC.CallDataLength)
+        cd_offset = 0
+    else:
+        src_id = i.call_context_lookup(CC.CallerId)
+        cd_length = i.call_context_lookup(CC.CallDataLength)
+        cd_offset = i.call_context_lookup(CC.CallDataOffset)
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mem_off, length)
+    gas = i.memory_copier_gas_cost(length, exp_gas)
+    src_tag = i.select(int(is_root), CDT_TXCALLDATA, CDT_MEMORY)
+    rwc_inc = 0
+    if length != 0:
+        rwc_inc, _ = i.copy_lookup((src_id, 0), src_tag, (i.curr[S_CALL_ID], 0), CDT_MEMORY, cd_offset + data_off,
+                                   cd_offset + cd_length, mem_off, length, i.curr[S_RWC] + i.rw_off)
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(3),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=gas)
+
+
+def g_returndatacopy(i):  # returndatacopy.py
+    opcode = i.opcode_lookup(True)
+    mem_w, off_w, size_w = i.stack_pop(), i.stack_pop(), i.stack_pop()
+    last_callee = i.call_context_lookup(CC.LastCalleeId)
+    rd_length = i.call_context_lookup(CC.LastCalleeReturnDataLength)
+    rd_offset = i.call_context_lookup(CC.LastCalleeReturnDataOffset)
+    end = i.word_to_fq(off_w, 8) + i.word_to_fq(size_w, 8)
+    i.range_check(rd_length - end, 4)
+    mem_off, size = i.memory_offset_and_length(mem_w, size_w)
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mem_off, size)
+    gas = i.memory_copier_gas_cost(size, exp_gas)
+    rwc_inc, _ = i.copy_lookup((last_callee, 0), CDT_MEMORY, (i.curr[S_CALL_ID], 0), CDT_MEMORY, rd_offset, rd_offset + size,
+                               mem_off, size, i.curr[S_RWC] + i.rw_off)
+    i.require(rwc_inc % P == size * 2 % P)  # plain assert (:44)
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(3),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=gas)
+
+
+def g_extcodecopy(i):  # extcodecopy.py
+    opcode = i.opcode_lookup(True)
+    address = i.word_to_fq(i.stack_pop(), 20)
+    mem_w, code_w, size_w = i.stack_pop(), i.stack_pop(), i.stack_pop()
+    code_off = i.word_to_fq(code_w, 8)
+    mem_off, size = i.memory_offset_and_length(mem_w, size_w)
+    tx_id = i.call_context_lookup(CC.TxId)
+    rev = i.reversion_info()
+    rowf = i.state_write(TG.TxAccessListAccount, tx_id, address, value=(1, 0), reversion_info=rev)
+    is_warm = i.value_of(i.row_value_prev(rowf))
+    code_hash = _account_read_word(i, address, ACC.CodeHash)
+    exists = 1 - i.is_zero_word(code_hash)
+    code_size = i.bytecode_length(code_hash) if exists == 1 else 0
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mem_off, size)
+    copier = i.memory_copier_gas_cost(size, exp_gas)
+    gas = (copier + i.select(is_warm, 0, COLD_ACCOUNT_EXTRA)) % P
+    rwc_inc = 0
+    if size != 0:
+        rwc_inc, _ = i.copy_lookup(code_hash, CDT_BYTECODE, (i.curr[S_CALL_ID], 0), CDT_MEMORY, code_off, code_size, mem_off,
+                                   size, i.curr[S_RWC] + i.rw_off)
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(4),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=gas)
+
+
+def g_exp(i):  # exp.py
+    opcode = i.opcode_lookup(True)
+    base, exponent, result = i.stack_pop(), i.stack_pop(), i.stack_push()
+    e_lo, e_hi = exponent[0] % P, exponent[1] % P
+    if e_hi == 0 and e_lo == 0:
+        i.constrain_equal(result[0], 1)
+        i.constrain_zero(result[1])
+    elif e_hi == 0 and e_lo == 1:
+        i.constrain_equal(result[0], base[0])
+        i.constrain_equal(result[1], base[1])
+    else:
+        limbs = i.to_64s(base)
+        identifier = (i.curr[S_RWC] + i.rw_off) % P
+        single_step = int(e_hi == 0 and e_lo == 2)
+        res = i.exp_lookup(identifier, single_step, limbs, exponent)
+        two = i.word_checked(2, 0)
+        int_res = i.exp_lookup(identifier, 1, limbs, two)
+        zero = i.word_from_int(0)
+        i.mul_add_words(base, base, zero, int_res)
+        i.constrain_equal_word(res, result)
+    eb = i.to_le_bytes(exponent)  # byte_size (instruction.py:492-494)
+    byte_size = len(bytes(eb).rstrip(b"\x00"))
+    i.same_context(opcode, rw_counter=D(3), program_counter=D(1), stack_pointer=D(1), dynamic_gas_cost=50 * byte_size)
+
+
 def g_gas(i):  # gas.py
     opcode = i.opcode_lookup(True)
     i.constrain_equal(opcode, OP.GAS)
@@ -1275,6 +1461,8 @@ GADGETS = {
     ES.SELFBALANCE: g_selfbalance, ES.BlockCtx: g_blockctx, ES.GAS: g_gas, ES.MSIZE: g_msize,
     ES.CODESIZE: g_codesize, ES.SAR: g_sar, ES.SDIV_SMOD: g_sdiv_smod, ES.BALANCE: g_balance, ES.EXTCODESIZE: g_extcodesize,
     ES.EXTCODEHASH: g_extcodehash, ES.BLOCKHASH: g_blockhash, ES.CALLDATALOAD: g_calldataload,
+    ES.SHA3: g_sha3, ES.CODECOPY: g_codecopy, ES.CALLDATACOPY: g_calldatacopy, ES.RETURNDATACOPY: g_returndatacopy,
+    ES.EXTCODECOPY: g_extcodecopy, ES.EXP: g_exp,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }

@@ -22,7 +22,8 @@ from oracle.gen_golden_evm import REF_TESTS, TEST_FILES, Harvest, fuzz_wire, ref
 def to_witness(w):
     return eo.EvmWitness(wire.rowmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
-                         wire.rowmajor_to_rows(w["block"]), w["block_flags"])
+                         wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
+                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]))
 
 
 def main():

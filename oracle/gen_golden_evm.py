@@ -25,7 +25,8 @@ from oracle.gen_golden import kind_of_exception  # noqa: E402
 TEST_FILES = """add_sub mul_div_mod comparator slt_sgt iszero not bitwise byte signextend push pop shl_shr addmod
 mulmod memory caller callvalue address calldatasize returndatasize origin gasprice selfbalance block_ctx gas
 msize codesize jump jumpi sload sstore stop sar sdiv_smod balance extcodesize extcodehash blockhash
-calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_jump""".split()
+calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_jump sha3 codecopy calldatacopy
+returndatacopy extcodecopy exp""".split()
 MAX_CASES_PER_FILE = 48
 
 
@@ -69,6 +70,7 @@ def unflatten(wire):
     """wire dict -> reference (Tables, steps): used to ask the reference about fuzzed cells."""
     from zkevm_specs.evm_circuit import (BlockTableRow, BytecodeTableRow, ExecutionState, RWTableRow, StepState,
                                          Tables, TxTableRow)
+    from zkevm_specs.evm_circuit.table import CopyTableRow, ExpTableRow, KeccakTableRow
     from zkevm_specs.util import FQ, Word, WordOrValue
 
     from oracle.wire import colmajor_to_rows, rowmajor_to_rows
@@ -98,7 +100,15 @@ def unflatten(wire):
              for c, f in zip(rowmajor_to_rows(wire["tx"]), wire["tx_flags"]))
     blk = set(BlockTableRow(FQ(c[0]), FQ(c[1]), wov(c[2], c[3], f & 1))
               for c, f in zip(rowmajor_to_rows(wire["block"]), wire["block_flags"]))
-    return Tables(block_table=blk, tx_table=tx, withdrawal_table=set(), bytecode_table=bc, rw_table=rw), steps
+    tables = Tables(block_table=blk, tx_table=tx, withdrawal_table=set(), bytecode_table=bc, rw_table=rw)
+    WV = lambda lo, hi: WordOrValue(W(lo, hi))  # noqa: E731  (ids match on lo/hi only)
+    tables.copy_table = set(CopyTableRow(FQ(c[0]), WV(c[1], c[2]), FQ(c[3]), WV(c[4], c[5]), FQ(c[6]), FQ(c[7]), FQ(c[8]),
+                                         FQ(c[9]), FQ(c[10]), FQ(c[11]), FQ(c[12]), FQ(c[13]))
+                            for c in rowmajor_to_rows(wire["copy"]))
+    tables.keccak_table = set(KeccakTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), W(c[3], c[4])) for c in rowmajor_to_rows(wire["keccak"]))
+    tables.exp_table = set(ExpTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), FQ(c[6]), W(c[7], c[8]),
+                                       W(c[9], c[10])) for c in rowmajor_to_rows(wire["exp"]))
+    return tables, steps
 
 
 def fuzz_wire(wire, rng):
@@ -114,7 +124,13 @@ def fuzz_wire(wire, rng):
 
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
-        if which == "steps":
+        aux = [k for k in ("copy", "keccak", "exp") if k in w and w[k].shape[0]]
+        if aux and rng.random() < 0.25:
+            k = rng.choice(aux)
+            i, c = rng.randrange(w[k].shape[0]), rng.randrange(w[k].shape[1])
+            old = cur(w[k], (i, c))
+            put(w[k], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(64))]))
+        elif which == "steps":
             c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[0])
             if c in (3, 4):
                 put(w["steps"], (i, c), rng.randrange(2))

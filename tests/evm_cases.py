@@ -7,7 +7,16 @@ import numpy as np
 
 from oracle import evm_oracle as eo, wire
 
-FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags")
+FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp")
+_OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11}  # tables only some gadgets need; absent = empty
+
+
+def with_defaults(w):
+    w = dict(w)
+    for k, nc in _OPTIONAL.items():
+        if k not in w:
+            w[k] = np.zeros((0, nc, 4), dtype=np.uint64)
+    return w
 
 
 def golden_files(golden_dir):
@@ -18,14 +27,16 @@ def load_cases(fn):
     g = np.load(fn)
     for i, nm in enumerate(g["names"]):
         k = f"c{i:04d}"
-        w = {f: g[f"{k}_{f}"] for f in FIELDS}
+        w = with_defaults({f: g[f"{k}_{f}"] for f in FIELDS if f"{k}_{f}" in g.files})
         yield str(nm), w, g[k + "_opts"], g[k + "_ref_kind"]
 
 
 def to_witness(w):
+    w = with_defaults(w)
     return eo.EvmWitness(wire.rowmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
-                         wire.rowmajor_to_rows(w["block"]), w["block_flags"])
+                         wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
+                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]))
 
 
 def oracle_status(w, opts=(0, 0)):
@@ -33,6 +44,7 @@ def oracle_status(w, opts=(0, 0)):
 
 
 def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
+    w = with_defaults(w)
     a = {k: np.ascontiguousarray(w[k]) for k in FIELDS}
     n = a["steps"].shape[0]
     st = np.zeros(max(n - 1, 1), dtype=np.uint32)
@@ -41,6 +53,8 @@ def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
     lib.sim_evm_verify(vp(a["steps"]), u64(n), vp(a["rw"]), vp(a["rw_flags"]), u64(a["rw"].shape[0]),
                        vp(a["bytecode"]), u64(a["bytecode"].shape[0]), vp(a["tx"]), vp(a["tx_flags"]),
                        u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
+                       vp(a["copy"]), u64(a["copy"].shape[0]), vp(a["keccak"]), u64(a["keccak"].shape[0]),
+                       vp(a["exp"]), u64(a["exp"].shape[0]),
                        ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1) | (4 if generic_index else 0)), vp(st))
     return st[: n - 1].tolist()
 
@@ -58,7 +72,13 @@ def fuzz_wire(w, rng):
 
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
-        if which == "steps":
+        aux = [k for k in ("copy", "keccak", "exp") if k in w and w[k].shape[0]]
+        if aux and rng.random() < 0.25:
+            k = rng.choice(aux)
+            i, c = rng.randrange(w[k].shape[0]), rng.randrange(w[k].shape[1])
+            old = cur(w[k], (i, c))
+            put(w[k], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(64))]))
+        elif which == "steps":
             c, i = rng.randrange(1, 13), rng.randrange(w["steps"].shape[0])
             if c in (3, 4):
                 put(w["steps"], (i, c), rng.randrange(2))

@@ -83,11 +83,18 @@ static void host_table(HostTable& h, const u64* cells, const u32* flags, u64 n, 
 
 extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, const u32* rw_flags, u64 n_rw,
                               const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
-                              const u64* block, const u32* block_flags, u64 n_blk, u32 opts, u32* status) {
+                              const u64* block, const u32* block_flags, u64 n_blk, const u64* copy, u64 n_copy,
+                              const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, u32 opts, u32* status) {
     EvmArgs a;
     a.steps = steps;
     a.n_steps = n_steps;
-    HostTable trw, tbc, ttx, tblk;
+    HostTable trw, tbc, ttx, tblk, tcopy, tkeccak, texp;
+    host_table(tcopy, copy, nullptr, n_copy, COPY_T_NCELLS, copy_key_hash);
+    host_table(tkeccak, keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    host_table(texp, exp, nullptr, n_exp, EXP_T_NCELLS, expt_key_hash);
+    a.copy = tcopy.t;
+    a.keccak = tkeccak.t;
+    a.exp = texp.t;
     host_table(trw, rw, rw_flags, n_rw, RW_NCELLS, rw_key_hash);
     host_table(tbc, bytecode, nullptr, n_bc, BYTECODE_NCELLS, bc_key_hash);
     host_table(ttx, tx, tx_flags, n_tx, TX_NCELLS, tx_key_hash);

@@ -36,6 +36,9 @@ class ZkEvmTables(ctypes.Structure):
         ("tx", ctypes.c_void_p), ("tx_flags", ctypes.c_void_p), ("n_tx", ctypes.c_uint64),
         ("block", ctypes.c_void_p), ("block_flags", ctypes.c_void_p), ("n_block", ctypes.c_uint64),
         ("begin_with_first_step", ctypes.c_uint32), ("end_with_last_step", ctypes.c_uint32),
+        ("copy", ctypes.c_void_p), ("n_copy", ctypes.c_uint64),
+        ("keccak", ctypes.c_void_p), ("n_keccak", ctypes.c_uint64),
+        ("exp", ctypes.c_void_p), ("n_exp", ctypes.c_uint64),
     ]
 
 

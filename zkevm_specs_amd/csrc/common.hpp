@@ -94,6 +94,10 @@ struct ZkCodeDir {
     u32 mask;
     u32 n;
 };
+// keccak table (KeccakTableRow, table.py:511-515: state_tag, input_rlc, input_len, output lo/hi), keyed on (rlc, len)
+enum { KECCAK_NCELLS = 5 };
+ZK_HD u64 keccak_key_hash_cells(const Fr& rlc, const Fr& len) { return zk_hash_cell(zk_hash_cell(0x6b656363u, rlc), len); }
+ZK_HD u64 keccak_key_hash(const ZkTable& t, u32 r) { return keccak_key_hash_cells(zk_table_cell(t, r, 1), zk_table_cell(t, r, 2)); }
 ZK_HD u64 zk_code_hash_key(const Fr& lo, const Fr& hi) { return zk_hash_cell(zk_hash_cell(0xc0de5u, lo), hi); }
 
 // Column-major witness: cell c of row i at cells[(c * n + i) * 4].

@@ -28,11 +28,18 @@ enum { S_STATE = 0, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, 
 enum { R_RWC = 0, R_RW, R_TAG, R_ID, R_ADDR, R_FT, R_KEY_LO, R_KEY_HI, R_VAL_LO, R_VAL_HI, R_PREV_LO, R_PREV_HI, R_AUX_LO, R_AUX_HI, RW_NCELLS };
 enum { B_HASH_LO = 0, B_HASH_HI, B_TAG, B_INDEX, B_IS_CODE, B_VALUE, BYTECODE_NCELLS };
 enum { TX_NCELLS = 5, BLOCK_NCELLS = 4 };
+// CopyTableRow (table.py:494-507) and ExpTableRow (:538-548) as the EVM circuit looks them up
+enum { CT_IS_FIRST = 0, CT_SRC_ID_LO, CT_SRC_ID_HI, CT_SRC_TAG, CT_DST_ID_LO, CT_DST_ID_HI, CT_DST_TAG, CT_SRC_ADDR,
+       CT_SRC_ADDR_END, CT_DST_ADDR, CT_LENGTH, CT_RLC_ACC, CT_RWC, CT_RWC_INC, COPY_T_NCELLS };
+enum { XT_IS_STEP = 0, XT_ID, XT_IS_LAST, XT_BASE0, XT_BASE1, XT_BASE2, XT_BASE3, XT_EXP_LO, XT_EXP_HI, XT_RES_LO, XT_RES_HI,
+       EXP_T_NCELLS };
+enum { CDT_Bytecode = 1, CDT_Memory, CDT_TxCalldata, CDT_TxLog, CDT_RlcAcc };  // CopyDataTypeTag (table.py:336-353)
 
 struct EvmArgs {
     const u64* steps;  // [n_steps][13][4]
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
+    ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
     const ZkRwMeta* rw_meta;  // nullptr = generic index only
     ZkCodeDir codes;          // n == 0 = generic index only
     unsigned long long* prof;  // optional phase timestamps (tuning aid): [block][8]
@@ -184,6 +191,11 @@ ZK_HD u64 tx_key_hash(const ZkTable& t, u32 r) {
 }
 ZK_HD u64 blk_key_hash_cells(const Fr& a, const Fr& b) { return zk_hash_cell(zk_hash_cell(0x3c6efu, a), b); }
 ZK_HD u64 blk_key_hash(const ZkTable& t, u32 r) { return blk_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1)); }
+
+ZK_HD u64 copy_key_hash_cells(const Fr& rwc, const Fr& src_addr) { return zk_hash_cell(zk_hash_cell(0xc09fu, rwc), src_addr); }
+ZK_HD u64 copy_key_hash(const ZkTable& t, u32 r) { return copy_key_hash_cells(zk_table_cell(t, r, CT_RWC), zk_table_cell(t, r, CT_SRC_ADDR)); }
+ZK_HD u64 expt_key_hash_cells(const Fr& id, const Fr& is_last) { return zk_hash_cell(zk_hash_cell(0xe4b7u, id), is_last); }
+ZK_HD u64 expt_key_hash(const ZkTable& t, u32 r) { return expt_key_hash_cells(zk_table_cell(t, r, XT_ID), zk_table_cell(t, r, XT_IS_LAST)); }
 
 ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
     bool same = true;
@@ -372,6 +384,43 @@ ZK_HD WordOrValue block_lookup(Ins& I, u32 field_tag, const Fr* number = nullptr
     v.w = word_of(zk_table_cell(I.a->block, r, 2), zk_table_cell(I.a->block, r, 3));
     v.is_word = I.a->block.flags ? (I.a->block.flags[r] & 1u) : true;
     return v;
+}
+
+// Tables.copy_lookup (table.py:760-787) for non-TxLog destinations: nine query cells
+struct CopyRes {
+    Fr rwc_inc, rlc_acc;
+};
+ZK_HD CopyRes copy_lookup(Ins& I, const Word& src_id, u32 src_tag, const Word& dst_id, u32 dst_tag, const Fr& src_addr,
+                          const Fr& src_addr_end, const Fr& dst_addr, const Fr& length, const Fr& rw_counter) {
+    Fr q[COPY_T_NCELLS];
+    q[CT_IS_FIRST] = fr_zero();
+    q[CT_SRC_ID_LO] = src_id.lo; q[CT_SRC_ID_HI] = src_id.hi; q[CT_SRC_TAG] = fr_u(src_tag);
+    q[CT_DST_ID_LO] = dst_id.lo; q[CT_DST_ID_HI] = dst_id.hi; q[CT_DST_TAG] = fr_u(dst_tag);
+    q[CT_SRC_ADDR] = src_addr; q[CT_SRC_ADDR_END] = src_addr_end; q[CT_DST_ADDR] = dst_addr;
+    q[CT_LENGTH] = length; q[CT_RLC_ACC] = fr_zero(); q[CT_RWC] = rw_counter; q[CT_RWC_INC] = fr_zero();
+    const u32 mask = ((1u << COPY_T_NCELLS) - 1u) & ~((1u << CT_IS_FIRST) | (1u << CT_RLC_ACC) | (1u << CT_RWC_INC));
+    u32 r = table_lookup<COPY_T_NCELLS>(I, I.a->copy, copy_key_hash_cells(rw_counter, src_addr), q, mask);
+    CopyRes R;
+    R.rwc_inc = zk_table_cell(I.a->copy, r, CT_RWC_INC);
+    R.rlc_acc = zk_table_cell(I.a->copy, r, CT_RLC_ACC);
+    return R;
+}
+ZK_HD Word word_value(const Fr& v) { return word_of(v, fr_zero()); }  // WordOrValue(FQ): hi cell is 0
+// Tables.keccak_lookup (table.py:789-795): state_tag = 2 (Finalize), input_len, input_rlc -> output
+ZK_HD Word keccak_lookup(Ins& I, const Fr& length, const Fr& value_rlc) {
+    Fr q[KECCAK_NCELLS];
+    q[0] = fr_u(2); q[1] = value_rlc; q[2] = length; q[3] = fr_zero(); q[4] = fr_zero();
+    u32 r = table_lookup<KECCAK_NCELLS>(I, I.a->keccak, keccak_key_hash_cells(value_rlc, length), q, 0x7u);
+    return word_of(zk_table_cell(I.a->keccak, r, 3), zk_table_cell(I.a->keccak, r, 4));
+}
+// Tables.exp_lookup (table.py:797-814): is_step = 1, identifier, is_last, base limbs, exponent -> exponentiation
+ZK_HD Word exp_lookup(Ins& I, const Fr& identifier, const Fr& is_last, const u64 base_limbs[4], const Word& exponent) {
+    Fr q[EXP_T_NCELLS];
+    q[XT_IS_STEP] = fr_u(1); q[XT_ID] = identifier; q[XT_IS_LAST] = is_last;
+    for (int k = 0; k < 4; k++) q[XT_BASE0 + k] = fr_u(base_limbs[k]);
+    q[XT_EXP_LO] = exponent.lo; q[XT_EXP_HI] = exponent.hi; q[XT_RES_LO] = fr_zero(); q[XT_RES_HI] = fr_zero();
+    u32 r = table_lookup<EXP_T_NCELLS>(I, I.a->exp, expt_key_hash_cells(identifier, is_last), q, 0x1ffu);
+    return word_of(zk_table_cell(I.a->exp, r, XT_RES_LO), zk_table_cell(I.a->exp, r, XT_RES_HI));
 }
 
 // Fixed-table membership in closed form (table.py:37-103, 673-688): exact 4-tuple semantics,
@@ -632,6 +681,8 @@ struct Tail {
     Fr opcode, pc_val, mws_val, dyn_gas;
     int rw_delta, sp_delta, rev_delta;
     u32 pc_kind, mws_kind;  // Trans kinds: 0 same, 1 delta, 2 to
+    u32 rwc_mode;           // 0: rw_counter delta is rw_delta; 1 / 2: the gadget already compared next.rw_counter
+                            // with a field-valued delta (copy gadgets: rw_counter_offset + rwc_inc) -> equal / different
     bool enabled;
 };
 ZK_HD void set_tail(Tail& T, const Fr& opcode, int rw_delta, const Trans& pc, int sp_delta, const Trans& mws,
@@ -645,7 +696,12 @@ ZK_HD void set_tail(Tail& T, const Fr& opcode, int rw_delta, const Trans& pc, in
     T.mws_val = mws.value;
     T.rev_delta = rev_delta;
     T.dyn_gas = dyn_gas;
+    T.rwc_mode = 0;
     T.enabled = true;
+}
+// rw_counter = Transition.delta(field value): compare now, report at the transition's checkpoint
+ZK_HD void set_tail_rwc_delta(Ins& I, Tail& T, const Fr& delta) {
+    T.rwc_mode = fr_eq(ev_next(I, S_RWC), fr_add(ev_curr(I, S_RWC), delta)) ? 1u : 2u;
 }
 ZK_HD void set_tail3(Tail& T, const Fr& opcode, int rwc, int pc, int sp) {
     set_tail(T, opcode, rwc, t_delta_i(pc), sp, t_same(), 0, fr_zero());
@@ -663,7 +719,8 @@ ZK_HD void same_context(Ins& I, const Tail& T) {
     Trans pc, mws;
     pc.kind = T.pc_kind; pc.value = T.pc_val;
     mws.kind = T.mws_kind; mws.value = T.mws_val;
-    transition(I, S_RWC, t_delta_i(T.rw_delta));  // Transition.delta(0) == same
+    if (T.rwc_mode == 0u) transition(I, S_RWC, t_delta_i(T.rw_delta));  // Transition.delta(0) == same
+    else ev_require(I, T.rwc_mode == 1u);
     transition(I, S_PC, pc);
     transition(I, S_SP, t_int(T.sp_delta));
     transition(I, S_GAS, t_delta(fr_neg(gas_cost)));
@@ -1408,6 +1465,156 @@ ZK_HD void g_calldataload(Ins& I, Tail& T) {  // calldataload.py
     constrain_equal_word(I, word_from_u256(data), push);
     set_tail3(T, opcode, (int)I.rw_off, 1, 0);
 }
+// ---- copy-table gadgets (sha3.py, codecopy.py, calldatacopy.py, returndatacopy.py, extcodecopy.py) ----
+// memory_offset_and_length (instruction.py:1122-1127)
+ZK_HD void memory_offset_and_length(Ins& I, const Word& offset_word, const Word& length_word, Fr& offset, Fr& length) {
+    offset = fr_zero();
+    length = word_to_fq(I, length_word, 5);
+    if (I.err || fr_is_zero(length)) return;
+    offset = word_to_fq(I, offset_word, 5);
+}
+// memory_expansion_dynamic_length (instruction.py:1157-1181, rd_* = None) then memory_copier_gas_cost (:1183-1192)
+ZK_HD void copy_memory_gas(Ins& I, const Fr& mem_off, const Fr& length, u32 per_word, Fr& next_size, Fr& gas) {
+    Fr mws = ev_curr(I, S_MWS);
+    Fr cd_size = constant_divmod_shift(I, fr_add_u64(fr_add(mem_off, length), 31), 5, 4);
+    u32 lt, eq;
+    ev_compare(I, mws, cd_size, 4, lt, eq);
+    next_size = ev_select_b(I, lt) ? cd_size : mws;
+    Fr g0 = memory_gas_cost(I, mws);
+    Fr g1 = memory_gas_cost(I, next_size);
+    Fr words = constant_divmod_shift(I, fr_add_u64(length, 31), 5, 4);
+    gas = fr_add(fr_mul_u64(words, per_word), fr_sub(g1, g0));
+    range_check(I, gas, 8);
+}
+ZK_HD void copy_tail(Ins& I, Tail& T, const Fr& opcode, const Fr& rwc_inc, int sp_delta, const Fr& next_size, const Fr& gas) {
+    set_tail(T, opcode, 0, t_delta_i(1), sp_delta, t_to(next_size), 0, gas);
+    set_tail_rwc_delta(I, T, fr_add_u64(rwc_inc, I.rw_off));
+}
+ZK_HD void g_sha3(Ins& I, Tail& T) {  // sha3.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word offset, size, sha3_value;
+    offset = stack_pop(I); size = stack_pop(I); sha3_value = stack_push(I);
+    Fr mem_off, length; EV_TRY(memory_offset_and_length(I, offset, size, mem_off, length));
+    const Word cid = word_value(I.call_id);
+    CopyRes cr; cr.rwc_inc = fr_zero(); cr.rlc_acc = fr_zero();
+    if (!fr_is_zero(length))
+        EV_TRY(cr = copy_lookup(I, cid, CDT_Memory, cid, CDT_RlcAcc, mem_off, fr_add(mem_off, length), fr_zero(), length,
+                                fr_add_u64(I.rwc, I.rw_off)));
+    Word out; EV_TRY(out = keccak_lookup(I, length, cr.rlc_acc));
+    constrain_equal_word(I, out, sha3_value);
+    Fr next_size, gas; EV_TRY(copy_memory_gas(I, mem_off, length, 6, next_size, gas));
+    copy_tail(I, T, opcode, cr.rwc_inc, 1, next_size, gas);
+}
+ZK_HD void g_codecopy(Ins& I, Tail& T) {  // codecopy.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word mem_w, code_w, size_w;
+    mem_w = stack_pop(I); code_w = stack_pop(I); size_w = stack_pop(I);
+    Fr mem_off, size; EV_TRY(memory_offset_and_length(I, mem_w, size_w, mem_off, size));
+    Fr code_off; EV_TRY(code_off = word_to_fq(I, code_w, 5));
+    Fr code_size; code_size = bytecode_length(I, curr_code_hash(I));
+    Fr next_size, gas; EV_TRY(copy_memory_gas(I, mem_off, size, 3, next_size, gas));
+    CopyRes cr; cr.rwc_inc = fr_zero();
+    if (!fr_is_zero(size))
+        EV_TRY(cr = copy_lookup(I, curr_code_hash(I), CDT_Bytecode, word_value(I.call_id), CDT_Memory, code_off, code_size, mem_off,
+                                size, fr_add_u64(I.rwc, I.rw_off)));
+    copy_tail(I, T, opcode, cr.rwc_inc, 3, next_size, gas);
+}
+ZK_HD void g_calldatacopy(Ins& I, Tail& T) {  // calldatacopy.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word mem_w, data_w, len_w;
+    mem_w = stack_pop(I); data_w = stack_pop(I); len_w = stack_pop(I);
+    Fr mem_off, length; EV_TRY(memory_offset_and_length(I, mem_w, len_w, mem_off, length));
+    Fr data_off; EV_TRY(data_off = word_to_fq(I, data_w, 5));
+    const bool is_root = !fr_is_zero(ev_curr(I, S_IS_ROOT));
+    Fr src_id, cd_length, cd_offset = fr_zero();
+    src_id = call_context_lookup(I, is_root ? CC_TxId : CC_CallerId);
+    cd_length = call_context_lookup(I, CC_CallDataLength);
+    if (!is_root) cd_offset = call_context_lookup(I, CC_CallDataOffset);
+    if (I.err) return;
+    Fr next_size, gas; EV_TRY(copy_memory_gas(I, mem_off, length, 3, next_size, gas));
+    I.seq++;  // select(FQ(is_root), TxCalldata, Memory)
+    CopyRes cr; cr.rwc_inc = fr_zero();
+    if (!fr_is_zero(length))
+        EV_TRY(cr = copy_lookup(I, word_value(src_id), is_root ? CDT_TxCalldata : CDT_Memory, word_value(I.call_id), CDT_Memory,
+                                fr_add(cd_offset, data_off), fr_add(cd_offset, cd_length), mem_off, length,
+                                fr_add_u64(I.rwc, I.rw_off)));
+    copy_tail(I, T, opcode, cr.rwc_inc, 3, next_size, gas);
+}
+ZK_HD void g_returndatacopy(Ins& I, Tail& T) {  // returndatacopy.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word mem_w, off_w, size_w;
+    mem_w = stack_pop(I); off_w = stack_pop(I); size_w = stack_pop(I);
+    Fr last_callee, rd_length, rd_offset;
+    last_callee = call_context_lookup(I, CC_LastCalleeId);
+    rd_length = call_context_lookup(I, CC_LastCalleeReturnDataLength);
+    rd_offset = call_context_lookup(I, CC_LastCalleeReturnDataOffset);
+    if (I.err) return;
+    Fr o8, s8; EV_TRY(o8 = word_to_fq(I, off_w, 8)); EV_TRY(s8 = word_to_fq(I, size_w, 8));
+    range_check(I, fr_sub(rd_length, fr_add(o8, s8)), 4); if (I.err) return;
+    Fr mem_off, size; EV_TRY(memory_offset_and_length(I, mem_w, size_w, mem_off, size));
+    Fr next_size, gas; EV_TRY(copy_memory_gas(I, mem_off, size, 3, next_size, gas));
+    CopyRes cr;
+    EV_TRY(cr = copy_lookup(I, word_value(last_callee), CDT_Memory, word_value(I.call_id), CDT_Memory, rd_offset,
+                            fr_add(rd_offset, size), mem_off, size, fr_add_u64(I.rwc, I.rw_off)));
+    ev_require(I, fr_eq(cr.rwc_inc, fr_add(size, size))); if (I.err) return;  // plain assert (:44)
+    copy_tail(I, T, opcode, cr.rwc_inc, 3, next_size, gas);
+}
+ZK_HD void g_extcodecopy(Ins& I, Tail& T) {  // extcodecopy.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word aw; aw = stack_pop(I);
+    Fr address; EV_TRY(address = word_to_fq(I, aw, 20));
+    Word mem_w, code_w, size_w;
+    mem_w = stack_pop(I); code_w = stack_pop(I); size_w = stack_pop(I);
+    Fr code_off; EV_TRY(code_off = word_to_fq(I, code_w, 8));
+    Fr mem_off, size; EV_TRY(memory_offset_and_length(I, mem_w, size_w, mem_off, size));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Reversion rv; EV_TRY(rv = reversion_info(I));
+    RwQ W;
+    rwq_init(W, 1, TG_TxAccessListAccount);
+    rwq_set(W, R_ID, tx_id);
+    rwq_set(W, R_ADDR, address);
+    rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+    u32 wr; wr = state_write(I, W, rv);
+    Fr is_warm; EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
+    Word ch; ch = account_read_word(I, address, ACC_CodeHash);
+    if (I.err) return;
+    Fr code_size = fr_zero();
+    if (!is_zero_word(ch)) code_size = bytecode_length(I, ch, true);
+    Fr next_size, copier; EV_TRY(copy_memory_gas(I, mem_off, size, 3, next_size, copier));
+    const bool warm = ev_select(I, is_warm); if (I.err) return;
+    const Fr gas = fr_add_u64(copier, warm ? 0 : 2500);
+    CopyRes cr; cr.rwc_inc = fr_zero();
+    if (!fr_is_zero(size))
+        EV_TRY(cr = copy_lookup(I, ch, CDT_Bytecode, word_value(I.call_id), CDT_Memory, code_off, code_size, mem_off, size,
+                                fr_add_u64(I.rwc, I.rw_off)));
+    copy_tail(I, T, opcode, cr.rwc_inc, 4, next_size, gas);
+}
+ZK_HD void g_exp(Ins& I, Tail& T) {  // exp.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    Word base, exponent, result;
+    base = stack_pop(I); exponent = stack_pop(I); result = stack_push(I);
+    const bool hi0 = fr_is_zero(exponent.hi);
+    if (hi0 && fr_is_zero(exponent.lo)) {
+        constrain_equal(I, result.lo, fr_u(1));
+        constrain_zero(I, result.hi);
+    } else if (hi0 && fr_eq_u64(exponent.lo, 1)) {
+        constrain_equal(I, result.lo, base.lo);
+        constrain_equal(I, result.hi, base.hi);
+    } else {
+        Limbs64 limbs; EV_TRY(limbs = to_64s(I, base));
+        const Fr identifier = fr_add_u64(I.rwc, I.rw_off);
+        const Fr single_step = fr_u(hi0 && fr_eq_u64(exponent.lo, 2) ? 1 : 0);
+        Word res; EV_TRY(res = exp_lookup(I, identifier, single_step, limbs.v, exponent));
+        Word two; two = word_checked(I, fr_u(2), fr_zero());
+        Word int_res; EV_TRY(int_res = exp_lookup(I, identifier, fr_u(1), limbs.v, two));
+        Word zero; zero = word_from_int(I, fr_zero());
+        EV_TRY(mul_add_words(I, base, base, zero, int_res));
+        constrain_equal_word(I, res, result);
+    }
+    if (I.err) return;
+    U256 eb; EV_TRY(eb = to_u256(I, exponent));  // byte_size (instruction.py:492-494)
+    set_tail(T, opcode, 3, t_delta_i(1), 1, t_same(), 0, fr_u(50u * (u32)fr_byte_len(eb)));
+}
 ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
     Fr opcode; opcode = opcode_lookup(I, true);
     u32 tag = 0;
@@ -1720,10 +1927,11 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
-    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: case ES_SDIV_SMOD: return EVM_GROUP_MUL;
+    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: case ES_SDIV_SMOD: case ES_EXP: return EVM_GROUP_MUL;
     case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: case ES_BALANCE: case ES_EXTCODESIZE:
     case ES_EXTCODEHASH: case ES_BLOCKHASH: case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack:
-    case ES_ErrorOutOfGasConstant: case ES_ErrorInvalidJump: return EVM_GROUP_MEM;
+    case ES_ErrorOutOfGasConstant: case ES_ErrorInvalidJump: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY:
+    case ES_RETURNDATACOPY: case ES_EXTCODECOPY: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -1805,6 +2013,12 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
     case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
     case ES_ErrorInvalidJump: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_jump(I, T); } break;
+    case ES_SHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_sha3(I, T); } break;
+    case ES_CODECOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_codecopy(I, T); } break;
+    case ES_CALLDATACOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_calldatacopy(I, T); } break;
+    case ES_RETURNDATACOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_returndatacopy(I, T); } break;
+    case ES_EXTCODECOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodecopy(I, T); } break;
+    case ES_EXP: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MUL) { g_exp(I, T); } break;
     case ES_BALANCE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_balance(I, T); } break;
     case ES_EXTCODESIZE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodesize(I, T); } break;
     case ES_EXTCODEHASH: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodehash(I, T); } break;

@@ -20,7 +20,6 @@
 // ----------------------------------------------------------------------------------------------
 enum { BC_Q_FIRST = 0, BC_Q_LAST, BC_HASH_LO, BC_HASH_HI, BC_TAG, BC_INDEX, BC_VALUE, BC_IS_CODE, BC_PUSH_LEFT,
        BC_VALUE_RLC, BC_LENGTH, BC_PUSH_SIZE, BC_NCELLS };
-enum { KECCAK_NCELLS = 5 };
 
 struct BytecodeArgs {
     ZkCols rows;
@@ -28,8 +27,6 @@ struct BytecodeArgs {
     Fr r;  // keccak randomness (canonical)
 };
 
-ZK_HD u64 keccak_key_hash_cells(const Fr& rlc, const Fr& len) { return zk_hash_cell(zk_hash_cell(0x6b656363u, rlc), len); }
-ZK_HD u64 keccak_key_hash(const ZkTable& t, u32 r) { return keccak_key_hash_cells(zk_table_cell(t, r, 1), zk_table_cell(t, r, 2)); }
 
 // `row in keccak_table` with all five cells given (set membership, bytecode_circuit.py:100)
 ZK_HD bool keccak_contains(const ZkTable& t, const Fr q[KECCAK_NCELLS]) {

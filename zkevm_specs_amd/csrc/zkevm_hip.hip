@@ -423,8 +423,8 @@ static int evm_build_perm(zk_session* s) {
 extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out) {
     ARG_TRY(g_device >= 0, "zk_evm_open: call zk_init first");
     ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
-    ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31),
-            "zk_evm_open: table too large");
+    ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31) &&
+            t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31), "zk_evm_open: table too large");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     zk_session* s = new zk_session();
     s->kind = SESSION_EVM;
@@ -442,6 +442,12 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = build_index<bc_key_hash>(s, s->evm.bytecode))) goto fail;
     if ((rc = build_index<tx_key_hash>(s, s->evm.tx))) goto fail;
     if ((rc = build_index<blk_key_hash>(s, s->evm.block))) goto fail;
+    if ((rc = table_stage(s, s->evm.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
+    if ((rc = build_index<copy_key_hash>(s, s->evm.copy))) goto fail;
+    if ((rc = build_index<keccak_key_hash>(s, s->evm.keccak))) goto fail;
+    if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;
     s->evm.rw_meta = nullptr;
     s->evm.codes.n = 0;
     if (!(opts & ZK_OPT_GENERIC_INDEX)) {

@@ -112,9 +112,10 @@ def open_state(rows, flags, mpt, device=None):
 def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
              generic_index=False):
     """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
+    and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4]
     (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
     lib = _lib.init(device)
-    names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags"]
+    names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp"]
     arrs, opts = _prep([wire.get(k) for k in names])
     a = dict(zip(names, arrs))
 
@@ -131,7 +132,10 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         p(a["bytecode"]) if rows(a["bytecode"]) else None, rows(a["bytecode"]),
         p(a["tx"]) if rows(a["tx"]) else None, p(a["tx_flags"]) if rows(a["tx"]) else None, rows(a["tx"]),
         p(a["block"]) if rows(a["block"]) else None, p(a["block_flags"]) if rows(a["block"]) else None, rows(a["block"]),
-        int(bool(begin_with_first_step)), int(bool(end_with_last_step)))
+        int(bool(begin_with_first_step)), int(bool(end_with_last_step)),
+        p(a["copy"]) if rows(a["copy"]) else None, rows(a["copy"]),
+        p(a["keccak"]) if rows(a["keccak"]) else None, rows(a["keccak"]),
+        p(a["exp"]) if rows(a["exp"]) else None, rows(a["exp"]))
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:

@@ -142,8 +142,30 @@ def flatten_block_table(block_table):
     return rows_to_rowmajor(rows, BLOCK_NCELLS), np.array(flags, dtype=np.uint32)
 
 
+COPY_T_NCELLS, KECCAK_T_NCELLS, EXP_T_NCELLS = 14, 5, 11
+
+
+def flatten_copy_table(copy_table):
+    """set of CopyTableRow (evm_circuit/table.py:494-507) -> uint64[m, 14, 4]; ids match on their
+    lo/hi cells only (TableRow.match, table.py:389-401), so no type bits travel"""
+    rows, _ = _dedup([([_n(r.is_first), _n(r.src_id.lo), _n(r.src_id.hi), _n(r.src_tag), _n(r.dst_id.lo), _n(r.dst_id.hi),
+                        _n(r.dst_tag), _n(r.src_addr), _n(r.src_addr_end), _n(r.dst_addr), _n(r.length), _n(r.rlc_acc),
+                        _n(r.rw_counter), _n(r.rwc_inc)], 0) for r in _iter_table(copy_table)])
+    return rows_to_rowmajor(rows, COPY_T_NCELLS)
+
+
+def flatten_exp_table(exp_table):
+    """set of ExpTableRow (evm_circuit/table.py:538-548) -> uint64[m, 11, 4]"""
+    rows, _ = _dedup([([_n(r.is_step), _n(r.identifier), _n(r.is_last), _n(r.base_limb0), _n(r.base_limb1),
+                        _n(r.base_limb2), _n(r.base_limb3), _n(r.exponent.lo), _n(r.exponent.hi),
+                        _n(r.exponentiation.lo), _n(r.exponentiation.hi)], 0) for r in _iter_table(exp_table)])
+    return rows_to_rowmajor(rows, EXP_T_NCELLS)
+
+
 def flatten_evm(tables, steps):
-    """reference `Tables` (evm_circuit/table.py:578-671) + list of StepState -> dict of wire arrays"""
+    """reference `Tables` (evm_circuit/table.py:578-671) + list of StepState -> dict of wire arrays.
+    The copy / keccak / exp tables only exist on `Tables` built with those circuits (:614-619);
+    absent ones travel as empty tables."""
     rw, rw_flags = flatten_rw_table(tables.rw_table)
     tx, tx_flags = flatten_tx_table(tables.tx_table)
     blk, blk_flags = flatten_block_table(tables.block_table)
@@ -153,6 +175,9 @@ def flatten_evm(tables, steps):
         "bytecode": flatten_bytecode_table(tables.bytecode_table),
         "tx": tx, "tx_flags": tx_flags,
         "block": blk, "block_flags": blk_flags,
+        "copy": flatten_copy_table(getattr(tables, "copy_table", None)),
+        "keccak": flatten_keccak_table(getattr(tables, "keccak_table", None)),
+        "exp": flatten_exp_table(getattr(tables, "exp_table", None)),
     }
 
 
