@@ -1434,6 +1434,117 @@ def g_error_invalid_jump(i):  # error_invalid_jump.py
         _constrain_error_state(i, i.rw_off + i.curr[S_REV])
 
 
+def _oog_tail(i, gas_cost):
+    """`compare(gas_left, cost, N_BYTES_GAS)`, `constrain_equal(insufficient, 1)`, constrain_error_state"""
+    lt, _ = i.compare(i.curr[S_GAS], gas_cost % P, 8)
+    i.constrain_equal(lt, 1)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def _read_account_to_access_list(i, tx_id, address):  # instruction.py:1059-1069
+    return i.value_of(i.row_value_prev(i.rw_lookup(0, TG.TxAccessListAccount, tx_id, address)))
+
+
+def g_error_oog_static_memory(i):  # error_oog_static_memory_expansion.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.MLOAD, OP.MSTORE, OP.MSTORE8))
+    offset = i.word_to_fq(i.stack_pop(), 5)
+    # `size = 1 if is_mstore8 else 32` (:21): an FQ is always truthy, so size is 1 for all three opcodes
+    _, exp_gas = i.memory_expansion_dynamic_length(offset, 1)
+    _oog_tail(i, 3 + exp_gas)
+
+
+def g_error_oog_dynamic_memory(i):  # error_oog_dynamic_memory_expansion.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.RETURN, OP.REVERT))
+    offset_w, size_w = i.stack_pop(), i.stack_pop()
+    offset, size = i.memory_offset_and_length(offset_w, size_w)
+    _, exp_gas = i.memory_expansion(offset, size)
+    _oog_tail(i, exp_gas)
+
+
+def g_error_oog_memory_copy(i):  # error_oog_memory_copy.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.CALLDATACOPY, OP.CODECOPY, OP.EXTCODECOPY, OP.RETURNDATACOPY))
+    is_ext = opcode == OP.EXTCODECOPY
+    off = 0
+    if is_ext:
+        ext_addr = i.stack_lookup(0, 0)
+        off = 1
+    mem_w = i.stack_lookup(0, off)
+    size_w = i.stack_lookup(0, off + 2)
+    if is_ext:
+        address = i.word_to_fq(ext_addr, 5)  # N_BYTES_MEMORY_ADDRESS, as written (:41)
+        tx_id = i.call_context_lookup(CC.TxId)
+        is_warm = _read_account_to_access_list(i, tx_id, address)
+        constant_gas = 100 if is_warm == 1 else 2600
+    else:
+        constant_gas = 3
+    mem_off, size = i.memory_offset_and_length(mem_w, size_w)
+    _, exp_gas = i.memory_expansion_dynamic_length(mem_off, size)
+    dyn = i.memory_copier_gas_cost(size, exp_gas)
+    _oog_tail(i, constant_gas + dyn)
+
+
+def g_error_oog_account_access(i):  # error_oog_account_access.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.BALANCE, OP.EXTCODESIZE, OP.EXTCODEHASH))
+    address = i.word_to_fq(i.stack_pop(), 20)
+    tx_id = i.call_context_lookup(CC.TxId)
+    is_warm = _read_account_to_access_list(i, tx_id, address)
+    _oog_tail(i, 100 if is_warm == 1 else 2600)
+
+
+def g_error_oog_log(i):  # error_oog_log.py
+    opcode = i.opcode_lookup(True)
+    i.fixed_lookup(T.FixedTableTag.Range5, opcode - OP.LOG0)
+    mstart = i.word_to_fq(i.stack_pop(), 5)
+    msize = i.word_to_fq(i.stack_pop(), 5)
+    _, exp_gas = i.memory_expansion_dynamic_length(mstart, msize)
+    _oog_tail(i, 375 + 375 * (opcode - OP.LOG0) + 8 * msize + exp_gas)
+
+
+def g_error_oog_exp(i):  # error_oog_exp.py
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.EXP)
+    exponent = i.stack_lookup(0, 1)
+    byte_size = len(bytes(i.to_le_bytes(exponent)).rstrip(b"\x00"))
+    _oog_tail(i, 50 * byte_size + 10)
+
+
+def g_error_oog_sha3(i):  # error_oog_sha3.py
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.SHA3)
+    offset_w, size_w = i.stack_pop(), i.stack_pop()
+    mem_off, size = i.memory_offset_and_length(offset_w, size_w)
+    _, exp_gas = i.memory_expansion_dynamic_length(mem_off, size)
+    words, _ = i.constant_divmod(size + 31, 32, 4)
+    _oog_tail(i, 30 + words * 6 + exp_gas)
+
+
+def g_error_return_data_oob(i):  # error_return_data_out_of_bound.py
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.RETURNDATACOPY)
+    data_offset = i.word_to_fq(i.stack_lookup(0, 1), 31)
+    length = i.word_to_fq(i.stack_lookup(0, 2), 31)
+    rd_len = i.call_context_lookup(CC.LastCalleeReturnDataLength)
+    end = (data_offset + length) % P
+    over, _ = i.compare(rd_len, end, 31)
+    i.require(int(data_offset > MAX_U64) + int(end > MAX_U64) + over != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_error_write_protection(i):  # error_write_protection.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode % P in _STATE_WRITE_OPCODES)
+    is_static = i.call_context_lookup(CC.IsStatic)
+    i.constrain_equal(is_static, 1)
+    if opcode == OP.CALL:
+        value = i.stack_lookup(0, 2)
+        i.require(value[0] % P != 0 or value[1] % P != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1463,6 +1574,11 @@ GADGETS = {
     ES.EXTCODEHASH: g_extcodehash, ES.BLOCKHASH: g_blockhash, ES.CALLDATALOAD: g_calldataload,
     ES.SHA3: g_sha3, ES.CODECOPY: g_codecopy, ES.CALLDATACOPY: g_calldatacopy, ES.RETURNDATACOPY: g_returndatacopy,
     ES.EXTCODECOPY: g_extcodecopy, ES.EXP: g_exp,
+    ES.ErrorOutOfGasStaticMemoryExpansion: g_error_oog_static_memory,
+    ES.ErrorOutOfGasDynamicMemoryExpansion: g_error_oog_dynamic_memory, ES.ErrorOutOfGasMemoryCopy: g_error_oog_memory_copy,
+    ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
+    ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
+    ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }

@@ -684,6 +684,7 @@ struct Tail {
     u32 rwc_mode;           // 0: rw_counter delta is rw_delta; 1 / 2: the gadget already compared next.rw_counter
                             // with a field-valued delta (copy gadgets: rw_counter_offset + rwc_inc) -> equal / different
     bool enabled;
+    u32 err_tail;  // error states: 1 = constrain_error_state, 2 = out-of-gas compare (cost in dyn_gas) first
 };
 ZK_HD void set_tail(Tail& T, const Fr& opcode, int rw_delta, const Trans& pc, int sp_delta, const Trans& mws,
                     int rev_delta, const Fr& dyn_gas) {
@@ -1828,15 +1829,28 @@ ZK_HD void constrain_error_state(Ins& I) {
         restore_context(I, delta, fr_zero());
     }
 }
+// the out-of-gas states end with compare(gas_left, cost, N_BYTES_GAS), constrain_equal(lt, 1) and
+// constrain_error_state: evaluated once after the gadget switch (error_tail)
+ZK_HD void oog_tail(Tail& T, const Fr& gas_cost) {
+    T.dyn_gas = gas_cost;
+    T.err_tail = 2;
+}
+ZK_HD void error_tail(Ins& I, const Tail& T) {
+    if (T.err_tail == 2u) {
+        u32 lt, eq; ev_compare(I, ev_curr(I, S_GAS), T.dyn_gas, 8, lt, eq); if (I.err) return;
+        ev_require(I, lt == 1u); if (I.err) return;
+    }
+    constrain_error_state(I);
+}
 ZK_HD void g_error_invalid_opcode(Ins& I, Tail& T) {  // error_invalid_opcode.py
     Fr opcode; opcode = opcode_lookup(I, true);
     fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
-    constrain_error_state(I);
+    T.err_tail = 1;
 }
 ZK_HD void g_error_stack(Ins& I, Tail& T) {  // error_stack.py
     Fr opcode; opcode = opcode_lookup(I, true);
     fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, I.sp); if (I.err) return;
-    constrain_error_state(I);
+    T.err_tail = 1;
 }
 ZK_HD void g_error_oog_constant(Ins& I, Tail& T) {  // error_oog_constant.py
     Fr opcode; opcode = opcode_lookup(I, true);
@@ -1847,9 +1861,7 @@ ZK_HD void g_error_oog_constant(Ins& I, Tail& T) {  // error_oog_constant.py
     if (I.err) return;
     const Fr gas = fr_u(cgas[opcode.v[0] & 0xff]);
     fixed_lookup(I, FX_OpcodeConstantGas, opcode, gas, fr_zero()); if (I.err) return;
-    u32 lt, eq; ev_compare(I, ev_curr(I, S_GAS), gas, 8, lt, eq); if (I.err) return;
-    ev_require(I, lt == 1u); if (I.err) return;
-    constrain_error_state(I);
+    oog_tail(T, gas);
 }
 ZK_HD void g_error_invalid_jump(Ins& I, Tail& T) {  // error_invalid_jump.py
     Fr opcode; opcode = opcode_lookup(I, true);
@@ -1869,8 +1881,131 @@ ZK_HD void g_error_invalid_jump(Ins& I, Tail& T) {  // error_invalid_jump.py
         const bool is_code = !fr_is_zero(zk_table_cell(I.a->bytecode, r, B_IS_CODE));
         const bool is_dest = fr_eq_u64(zk_table_cell(I.a->bytecode, r, B_VALUE), OP_JUMPDEST);
         ev_require(I, !(is_code && is_dest)); if (I.err) return;
-        constrain_error_state(I);
+        T.err_tail = 1;
     }
+}
+
+ZK_HD Fr read_account_to_access_list(Ins& I, const Fr& tx_id, const Fr& address) {  // instruction.py:1059-1069
+    RwQ Q;
+    rwq_init(Q, 0, TG_TxAccessListAccount);
+    rwq_set(Q, R_ID, tx_id);
+    rwq_set(Q, R_ADDR, address);
+    u32 r; r = rw_lookup(I, Q);
+    return value_of(I, rw_value_prev(I, r));
+}
+// memory_expansion_dynamic_length's gas only (instruction.py:1157-1181)
+ZK_HD Fr dyn_expansion_gas(Ins& I, const Fr& offset, const Fr& length) {
+    Fr mws = ev_curr(I, S_MWS);
+    Fr cd_size = constant_divmod_shift(I, fr_add_u64(fr_add(offset, length), 31), 5, 4);
+    u32 lt, eq;
+    ev_compare(I, mws, cd_size, 4, lt, eq);
+    Fr next_size = ev_select_b(I, lt) ? cd_size : mws;
+    Fr g0 = memory_gas_cost(I, mws);
+    Fr g1 = memory_gas_cost(I, next_size);
+    return fr_sub(g1, g0);
+}
+ZK_HD void g_error_oog_static_memory(Ins& I, Tail& T) {  // error_oog_static_memory_expansion.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    ev_require(I, fr_eq_u64(opcode, OP_MLOAD) || fr_eq_u64(opcode, OP_MSTORE) || fr_eq_u64(opcode, OP_MSTORE8)); if (I.err) return;
+    Word ow; ow = stack_pop(I);
+    Fr offset; EV_TRY(offset = word_to_fq(I, ow, 5));
+    // `size = 1 if is_mstore8 else 32` (:21): an FQ is always truthy, so the size is 1 for all three opcodes
+    Fr gas; EV_TRY(gas = dyn_expansion_gas(I, offset, fr_u(1)));
+    oog_tail(T, fr_add_u64(gas, 3));
+}
+ZK_HD void g_error_oog_dynamic_memory(Ins& I, Tail& T) {  // error_oog_dynamic_memory_expansion.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    ev_require(I, fr_eq_u64(opcode, OP_RETURN) || fr_eq_u64(opcode, OP_REVERT)); if (I.err) return;
+    Word ow, sw; ow = stack_pop(I); sw = stack_pop(I);
+    Fr offset, size; EV_TRY(memory_offset_and_length(I, ow, sw, offset, size));
+    Fr next_size, gas; EV_TRY(memory_expansion(I, offset, size, next_size, gas));
+    oog_tail(T, gas);
+}
+ZK_HD void g_error_oog_memory_copy(Ins& I, Tail& T) {  // error_oog_memory_copy.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const bool is_ext = fr_eq_u64(opcode, OP_EXTCODECOPY);
+    ev_require(I, is_ext || fr_eq_u64(opcode, OP_CALLDATACOPY) || fr_eq_u64(opcode, OP_CODECOPY) || fr_eq_u64(opcode, OP_RETURNDATACOPY));
+    if (I.err) return;
+    Word ext_addr = word_zero();
+    int off = 0;
+    if (is_ext) { ext_addr = stack_lookup(I, 0, 0); off = 1; }
+    Word mem_w, size_w;
+    mem_w = stack_lookup(I, 0, off); size_w = stack_lookup(I, 0, off + 2);
+    if (I.err) return;
+    u64 constant_gas = 3;
+    if (is_ext) {
+        Fr address; EV_TRY(address = word_to_fq(I, ext_addr, 5));  // N_BYTES_MEMORY_ADDRESS, as written (:41)
+        Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+        Fr is_warm; EV_TRY(is_warm = read_account_to_access_list(I, tx_id, address));
+        constant_gas = fr_eq_u64(is_warm, 1) ? 100 : 2600;
+    }
+    Fr mem_off, size; EV_TRY(memory_offset_and_length(I, mem_w, size_w, mem_off, size));
+    Fr next_size, dyn; EV_TRY(copy_memory_gas(I, mem_off, size, 3, next_size, dyn));
+    oog_tail(T, fr_add_u64(dyn, constant_gas));
+}
+ZK_HD void g_error_oog_account_access(Ins& I, Tail& T) {  // error_oog_account_access.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    ev_require(I, fr_eq_u64(opcode, OP_BALANCE) || fr_eq_u64(opcode, OP_EXTCODESIZE) || fr_eq_u64(opcode, OP_EXTCODEHASH)); if (I.err) return;
+    Word aw; aw = stack_pop(I);
+    Fr address; EV_TRY(address = word_to_fq(I, aw, 20));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Fr is_warm; EV_TRY(is_warm = read_account_to_access_list(I, tx_id, address));
+    oog_tail(T, fr_u(fr_eq_u64(is_warm, 1) ? 100 : 2600));
+}
+ZK_HD void g_error_oog_log(Ins& I, Tail& T) {  // error_oog_log.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const Fr topics = fr_sub_u64(opcode, OP_LOG0);
+    fixed_lookup(I, FX_Range5, topics, fr_zero(), fr_zero()); if (I.err) return;
+    Word w1, w2; w1 = stack_pop(I);
+    Fr mstart; EV_TRY(mstart = word_to_fq(I, w1, 5));
+    w2 = stack_pop(I);
+    Fr msize; EV_TRY(msize = word_to_fq(I, w2, 5));
+    Fr gas; EV_TRY(gas = dyn_expansion_gas(I, mstart, msize));
+    oog_tail(T, fr_add(fr_add_u64(fr_mul_u64(topics, 375), 375), fr_add(fr_mul_u64(msize, 8), gas)));
+}
+ZK_HD void g_error_oog_exp(Ins& I, Tail& T) {  // error_oog_exp.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_EXP));
+    Word exponent; exponent = stack_lookup(I, 0, 1);
+    U256 eb; EV_TRY(eb = to_u256(I, exponent));
+    oog_tail(T, fr_u(50u * (u32)fr_byte_len(eb) + 10u));
+}
+ZK_HD void g_error_oog_sha3(Ins& I, Tail& T) {  // error_oog_sha3.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_SHA3));
+    Word ow, sw; ow = stack_pop(I); sw = stack_pop(I);
+    Fr mem_off, size; EV_TRY(memory_offset_and_length(I, ow, sw, mem_off, size));
+    Fr gas; EV_TRY(gas = dyn_expansion_gas(I, mem_off, size));
+    Fr words; EV_TRY(words = constant_divmod_shift(I, fr_add_u64(size, 31), 5, 4));
+    oog_tail(T, fr_add_u64(fr_add(fr_mul_u64(words, 6), gas), 30));
+}
+ZK_HD void g_error_return_data_oob(Ins& I, Tail& T) {  // error_return_data_out_of_bound.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_RETURNDATACOPY));
+    Word w1; w1 = stack_lookup(I, 0, 1);
+    Fr data_offset; EV_TRY(data_offset = word_to_fq(I, w1, 31));
+    Word w2; w2 = stack_lookup(I, 0, 2);
+    Fr length; EV_TRY(length = word_to_fq(I, w2, 31));
+    Fr rd_len; rd_len = call_context_lookup(I, CC_LastCalleeReturnDataLength);
+    const Fr end = fr_add(data_offset, length);
+    u32 over, eq; EV_TRY(ev_compare(I, rd_len, end, 31, over, eq));
+    ev_require(I, !fr_fits64(data_offset) || !fr_fits64(end) || over != 0u); if (I.err) return;
+    T.err_tail = 1;
+}
+ZK_HD void g_error_write_protection(Ins& I, Tail& T) {  // error_write_protection.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const u32 y = opcode.v[0];
+    const bool ok = fr_le_u64(opcode, 255) && (y == OP_SSTORE || (y >= OP_LOG0 && y <= OP_LOG4) || y == OP_CREATE || y == OP_CALL ||
+                                               y == OP_CREATE2 || y == OP_SELFDESTRUCT);
+    ev_require(I, ok); if (I.err) return;
+    Fr is_static; is_static = call_context_lookup(I, CC_IsStatic);
+    constrain_equal(I, is_static, fr_u(1));
+    if (y == OP_CALL) {
+        Word value; value = stack_lookup(I, 0, 2);
+        ev_require(I, !fr_is_zero(value.lo) || !fr_is_zero(value.hi));
+    }
+    if (I.err) return;
+    T.err_tail = 1;
 }
 
 // ExecutionState transition constraint (instruction.py:189-204)
@@ -1931,7 +2066,10 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: case ES_BALANCE: case ES_EXTCODESIZE:
     case ES_EXTCODEHASH: case ES_BLOCKHASH: case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack:
     case ES_ErrorOutOfGasConstant: case ES_ErrorInvalidJump: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY:
-    case ES_RETURNDATACOPY: case ES_EXTCODECOPY: return EVM_GROUP_MEM;
+    case ES_RETURNDATACOPY: case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion:
+    case ES_ErrorOutOfGasDynamicMemoryExpansion: case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess:
+    case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP: case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound:
+    case ES_ErrorWriteProtection: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -1975,6 +2113,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     EV_PROF(I, 1);
     Tail T;
     T.enabled = false;
+    T.err_tail = 0;
     if (G != EVM_GROUP_ALL && evm_state_group(state) != G) {  // cannot happen with a correct lane mapping
         ev_fail(I, ZK_UNSUPPORTED);
         return I.err;
@@ -2009,6 +2148,15 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
     case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
     case ES_SAR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SAR) { g_sar(I, T); } break;
+    case ES_ErrorOutOfGasStaticMemoryExpansion: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_static_memory(I, T); } break;
+    case ES_ErrorOutOfGasDynamicMemoryExpansion: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_dynamic_memory(I, T); } break;
+    case ES_ErrorOutOfGasMemoryCopy: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_memory_copy(I, T); } break;
+    case ES_ErrorOutOfGasAccountAccess: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_account_access(I, T); } break;
+    case ES_ErrorOutOfGasLOG: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_log(I, T); } break;
+    case ES_ErrorOutOfGasEXP: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_exp(I, T); } break;
+    case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_sha3(I, T); } break;
+    case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_return_data_oob(I, T); } break;
+    case ES_ErrorWriteProtection: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_write_protection(I, T); } break;
     case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_opcode(I, T); } break;
     case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
     case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
@@ -2033,6 +2181,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     }
     EV_PROF(I, 2);
     if (I.err == 0u && T.enabled) same_context(I, T);
+    if (I.err == 0u && T.err_tail) error_tail(I, T);
     EV_PROF(I, 3);
     return I.err;
 }
