@@ -1247,6 +1247,43 @@ def g_exp(i):  # exp.py
     i.same_context(opcode, rw_counter=D(3), program_counter=D(1), stack_pointer=D(1), dynamic_gas_cost=50 * byte_size)
 
 
+def _tx_log_lookup_word(i, tx_id, log_id, field_tag, index=0):  # instruction.py:708-720
+    address = (index + (field_tag << 32) + ((log_id % P) << 48)) % P
+    zero = i.word_from_int(0)
+    return i.row_value(i.rw_lookup(1, TG.TxLog, tx_id, address, 0, zero))[0]
+
+
+def g_log(i):  # log.py
+    opcode = i.opcode_lookup(True)
+    i.fixed_lookup(T.FixedTableTag.Range5, opcode - OP.LOG0)
+    mstart = i.word_to_fq(i.stack_pop(), 8)
+    msize = i.word_to_fq(i.stack_pop(), 8)
+    tx_id = i.call_context_lookup(CC.TxId)
+    is_static = i.call_context_lookup(CC.IsStatic)
+    i.constrain_equal(0, is_static)
+    contract, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    is_persistent = i.call_context_lookup(CC.IsPersistent)
+    log_id = i.curr[S_LOG] + 1
+    if is_persistent % P != 0:
+        i.constrain_equal_word(contract, _tx_log_lookup_word(i, tx_id, log_id, 1))
+    topic_count = opcode % P - OP.LOG0
+    for k in range(topic_count):
+        topic = i.stack_pop()
+        if is_persistent % P != 0:
+            i.constrain_equal_word(topic, _tx_log_lookup_word(i, tx_id, log_id, 2, k))
+    for _ in range(7):
+        i.cp()  # constrain_bool on the constant topic selectors (:70-74)
+    rwc_inc = 0
+    if msize != 0 and is_persistent % P == 1:
+        dst_addr = ((3 << 32) + ((log_id % P) << 48)) % P  # table.py:773-775
+        rwc_inc, _ = i.copy_lookup((i.curr[S_CALL_ID], 0), CDT_MEMORY, (tx_id, 0), CDT_TXLOG, mstart, mstart + msize, dst_addr,
+                                   msize, i.curr[S_RWC] + i.rw_off)
+    nxt, exp_gas = i.memory_expansion_dynamic_length(mstart, msize)
+    dyn = (375 + 375 * topic_count + 8 * msize + exp_gas) % P
+    i.same_context(opcode, rw_counter=D(i.rw_off + rwc_inc), program_counter=D(1), stack_pointer=D(2 + topic_count),
+                   memory_word_size=TO(nxt), dynamic_gas_cost=dyn, log_id=D(is_persistent))
+
+
 def g_gas(i):  # gas.py
     opcode = i.opcode_lookup(True)
     i.constrain_equal(opcode, OP.GAS)
@@ -1573,7 +1610,7 @@ GADGETS = {
     ES.CODESIZE: g_codesize, ES.SAR: g_sar, ES.SDIV_SMOD: g_sdiv_smod, ES.BALANCE: g_balance, ES.EXTCODESIZE: g_extcodesize,
     ES.EXTCODEHASH: g_extcodehash, ES.BLOCKHASH: g_blockhash, ES.CALLDATALOAD: g_calldataload,
     ES.SHA3: g_sha3, ES.CODECOPY: g_codecopy, ES.CALLDATACOPY: g_calldatacopy, ES.RETURNDATACOPY: g_returndatacopy,
-    ES.EXTCODECOPY: g_extcodecopy, ES.EXP: g_exp,
+    ES.EXTCODECOPY: g_extcodecopy, ES.EXP: g_exp, ES.LOG: g_log,
     ES.ErrorOutOfGasStaticMemoryExpansion: g_error_oog_static_memory,
     ES.ErrorOutOfGasDynamicMemoryExpansion: g_error_oog_dynamic_memory, ES.ErrorOutOfGasMemoryCopy: g_error_oog_memory_copy,
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,

@@ -28,7 +28,7 @@ msize codesize jump jumpi sload sstore stop sar sdiv_smod balance extcodesize ex
 calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_jump sha3 codecopy calldatacopy
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
-error_return_data_out_of_bound error_write_protection""".split()
+error_return_data_out_of_bound error_write_protection logs""".split()
 MAX_CASES_PER_FILE = 48
 
 

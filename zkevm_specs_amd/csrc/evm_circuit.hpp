@@ -683,6 +683,7 @@ struct Tail {
     u32 pc_kind, mws_kind;  // Trans kinds: 0 same, 1 delta, 2 to
     u32 rwc_mode;           // 0: rw_counter delta is rw_delta; 1 / 2: the gadget already compared next.rw_counter
                             // with a field-valued delta (copy gadgets: rw_counter_offset + rwc_inc) -> equal / different
+    u32 log_mode;           // same scheme for log_id: 0 = same, 1 / 2 = precomputed delta matched / did not
     bool enabled;
     u32 err_tail;  // error states: 1 = constrain_error_state, 2 = out-of-gas compare (cost in dyn_gas) first
 };
@@ -698,6 +699,7 @@ ZK_HD void set_tail(Tail& T, const Fr& opcode, int rw_delta, const Trans& pc, in
     T.rev_delta = rev_delta;
     T.dyn_gas = dyn_gas;
     T.rwc_mode = 0;
+    T.log_mode = 0;
     T.enabled = true;
 }
 // rw_counter = Transition.delta(field value): compare now, report at the transition's checkpoint
@@ -727,7 +729,8 @@ ZK_HD void same_context(Ins& I, const Tail& T) {
     transition(I, S_GAS, t_delta(fr_neg(gas_cost)));
     transition(I, S_MWS, mws);
     transition(I, S_REV, t_int(T.rev_delta));
-    transition(I, S_LOG, t_same());
+    if (T.log_mode == 0u) transition(I, S_LOG, t_same());
+    else ev_require(I, T.log_mode == 1u);
     transition(I, S_CALL_ID, t_same());
     transition(I, S_IS_ROOT, t_same());
     transition(I, S_IS_CREATE, t_same());
@@ -1616,6 +1619,73 @@ ZK_HD void g_exp(Ins& I, Tail& T) {  // exp.py
     U256 eb; EV_TRY(eb = to_u256(I, exponent));  // byte_size (instruction.py:492-494)
     set_tail(T, opcode, 3, t_delta_i(1), 1, t_same(), 0, fr_u(50u * (u32)fr_byte_len(eb)));
 }
+// tx_log_lookup_word (instruction.py:708-720): address = index + (field_tag << 32) + (log_id.n << 48)
+ZK_HD Fr tx_log_address(const Fr& log_id, u32 field_tag, u32 index) {
+    // log_id.n << 48 as an integer, reduced mod p: multiply by 2^48 in the field
+    return fr_add(fr_mul_u64(log_id, 1ull << 48), fr_u(((u64)field_tag << 32) + index));
+}
+ZK_HD Word tx_log_lookup_word(Ins& I, const Fr& tx_id, const Fr& log_id, u32 field_tag, u32 index) {
+    I.seq++;  // Word(0) storage key
+    RwQ Q;
+    rwq_init(Q, 1, TG_TxLog);
+    rwq_set(Q, R_ID, tx_id);
+    rwq_set(Q, R_ADDR, tx_log_address(log_id, field_tag, index));
+    rwq_set(Q, R_FT, fr_zero());
+    rwq_set_word(Q, R_KEY_LO, word_zero());
+    u32 r; r = rw_lookup(I, Q);
+    return rw_word(I, r, R_VAL_LO);
+}
+ZK_HD void g_log(Ins& I, Tail& T) {  // log.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const Fr topics_f = fr_sub_u64(opcode, OP_LOG0);
+    fixed_lookup(I, FX_Range5, topics_f, fr_zero(), fr_zero()); if (I.err) return;
+    const int topic_count = (int)topics_f.v[0];
+    Word w1; w1 = stack_pop(I);
+    Fr mstart; EV_TRY(mstart = word_to_fq(I, w1, 8));
+    Word w2; w2 = stack_pop(I);
+    Fr msize; EV_TRY(msize = word_to_fq(I, w2, 8));
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Fr is_static; is_static = call_context_lookup(I, CC_IsStatic);
+    constrain_equal(I, fr_zero(), is_static);
+    WordOrValue contract; contract = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr is_persistent; is_persistent = call_context_lookup(I, CC_IsPersistent);
+    if (I.err) return;
+    const Fr log_id = fr_add_u64(ev_curr(I, S_LOG), 1);
+    const bool persistent_nz = !fr_is_zero(is_persistent);
+    if (persistent_nz) {
+        Word a; a = tx_log_lookup_word(I, tx_id, log_id, 1, 0);
+        constrain_equal_word(I, contract.w, a);
+    }
+    for (int k = 0; k < 4; k++) {
+        if (k < topic_count) {
+            Word topic; topic = stack_pop(I);
+            if (persistent_nz) {
+                Word t; t = tx_log_lookup_word(I, tx_id, log_id, 2, (u32)k);
+                constrain_equal_word(I, topic, t);
+            }
+        }
+    }
+    if (I.err) return;
+    I.seq += 7;  // constrain_bool on the constant topic selectors (:70-74)
+    CopyRes cr; cr.rwc_inc = fr_zero();
+    if (!fr_is_zero(msize) && fr_eq_u64(is_persistent, 1))
+        EV_TRY(cr = copy_lookup(I, word_value(I.call_id), CDT_Memory, word_value(tx_id), CDT_TxLog, mstart, fr_add(mstart, msize),
+                                tx_log_address(log_id, 3, 0), msize, fr_add_u64(I.rwc, I.rw_off)));
+    Fr next_size = ev_curr(I, S_MWS), gas;
+    {
+        Fr mws = next_size;
+        Fr cd_size; EV_TRY(cd_size = constant_divmod_shift(I, fr_add_u64(fr_add(mstart, msize), 31), 5, 4));
+        u32 lt, eq; EV_TRY(ev_compare(I, mws, cd_size, 4, lt, eq));
+        next_size = ev_select_b(I, lt) ? cd_size : mws;
+        Fr g0; EV_TRY(g0 = memory_gas_cost(I, mws));
+        Fr g1; EV_TRY(g1 = memory_gas_cost(I, next_size));
+        gas = fr_sub(g1, g0);
+    }
+    const Fr dyn = fr_add(fr_add_u64(fr_mul_u64(msize, 8), 375u + 375u * (u32)topic_count), gas);
+    set_tail(T, opcode, 0, t_delta_i(1), 2 + topic_count, t_to(next_size), 0, dyn);
+    set_tail_rwc_delta(I, T, fr_add_u64(cr.rwc_inc, I.rw_off));
+    T.log_mode = fr_eq(ev_next(I, S_LOG), fr_add(ev_curr(I, S_LOG), is_persistent)) ? 1u : 2u;
+}
 ZK_HD void g_blockctx(Ins& I, Tail& T) {  // block_ctx.py
     Fr opcode; opcode = opcode_lookup(I, true);
     u32 tag = 0;
@@ -2069,7 +2139,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_RETURNDATACOPY: case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion:
     case ES_ErrorOutOfGasDynamicMemoryExpansion: case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess:
     case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP: case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound:
-    case ES_ErrorWriteProtection: return EVM_GROUP_MEM;
+    case ES_ErrorWriteProtection: case ES_LOG: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -2161,6 +2231,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
     case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
     case ES_ErrorInvalidJump: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_jump(I, T); } break;
+    case ES_LOG: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_log(I, T); } break;
     case ES_SHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_sha3(I, T); } break;
     case ES_CODECOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_codecopy(I, T); } break;
     case ES_CALLDATACOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_calldatacopy(I, T); } break;
