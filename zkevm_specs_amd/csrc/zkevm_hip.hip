@@ -292,10 +292,7 @@ struct zk_session {
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
-    hipStream_t side[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};  // indexed by group; the LIGHT group uses the main stream  // EVM: group kernels run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[EVM_N_GROUPS] = {nullptr, nullptr, nullptr};
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
-    u32 evm_strategy = 1;    // launch strategy: 1 = one state-sorted kernel (default), 0 = concurrent group kernels, 2 = sequential group kernels, 3 = one kernel at 4 waves/SIMD (tuning knob, ZK_EVM_STRATEGY env)
 };
 
 static const int MAX_EVENT_PAIRS = 256;
@@ -355,11 +352,6 @@ extern "C" int zk_close(zk_session* s) {
     (void)hipStreamSynchronize(g_stream);
     for (void* p : s->owned) (void)hipFree(p);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-    for (int g = 0; g < EVM_N_GROUPS; g++) {
-        if (s->side[g]) { (void)hipStreamSynchronize(s->side[g]); (void)hipStreamDestroy(s->side[g]); }
-        if (s->ev_join[g]) (void)hipEventDestroy(s->ev_join[g]);
-    }
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     delete s;
     return 0;
 }
@@ -498,14 +490,6 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         if (hipMemset(s->evm.prof, 0, 512 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) { rc = -2; goto fail; }
     }
     s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
-    if (const char* e = getenv("ZK_EVM_STRATEGY")) s->evm_strategy = (u32)atoi(e);
-    if (s->evm.perm) {
-        if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "event create failed"; goto fail; }
-        for (int g = 0; g < EVM_N_GROUPS - 1; g++) {
-            if (hipStreamCreateWithFlags(&s->side[g], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&s->ev_join[g], hipEventDisableTiming) != hipSuccess) { rc = -2; g_err = "stream create failed"; goto fail; }
-        }
-    }
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
@@ -817,29 +801,8 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed) HIP_TRY(hipEventRecord(e0, g_stream)); }
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
-        const u32 strat = s->evm_strategy;
-        if (s->evm.perm && strat == 1) {  // one kernel with every gadget, state-sorted lanes
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        } else if (s->evm.perm && strat == 2) {  // group kernels back to back on one stream
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM, 1>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        } else if (s->evm.perm && strat == 3) {  // one kernel, tighter register budget
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        } else if (s->evm.perm) {
-            // fork: the heavy groups run on side streams concurrently with the light group
-            HIP_TRY(hipEventRecord(s->ev_fork, g_stream));
-            for (int g = 0; g < EVM_N_GROUPS - 1; g++) HIP_TRY(hipStreamWaitEvent(s->side[g], s->ev_fork, 0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MEM, 1>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MEM], s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_MUL, 2>), dim3(grid), dim3(block), 0, s->side[EVM_GROUP_MUL], s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_LIGHT, 4>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-            for (int g = 0; g < EVM_N_GROUPS - 1; g++) {
-                HIP_TRY(hipEventRecord(s->ev_join[g], s->side[g]));
-                HIP_TRY(hipStreamWaitEvent(g_stream, s->ev_join[g], 0));
-            }
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 1>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        }
+        // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
         break;
     }
     }
