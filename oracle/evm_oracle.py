@@ -1389,14 +1389,15 @@ def g_sstore(i):  # storage.py:50-153
                    reversible_write_counter=D(3), dynamic_gas_cost=dyn)
 
 
-def _restore_context(i, rw_counter_delta, gas_left):  # instruction.py:292-363 (caller_id=None form)
+def _restore_context(i, rw_counter_delta, gas_left, return_data_offset=0, return_data_length=0):
+    """step_state_transition_to_restored_context (instruction.py:292-363, caller_id=None form)"""
     rw_counter_delta += 12
     caller_id = i.call_context_lookup(CC.CallerId)
     saved = [i.call_context_lookup_word(t, call_id=caller_id) for t in (
         CC.IsRoot, CC.IsCreate, CC.CodeHash, CC.ProgramCounter, CC.StackPointer, CC.GasLeft, CC.MemorySize,
         CC.ReversibleWriteCounter)]
-    for tag, expected in ((CC.LastCalleeId, i.curr[S_CALL_ID]), (CC.LastCalleeReturnDataOffset, 0),
-                          (CC.LastCalleeReturnDataLength, 0)):
+    for tag, expected in ((CC.LastCalleeId, i.curr[S_CALL_ID]), (CC.LastCalleeReturnDataOffset, return_data_offset),
+                          (CC.LastCalleeReturnDataLength, return_data_length)):
         v = i.call_context_lookup(tag, rw=1, call_id=caller_id)
         i.constrain_equal(v, expected)
     rev = i.curr[S_REV] if ES(i.curr[S_STATE]).name in T.HALTS_IN_SUCCESS else 0
@@ -1582,6 +1583,90 @@ def g_error_write_protection(i):  # error_write_protection.py
     _constrain_error_state(i, i.rw_off + i.curr[S_REV])
 
 
+EMPTY_HASH = 0xC5D2460186F7233C927E7DB2DCC703C0E500B653CA82273B7BFAD8045D85A470  # util/hash.py:13 (keccak256(""))
+
+
+def g_return(i):  # return_revert.py (REVERT is not dispatched by the reference; `not is_return` is never true for an FQ)
+    opcode = i.opcode_lookup(True)
+    is_return = int(opcode == OP.RETURN)
+    is_success = i.call_context_lookup(CC.IsSuccess)
+    i.constrain_equal(is_success, is_return)
+    off_w, len_w = i.stack_pop(), i.stack_pop()
+    ret_off = i.word_to_fq(off_w, 5)
+    ret_len = i.word_to_fq(len_w, 5)
+    ret_end = ret_off + ret_len
+    rwc_delta = 3
+    gas_left = i.curr[S_GAS]
+    is_root, is_create = i.curr[S_IS_ROOT] != 0, i.curr[S_IS_CREATE] != 0
+    if is_create:  # `curr.is_create and is_success`: an FQ is always truthy
+        callee_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+        callee = i.word_to_fq(callee_w, 20)
+        rowf = i.rw_lookup(1, TG.Account, address=callee, field_tag=int(ACC.CodeHash))  # account_write_word, no reversion
+        code_hash, code_hash_prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+        i.constrain_equal_word(code_hash_prev, i.word_from_int(EMPTY_HASH))
+        i.constrain_equal_word(code_hash, (i.curr[S_CH_LO], i.curr[S_CH_HI]))
+        i.fixed_lookup(T.FixedTableTag.Range24_576, ret_len)
+        gas_left = (gas_left - ret_len * 200) % P
+        if ret_len > 0:
+            inc, _ = i.copy_lookup((i.curr[S_CALL_ID], 0), CDT_MEMORY, code_hash, CDT_BYTECODE, ret_off, ret_end, 0, ret_len,
+                                   i.curr[S_RWC] + i.rw_off)
+            i.constrain_equal(inc, ret_len)
+            i.rw_off += inc
+            rwc_delta += ret_len
+            code_size = i.bytecode_length(code_hash)
+            i.constrain_equal(code_size, ret_len)
+    if not is_root and not is_create:
+        caller_off = i.call_context_lookup(CC.ReturnDataOffset)
+        caller_len = i.call_context_lookup(CC.ReturnDataLength)
+        lt, _ = i.compare(ret_len, caller_len, 5)
+        copy_len = i.select(lt, ret_len, caller_len)
+        inc, _ = i.copy_lookup((i.curr[S_CALL_ID], 0), CDT_MEMORY, (i.next[S_CALL_ID], 0), CDT_MEMORY, ret_off, ret_end,
+                               caller_off, copy_len, i.curr[S_RWC] + i.rw_off)
+        i.constrain_equal(inc, 2 * copy_len)
+        i.rw_off += inc
+        rwc_delta += 2 + 2 * copy_len
+    i.constrain_equal(int(is_root), int(i.next[S_STATE] == ES.EndTx))
+    _, exp_gas = i.memory_expansion_dynamic_length(ret_off, ret_len)
+    if is_root:
+        is_persistent = i.call_context_lookup(CC.IsPersistent)
+        i.constrain_equal(is_persistent, is_return)
+        i.transition(S_RWC, "delta", rwc_delta + 1)
+        i.transition(S_GAS, "to", gas_left)
+        i.transition(S_CALL_ID, "same")
+    else:
+        _restore_context(i, rwc_delta, (gas_left - exp_gas) % P, ret_off, ret_len)
+
+
+def g_error_invalid_creation_code(i):  # error_invalid_creation_code.py
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.RETURN)
+    i.constrain_equal(int(i.curr[S_IS_CREATE] != 0), 1)
+    ret_off = i.word_to_fq(i.stack_pop(), 5)
+    first = i.memory_lookup(0, ret_off)
+    i.constrain_equal(first, 0xEF)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_error_code_store(i):  # error_code_store.py (ErrorMaxCodeSizeExceeded and ErrorOutOfGasCodeStore)
+    opcode = i.opcode_lookup(True)
+    i.constrain_equal(opcode, OP.RETURN)
+    i.constrain_equal(int(i.curr[S_IS_CREATE] != 0), 1)
+    ret_len = i.word_to_fq(i.stack_lookup(0, 1), 5)
+    is_static = i.call_context_lookup(CC.IsStatic)
+    i.constrain_equal(is_static, 0)
+    over, _ = i.compare(24576, ret_len, 2)
+    insufficient, _ = i.compare(i.curr[S_GAS], 200 * ret_len, 8)
+    i.require(insufficient + over != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def g_end_block(i):  # end_block.py: padding steps (the is_last_step branch needs whole-table aggregates: not evaluated)
+    if i.is_last:
+        raise Fail(UNSUPPORTED, i.seq)
+    i.transition(S_RWC, "same")
+    i.transition(S_CALL_ID, "same")
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1616,6 +1701,8 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
+    ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,
 }

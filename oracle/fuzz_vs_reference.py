@@ -36,11 +36,17 @@ def main():
     for name in TEST_FILES:
         if only and name not in only:
             continue
-        h = Harvest()
-        rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null",
-                          os.path.join(REF_TESTS, f"test_{name}.py")], plugins=[h])
-        assert rc == 0
-        cases = h.cases if len(h.cases) <= 60 else rng.sample(h.cases, 60)
+        if name == "end_block_padding":
+            from oracle.gen_golden_evm import end_block_padding_cases
+
+            all_cases = end_block_padding_cases()
+        else:
+            h = Harvest()
+            rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null",
+                              os.path.join(REF_TESTS, f"test_{name}.py")], plugins=[h])
+            assert rc == 0
+            all_cases = h.cases
+        cases = all_cases if len(all_cases) <= 60 else rng.sample(all_cases, 60)
         nb = 0
         for tid, tables, steps, begin, end, _ in cases:
             wire0 = flatten_evm(tables, steps)

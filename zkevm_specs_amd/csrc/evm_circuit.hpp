@@ -61,7 +61,8 @@ struct Ins {
     u64 idx;   // pair index: curr = idx, next = idx + 1
     u32 err;   // first failure's status code (0 = none yet)
     u32 seq;   // checkpoint counter
-    u32 rw_off, pc_off;
+    u64 rw_off;  // rw_counter_offset (copy gadgets add a table value to it)
+    u32 pc_off;
     int sp_off;
     Fr rwc, call_id, sp, pc;  // curr step cells every lookup needs (loaded once)
     // bytecode-directory entry of curr.code_hash, probed once per step (every opcode/push-data
@@ -1825,7 +1826,8 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
 }
 
 // step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
-ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_left) {
+ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_left, const Fr& rd_offset = fr_zero(),
+                           const Fr& rd_length = fr_zero()) {
     const Fr rw_counter_delta = fr_add_u64(rw_counter_delta_in, 12);
     Fr caller_id; caller_id = call_context_lookup(I, CC_CallerId);
     const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
@@ -1836,9 +1838,9 @@ ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_
         Fr v; v = call_context_lookup(I, CC_LastCalleeId, 1, &caller_id);
         constrain_equal(I, v, ev_curr(I, S_CALL_ID));
         v = call_context_lookup(I, CC_LastCalleeReturnDataOffset, 1, &caller_id);
-        constrain_equal(I, v, fr_zero());
+        constrain_equal(I, v, rd_offset);
         v = call_context_lookup(I, CC_LastCalleeReturnDataLength, 1, &caller_id);
-        constrain_equal(I, v, fr_zero());
+        constrain_equal(I, v, rd_length);
     }
     const u32 st = ev_curr(I, S_STATE).v[0];
     const bool halts_ok = st == ES_STOP || st == ES_RETURN || st == ES_SELFDESTRUCT;
@@ -2078,6 +2080,102 @@ ZK_HD void g_error_write_protection(Ins& I, Tail& T) {  // error_write_protectio
     T.err_tail = 1;
 }
 
+ZK_HD void g_return(Ins& I, Tail& T) {  // return_revert.py (`not is_return` never holds for an FQ; REVERT is not dispatched)
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const u32 is_return = fr_eq_u64(opcode, OP_RETURN) ? 1u : 0u;
+    Fr is_success; is_success = call_context_lookup(I, CC_IsSuccess);
+    constrain_equal(I, is_success, fr_u(is_return));
+    Word off_w, len_w; off_w = stack_pop(I); len_w = stack_pop(I);
+    Fr ret_off; EV_TRY(ret_off = word_to_fq(I, off_w, 5));
+    Fr ret_len; EV_TRY(ret_len = word_to_fq(I, len_w, 5));
+    const Fr ret_end = fr_add(ret_off, ret_len);
+    Fr rwc_delta = fr_u(3);
+    Fr gas_left = ev_curr(I, S_GAS);
+    const bool is_root = !fr_is_zero(ev_curr(I, S_IS_ROOT)), is_create = !fr_is_zero(ev_curr(I, S_IS_CREATE));
+    if (is_create) {  // `curr.is_create and is_success`: an FQ is always truthy
+        WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
+        Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
+        RwQ Q;
+        rwq_init(Q, 1, TG_Account);
+        rwq_set(Q, R_ADDR, callee);
+        rwq_set(Q, R_FT, fr_u(ACC_CodeHash));
+        u32 r; r = rw_lookup(I, Q); if (I.err) return;
+        const Word code_hash = rw_word(I, r, R_VAL_LO), code_hash_prev = rw_word(I, r, R_PREV_LO);
+        I.seq++;  // Word(EMPTY_HASH)
+        constrain_equal_word(I, code_hash_prev, word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull),
+                                                        fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull)));
+        constrain_equal_word(I, code_hash, curr_code_hash(I));
+        fixed_lookup(I, FX_Range24_576, ret_len, fr_zero(), fr_zero()); if (I.err) return;
+        gas_left = fr_sub(gas_left, fr_mul_u64(ret_len, 200));
+        if (!fr_is_zero(ret_len)) {
+            CopyRes cr;
+            EV_TRY(cr = copy_lookup(I, word_value(I.call_id), CDT_Memory, code_hash, CDT_Bytecode, ret_off, ret_end, fr_zero(), ret_len,
+                                    fr_add_u64(I.rwc, I.rw_off)));
+            constrain_equal(I, cr.rwc_inc, ret_len); if (I.err) return;
+            I.rw_off += fr_lo64(ret_len);  // < 2^40
+            rwc_delta = fr_add(rwc_delta, ret_len);
+            Fr code_size; code_size = bytecode_length(I, code_hash, true);
+            constrain_equal(I, code_size, ret_len); if (I.err) return;
+        }
+    }
+    if (!is_root && !is_create) {
+        Fr caller_off, caller_len;
+        caller_off = call_context_lookup(I, CC_ReturnDataOffset);
+        caller_len = call_context_lookup(I, CC_ReturnDataLength);
+        if (I.err) return;
+        u32 lt, eq; EV_TRY(ev_compare(I, ret_len, caller_len, 5, lt, eq));
+        const Fr copy_len = ev_select_b(I, lt) ? ret_len : caller_len;
+        CopyRes cr;
+        EV_TRY(cr = copy_lookup(I, word_value(I.call_id), CDT_Memory, word_value(ev_next(I, S_CALL_ID)), CDT_Memory, ret_off, ret_end,
+                                caller_off, copy_len, fr_add_u64(I.rwc, I.rw_off)));
+        const Fr twice = fr_add(copy_len, copy_len);
+        constrain_equal(I, cr.rwc_inc, twice); if (I.err) return;
+        I.rw_off += fr_lo64(twice);
+        rwc_delta = fr_add(fr_add_u64(rwc_delta, 2), twice);
+    }
+    const u32 to_end_tx = ev_next(I, S_STATE).v[0] == ES_EndTx ? 1u : 0u;
+    constrain_equal(I, fr_u(is_root ? 1 : 0), fr_u(to_end_tx)); if (I.err) return;
+    Fr exp_gas; EV_TRY(exp_gas = dyn_expansion_gas(I, ret_off, ret_len));
+    if (is_root) {
+        Fr is_persistent; is_persistent = call_context_lookup(I, CC_IsPersistent);
+        constrain_equal(I, is_persistent, fr_u(is_return)); if (I.err) return;
+        transition(I, S_RWC, t_delta(fr_add_u64(rwc_delta, 1)));
+        transition(I, S_GAS, t_to(gas_left));
+        transition(I, S_CALL_ID, t_same());
+    } else {
+        restore_context(I, rwc_delta, fr_sub(gas_left, exp_gas), ret_off, ret_len);
+    }
+}
+ZK_HD void g_error_invalid_creation_code(Ins& I, Tail& T) {  // error_invalid_creation_code.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_RETURN));
+    ev_require(I, !fr_is_zero(ev_curr(I, S_IS_CREATE))); if (I.err) return;
+    Word ow; ow = stack_pop(I);
+    Fr ret_off; EV_TRY(ret_off = word_to_fq(I, ow, 5));
+    Fr first; first = memory_lookup(I, 0, ret_off);
+    constrain_equal(I, first, fr_u(0xEF)); if (I.err) return;
+    T.err_tail = 1;
+}
+ZK_HD void g_error_code_store(Ins& I, Tail& T) {  // error_code_store.py (ErrorMaxCodeSizeExceeded, ErrorOutOfGasCodeStore)
+    Fr opcode; opcode = opcode_lookup(I, true);
+    constrain_equal(I, opcode, fr_u(OP_RETURN));
+    ev_require(I, !fr_is_zero(ev_curr(I, S_IS_CREATE))); if (I.err) return;
+    Word lw; lw = stack_lookup(I, 0, 1);
+    Fr ret_len; EV_TRY(ret_len = word_to_fq(I, lw, 5));
+    Fr is_static; is_static = call_context_lookup(I, CC_IsStatic);
+    constrain_equal(I, is_static, fr_zero()); if (I.err) return;
+    u32 over, insufficient, eq;
+    EV_TRY(ev_compare(I, fr_u(24576), ret_len, 2, over, eq));
+    EV_TRY(ev_compare(I, ev_curr(I, S_GAS), fr_mul_u64(ret_len, 200), 8, insufficient, eq));
+    ev_require(I, (insufficient | over) != 0u); if (I.err) return;
+    T.err_tail = 1;
+}
+ZK_HD void g_end_block(Ins& I, Tail& T, bool is_last) {  // end_block.py: padding steps only
+    if (is_last) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    transition(I, S_RWC, t_same());
+    transition(I, S_CALL_ID, t_same());
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_transition_ok(u32 curr, u32 next) {
     static const uint8_t halts[] = ZK_STATE_HALTS_INIT;
@@ -2139,7 +2237,8 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_RETURNDATACOPY: case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion:
     case ES_ErrorOutOfGasDynamicMemoryExpansion: case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess:
     case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP: case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound:
-    case ES_ErrorWriteProtection: case ES_LOG: return EVM_GROUP_MEM;
+    case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN: case ES_ErrorInvalidCreationCode:
+    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: return EVM_GROUP_MEM;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -2155,7 +2254,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     I.idx = idx;
     I.err = 0;
     I.seq = 0;
-    I.rw_off = I.pc_off = 0;
+    I.rw_off = 0;
+    I.pc_off = 0;
     I.sp_off = 0;
     I.code_state = 0;
     EV_PROF(I, 0);
@@ -2227,6 +2327,10 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_write_protection(I, T); } break;
+    case ES_RETURN: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_return(I, T); } break;
+    case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_creation_code(I, T); } break;
+    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_code_store(I, T); } break;
+    case ES_EndBlock: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_end_block(I, T, is_last); } break;
     case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_opcode(I, T); } break;
     case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
     case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
