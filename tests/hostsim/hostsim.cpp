@@ -120,7 +120,11 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
         a.codes.mask = dir.mask;
         a.codes.n = (u32)dir.entries.size();
     }
-    for (u64 i = 0; i + 1 < n_steps; i++) status[i] = evm_check_step<EVM_GROUP_ALL>(a, i);
+    for (u64 i = 0; i + 1 < n_steps; i++) {  // as on the device: the hot and the cold instantiation split the states
+        u32 c = evm_check_step<EVM_GROUP_ALL>(a, i);
+        if (c == ZK_NOT_MINE) c = evm_check_step<EVM_GROUP_COLD>(a, i);
+        status[i] = c;
+    }
     return 0;
 }
 

@@ -2227,18 +2227,23 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 // (smaller instruction footprint, fewer live registers -> more resident wavefronts).
 // numbered in launch order: the long-running gadgets get the first lanes so that their wavefronts start
 // first and the short ones fill in behind them (no long tail at the end of the kernel)
-enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_N_GROUPS = 3, EVM_GROUP_ALL = -1 };
+// EVM_GROUP_COLD: states outside BASELINE config 3's opcode mix (error states, copy / account-access
+// gadgets, EXP, SDIV/SMOD, RETURN, LOG, EndBlock).  They get their own kernel instantiation so that
+// their code and register pressure stay out of the hot kernel (EVM_GROUP_ALL = the three hot groups).
+enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_GROUP_COLD = 3, EVM_N_GROUPS = 4, EVM_GROUP_ALL = -1 };
+#define ZK_NOT_MINE 0xffffffffu  // evm_check_step<G>: the state belongs to the other instantiation
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
-    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: case ES_SDIV_SMOD: case ES_EXP: return EVM_GROUP_MUL;
-    case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: case ES_BALANCE: case ES_EXTCODESIZE:
-    case ES_EXTCODEHASH: case ES_BLOCKHASH: case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack:
-    case ES_ErrorOutOfGasConstant: case ES_ErrorInvalidJump: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY:
-    case ES_RETURNDATACOPY: case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion:
-    case ES_ErrorOutOfGasDynamicMemoryExpansion: case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess:
-    case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP: case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound:
-    case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN: case ES_ErrorInvalidCreationCode:
-    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: return EVM_GROUP_MEM;
+    case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
+    case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: return EVM_GROUP_MEM;
+    case ES_SDIV_SMOD: case ES_EXP: case ES_BALANCE: case ES_EXTCODESIZE: case ES_EXTCODEHASH: case ES_BLOCKHASH:
+    case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack: case ES_ErrorOutOfGasConstant:
+    case ES_ErrorInvalidJump: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY: case ES_RETURNDATACOPY:
+    case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
+    case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
+    case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
+    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock:
+        return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -2267,6 +2272,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
     const Fr statef = ev_curr(I, S_STATE);
     const u32 state = statef.v[0];
+    if ((G == EVM_GROUP_COLD) != (evm_state_group(state) == EVM_GROUP_COLD)) return ZK_NOT_MINE;
     if (is_first) {
         ev_require(I, state == ES_BeginTx || state == ES_EndBlock);
         constrain_equal(I, ev_curr(I, S_RWC), fr_u(1));
@@ -2284,10 +2290,6 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     Tail T;
     T.enabled = false;
     T.err_tail = 0;
-    if (G != EVM_GROUP_ALL && evm_state_group(state) != G) {  // cannot happen with a correct lane mapping
-        ev_fail(I, ZK_UNSUPPORTED);
-        return I.err;
-    }
     switch (state) {
     case ES_ADD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADD) { g_add_sub(I, T); } break;
     case ES_MUL: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MUL) { g_mul_div_mod(I, T); } break;
@@ -2318,36 +2320,36 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
     case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
     case ES_SAR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SAR) { g_sar(I, T); } break;
-    case ES_ErrorOutOfGasStaticMemoryExpansion: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_static_memory(I, T); } break;
-    case ES_ErrorOutOfGasDynamicMemoryExpansion: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_dynamic_memory(I, T); } break;
-    case ES_ErrorOutOfGasMemoryCopy: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_memory_copy(I, T); } break;
-    case ES_ErrorOutOfGasAccountAccess: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_account_access(I, T); } break;
-    case ES_ErrorOutOfGasLOG: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_log(I, T); } break;
-    case ES_ErrorOutOfGasEXP: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_exp(I, T); } break;
-    case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_sha3(I, T); } break;
-    case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_return_data_oob(I, T); } break;
-    case ES_ErrorWriteProtection: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_write_protection(I, T); } break;
-    case ES_RETURN: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_return(I, T); } break;
-    case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_creation_code(I, T); } break;
-    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_code_store(I, T); } break;
-    case ES_EndBlock: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_end_block(I, T, is_last); } break;
-    case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_opcode(I, T); } break;
-    case ES_ErrorStack: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_stack(I, T); } break;
-    case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_oog_constant(I, T); } break;
-    case ES_ErrorInvalidJump: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_error_invalid_jump(I, T); } break;
-    case ES_LOG: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_log(I, T); } break;
-    case ES_SHA3: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_sha3(I, T); } break;
-    case ES_CODECOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_codecopy(I, T); } break;
-    case ES_CALLDATACOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_calldatacopy(I, T); } break;
-    case ES_RETURNDATACOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_returndatacopy(I, T); } break;
-    case ES_EXTCODECOPY: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodecopy(I, T); } break;
-    case ES_EXP: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MUL) { g_exp(I, T); } break;
-    case ES_BALANCE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_balance(I, T); } break;
-    case ES_EXTCODESIZE: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodesize(I, T); } break;
-    case ES_EXTCODEHASH: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_extcodehash(I, T); } break;
-    case ES_BLOCKHASH: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_blockhash(I, T); } break;
-    case ES_CALLDATALOAD: if (G == EVM_GROUP_ALL || G == EVM_GROUP_MEM) { g_calldataload(I, T); } break;
-    case ES_SDIV_SMOD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SDIV_SMOD) { g_sdiv_smod(I, T); } break;
+    case ES_ErrorOutOfGasStaticMemoryExpansion: if (G == EVM_GROUP_COLD) { g_error_oog_static_memory(I, T); } break;
+    case ES_ErrorOutOfGasDynamicMemoryExpansion: if (G == EVM_GROUP_COLD) { g_error_oog_dynamic_memory(I, T); } break;
+    case ES_ErrorOutOfGasMemoryCopy: if (G == EVM_GROUP_COLD) { g_error_oog_memory_copy(I, T); } break;
+    case ES_ErrorOutOfGasAccountAccess: if (G == EVM_GROUP_COLD) { g_error_oog_account_access(I, T); } break;
+    case ES_ErrorOutOfGasLOG: if (G == EVM_GROUP_COLD) { g_error_oog_log(I, T); } break;
+    case ES_ErrorOutOfGasEXP: if (G == EVM_GROUP_COLD) { g_error_oog_exp(I, T); } break;
+    case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
+    case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
+    case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_RETURN: if (G == EVM_GROUP_COLD) { g_return(I, T); } break;
+    case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_COLD) { g_error_invalid_creation_code(I, T); } break;
+    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (G == EVM_GROUP_COLD) { g_error_code_store(I, T); } break;
+    case ES_EndBlock: if (G == EVM_GROUP_COLD) { g_end_block(I, T, is_last); } break;
+    case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_COLD) { g_error_invalid_opcode(I, T); } break;
+    case ES_ErrorStack: if (G == EVM_GROUP_COLD) { g_error_stack(I, T); } break;
+    case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_COLD) { g_error_oog_constant(I, T); } break;
+    case ES_ErrorInvalidJump: if (G == EVM_GROUP_COLD) { g_error_invalid_jump(I, T); } break;
+    case ES_LOG: if (G == EVM_GROUP_COLD) { g_log(I, T); } break;
+    case ES_SHA3: if (G == EVM_GROUP_COLD) { g_sha3(I, T); } break;
+    case ES_CODECOPY: if (G == EVM_GROUP_COLD) { g_codecopy(I, T); } break;
+    case ES_CALLDATACOPY: if (G == EVM_GROUP_COLD) { g_calldatacopy(I, T); } break;
+    case ES_RETURNDATACOPY: if (G == EVM_GROUP_COLD) { g_returndatacopy(I, T); } break;
+    case ES_EXTCODECOPY: if (G == EVM_GROUP_COLD) { g_extcodecopy(I, T); } break;
+    case ES_EXP: if (G == EVM_GROUP_COLD) { g_exp(I, T); } break;
+    case ES_BALANCE: if (G == EVM_GROUP_COLD) { g_balance(I, T); } break;
+    case ES_EXTCODESIZE: if (G == EVM_GROUP_COLD) { g_extcodesize(I, T); } break;
+    case ES_EXTCODEHASH: if (G == EVM_GROUP_COLD) { g_extcodehash(I, T); } break;
+    case ES_BLOCKHASH: if (G == EVM_GROUP_COLD) { g_blockhash(I, T); } break;
+    case ES_CALLDATALOAD: if (G == EVM_GROUP_COLD) { g_calldataload(I, T); } break;
+    case ES_SDIV_SMOD: if (G == EVM_GROUP_COLD) { g_sdiv_smod(I, T); } break;
     case ES_JUMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMP) { g_jump(I, T); } break;
     case ES_JUMPI: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMPI) { g_jumpi(I, T); } break;
     case ES_SLOAD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SLOAD) { g_sload(I, T); } break;

@@ -123,23 +123,34 @@ __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* statu
 // ---------------------------------------------------------------------------------------
 template <int G, int OCC>
 __global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    u64 idx = t;
-    bool active;
-    if (G == EVM_GROUP_ALL) {
-        active = t < a.n_pairs;
-        if (active && a.perm) idx = a.perm[t];
-    } else {
-        const u32 lo = group_start[G], hi = group_start[G + 1];
-        active = t < (u64)(hi - lo);
-        if (active) idx = a.perm[lo + t];
+    // lane range: with the state-sorted mapping the hot instantiation owns [0, group_start[COLD]) and the
+    // cold one [group_start[COLD], n); without it both walk all pairs and skip the other's states
+    u32 lo = 0, hi = a.n_pairs;
+    if (a.perm) {
+        if (G == EVM_GROUP_COLD) lo = group_start[EVM_GROUP_COLD];
+        else hi = group_start[EVM_GROUP_COLD];
     }
-    if (active) {
-        code = evm_check_step<G>(a, idx);
-        if (status) status[idx] = code;
+    u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
+        u32 code = 0;
+        u64 idx = t;
+        if (t < (u64)hi) {
+            if (a.perm) idx = a.perm[t];
+            code = evm_check_step<G>(a, idx);
+            if (code == ZK_NOT_MINE) code = 0;
+            else if (status) status[idx] = code;
+        }
+        tally_commit(tally, idx, code);
+    } else {  // small grid, grid-stride loop
+        const u64 stride = (u64)gridDim.x * blockDim.x;
+        for (; t < (u64)hi; t += stride) {
+            const u64 idx = a.perm ? (u64)a.perm[t] : t;
+            u32 code = evm_check_step<G>(a, idx);
+            if (code == ZK_NOT_MINE) code = 0;
+            else if (status) status[idx] = code;
+            tally_commit(tally, idx, code);  // ballot over the lanes still in the loop
+        }
     }
-    tally_commit(tally, idx, code);
 }
 
 // RW-table density check (see ZkRwMeta): meta->dense must be pre-set to 1.
@@ -803,6 +814,8 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const u32 grid = (u32)((s->n + block - 1) / block);
         // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        // the rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(s->evm.perm ? (grid < 256u ? grid : 256u) : grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
         break;
     }
     }
