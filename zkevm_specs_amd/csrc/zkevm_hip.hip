@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* statu
 // steps contains; each group has its own kernel instantiation (evm_circuit.hpp).
 // group_start[g] .. group_start[g+1] is the lane range of group g inside `perm`.
 // ---------------------------------------------------------------------------------------
+#ifndef ZK_HOT_OCC
+#define ZK_HOT_OCC 2  // waves per SIMD the hot EVM kernel is compiled for
+#endif
 template <int G, int OCC>
 __global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
     // lane range: with the state-sorted mapping the hot instantiation owns [0, group_start[COLD]) and the
@@ -813,7 +816,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
         // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, 2>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
         // the rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces
         hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(s->evm.perm ? (grid < 256u ? grid : 256u) : grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
         break;
