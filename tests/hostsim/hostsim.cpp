@@ -212,6 +212,9 @@ extern "C" int sim_sign_verify(const uint8_t* bytes, const u64* cells, const u32
     a.tx_rows = tt.t;
     a.tx_rows.n = (u32)n_tx_rows;
     a.r = fr_load(r);
+    std::vector<u64> rpow(64 * 4);
+    sign_fill_rpow(a.r, rpow.data());
+    a.rpow = rpow.data();
     a.is_sig = is_sig;
     for (u64 i = 0; i < n; i++) status[i] = sign_check_unit(a, i);
     return 0;

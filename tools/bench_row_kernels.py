@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Throughput of the row-stencil kernels (Bytecode / Exp / Tx-Sig circuits) on synthetic witnesses:
+rows/s and algorithmic GB/s (SURVEY.md §8d bytes per unit), device-resident inputs, HIP-event kernel
+time.  bench.py carries the headline EVM / State workloads; this is the side table in DESIGN.md §3."""
+import json
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from zkevm_specs_amd import _lib, engine
+from zkevm_specs_amd.synth import synth_bytecode_witness, synth_exp_witness, synth_tx_witness
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()
+_lib.init(0)
+out = {}
+
+
+def run(name, sess, units, bytes_per_unit):
+    with sess as s:
+        for _ in range(3):
+            s.launch()
+        s.collect()
+        for _ in range(20):
+            s.launch()
+        r = s.collect()
+        assert r.ok, (name, r)
+    out[name] = {"units": units, "kernel_ms": round(r.kernel_ms, 4), "units_per_s": round(units / r.kernel_ms * 1e3),
+                 "algorithmic_GBps": round(units * bytes_per_unit / r.kernel_ms / 1e6, 1),
+                 "frac_of_8TBps": round(units * bytes_per_unit / r.kernel_ms / 1e6 / 8000, 4)}
+    print(name, out[name], flush=True)
+
+
+rng = random.Random(1)
+r = rng.randrange(P)
+k = int(os.environ.get("LOGN", "20"))
+codes = [bytes(rng.getrandbits(8) for _ in range(24000)) for _ in range((1 << k) // 24576)]
+cols, keccak = synth_bytecode_witness(codes, k, r)
+run("bytecode", engine.open_bytecode(cols, keccak, r), 1 << k, 12 * 32)
+cols = synth_exp_witness(1 << k, seed=8)
+run("exp", engine.open_exp(cols), 1 << k, 21 * 32)
+n_tx = 1 << min(k, 17)
+w = synth_tx_witness(n_tx, r, seed=4)
+run("tx_sign", engine.open_sign(w, r, False), n_tx,
+    8 * 32 + 288 + 2 * 5 * 32)
+print(json.dumps(out))

@@ -27,20 +27,77 @@ struct SignArgs {
     ZkTable keccak;
     ZkTable tx_rows;       // Tx circuit only (n = 0 for the Sig circuit)
     Fr r;
+    const u64* rpow;       // [64][4]: r^0 .. r^63 (canonical), built once per session (sign_fill_rpow)
     u32 is_sig;            // 0 = Tx circuit semantics, 1 = Sig circuit semantics
 };
-
-ZK_HD const uint8_t* sg_bytes(const SignArgs& a, u64 i, int k) { return a.bytes + (i * SG_NBYTES_ROWS + k) * 32; }
-ZK_HD bool sg_bytes_eq(const uint8_t* x, const uint8_t* y) {
-    bool eq = true;
-    for (int k = 0; k < 32; k++) eq = eq && x[k] == y[k];
-    return eq;
+// powers of the keccak randomness for the 64-byte public-key RLC
+ZK_HD void sign_fill_rpow(const Fr& r, u64* out) {
+    Fr p = fr_from_u64(1);
+    for (int k = 0; k < 64; k++) {
+        for (int j = 0; j < 4; j++) out[4 * k + j] = (u64)p.v[2 * j] | ((u64)p.v[2 * j + 1] << 32);
+        p = fr_mul(p, r);
+    }
 }
-// little-endian integer of n (<= 16) bytes
-ZK_HD Fr sg_le128(const uint8_t* b, int n) {
+
+// one 32-byte row of the unit's byte block, fetched with two 16-byte loads (the rows are 32-byte
+// aligned: unit stride 9 x 32 B) and kept as eight little-endian words
+struct B32 {
+    u32 w[8];
+};
+ZK_HD B32 sg_bytes(const SignArgs& a, u64 i, int k) {
+    const uint4* p = reinterpret_cast<const uint4*>(a.bytes + (i * SG_NBYTES_ROWS + k) * 32);
+    const uint4 lo = p[0], hi = p[1];
+    B32 b;
+    b.w[0] = lo.x; b.w[1] = lo.y; b.w[2] = lo.z; b.w[3] = lo.w;
+    b.w[4] = hi.x; b.w[5] = hi.y; b.w[6] = hi.z; b.w[7] = hi.w;
+    return b;
+}
+ZK_HD bool sg_bytes_eq(const B32& x, const B32& y) {
+    u32 d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d |= x.w[k] ^ y.w[k];
+    return d == 0;
+}
+ZK_HD u32 sg_byte(const B32& b, int k) { return (b.w[k >> 2] >> (8 * (k & 3))) & 0xffu; }
+// little-endian integer of bytes [off, off + 16)
+ZK_HD Fr sg_le128(const B32& b, int off) {
     Fr r = fr_zero();
-    for (int k = 0; k < n; k++) r.v[k >> 2] |= (u32)b[k] << (8 * (k & 3));
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.v[k] = b.w[(off >> 2) + k];
     return r;
+}
+
+// RLC of 64 bytes: sum of byte_k * r^k with lazy reduction.  Each term is < 2^262, the sum < 2^268:
+// nine 32-bit limbs, reduced once (64 x 8 multiply-adds instead of 64 Montgomery multiplications).
+ZK_HD Fr sg_rlc64(const B32& first32, const B32& last32, const u64* rpow) {
+    u32 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[j] = 0;
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        const u32 byte = k < 32 ? sg_byte(first32, k) : sg_byte(last32, k - 32);
+        const Fr pw = fr_load(rpow + 4 * k);  // same address in every lane
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)acc[j] + (u64)pw.v[j] * byte;
+            acc[j] = (u32)c;
+            c >>= 32;
+        }
+        acc[8] += (u32)c;
+    }
+    Fr lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) lo.v[j] = acc[j];
+    const Fr p = fr_modulus();
+#pragma unroll
+    for (int it = 0; it < 5; it++) {  // lo < 2^256 < 6p
+        Fr t;
+        const u32 bw = u256_sub(t, lo, p);
+        lo = bw ? lo : t;
+    }
+    // acc[8] * 2^256 mod p: 2^256 mod p is the Montgomery one in canonical form
+    return fr_add(lo, fr_mul(fr_from_u64(acc[8]), frm_one()));
 }
 
 #define SG_FAIL(kind, site) code = (code == 0u) ? ZK_CODE(kind, site) : code
@@ -54,14 +111,16 @@ ZK_HD u32 sign_check_unit(const SignArgs& a, u64 i) {
     const bool is_np = a.is_sig ? true : !fr_is_zero(address);  // is_not_padding (:206)
 
     // 0. copy constraints between the chip and the ECDSA chip
-    SG_ASSERT(!(bad & 0x5u) && sg_bytes_eq(sg_bytes(a, i, SG_PK_X), sg_bytes(a, i, SG_E_PK_X)), 1);
-    SG_ASSERT(!(bad & 0xau) && sg_bytes_eq(sg_bytes(a, i, SG_PK_Y), sg_bytes(a, i, SG_E_PK_Y)), 2);
-    SG_ASSERT(!(bad & 0x30u) && sg_bytes_eq(sg_bytes(a, i, SG_MSG), sg_bytes(a, i, SG_E_MSG)), 3);
+    const B32 pk_x = sg_bytes(a, i, SG_PK_X), pk_y = sg_bytes(a, i, SG_PK_Y), msg = sg_bytes(a, i, SG_MSG);
+    const B32 pk_hash = sg_bytes(a, i, SG_PK_HASH);
+    SG_ASSERT(!(bad & 0x5u) && sg_bytes_eq(pk_x, sg_bytes(a, i, SG_E_PK_X)), 1);
+    SG_ASSERT(!(bad & 0xau) && sg_bytes_eq(pk_y, sg_bytes(a, i, SG_E_PK_Y)), 2);
+    SG_ASSERT(!(bad & 0x30u) && sg_bytes_eq(msg, sg_bytes(a, i, SG_E_MSG)), 3);
     if (a.is_sig) {
         // sig_r/sig_s.int_value() == int.from_bytes(ecdsa sig bytes, "little")  (sig_circuit.py:70-71)
         for (int which = 0; which < 2; which++) {
             const Fr lo = zk_col(a.cells, SG_SIG_R_LO + 2 * which, i), hi = zk_col(a.cells, SG_SIG_R_HI + 2 * which, i);
-            const uint8_t* b = sg_bytes(a, i, SG_E_SIG_R + which);
+            const B32 b = sg_bytes(a, i, SG_E_SIG_R + which);
             // lo + (hi << 128) as a 384-bit integer vs the 256-bit byte value
             u32 sum[12];
             u64 c = 0;
@@ -73,7 +132,7 @@ ZK_HD u32 sign_check_unit(const SignArgs& a, u64 i) {
             bool eq = c == 0;
             for (int k = 0; k < 12; k++) {
                 u32 want = 0;
-                if (k < 8) want = (u32)b[4 * k] | ((u32)b[4 * k + 1] << 8) | ((u32)b[4 * k + 2] << 16) | ((u32)b[4 * k + 3] << 24);
+                if (k < 8) want = b.w[k];
                 eq = eq && sum[k] == want;
             }
             SG_ASSERT(eq, 12 + which);
@@ -83,32 +142,26 @@ ZK_HD u32 sign_check_unit(const SignArgs& a, u64 i) {
     // 1. keccak(pub_key_bytes) == pub_key_hash through the keccak table.  The RLC input is
     //    pk_y bytes then pk_x bytes in little-endian positions (see the oracle for the derivation).
     {
-        Fr acc = fr_zero();
-        const Fr rM = fr_to_mont(a.r);
-        for (int k = 63; k >= 0; k--) {
-            const uint8_t byte = k < 32 ? sg_bytes(a, i, SG_PK_Y)[k] : sg_bytes(a, i, SG_PK_X)[k - 32];
-            acc = fr_add(fr_mulc(acc, rM), fr_from_u64(byte));
-        }
-        const uint8_t* h = sg_bytes(a, i, SG_PK_HASH);
+        const Fr acc = sg_rlc64(pk_y, pk_x, a.rpow);
+        const B32& h = pk_hash;
         Fr q[KECCAK_NCELLS];
         q[0] = fr_from_u64(is_np ? 1 : 0);
         q[1] = is_np ? acc : fr_zero();
         q[2] = fr_from_u64(is_np ? 64 : 0);
-        q[3] = is_np ? sg_le128(h, 16) : fr_zero();       // Word(bytes): lo = bytes[0:16] little-endian
-        q[4] = is_np ? sg_le128(h + 16, 16) : fr_zero();
+        q[3] = is_np ? sg_le128(h, 0) : fr_zero();        // Word(bytes): lo = bytes[0:16] little-endian
+        q[4] = is_np ? sg_le128(h, 16) : fr_zero();
         if (code == 0u) SG_ASSERT(!(bad & 0x40u) && keccak_contains(a.keccak, q), 4);
     }
     // 2. low 20 bytes of the hash (big-endian) == address
     {
-        const uint8_t* h = sg_bytes(a, i, SG_PK_HASH);
         Fr addr = fr_zero();
-        for (int k = 0; k < 20; k++) addr.v[k >> 2] |= (u32)h[31 - k] << (8 * (k & 3));
+#pragma unroll
+        for (int k = 0; k < 20; k++) addr.v[k >> 2] |= sg_byte(pk_hash, 31 - k) << (8 * (k & 3));
         SG_ASSERT(fr_eq(addr, address), 5);
     }
     // 3. Word(msg_hash_bytes) (select(is_not_padding) for Tx) == msg_hash
     {
-        const uint8_t* m = sg_bytes(a, i, SG_MSG);
-        const Fr lo = is_np ? sg_le128(m, 16) : fr_zero(), hi = is_np ? sg_le128(m + 16, 16) : fr_zero();
+        const Fr lo = is_np ? sg_le128(msg, 0) : fr_zero(), hi = is_np ? sg_le128(msg, 16) : fr_zero();
         SG_ASSERT(fr_eq(lo, msg_lo) && fr_eq(hi, msg_hi), 6);
     }
     // 4. ECDSA outcome (pre-computed column)

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status,
     tally_commit(tally, i, code);
 }
 // Tx / Sig circuits: one lane per tx slot / signature row (units are independent: no halo).
+__global__ void sign_rpow_kernel(Fr r, u64* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sign_fill_rpow(r, out);
+}
 __global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
@@ -664,6 +667,12 @@ extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** 
         memcpy(rh, t->randomness, 32);
     }
     for (int k = 0; k < 4; k++) { s->sign.r.v[2 * k] = (u32)rh[k]; s->sign.r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    {
+        u64* d_rpow = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_rpow, 64 * 4 * sizeof(u64)))) goto fail;
+        hipLaunchKernelGGL(sign_rpow_kernel, dim3(1), dim3(64), 0, g_stream, s->sign.r, d_rpow);
+        s->sign.rpow = d_rpow;
+    }
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
