@@ -129,75 +129,152 @@ ZK_HD u64 state_mpt_key_hash(const ZkTable& t, u32 r) {
 #define ST_FAIL(kind, site) code = (code == 0u) ? ZK_CODE(kind, site) : code
 #define ST_ASSERT(cond, site) code = (code == 0u && !(cond)) ? ZK_CODE(ZK_ASSERT, site) : code
 
-// Evaluate row i against prev = (i-1) mod n and next = (i+1) mod n.
-ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
-    const ZkCols& w = a.rows;
-    const u64 n = w.n;
-    const u64 ip = i == 0 ? n - 1 : i - 1;   // (i - 1) mod n without a 64-bit division
-    const u64 in = i + 1 == n ? 0 : i + 1;
-    const u32 fl = w.flags ? w.flags[i] : 0u;
-    const bool val_is_word = fl & 1u, init_is_word = fl & 2u;
-    u32 code = 0;
+// Everything the checks need from ONE row.  A lane loads only its own row (57 coalesced cells);
+// the previous row's values come from the neighbouring lane (wave_shr DPP moves on the device, the
+// separately loaded previous row in the host build): a wavefront evaluates 63 rows, lane 0 is the
+// read-only halo row in front of them.
+struct StRow {
+    Fr rwc, tag, id, addr, ftag, key_lo, key_hi, val_lo, val_hi, init_lo, init_hi, root_lo, root_hi;
+    u32 pack[16];  // keys_rwc_to_limbs_in_order packing of this row (state_circuit.py:552-565), 496 bits
+    u32 pack_ok;   // 0 when a storage-key byte cell is >= 256 (Python: bytes() raises ValueError)
+    u32 flags;
+    u32 is_write01;  // is_write cell: 0, 1, or 2 = anything else
+};
 
-    const Fr rwc = zk_col(w, ST_RWC, i);
+// Loads row i and evaluates the checks that involve this row only (sites 1..8, evaluation order
+// of check_state_row :498-520); `code` is the row's running first-failure code.
+ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
+    R.flags = w.flags ? w.flags[i] : 0u;
+    R.rwc = zk_col(w, ST_RWC, i);
     const Fr is_write = zk_col(w, ST_IS_WRITE, i);
-    const Fr tag = zk_col(w, ST_TAG, i);
-    const Fr id = zk_col(w, ST_ID, i);
-    const Fr addr = zk_col(w, ST_ADDR, i);
-    const Fr ftag = zk_col(w, ST_FIELD_TAG, i);
-
+    R.tag = zk_col(w, ST_TAG, i);
+    R.id = zk_col(w, ST_ID, i);
+    R.addr = zk_col(w, ST_ADDR, i);
+    R.ftag = zk_col(w, ST_FIELD_TAG, i);
+    R.key_lo = zk_col(w, ST_KEY_LO, i);
+    R.key_hi = zk_col(w, ST_KEY_HI, i);
     // 0.0 tag, id, field_tag ranges (:498-502)
-    ST_ASSERT(fr_fits64(tag) && fr_lo64(tag) >= 1 && fr_lo64(tag) <= 12, 1);
-    ST_ASSERT(fr_le_u64(id, (1ull << 28) - 1), 2);
-    ST_ASSERT(fr_le_u64(ftag, 24), 3);
-    const u32 tagv = tag.v[0];
-
+    ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
+    ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
+    ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
     // 0.1 address limbs are 16-bit and recompose to address in Fr (:505-509)
     {
         U256 lc = fr_zero();
+        bool limbs_ok = true;
+#pragma unroll
         for (int k = 0; k < 10; k++) {
-            Fr limb = zk_col(w, ST_LIMB0 + k, i);
-            ST_ASSERT(fr_le_u64(limb, 65535), 4);
+            const Fr limb = zk_col(w, ST_LIMB0 + k, i);
+            limbs_ok = limbs_ok && fr_le_u64(limb, 65535);
             lc.v[k >> 1] |= (limb.v[0] & 0xffffu) << (16 * (k & 1));
         }
-        ST_ASSERT(fr_eq(addr, lc), 5);  // sum < 2^160 < p: integer value == field value
+        ST_ASSERT(limbs_ok, 4);
+        ST_ASSERT(fr_eq(R.addr, lc), 5);  // sum < 2^160 < p: integer value == field value
     }
     // 0.2 storage-key bytes are bytes and recompose to (lo, hi) (:512-517)
+    U256 key = fr_zero();
     {
-        Fr lo = fr_zero(), hi = fr_zero();
+        bool bytes_ok = true;
+#pragma unroll
         for (int b = 0; b < 32; b++) {
-            Fr c = zk_col(w, ST_BYTE0 + b, i);
-            ST_ASSERT(fr_le_u64(c, 255), 6);
-            u32 byte = c.v[0] & 0xff;
-            if (b < 16) lo.v[b >> 2] |= byte << (8 * (b & 3));
-            else hi.v[(b - 16) >> 2] |= byte << (8 * (b & 3));
+            const Fr c = zk_col(w, ST_BYTE0 + b, i);
+            bytes_ok = bytes_ok && fr_le_u64(c, 255);
+            key.v[b >> 2] |= (c.v[0] & 0xffu) << (8 * (b & 3));
         }
-        ST_ASSERT(fr_eq(zk_col(w, ST_KEY_LO, i), lo) && fr_eq(zk_col(w, ST_KEY_HI, i), hi), 7);
+        R.pack_ok = bytes_ok ? 1u : 0u;
+        ST_ASSERT(bytes_ok, 6);
+        ST_ASSERT(fr_eq(R.key_lo, u256_lo(key)) && fr_eq(R.key_hi, u256_hi(key)), 7);
     }
     // 0.3 is_write boolean (:520)
     ST_ASSERT(fr_le_u64(is_write, 1), 8);
-    const bool is_read = fr_is_zero(is_write);
-
-    // 0.4 lexicographic ordering (:552-570).  Both limb vectors are built unconditionally.
+    R.is_write01 = fr_is_zero(is_write) ? 0u : (fr_eq_u64(is_write, 1) ? 1u : 2u);
+    // key packing (tag, id, address, field_tag, storage_key_bytes, rw_counter), :552-565
     {
-        Big18 kp, kc;
-        if (!state_pack_keys(w, ip, kp)) ST_FAIL(ZK_VALUE_ERROR, 9);
-        state_pack_keys(w, i, kc);
-        ST_ASSERT(tagv == 1 || big_lt(kp, kc), 10);
+        Big18 out;
+        for (int k = 0; k < 18; k++) out.v[k] = 0;
+        big_shl_add(out, 0, 0, R.tag);
+        big_shl_add(out, 0, 28, R.id);     // v * 2^ID_BITS + id
+        big_shl_add(out, 5, 0, R.addr);    // v * 2^160 + address
+        big_shl_add(out, 0, 16, R.ftag);   // v * 2^16 + field_tag
+        big_shl_add(out, 1, 0, key);       // v * 2^32 + storage key (256-bit)
+        big_shl_add(out, 1, 0, R.rwc);     // v * 2^32 + rw_counter
+        out.v[15] &= 0xffffu;              // keep 31 limbs of 16 bits = 496 bits
+#pragma unroll
+        for (int k = 0; k < 16; k++) R.pack[k] = out.v[k];
     }
-    const bool keys_eq_prev = state_keys_eq(w, i, ip);
+    R.val_lo = zk_col(w, ST_VAL_LO, i);
+    R.val_hi = zk_col(w, ST_VAL_HI, i);
+    R.init_lo = zk_col(w, ST_INIT_LO, i);
+    R.init_hi = zk_col(w, ST_INIT_HI, i);
+    R.root_lo = zk_col(w, ST_ROOT_LO, i);
+    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+}
+
+#ifdef ZK_HOSTSIM
+#define ST_PREV_U32(x) (P.x)
+#define ST_PREV_FR(f) (P.f)
+#else
+// value of the same expression in lane - 1 (gfx9 DPP wave_shr:1; lane 0 is the halo and unused)
+ZK_HD u32 st_shr_u32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+ZK_HD Fr st_shr_fr(const Fr& x) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = st_shr_u32(x.v[k]);
+    return r;
+}
+#define ST_PREV_U32(x) st_shr_u32(C.x)
+#define ST_PREV_FR(f) st_shr_fr(C.f)
+#endif
+
+// Checks of row i that involve the previous row (sites 9..13) and the per-tag rules; C = this
+// row, P = previous row (host build only; the device takes it from the neighbouring lane).
+// Must be called by every lane of the wavefront (the DPP moves read the neighbour's registers).
+ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const StRow& P, u32 code) {
+    (void)P;
+    const ZkCols& w = a.rows;
+    const u64 n = w.n;
+    const u64 ip = i == 0 ? n - 1 : i - 1;
+    const u64 in = i + 1 == n ? 0 : i + 1;
+    const bool val_is_word = C.flags & 1u, init_is_word = C.flags & 2u;
+    const u32 tagv = C.tag.v[0];
+    const Fr& rwc = C.rwc; const Fr& tag = C.tag; const Fr& id = C.id; const Fr& addr = C.addr; const Fr& ftag = C.ftag;
+    const bool is_read = C.is_write01 == 0u;
+
+    // 0.4 lexicographic ordering (:552-570)
+    {
+        const u32 p_ok = ST_PREV_U32(pack_ok);
+        u32 kp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) kp[k] = ST_PREV_U32(pack[k]);
+        if (!p_ok) ST_FAIL(ZK_VALUE_ERROR, 9);
+        bool lt = false;
+#pragma unroll
+        for (int k = 0; k < 16; k++) lt = (kp[k] < C.pack[k]) | ((kp[k] == C.pack[k]) & lt);
+        ST_ASSERT(tagv == 1 || lt, 10);
+    }
+    // every neighbour read happens unconditionally, with all lanes active (no short-circuit around a DPP move)
+    const Fr p_tag = ST_PREV_FR(tag), p_id = ST_PREV_FR(id), p_addr = ST_PREV_FR(addr), p_ftag = ST_PREV_FR(ftag);
+    const Fr p_key_lo = ST_PREV_FR(key_lo), p_key_hi = ST_PREV_FR(key_hi);
+    const Fr p_val_lo = ST_PREV_FR(val_lo), p_val_hi = ST_PREV_FR(val_hi);
+    const Fr p_init_lo = ST_PREV_FR(init_lo), p_init_hi = ST_PREV_FR(init_hi);
+    const Fr p_root_lo = ST_PREV_FR(root_lo), p_root_hi = ST_PREV_FR(root_hi);
+    const bool keys_eq_prev = fr_eq(tag, p_tag) & fr_eq(id, p_id) & fr_eq(addr, p_addr) & fr_eq(ftag, p_ftag) &
+                              fr_eq(C.key_lo, p_key_lo) & fr_eq(C.key_hi, p_key_hi);
+    const bool val_same = fr_eq(C.val_lo, p_val_lo) & fr_eq(C.val_hi, p_val_hi);
+    const bool init_same = fr_eq(C.init_lo, p_init_lo) & fr_eq(C.init_hi, p_init_hi);
+    const bool root_same = fr_eq(C.root_lo, p_root_lo) & fr_eq(C.root_hi, p_root_hi);
+    const Fr p_rwc = ST_PREV_FR(rwc);
+    const u32 p_flags = ST_PREV_U32(flags);
     // 0.5 read consistency (:577-581)
-    ST_ASSERT(!(is_read && keys_eq_prev) || state_pair_eq(w, ST_VAL_LO, i, ip), 11);
-    ST_ASSERT(!keys_eq_prev || state_pair_eq(w, ST_INIT_LO, i, ip), 12);
+    ST_ASSERT(!(is_read && keys_eq_prev) || val_same, 11);
+    ST_ASSERT(!keys_eq_prev || init_same, 12);
     // 8. rw_counter != 0 except Start (:584-585)
     ST_ASSERT(tagv == 1 || !fr_is_zero(rwc), 13);
 
-    const Fr val_lo = zk_col(w, ST_VAL_LO, i), val_hi = zk_col(w, ST_VAL_HI, i);
-    const Fr init_lo = zk_col(w, ST_INIT_LO, i), init_hi = zk_col(w, ST_INIT_HI, i);
-    const bool key_zero = state_pair_zero(w, ST_KEY_LO, i);
-    const bool root_same = state_pair_eq(w, ST_ROOT_LO, i, ip);
+    const Fr& val_lo = C.val_lo; const Fr& val_hi = C.val_hi; const Fr& init_lo = C.init_lo; const Fr& init_hi = C.init_hi;
+    const bool key_zero = fr_is_zero(C.key_lo) && fr_is_zero(C.key_hi);
     const bool val_zero = fr_is_zero(val_lo) && fr_is_zero(val_hi);
     const bool init_zero = fr_is_zero(init_lo) && fr_is_zero(init_hi);
+    const bool is_write_one = C.is_write01 == 1u;
 
     switch (tagv) {
     case 1:  // Start (:216-236)
@@ -209,7 +286,7 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
         ST_ASSERT(fr_is_zero(init_hi), 25);
         {
             Fr lex = zk_col(w, ST_LEX, i);
-            Fr d = fr_sub_u64(fr_sub(rwc, zk_col(w, ST_RWC, ip)), 1);
+            Fr d = fr_sub_u64(fr_sub(rwc, p_rwc), 1);
             ST_ASSERT(fr_is_zero(lex) || fr_is_zero(d), 26);  // p prime: product zero iff a factor is
             ST_ASSERT(!val_is_word, 27);
             ST_ASSERT(fr_is_zero(val_lo), 28);
@@ -237,10 +314,10 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
     case 3:  // Stack (:270-301)
         ST_ASSERT(fr_is_zero(ftag), 60);
         ST_ASSERT(key_zero, 61);
-        if (!keys_eq_prev) ST_ASSERT(fr_eq_u64(is_write, 1), 62);
+        if (!keys_eq_prev) ST_ASSERT(is_write_one, 62);
         ST_ASSERT(fr_le_u64(addr, 1023), 63);
-        if (fr_eq(tag, zk_col(w, ST_TAG, ip)) && fr_eq(id, zk_col(w, ST_ID, ip))) {
-            Fr d = fr_sub(addr, zk_col(w, ST_ADDR, ip));
+        if (fr_eq(tag, p_tag) && fr_eq(id, p_id)) {
+            Fr d = fr_sub(addr, p_addr);
             ST_ASSERT(fr_le_u64(d, 1), 64);
         }
         ST_ASSERT(init_zero, 65);
@@ -268,10 +345,10 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
             Fr q[MPT_NCELLS];
             q[0] = addr;
             q[1] = fr_from_u64(proof_type);
-            q[2] = zk_col(w, ST_KEY_LO, i);
-            q[3] = zk_col(w, ST_KEY_HI, i);
-            q[4] = zk_col(w, ST_ROOT_LO, i);
-            q[5] = zk_col(w, ST_ROOT_HI, i);
+            q[2] = C.key_lo;
+            q[3] = C.key_hi;
+            q[4] = C.root_lo;
+            q[5] = C.root_hi;
             q[6] = zk_col(w, ST_ROOT_LO, ip);
             q[7] = zk_col(w, ST_ROOT_HI, ip);
             q[8] = val_lo;
@@ -329,7 +406,7 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
             ST_ASSERT(fr_is_zero(val_hi), 130);
             ST_ASSERT(fr_is_zero(init_hi), 131);
         }
-        ST_ASSERT(fr_eq_u64(is_write, 1), 132);
+        ST_ASSERT(is_write_one, 132);
         ST_ASSERT(root_same, 133);
         break;
     case 11: {  // TxReceipt (:460-488)
@@ -341,15 +418,13 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
             ST_ASSERT(!val_is_word, 144);
             ST_ASSERT(fr_le_u64(val_lo, 1), 145);
         }
-        const Fr pid = zk_col(w, ST_ID, ip);
-        const bool same_tag = fr_eq(tag, zk_col(w, ST_TAG, ip));
-        if (!fr_eq(id, pid) && same_tag) {
-            ST_ASSERT(fr_eq(id, fr_add_u64(pid, 1)), 146);
+        const bool same_tag = fr_eq(tag, p_tag);
+        if (!fr_eq(id, p_id) && same_tag) {
+            ST_ASSERT(fr_eq(id, fr_add_u64(p_id, 1)), 146);
             if (fr_eq_u64(ftag, 2)) {  // CumulativeGasUsed
                 ST_ASSERT(!val_is_word, 147);
-                const u32 pfl = w.flags ? w.flags[ip] : 0u;
-                ST_ASSERT(!(pfl & 1u), 148);
-                ST_ASSERT(fr_lt(zk_col(w, ST_VAL_LO, ip), val_lo), 149);
+                ST_ASSERT(!(p_flags & 1u), 148);
+                ST_ASSERT(fr_lt(p_val_lo, val_lo), 149);
             }
         }
         if (!same_tag) ST_ASSERT(fr_eq_u64(id, 1), 150);
@@ -362,3 +437,15 @@ ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
     }
     return code;
 }
+
+#ifdef ZK_HOSTSIM
+// Evaluate row i against prev = (i-1) mod n and next = (i+1) mod n (host build: both rows loaded).
+ZK_HD u32 state_check_row(const StateArgs& a, u64 i) {
+    const u64 n = a.rows.n;
+    StRow C, P;
+    u32 code = 0, pcode = 0;
+    state_load_row(a.rows, i == 0 ? n - 1 : i - 1, P, pcode);
+    state_load_row(a.rows, i, C, code);
+    return state_check_loaded(a, i, C, P, code);
+}
+#endif
