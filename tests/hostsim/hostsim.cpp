@@ -110,10 +110,12 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     // bit 2 of opts: generic open-addressing indices only (no dense RW index / code directory)
     ZkRwMeta meta = rw_dense_meta_host(rw, n_rw);
     HostCodeDir dir;
-    a.rw_meta = nullptr;
+    a.rw_dense = 0;
+    a.rw_base = 0;
     a.codes.n = 0;
     if (!(opts & 4u)) {
-        a.rw_meta = &meta;
+        a.rw_dense = meta.dense;
+        a.rw_base = meta.base;
         build_code_dir(bytecode, n_bc, dir);
         a.codes.entries = dir.entries.data();
         a.codes.slots = dir.slots.data();

@@ -40,7 +40,8 @@ struct EvmArgs {
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
-    const ZkRwMeta* rw_meta;  // nullptr = generic index only
+    u32 rw_dense;     // 1: the RW rows are sorted with consecutive rw_counters (row = rw_counter - rw_base); 0: generic index
+    u64 rw_base;
     ZkCodeDir codes;          // n == 0 = generic index only
     unsigned long long* prof;  // optional phase timestamps (tuning aid): [block][8]
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
@@ -264,13 +265,13 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
         Q.q[R_RWC] = fr_add_u64(I.rwc, I.rw_off);
         I.rw_off++;
     }
-    const ZkRwMeta* m = I.a->rw_meta;
-    if (m && m->dense) {
+    if (I.a->rw_dense) {
+        const u64 rw_base = I.a->rw_base;
         // direct index: the only row with this rw_counter is row (rw_counter - base)
         I.seq++;
         const Fr& rwc = Q.q[R_RWC];
-        const u64 off = fr_lo64(rwc) - m->base;
-        bool ok = fr_fits64(rwc) && fr_lo64(rwc) >= m->base && off < (u64)I.a->rw.n;
+        const u64 off = fr_lo64(rwc) - rw_base;
+        bool ok = fr_fits64(rwc) && fr_lo64(rwc) >= rw_base && off < (u64)I.a->rw.n;
         const u32 r = ok ? (u32)off : 0u;  // row 0 always exists (tables keep one zero row when empty)
         // branch-free compare: the row loads do not depend on earlier lookups' outcomes, so the
         // loads of consecutive lookups (MLOAD: 32 rows, PUSH32: 33 rows) overlap in flight
@@ -713,12 +714,17 @@ ZK_HD void set_tail3(Tail& T, const Fr& opcode, int rwc, int pc, int sp) {
 ZK_HD Trans t_int(int d) { return d == 0 ? t_same() : t_delta_i(d); }
 ZK_HD void same_context(Ins& I, const Tail& T) {
     const Fr& opcode = T.opcode;
-    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero());
-    static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
-    static const uint16_t cgas[256] = ZK_OPCODE_CONST_GAS_INIT;
-    const bool op_ok = fr_le_u64(opcode, 255) && valid[opcode.v[0] & 0xff];
+    // responsible-opcode membership (success states: (state, opcode, 0) rows, table.py:71-79), opcode
+    // validity and the constant gas come from ONE packed table word
+    static const uint32_t opinfo[256] = ZK_OPINFO_INIT;
+    const bool op_byte = fr_le_u64(opcode, 255);
+    const u32 info = opinfo[opcode.v[0] & 0xff];
+    const u32 st = ev_curr(I, S_STATE).v[0];
+    I.seq++;
+    if (!(op_byte && st != 0u && (info & 0xffu) == st && fr_fits32(ev_curr(I, S_STATE)))) ev_fail(I, ZK_LOOKUP_UNSAT);
+    const bool op_ok = op_byte && ((info >> 8) & 1u);
     ev_require(I, op_ok, ZK_VALUE_ERROR);  // Opcode(opcode.n)
-    Fr gas_cost = fr_add(fr_u(op_ok ? cgas[opcode.v[0] & 0xff] : 0), T.dyn_gas);
+    Fr gas_cost = fr_add(fr_u(op_ok ? (info >> 16) : 0), T.dyn_gas);
     range_check(I, fr_sub(ev_curr(I, S_GAS), gas_cost), 8);
     Trans pc, mws;
     pc.kind = T.pc_kind; pc.value = T.pc_val;
@@ -2177,12 +2183,14 @@ ZK_HD void g_end_block(Ins& I, Tail& T, bool is_last) {  // end_block.py: paddin
 }
 
 // ExecutionState transition constraint (instruction.py:189-204)
+ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
+    return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
+}
 ZK_HD bool state_transition_ok(u32 curr, u32 next) {
-    static const uint8_t halts[] = ZK_STATE_HALTS_INIT;
     if (curr == ES_EndTx && !(next == ES_BeginTx || next == ES_EndBlock)) return false;
     if (curr == ES_EndBlock && next != ES_EndBlock) return false;
     if (next == ES_BeginTx) return curr == ES_EndTx;
-    if (next == ES_EndTx) return (curr < ES_COUNT && halts[curr]) || curr == ES_BeginTx;
+    if (next == ES_EndTx) return (curr < ES_COUNT && state_bit(ZK_STATE_HALTS_MASK_LO, ZK_STATE_HALTS_MASK_HI, curr)) || curr == ES_BeginTx;
     if (next == ES_EndBlock) return curr == ES_EndTx || curr == ES_EndBlock;
     return true;
 }
@@ -2272,17 +2280,17 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
     const Fr statef = ev_curr(I, S_STATE);
     const u32 state = statef.v[0];
+    const u32 next_state = ev_next(I, S_STATE).v[0];  // loaded with the first batch (used unless is_last)
     if ((G == EVM_GROUP_COLD) != (evm_state_group(state) == EVM_GROUP_COLD)) return ZK_NOT_MINE;
     if (is_first) {
         ev_require(I, state == ES_BeginTx || state == ES_EndBlock);
         constrain_equal(I, ev_curr(I, S_RWC), fr_u(1));
     }
     if (is_last) ev_require(I, state == ES_EndBlock);
-    else ev_require(I, state_transition_ok(state, ev_next(I, S_STATE).v[0]));
+    else ev_require(I, state_transition_ok(state, next_state));
     if (I.err) return I.err;
     I.seq++;
-    static const uint8_t ref_impl[] = ZK_STATE_REF_IMPLEMENTED_INIT;
-    if (state >= ES_COUNT || !ref_impl[state]) {
+    if (state >= ES_COUNT || !state_bit(ZK_STATE_REF_IMPL_MASK_LO, ZK_STATE_REF_IMPL_MASK_HI, state)) {
         ev_fail(I, ZK_NOT_IMPLEMENTED);
         return I.err;
     }
@@ -2290,6 +2298,9 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     Tail T;
     T.enabled = false;
     T.err_tail = 0;
+#ifdef ZK_ONLY_STATE
+    if (state != ZK_ONLY_STATE) return 0;  // ISA-inspection builds: keep a single gadget
+#endif
     switch (state) {
     case ES_ADD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADD) { g_add_sub(I, T); } break;
     case ES_MUL: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MUL) { g_mul_div_mod(I, T); } break;

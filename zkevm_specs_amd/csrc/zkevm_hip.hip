@@ -469,7 +469,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = build_index<copy_key_hash>(s, s->evm.copy))) goto fail;
     if ((rc = build_index<keccak_key_hash>(s, s->evm.keccak))) goto fail;
     if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;
-    s->evm.rw_meta = nullptr;
+    s->evm.rw_dense = 0;
+    s->evm.rw_base = 0;
     s->evm.codes.n = 0;
     if (!(opts & ZK_OPT_GENERIC_INDEX)) {
         // dense RW index: verified on the device (the table can be hundreds of MB)
@@ -482,7 +483,13 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         if (hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, g_stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
         if (t->n_rw)
             hipLaunchKernelGGL(rw_dense_check_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, g_stream, s->evm.rw, d_meta);
-        s->evm.rw_meta = d_meta;
+        {   // the verdict travels as kernel arguments: no per-lookup metadata loads
+            ZkRwMeta h_meta;
+            if (hipMemcpyAsync(&h_meta, d_meta, sizeof h_meta, hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
+                hipStreamSynchronize(g_stream) != hipSuccess) { rc = -2; g_err = "meta download failed"; goto fail; }
+            s->evm.rw_dense = h_meta.dense;
+            s->evm.rw_base = h_meta.base;
+        }
         // bytecode directory: built on the host (the table is small), then uploaded
         if (t->n_bytecode) {
             std::vector<u64> host_rows;

@@ -191,6 +191,16 @@ def gen_header():
     for s in ExecutionState:
         hl[int(s)] = 1 if halts(s) else 0
     arr("ZK_STATE_HALTS", "uint8_t", hl)
+    # the same tables as immediates / one packed word per opcode: no dependent table loads on the hot path
+    def mask64(bits, lo):
+        return sum(1 << (k - lo) for k in range(lo, lo + 64) if k < len(bits) and bits[k])
+    out.append(f"#define ZK_STATE_REF_IMPL_MASK_LO 0x{mask64(impl, 0):016x}ull")
+    out.append(f"#define ZK_STATE_REF_IMPL_MASK_HI 0x{mask64(impl, 64):016x}ull")
+    out.append(f"#define ZK_STATE_HALTS_MASK_LO 0x{mask64(hl, 0):016x}ull")
+    out.append(f"#define ZK_STATE_HALTS_MASK_HI 0x{mask64(hl, 64):016x}ull")
+    assert len(impl) <= 128
+    # opinfo[opcode] = responsible state | valid << 8 | constant gas << 16
+    arr("ZK_OPINFO", "uint32_t", [resp[v] | (valid[v] << 8) | (gas[v] << 16) for v in range(256)])
     for enum, prefix in [(Target, "TG"), (CallContextFieldTag, "CC"), (AccountFieldTag, "ACC"),
                          (TxContextFieldTag, "TXC"), (BlockContextFieldTag, "BLK"), (FixedTableTag, "FX")]:
         out.append(f"enum Zk{enum.__name__} : uint32_t {{")
