@@ -112,10 +112,17 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     HostCodeDir dir;
     a.rw_dense = 0;
     a.rw_base = 0;
+    a.rw_keys = nullptr;
+    std::vector<u64> rw_keys;
     a.codes.n = 0;
     if (!(opts & 4u)) {
         a.rw_dense = meta.dense;
         a.rw_base = meta.base;
+        if (meta.dense) {  // packed key records, as rw_pack_kernel builds them on the device
+            rw_keys.resize((size_t)n_rw * 4);
+            for (u64 r = 0; r < n_rw; r++) { RwKey k = rw_pack_row(a.rw, (u32)r); for (int j = 0; j < 4; j++) rw_keys[4 * r + j] = k.w[j]; }
+            a.rw_keys = rw_keys.data();
+        }
         build_code_dir(bytecode, n_bc, dir);
         a.codes.entries = dir.entries.data();
         a.codes.slots = dir.slots.data();

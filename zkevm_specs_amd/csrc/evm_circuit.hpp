@@ -42,6 +42,7 @@ struct EvmArgs {
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
     u32 rw_dense;     // 1: the RW rows are sorted with consecutive rw_counters (row = rw_counter - rw_base); 0: generic index
     u64 rw_base;
+    const u64* rw_keys;  // optional [n_rw][4]: packed (rw, tag, field_tag, id, address) of every row, see rw_pack_row
     ZkCodeDir codes;          // n == 0 = generic index only
     unsigned long long* prof;  // optional phase timestamps (tuning aid): [block][8]
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
@@ -257,6 +258,36 @@ ZK_HD void rwq_set_word(RwQ& Q, int c, const Word& w) {
     rwq_set(Q, c, w.lo);
     rwq_set(Q, c + 1, w.hi);
 }
+// Packed key record of an RW row: the five cells nearly every lookup compares (rw, tag, id, address,
+// field_tag: 160 B on the wire) in 32 B, so a lookup reads 2 x 16 B instead of 10 x 16 B.
+//   w0: bit 63 = "fits" | bits 0-7 rw | 8-15 tag | 16-23 field_tag | 24-55 address[128..160)
+//   w1: id | w2: address[0..64) | w3: address[64..128)
+// A row whose cells exceed those widths (only malformed witnesses) has fits = 0 and is compared cell
+// by cell.  Built once per session for the dense index (rw_pack_kernel), like the other indices.
+struct RwKey {
+    u64 w[4];
+};
+ZK_HD bool rw_key_fields_fit(const Fr& rw, const Fr& tag, const Fr& id, const Fr& addr, const Fr& ft) {
+    return fr_le_u64(rw, 255) && fr_le_u64(tag, 255) && fr_le_u64(ft, 255) && fr_fits64(id) && (addr.v[5] | addr.v[6] | addr.v[7]) == 0u;
+}
+ZK_HD RwKey rw_pack_fields(const Fr& rw, const Fr& tag, const Fr& id, const Fr& addr, const Fr& ft) {
+    RwKey k;
+    k.w[0] = (1ull << 63) | (u64)(rw.v[0] & 0xffu) | ((u64)(tag.v[0] & 0xffu) << 8) | ((u64)(ft.v[0] & 0xffu) << 16) | ((u64)addr.v[4] << 24);
+    k.w[1] = fr_lo64(id);
+    k.w[2] = fr_lo64(addr);
+    k.w[3] = fr_hi64of128(addr);
+    return k;
+}
+ZK_HD RwKey rw_pack_row(const ZkTable& t, u32 r) {
+    const Fr rw = zk_table_cell(t, r, R_RW), tag = zk_table_cell(t, r, R_TAG), id = zk_table_cell(t, r, R_ID);
+    const Fr addr = zk_table_cell(t, r, R_ADDR), ft = zk_table_cell(t, r, R_FT);
+    if (!rw_key_fields_fit(rw, tag, id, addr, ft)) {
+        RwKey k;
+        k.w[0] = k.w[1] = k.w[2] = k.w[3] = 0;
+        return k;
+    }
+    return rw_pack_fields(rw, tag, id, addr, ft);
+}
 // Instruction.rw_lookup (instruction.py:792-824); rw_counter = curr.rw_counter + offset unless given
 ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
     if (rw_counter) {
@@ -275,7 +306,33 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
         const u32 r = ok ? (u32)off : 0u;  // row 0 always exists (tables keep one zero row when empty)
         // branch-free compare: the row loads do not depend on earlier lookups' outcomes, so the
         // loads of consecutive lookups (MLOAD: 32 rows, PUSH32: 33 rows) overlap in flight
-        for (int c = 1; c < RW_NCELLS; c++)
+        bool key_cells = true;  // compare cells 1..5 one by one (no packed record, or the row does not fit it)
+        if (I.a->rw_keys) {
+            const uint4* kp = reinterpret_cast<const uint4*>(I.a->rw_keys + (u64)r * 4);
+            const uint4 k01 = kp[0], k23 = kp[1];
+            const u64 w0 = (u64)k01.x | ((u64)k01.y << 32), w1 = (u64)k01.z | ((u64)k01.w << 32);
+            const u64 w2 = (u64)k23.x | ((u64)k23.y << 32), w3 = (u64)k23.z | ((u64)k23.w << 32);
+            if (w0 >> 63) {  // the row's key cells fit the packed widths: a queried cell matches iff it fits and is equal
+                const u32 m = Q.mask;
+                if ((m >> R_RW) & 1u) ok = ok & (fr_le_u64(Q.q[R_RW], 255) & ((u32)(w0 & 0xffu) == Q.q[R_RW].v[0]));
+                if ((m >> R_TAG) & 1u) ok = ok & (fr_le_u64(Q.q[R_TAG], 255) & ((u32)((w0 >> 8) & 0xffu) == Q.q[R_TAG].v[0]));
+                if ((m >> R_FT) & 1u) ok = ok & (fr_le_u64(Q.q[R_FT], 255) & ((u32)((w0 >> 16) & 0xffu) == Q.q[R_FT].v[0]));
+                if ((m >> R_ID) & 1u) ok = ok & (fr_fits64(Q.q[R_ID]) & (w1 == fr_lo64(Q.q[R_ID])));
+                if ((m >> R_ADDR) & 1u) {
+                    const Fr& qa = Q.q[R_ADDR];
+                    ok = ok & (((qa.v[5] | qa.v[6] | qa.v[7]) == 0u) & (w2 == fr_lo64(qa)) & (w3 == fr_hi64of128(qa)) &
+                               ((u32)((w0 >> 24) & 0xffffffffull) == qa.v[4]));
+                }
+                key_cells = false;
+            }
+        }
+        if (key_cells) {
+#pragma unroll
+            for (int c = 1; c <= R_FT; c++)
+                if ((Q.mask >> c) & 1u) ok = ok & fr_eq(zk_table_cell(I.a->rw, r, c), Q.q[c]);
+        }
+#pragma unroll
+        for (int c = R_FT + 1; c < RW_NCELLS; c++)
             if ((Q.mask >> c) & 1u) ok = ok & fr_eq(zk_table_cell(I.a->rw, r, c), Q.q[c]);
         if (!ok) ev_fail(I, ZK_LOOKUP_UNSAT);
         return r;

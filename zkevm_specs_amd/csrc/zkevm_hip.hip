@@ -180,6 +180,16 @@ __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
     if (!ok) atomicAnd(&meta->dense, 0u);
 }
 
+// Packed key records of the RW rows (RwKey, evm_circuit.hpp): one lane per row, 32 B out per row.
+__global__ void rw_pack_kernel(ZkTable t, u64* keys) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.n) return;
+    const RwKey k = rw_pack_row(t, r);
+    uint4* out = reinterpret_cast<uint4*>(keys + (u64)r * 4);
+    out[0] = make_uint4((u32)k.w[0], (u32)(k.w[0] >> 32), (u32)k.w[1], (u32)(k.w[1] >> 32));
+    out[1] = make_uint4((u32)k.w[2], (u32)(k.w[2] >> 32), (u32)k.w[3], (u32)(k.w[3] >> 32));
+}
+
 // Counting sort of the step pairs by (group, state): histogram, scan, scatter.
 __global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, ZkTally* tally) {
     __shared__ u32 local[EVM_N_BINS];
@@ -471,6 +481,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;
     s->evm.rw_dense = 0;
     s->evm.rw_base = 0;
+    s->evm.rw_keys = nullptr;
     s->evm.codes.n = 0;
     if (!(opts & ZK_OPT_GENERIC_INDEX)) {
         // dense RW index: verified on the device (the table can be hundreds of MB)
@@ -489,6 +500,12 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
                 hipStreamSynchronize(g_stream) != hipSuccess) { rc = -2; g_err = "meta download failed"; goto fail; }
             s->evm.rw_dense = h_meta.dense;
             s->evm.rw_base = h_meta.base;
+        }
+        if (s->evm.rw_dense && t->n_rw) {
+            u64* d_keys = nullptr;
+            if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
+            hipLaunchKernelGGL(rw_pack_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, g_stream, s->evm.rw, d_keys);
+            s->evm.rw_keys = d_keys;
         }
         // bytecode directory: built on the host (the table is small), then uploaded
         if (t->n_bytecode) {
