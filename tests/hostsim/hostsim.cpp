@@ -115,6 +115,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     a.rw_keys = nullptr;
     std::vector<u64> rw_keys;
     a.codes.n = 0;
+    a.codes.packed = nullptr;
     if (!(opts & 4u)) {
         a.rw_dense = meta.dense;
         a.rw_base = meta.base;
@@ -128,6 +129,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
         a.codes.slots = dir.slots.data();
         a.codes.mask = dir.mask;
         a.codes.n = (u32)dir.entries.size();
+        a.codes.packed = dir.packed.data();
     }
     for (u64 i = 0; i + 1 < n_steps; i++) {  // as on the device: the hot and the cold instantiation split the states
         u32 c = evm_check_step<EVM_GROUP_ALL>(a, i);

@@ -87,12 +87,19 @@ struct ZkCodeEntry {
     u32 byte_base;
     u32 n_bytes;
     u32 regular;
+    u64 header_value;  // the Header row's value cell (code length) when header_ok
+    u32 header_ok;     // 1: that cell fits 64 bits and the row's is_code cell is 0
+    u32 pad;
 };
 struct ZkCodeDir {
     const ZkCodeEntry* entries;
     const u32* slots;  // open addressing over entries, keyed on the hash cells
     u32 mask;
     u32 n;
+    // one u16 per bytecode-table row: bit 15 = "fits" (value < 256, is_code < 2), bit 8 = is_code,
+    // bits 0-7 = value; 0 = compare the row's cells instead.  A lookup of a regular code reads 2 B
+    // instead of two 32-byte cells; nullptr when no directory was built.
+    const uint16_t* packed;
 };
 // keccak table (KeccakTableRow, table.py:511-515: state_tag, input_rlc, input_len, output lo/hi), keyed on (rlc, len)
 enum { KECCAK_NCELLS = 5 };

@@ -70,7 +70,8 @@ struct Ins {
     // bytecode-directory entry of curr.code_hash, probed once per step (every opcode/push-data
     // lookup of the step goes to the same code): state 0 = not probed, 1 = regular entry cached,
     // 2 = hash absent from the table, 3 = use the generic index
-    u32 code_state, code_header_row, code_byte_base, code_n_bytes;
+    u32 code_state, code_header_row, code_byte_base, code_n_bytes, code_header_ok;
+    u64 code_header_value;
 };
 
 #if defined(ZK_HOSTSIM)
@@ -354,6 +355,32 @@ ZK_HD WordOrValue rw_value_prev(const Ins& I, u32 row) {
     return v;
 }
 
+// Directory entry of a code hash, resolved once per step: I.code_state = 1 regular code (rows
+// addressable directly), 2 no row carries the hash, 3 irregular -> generic index.
+ZK_HD void code_dir_resolve(Ins& I, const Word& code_hash) {
+    if (I.code_state != 0) return;
+    const ZkCodeDir& dir = I.a->codes;
+    I.code_state = 3;
+    if (dir.n != 0) {
+        u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
+        I.code_state = 2;
+        for (u32 probes = 0; probes <= dir.mask; probes++) {
+            const u32 k = dir.slots[slot];
+            if (k == ZK_EMPTY_SLOT) break;
+            const ZkCodeEntry* c = dir.entries + k;
+            if (fr_eq(fr_load(c->hash), code_hash.lo) && fr_eq(fr_load(c->hash + 4), code_hash.hi)) {
+                I.code_state = c->regular ? 1 : 3;
+                I.code_header_row = c->header_row;
+                I.code_byte_base = c->byte_base;
+                I.code_n_bytes = c->n_bytes;
+                I.code_header_value = c->header_value;
+                I.code_header_ok = c->header_ok;
+                break;
+            }
+            slot = (slot + 1) & dir.mask;
+        }
+    }
+}
 // Tables.bytecode_lookup (table.py:718-731); is_code < 0 = not part of the query
 ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& index, int is_code, bool foreign = false) {
     Fr q[BYTECODE_NCELLS];
@@ -367,27 +394,7 @@ ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& inde
     // a hash other than curr.code_hash (EXTCODESIZE, ...) goes through the generic index
     if (foreign) return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
     // all other bytecode lookups of a step query curr.code_hash: probe the directory once per step
-    if (I.code_state == 0) {
-        const ZkCodeDir& dir = I.a->codes;
-        I.code_state = 3;
-        if (dir.n != 0) {
-            u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
-            I.code_state = 2;
-            for (u32 probes = 0; probes <= dir.mask; probes++) {
-                const u32 k = dir.slots[slot];
-                if (k == ZK_EMPTY_SLOT) break;
-                const ZkCodeEntry* c = dir.entries + k;
-                if (fr_eq(fr_load(c->hash), code_hash.lo) && fr_eq(fr_load(c->hash + 4), code_hash.hi)) {
-                    I.code_state = c->regular ? 1 : 3;
-                    I.code_header_row = c->header_row;
-                    I.code_byte_base = c->byte_base;
-                    I.code_n_bytes = c->n_bytes;
-                    break;
-                }
-                slot = (slot + 1) & dir.mask;
-            }
-        }
-    }
+    code_dir_resolve(I, code_hash);
     if (I.code_state == 2) {  // no row carries this hash
         I.seq++;
         ev_fail(I, ZK_LOOKUP_UNSAT);
@@ -406,9 +413,32 @@ ZK_HD u32 bytecode_lookup(Ins& I, const Word& code_hash, u32 tag, const Fr& inde
     return table_lookup<BYTECODE_NCELLS>(I, I.a->bytecode, bc_key_hash_cells(q[0], q[1], q[2], q[3]), q, mask);
 }
 ZK_HD Word curr_code_hash(const Ins& I) { return word_of(ev_curr(I, S_CH_LO), ev_curr(I, S_CH_HI)); }
-ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instruction.py:789-790
-    u32 r = bytecode_lookup(I, curr_code_hash(I), 2, index, is_code ? 1 : 0);
+// bytecode_lookup(...).value for curr.code_hash.  Regular codes (directory hit) are served from the
+// packed per-row record / the directory entry: 2 bytes instead of two 32-byte cells per lookup.
+ZK_HD Fr bytecode_value(Ins& I, u32 tag, const Fr& index, int is_code) {
+    code_dir_resolve(I, curr_code_hash(I));
+    if (I.code_state == 1) {
+        const uint16_t* packed = I.a->codes.packed;
+        if (tag == 1) {
+            if (I.code_header_ok && is_code == 0) {
+                I.seq++;
+                if (!fr_is_zero(index)) ev_fail(I, ZK_LOOKUP_UNSAT);
+                return fr_u(I.code_header_value);
+            }
+        } else if (packed && tag == 2 && fr_fits64(index) && fr_lo64(index) < (u64)I.code_n_bytes) {
+            const u32 p = packed[I.code_byte_base + (u32)fr_lo64(index)];
+            if (p >> 15) {
+                I.seq++;
+                if (is_code >= 0 && ((p >> 8) & 1u) != (u32)(is_code > 0 ? 1 : 0)) ev_fail(I, ZK_LOOKUP_UNSAT);
+                return fr_u(p & 0xffu);
+            }
+        }
+    }
+    u32 r = bytecode_lookup(I, curr_code_hash(I), tag, index, is_code);
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
+}
+ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instruction.py:789-790
+    return bytecode_value(I, 2, index, is_code ? 1 : 0);
 }
 ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
     Fr index = fr_add_u64(I.pc, I.pc_off);
@@ -416,6 +446,7 @@ ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
     return opcode_lookup_at(I, index, is_code);
 }
 ZK_HD Fr bytecode_length(Ins& I, const Word& code_hash, bool foreign = false) {  // instruction.py:771-774
+    if (!foreign) return bytecode_value(I, 1, fr_zero(), 0);  // every non-foreign caller passes curr.code_hash
     u32 r = bytecode_lookup(I, code_hash, 1, fr_zero(), 0, foreign);
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
 }

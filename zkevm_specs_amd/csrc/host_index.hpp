@@ -9,6 +9,7 @@
 #include "common.hpp"
 
 struct HostCodeDir {
+    std::vector<uint16_t> packed;  // per bytecode-table row, see ZkCodeDir::packed
     std::vector<ZkCodeEntry> entries;
     std::vector<u32> slots;
     u32 mask = 0;
@@ -47,11 +48,20 @@ static inline void build_code_dir(const u64* rows, u64 n, HostCodeDir& out) {
         v = p[0];
         return (p[1] | p[2] | p[3]) == 0;
     };
+    out.packed.assign(n, 0);
+    for (u64 r = 0; r < n; r++) {
+        u64 is_code, value;
+        if (small(r, 4, is_code) && small(r, 5, value) && is_code < 2 && value < 256)
+            out.packed[r] = (uint16_t)(0x8000u | (is_code << 8) | value);
+    }
     for (auto& kv : groups) {
         ZkCodeEntry e;
         memcpy(e.hash, kv.first.data(), 64);
         e.header_row = e.byte_base = e.n_bytes = 0;
         e.regular = 0;
+        e.header_value = 0;
+        e.header_ok = 0;
+        e.pad = 0;
         const std::vector<u32>& ix = kv.second.idx;
         int headers = 0;
         bool ok = true;
@@ -73,6 +83,8 @@ static inline void build_code_dir(const u64* rows, u64 n, HostCodeDir& out) {
             }
         }
         if (ok && headers == 1) {
+            u64 hv, hc;
+            if (small(e.header_row, 5, hv) && small(e.header_row, 4, hc) && hc == 0) { e.header_value = hv; e.header_ok = 1; }
             e.regular = 1;
             e.byte_base = first_byte == 0xffffffffu ? 0 : first_byte;
             e.n_bytes = n_bytes;

@@ -483,6 +483,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     s->evm.rw_base = 0;
     s->evm.rw_keys = nullptr;
     s->evm.codes.n = 0;
+    s->evm.codes.packed = nullptr;
     if (!(opts & ZK_OPT_GENERIC_INDEX)) {
         // dense RW index: verified on the device (the table can be hundreds of MB)
         ZkRwMeta* d_meta = nullptr;
@@ -528,6 +529,12 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             s->evm.codes.slots = d_slots;
             s->evm.codes.mask = dir.mask;
             s->evm.codes.n = (u32)dir.entries.size();
+            {
+                uint16_t* d_packed = nullptr;
+                if ((rc = dev_alloc(s, (void**)&d_packed, dir.packed.size() * sizeof(uint16_t)))) goto fail;
+                if (hipMemcpy(d_packed, dir.packed.data(), dir.packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; g_err = "directory upload failed"; goto fail; }
+                s->evm.codes.packed = d_packed;
+            }
         }
     }
     s->evm.n_pairs = (u32)(t->n_steps - 1);
