@@ -1667,6 +1667,79 @@ def g_end_block(i):  # end_block.py: padding steps (the is_last_step branch need
     i.transition(S_CALL_ID, "same")
 
 
+TXC, BLK = T.TxContextFieldTag, T.BlockContextFieldTag
+
+
+def _mul_word_by_u64(i, w, m):  # instruction.py:587-597 (products are taken in the field, then split)
+    q_lo, p_lo = divmod(w[0] * m % P, 1 << 128)
+    q_hi, p_hi = divmod((w[1] * m + q_lo) % P, 1 << 128)
+    i.constrain_zero(q_hi)
+    return i.word_checked(p_lo, p_hi)
+
+
+def _sub_word(i, a, b):  # instruction.py:576-585
+    borrow_lo = int(a[0] % P < b[0] % P)
+    diff_lo = (a[0] - b[0] + ((1 << 128) if borrow_lo else 0)) % P
+    borrow_hi = int(a[1] % P < b[1] % P + borrow_lo)
+    diff_hi = (a[1] - b[1] - borrow_lo + ((1 << 128) if borrow_hi else 0)) % P
+    return i.word_checked(diff_lo, diff_hi), borrow_hi
+
+
+def _add_balance(i, address, value):  # instruction.py:987-999 (one addend, no reversion)
+    rowf = i.rw_lookup(1, TG.Account, address=address, field_tag=int(ACC.Balance))
+    balance, balance_prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+    result, carry = i.add_words([balance_prev, value])
+    i.constrain_equal_word(balance, result)
+    i.constrain_zero(carry)
+
+
+def _tx_receipt(i, rw, tx_id, field_tag):  # instruction.py:723-754
+    zero = i.word_from_int(0)
+    return i.value_of(i.row_value(i.rw_lookup(rw, TG.TxReceipt, tx_id, 0, field_tag, zero)))
+
+
+def g_end_tx(i):  # end_tx.py
+    tx_id = i.call_context_lookup(CC.TxId)
+    is_persistent = i.call_context_lookup(CC.IsPersistent)
+    is_tx_invalid = i.value_of(i.tx_lookup(tx_id, int(TXC.TxInvalid)))
+    tx_gas = i.value_of(i.tx_lookup(tx_id, int(TXC.Gas)))
+    gas_used = (tx_gas - i.curr[S_GAS]) % P
+    max_refund, _ = i.constant_divmod(gas_used, 5, 8)
+    refund = i.value_of(i.row_value(i.rw_lookup(0, TG.TxRefund, tx_id)))
+    lt, _ = i.compare(max_refund, refund, 8)
+    effective_refund = i.select(lt, max_refund, refund)
+    if is_tx_invalid == 1:
+        i.constrain_zero(effective_refund)
+    gas_price, _ = i.tx_lookup(tx_id, int(TXC.GasPrice))
+    value = _mul_word_by_u64(i, gas_price, (i.curr[S_GAS] + effective_refund) % P)
+    caller_w, _ = i.tx_lookup(tx_id, int(TXC.CallerAddress))
+    caller = i.word_to_fq(caller_w, 20)
+    _add_balance(i, caller, value)
+    base_fee, _ = i.block_lookup(int(BLK.BaseFee))
+    tip, _ = _sub_word(i, gas_price, base_fee)
+    reward = _mul_word_by_u64(i, tip, gas_used)
+    coinbase_w, _ = i.block_lookup(int(BLK.Coinbase))
+    coinbase = i.word_to_fq(coinbase_w, 20)
+    _add_balance(i, coinbase, reward)
+    status = _tx_receipt(i, 1, tx_id, 1)  # PostStateOrStatus
+    i.constrain_equal((1 - is_tx_invalid) * is_persistent, status)
+    log_id = _tx_receipt(i, 1, tx_id, 3)  # LogLength
+    i.constrain_equal(log_id, i.curr[S_LOG])
+    if is_tx_invalid == 1:
+        i.constrain_zero(log_id)
+    is_first_tx = int(tx_id == 1)
+    cum = 0 if is_first_tx else _tx_receipt(i, 0, (tx_id - 1) % P, 2)  # CumulativeGasUsed of the previous tx
+    new_cum = _tx_receipt(i, 1, tx_id, 2)
+    i.constrain_equal(cum + gas_used, new_cum)
+    if i.next[S_STATE] == ES.BeginTx:
+        nxt_tx = i.call_context_lookup(CC.TxId, call_id=i.next[S_RWC])
+        i.constrain_equal(nxt_tx, tx_id + 1)
+        i.transition(S_RWC, "delta", 10 - is_first_tx)
+    if i.next[S_STATE] == ES.EndBlock:
+        i.transition(S_RWC, "delta", 9 - is_first_tx)
+        i.transition(S_CALL_ID, "same")
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1701,7 +1774,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

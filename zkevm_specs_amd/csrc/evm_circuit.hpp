@@ -2270,6 +2270,121 @@ ZK_HD void g_end_block(Ins& I, Tail& T, bool is_last) {  // end_block.py: paddin
     transition(I, S_CALL_ID, t_same());
 }
 
+// ---- EndTx (end_tx.py) ---------------------------------------------------------------------------
+// split a canonical field element at bit 128: value = hi * 2^128 + lo
+ZK_HD void split128(const Fr& x, Fr& lo, Fr& hi) {
+    lo = x; hi = fr_zero();
+    for (int k = 4; k < 8; k++) { hi.v[k - 4] = x.v[k]; lo.v[k] = 0; }
+}
+// mul_word_by_u64 (instruction.py:587-597): the two products are taken in the field, then split
+ZK_HD Word mul_word_by_u64(Ins& I, const Word& w, const Fr& m) {
+    Fr p_lo, q_lo, p_hi, q_hi;
+    split128(fr_mul(w.lo, m), p_lo, q_lo);
+    split128(fr_add(fr_mul(w.hi, m), q_lo), p_hi, q_hi);
+    constrain_zero(I, q_hi);
+    return word_checked(I, p_lo, p_hi);
+}
+// sub_word (instruction.py:576-585)
+ZK_HD Word sub_word(Ins& I, const Word& a, const Word& b) {
+    const u32 borrow_lo = fr_lt(a.lo, b.lo) ? 1u : 0u;
+    Fr two128 = fr_zero(); two128.v[4] = 1u;
+    Fr diff_lo = fr_sub(a.lo, b.lo);
+    if (borrow_lo) diff_lo = fr_add(diff_lo, two128);
+    // minuend_hi.n < subtrahend_hi.n + borrow_lo on the integers (b.hi + 1 cannot wrap: b.hi < p)
+    Fr bh; const u32 carry = u256_add(bh, b.hi, fr_u(borrow_lo));
+    const u32 borrow_hi = (carry || fr_lt(a.hi, bh)) ? 1u : 0u;
+    Fr diff_hi = fr_sub(fr_sub(a.hi, b.hi), fr_u(borrow_lo));
+    if (borrow_hi) diff_hi = fr_add(diff_hi, two128);
+    return word_checked(I, diff_lo, diff_hi);
+}
+// add_balance (instruction.py:987-999) with one addend and no reversion info
+ZK_HD void add_balance(Ins& I, const Fr& address, const Word& value) {
+    RwQ Q;
+    rwq_init(Q, 1, TG_Account);
+    rwq_set(Q, R_ADDR, address);
+    rwq_set(Q, R_FT, fr_u(ACC_Balance));
+    u32 r; r = rw_lookup(I, Q); if (I.err) return;
+    const Word balance = rw_word(I, r, R_VAL_LO), balance_prev = rw_word(I, r, R_PREV_LO);
+    Fr carry; Word sum; sum = add_words2(I, balance_prev, value, carry);
+    constrain_equal_word(I, balance, sum);
+    constrain_zero(I, carry);
+}
+ZK_HD Fr tx_receipt(Ins& I, u32 rw, const Fr& tx_id, u32 field_tag) {  // instruction.py:723-754
+    I.seq++;  // Word(0) storage key
+    RwQ Q;
+    rwq_init(Q, rw, TG_TxReceipt);
+    rwq_set(Q, R_ID, tx_id);
+    rwq_set(Q, R_ADDR, fr_zero());
+    rwq_set(Q, R_FT, fr_u(field_tag));
+    rwq_set_word(Q, R_KEY_LO, word_zero());
+    u32 r; r = rw_lookup(I, Q);
+    return value_of(I, rw_value(I, r));
+}
+ZK_HD void g_end_tx(Ins& I, Tail& T) {
+    Fr tx_id, is_persistent;
+    tx_id = call_context_lookup(I, CC_TxId);
+    is_persistent = call_context_lookup(I, CC_IsPersistent);
+    if (I.err) return;
+    WordOrValue v; v = tx_lookup(I, tx_id, TXC_TxInvalid);
+    Fr is_tx_invalid; EV_TRY(is_tx_invalid = value_of(I, v));
+    v = tx_lookup(I, tx_id, TXC_Gas);
+    Fr tx_gas; EV_TRY(tx_gas = value_of(I, v));
+    const Fr gas_left = ev_curr(I, S_GAS);
+    const Fr gas_used = fr_sub(tx_gas, gas_left);
+    Fr max_refund;
+    {
+        U256 q, r; u256_divmod(gas_used, fr_u(5), q, r);  // constant_divmod(gas_used, 5, N_BYTES_GAS)
+        max_refund = q;
+        range_check(I, max_refund, 8); if (I.err) return;
+    }
+    Fr refund;
+    {
+        RwQ Q;
+        rwq_init(Q, 0, TG_TxRefund);
+        rwq_set(Q, R_ID, tx_id);
+        u32 r; r = rw_lookup(I, Q);
+        EV_TRY(refund = value_of(I, rw_value(I, r)));
+    }
+    u32 lt, eq; EV_TRY(ev_compare(I, max_refund, refund, 8, lt, eq));
+    const Fr effective_refund = ev_select_b(I, lt) ? max_refund : refund;
+    const bool invalid = fr_eq_u64(is_tx_invalid, 1);
+    if (invalid) constrain_zero(I, effective_refund);
+    v = tx_lookup(I, tx_id, TXC_GasPrice); if (I.err) return;
+    const Word gas_price = v.w;
+    Word value; EV_TRY(value = mul_word_by_u64(I, gas_price, fr_add(gas_left, effective_refund)));
+    v = tx_lookup(I, tx_id, TXC_CallerAddress);
+    Fr caller; EV_TRY(caller = word_to_fq(I, v.w, 20));
+    EV_TRY(add_balance(I, caller, value));
+    WordOrValue bf; bf = block_lookup(I, BLK_BaseFee); if (I.err) return;
+    Word tip; EV_TRY(tip = sub_word(I, gas_price, bf.w));
+    Word reward; EV_TRY(reward = mul_word_by_u64(I, tip, gas_used));
+    WordOrValue cb; cb = block_lookup(I, BLK_Coinbase);
+    Fr coinbase; EV_TRY(coinbase = word_to_fq(I, cb.w, 20));
+    EV_TRY(add_balance(I, coinbase, reward));
+    Fr status; EV_TRY(status = tx_receipt(I, 1, tx_id, 1));  // PostStateOrStatus
+    constrain_equal(I, fr_mul(fr_sub(fr_u(1), is_tx_invalid), is_persistent), status);
+    Fr log_id; EV_TRY(log_id = tx_receipt(I, 1, tx_id, 3));  // LogLength
+    constrain_equal(I, log_id, ev_curr(I, S_LOG));
+    if (invalid) constrain_zero(I, log_id);
+    if (I.err) return;
+    const bool is_first_tx = fr_eq_u64(tx_id, 1);
+    Fr cum = fr_zero();
+    if (!is_first_tx) EV_TRY(cum = tx_receipt(I, 0, fr_sub_u64(tx_id, 1), 2));  // CumulativeGasUsed of the previous tx
+    Fr new_cum; EV_TRY(new_cum = tx_receipt(I, 1, tx_id, 2));
+    constrain_equal(I, fr_add(cum, gas_used), new_cum); if (I.err) return;
+    const u32 next_state = ev_next(I, S_STATE).v[0];
+    if (next_state == ES_BeginTx) {
+        const Fr next_rwc = ev_next(I, S_RWC);
+        Fr nxt_tx; nxt_tx = call_context_lookup(I, CC_TxId, 0, &next_rwc);
+        constrain_equal(I, nxt_tx, fr_add_u64(tx_id, 1));
+        transition(I, S_RWC, t_delta_i(10 - (is_first_tx ? 1 : 0)));
+    }
+    if (next_state == ES_EndBlock) {
+        transition(I, S_RWC, t_delta_i(9 - (is_first_tx ? 1 : 0)));
+        transition(I, S_CALL_ID, t_same());
+    }
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -2338,7 +2453,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
-    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock:
+    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx:
         return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
@@ -2428,6 +2543,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_EndTx: if (G == EVM_GROUP_COLD) { g_end_tx(I, T); } break;
     case ES_RETURN: if (G == EVM_GROUP_COLD) { g_return(I, T); } break;
     case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_COLD) { g_error_invalid_creation_code(I, T); } break;
     case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (G == EVM_GROUP_COLD) { g_error_code_store(I, T); } break;
