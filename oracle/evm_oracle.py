@@ -381,10 +381,10 @@ class Ins:
     def call_context_lookup(self, field_tag, rw=0, call_id=None):
         return self.value_of(self.call_context_lookup_word(field_tag, rw, call_id))
 
-    def reversion_info(self):  # instruction.py:901-913 (call_id=None form)
-        end = self.call_context_lookup(CC.RwCounterEndOfReversion)
-        persistent = self.call_context_lookup(CC.IsPersistent)
-        return {"end": end, "persistent": persistent, "rwc": self.curr[S_REV]}
+    def reversion_info(self, call_id=None):  # instruction.py:901-913
+        end = self.call_context_lookup(CC.RwCounterEndOfReversion, call_id=call_id)
+        persistent = self.call_context_lookup(CC.IsPersistent, call_id=call_id)
+        return {"end": end, "persistent": persistent, "rwc": self.curr[S_REV] if call_id is None else 0}
 
     def state_write(self, tag, id=None, address=None, field_tag=None, storage_key=None, value=None,
                     value_prev=None, aux0=None, reversion_info=None):  # instruction.py:826-863
@@ -1740,6 +1740,105 @@ def g_end_tx(i):  # end_tx.py
         i.transition(S_CALL_ID, "same")
 
 
+def _access_list_must_be_cold(i, tx_id, address):  # constrain_zero(add_account_to_access_list(tx_id, address))
+    rowf = i.state_write(TG.TxAccessListAccount, tx_id, address, value=(1, 0))
+    i.constrain_zero(i.value_of(i.row_value_prev(rowf)))
+
+
+def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rlp(..)) in the gadget: not evaluated)
+    call_id = i.curr[S_RWC]
+    tx_id = i.call_context_lookup(CC.TxId, call_id=call_id)
+    rev = i.reversion_info(call_id=call_id)
+    is_success = i.call_context_lookup(CC.IsSuccess, call_id=call_id)
+    i.constrain_equal(is_success, rev["persistent"])
+    if i.is_first:
+        i.constrain_equal(tx_id, 1)
+    coinbase = i.word_to_fq(i.block_lookup(int(BLK.Coinbase))[0], 20)
+    caller_w, _ = i.tx_lookup(tx_id, int(TXC.CallerAddress))
+    caller = i.word_to_fq(caller_w, 20)
+    callee_w, _ = i.tx_lookup(tx_id, int(TXC.CalleeAddress))
+    callee = i.word_to_fq(callee_w, 20)
+    tx_is_create = i.value_of(i.tx_lookup(tx_id, int(TXC.IsCreate)))
+    tx_value, _ = i.tx_lookup(tx_id, int(TXC.Value))
+    cd_length = i.value_of(i.tx_lookup(tx_id, int(TXC.CallDataLength)))
+    i.require(caller % P != 0)
+    is_tx_invalid = i.value_of(i.tx_lookup(tx_id, int(TXC.TxInvalid)))
+    tx_nonce = i.value_of(i.tx_lookup(tx_id, int(TXC.Nonce)))
+    rowf = i.rw_lookup(1, TG.Account, address=caller, field_tag=int(ACC.Nonce))
+    nonce = i.value_of(i.row_value(rowf))
+    nonce_prev = i.value_of(i.row_value_prev(rowf))
+    is_nonce_valid = int((tx_nonce - nonce_prev) % P == 0)
+    i.constrain_equal(nonce, nonce_prev + 1 - is_tx_invalid)
+    tx_gas = i.value_of(i.tx_lookup(tx_id, int(TXC.Gas)))
+    gas_price, _ = i.tx_lookup(tx_id, int(TXC.GasPrice))
+    gas_fee = _mul_word_by_u64(i, gas_price, tx_gas)
+    calldata_gas = i.value_of(i.tx_lookup(tx_id, int(TXC.CallDataGasCost)))
+    cost = 21000
+    if tx_is_create % P == 1:
+        words, _ = i.constant_divmod(cd_length + 31, 32, 8)
+        cost = 53000 + words * 2
+    accesslist_gas = i.value_of(i.tx_lookup(tx_id, int(TXC.AccessListGasCost)))
+    intrinsic = (calldata_gas + cost + accesslist_gas) % P
+    gas_not_enough, _ = i.compare(tx_gas, intrinsic, 31)
+    gas_left = tx_gas if gas_not_enough == 1 else (tx_gas - intrinsic) % P
+    if tx_is_create % P == 1:
+        raise Fail(UNSUPPORTED, i.seq)  # generate_contract_address: keccak(rlp([caller, nonce])) inside the gadget
+    i.cp()  # address_to_word(contract_address): the unused CREATE address always fits 160 bits
+    callee_address = callee
+    _access_list_must_be_cold(i, tx_id, coinbase)
+    _access_list_must_be_cold(i, tx_id, caller)
+    _access_list_must_be_cold(i, tx_id, callee_address)
+    invalid = is_tx_invalid % P == 1
+    value = i.word_from_int(0) if invalid else tx_value
+    fee = i.word_from_int(0) if invalid else gas_fee
+    # transfer_with_gas_fee (instruction.py:1099-1109)
+    rowf = i.state_write(TG.Account, address=caller, field_tag=int(ACC.Balance), reversion_info=rev)
+    balance, sender_prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+    result, carry = i.add_words([balance, value, fee])
+    i.constrain_equal_word(sender_prev, result)
+    i.constrain_zero(carry)
+    rowf = i.state_write(TG.Account, address=callee_address, field_tag=int(ACC.Balance), reversion_info=rev)
+    balance, balance_prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+    result, carry = i.add_words([balance_prev, value])
+    i.constrain_equal_word(balance, result)
+    i.constrain_zero(carry)
+    lhs = i.word_to_fq(sender_prev, 31)
+    rhs = i.word_to_fq(tx_value, 31) + i.word_to_fq(gas_fee, 31)
+    balance_not_enough, _ = i.compare(lhs, rhs, 31)
+    invalid_tx = 1 - (1 - balance_not_enough) * (1 - gas_not_enough) * is_nonce_valid
+    i.constrain_equal(is_tx_invalid, invalid_tx)
+    i.cp()
+    if 1 <= callee % P <= 9:  # `tx_callee_address in list(Precompile)` (precompile.py:8-17)
+        i.fail(NOT_IMPLEMENTED)
+    code_hash = _account_read_word(i, callee, ACC.CodeHash)
+    empty = i.is_equal_word(code_hash, i.word_from_int(EMPTY_HASH))
+    if empty == 1 or invalid:
+        i.constrain_equal(rev["persistent"], 1)
+        i.constrain_equal(i.next[S_STATE], int(ES.EndTx))
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_CALL_ID, "to", call_id)
+    else:
+        for tag, want in ((CC.Depth, (1, 0)), (CC.CallerAddress, caller_w), (CC.CalleeAddress, callee_w), (CC.CallDataOffset, (0, 0)),
+                          (CC.CallDataLength, (cd_length, 0)), (CC.Value, tx_value), (CC.IsStatic, (0, 0)),
+                          (CC.LastCalleeId, (0, 0)), (CC.LastCalleeReturnDataOffset, (0, 0)),
+                          (CC.LastCalleeReturnDataLength, (0, 0)), (CC.IsRoot, (1, 0)), (CC.IsCreate, (0, 0)),
+                          (CC.CodeHash, code_hash)):
+            got, _ = i.call_context_lookup_word(tag, call_id=call_id)
+            i.constrain_equal_word(got, want)
+        # step_state_transition_to_new_context (instruction.py:266-290)
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_CALL_ID, "to", call_id)
+        i.transition(S_IS_ROOT, "to", 1)
+        i.transition(S_IS_CREATE, "to", 0)
+        i.require(i.next[S_CH_LO] == code_hash[0] % P and i.next[S_CH_HI] == code_hash[1] % P)
+        i.transition(S_GAS, "to", gas_left)
+        i.transition(S_REV, "to", 2)
+        i.transition(S_LOG, "to", 0)
+        i.transition(S_PC, "to", 0)
+        i.transition(S_SP, "to", 1024)
+        i.transition(S_MWS, "to", 0)
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1774,7 +1873,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

@@ -615,11 +615,11 @@ ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_i
 struct Reversion {
     Fr end, persistent, rwc;
 };
-ZK_HD Reversion reversion_info(Ins& I) {  // instruction.py:901-913
+ZK_HD Reversion reversion_info(Ins& I, const Fr* call_id = nullptr) {  // instruction.py:901-913
     Reversion rv;
-    rv.end = call_context_lookup(I, CC_RwCounterEndOfReversion);
-    rv.persistent = call_context_lookup(I, CC_IsPersistent);
-    rv.rwc = ev_curr(I, S_REV);
+    rv.end = call_context_lookup(I, CC_RwCounterEndOfReversion, 0, call_id);
+    rv.persistent = call_context_lookup(I, CC_IsPersistent, 0, call_id);
+    rv.rwc = call_id ? fr_zero() : ev_curr(I, S_REV);
     return rv;
 }
 // state_write (instruction.py:826-863): the write plus, when not persistent, its reversion row
@@ -2385,6 +2385,158 @@ ZK_HD void g_end_tx(Ins& I, Tail& T) {
     }
 }
 
+// ---- BeginTx (begin_tx.py) -----------------------------------------------------------------------
+// add_words (util/arithmetic.py:236-242) for three addends
+ZK_HD Word add_words3(Ins& I, const Word& x, const Word& y, const Word& z, Fr& carry_hi) {
+    Fr slo = fr_add(fr_add(x.lo, y.lo), z.lo), sum_lo, c_lo;
+    split128(slo, sum_lo, c_lo);
+    Fr shi = fr_add(fr_add(fr_add(x.hi, y.hi), z.hi), c_lo), sum_hi;
+    split128(shi, sum_hi, carry_hi);
+    return word_checked(I, sum_lo, sum_hi);
+}
+// constrain_zero(add_account_to_access_list(tx_id, address)) without reversion info
+ZK_HD void access_list_must_be_cold(Ins& I, const Fr& tx_id, const Fr& address) {
+    RwQ W;
+    rwq_init(W, 1, TG_TxAccessListAccount);
+    rwq_set(W, R_ID, tx_id);
+    rwq_set(W, R_ADDR, address);
+    rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+    u32 r; r = rw_lookup(I, W); if (I.err) return;
+    Fr prev = value_of(I, rw_value_prev(I, r)); if (I.err) return;
+    constrain_zero(I, prev);
+}
+ZK_HD Fr tx_value_of(Ins& I, const Fr& tx_id, u32 tag) {  // tx_context_lookup (instruction.py:686-687)
+    WordOrValue v; v = tx_lookup(I, tx_id, tag);
+    return value_of(I, v);
+}
+ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation txs: ZK_UNSUPPORTED (keccak(rlp) in the gadget)
+    const Fr call_id = I.rwc;
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId, 0, &call_id);
+    Reversion rv; EV_TRY(rv = reversion_info(I, &call_id));
+    Fr is_success; is_success = call_context_lookup(I, CC_IsSuccess, 0, &call_id);
+    constrain_equal(I, is_success, rv.persistent);
+    if (is_first) constrain_equal(I, tx_id, fr_u(1));
+    if (I.err) return;
+    WordOrValue cbw; cbw = block_lookup(I, BLK_Coinbase);
+    Fr coinbase; EV_TRY(coinbase = word_to_fq(I, cbw.w, 20));
+    WordOrValue caller_w; caller_w = tx_lookup(I, tx_id, TXC_CallerAddress);
+    Fr caller; EV_TRY(caller = word_to_fq(I, caller_w.w, 20));
+    WordOrValue callee_w; callee_w = tx_lookup(I, tx_id, TXC_CalleeAddress);
+    Fr callee; EV_TRY(callee = word_to_fq(I, callee_w.w, 20));
+    Fr tx_is_create; EV_TRY(tx_is_create = tx_value_of(I, tx_id, TXC_IsCreate));
+    WordOrValue tx_value; tx_value = tx_lookup(I, tx_id, TXC_Value);
+    Fr cd_length; EV_TRY(cd_length = tx_value_of(I, tx_id, TXC_CallDataLength));
+    ev_require(I, !fr_is_zero(caller)); if (I.err) return;
+    Fr is_tx_invalid; EV_TRY(is_tx_invalid = tx_value_of(I, tx_id, TXC_TxInvalid));
+    Fr tx_nonce; EV_TRY(tx_nonce = tx_value_of(I, tx_id, TXC_Nonce));
+    Fr nonce, nonce_prev;
+    {
+        RwQ Q;
+        rwq_init(Q, 1, TG_Account);
+        rwq_set(Q, R_ADDR, caller);
+        rwq_set(Q, R_FT, fr_u(ACC_Nonce));
+        u32 r; r = rw_lookup(I, Q); if (I.err) return;
+        EV_TRY(nonce = value_of(I, rw_value(I, r)));
+        EV_TRY(nonce_prev = value_of(I, rw_value_prev(I, r)));
+    }
+    const u32 is_nonce_valid = fr_eq(tx_nonce, nonce_prev) ? 1u : 0u;
+    constrain_equal(I, nonce, fr_sub(fr_add_u64(nonce_prev, 1), is_tx_invalid)); if (I.err) return;
+    Fr tx_gas; EV_TRY(tx_gas = tx_value_of(I, tx_id, TXC_Gas));
+    WordOrValue gpw; gpw = tx_lookup(I, tx_id, TXC_GasPrice); if (I.err) return;
+    Word gas_fee; EV_TRY(gas_fee = mul_word_by_u64(I, gpw.w, tx_gas));
+    Fr calldata_gas; EV_TRY(calldata_gas = tx_value_of(I, tx_id, TXC_CallDataGasCost));
+    const bool is_create = fr_eq_u64(tx_is_create, 1);
+    Fr cost = fr_u(21000);
+    if (is_create) {
+        Fr words; EV_TRY(words = constant_divmod_shift(I, fr_add_u64(cd_length, 31), 5, 8));
+        cost = fr_add_u64(fr_add(words, words), 53000);
+    }
+    Fr accesslist_gas; EV_TRY(accesslist_gas = tx_value_of(I, tx_id, TXC_AccessListGasCost));
+    const Fr intrinsic = fr_add(fr_add(calldata_gas, cost), accesslist_gas);
+    u32 gas_not_enough, eq; EV_TRY(ev_compare(I, tx_gas, intrinsic, 31, gas_not_enough, eq));
+    const Fr gas_left = gas_not_enough ? tx_gas : fr_sub(tx_gas, intrinsic);
+    if (is_create) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    I.seq++;  // address_to_word(contract_address)
+    EV_TRY(access_list_must_be_cold(I, tx_id, coinbase));
+    EV_TRY(access_list_must_be_cold(I, tx_id, caller));
+    EV_TRY(access_list_must_be_cold(I, tx_id, callee));
+    const bool invalid = fr_eq_u64(is_tx_invalid, 1);
+    Word value = tx_value.w, fee = gas_fee;
+    if (invalid) { I.seq += 2; value = word_zero(); fee = word_zero(); }
+    Word sender_prev;
+    {   // transfer_with_gas_fee (instruction.py:1099-1109): sub_balance then add_balance, both reversible
+        RwQ Q;
+        rwq_init(Q, 1, TG_Account);
+        rwq_set(Q, R_ADDR, caller);
+        rwq_set(Q, R_FT, fr_u(ACC_Balance));
+        u32 r; r = state_write(I, Q, rv); if (I.err) return;
+        const Word balance = rw_word(I, r, R_VAL_LO);
+        sender_prev = rw_word(I, r, R_PREV_LO);
+        Fr carry; Word sum; sum = add_words3(I, balance, value, fee, carry);
+        constrain_equal_word(I, sender_prev, sum);
+        constrain_zero(I, carry);
+        if (I.err) return;
+        RwQ R;
+        rwq_init(R, 1, TG_Account);
+        rwq_set(R, R_ADDR, callee);
+        rwq_set(R, R_FT, fr_u(ACC_Balance));
+        r = state_write(I, R, rv); if (I.err) return;
+        const Word rbal = rw_word(I, r, R_VAL_LO), rprev = rw_word(I, r, R_PREV_LO);
+        Fr carry2; Word sum2; sum2 = add_words2(I, rprev, value, carry2);
+        constrain_equal_word(I, rbal, sum2);
+        constrain_zero(I, carry2);
+        if (I.err) return;
+    }
+    Fr lhs; EV_TRY(lhs = word_to_fq(I, sender_prev, 31));
+    Fr v31; EV_TRY(v31 = word_to_fq(I, tx_value.w, 31));
+    Fr f31; EV_TRY(f31 = word_to_fq(I, gas_fee, 31));
+    u32 balance_not_enough; EV_TRY(ev_compare(I, lhs, fr_add(v31, f31), 31, balance_not_enough, eq));
+    const u32 invalid_tx = 1u - (1u - balance_not_enough) * (1u - gas_not_enough) * is_nonce_valid;
+    constrain_equal(I, is_tx_invalid, fr_u(invalid_tx)); if (I.err) return;
+    I.seq++;
+    if (fr_fits64(callee) && fr_lo64(callee) >= 1 && fr_lo64(callee) <= 9) { ev_fail(I, ZK_NOT_IMPLEMENTED); return; }  // precompile callee
+    Word code_hash; code_hash = account_read_word(I, callee, ACC_CodeHash); if (I.err) return;
+    I.seq++;  // Word(EMPTY_CODE_HASH)
+    const Word empty_hash = word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+    const bool empty = is_equal_word(code_hash, empty_hash);
+    if (empty || invalid) {
+        constrain_equal(I, rv.persistent, fr_u(1));
+        ev_require(I, ev_next(I, S_STATE).v[0] == ES_EndTx && fr_fits32(ev_next(I, S_STATE)));
+        transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+        transition(I, S_CALL_ID, t_to(call_id));
+        return;
+    }
+    const u32 tags[13] = {CC_Depth, CC_CallerAddress, CC_CalleeAddress, CC_CallDataOffset, CC_CallDataLength, CC_Value, CC_IsStatic,
+                          CC_LastCalleeId, CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength, CC_IsRoot, CC_IsCreate, CC_CodeHash};
+    for (int k = 0; k < 13; k++) {
+        Word want = word_zero();
+        switch (k) {
+        case 0: case 10: want = word_value(fr_u(1)); break;
+        case 1: want = caller_w.w; break;
+        case 2: want = callee_w.w; break;
+        case 4: want = word_value(cd_length); break;
+        case 5: want = tx_value.w; break;
+        case 12: want = code_hash; break;
+        default: break;
+        }
+        WordOrValue got; got = call_context_lookup_word(I, tags[k], 0, &call_id);
+        constrain_equal_word(I, got.w, want);
+        if (I.err) return;
+    }
+    // step_state_transition_to_new_context (instruction.py:266-290)
+    transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+    transition(I, S_CALL_ID, t_to(call_id));
+    transition(I, S_IS_ROOT, t_to(fr_u(1)));
+    transition(I, S_IS_CREATE, t_to(fr_zero()));
+    ev_require(I, fr_eq(ev_next(I, S_CH_LO), code_hash.lo) && fr_eq(ev_next(I, S_CH_HI), code_hash.hi));
+    transition(I, S_GAS, t_to(gas_left));
+    transition(I, S_REV, t_to(fr_u(2)));
+    transition(I, S_LOG, t_to(fr_zero()));
+    transition(I, S_PC, t_to(fr_zero()));
+    transition(I, S_SP, t_to(fr_u(1024)));
+    transition(I, S_MWS, t_to(fr_zero()));
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -2453,7 +2605,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
-    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx:
+    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx:
         return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
@@ -2543,6 +2695,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_BeginTx: if (G == EVM_GROUP_COLD) { g_begin_tx(I, T, is_first); } break;
     case ES_EndTx: if (G == EVM_GROUP_COLD) { g_end_tx(I, T); } break;
     case ES_RETURN: if (G == EVM_GROUP_COLD) { g_return(I, T); } break;
     case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_COLD) { g_error_invalid_creation_code(I, T); } break;
