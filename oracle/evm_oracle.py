@@ -339,9 +339,12 @@ class Ins:
         lt, _ = self.compare(lhs, rhs, n_bytes)
         return self.select(lt, rhs, lhs)
 
-    def memory_expansion_dynamic_length(self, cd_offset, cd_length):  # (rd_* = None form)
+    def memory_expansion_dynamic_length(self, cd_offset, cd_length, rd_offset=None, rd_length=None):
         cd_size, _ = self.constant_divmod(cd_offset + cd_length + 31, 32, 4)
         nxt = self.max_(self.curr[S_MWS], cd_size, 4)
+        if rd_offset is not None:
+            rd_size, _ = self.constant_divmod(rd_offset + rd_length + 31, 32, 4)
+            nxt = self.max_(nxt, rd_size, 4)
         g0 = self.memory_gas_cost(self.curr[S_MWS])
         g1 = self.memory_gas_cost(nxt)
         return nxt, (g1 - g0) % P
@@ -1839,6 +1842,160 @@ def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rl
         i.transition(S_MWS, "to", 0)
 
 
+class _CallGadget:  # util/call_gadget.py:18-124
+    def __init__(self, i, is_success_call, opcode):
+        is_call, is_callcode = int(opcode == OP.CALL), int(opcode == OP.CALLCODE)
+        is_delegatecall, is_staticcall = int(opcode == OP.DELEGATECALL), int(opcode == OP.STATICCALL)
+        i.constrain_equal(is_call + is_callcode + is_delegatecall + is_staticcall, 1)
+        gas, callee_w = i.stack_pop(), i.stack_pop()
+        self.value = i.stack_pop() if is_call + is_callcode == 1 else i.word_from_int(0)
+        cd_off_w, cd_len_w, rd_off_w, rd_len_w = i.stack_pop(), i.stack_pop(), i.stack_pop(), i.stack_pop()
+        result = i.stack_push()
+        self.is_success = result[0] % P
+        i.constrain_equal_word(i.word_checked(self.is_success, 0), result)
+        i.constrain_bool(self.is_success)
+        if is_success_call == 0:
+            i.constrain_zero(self.is_success)
+        self.gas = i.word_to_fq(gas, 8)
+        self.is_u64_gas = int(sum(i.to_le_bytes(gas)[8:]) == 0)
+        no_value_op = is_delegatecall + is_staticcall == 1
+        self.has_value = 0 if no_value_op else 1 - i.is_zero_word(self.value)
+        if no_value_op:
+            i.require(self.value[0] % P == 0 and self.value[1] % P == 0)
+        self.callee_address = i.word_to_fq(callee_w, 20)
+        self.cd_offset, self.cd_length = i.memory_offset_and_length(cd_off_w, cd_len_w)
+        self.rd_offset, self.rd_length = i.memory_offset_and_length(rd_off_w, rd_len_w)
+        self.next_memory_size, self.memory_expansion_gas = i.memory_expansion_dynamic_length(
+            self.cd_offset, self.cd_length, self.rd_offset, self.rd_length)
+        self.callee_code_hash = _account_read_word(i, self.callee_address, ACC.CodeHash)
+        self.is_empty_code_hash = i.is_equal_word(self.callee_code_hash, i.word_from_int(EMPTY_HASH))
+        self.callee_not_exists = i.is_zero_word(self.callee_code_hash)
+
+    def gas_cost(self, i, is_warm, is_call=1):
+        return (i.select(is_warm, 100, 2600) + self.has_value * (9000 + is_call * self.is_success * self.callee_not_exists * 25000)
+                + self.memory_expansion_gas) % P
+
+
+def g_error_oog_call(i):  # error_oog_call.py
+    opcode = i.opcode_lookup(True)
+    i.require(opcode in (OP.CALL, OP.CALLCODE, OP.DELEGATECALL, OP.STATICCALL))
+    tx_id = i.call_context_lookup(CC.TxId)
+    call = _CallGadget(i, 0, opcode)
+    is_warm = _read_account_to_access_list(i, tx_id, call.callee_address)
+    _oog_tail(i, call.gas_cost(i, is_warm))
+
+
+def g_callop(i):  # callop.py (precompile callees read StepState.aux_data: not evaluated)
+    opcode = i.opcode_lookup(True)
+    is_call, is_callcode = int(opcode == OP.CALL), int(opcode == OP.CALLCODE)
+    is_delegatecall = int(opcode == OP.DELEGATECALL)
+    i.fixed_lookup(T.FixedTableTag.ResponsibleOpcode, i.curr[S_STATE], opcode, 0)
+    callee_call_id = i.curr[S_RWC]
+    tx_id = i.call_context_lookup(CC.TxId)
+    rev = i.reversion_info()
+    ctx_caller_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    ctx_caller = i.word_to_fq(ctx_caller_w, 20)
+    is_static = i.call_context_lookup(CC.IsStatic)
+    depth = i.call_context_lookup(CC.Depth)
+    if is_delegatecall == 1:
+        parent_caller_w, _ = i.call_context_lookup_word(CC.CallerAddress)
+        parent_value, _ = i.call_context_lookup_word(CC.Value)
+    else:
+        parent_caller_w, parent_value = i.word_from_int(0), i.word_from_int(0)
+    call = _CallGadget(i, 1, opcode)
+    callee_address = i.select(is_callcode + is_delegatecall, ctx_caller, call.callee_address)
+    i.constrain_zero(callee_address >> 160)  # address_to_word
+    callee_address_w = (callee_address & M128, callee_address >> 128)
+    caller_w = parent_caller_w if i.select(is_delegatecall, 1, 0) else ctx_caller_w
+    caller_address = i.word_to_fq(caller_w, 20)
+    rowf = i.state_write(TG.TxAccessListAccount, tx_id, call.callee_address, value=(1, 0), reversion_info=rev)
+    is_warm = i.value_of(i.row_value_prev(rowf))
+    i.constrain_zero(call.has_value * is_static)
+    callee_rev = i.reversion_info(call_id=callee_call_id)
+    i.constrain_equal(callee_rev["persistent"], rev["persistent"] * call.is_success)
+    if call.is_success == 1 and rev["persistent"] % P == 0:
+        want = (rev["end"] - rev["rwc"]) % P
+        rev["rwc"] = (rev["rwc"] + 1) % P
+        i.constrain_equal(callee_rev["end"], want)
+    insufficient = 0
+    if is_call == 1 or is_callcode == 1:
+        caller_balance = _account_read_word(i, caller_address, ACC.Balance)
+        insufficient, _ = i.compare_word(caller_balance, call.value)
+    depth_ok, _ = i.compare(depth, 1025, 2)
+    precheck_ok = depth_ok == 1 and insufficient == 0
+    if not precheck_ok:
+        i.constrain_zero(call.is_success)
+    if is_call == 1 and precheck_ok:  # transfer (instruction.py:1111-1120) with the callee's reversion info
+        rowf = i.state_write(TG.Account, address=caller_address, field_tag=int(ACC.Balance), reversion_info=callee_rev)
+        bal, prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+        result, carry = i.add_words([bal, call.value])
+        i.constrain_equal_word(prev, result)
+        i.constrain_zero(carry)
+        rowf = i.state_write(TG.Account, address=callee_address, field_tag=int(ACC.Balance), reversion_info=callee_rev)
+        bal, prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+        result, carry = i.add_words([prev, call.value])
+        i.constrain_equal_word(bal, result)
+        i.constrain_zero(carry)
+    if is_callcode == 1 and call.is_success == 1:
+        i.constrain_zero(insufficient)
+    gas_cost = call.gas_cost(i, is_warm, is_call)
+    gas_available = (i.curr[S_GAS] - gas_cost) % P
+    one_64th, _ = i.constant_divmod(gas_available, 64, 8)
+    all_but = (gas_available - one_64th) % P
+    lt, _ = i.compare(all_but, call.gas, 8)
+    capped = i.select(lt, all_but, call.gas)
+    callee_gas_left = i.select(call.is_u64_gas, capped, all_but)
+    is_precompile = int(1 <= call.callee_address <= 9)
+    nxt_is_precompile = int(ES(i.next[S_STATE]).name in ("ECRECOVER", "SHA256", "RIPEMD160", "DATACOPY", "BIGMODEXP", "BN254_ADD",
+                                                         "BN254_SCALAR_MUL", "BN254_PAIRING", "BLAKE2F")) \
+        if 1 <= i.next[S_STATE] <= len(ES) else 0
+    i.constrain_equal(is_precompile, nxt_is_precompile)
+    sp_delta = 5 + is_call + is_callcode
+    no_callee_code = call.is_empty_code_hash + call.callee_not_exists
+    if (not precheck_ok) or (no_callee_code == 1 and is_precompile == 0):
+        for tag in (CC.LastCalleeId, CC.LastCalleeReturnDataOffset, CC.LastCalleeReturnDataLength):
+            i.constrain_equal(i.call_context_lookup(tag, rw=1), 0)
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_PC, "delta", 1)
+        i.transition(S_SP, "delta", sp_delta)
+        i.transition(S_GAS, "delta", call.has_value * 2300 - gas_cost)
+        i.transition(S_MWS, "to", call.next_memory_size)
+        i.transition(S_REV, "delta", 3)
+        i.transition(S_CALL_ID, "same")
+        i.transition(S_IS_ROOT, "same")
+        i.transition(S_IS_CREATE, "same")
+        i.require(i.next[S_CH_LO] == i.curr[S_CH_LO] and i.next[S_CH_HI] == i.curr[S_CH_HI])
+    elif is_precompile == 1:
+        raise Fail(UNSUPPORTED, i.seq)  # precompile_input_len / return_length come from StepState.aux_data
+    else:
+        for tag, want in ((CC.ProgramCounter, i.curr[S_PC] + 1), (CC.StackPointer, i.curr[S_SP] + sp_delta),
+                          (CC.GasLeft, i.curr[S_GAS] - gas_cost - callee_gas_left), (CC.MemorySize, call.next_memory_size),
+                          (CC.ReversibleWriteCounter, i.curr[S_REV] + 1)):
+            i.constrain_equal(i.call_context_lookup(tag, rw=1), want)
+        value_w = parent_value if i.select(is_delegatecall, 1, 0) else call.value
+        for tag, want in ((CC.CallerId, (i.curr[S_CALL_ID], 0)), (CC.TxId, (tx_id, 0)), (CC.Depth, (depth + 1, 0)),
+                          (CC.CallerAddress, caller_w), (CC.CalleeAddress, callee_address_w), (CC.CallDataOffset, (call.cd_offset, 0)),
+                          (CC.CallDataLength, (call.cd_length, 0)), (CC.ReturnDataOffset, (call.rd_offset, 0)),
+                          (CC.ReturnDataLength, (call.rd_length, 0)), (CC.Value, value_w), (CC.IsSuccess, (call.is_success, 0)),
+                          (CC.IsStatic, (is_static, 0)), (CC.LastCalleeId, (0, 0)), (CC.LastCalleeReturnDataOffset, (0, 0)),
+                          (CC.LastCalleeReturnDataLength, (0, 0)), (CC.IsRoot, (0, 0)), (CC.IsCreate, (0, 0)),
+                          (CC.CodeHash, call.callee_code_hash)):
+            got, _ = i.call_context_lookup_word(tag, call_id=callee_call_id)
+            i.constrain_equal_word(got, want)
+        callee_gas_left = (callee_gas_left + call.has_value * 2300) % P
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_CALL_ID, "to", callee_call_id)
+        i.transition(S_IS_ROOT, "to", 0)
+        i.transition(S_IS_CREATE, "to", 0)
+        i.require(i.next[S_CH_LO] == call.callee_code_hash[0] % P and i.next[S_CH_HI] == call.callee_code_hash[1] % P)
+        i.transition(S_GAS, "to", callee_gas_left)
+        i.transition(S_REV, "to", 2)
+        i.transition(S_LOG, "same")
+        i.transition(S_PC, "to", 0)
+        i.transition(S_SP, "to", 1024)
+        i.transition(S_MWS, "to", 0)
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -1873,7 +2030,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

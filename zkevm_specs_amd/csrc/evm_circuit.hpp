@@ -2537,6 +2537,249 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
     transition(I, S_MWS, t_to(fr_zero()));
 }
 
+// ---- CALL / CALLCODE / DELEGATECALL / STATICCALL (callop.py, util/call_gadget.py, error_oog_call.py) ----
+struct CallGadget {
+    Word value, callee_code_hash;
+    Fr gas, callee_address, cd_offset, cd_length, rd_offset, rd_length, next_memory_size, memory_expansion_gas, is_success;
+    u32 is_u64_gas, has_value, is_empty_code_hash, callee_not_exists;
+};
+ZK_HD void call_gadget(Ins& I, CallGadget& C, bool is_success_call, u32 opcode_v) {  // call_gadget.py:39-106
+    const bool is_call = opcode_v == OP_CALL, is_callcode = opcode_v == OP_CALLCODE;
+    const bool is_delegatecall = opcode_v == OP_DELEGATECALL, is_staticcall = opcode_v == OP_STATICCALL;
+    ev_require(I, is_call || is_callcode || is_delegatecall || is_staticcall); if (I.err) return;
+    Word gas_w, callee_w;
+    gas_w = stack_pop(I); callee_w = stack_pop(I);
+    if (is_call || is_callcode) C.value = stack_pop(I);
+    else { I.seq++; C.value = word_zero(); }  // Word(0)
+    Word cd_off_w, cd_len_w, rd_off_w, rd_len_w, result;
+    cd_off_w = stack_pop(I); cd_len_w = stack_pop(I); rd_off_w = stack_pop(I); rd_len_w = stack_pop(I);
+    result = stack_push(I);
+    if (I.err) return;
+    C.is_success = result.lo;
+    Word sw; sw = word_checked(I, C.is_success, fr_zero());
+    constrain_equal_word(I, sw, result);
+    ev_require(I, fr_le_u64(C.is_success, 1));
+    if (!is_success_call) constrain_zero(I, C.is_success);
+    if (I.err) return;
+    C.gas = word_to_fq(I, gas_w, 8); if (I.err) return;
+    {
+        U256 gb = to_u256(I, gas_w); if (I.err) return;
+        C.is_u64_gas = (gb.v[2] | gb.v[3] | gb.v[4] | gb.v[5] | gb.v[6] | gb.v[7]) == 0u ? 1u : 0u;
+    }
+    const bool no_value_op = is_delegatecall || is_staticcall;
+    C.has_value = no_value_op ? 0u : 1u - is_zero_word(C.value);
+    if (no_value_op) { ev_require(I, fr_is_zero(C.value.lo) && fr_is_zero(C.value.hi)); if (I.err) return; }
+    C.callee_address = word_to_fq(I, callee_w, 20); if (I.err) return;
+    memory_offset_and_length(I, cd_off_w, cd_len_w, C.cd_offset, C.cd_length); if (I.err) return;
+    memory_offset_and_length(I, rd_off_w, rd_len_w, C.rd_offset, C.rd_length); if (I.err) return;
+    {   // memory_expansion_dynamic_length with the return-data range (instruction.py:1157-1181)
+        const Fr mws = ev_curr(I, S_MWS);
+        Fr cd_size = constant_divmod_shift(I, fr_add_u64(fr_add(C.cd_offset, C.cd_length), 31), 5, 4); if (I.err) return;
+        u32 lt, eq; ev_compare(I, mws, cd_size, 4, lt, eq); if (I.err) return;
+        Fr nxt = ev_select_b(I, lt) ? cd_size : mws;
+        Fr rd_size = constant_divmod_shift(I, fr_add_u64(fr_add(C.rd_offset, C.rd_length), 31), 5, 4); if (I.err) return;
+        ev_compare(I, nxt, rd_size, 4, lt, eq); if (I.err) return;
+        nxt = ev_select_b(I, lt) ? rd_size : nxt;
+        Fr g0 = memory_gas_cost(I, mws); if (I.err) return;
+        Fr g1 = memory_gas_cost(I, nxt); if (I.err) return;
+        C.next_memory_size = nxt;
+        C.memory_expansion_gas = fr_sub(g1, g0);
+    }
+    C.callee_code_hash = account_read_word(I, C.callee_address, ACC_CodeHash); if (I.err) return;
+    I.seq++;  // Word(EMPTY_CODE_HASH)
+    const Word empty_hash = word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+    C.is_empty_code_hash = is_equal_word(C.callee_code_hash, empty_hash);
+    C.callee_not_exists = is_zero_word(C.callee_code_hash);
+}
+ZK_HD Fr call_gas_cost(Ins& I, const CallGadget& C, const Fr& is_warm, bool is_call) {  // call_gadget.py:108-124
+    const bool warm = ev_select(I, is_warm);
+    u64 g = warm ? 100 : 2600;
+    if (C.has_value) {
+        g += 9000;
+        if (is_call && C.callee_not_exists && fr_eq_u64(C.is_success, 1)) g += 25000;
+    }
+    return fr_add_u64(C.memory_expansion_gas, g);
+}
+ZK_HD void g_error_oog_call(Ins& I, Tail& T) {  // error_oog_call.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const u32 ov = fr_le_u64(opcode, 255) ? opcode.v[0] : 0u;
+    ev_require(I, ov == OP_CALL || ov == OP_CALLCODE || ov == OP_DELEGATECALL || ov == OP_STATICCALL); if (I.err) return;
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId); if (I.err) return;
+    CallGadget C; call_gadget(I, C, false, ov); if (I.err) return;
+    Fr is_warm; EV_TRY(is_warm = read_account_to_access_list(I, tx_id, C.callee_address));
+    Fr gas_cost; EV_TRY(gas_cost = call_gas_cost(I, C, is_warm, true));
+    oog_tail(T, gas_cost);
+}
+// state_write of an Account.Balance row (sub_balance / add_balance, instruction.py:987-1013)
+ZK_HD void balance_move(Ins& I, const Fr& address, const Word& value, Reversion& rv, bool subtract) {
+    RwQ Q;
+    rwq_init(Q, 1, TG_Account);
+    rwq_set(Q, R_ADDR, address);
+    rwq_set(Q, R_FT, fr_u(ACC_Balance));
+    u32 r; r = state_write(I, Q, rv); if (I.err) return;
+    const Word bal = rw_word(I, r, R_VAL_LO), prev = rw_word(I, r, R_PREV_LO);
+    Fr carry; Word sum; sum = add_words2(I, subtract ? bal : prev, value, carry);
+    constrain_equal_word(I, subtract ? prev : bal, sum);
+    constrain_zero(I, carry);
+}
+ZK_HD void g_callop(Ins& I, Tail& T) {  // callop.py; precompile callees (StepState.aux_data) -> ZK_UNSUPPORTED
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const u32 ov = fr_le_u64(opcode, 255) ? opcode.v[0] : 0u;
+    const bool is_call = ov == OP_CALL, is_callcode = ov == OP_CALLCODE, is_delegatecall = ov == OP_DELEGATECALL;
+    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
+    const Fr callee_call_id = I.rwc;
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    Reversion rv; EV_TRY(rv = reversion_info(I));
+    WordOrValue ctx_caller_w; ctx_caller_w = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr ctx_caller; EV_TRY(ctx_caller = word_to_fq(I, ctx_caller_w.w, 20));
+    Fr is_static, depth;
+    is_static = call_context_lookup(I, CC_IsStatic);
+    depth = call_context_lookup(I, CC_Depth);
+    if (I.err) return;
+    Word parent_caller_w = word_zero(), parent_value = word_zero();
+    if (is_delegatecall) {
+        WordOrValue a, b;
+        a = call_context_lookup_word(I, CC_CallerAddress);
+        b = call_context_lookup_word(I, CC_Value);
+        parent_caller_w = a.w; parent_value = b.w;
+    } else {
+        I.seq += 2;  // Word(0), Word(0)
+    }
+    if (I.err) return;
+    CallGadget C; call_gadget(I, C, true, ov); if (I.err) return;
+    I.seq++;  // select(is_callcode + is_delegatecall, ..)
+    const Fr callee_address = (is_callcode || is_delegatecall) ? ctx_caller : C.callee_address;
+    I.seq++;  // address_to_word: both candidates passed word_to_fq(.., 20)
+    const Word callee_address_w = word_of(fr_from_u128(fr_lo64(callee_address), fr_hi64of128(callee_address)),
+                                          fr_u((u64)callee_address.v[4]));
+    I.seq++;  // select_word(is_delegatecall, ..)
+    const Word caller_w = is_delegatecall ? parent_caller_w : ctx_caller_w.w;
+    Fr caller_address; EV_TRY(caller_address = word_to_fq(I, caller_w, 20));
+    Fr is_warm;
+    {
+        RwQ W;
+        rwq_init(W, 1, TG_TxAccessListAccount);
+        rwq_set(W, R_ID, tx_id);
+        rwq_set(W, R_ADDR, C.callee_address);
+        rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+        u32 wr; wr = state_write(I, W, rv); if (I.err) return;
+        EV_TRY(is_warm = value_of(I, rw_value_prev(I, wr)));
+    }
+    constrain_zero(I, C.has_value ? is_static : fr_zero()); if (I.err) return;
+    Reversion crv; EV_TRY(crv = reversion_info(I, &callee_call_id));
+    constrain_equal(I, crv.persistent, fr_mul(rv.persistent, C.is_success)); if (I.err) return;
+    const bool success = fr_eq_u64(C.is_success, 1);
+    if (success && fr_is_zero(rv.persistent)) {
+        const Fr want = fr_sub(rv.end, rv.rwc);
+        rv.rwc = fr_add_u64(rv.rwc, 1);
+        constrain_equal(I, crv.end, want); if (I.err) return;
+    }
+    u32 insufficient = 0;
+    if (is_call || is_callcode) {
+        Word caller_balance; caller_balance = account_read_word(I, caller_address, ACC_Balance); if (I.err) return;
+        u32 eqw; compare_word(I, caller_balance, C.value, insufficient, eqw); if (I.err) return;
+    }
+    u32 depth_ok, eq; EV_TRY(ev_compare(I, depth, fr_u(1025), 2, depth_ok, eq));
+    const bool precheck_ok = depth_ok == 1u && insufficient == 0u;
+    if (!precheck_ok) { constrain_zero(I, C.is_success); if (I.err) return; }
+    if (is_call && precheck_ok) {  // transfer (instruction.py:1111-1120) under the callee's reversion info
+        EV_TRY(balance_move(I, caller_address, C.value, crv, true));
+        EV_TRY(balance_move(I, callee_address, C.value, crv, false));
+    }
+    if (is_callcode && success) { ev_require(I, insufficient == 0u); if (I.err) return; }
+    Fr gas_cost; EV_TRY(gas_cost = call_gas_cost(I, C, is_warm, is_call));
+    const Fr gas_available = fr_sub(ev_curr(I, S_GAS), gas_cost);
+    Fr one_64th; EV_TRY(one_64th = constant_divmod_shift(I, gas_available, 6, 8));
+    const Fr all_but = fr_sub(gas_available, one_64th);
+    u32 lt; EV_TRY(ev_compare(I, all_but, C.gas, 8, lt, eq));
+    const Fr capped = ev_select_b(I, lt) ? all_but : C.gas;
+    Fr callee_gas_left = ev_select_b(I, C.is_u64_gas) ? capped : all_but;
+    const bool is_precompile = fr_fits64(C.callee_address) && fr_lo64(C.callee_address) >= 1 && fr_lo64(C.callee_address) <= 9;
+    {
+        const Fr ns = ev_next(I, S_STATE);
+        const u32 nsv = ns.v[0];
+        const bool nxt_pre = fr_fits32(ns) && (nsv == ES_ECRECOVER || nsv == ES_SHA256 || nsv == ES_RIPEMD160 || nsv == ES_DATACOPY ||
+                                                nsv == ES_BIGMODEXP || nsv == ES_BN254_ADD || nsv == ES_BN254_SCALAR_MUL ||
+                                                nsv == ES_BN254_PAIRING || nsv == ES_BLAKE2F);
+        ev_require(I, is_precompile == nxt_pre); if (I.err) return;
+    }
+    const int sp_delta = 5 + (is_call ? 1 : 0) + (is_callcode ? 1 : 0);
+    const u32 no_callee_code = C.is_empty_code_hash + C.callee_not_exists;
+    if (!precheck_ok || (no_callee_code == 1u && !is_precompile)) {
+        const u32 tags[3] = {CC_LastCalleeId, CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength};
+        for (int k = 0; k < 3; k++) {
+            Fr v; v = call_context_lookup(I, tags[k], 1);
+            constrain_equal(I, v, fr_zero()); if (I.err) return;
+        }
+        transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+        transition(I, S_PC, t_delta_i(1));
+        transition(I, S_SP, t_delta_i(sp_delta));
+        transition(I, S_GAS, t_delta(fr_sub(fr_u(C.has_value ? 2300 : 0), gas_cost)));
+        transition(I, S_MWS, t_to(C.next_memory_size));
+        transition(I, S_REV, t_delta_i(3));
+        transition(I, S_CALL_ID, t_same());
+        transition(I, S_IS_ROOT, t_same());
+        transition(I, S_IS_CREATE, t_same());
+        ev_require(I, fr_eq(ev_next(I, S_CH_LO), ev_curr(I, S_CH_LO)) && fr_eq(ev_next(I, S_CH_HI), ev_curr(I, S_CH_HI)));
+        return;
+    }
+    if (is_precompile) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    {   // save the caller's call state
+        const u32 tags[5] = {CC_ProgramCounter, CC_StackPointer, CC_GasLeft, CC_MemorySize, CC_ReversibleWriteCounter};
+        for (int k = 0; k < 5; k++) {
+            Fr want;
+            switch (k) {
+            case 0: want = fr_add_u64(I.pc, 1); break;
+            case 1: want = fr_add_u64(I.sp, (u64)sp_delta); break;
+            case 2: want = fr_sub(fr_sub(ev_curr(I, S_GAS), gas_cost), callee_gas_left); break;
+            case 3: want = C.next_memory_size; break;
+            default: want = fr_add_u64(ev_curr(I, S_REV), 1); break;
+            }
+            Fr v; v = call_context_lookup(I, tags[k], 1);
+            constrain_equal(I, v, want); if (I.err) return;
+        }
+    }
+    I.seq++;  // select_word(is_delegatecall, parent_call_value, call.value), evaluated while the list is built
+    {
+        const u32 tags[18] = {CC_CallerId, CC_TxId, CC_Depth, CC_CallerAddress, CC_CalleeAddress, CC_CallDataOffset, CC_CallDataLength,
+                              CC_ReturnDataOffset, CC_ReturnDataLength, CC_Value, CC_IsSuccess, CC_IsStatic, CC_LastCalleeId,
+                              CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength, CC_IsRoot, CC_IsCreate, CC_CodeHash};
+        for (int k = 0; k < 18; k++) {
+            Word want = word_zero();
+            switch (k) {
+            case 0: want = word_value(I.call_id); break;
+            case 1: want = word_value(tx_id); break;
+            case 2: want = word_value(fr_add_u64(depth, 1)); break;
+            case 3: want = caller_w; break;
+            case 4: want = callee_address_w; break;
+            case 5: want = word_value(C.cd_offset); break;
+            case 6: want = word_value(C.cd_length); break;
+            case 7: want = word_value(C.rd_offset); break;
+            case 8: want = word_value(C.rd_length); break;
+            case 9: want = is_delegatecall ? parent_value : C.value; break;
+            case 10: want = word_value(C.is_success); break;
+            case 11: want = word_value(is_static); break;
+            case 17: want = C.callee_code_hash; break;
+            default: break;
+            }
+            WordOrValue got; got = call_context_lookup_word(I, tags[k], 0, &callee_call_id);
+            constrain_equal_word(I, got.w, want); if (I.err) return;
+        }
+    }
+    if (C.has_value) callee_gas_left = fr_add_u64(callee_gas_left, 2300);
+    transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+    transition(I, S_CALL_ID, t_to(callee_call_id));
+    transition(I, S_IS_ROOT, t_to(fr_zero()));
+    transition(I, S_IS_CREATE, t_to(fr_zero()));
+    ev_require(I, fr_eq(ev_next(I, S_CH_LO), C.callee_code_hash.lo) && fr_eq(ev_next(I, S_CH_HI), C.callee_code_hash.hi));
+    transition(I, S_GAS, t_to(callee_gas_left));
+    transition(I, S_REV, t_to(fr_u(2)));
+    transition(I, S_LOG, t_same());
+    transition(I, S_PC, t_to(fr_zero()));
+    transition(I, S_SP, t_to(fr_u(1024)));
+    transition(I, S_MWS, t_to(fr_zero()));
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -2605,8 +2848,8 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
-    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx:
-        return EVM_GROUP_COLD;
+    case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
+    case ES_ErrorOutOfGasCall: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -2695,6 +2938,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;
+    case ES_ErrorOutOfGasCall: if (G == EVM_GROUP_COLD) { g_error_oog_call(I, T); } break;
     case ES_BeginTx: if (G == EVM_GROUP_COLD) { g_begin_tx(I, T, is_first); } break;
     case ES_EndTx: if (G == EVM_GROUP_COLD) { g_end_tx(I, T); } break;
     case ES_RETURN: if (G == EVM_GROUP_COLD) { g_return(I, T); } break;
