@@ -261,7 +261,8 @@ ZK_HD void rwq_set_word(RwQ& Q, int c, const Word& w) {
 }
 // Packed key record of an RW row: the five cells nearly every lookup compares (rw, tag, id, address,
 // field_tag: 160 B on the wire) in 32 B, so a lookup reads 2 x 16 B instead of 10 x 16 B.
-//   w0: bit 63 = "fits" | bits 0-7 rw | 8-15 tag | 16-23 field_tag | 24-55 address[128..160)
+//   w0: bit 63 = "fits" | bits 0-7 rw | 8-15 tag | 16-23 field_tag | 24-55 address[128..160) | 56-57 the row's
+//       type bits (value.is_word, value_prev.is_word)
 //   w1: id | w2: address[0..64) | w3: address[64..128)
 // A row whose cells exceed those widths (only malformed witnesses) has fits = 0 and is compared cell
 // by cell.  Built once per session for the dense index (rw_pack_kernel), like the other indices.
@@ -287,7 +288,9 @@ ZK_HD RwKey rw_pack_row(const ZkTable& t, u32 r) {
         k.w[0] = k.w[1] = k.w[2] = k.w[3] = 0;
         return k;
     }
-    return rw_pack_fields(rw, tag, id, addr, ft);
+    RwKey k = rw_pack_fields(rw, tag, id, addr, ft);
+    k.w[0] |= (u64)((t.flags ? t.flags[r] : 3u) & 3u) << 56;
+    return k;
 }
 // Instruction.rw_lookup (instruction.py:792-824); rw_counter = curr.rw_counter + offset unless given
 ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
@@ -599,6 +602,56 @@ ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr, const Fr* call_id = nullp
     rwq_set(Q, R_ADDR, addr);
     u32 r = rw_lookup(I, Q);
     return value_of(I, rw_value(I, r));
+}
+// The 32 memory_lookup calls of MLOAD / MSTORE (memory.py:32-40): rows rw_counter .. +31 of the dense RW
+// table, keys (rw, Memory, call_id, address + k), each followed by `.value.value()` (type bit must be
+// clear).  With the packed key records the 32 records of a lane are contiguous (1 KB): they are fetched
+// in batches of eight and compared in registers; failures are reported at the same checkpoints as the
+// one-by-one form.  Falls back to the generic lookups whenever a record or the query does not fit.
+ZK_HD void memory_lookup_run32(Ins& I, u32 rw, const Fr& address) {
+    const EvmArgs& a = *I.a;
+    const Fr rwc0 = fr_add_u64(I.rwc, I.rw_off);
+    const u64 off = fr_lo64(rwc0) - a.rw_base;
+    bool fastpath = a.rw_dense && a.rw_keys && fr_fits64(rwc0) && fr_lo64(rwc0) >= a.rw_base && off + 32 <= (u64)a.rw.n && off + 32 > off &&
+                    fr_fits64(I.call_id) && (address.v[5] | address.v[6] | address.v[7]) == 0u &&
+                    !(address.v[4] == 0xffffffffu && address.v[3] == 0xffffffffu && address.v[2] == 0xffffffffu && address.v[1] == 0xffffffffu &&
+                      address.v[0] >= 0xffffffe0u);  // address + 31 stays below 2^160
+    u32 bad_lookup = 0, bad_type = 0;
+    if (fastpath) {
+        const uint4* kp = reinterpret_cast<const uint4*>(a.rw_keys + off * 4);
+        const u64 id = fr_lo64(I.call_id);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint4 k01[8], k23[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { k01[j] = kp[2 * (8 * b + j)]; k23[j] = kp[2 * (8 * b + j) + 1]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 8 * b + j;
+                const Fr ak = fr_add_u64(address, (u64)k);
+                const u64 w0 = (u64)k01[j].x | ((u64)k01[j].y << 32), w1 = (u64)k01[j].z | ((u64)k01[j].w << 32);
+                const u64 w2 = (u64)k23[j].x | ((u64)k23[j].y << 32), w3 = (u64)k23[j].z | ((u64)k23[j].w << 32);
+                // expected: fits | rw | Memory << 8 | address[128..160) << 24 (field_tag is not part of the query)
+                const u64 want0 = (1ull << 63) | (u64)rw | ((u64)TG_Memory << 8) | ((u64)ak.v[4] << 24);
+                const u64 cmp_mask = ~((0xffull << 16) | (3ull << 56));
+                if (!(w0 >> 63)) fastpath = false;  // a record that does not fit: redo everything one by one
+                const bool ok = ((w0 ^ want0) & cmp_mask) == 0 && w1 == id && w2 == fr_lo64(ak) && w3 == fr_hi64of128(ak);
+                bad_lookup |= (ok ? 0u : 1u) << k;
+                bad_type |= (u32)((w0 >> 56) & 1u) << k;
+            }
+        }
+    }
+    if (fastpath) {
+        for (int k = 0; k < 32; k++) {
+            I.seq++;
+            if ((bad_lookup >> k) & 1u) ev_fail(I, ZK_LOOKUP_UNSAT);
+            I.seq++;
+            if ((bad_type >> k) & 1u) ev_fail(I, ZK_ASSERT);
+        }
+        I.rw_off += 32;
+        return;
+    }
+    for (int k = 0; k < 32; k++) memory_lookup(I, rw, fr_add_u64(address, (u64)k));
 }
 ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
     RwQ Q;
@@ -1382,8 +1435,7 @@ ZK_HD void g_memory(Ins& I, Tail& T) {  // memory.py
     Fr next_size, gas;
     EV_TRY(memory_expansion(I, ev_curr(I, S_MWS), fr_add_u64(address, 1 + (is_not8 ? 31 : 0)), next_size, gas));
     if (is_mstore8) memory_lookup(I, 1, address);
-    if (is_not8)
-        for (int k = 0; k < 32; k++) memory_lookup(I, is_store ? 1 : 0, fr_add_u64(address, (u64)k));
+    if (is_not8) memory_lookup_run32(I, is_store ? 1 : 0, address);
     if (I.err) return;
     set_tail(T, opcode, 34 - (is_mstore8 ? 31 : 0), t_delta_i(1), is_store ? 2 : 0, t_to(next_size), 0, gas);
 }
