@@ -108,6 +108,10 @@ typedef struct zk_evm_tables {
     const uint64_t* copy;       uint64_t n_copy;
     const uint64_t* keccak;     uint64_t n_keccak;
     const uint64_t* exp;        uint64_t n_exp;
+    /* StepState.aux_data (step.py:44), optional (NULL = absent for every step): aux uint64[n_steps][2][4] and
+     * aux_kind uint32[n_steps]: 0 none, 1 Word (lo, hi), 2 int < 2^256 (lo, hi), 3 pair of field values,
+     * 4 not representable (a gadget that reads it reports ZK_UNSUPPORTED). */
+    const uint64_t* aux;        const uint32_t* aux_kind;
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
 #define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */

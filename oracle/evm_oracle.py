@@ -52,7 +52,7 @@ class EvmWitness:
     """Flattened tables as Python ints + the indices the lookups use."""
 
     def __init__(self, steps, rw, rw_flags, bytecode, tx=(), tx_flags=(), block=(), block_flags=(), copy=(),
-                 keccak=(), exp=()):
+                 keccak=(), exp=(), aux=None, aux_kind=None):
         self.steps = steps
         self.rw = [tuple(r) for r in rw]
         self.rw_flags = list(rw_flags)
@@ -74,6 +74,9 @@ class EvmWitness:
         for i, r in enumerate(self.block):
             self.blk_idx.setdefault(r[:2], []).append(i)
         # copy table (14 cells, table.py:494-507), keccak table (5, :511-515), exp table (11, :538-548)
+        # StepState.aux_data per step: (cell0, cell1) + kind (0 none, 1 Word, 2 int, 3 pair, 4 other), flatten.py
+        self.aux = [tuple(r) for r in aux] if aux is not None else [(0, 0)] * len(steps)
+        self.aux_kind = list(aux_kind) if aux_kind is not None else [0] * len(steps)
         self.copy = [tuple(r) for r in copy]
         self.keccak = [tuple(r) for r in keccak]
         self.exp = [tuple(r) for r in exp]
@@ -102,6 +105,7 @@ def _distinct_match(rows, cands, query):
 class Ins:
     def __init__(self, w, idx, is_first, is_last):
         self.w = w
+        self.idx = idx
         self.curr = w.steps[idx]
         self.next = w.steps[idx + 1]
         self.is_first, self.is_last = is_first, is_last
@@ -1996,6 +2000,44 @@ def g_callop(i):  # callop.py (precompile callees read StepState.aux_data: not e
         i.transition(S_MWS, "to", 0)
 
 
+def g_error_oog_sload_sstore(i):  # error_oog_sload_sstore.py
+    opcode = i.opcode_lookup(True)
+    is_sstore, is_sload = int(opcode == OP.SSTORE), int(opcode == OP.SLOAD)
+    i.constrain_equal(is_sstore + is_sload, 1)
+    key = i.stack_pop()
+    tx_id = i.call_context_lookup(CC.TxId)
+    callee_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    callee = i.word_to_fq(callee_w, 20)
+    rowf = i.rw_lookup(0, TG.TxAccessListAccountStorage, tx_id, callee, None, key)
+    is_warm = i.value_of(i.row_value(rowf))  # read_account_storage_to_access_list returns row.value (instruction.py:1088-1097)
+    if is_sload == 1:
+        gas_cost = 100 if is_warm == 1 else 2100
+    else:
+        value = i.stack_pop()
+        value_prev = i.row_value(i.rw_lookup(0, TG.AccountStorage, tx_id, callee, None, key))[0]
+        idx = i.idx
+        if i.w.aux_kind[idx] != 2:
+            raise Fail(UNSUPPORTED, i.seq)  # Word(curr.aux_data) needs an int original value on the wire
+        orig = i.word_from_int(i.w.aux[idx][0] | (i.w.aux[idx][1] << 128))
+        weq = lambda a, b: a[0] % P == b[0] % P and a[1] % P == b[1] % P  # noqa: E731  (Word.__eq__)
+        if weq(value, value_prev):
+            gas_cost = 100
+        elif weq(value_prev, orig):
+            zero = i.word_from_int(0)
+            gas_cost = 20000 if weq(orig, zero) else 2900
+        else:
+            gas_cost = 100
+        if is_warm == 0:
+            gas_cost += 2100
+    insufficient, _ = i.compare(i.curr[S_GAS], gas_cost, 8)
+    if is_sload == 1:
+        i.constrain_equal(insufficient, 1)
+    else:
+        lt, eq = i.compare(i.curr[S_GAS], 2300, 8)
+        i.require(lt + eq + insufficient != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -2030,7 +2072,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

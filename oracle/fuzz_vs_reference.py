@@ -23,7 +23,8 @@ def to_witness(w):
     return eo.EvmWitness(wire.rowmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
-                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]))
+                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"])
 
 
 def main():

@@ -29,7 +29,7 @@ calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_j
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
 error_return_data_out_of_bound error_write_protection logs return_revert
-error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call""".split()
+error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store""".split()
 MAX_CASES_PER_FILE = 48
 
 
@@ -94,6 +94,11 @@ def unflatten(wire):
         s.program_counter, s.stack_pointer, s.gas_left = FQ(c[7]), FQ(c[8]), FQ(c[9])
         s.memory_word_size, s.reversible_write_counter, s.log_id = FQ(c[10]), FQ(c[11]), FQ(c[12])
         steps.append(s)
+    if "aux" in wire:  # StepState.aux_data (kinds: zkevm_specs_amd/flatten.py flatten_step_aux)
+        for s, a, k in zip(steps, rowmajor_to_rows(wire["aux"]), wire["aux_kind"]):
+            k = int(k)
+            assert k != 4, "aux_data kind that the wire format cannot carry"
+            s.aux_data = None if k == 0 else (W(a[0], a[1]) if k == 1 else (a[0] | (a[1] << 128) if k == 2 else [FQ(a[0]), FQ(a[1])]))
     rw = set()
     for c, f in zip(rowmajor_to_rows(wire["rw"]), wire["rw_flags"]):
         rw.add(RWTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), W(c[6], c[7]),

@@ -7,7 +7,8 @@ import numpy as np
 
 from oracle import evm_oracle as eo, wire
 
-FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp")
+FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
+          "aux_kind")
 _OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11}  # tables only some gadgets need; absent = empty
 
 
@@ -16,6 +17,10 @@ def with_defaults(w):
     for k, nc in _OPTIONAL.items():
         if k not in w:
             w[k] = np.zeros((0, nc, 4), dtype=np.uint64)
+    n = w["steps"].shape[0]
+    if "aux" not in w:  # StepState.aux_data: absent for every step
+        w["aux"] = np.zeros((n, 2, 4), dtype=np.uint64)
+        w["aux_kind"] = np.zeros(n, dtype=np.uint32)
     return w
 
 
@@ -36,7 +41,8 @@ def to_witness(w):
     return eo.EvmWitness(wire.rowmajor_to_rows(w["steps"]), wire.rowmajor_to_rows(w["rw"]), w["rw_flags"],
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
-                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]))
+                         wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"])
 
 
 def oracle_status(w, opts=(0, 0)):
@@ -54,7 +60,7 @@ def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
                        vp(a["bytecode"]), u64(a["bytecode"].shape[0]), vp(a["tx"]), vp(a["tx_flags"]),
                        u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
                        vp(a["copy"]), u64(a["copy"].shape[0]), vp(a["keccak"]), u64(a["keccak"].shape[0]),
-                       vp(a["exp"]), u64(a["exp"].shape[0]),
+                       vp(a["exp"]), u64(a["exp"].shape[0]), vp(a["aux"]), vp(a["aux_kind"]),
                        ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1) | (4 if generic_index else 0)), vp(st))
     return st[: n - 1].tolist()
 

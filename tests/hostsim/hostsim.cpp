@@ -84,7 +84,8 @@ static void host_table(HostTable& h, const u64* cells, const u32* flags, u64 n, 
 extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, const u32* rw_flags, u64 n_rw,
                               const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
                               const u64* block, const u32* block_flags, u64 n_blk, const u64* copy, u64 n_copy,
-                              const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, u32 opts, u32* status) {
+                              const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, const u64* aux, const u32* aux_kind,
+                              u32 opts, u32* status) {
     EvmArgs a;
     a.steps = steps;
     a.n_steps = n_steps;
@@ -92,6 +93,8 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     host_table(tcopy, copy, nullptr, n_copy, COPY_T_NCELLS, copy_key_hash);
     host_table(tkeccak, keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
     host_table(texp, exp, nullptr, n_exp, EXP_T_NCELLS, expt_key_hash);
+    a.aux = aux;
+    a.aux_kind = aux_kind;
     a.copy = tcopy.t;
     a.keccak = tkeccak.t;
     a.exp = texp.t;

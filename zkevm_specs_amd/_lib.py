@@ -39,6 +39,7 @@ class ZkEvmTables(ctypes.Structure):
         ("copy", ctypes.c_void_p), ("n_copy", ctypes.c_uint64),
         ("keccak", ctypes.c_void_p), ("n_keccak", ctypes.c_uint64),
         ("exp", ctypes.c_void_p), ("n_exp", ctypes.c_uint64),
+        ("aux", ctypes.c_void_p), ("aux_kind", ctypes.c_void_p),
     ]
 
 

@@ -40,6 +40,8 @@ struct EvmArgs {
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
+    const u64* aux;             // optional StepState.aux_data: [n_steps][2][4] cells ...
+    const u32* aux_kind;        // ... and kinds (0 none, 1 Word, 2 int, 3 pair, 4 not representable)
     u32 rw_dense;     // 1: the RW rows are sorted with consecutive rw_counters (row = rw_counter - rw_base); 0: generic index
     u64 rw_base;
     const u64* rw_keys;  // optional [n_rw][4]: packed (rw, tag, field_tag, id, address) of every row, see rw_pack_row
@@ -2832,6 +2834,58 @@ ZK_HD void g_callop(Ins& I, Tail& T) {  // callop.py; precompile callees (StepSt
     transition(I, S_MWS, t_to(fr_zero()));
 }
 
+// StepState.aux_data of the current step (EvmArgs::aux): kind and the two cells
+ZK_HD u32 aux_kind(const Ins& I) { return I.a->aux_kind ? I.a->aux_kind[I.idx] : 0u; }
+ZK_HD Word aux_word(const Ins& I) { return word_of(fr_load(I.a->aux + I.idx * 8), fr_load(I.a->aux + I.idx * 8 + 4)); }
+ZK_HD void g_error_oog_sload_sstore(Ins& I, Tail& T) {  // error_oog_sload_sstore.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const bool is_sstore = fr_eq_u64(opcode, OP_SSTORE), is_sload = fr_eq_u64(opcode, OP_SLOAD);
+    ev_require(I, is_sstore || is_sload); if (I.err) return;
+    Word key; key = stack_pop(I);
+    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
+    Fr is_warm;
+    {   // read_account_storage_to_access_list returns row.value (instruction.py:1088-1097)
+        RwQ Q;
+        rwq_init(Q, 0, TG_TxAccessListAccountStorage);
+        rwq_set(Q, R_ID, tx_id);
+        rwq_set(Q, R_ADDR, callee);
+        rwq_set_word(Q, R_KEY_LO, key);
+        u32 r; r = rw_lookup(I, Q);
+        EV_TRY(is_warm = value_of(I, rw_value(I, r)));
+    }
+    u64 gas_cost;
+    if (is_sload) {
+        gas_cost = fr_eq_u64(is_warm, 1) ? 100 : 2100;
+    } else {
+        Word value; value = stack_pop(I);
+        RwQ Q;
+        rwq_init(Q, 0, TG_AccountStorage);
+        rwq_set(Q, R_ID, tx_id);
+        rwq_set(Q, R_ADDR, callee);
+        rwq_set_word(Q, R_KEY_LO, key);
+        u32 r; r = rw_lookup(I, Q); if (I.err) return;
+        const Word value_prev = rw_word(I, r, R_VAL_LO);
+        if (aux_kind(I) != 2u) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }  // Word(curr.aux_data)
+        I.seq++;
+        const Word orig = aux_word(I);
+        if (word_eq(value, value_prev)) gas_cost = 100;
+        else if (word_eq(value_prev, orig)) { I.seq++; gas_cost = (fr_is_zero(orig.lo) && fr_is_zero(orig.hi)) ? 20000 : 2900; }
+        else gas_cost = 100;
+        if (fr_is_zero(is_warm)) gas_cost += 2100;
+    }
+    u32 insufficient, eq; EV_TRY(ev_compare(I, ev_curr(I, S_GAS), fr_u(gas_cost), 8, insufficient, eq));
+    if (is_sload) {
+        ev_require(I, insufficient == 1u);
+    } else {
+        u32 lt; EV_TRY(ev_compare(I, ev_curr(I, S_GAS), fr_u(2300), 8, lt, eq));
+        ev_require(I, (lt + eq + insufficient) != 0u);
+    }
+    if (I.err) return;
+    T.err_tail = 1;
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -2901,7 +2955,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
-    case ES_ErrorOutOfGasCall: return EVM_GROUP_COLD;
+    case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -2990,6 +3044,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_ErrorOutOfGasSloadSstore: if (G == EVM_GROUP_COLD) { g_error_oog_sload_sstore(I, T); } break;
     case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;
     case ES_ErrorOutOfGasCall: if (G == EVM_GROUP_COLD) { g_error_oog_call(I, T); } break;
     case ES_BeginTx: if (G == EVM_GROUP_COLD) { g_begin_tx(I, T, is_first); } break;

@@ -476,6 +476,14 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = table_stage(s, s->evm.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
+    s->evm.aux = nullptr;
+    s->evm.aux_kind = nullptr;
+    if (t->aux && t->aux_kind) {
+        if ((rc = stage(s, t->aux, (size_t)t->n_steps * 2 * 32, dev, &p))) goto fail;
+        s->evm.aux = (const u64*)p;
+        if ((rc = stage(s, t->aux_kind, (size_t)t->n_steps * 4, dev, &p))) goto fail;
+        s->evm.aux_kind = (const u32*)p;
+    }
     if ((rc = build_index<copy_key_hash>(s, s->evm.copy))) goto fail;
     if ((rc = build_index<keccak_key_hash>(s, s->evm.keccak))) goto fail;
     if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;

@@ -32,6 +32,9 @@ def shard_evm(wire, rank, world, begin_with_first_step=False, end_with_last_step
     lo, hi = shard_bounds(n_pairs, rank, world)
     local = dict(wire)
     local["steps"] = np.ascontiguousarray(wire["steps"][lo : hi + 1])
+    for k in ("aux", "aux_kind"):  # per-step side data travels with the step rows
+        if wire.get(k) is not None:
+            local[k] = np.ascontiguousarray(wire[k][lo : hi + 1])
     return local, bool(begin_with_first_step and rank == 0), bool(end_with_last_step and rank == world - 1), lo
 
 

@@ -115,7 +115,8 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
     and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4]
     (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
     lib = _lib.init(device)
-    names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp"]
+    names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
+             "aux_kind"]
     arrs, opts = _prep([wire.get(k) for k in names])
     a = dict(zip(names, arrs))
 
@@ -135,7 +136,8 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         int(bool(begin_with_first_step)), int(bool(end_with_last_step)),
         p(a["copy"]) if rows(a["copy"]) else None, rows(a["copy"]),
         p(a["keccak"]) if rows(a["keccak"]) else None, rows(a["keccak"]),
-        p(a["exp"]) if rows(a["exp"]) else None, rows(a["exp"]))
+        p(a["exp"]) if rows(a["exp"]) else None, rows(a["exp"]),
+        p(a["aux"]) if rows(a["aux"]) else None, p(a["aux_kind"]) if rows(a["aux"]) else None)
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:

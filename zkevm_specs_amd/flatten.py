@@ -162,6 +162,34 @@ def flatten_exp_table(exp_table):
     return rows_to_rowmajor(rows, EXP_T_NCELLS)
 
 
+AUX_NONE, AUX_WORD, AUX_INT, AUX_PAIR, AUX_OTHER = 0, 1, 2, 3, 4
+
+
+def flatten_step_aux(steps):
+    """StepState.aux_data (step.py:44, "auxiliary witness data needed by gadgets") -> two cells + a kind per
+    step: 1 = a Word (CREATE: init-code hash), 2 = a non-negative int < 2^256 (ErrorOutOfGasSloadSstore:
+    original value, lo/hi split), 3 = a pair of field values (CALL into a precompile: input / return
+    length), 4 = anything else (precompile states: not representable, gadgets that read it report
+    ZK_UNSUPPORTED), 0 = absent."""
+    cells, kinds = [], []
+    for st in steps:
+        a = getattr(st, "aux_data", None)
+        c, k = [0, 0], AUX_NONE
+        if a is None:
+            pass
+        elif hasattr(a, "lo") and hasattr(a, "hi"):
+            c, k = [_n(a.lo), _n(a.hi)], AUX_WORD
+        elif isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 256):
+            c, k = [a & ((1 << 128) - 1), a >> 128], AUX_INT
+        elif isinstance(a, (list, tuple)) and len(a) == 2 and all(hasattr(x, "n") or isinstance(x, int) for x in a):
+            c, k = [_n(a[0]), _n(a[1])], AUX_PAIR
+        else:
+            k = AUX_OTHER
+        cells.append(c)
+        kinds.append(k)
+    return {"aux": rows_to_rowmajor(cells, 2), "aux_kind": np.array(kinds, dtype=np.uint32)}
+
+
 def flatten_evm(tables, steps):
     """reference `Tables` (evm_circuit/table.py:578-671) + list of StepState -> dict of wire arrays.
     The copy / keccak / exp tables only exist on `Tables` built with those circuits (:614-619);
@@ -175,6 +203,7 @@ def flatten_evm(tables, steps):
         "bytecode": flatten_bytecode_table(tables.bytecode_table),
         "tx": tx, "tx_flags": tx_flags,
         "block": blk, "block_flags": blk_flags,
+        **flatten_step_aux(steps),
         "copy": flatten_copy_table(getattr(tables, "copy_table", None)),
         "keccak": flatten_keccak_table(getattr(tables, "keccak_table", None)),
         "exp": flatten_exp_table(getattr(tables, "exp_table", None)),
