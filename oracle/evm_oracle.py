@@ -13,6 +13,7 @@ Pinned against the reference itself by oracle/gen_golden_evm.py (tests/golden/ev
 from .codes import (ASSERT, CONSTRAINT, LOOKUP_AMBIGUOUS, LOOKUP_UNSAT, NAME_ERROR, NOT_IMPLEMENTED, OK, OVERFLOW_ERROR,
                     UNSUPPORTED, VALUE_ERROR, ZERO_DIVISION, Fail)
 from .wire import P
+from . import keccak as _keccak
 
 # step cells
 S_STATE, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, S_PC, S_SP, S_GAS, S_MWS, S_REV, S_LOG = range(13)
@@ -1752,7 +1753,7 @@ def _access_list_must_be_cold(i, tx_id, address):  # constrain_zero(add_account_
     i.constrain_zero(i.value_of(i.row_value_prev(rowf)))
 
 
-def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rlp(..)) in the gadget: not evaluated)
+def g_begin_tx(i):  # begin_tx.py
     call_id = i.curr[S_RWC]
     tx_id = i.call_context_lookup(CC.TxId, call_id=call_id)
     rev = i.reversion_info(call_id=call_id)
@@ -1788,10 +1789,11 @@ def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rl
     intrinsic = (calldata_gas + cost + accesslist_gas) % P
     gas_not_enough, _ = i.compare(tx_gas, intrinsic, 31)
     gas_left = tx_gas if gas_not_enough == 1 else (tx_gas - intrinsic) % P
-    if tx_is_create % P == 1:
-        raise Fail(UNSUPPORTED, i.seq)  # generate_contract_address: keccak(rlp([caller, nonce])) inside the gadget
-    i.cp()  # address_to_word(contract_address): the unused CREATE address always fits 160 bits
-    callee_address = callee
+    is_create = tx_is_create % P == 1
+    contract = _keccak.create_address(caller, tx_nonce % P) if is_create else 0  # the value is only used by creations
+    i.cp()  # address_to_word(contract_address): a 20-byte digest always fits 160 bits
+    contract_w = (contract & M128, contract >> 128)
+    callee_address = contract if is_create else callee
     _access_list_must_be_cold(i, tx_id, coinbase)
     _access_list_must_be_cold(i, tx_id, caller)
     _access_list_must_be_cold(i, tx_id, callee_address)
@@ -1814,21 +1816,12 @@ def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rl
     balance_not_enough, _ = i.compare(lhs, rhs, 31)
     invalid_tx = 1 - (1 - balance_not_enough) * (1 - gas_not_enough) * is_nonce_valid
     i.constrain_equal(is_tx_invalid, invalid_tx)
-    i.cp()
-    if 1 <= callee % P <= 9:  # `tx_callee_address in list(Precompile)` (precompile.py:8-17)
-        i.fail(NOT_IMPLEMENTED)
-    code_hash = _account_read_word(i, callee, ACC.CodeHash)
-    empty = i.is_equal_word(code_hash, i.word_from_int(EMPTY_HASH))
-    if empty == 1 or invalid:
-        i.constrain_equal(rev["persistent"], 1)
-        i.constrain_equal(i.next[S_STATE], int(ES.EndTx))
-        i.transition(S_RWC, "delta", i.rw_off)
-        i.transition(S_CALL_ID, "to", call_id)
-    else:
-        for tag, want in ((CC.Depth, (1, 0)), (CC.CallerAddress, caller_w), (CC.CalleeAddress, callee_w), (CC.CallDataOffset, (0, 0)),
+
+    def new_context(callee_word, is_create_flag, code_hash):
+        for tag, want in ((CC.Depth, (1, 0)), (CC.CallerAddress, caller_w), (CC.CalleeAddress, callee_word), (CC.CallDataOffset, (0, 0)),
                           (CC.CallDataLength, (cd_length, 0)), (CC.Value, tx_value), (CC.IsStatic, (0, 0)),
                           (CC.LastCalleeId, (0, 0)), (CC.LastCalleeReturnDataOffset, (0, 0)),
-                          (CC.LastCalleeReturnDataLength, (0, 0)), (CC.IsRoot, (1, 0)), (CC.IsCreate, (0, 0)),
+                          (CC.LastCalleeReturnDataLength, (0, 0)), (CC.IsRoot, (1, 0)), (CC.IsCreate, (is_create_flag, 0)),
                           (CC.CodeHash, code_hash)):
             got, _ = i.call_context_lookup_word(tag, call_id=call_id)
             i.constrain_equal_word(got, want)
@@ -1836,7 +1829,7 @@ def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rl
         i.transition(S_RWC, "delta", i.rw_off)
         i.transition(S_CALL_ID, "to", call_id)
         i.transition(S_IS_ROOT, "to", 1)
-        i.transition(S_IS_CREATE, "to", 0)
+        i.transition(S_IS_CREATE, "to", is_create_flag)
         i.require(i.next[S_CH_LO] == code_hash[0] % P and i.next[S_CH_HI] == code_hash[1] % P)
         i.transition(S_GAS, "to", gas_left)
         i.transition(S_REV, "to", 2)
@@ -1844,6 +1837,34 @@ def g_begin_tx(i):  # begin_tx.py (contract-creation transactions need keccak(rl
         i.transition(S_PC, "to", 0)
         i.transition(S_SP, "to", 1024)
         i.transition(S_MWS, "to", 0)
+
+    def straight_to_end_tx():
+        i.constrain_equal(rev["persistent"], 1)
+        i.constrain_equal(i.next[S_STATE], int(ES.EndTx))
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_CALL_ID, "to", call_id)
+
+    if is_create:
+        if invalid or cd_length % P == 0:
+            straight_to_end_tx()
+            return
+        # the creation code is the tx calldata: its keccak is the code hash, and it is copied to the bytecode table
+        inc, rlc = i.copy_lookup((tx_id, 0), CDT_TXCALLDATA, (call_id, 0), CDT_RLCACC, 0, cd_length, 0, cd_length, i.curr[S_RWC] + i.rw_off)
+        i.require(inc % P == 0)
+        code_hash = i.keccak_lookup(cd_length, rlc)
+        inc, _ = i.copy_lookup((tx_id, 0), CDT_TXCALLDATA, code_hash, CDT_BYTECODE, 0, cd_length, 0, cd_length, i.curr[S_RWC] + i.rw_off)
+        i.require(inc % P == 0)
+        new_context(contract_w, 1, code_hash)
+        return
+    i.cp()
+    if 1 <= callee % P <= 9:  # `tx_callee_address in list(Precompile)` (precompile.py:8-17)
+        i.fail(NOT_IMPLEMENTED)
+    code_hash = _account_read_word(i, callee, ACC.CodeHash)
+    empty = i.is_equal_word(code_hash, i.word_from_int(EMPTY_HASH))
+    if empty == 1 or invalid:
+        straight_to_end_tx()
+    else:
+        new_context(callee_w, 0, code_hash)
 
 
 class _CallGadget:  # util/call_gadget.py:18-124
@@ -2038,6 +2059,133 @@ def g_error_oog_sload_sstore(i):  # error_oog_sload_sstore.py
     _constrain_error_state(i, i.rw_off + i.curr[S_REV])
 
 
+def g_create(i):  # create.py (CREATE and CREATE2)
+    opcode = i.opcode_lookup(True)
+    is_create, is_create2 = int(opcode == OP.CREATE), int(opcode == OP.CREATE2)
+    i.fixed_lookup(T.FixedTableTag.ResponsibleOpcode, i.curr[S_STATE], opcode, 0)
+    callee_call_id = i.curr[S_RWC]
+    value_w, offset_w, size_w = i.stack_pop(), i.stack_pop(), i.stack_pop()
+    salt_w = i.stack_pop() if is_create2 == 1 else i.word_from_int(0)
+    ret_addr_w = i.stack_push()
+    offset = i.word_to_fq(offset_w, 5)
+    size = i.word_to_fq(size_w, 5)
+    depth = i.call_context_lookup(CC.Depth)
+    tx_id = i.call_context_lookup(CC.TxId)
+    caller_w, _ = i.call_context_lookup_word(CC.CallerAddress)
+    caller = i.word_to_fq(caller_w, 20)
+    rowf = i.rw_lookup(1, TG.Account, address=caller, field_tag=int(ACC.Nonce))
+    nonce = i.value_of(i.row_value(rowf))
+    nonce_prev = i.value_of(i.row_value_prev(rowf))
+    balance = i.value_of(i.row_value(i.rw_lookup(0, TG.Account, address=caller, field_tag=int(ACC.Balance))))
+    is_success = i.call_context_lookup(CC.IsSuccess)
+    i.call_context_lookup(CC.IsStatic)  # is_zero(is_static): result discarded (:48)
+    rev = i.reversion_info()
+    has_init_code = size != 0
+    next_mem, mem_gas = i.memory_expansion(offset, size)
+    word_len, _ = i.constant_divmod(size + 31, 32, 4)
+    gas_left = i.curr[S_GAS]
+    gas_cost = (32000 + mem_gas + word_len * 2 + (6 * word_len if is_create2 == 1 else 0)) % P
+    gas_available = (gas_left - gas_cost) % P
+    one_64th, _ = i.constant_divmod(gas_available, 64, 8)
+    all_but = (gas_available - one_64th) % P
+    i.require(gas_left <= M128, OVERFLOW_ERROR)  # WordOrValue(gas_left).to_le_bytes()
+    is_u64_gas = int(gas_left < (1 << 64))
+    lt, _ = i.compare(all_but, gas_left, 8)
+    capped = i.select(lt, all_but, gas_left)
+    callee_gas_left = i.select(is_u64_gas, capped, all_but)
+    depth_ok, _ = i.compare(depth, 1025, 2)
+    insufficient, _ = i.compare_word(i.word_from_int(balance), value_w)
+    nonce_ok, _ = i.compare(nonce_prev, MAX_U64, 8)
+    precheck_ok = depth_ok == 1 and insufficient == 0 and nonce_ok == 1
+    sp_delta = 2 + is_create2
+    nac = False
+    if precheck_ok:
+        if has_init_code:
+            if i.w.aux_kind[i.idx] != 1:
+                raise Fail(UNSUPPORTED, i.seq)  # code_hash = curr.aux_data must be a Word on the wire
+            code_hash = i.w.aux[i.idx]
+        else:
+            code_hash = i.word_from_int(EMPTY_HASH)
+        if is_create == 1:
+            contract = _keccak.create_address(caller, nonce % P)
+        else:
+            contract = _keccak.create2_address(caller, i.int_value(salt_w), i.int_value(code_hash))
+        i.cp()  # address_to_word: a 20-byte digest always fits
+        contract_w = (contract & M128, contract >> 128)
+        rowf = i.state_write(TG.TxAccessListAccount, tx_id, contract, value=(1, 0))
+        i.value_of(i.row_value_prev(rowf))
+        callee_code_hash = _account_read_word(i, contract, ACC.CodeHash)
+        callee_nonce = i.value_of(i.row_value(i.rw_lookup(0, TG.Account, address=contract, field_tag=int(ACC.Nonce))))
+        is_empty = i.is_equal_word(callee_code_hash, i.word_from_int(EMPTY_HASH))
+        is_zero_hash = i.is_equal_word(callee_code_hash, i.word_from_int(0))
+        nac = callee_nonce == 0 and (is_empty == 1 or is_zero_hash == 1)
+        if nac:
+            i.constrain_equal(i.word_to_fq(ret_addr_w, 20), is_success * contract)
+            callee_rev = i.reversion_info(call_id=callee_call_id)
+            i.constrain_equal(callee_rev["persistent"], rev["persistent"] * is_success)
+            rowf = i.state_write(TG.Account, address=caller, field_tag=int(ACC.Balance), reversion_info=callee_rev)
+            bal, prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+            result, carry = i.add_words([bal, value_w])
+            i.constrain_equal_word(prev, result)
+            i.constrain_zero(carry)
+            rowf = i.state_write(TG.Account, address=contract, field_tag=int(ACC.Balance), reversion_info=callee_rev)
+            bal, prev = i.row_value(rowf)[0], i.row_value_prev(rowf)[0]
+            result, carry = i.add_words([prev, value_w])
+            i.constrain_equal_word(bal, result)
+            i.constrain_zero(carry)
+            rowf = i.rw_lookup(1, TG.Account, address=contract, field_tag=int(ACC.Nonce))
+            new_nonce = i.value_of(i.row_value(rowf))
+            i.value_of(i.row_value_prev(rowf))
+            i.constrain_equal(new_nonce, 1)
+            if has_init_code:
+                next_hash = (i.next[S_CH_LO], i.next[S_CH_HI])
+                inc, _ = i.copy_lookup((i.curr[S_CALL_ID], 0), CDT_MEMORY, next_hash, CDT_BYTECODE, offset, offset + size, 0, size,
+                                       i.curr[S_RWC] + i.rw_off)
+                if inc >= 1 << 62:
+                    raise Fail(UNSUPPORTED, i.seq)  # rw_counter_offset += int(copy_rwc_inc): kept in 64 bits on the device
+                i.rw_off += inc
+                code_size = i.bytecode_length(next_hash)
+                i.constrain_equal(code_size, size)
+                for tag, want in ((CC.ProgramCounter, i.curr[S_PC] + 1), (CC.StackPointer, i.curr[S_SP] + sp_delta),
+                                  (CC.GasLeft, gas_left - gas_cost - callee_gas_left), (CC.MemorySize, next_mem),
+                                  (CC.ReversibleWriteCounter, i.curr[S_REV] + 1)):
+                    i.constrain_equal(i.call_context_lookup(tag, rw=1), want)
+                for tag, want in ((CC.CallerId, (i.curr[S_CALL_ID], 0)), (CC.TxId, (tx_id, 0)), (CC.Depth, (depth + 1, 0)),
+                                  (CC.CallerAddress, caller_w), (CC.CalleeAddress, contract_w), (CC.IsSuccess, (is_success, 0)),
+                                  (CC.IsStatic, (0, 0)), (CC.IsRoot, (0, 0)), (CC.IsCreate, (1, 0))):
+                    got, _ = i.call_context_lookup_word(tag, call_id=callee_call_id)
+                    i.constrain_equal_word(got, want)
+                got, _ = i.call_context_lookup_word(CC.CodeHash, call_id=callee_call_id)
+                i.constrain_equal_word(got, code_hash)
+                i.transition(S_RWC, "delta", i.rw_off)
+                i.transition(S_CALL_ID, "to", callee_call_id)
+                i.transition(S_IS_ROOT, "to", 0)
+                i.transition(S_IS_CREATE, "to", 1)
+                i.cp()  # code_hash = Transition.to_word(next.code_hash): trivially true
+                i.transition(S_GAS, "to", callee_gas_left)
+                i.transition(S_REV, "to", 3)
+                i.transition(S_LOG, "same")
+                i.transition(S_PC, "to", 0)
+                i.transition(S_SP, "to", 1024)
+                i.transition(S_MWS, "to", 0)
+    if (not precheck_ok) or (not nac) or (not has_init_code):
+        if (not precheck_ok) or (not nac):
+            i.constrain_equal(is_success, 0)
+        for tag in (CC.LastCalleeId, CC.LastCalleeReturnDataOffset, CC.LastCalleeReturnDataLength):
+            i.constrain_equal(i.call_context_lookup(tag, rw=1), 0)
+        rev_delta = 3 if (nac and not has_init_code) else 0
+        i.transition(S_RWC, "delta", i.rw_off)
+        i.transition(S_PC, "delta", 1)
+        i.transition(S_SP, "delta", sp_delta)
+        i.transition(S_REV, "delta", rev_delta)
+        i.transition(S_GAS, "delta", -gas_cost)
+        i.transition(S_MWS, "to", next_mem)
+        i.transition(S_CALL_ID, "same")
+        i.transition(S_IS_ROOT, "same")
+        i.transition(S_IS_CREATE, "same")
+        i.require(i.next[S_CH_LO] == i.curr[S_CH_LO] and i.next[S_CH_HI] == i.curr[S_CH_HI])
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -2072,7 +2220,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

@@ -142,6 +142,17 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     return 0;
 }
 
+// keccak KAT hooks: digest of a short message; CREATE / CREATE2 addresses
+extern "C" void sim_keccak256(const uint8_t* msg, int len, uint8_t* out) { keccak256_block(msg, len, out); }
+extern "C" void sim_create_address(const u64* address, const u64* nonce, u64* out) {
+    Fr r = keccak_create_address(fr_load(address), fr_load(nonce));
+    for (int k = 0; k < 4; k++) out[k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
+}
+extern "C" void sim_create2_address(const u64* address, const u64* salt, const u64* code_hash, u64* out) {
+    Fr r = keccak_create2_address(fr_load(address), fr_load(salt), fr_load(code_hash));
+    for (int k = 0; k < 4; k++) out[k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
+}
+
 // 512/256 and 256/256 division KAT hooks: n (16 or 8 u32 limbs as u64 pairs), d -> q, r
 extern "C" void sim_divmod(int wide, const u64* n, const u64* d, u64* q, u64* r, u64 count) {
     for (u64 i = 0; i < count; i++) {

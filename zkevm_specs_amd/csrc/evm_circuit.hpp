@@ -23,6 +23,7 @@
 #pragma once
 #include "common.hpp"
 #include "evm_tables.h"
+#include "keccak.hpp"
 
 enum { S_STATE = 0, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, S_PC, S_SP, S_GAS, S_MWS, S_REV, S_LOG, STEP_NCELLS };
 enum { R_RWC = 0, R_RW, R_TAG, R_ID, R_ADDR, R_FT, R_KEY_LO, R_KEY_HI, R_VAL_LO, R_VAL_HI, R_PREV_LO, R_PREV_HI, R_AUX_LO, R_AUX_HI, RW_NCELLS };
@@ -2463,7 +2464,7 @@ ZK_HD Fr tx_value_of(Ins& I, const Fr& tx_id, u32 tag) {  // tx_context_lookup (
     WordOrValue v; v = tx_lookup(I, tx_id, tag);
     return value_of(I, v);
 }
-ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation txs: ZK_UNSUPPORTED (keccak(rlp) in the gadget)
+ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {
     const Fr call_id = I.rwc;
     Fr tx_id; tx_id = call_context_lookup(I, CC_TxId, 0, &call_id);
     Reversion rv; EV_TRY(rv = reversion_info(I, &call_id));
@@ -2509,11 +2510,14 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
     const Fr intrinsic = fr_add(fr_add(calldata_gas, cost), accesslist_gas);
     u32 gas_not_enough, eq; EV_TRY(ev_compare(I, tx_gas, intrinsic, 31, gas_not_enough, eq));
     const Fr gas_left = gas_not_enough ? tx_gas : fr_sub(tx_gas, intrinsic);
-    if (is_create) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    // generate_contract_address (keccak of rlp([caller, nonce])): the value is only used by creations
+    const Fr contract = is_create ? keccak_create_address(caller, tx_nonce) : fr_zero();
     I.seq++;  // address_to_word(contract_address)
+    const Word contract_w = word_of(fr_from_u128(fr_lo64(contract), fr_hi64of128(contract)), fr_u((u64)contract.v[4]));
+    const Fr callee_address = is_create ? contract : callee;
     EV_TRY(access_list_must_be_cold(I, tx_id, coinbase));
     EV_TRY(access_list_must_be_cold(I, tx_id, caller));
-    EV_TRY(access_list_must_be_cold(I, tx_id, callee));
+    EV_TRY(access_list_must_be_cold(I, tx_id, callee_address));
     const bool invalid = fr_eq_u64(is_tx_invalid, 1);
     Word value = tx_value.w, fee = gas_fee;
     if (invalid) { I.seq += 2; value = word_zero(); fee = word_zero(); }
@@ -2532,7 +2536,7 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
         if (I.err) return;
         RwQ R;
         rwq_init(R, 1, TG_Account);
-        rwq_set(R, R_ADDR, callee);
+        rwq_set(R, R_ADDR, callee_address);
         rwq_set(R, R_FT, fr_u(ACC_Balance));
         r = state_write(I, R, rv); if (I.err) return;
         const Word rbal = rw_word(I, r, R_VAL_LO), rprev = rw_word(I, r, R_PREV_LO);
@@ -2547,13 +2551,30 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
     u32 balance_not_enough; EV_TRY(ev_compare(I, lhs, fr_add(v31, f31), 31, balance_not_enough, eq));
     const u32 invalid_tx = 1u - (1u - balance_not_enough) * (1u - gas_not_enough) * is_nonce_valid;
     constrain_equal(I, is_tx_invalid, fr_u(invalid_tx)); if (I.err) return;
-    I.seq++;
-    if (fr_fits64(callee) && fr_lo64(callee) >= 1 && fr_lo64(callee) <= 9) { ev_fail(I, ZK_NOT_IMPLEMENTED); return; }  // precompile callee
-    Word code_hash; code_hash = account_read_word(I, callee, ACC_CodeHash); if (I.err) return;
-    I.seq++;  // Word(EMPTY_CODE_HASH)
     const Word empty_hash = word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
-    const bool empty = is_equal_word(code_hash, empty_hash);
-    if (empty || invalid) {
+    Word code_hash = word_zero();
+    bool to_end_tx;
+    if (is_create) {
+        to_end_tx = invalid || fr_is_zero(cd_length);
+        if (!to_end_tx) {
+            // the creation code is the tx calldata: its keccak is the code hash, and it is copied to the bytecode table
+            CopyRes cr;
+            EV_TRY(cr = copy_lookup(I, word_value(tx_id), CDT_TxCalldata, word_value(call_id), CDT_RlcAcc, fr_zero(), cd_length, fr_zero(), cd_length,
+                                    fr_add_u64(I.rwc, I.rw_off)));
+            ev_require(I, fr_is_zero(cr.rwc_inc)); if (I.err) return;
+            EV_TRY(code_hash = keccak_lookup(I, cd_length, cr.rlc_acc));
+            EV_TRY(cr = copy_lookup(I, word_value(tx_id), CDT_TxCalldata, code_hash, CDT_Bytecode, fr_zero(), cd_length, fr_zero(), cd_length,
+                                    fr_add_u64(I.rwc, I.rw_off)));
+            ev_require(I, fr_is_zero(cr.rwc_inc)); if (I.err) return;
+        }
+    } else {
+        I.seq++;
+        if (fr_fits64(callee) && fr_lo64(callee) >= 1 && fr_lo64(callee) <= 9) { ev_fail(I, ZK_NOT_IMPLEMENTED); return; }  // precompile callee
+        code_hash = account_read_word(I, callee, ACC_CodeHash); if (I.err) return;
+        I.seq++;  // Word(EMPTY_CODE_HASH)
+        to_end_tx = is_equal_word(code_hash, empty_hash) || invalid;
+    }
+    if (to_end_tx) {
         constrain_equal(I, rv.persistent, fr_u(1));
         ev_require(I, ev_next(I, S_STATE).v[0] == ES_EndTx && fr_fits32(ev_next(I, S_STATE)));
         transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
@@ -2567,9 +2588,10 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
         switch (k) {
         case 0: case 10: want = word_value(fr_u(1)); break;
         case 1: want = caller_w.w; break;
-        case 2: want = callee_w.w; break;
+        case 2: want = is_create ? contract_w : callee_w.w; break;
         case 4: want = word_value(cd_length); break;
         case 5: want = tx_value.w; break;
+        case 11: want = word_value(fr_u(is_create ? 1 : 0)); break;
         case 12: want = code_hash; break;
         default: break;
         }
@@ -2581,7 +2603,7 @@ ZK_HD void g_begin_tx(Ins& I, Tail& T, bool is_first) {  // contract-creation tx
     transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
     transition(I, S_CALL_ID, t_to(call_id));
     transition(I, S_IS_ROOT, t_to(fr_u(1)));
-    transition(I, S_IS_CREATE, t_to(fr_zero()));
+    transition(I, S_IS_CREATE, t_to(fr_u(is_create ? 1 : 0)));
     ev_require(I, fr_eq(ev_next(I, S_CH_LO), code_hash.lo) && fr_eq(ev_next(I, S_CH_HI), code_hash.hi));
     transition(I, S_GAS, t_to(gas_left));
     transition(I, S_REV, t_to(fr_u(2)));
@@ -2886,6 +2908,207 @@ ZK_HD void g_error_oog_sload_sstore(Ins& I, Tail& T) {  // error_oog_sload_sstor
     T.err_tail = 1;
 }
 
+// ---- CREATE / CREATE2 (create.py) ----------------------------------------------------------------
+ZK_HD void g_create(Ins& I, Tail& T) {
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const bool is_create = fr_eq_u64(opcode, OP_CREATE), is_create2 = fr_eq_u64(opcode, OP_CREATE2);
+    fixed_lookup(I, FX_ResponsibleOpcode, ev_curr(I, S_STATE), opcode, fr_zero()); if (I.err) return;
+    const Fr callee_call_id = I.rwc;
+    Word value_w, offset_w, size_w, salt_w = word_zero(), ret_addr_w;
+    value_w = stack_pop(I); offset_w = stack_pop(I); size_w = stack_pop(I);
+    if (is_create2) salt_w = stack_pop(I);
+    else I.seq++;  // Word(0)
+    ret_addr_w = stack_push(I);
+    if (I.err) return;
+    Fr offset; EV_TRY(offset = word_to_fq(I, offset_w, 5));
+    Fr size; EV_TRY(size = word_to_fq(I, size_w, 5));
+    Fr depth, tx_id;
+    depth = call_context_lookup(I, CC_Depth);
+    tx_id = call_context_lookup(I, CC_TxId);
+    WordOrValue caller_w; caller_w = call_context_lookup_word(I, CC_CallerAddress);
+    if (I.err) return;
+    Fr caller; EV_TRY(caller = word_to_fq(I, caller_w.w, 20));
+    Fr nonce, nonce_prev, balance;
+    {
+        RwQ Q;
+        rwq_init(Q, 1, TG_Account);
+        rwq_set(Q, R_ADDR, caller);
+        rwq_set(Q, R_FT, fr_u(ACC_Nonce));
+        u32 r; r = rw_lookup(I, Q); if (I.err) return;
+        EV_TRY(nonce = value_of(I, rw_value(I, r)));
+        EV_TRY(nonce_prev = value_of(I, rw_value_prev(I, r)));
+        RwQ B;
+        rwq_init(B, 0, TG_Account);
+        rwq_set(B, R_ADDR, caller);
+        rwq_set(B, R_FT, fr_u(ACC_Balance));
+        r = rw_lookup(I, B); if (I.err) return;
+        EV_TRY(balance = value_of(I, rw_value(I, r)));
+    }
+    Fr is_success, is_static;
+    is_success = call_context_lookup(I, CC_IsSuccess);
+    is_static = call_context_lookup(I, CC_IsStatic);  // is_zero(is_static): result discarded (:48)
+    (void)is_static;
+    Reversion rv; EV_TRY(rv = reversion_info(I));
+    const bool has_init_code = !fr_is_zero(size);
+    Fr next_mem, mem_gas; EV_TRY(memory_expansion(I, offset, size, next_mem, mem_gas));
+    Fr word_len; EV_TRY(word_len = constant_divmod_shift(I, fr_add_u64(size, 31), 5, 4));
+    const Fr gas_left = ev_curr(I, S_GAS);
+    Fr gas_cost = fr_add(fr_add_u64(mem_gas, 32000), fr_add(word_len, word_len));
+    if (is_create2) gas_cost = fr_add(gas_cost, fr_mul_u64(word_len, 6));
+    const Fr gas_available = fr_sub(gas_left, gas_cost);
+    Fr one_64th; EV_TRY(one_64th = constant_divmod_shift(I, gas_available, 6, 8));
+    const Fr all_but = fr_sub(gas_available, one_64th);
+    ev_require(I, fr_fits128(gas_left), ZK_OVERFLOW_ERROR); if (I.err) return;  // WordOrValue(gas_left).to_le_bytes()
+    const u32 is_u64_gas = fr_fits64(gas_left) ? 1u : 0u;
+    u32 lt, eq; EV_TRY(ev_compare(I, all_but, gas_left, 8, lt, eq));
+    const Fr capped = ev_select_b(I, lt) ? all_but : gas_left;
+    const Fr callee_gas_left = ev_select_b(I, is_u64_gas) ? capped : all_but;
+    u32 depth_ok; EV_TRY(ev_compare(I, depth, fr_u(1025), 2, depth_ok, eq));
+    I.seq++;  // Word(balance.n)
+    u32 insufficient, eqw;
+    EV_TRY(compare_word(I, word_from_u256(balance), value_w, insufficient, eqw));
+    u32 nonce_ok; EV_TRY(ev_compare(I, nonce_prev, fr_u(0xffffffffffffffffull), 8, nonce_ok, eq));
+    const bool precheck_ok = depth_ok == 1u && insufficient == 0u && nonce_ok == 1u;
+    const int sp_delta = 2 + (is_create2 ? 1 : 0);
+    bool nac = false;
+    if (precheck_ok) {
+        Word code_hash;
+        if (has_init_code) {
+            if (aux_kind(I) != 1u) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }  // curr.aux_data: a Word
+            code_hash = aux_word(I);
+        } else {
+            I.seq++;  // Word(EMPTY_CODE_HASH)
+            code_hash = word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+        }
+        Fr contract;
+        if (is_create) {
+            contract = keccak_create_address(caller, nonce);
+        } else {
+            U256 salt_v, hash_v;
+            EV_TRY(salt_v = int_value(I, salt_w));
+            EV_TRY(hash_v = int_value(I, code_hash));
+            contract = keccak_create2_address(caller, salt_v, hash_v);
+        }
+        I.seq++;  // address_to_word
+        const Word contract_w = word_of(fr_from_u128(fr_lo64(contract), fr_hi64of128(contract)), fr_u((u64)contract.v[4]));
+        {
+            RwQ W;
+            rwq_init(W, 1, TG_TxAccessListAccount);
+            rwq_set(W, R_ID, tx_id);
+            rwq_set(W, R_ADDR, contract);
+            rwq_set_word(W, R_VAL_LO, word_of(fr_u(1), fr_zero()));
+            u32 r; r = rw_lookup(I, W); if (I.err) return;
+            EV_TRY(value_of(I, rw_value_prev(I, r)));
+        }
+        Word callee_code_hash; callee_code_hash = account_read_word(I, contract, ACC_CodeHash); if (I.err) return;
+        Fr callee_nonce;
+        {
+            RwQ Q;
+            rwq_init(Q, 0, TG_Account);
+            rwq_set(Q, R_ADDR, contract);
+            rwq_set(Q, R_FT, fr_u(ACC_Nonce));
+            u32 r; r = rw_lookup(I, Q); if (I.err) return;
+            EV_TRY(callee_nonce = value_of(I, rw_value(I, r)));
+        }
+        I.seq += 2;  // Word(EMPTY_CODE_HASH), Word(0)
+        const Word empty_hash = word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+        nac = fr_is_zero(callee_nonce) && (is_equal_word(callee_code_hash, empty_hash) || is_equal_word(callee_code_hash, word_zero()));
+        if (nac) {
+            Fr ret_addr; EV_TRY(ret_addr = word_to_fq(I, ret_addr_w, 20));
+            constrain_equal(I, ret_addr, fr_mul(is_success, contract)); if (I.err) return;
+            Reversion crv; EV_TRY(crv = reversion_info(I, &callee_call_id));
+            constrain_equal(I, crv.persistent, fr_mul(rv.persistent, is_success)); if (I.err) return;
+            EV_TRY(balance_move(I, caller, value_w, crv, true));
+            EV_TRY(balance_move(I, contract, value_w, crv, false));
+            {
+                RwQ Q;
+                rwq_init(Q, 1, TG_Account);
+                rwq_set(Q, R_ADDR, contract);
+                rwq_set(Q, R_FT, fr_u(ACC_Nonce));
+                u32 r; r = rw_lookup(I, Q); if (I.err) return;
+                Fr n2; EV_TRY(n2 = value_of(I, rw_value(I, r)));
+                EV_TRY(value_of(I, rw_value_prev(I, r)));
+                constrain_equal(I, n2, fr_u(1)); if (I.err) return;
+            }
+            if (has_init_code) {
+                const Word next_hash = word_of(ev_next(I, S_CH_LO), ev_next(I, S_CH_HI));
+                CopyRes cr;
+                EV_TRY(cr = copy_lookup(I, word_value(I.call_id), CDT_Memory, next_hash, CDT_Bytecode, offset, fr_add(offset, size), fr_zero(),
+                                        size, fr_add_u64(I.rwc, I.rw_off)));
+                if (!(fr_fits64(cr.rwc_inc) && fr_lo64(cr.rwc_inc) < (1ull << 62))) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+                I.rw_off += fr_lo64(cr.rwc_inc);
+                Fr code_size; code_size = bytecode_length(I, next_hash, true);
+                constrain_equal(I, code_size, size); if (I.err) return;
+                {
+                    const u32 tags[5] = {CC_ProgramCounter, CC_StackPointer, CC_GasLeft, CC_MemorySize, CC_ReversibleWriteCounter};
+                    for (int k = 0; k < 5; k++) {
+                        Fr want;
+                        switch (k) {
+                        case 0: want = fr_add_u64(I.pc, 1); break;
+                        case 1: want = fr_add_u64(I.sp, (u64)sp_delta); break;
+                        case 2: want = fr_sub(fr_sub(gas_left, gas_cost), callee_gas_left); break;
+                        case 3: want = next_mem; break;
+                        default: want = fr_add_u64(ev_curr(I, S_REV), 1); break;
+                        }
+                        Fr v; v = call_context_lookup(I, tags[k], 1);
+                        constrain_equal(I, v, want); if (I.err) return;
+                    }
+                }
+                {
+                    const u32 tags[10] = {CC_CallerId, CC_TxId, CC_Depth, CC_CallerAddress, CC_CalleeAddress, CC_IsSuccess, CC_IsStatic, CC_IsRoot,
+                                          CC_IsCreate, CC_CodeHash};
+                    for (int k = 0; k < 10; k++) {
+                        Word want = word_zero();
+                        switch (k) {
+                        case 0: want = word_value(I.call_id); break;
+                        case 1: want = word_value(tx_id); break;
+                        case 2: want = word_value(fr_add_u64(depth, 1)); break;
+                        case 3: want = caller_w.w; break;
+                        case 4: want = contract_w; break;
+                        case 5: want = word_value(is_success); break;
+                        case 8: want = word_value(fr_u(1)); break;
+                        case 9: want = code_hash; break;
+                        default: break;
+                        }
+                        WordOrValue got; got = call_context_lookup_word(I, tags[k], 0, &callee_call_id);
+                        constrain_equal_word(I, got.w, want); if (I.err) return;
+                    }
+                }
+                transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+                transition(I, S_CALL_ID, t_to(callee_call_id));
+                transition(I, S_IS_ROOT, t_to(fr_zero()));
+                transition(I, S_IS_CREATE, t_to(fr_u(1)));
+                I.seq++;  // code_hash = Transition.to_word(next.code_hash)
+                transition(I, S_GAS, t_to(callee_gas_left));
+                transition(I, S_REV, t_to(fr_u(3)));
+                transition(I, S_LOG, t_same());
+                transition(I, S_PC, t_to(fr_zero()));
+                transition(I, S_SP, t_to(fr_u(1024)));
+                transition(I, S_MWS, t_to(fr_zero()));
+                if (I.err) return;
+            }
+        }
+    }
+    if (!precheck_ok || !nac || !has_init_code) {
+        if (!precheck_ok || !nac) { constrain_equal(I, is_success, fr_zero()); if (I.err) return; }
+        const u32 tags[3] = {CC_LastCalleeId, CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength};
+        for (int k = 0; k < 3; k++) {
+            Fr v; v = call_context_lookup(I, tags[k], 1);
+            constrain_equal(I, v, fr_zero()); if (I.err) return;
+        }
+        transition(I, S_RWC, t_delta(fr_u(I.rw_off)));
+        transition(I, S_PC, t_delta_i(1));
+        transition(I, S_SP, t_delta_i(sp_delta));
+        transition(I, S_REV, t_int((nac && !has_init_code) ? 3 : 0));
+        transition(I, S_GAS, t_delta(fr_neg(gas_cost)));
+        transition(I, S_MWS, t_to(next_mem));
+        transition(I, S_CALL_ID, t_same());
+        transition(I, S_IS_ROOT, t_same());
+        transition(I, S_IS_CREATE, t_same());
+        ev_require(I, fr_eq(ev_next(I, S_CH_LO), ev_curr(I, S_CH_LO)) && fr_eq(ev_next(I, S_CH_HI), ev_curr(I, S_CH_HI)));
+    }
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -2955,7 +3178,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
-    case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: return EVM_GROUP_COLD;
+    case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -3044,6 +3267,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_CREATE: case ES_CREATE2: if (G == EVM_GROUP_COLD) { g_create(I, T); } break;
     case ES_ErrorOutOfGasSloadSstore: if (G == EVM_GROUP_COLD) { g_error_oog_sload_sstore(I, T); } break;
     case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;
     case ES_ErrorOutOfGasCall: if (G == EVM_GROUP_COLD) { g_error_oog_call(I, T); } break;
