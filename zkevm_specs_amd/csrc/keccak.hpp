@@ -27,7 +27,8 @@ ZK_HD void keccak_f1600(u64 a[25]) {  // a[x + 5 * y]
     }
 }
 // digest of msg[0..len), len <= 135
-ZK_HD void keccak256_block(const uint8_t* msg, int len, uint8_t out[32]) {
+// out of line: three call sites, all on cold paths (keeps the compile time and the code size down)
+ZK_NOINLINE void keccak256_block(const uint8_t* msg, int len, uint8_t out[32]) {
     u64 a[25];
     for (int k = 0; k < 25; k++) a[k] = 0;
     for (int k = 0; k < len; k++) a[k >> 3] ^= (u64)msg[k] << (8 * (k & 7));
