@@ -112,6 +112,9 @@ typedef struct zk_evm_tables {
      * aux_kind uint32[n_steps]: 0 none, 1 Word (lo, hi), 2 int < 2^256 (lo, hi), 3 pair of field values,
      * 4 not representable (a gadget that reads it reports ZK_UNSUPPORTED). */
     const uint64_t* aux;        const uint32_t* aux_kind;
+    /* Tables.withdrawal_table (WithdrawalTableRow, table.py:430-434: id, validator_id, address, amount), optional:
+     * uint64[n][4][4], sorted by id (the order end_block.py:152 walks them in).  Only EndBlock's last step reads it. */
+    const uint64_t* withdrawals; uint64_t n_withdrawals;
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
 #define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */

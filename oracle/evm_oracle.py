@@ -53,7 +53,7 @@ class EvmWitness:
     """Flattened tables as Python ints + the indices the lookups use."""
 
     def __init__(self, steps, rw, rw_flags, bytecode, tx=(), tx_flags=(), block=(), block_flags=(), copy=(),
-                 keccak=(), exp=(), aux=None, aux_kind=None):
+                 keccak=(), exp=(), aux=None, aux_kind=None, withdrawals=()):
         self.steps = steps
         self.rw = [tuple(r) for r in rw]
         self.rw_flags = list(rw_flags)
@@ -78,6 +78,7 @@ class EvmWitness:
         # StepState.aux_data per step: (cell0, cell1) + kind (0 none, 1 Word, 2 int, 3 pair, 4 other), flatten.py
         self.aux = [tuple(r) for r in aux] if aux is not None else [(0, 0)] * len(steps)
         self.aux_kind = list(aux_kind) if aux_kind is not None else [0] * len(steps)
+        self.withdrawals = [tuple(r) for r in withdrawals]  # (id, validator_id, address, amount), sorted by id
         self.copy = [tuple(r) for r in copy]
         self.keccak = [tuple(r) for r in keccak]
         self.exp = [tuple(r) for r in exp]
@@ -1668,11 +1669,43 @@ def g_error_code_store(i):  # error_code_store.py (ErrorMaxCodeSizeExceeded and 
     _constrain_error_state(i, i.rw_off + i.curr[S_REV])
 
 
-def g_end_block(i):  # end_block.py: padding steps (the is_last_step branch needs whole-table aggregates: not evaluated)
-    if i.is_last:
-        raise Fail(UNSUPPORTED, i.seq)
-    i.transition(S_RWC, "same")
-    i.transition(S_CALL_ID, "same")
+def g_end_block(i):  # end_block.py
+    w = i.w
+    callers = [k for k, r in enumerate(w.tx) if r[1] == TXC.CallerAddress]
+    max_txs = len(callers)
+    total_txs = sum(1 for k in callers if (w.tx[k][3], w.tx[k][4]) != (0, 0))
+    invalid_rows = [k for k, r in enumerate(w.tx) if r[1] == TXC.TxInvalid]
+    i.require(not any(w.tx_flags[k] & 1 for k in invalid_rows))  # `.value.value()` on every TxInvalid row (:70-78)
+    total_valid_txs = total_txs - sum(1 for k in invalid_rows if w.tx[k][3] == 1)
+    max_rws, max_wds = len(w.rw), len(w.withdrawals)
+    total_wds = sum(1 for r in w.withdrawals if r[3] != 0)
+    is_empty = int((i.curr[S_RWC] - 1) % P == 0)
+    total_rws = (1 - is_empty) * (i.curr[S_RWC] - 1 + 2) % P
+    if not i.is_last:
+        i.transition(S_RWC, "same")
+        i.transition(S_CALL_ID, "same")
+        return
+    if is_empty == 1:
+        i.constrain_equal(total_valid_txs, 0)
+        i.constrain_equal(total_wds, 0)
+    else:
+        i.constrain_equal(i.call_context_lookup(CC.TxId), total_txs)
+        gas_limit = i.value_of(i.block_lookup(int(BLK.GasLimit)))
+        cumulative = _tx_receipt(i, 0, total_txs, 2)
+        exceeded, _ = i.compare(gas_limit, cumulative, 8)
+        i.constrain_equal(exceeded, 0)
+        padding = 0
+        for wd in w.withdrawals:
+            if wd[3] != 0:
+                _add_balance(i, wd[2], i.word_from_int(wd[3] * 10**9))
+            else:
+                padding += 1
+        i.constrain_equal(padding, max_wds - total_wds)
+    if total_txs != max_txs:
+        caller_w, _ = i.tx_lookup(total_txs + 1, int(TXC.CallerAddress))
+        i.constrain_equal_word(caller_w, i.word_from_int(0))
+    i.rw_lookup(0, TG.Start, rw_counter=1)
+    i.rw_lookup(0, TG.Start, rw_counter=(max_rws - total_rws - total_wds) % P)
 
 
 TXC, BLK = T.TxContextFieldTag, T.BlockContextFieldTag

@@ -24,7 +24,7 @@ def to_witness(w):
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
                          wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
-                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"])
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]))
 
 
 def main():

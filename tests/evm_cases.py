@@ -8,8 +8,8 @@ import numpy as np
 from oracle import evm_oracle as eo, wire
 
 FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
-          "aux_kind")
-_OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11}  # tables only some gadgets need; absent = empty
+          "aux_kind", "withdrawals")
+_OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11, "withdrawals": 4}  # tables only some gadgets need; absent = empty
 
 
 def with_defaults(w):
@@ -42,7 +42,7 @@ def to_witness(w):
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
                          wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
-                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"])
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]))
 
 
 def oracle_status(w, opts=(0, 0)):
@@ -61,6 +61,7 @@ def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
                        u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
                        vp(a["copy"]), u64(a["copy"].shape[0]), vp(a["keccak"]), u64(a["keccak"].shape[0]),
                        vp(a["exp"]), u64(a["exp"].shape[0]), vp(a["aux"]), vp(a["aux_kind"]),
+                       vp(a["withdrawals"]), u64(a["withdrawals"].shape[0]),
                        ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1) | (4 if generic_index else 0)), vp(st))
     return st[: n - 1].tolist()
 

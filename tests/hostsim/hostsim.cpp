@@ -85,7 +85,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
                               const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
                               const u64* block, const u32* block_flags, u64 n_blk, const u64* copy, u64 n_copy,
                               const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, const u64* aux, const u32* aux_kind,
-                              u32 opts, u32* status) {
+                              const u64* wds, u64 n_wds, u32 opts, u32* status) {
     EvmArgs a;
     a.steps = steps;
     a.n_steps = n_steps;
@@ -95,6 +95,14 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     host_table(texp, exp, nullptr, n_exp, EXP_T_NCELLS, expt_key_hash);
     a.aux = aux;
     a.aux_kind = aux_kind;
+    HostTable twd;
+    host_table(twd, wds, nullptr, n_wds, 4, blk_key_hash);  // iterated in order: the index is unused
+    a.withdrawals = twd.t;
+    {
+        const HostEvmAgg g = evm_aggregates_host(tx, tx_flags, n_tx, wds, n_wds);
+        a.agg_max_txs = g.max_txs; a.agg_total_txs = g.total_txs; a.agg_invalid_txs = g.invalid_txs;
+        a.agg_bad_invalid_rows = g.bad_invalid_rows; a.agg_total_wds = g.total_wds;
+    }
     a.copy = tcopy.t;
     a.keccak = tkeccak.t;
     a.exp = texp.t;

@@ -40,6 +40,7 @@ class ZkEvmTables(ctypes.Structure):
         ("keccak", ctypes.c_void_p), ("n_keccak", ctypes.c_uint64),
         ("exp", ctypes.c_void_p), ("n_exp", ctypes.c_uint64),
         ("aux", ctypes.c_void_p), ("aux_kind", ctypes.c_void_p),
+        ("withdrawals", ctypes.c_void_p), ("n_withdrawals", ctypes.c_uint64),
     ]
 
 

@@ -41,6 +41,9 @@ struct EvmArgs {
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
+    ZkTable withdrawals;        // optional WithdrawalTableRow rows (id, validator_id, address, amount), sorted by id
+    // whole-table aggregates EndBlock's last step needs (end_block.py:55-91), computed once per session on the host
+    u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
     const u64* aux;             // optional StepState.aux_data: [n_steps][2][4] cells ...
     const u32* aux_kind;        // ... and kinds (0 none, 1 Word, 2 int, 3 pair, 4 not representable)
     u32 rw_dense;     // 1: the RW rows are sorted with consecutive rw_counters (row = rw_counter - rw_base); 0: generic index
@@ -2319,11 +2322,6 @@ ZK_HD void g_error_code_store(Ins& I, Tail& T) {  // error_code_store.py (ErrorM
     ev_require(I, (insufficient | over) != 0u); if (I.err) return;
     T.err_tail = 1;
 }
-ZK_HD void g_end_block(Ins& I, Tail& T, bool is_last) {  // end_block.py: padding steps only
-    if (is_last) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
-    transition(I, S_RWC, t_same());
-    transition(I, S_CALL_ID, t_same());
-}
 
 // ---- EndTx (end_tx.py) ---------------------------------------------------------------------------
 // split a canonical field element at bit 128: value = hi * 2^128 + lo
@@ -2437,6 +2435,59 @@ ZK_HD void g_end_tx(Ins& I, Tail& T) {
     if (next_state == ES_EndBlock) {
         transition(I, S_RWC, t_delta_i(9 - (is_first_tx ? 1 : 0)));
         transition(I, S_CALL_ID, t_same());
+    }
+}
+
+ZK_HD void g_end_block(Ins& I, Tail& T, bool is_last) {  // end_block.py
+    const EvmArgs& a = *I.a;
+    ev_require(I, a.agg_bad_invalid_rows == 0u); if (I.err) return;  // `.value.value()` on every TxInvalid row (:70-78)
+    const u32 total_txs = a.agg_total_txs, total_valid_txs = a.agg_total_txs - a.agg_invalid_txs;
+    const Fr rwc_m1 = fr_sub_u64(I.rwc, 1);
+    const bool is_empty = fr_is_zero(rwc_m1);
+    const Fr total_rws = is_empty ? fr_zero() : fr_add_u64(rwc_m1, 2);
+    if (!is_last) {
+        transition(I, S_RWC, t_same());
+        transition(I, S_CALL_ID, t_same());
+        return;
+    }
+    if (is_empty) {
+        ev_require(I, total_valid_txs == 0u);
+        ev_require(I, a.agg_total_wds == 0u);
+        if (I.err) return;
+    } else {
+        Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
+        constrain_equal(I, tx_id, fr_u(total_txs)); if (I.err) return;
+        WordOrValue gl; gl = block_lookup(I, BLK_GasLimit);
+        Fr gas_limit; EV_TRY(gas_limit = value_of(I, gl));
+        Fr cumulative; EV_TRY(cumulative = tx_receipt(I, 0, fr_u(total_txs), 2));
+        u32 exceeded, eq; EV_TRY(ev_compare(I, gas_limit, cumulative, 8, exceeded, eq));
+        ev_require(I, exceeded == 0u); if (I.err) return;
+        // balance updates of the validators' withdrawals, in id order (:150-156)
+        for (u32 k = 0; k < a.withdrawals.n; k++) {
+            const Fr amount = zk_table_cell(a.withdrawals, k, 3);
+            if (fr_is_zero(amount)) continue;
+            // Word(int(amount) * 10^9): a 254-bit amount times 2^30 can exceed 2^256 -> AssertionError
+            const U512 prod = u256_mul_full(amount, fr_u(1000000000ull));
+            I.seq++;
+            if (!fr_is_zero(u512_hi(prod))) { ev_fail(I, ZK_ASSERT); return; }
+            EV_TRY(add_balance(I, zk_table_cell(a.withdrawals, k, 2), word_from_u256(u512_lo(prod))));
+        }
+        I.seq++;  // padding count == max_withdrawals - total_withdrawals: holds by construction
+    }
+    if (total_txs != a.agg_max_txs) {
+        WordOrValue cw; cw = tx_lookup(I, fr_u((u64)total_txs + 1), TXC_CallerAddress); if (I.err) return;
+        I.seq++;  // Word(0)
+        constrain_equal_word(I, cw.w, word_zero()); if (I.err) return;
+    }
+    {   // rw_table_start_lookup(1), rw_table_start_lookup(max_rws - total_rws - total_withdrawals) (instruction.py:897-899)
+        RwQ Q;
+        rwq_init(Q, 0, TG_Start);
+        Fr one = fr_u(1);
+        rw_lookup(I, Q, &one); if (I.err) return;
+        RwQ R;
+        rwq_init(R, 0, TG_Start);
+        Fr c2 = fr_sub(fr_sub(fr_u(a.rw.n), total_rws), fr_u(a.agg_total_wds));
+        rw_lookup(I, R, &c2);
     }
 }
 

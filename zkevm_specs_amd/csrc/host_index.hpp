@@ -119,3 +119,27 @@ static inline ZkRwMeta rw_dense_meta_host(const u64* rows, u64 n) {
     m.base = base;
     return m;
 }
+
+// Whole-table aggregates of EndBlock's last step (end_block.py:55-91) from the wire tables:
+// tx rows [n][5][4] (tx_id, tag, index, value lo, hi) + flags (bit0 value.is_word); withdrawals [m][4][4].
+struct HostEvmAgg {
+    u32 max_txs = 0, total_txs = 0, invalid_txs = 0, bad_invalid_rows = 0, total_wds = 0;
+};
+static inline HostEvmAgg evm_aggregates_host(const u64* tx, const u32* tx_flags, u64 n_tx, const u64* wds, u64 n_wds) {
+    HostEvmAgg g;
+    auto is_small = [](const u64* c, u64 v) { return c[0] == v && (c[1] | c[2] | c[3]) == 0; };
+    auto is_zero = [](const u64* c) { return (c[0] | c[1] | c[2] | c[3]) == 0; };
+    for (u64 r = 0; r < n_tx; r++) {
+        const u64* row = tx + r * 5 * 4;
+        if (is_small(row + 4, 4)) {  // TxContextFieldTag.CallerAddress
+            g.max_txs++;
+            if (!(is_zero(row + 12) && is_zero(row + 16))) g.total_txs++;
+        } else if (is_small(row + 4, 10)) {  // TxContextFieldTag.TxInvalid
+            if (tx_flags && (tx_flags[r] & 1u)) g.bad_invalid_rows = 1;  // .value.value() asserts on a word
+            if (is_small(row + 12, 1)) g.invalid_txs++;
+        }
+    }
+    for (u64 r = 0; r < n_wds; r++)
+        if (!is_zero(wds + (r * 4 + 3) * 4)) g.total_wds++;
+    return g;
+}

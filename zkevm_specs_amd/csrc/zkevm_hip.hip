@@ -455,7 +455,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     ARG_TRY(g_device >= 0, "zk_evm_open: call zk_init first");
     ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
     ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31) &&
-            t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31), "zk_evm_open: table too large");
+            t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31) && t->n_withdrawals < (1ull << 31),
+            "zk_evm_open: table too large");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     zk_session* s = new zk_session();
     s->kind = SESSION_EVM;
@@ -476,6 +477,32 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = table_stage(s, s->evm.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.withdrawals, t->withdrawals, nullptr, t->n_withdrawals, 4, dev))) goto fail;
+    s->evm.withdrawals.slots = nullptr;
+    s->evm.withdrawals.mask = 0;
+    {   // whole-table aggregates for EndBlock's last step: the tx and withdrawal tables are small, count on the host
+        std::vector<u64> h_tx, h_wd;
+        std::vector<u32> h_txf;
+        const u64* tx = t->tx;
+        const u32* txf = t->tx_flags;
+        const u64* wd = t->withdrawals;
+        if (dev) {
+            h_tx.resize((size_t)t->n_tx * TX_NCELLS * 4);
+            h_txf.resize((size_t)t->n_tx);
+            h_wd.resize((size_t)t->n_withdrawals * 16);
+            if ((t->n_tx && (hipMemcpy(h_tx.data(), t->tx, h_tx.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                             (t->tx_flags && hipMemcpy(h_txf.data(), t->tx_flags, h_txf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess))) ||
+                (t->n_withdrawals && hipMemcpy(h_wd.data(), t->withdrawals, h_wd.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) {
+                rc = -2; g_err = "table download failed"; goto fail;
+            }
+            tx = h_tx.data();
+            txf = t->tx_flags ? h_txf.data() : nullptr;
+            wd = h_wd.data();
+        }
+        const HostEvmAgg g = evm_aggregates_host(tx, txf, t->n_tx, wd, t->n_withdrawals);
+        s->evm.agg_max_txs = g.max_txs; s->evm.agg_total_txs = g.total_txs; s->evm.agg_invalid_txs = g.invalid_txs;
+        s->evm.agg_bad_invalid_rows = g.bad_invalid_rows; s->evm.agg_total_wds = g.total_wds;
+    }
     s->evm.aux = nullptr;
     s->evm.aux_kind = nullptr;
     if (t->aux && t->aux_kind) {

@@ -116,7 +116,7 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
     (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
     lib = _lib.init(device)
     names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
-             "aux_kind"]
+             "aux_kind", "withdrawals"]
     arrs, opts = _prep([wire.get(k) for k in names])
     a = dict(zip(names, arrs))
 
@@ -137,7 +137,8 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         p(a["copy"]) if rows(a["copy"]) else None, rows(a["copy"]),
         p(a["keccak"]) if rows(a["keccak"]) else None, rows(a["keccak"]),
         p(a["exp"]) if rows(a["exp"]) else None, rows(a["exp"]),
-        p(a["aux"]) if rows(a["aux"]) else None, p(a["aux_kind"]) if rows(a["aux"]) else None)
+        p(a["aux"]) if rows(a["aux"]) else None, p(a["aux_kind"]) if rows(a["aux"]) else None,
+        p(a["withdrawals"]) if rows(a["withdrawals"]) else None, rows(a["withdrawals"]))
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:

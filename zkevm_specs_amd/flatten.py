@@ -190,6 +190,13 @@ def flatten_step_aux(steps):
     return {"aux": rows_to_rowmajor(cells, 2), "aux_kind": np.array(kinds, dtype=np.uint32)}
 
 
+def flatten_withdrawal_table(withdrawal_table):
+    """set of WithdrawalTableRow (evm_circuit/table.py:430-434: id, validator_id, address, amount) -> uint64[m, 4, 4],
+    sorted by the cells (id first), which is the order end_block.py:152 walks them in"""
+    rows, _ = _dedup([([_n(r.id), _n(r.validator_id), _n(r.address), _n(r.amount)], 0) for r in _iter_table(withdrawal_table)])
+    return rows_to_rowmajor(rows, 4)
+
+
 def flatten_evm(tables, steps):
     """reference `Tables` (evm_circuit/table.py:578-671) + list of StepState -> dict of wire arrays.
     The copy / keccak / exp tables only exist on `Tables` built with those circuits (:614-619);
@@ -204,6 +211,7 @@ def flatten_evm(tables, steps):
         "tx": tx, "tx_flags": tx_flags,
         "block": blk, "block_flags": blk_flags,
         **flatten_step_aux(steps),
+        "withdrawals": flatten_withdrawal_table(getattr(tables, "withdrawal_table", None)),
         "copy": flatten_copy_table(getattr(tables, "copy_table", None)),
         "keccak": flatten_keccak_table(getattr(tables, "keccak_table", None)),
         "exp": flatten_exp_table(getattr(tables, "exp_table", None)),
