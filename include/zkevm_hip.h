@@ -40,6 +40,7 @@ enum zk_kind {
     ZK_KIND_VALUE_ERROR = 9,
     ZK_KIND_ZERO_DIVISION = 10,
     ZK_KIND_INDEX_ERROR = 12,
+    ZK_KIND_ATTRIBUTE_ERROR = 13,
     ZK_KIND_NAME_ERROR = 11,          /* UnboundLocalError (execution/block_ctx.py:24) */
     ZK_KIND_UNSUPPORTED = 15          /* gadget not implemented by this engine */
 };

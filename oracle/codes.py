@@ -12,6 +12,7 @@ VALUE_ERROR = 9
 ZERO_DIVISION = 10
 NAME_ERROR = 11
 INDEX_ERROR = 12
+ATTRIBUTE_ERROR = 13
 UNSUPPORTED = 15
 
 KIND_NAMES = {
@@ -19,7 +20,8 @@ KIND_NAMES = {
     LOOKUP_UNSAT: "LookupUnsatFailure", LOOKUP_AMBIGUOUS: "LookupAmbiguousFailure",
     WRONG_QUERY_KEY: "WrongQueryKey", NOT_IMPLEMENTED: "NotImplementedError",
     TYPE_ERROR: "TypeError", OVERFLOW_ERROR: "OverflowError", VALUE_ERROR: "ValueError",
-    ZERO_DIVISION: "ZeroDivisionError", NAME_ERROR: "NameError", INDEX_ERROR: "IndexError", UNSUPPORTED: "Unsupported",
+    ZERO_DIVISION: "ZeroDivisionError", NAME_ERROR: "NameError", INDEX_ERROR: "IndexError", ATTRIBUTE_ERROR: "AttributeError",
+    UNSUPPORTED: "Unsupported",
 }
 NAME_TO_KIND = {v: k for k, v in KIND_NAMES.items()}
 

@@ -12,6 +12,7 @@ Pinned against the reference itself by oracle/gen_golden_evm.py (tests/golden/ev
 """
 from .codes import (ASSERT, CONSTRAINT, LOOKUP_AMBIGUOUS, LOOKUP_UNSAT, NAME_ERROR, NOT_IMPLEMENTED, OK, OVERFLOW_ERROR,
                     UNSUPPORTED, VALUE_ERROR, ZERO_DIVISION, Fail)
+from .codes import ATTRIBUTE_ERROR
 from .wire import P
 from . import keccak as _keccak
 
@@ -37,6 +38,9 @@ _VALID_OPCODES = {int(o) for o in OP}
 _CONST_GAS = {int(OP[k]): v[1] for k, v in T.OPCODES.items()}
 _DYNAMIC_GAS = {int(OP[k]): v[2] for k, v in T.OPCODES.items()}
 _STACK_BOUNDS = {int(OP[k]): v for k, v in T.STACK_BOUNDS.items()}
+_PRECOMPILE_BASE_GAS = {1: ("ECRECOVER", 3000), 2: ("SHA256", 60), 3: ("RIPEMD160", 600), 4: ("DATACOPY", 15), 5: ("BIGMODEXP", 0),
+                        6: ("BN254_ADD", 150), 7: ("BN254_SCALAR_MUL", 6000), 8: ("BN254_PAIRING", 45000), 9: ("BLAKE2F", 0)}
+_PRECOMPILE_INFO = {(int(ES[n]), a, g) for a, (n, g) in _PRECOMPILE_BASE_GAS.items()}
 _STATE_WRITE_OPCODES = {int(OP[k]) for k in "SSTORE LOG0 LOG1 LOG2 LOG3 LOG4 CREATE CALL CREATE2 SELFDESTRUCT".split()}
 _RESP = {}
 for _s, _ops in T.RESPONSIBLE.items():
@@ -305,6 +309,8 @@ class Ins:
                 ok = v2 < mn or mx + 1 <= v2 <= 1024
             elif v0 == ES.ErrorWriteProtection:  # opcode.py:395-407
                 ok = v2 == 0 and v1 in _STATE_WRITE_OPCODES
+        elif tag == F.PrecompileInfo:  # precompile.py:46-70: (execution state, address, base gas)
+            ok = (v0, v1, v2) in _PRECOMPILE_INFO
         elif tag == F.OpcodeConstantGas:  # opcode.py:387-392
             ok = v2 == 0 and v0 in _VALID_OPCODES and not _DYNAMIC_GAS[v0] and _CONST_GAS[v0] > 0 and v1 == _CONST_GAS[v0]
         elif tag == F.Pow2:
@@ -1398,10 +1404,11 @@ def g_sstore(i):  # storage.py:50-153
                    reversible_write_counter=D(3), dynamic_gas_cost=dyn)
 
 
-def _restore_context(i, rw_counter_delta, gas_left, return_data_offset=0, return_data_length=0):
-    """step_state_transition_to_restored_context (instruction.py:292-363, caller_id=None form)"""
-    rw_counter_delta += 12
-    caller_id = i.call_context_lookup(CC.CallerId)
+def _restore_context(i, rw_counter_delta, gas_left, return_data_offset=0, return_data_length=0, caller_id=None):
+    """step_state_transition_to_restored_context (instruction.py:292-363)"""
+    rw_counter_delta += 11 + int(caller_id is None)
+    if caller_id is None:
+        caller_id = i.call_context_lookup(CC.CallerId)
     saved = [i.call_context_lookup_word(t, call_id=caller_id) for t in (
         CC.IsRoot, CC.IsCreate, CC.CodeHash, CC.ProgramCounter, CC.StackPointer, CC.GasLeft, CC.MemorySize,
         CC.ReversibleWriteCounter)]
@@ -2219,6 +2226,46 @@ def g_create(i):  # create.py (CREATE and CREATE2)
         i.require(i.next[S_CH_LO] == i.curr[S_CH_LO] and i.next[S_CH_HI] == i.curr[S_CH_HI])
 
 
+def g_datacopy(i):  # dataCopy.py (the identity precompile)
+    addr_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    address = i.word_to_fq(addr_w, 20)
+    i.fixed_lookup(T.FixedTableTag.PrecompileInfo, i.curr[S_STATE], address, 15)
+    caller_id = i.call_context_lookup(CC.CallerId)
+    cd_offset = i.call_context_lookup(CC.CallDataOffset)
+    cd_length = i.call_context_lookup(CC.CallDataLength)
+    rd_offset = i.call_context_lookup(CC.ReturnDataOffset)
+    rd_length = i.call_context_lookup(CC.ReturnDataLength)
+    size = cd_length
+    gas_cost = (15 + i.memory_copier_gas_cost(cd_length, 0, 3)) % P
+    # the second copy's `length` argument really is return_data_offset + return_data_length (:41-51)
+    inc, _ = i.copy_lookup((caller_id, 0), CDT_MEMORY, (caller_id, 0), CDT_MEMORY, cd_offset, cd_offset + size, rd_offset,
+                           rd_offset + rd_length, i.curr[S_RWC] + i.rw_off)
+    i.copy_lookup((caller_id, 0), CDT_MEMORY, (i.curr[S_CALL_ID], 0), CDT_MEMORY, cd_offset, cd_offset + size, 0, rd_length,
+                  i.curr[S_RWC] + i.rw_off + inc)
+    if size % P >= 1 << 60:
+        raise Fail(UNSUPPORTED, i.seq)  # rw_counter_offset += 4 * int(size): kept in 64 bits on the device
+    i.rw_off += 4 * (size % P)
+    _restore_context(i, i.rw_off, (i.curr[S_GAS] - gas_cost) % P, 0, size, caller_id=caller_id)
+
+
+def g_error_oog_precompile(i):  # precompiles/error_oog_precompile.py
+    addr_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    address = i.word_to_fq(addr_w, 20)
+    calldata_len = i.call_context_lookup(CC.CallDataLength)
+    i.constrain_equal(int(1 <= address <= 9), 1)
+    gas_cost = _PRECOMPILE_BASE_GAS[address][1]
+    if address == 8:  # BN254PAIRING: pairs = calldata_len / 192 in the field
+        gas_cost += 34000 * (calldata_len * pow(192, -1, P) % P)
+    elif address == 4:  # DATACOPY
+        gas_cost += i.memory_copier_gas_cost(calldata_len, 0, 3)
+    else:
+        # the base cost stays a plain int and compare() calls .expr() on it (:33): AttributeError for every other
+        # precompile -- after compare's own check of the left operand (instruction.py:447-451)
+        i.cp()
+        i.fail(ATTRIBUTE_ERROR if i.curr[S_GAS] < 256**8 else ASSERT)
+    _oog_tail(i, gas_cost % P)
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -2253,7 +2300,7 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.DATACOPY: g_datacopy, ES.ErrorOutOfGasPrecompile: g_error_oog_precompile, ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

@@ -41,6 +41,10 @@ def main():
             from oracle.gen_golden_evm import end_block_padding_cases
 
             all_cases = end_block_padding_cases()
+        elif name == "error_oog_precompile_custom":
+            from oracle.gen_golden_evm import error_oog_precompile_cases
+
+            all_cases = error_oog_precompile_cases()
         else:
             h = Harvest()
             rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null",

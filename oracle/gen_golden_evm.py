@@ -29,7 +29,7 @@ calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_j
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
 error_return_data_out_of_bound error_write_protection logs return_revert
-error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block""".split()
+error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom""".split()
 MAX_CASES_PER_FILE = 48
 
 
@@ -205,6 +205,40 @@ def end_block_padding_cases():
     return cases
 
 
+def error_oog_precompile_cases():
+    """ErrorOutOfGasPrecompile (precompiles/error_oog_precompile.py) has no test in the reference's suite: these
+    witnesses are evaluated by the unmodified reference here, like every other golden case.  The state is not in the
+    reference's halts_in_exception list, so a root call cannot move on to EndTx (instruction.py:189-204): the valid
+    cases are internal calls that restore the caller's context."""
+    from zkevm_specs.evm_circuit import CallContextFieldTag as C, ExecutionState, RWDictionary, StepState, Tables
+    from zkevm_specs.util import Word
+
+    cases = []
+    code_hash = Word(0x1234567890ABCDEF << 130 | 0x42)
+    for address, calldata_len, gas_left, rev, is_root in ((4, 64, 10, 0, False), (4, 0, 14, 3, False), (8, 192, 78999, 0, False),
+                                                          (8, 384, 112999, 1, False), (1, 128, 2999, 0, False), (6, 128, 149, 2, False),
+                                                          (4, 64, 21, 0, False), (12, 64, 1, 0, False), (4, 64, 10, 0, True)):
+        rw = (RWDictionary(9).call_context_read(2, C.CalleeAddress, Word(address)).call_context_read(2, C.CallDataLength, calldata_len)
+              .call_context_read(2, C.IsSuccess, 0))
+        if is_root:
+            nxt = StepState(ExecutionState.EndTx, rw_counter=12 + rev, call_id=2, is_root=True)
+        else:
+            rw = (rw.call_context_read(2, C.CallerId, 1).call_context_read(1, C.IsRoot, 1).call_context_read(1, C.IsCreate, 0)
+                  .call_context_read(1, C.CodeHash, code_hash).call_context_read(1, C.ProgramCounter, 77)
+                  .call_context_read(1, C.StackPointer, 1000).call_context_read(1, C.GasLeft, 5000)
+                  .call_context_read(1, C.MemorySize, 3).call_context_read(1, C.ReversibleWriteCounter, 6)
+                  .call_context_write(1, C.LastCalleeId, 2).call_context_write(1, C.LastCalleeReturnDataOffset, 0)
+                  .call_context_write(1, C.LastCalleeReturnDataLength, 0))
+            nxt = StepState(ExecutionState.PUSH, rw_counter=9 + 3 + rev + 12, call_id=1, is_root=True, is_create=False,
+                            code_hash=code_hash, program_counter=77, stack_pointer=1000, gas_left=5000, memory_word_size=3,
+                            reversible_write_counter=6)
+        tables = Tables(block_table=set(), tx_table=set(), withdrawal_table=set(), bytecode_table=set(), rw_table=set(rw.rws))
+        steps = [StepState(ExecutionState.ErrorOutOfGasPrecompile, rw_counter=9, call_id=2, is_root=is_root, gas_left=gas_left,
+                           reversible_write_counter=rev), nxt]
+        cases.append((f"error_oog_precompile[{address}-{calldata_len}-{gas_left}-{rev}-{is_root}]", tables, steps, False, False, None))
+    return cases
+
+
 def main():
     from zkevm_specs_amd.flatten import flatten_evm
 
@@ -218,6 +252,8 @@ def main():
         rng = random.Random(hash(name) % 1000 + 20240807) if False else random.Random(sum(map(ord, name)) + 20240807)
         if name == "end_block_padding":
             cases = end_block_padding_cases()
+        elif name == "error_oog_precompile_custom":
+            cases = error_oog_precompile_cases()
         else:
             path = os.path.join(REF_TESTS, f"test_{name}.py")
             h = Harvest()
@@ -231,7 +267,7 @@ def main():
         for tid, tables, steps, begin, end, success in cases:
             wire = flatten_evm(tables, steps)
             kinds = ref_step_outcomes(tables, steps, begin, end)
-            assert success != any(kinds), (tid, kinds)  # a test expects a failure iff one of its step pairs fails
+            assert success is None or success != any(kinds), (tid, kinds)  # a test expects a failure iff a step pair fails
             # sanity: the unflattened witness behaves identically
             t2, s2 = unflatten(wire)
             assert ref_step_outcomes(t2, s2, begin, end) == kinds, tid

@@ -26,6 +26,7 @@ enum ZkKind : u32 {
     ZK_VALUE_ERROR = 9,       // ValueError (enum ctor, bytes() out of range)
     ZK_ZERO_DIVISION = 10,    // ZeroDivisionError
     ZK_INDEX_ERROR = 12,      // IndexError (tx rows shorter than MAX_TXS * 12)
+    ZK_ATTRIBUTE_ERROR = 13,  // AttributeError (error_oog_precompile.py:33 calls .expr() on a plain int gas cost)
     ZK_NAME_ERROR = 11,       // NameError / UnboundLocalError (block_ctx.py:24 with a foreign opcode)
     ZK_UNSUPPORTED = 15,      // engine limitation: state/gadget not implemented on device
 };

@@ -560,6 +560,13 @@ ZK_HD void fixed_lookup(Ins& I, u32 tag, const Fr& v0, const Fr& v1, const Fr& v
         }
         break;
     }
+    case FX_PrecompileInfo: {  // precompile.py:46-70: (execution state, address, base gas)
+        static const uint8_t pstate[10] = {0, ES_ECRECOVER, ES_SHA256, ES_RIPEMD160, ES_DATACOPY, ES_BIGMODEXP, ES_BN254_ADD, ES_BN254_SCALAR_MUL,
+                                           ES_BN254_PAIRING, ES_BLAKE2F};
+        static const uint16_t pgas[10] = {0, 3000, 60, 600, 15, 0, 150, 6000, 45000, 0};
+        ok = fr_le_u64(v1, 9) && y >= 1 && fr_eq_u64(v0, pstate[y]) && fr_eq_u64(v2, pgas[y]);
+        break;
+    }
     case FX_OpcodeConstantGas: {  // opcode.py:387-392
         static const uint8_t valid[256] = ZK_OPCODE_VALID_INIT;
         static const uint8_t dyn[256] = ZK_OPCODE_DYNAMIC_GAS_INIT;
@@ -1979,9 +1986,11 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
 
 // step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
 ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_left, const Fr& rd_offset = fr_zero(),
-                           const Fr& rd_length = fr_zero()) {
-    const Fr rw_counter_delta = fr_add_u64(rw_counter_delta_in, 12);
-    Fr caller_id; caller_id = call_context_lookup(I, CC_CallerId);
+                           const Fr& rd_length = fr_zero(), const Fr* caller_id_in = nullptr) {
+    const Fr rw_counter_delta = fr_add_u64(rw_counter_delta_in, caller_id_in ? 11 : 12);
+    Fr caller_id;
+    if (caller_id_in) caller_id = *caller_id_in;
+    else caller_id = call_context_lookup(I, CC_CallerId);
     const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
                          CC_MemorySize, CC_ReversibleWriteCounter};
     WordOrValue saved[8];
@@ -3160,6 +3169,63 @@ ZK_HD void g_create(Ins& I, Tail& T) {
     }
 }
 
+// ---- DATACOPY precompile (dataCopy.py) and ErrorOutOfGasPrecompile (precompiles/error_oog_precompile.py) ----
+// memory_copier_gas_cost(length, 0, per_word) (instruction.py:1183-1192)
+ZK_HD Fr copier_gas_only(Ins& I, const Fr& length, u32 per_word) {
+    Fr words = constant_divmod_shift(I, fr_add_u64(length, 31), 5, 4);
+    Fr gas = fr_mul_u64(words, per_word);
+    range_check(I, gas, 8);
+    return gas;
+}
+ZK_HD void g_datacopy(Ins& I, Tail& T) {
+    WordOrValue aw; aw = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr address; EV_TRY(address = word_to_fq(I, aw.w, 20));
+    fixed_lookup(I, FX_PrecompileInfo, ev_curr(I, S_STATE), address, fr_u(15)); if (I.err) return;
+    Fr caller_id, cd_offset, cd_length, rd_offset, rd_length;
+    caller_id = call_context_lookup(I, CC_CallerId);
+    cd_offset = call_context_lookup(I, CC_CallDataOffset);
+    cd_length = call_context_lookup(I, CC_CallDataLength);
+    rd_offset = call_context_lookup(I, CC_ReturnDataOffset);
+    rd_length = call_context_lookup(I, CC_ReturnDataLength);
+    if (I.err) return;
+    const Fr size = cd_length;
+    Fr copier; EV_TRY(copier = copier_gas_only(I, cd_length, 3));
+    const Fr gas_cost = fr_add_u64(copier, 15);
+    // the first copy's `length` argument really is return_data_offset + return_data_length (:41-51)
+    CopyRes cr;
+    EV_TRY(cr = copy_lookup(I, word_value(caller_id), CDT_Memory, word_value(caller_id), CDT_Memory, cd_offset, fr_add(cd_offset, size), rd_offset,
+                            fr_add(rd_offset, rd_length), fr_add_u64(I.rwc, I.rw_off)));
+    CopyRes cr2;
+    EV_TRY(cr2 = copy_lookup(I, word_value(caller_id), CDT_Memory, word_value(I.call_id), CDT_Memory, cd_offset, fr_add(cd_offset, size), fr_zero(),
+                             rd_length, fr_add(fr_add_u64(I.rwc, I.rw_off), cr.rwc_inc)));
+    if (!(fr_fits64(size) && fr_lo64(size) < (1ull << 60))) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    I.rw_off += 4 * fr_lo64(size);
+    restore_context(I, fr_u(I.rw_off), fr_sub(ev_curr(I, S_GAS), gas_cost), fr_zero(), size, &caller_id);
+}
+ZK_HD void g_error_oog_precompile(Ins& I, Tail& T) {
+    WordOrValue aw; aw = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr address; EV_TRY(address = word_to_fq(I, aw.w, 20));
+    Fr calldata_len; calldata_len = call_context_lookup(I, CC_CallDataLength); if (I.err) return;
+    const bool is_pre = fr_fits64(address) && fr_lo64(address) >= 1 && fr_lo64(address) <= 9;
+    ev_require(I, is_pre); if (I.err) return;
+    static const uint16_t pgas[10] = {0, 3000, 60, 600, 15, 0, 150, 6000, 45000, 0};
+    const u32 av = address.v[0];
+    Fr gas_cost = fr_u(pgas[av]);
+    if (av == 8u) {  // BN254PAIRING: pairs = calldata_len / 192 in the field
+        gas_cost = fr_add(gas_cost, fr_mul_u64(fr_mulc(calldata_len, frm_inv192()), 34000));
+    } else if (av == 4u) {  // DATACOPY
+        Fr copier; EV_TRY(copier = copier_gas_only(I, calldata_len, 3));
+        gas_cost = fr_add(gas_cost, copier);
+    } else {
+        // the base cost stays a plain int and compare() calls .expr() on it (:33): AttributeError for every other
+        // precompile -- after compare's own check of the left operand (instruction.py:447-451)
+        I.seq++;
+        ev_fail(I, fr_fits64(ev_curr(I, S_GAS)) ? ZK_ATTRIBUTE_ERROR : ZK_ASSERT);
+        return;
+    }
+    oog_tail(T, gas_cost);
+}
+
 // ExecutionState transition constraint (instruction.py:189-204)
 ZK_HD bool state_bit(u64 lo, u64 hi, u32 state) {  // bit `state` of a 128-bit immediate
     return state < 64 ? ((lo >> state) & 1ull) : (state < 128 ? ((hi >> (state - 64)) & 1ull) : 0ull);
@@ -3229,7 +3295,8 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
-    case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: return EVM_GROUP_COLD;
+    case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: case ES_DATACOPY:
+    case ES_ErrorOutOfGasPrecompile: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -3318,6 +3385,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
+    case ES_DATACOPY: if (G == EVM_GROUP_COLD) { g_datacopy(I, T); } break;
+    case ES_ErrorOutOfGasPrecompile: if (G == EVM_GROUP_COLD) { g_error_oog_precompile(I, T); } break;
     case ES_CREATE: case ES_CREATE2: if (G == EVM_GROUP_COLD) { g_create(I, T); } break;
     case ES_ErrorOutOfGasSloadSstore: if (G == EVM_GROUP_COLD) { g_error_oog_sload_sstore(I, T); } break;
     case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;

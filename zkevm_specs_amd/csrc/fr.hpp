@@ -53,6 +53,7 @@ FR_CONST_ARR(frm_inv_2p128, FRM_INV_2P128_LIMBS)
 FR_CONST_ARR(frm_inv2, FRM_INV2_LIMBS)
 FR_CONST_ARR(frm_inv4, FRM_INV4_LIMBS)
 FR_CONST_ARR(frm_inv8, FRM_INV8_LIMBS)
+FR_CONST_ARR(frm_inv192, FRM_INV192_LIMBS)
 
 ZK_HD Fr fr_zero() {
     Fr r;

@@ -36,7 +36,7 @@ KIND_VALUE_ERROR, KIND_ZERO_DIVISION, KIND_NAME_ERROR, KIND_INDEX_ERROR, KIND_UN
 KIND_NAMES = {
     0: "ok", 1: "AssertionError", 2: "ConstraintUnsatFailure", 3: "LookupUnsatFailure",
     4: "LookupAmbiguousFailure", 5: "WrongQueryKey", 6: "NotImplementedError", 7: "TypeError",
-    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 11: "UnboundLocalError", 12: "IndexError", 15: "UnsupportedOnDevice",
+    8: "OverflowError", 9: "ValueError", 10: "ZeroDivisionError", 11: "UnboundLocalError", 12: "IndexError", 13: "AttributeError", 15: "UnsupportedOnDevice",
 }
 
 
@@ -67,6 +67,8 @@ def exception_for_code(code, where=""):
         return UnboundLocalError(msg)
     if kind == KIND_INDEX_ERROR:
         return IndexError(msg)
+    if kind == 13:
+        return AttributeError(msg)
     if kind == KIND_UNSUPPORTED:
         return UnsupportedOnDevice(msg)
     return RuntimeError(f"{msg} (unknown kind {kind})")
