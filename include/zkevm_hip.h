@@ -176,6 +176,25 @@ typedef struct zk_sign_units {
 int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** out);
 int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* status_out, zk_result* result);
 
+/* ---- Keccak table generation: one table row per byte string.
+ *      mode 0 = KeccakCircuit.add (evm_circuit/typing.py:854-865; assign_keccak_table,
+ *               bytecode_circuit.py:182-186): row = (2, RLC(reversed(data), r), len, Word(int.from_bytes(digest, "big")));
+ *      mode 1 = KeccakTable.add (util/tables.py:18-27, tx_circuit.py:48-58):
+ *               row = (1, RLC(reversed(data), r, n_bytes = 64), len, Word(digest bytes)); inputs longer
+ *               than 64 bytes are rejected with status ZK_KIND_VALUE_ERROR like the reference's RLC.
+ *      data: the messages back to back; offsets: uint64[n_msgs + 1] byte offsets into data
+ *      (message i = data[offsets[i] .. offsets[i+1])); rows: uint64[n_msgs][5][4] row-major, the
+ *      layout every keccak-table argument above takes.  With ZK_OPT_DEVICE_PTRS data, offsets,
+ *      randomness and rows are device pointers (rows_dev may be NULL: the session then owns the
+ *      rows and zk_keccak_read_rows copies them out).  zk_launch / zk_collect / zk_read_status work
+ *      as for the circuits (status = per-message code, kernel_ms = device time of the pass). */
+int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
+                   const uint64_t* randomness, uint32_t mode, uint64_t* rows_dev, uint32_t opts, zk_session** out);
+int zk_keccak_read_rows(zk_session* s, uint64_t* rows_host);
+int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
+                    const uint64_t* randomness, uint32_t mode, uint64_t* rows_out, uint32_t opts,
+                    uint32_t* status_out, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

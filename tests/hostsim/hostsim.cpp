@@ -161,6 +161,22 @@ extern "C" void sim_create2_address(const u64* address, const u64* salt, const u
     for (int k = 0; k < 4; k++) out[k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
 }
 
+// keccak table generation (csrc/keccak_table.hpp): rows [n][5][4], status [n]
+#include "../../zkevm_specs_amd/csrc/keccak_table.hpp"
+extern "C" int sim_keccak_table(const uint8_t* data, const u64* offsets, u64 n, const u64* r, u32 mode, u64* rows, u32* status) {
+    std::vector<u64> rpow(KT_RPOW_ROWS * 4);
+    kt_fill_rpow(fr_load(r), rpow.data());
+    KeccakGenArgs g;
+    g.data = data;
+    g.offsets = offsets;
+    g.n = n;
+    g.rpow = rpow.data();
+    g.rows = rows;
+    g.mode = mode;
+    for (u64 i = 0; i < n; i++) status[i] = keccak_table_row(g, i);
+    return 0;
+}
+
 // 512/256 and 256/256 division KAT hooks: n (16 or 8 u32 limbs as u64 pairs), d -> q, r
 extern "C" void sim_divmod(int wide, const u64* n, const u64* d, u64* q, u64* r, u64 count) {
     for (u64 i = 0; i < count; i++) {

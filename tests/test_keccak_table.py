@@ -1,0 +1,179 @@
+"""Keccak table generation: the restatement oracle/keccak_table.py against the
+golden rows produced by the unmodified reference, the sponge against hashlib's SHA3 (same
+permutation and absorb loop, different padding byte), the kernel source on the CPU harness, and —
+on the GPU — the C ABI (zk_keccak_table / zk_keccak_open) against all of them."""
+import ctypes
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import keccak as K
+from oracle import keccak_table as KT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "keccak_table.npz"))
+    offs = z["offsets"]
+    data = z["data"]
+    msgs = [data[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+    rs = [int.from_bytes(c.tobytes(), "little") for c in z["randomness"]]
+    return z, msgs, rs
+
+
+def _sha3_sponge(data: bytes) -> bytes:
+    """oracle keccak's absorb/permutation with the SHA-3 domain byte: must equal hashlib.sha3_256"""
+    rate = 136
+    p = bytearray(data) + b"\x06"
+    p += b"\x00" * (-len(p) % rate)
+    p[-1] |= 0x80
+    a = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(p), rate):
+        for k in range(rate // 8):
+            a[k % 5][k // 5] ^= int.from_bytes(p[off + 8 * k: off + 8 * k + 8], "little")
+        a = K.keccak_f(a)
+    return b"".join(a[k % 5][k // 5].to_bytes(8, "little") for k in range(4))
+
+
+def test_sponge_against_hashlib_sha3():
+    rng = random.Random(3)
+    for n in list(range(0, 140)) + [271, 272, 273, 1000, 5000]:
+        m = bytes(rng.getrandbits(8) for _ in range(n))
+        assert _sha3_sponge(m) == hashlib.sha3_256(m).digest(), n
+
+
+def test_oracle_matches_reference_golden():
+    z, msgs, rs = _golden()
+    for ri, r in enumerate(rs):
+        rows0, st0 = KT.table_rows(msgs, r, KT.MODE_CIRCUIT)
+        assert not st0.any()
+        assert np.array_equal(rows0, z[f"rows0_{ri}"])
+        rows1, st1 = KT.table_rows(msgs, r, KT.MODE_TABLE)
+        assert np.array_equal(st1 >> 24, z[f"kind1_{ri}"])
+        assert np.array_equal(rows1, z[f"rows1_{ri}"])
+    assert (z["kind1_0"] != 0).sum() > 200  # the > 64-byte inputs raise ValueError in the reference
+
+
+def _sim_rows(hostsim, data, offsets, r, mode):
+    n = len(offsets) - 1
+    rows = np.zeros((n, 5, 4), dtype=np.uint64)
+    status = np.zeros(n, dtype=np.uint32)
+    rc = np.frombuffer(int(r).to_bytes(32, "little"), dtype="<u8").copy()
+    vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+    hostsim.sim_keccak_table(vp(data), vp(offsets), ctypes.c_uint64(n), vp(rc), ctypes.c_uint32(mode), vp(rows), vp(status))
+    return rows, status
+
+
+def test_kernel_source_on_cpu_matches_golden(hostsim):
+    z, msgs, rs = _golden()
+    data, offsets = np.ascontiguousarray(z["data"]), np.ascontiguousarray(z["offsets"])
+    for ri, r in enumerate(rs):
+        rows0, st0 = _sim_rows(hostsim, data, offsets, r, 0)
+        assert not st0.any()
+        assert np.array_equal(rows0, z[f"rows0_{ri}"])
+        rows1, st1 = _sim_rows(hostsim, data, offsets, r, 1)
+        assert np.array_equal(st1 >> 24, z[f"kind1_{ri}"])
+        assert np.array_equal(rows1, z[f"rows1_{ri}"])
+
+
+def test_kernel_source_every_alignment(hostsim):
+    """the aligned-word reader at all 8 byte alignments and ragged ends"""
+    rng = random.Random(11)
+    r = rng.randrange(KT.P)
+    for lead in range(8):
+        msgs = [bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 7, 8, 9, 63, 64, 65, 135, 136, 137, 200]))) for _ in range(40)]
+        blob = bytes(lead) + b"".join(msgs)
+        data = np.frombuffer(blob, dtype=np.uint8).copy()
+        offsets = (np.cumsum([0] + [len(m) for m in msgs]) + lead).astype(np.uint64)
+        rows, st = _sim_rows(hostsim, data, offsets, r, 0)
+        want, wst = KT.table_rows(msgs, r, 0)
+        assert np.array_equal(rows, want) and np.array_equal(st, wst)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_matches_reference_golden():
+    from zkevm_specs_amd import engine
+
+    z, msgs, rs = _golden()
+    for ri, r in enumerate(rs):
+        rows0 = engine.keccak_table(msgs, r, engine.KECCAK_MODE_CIRCUIT)
+        assert np.array_equal(rows0, z[f"rows0_{ri}"])
+        short = [m for m in msgs if len(m) <= 64]
+        keep = np.array([len(m) <= 64 for m in msgs])
+        rows1 = engine.keccak_table(short, r, engine.KECCAK_MODE_TABLE)
+        assert np.array_equal(rows1, z[f"rows1_{ri}"][keep])
+    with pytest.raises(ValueError):
+        engine.keccak_table(msgs, rs[0], engine.KECCAK_MODE_TABLE)
+    # per-message status of the failing batch == the reference's per-message outcome
+    data, offsets = engine.pack_messages(msgs)
+    with engine.open_keccak(data, offsets, rs[0], engine.KECCAK_MODE_TABLE) as s:
+        res = s.run()
+        st = s.read_status()
+        assert np.array_equal(st >> 24, z["kind1_0"])
+        assert res.fail_count == int((z["kind1_0"] != 0).sum())
+        assert res.first_fail_row == int(np.nonzero(z["kind1_0"])[0][0])
+        assert np.array_equal(s.rows(), z["rows1_0"])
+
+
+@pytest.mark.gpu
+def test_gpu_alignments_and_device_buffers():
+    import torch
+
+    from zkevm_specs_amd import engine
+
+    rng = random.Random(5)
+    r = rng.randrange(KT.P)
+    for lead in (0, 1, 3, 7):
+        msgs = [bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 7, 8, 9, 63, 64, 65, 135, 136, 137, 300, 1111]))) for _ in range(300)]
+        blob = bytes(lead) + b"".join(msgs)
+        data = np.frombuffer(blob, dtype=np.uint8).copy()
+        offsets = (np.cumsum([0] + [len(m) for m in msgs]) + lead).astype(np.uint64)
+        want, _ = KT.table_rows(msgs, r, 0)
+        with engine.open_keccak(data, offsets, r, 0) as s:
+            assert s.run().ok
+            assert np.array_equal(s.rows(), want)
+        # same through device-resident buffers (torch tensors used in place)
+        d = torch.from_numpy(data).cuda()
+        o = torch.from_numpy(offsets.view(np.int64)).cuda()
+        out = torch.zeros((len(msgs), 5, 4), dtype=torch.int64, device="cuda")
+        with engine.open_keccak(d, o, r, 0, rows_dev=out) as s:
+            assert s.run().ok
+            torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_properties():
+    """2^16 public keys (64 B, Tx/Sig shape) + bytecode-sized inputs: size-independent checks.
+    Row i depends only on message i: a shuffled batch gives the shuffled rows; sampled rows equal
+    the oracle; identical messages give identical rows."""
+    from zkevm_specs_amd import engine
+
+    rng = np.random.default_rng(4)
+    n = 1 << 16
+    keys = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    keys[1234] = keys[4321]
+    r = int.from_bytes(rng.bytes(31), "little")
+    data = keys.reshape(-1).copy()
+    offsets = (np.arange(n + 1, dtype=np.uint64) * 64)
+    with engine.open_keccak(data, offsets, r, 1) as s:
+        assert s.run().ok
+        rows = s.rows()
+    perm = rng.permutation(n)
+    with engine.open_keccak(keys[perm].reshape(-1).copy(), offsets, r, 1) as s:
+        assert s.run().ok
+        assert np.array_equal(s.rows(), rows[perm])
+    assert np.array_equal(rows[1234], rows[4321])
+    idx = rng.choice(n, size=64, replace=False)
+    want, _ = KT.table_rows([keys[i].tobytes() for i in idx], r, 1)
+    assert np.array_equal(rows[idx], want)
+    # bytecode-sized inputs (24,576 B = the EVM's contract size limit)
+    codes = [rng.integers(0, 256, size=24576, dtype=np.uint8).tobytes() for _ in range(4)]
+    got = engine.keccak_table(codes * 64, r, 0)
+    want, _ = KT.table_rows(codes, r, 0)
+    assert np.array_equal(got, np.concatenate([want] * 64))

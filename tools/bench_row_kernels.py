@@ -47,4 +47,16 @@ n_tx = 1 << min(k, 17)
 w = synth_tx_witness(n_tx, r, seed=4)
 run("tx_sign", engine.open_sign(w, r, False), n_tx,
     8 * 32 + 288 + 2 * 5 * 32)
+# keccak table generation (integer-ALU bound: ~3.6 k VALU ops per 136-byte block + ~25 per RLC byte)
+n_keys = 1 << k
+nrng = np.random.default_rng(6)
+keys = torch.from_numpy(nrng.integers(0, 256, size=n_keys * 64, dtype=np.uint8)).cuda()
+offs = torch.arange(0, (n_keys + 1) * 64, 64, dtype=torch.int64, device="cuda")
+rows_dev = torch.zeros((n_keys, 5, 4), dtype=torch.int64, device="cuda")
+run("keccak_table_64B", engine.open_keccak(keys, offs, r, engine.KECCAK_MODE_TABLE, rows_dev=rows_dev), n_keys, 64 + 160)
+n_codes = 1 << max(k - 8, 4)
+code_bytes = torch.from_numpy(nrng.integers(0, 256, size=n_codes * 24576, dtype=np.uint8)).cuda()
+offs = torch.arange(0, (n_codes + 1) * 24576, 24576, dtype=torch.int64, device="cuda")
+rows_dev = torch.zeros((n_codes, 5, 4), dtype=torch.int64, device="cuda")
+run("keccak_table_24KiB", engine.open_keccak(code_bytes, offs, r, engine.KECCAK_MODE_CIRCUIT, rows_dev=rows_dev), n_codes, 24576 + 160)
 print(json.dumps(out))

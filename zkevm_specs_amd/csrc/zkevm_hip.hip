@@ -13,6 +13,7 @@
 #include "row_circuits.hpp"
 #include "copy_circuit.hpp"
 #include "sign_circuit.hpp"
+#include "keccak_table.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -284,6 +285,19 @@ __global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status
     }
     tally_commit(tally, i, code);
 }
+// Keccak table generation: one lane per message (keccak_table.hpp)
+__global__ void keccak_rpow_kernel(Fr r, u64* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
+}
+__global__ __launch_bounds__(256) void keccak_table_kernel(KeccakGenArgs g, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < g.n) {
+        code = keccak_table_row(g, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 __global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
@@ -312,7 +326,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7 };
 
 struct zk_session {
     SessionKind kind;
@@ -328,6 +342,7 @@ struct zk_session {
     ExpArgs exp;
     CopyArgs copy;
     SignArgs sign;
+    KeccakGenArgs keccak_gen;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -766,6 +781,79 @@ extern "C" int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* s
     return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
 }
 
+// ---- Keccak table generation
+extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
+                              const uint64_t* randomness, uint32_t mode, uint64_t* rows_dev, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_keccak_open: call zk_init first");
+    ARG_TRY(out && offsets && randomness && n_msgs > 0 && n_msgs < (1ull << 32) && (data || n_bytes == 0) && mode <= 1u,
+            "zk_keccak_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || !rows_dev, "zk_keccak_open: rows_dev needs ZK_OPT_DEVICE_PTRS");
+    if (!dev) {
+        for (u64 k = 0; k < n_msgs; k++) ARG_TRY(offsets[k] <= offsets[k + 1], "zk_keccak_open: offsets must be non-decreasing");
+        ARG_TRY(offsets[n_msgs] <= n_bytes, "zk_keccak_open: offsets exceed the data buffer");
+    }
+    zk_session* s = new zk_session();
+    s->kind = SESSION_KECCAK;
+    s->n = n_msgs;
+    int rc = 0;
+    const void* p = nullptr;
+    u64 rh[4];
+    Fr r;
+    if ((rc = stage(s, data, (size_t)n_bytes, dev, &p))) goto fail;
+    s->keccak_gen.data = (const uint8_t*)p;
+    if ((rc = stage(s, offsets, (size_t)(n_msgs + 1) * 8, dev, &p))) goto fail;
+    s->keccak_gen.offsets = (const u64*)p;
+    s->keccak_gen.n = n_msgs;
+    s->keccak_gen.mode = mode;
+    if (dev) {
+        if (hipMemcpy(rh, randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, randomness, 32);
+    }
+    for (int k = 0; k < 4; k++) { r.v[2 * k] = (u32)rh[k]; r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    {
+        u64* d_rpow = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_rpow, KT_RPOW_ROWS * 4 * sizeof(u64)))) goto fail;
+        hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(64), 0, g_stream, r, d_rpow);
+        s->keccak_gen.rpow = d_rpow;
+    }
+    if (rows_dev) {
+        s->keccak_gen.rows = rows_dev;
+    } else {
+        u64* d_rows = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_rows, (size_t)n_msgs * KT_NCELLS * 32))) goto fail;
+        s->keccak_gen.rows = d_rows;
+    }
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_keccak_read_rows(zk_session* s, uint64_t* rows_host) {
+    ARG_TRY(s && rows_host && s->kind == SESSION_KECCAK, "zk_keccak_read_rows: bad arguments");
+    HIP_TRY(hipMemcpyAsync(rows_host, s->keccak_gen.rows, (size_t)s->n * KT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
+                               const uint64_t* randomness, uint32_t mode, uint64_t* rows_out, uint32_t opts,
+                               uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && rows_out, "zk_keccak_table: null output");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_keccak_open(data, n_bytes, offsets, n_msgs, randomness, mode, dev ? rows_out : nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && !dev) rc = zk_keccak_read_rows(s, rows_out);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -891,6 +979,11 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_SIGN: {
         const u32 grid = (u32)((s->n + 255) / 256);
         hipLaunchKernelGGL(sign_units_kernel, dim3(grid), dim3(256), 0, g_stream, s->sign, status, s->d_tally);
+        break;
+    }
+    case SESSION_KECCAK: {
+        const u32 grid = (u32)((s->n + 255) / 256);
+        hipLaunchKernelGGL(keccak_table_kernel, dim3(grid), dim3(256), 0, g_stream, s->keccak_gen, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

@@ -221,6 +221,62 @@ def open_sign(wire, randomness, is_sig, device=None):
     return Session(h, n, arrs)
 
 
+KECCAK_MODE_CIRCUIT = 0  # KeccakCircuit.add rows (EVM / bytecode circuits)
+KECCAK_MODE_TABLE = 1    # KeccakTable.add rows (Tx / Sig circuits)
+
+
+class KeccakSession(Session):
+    """Keccak-table generation session: launch()/collect() like the circuits, rows() for the table."""
+
+    def rows(self):
+        out = np.empty((self.n, 5, 4), dtype=np.uint64)
+        check(_lib.load().zk_keccak_read_rows(self._h, _lib.ptr(out)), "zk_keccak_read_rows")
+        return out
+
+
+def pack_messages(messages):
+    """list of bytes -> (data uint8[total], offsets uint64[n + 1])"""
+    offsets = np.zeros(len(messages) + 1, dtype=np.uint64)
+    if len(messages):
+        offsets[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+    data = np.frombuffer(b"".join(bytes(m) for m in messages), dtype=np.uint8).copy()
+    return data, offsets
+
+
+def open_keccak(data, offsets, randomness, mode=KECCAK_MODE_CIRCUIT, rows_dev=None, device=None):
+    """data uint8[total], offsets uint64[n + 1], randomness (int or uint64[4]) -> KeccakSession.
+    numpy arrays are staged to HBM; torch CUDA tensors are used in place (rows_dev: optional
+    CUDA uint64[n, 5, 4] tensor receiving the rows)."""
+    lib = _lib.init(device)
+    if isinstance(randomness, int):
+        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+        if _is_device(data):
+            import torch
+            randomness = torch.from_numpy(randomness.view(np.int64)).to(data.device)
+    (data, offsets, randomness, rows_dev), opts = _prep([data, offsets, randomness, rows_dev])
+    n = int(offsets.shape[0]) - 1
+    n_bytes = int(data.shape[0]) if data is not None else 0
+    h = ctypes.c_void_p()
+    check(lib.zk_keccak_open(_lib.ptr(data) if n_bytes else None, n_bytes, _lib.ptr(offsets), n, _lib.ptr(randomness),
+                             int(mode), _lib.ptr(rows_dev), opts, ctypes.byref(h)), "zk_keccak_open")
+    return KeccakSession(h, n, (data, offsets, randomness, rows_dev))
+
+
+def keccak_table(messages, randomness, mode=KECCAK_MODE_CIRCUIT, device=None):
+    """Keccak table rows uint64[n, 5, 4] of a list of byte strings, computed on the GPU
+    (replaces KeccakCircuit.add / KeccakTable.add loops; see include/zkevm_hip.h).  Raises the
+    reference's ValueError for a mode-1 input longer than 64 bytes."""
+    from .errors import exception_for_code
+    if len(messages) == 0:
+        return np.zeros((0, 5, 4), dtype=np.uint64)
+    data, offsets = pack_messages(messages)
+    with open_keccak(data, offsets, randomness, mode, device=device) as s:
+        res = s.run()
+        if not res.ok:
+            raise exception_for_code(res.first_fail_code, f"keccak table: message {res.first_fail_row}")
+        return s.rows()
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()
