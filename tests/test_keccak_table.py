@@ -177,3 +177,24 @@ def test_gpu_full_size_properties():
     got = engine.keccak_table(codes * 64, r, 0)
     want, _ = KT.table_rows(codes, r, 0)
     assert np.array_equal(got, np.concatenate([want] * 64))
+
+
+@pytest.mark.gpu
+def test_gpu_table_feeds_bytecode_circuit():
+    """assign_keccak_table on the device -> keccak_table argument of the Bytecode circuit:
+    the circuit accepts the witness of the same byte strings and rejects it under another randomness."""
+    from zkevm_specs_amd import bytecode_circuit, engine
+    from zkevm_specs_amd.synth import synth_bytecode_witness
+
+    rng = random.Random(9)
+    r = rng.randrange(KT.P)
+    codes = [bytes(rng.getrandbits(8) for _ in range(n)) for n in (0, 1, 33, 136, 500)]
+    digest = lambda c: int.from_bytes(K.keccak256(c), "big")  # noqa: E731  (witness builder = test side)
+    cols, kt_host = synth_bytecode_witness(codes, 11, r, digest=digest)
+    kt_dev = bytecode_circuit.assign_keccak_table(codes + [b""], r)
+    assert {tuple(x.reshape(-1)) for x in kt_dev} == {tuple(x.reshape(-1)) for x in kt_host} | {tuple(x.reshape(-1)) for x in KT.table_rows([b""], r, 0)[0]}
+    with engine.open_bytecode(cols, kt_dev, r) as s:
+        assert s.run().ok
+    with engine.open_bytecode(cols, bytecode_circuit.assign_keccak_table(codes + [b""], r + 1), r) as s:
+        res = s.run()
+        assert not res.ok and res.first_fail_kind == 1

@@ -10,6 +10,13 @@ from .errors import KIND_ASSERT, exception_for_code, raise_for_code
 from .flatten import _n, flatten_bytecode_rows, flatten_keccak_table
 
 
+def assign_keccak_table(bytecodes, keccak_randomness):
+    """`assign_keccak_table(bytecodes, keccak_randomness)` (bytecode_circuit.py:182-186) on the device:
+    one KeccakCircuit.add row per bytecode, as wire rows uint64[n, 5, 4] (accepted by every
+    keccak_table argument of this package)."""
+    return engine.keccak_table([bytes(b) for b in bytecodes], _n(keccak_randomness), engine.KECCAK_MODE_CIRCUIT)
+
+
 def verify_bytecode_rows(rows, keccak_table, keccak_randomness, success=True):
     cols = flatten_bytecode_rows(rows)
     kt = flatten_keccak_table(keccak_table)

@@ -232,7 +232,10 @@ def flatten_bytecode_rows(rows):
 
 
 def flatten_keccak_table(keccak_table):
-    """set of KeccakTableRow (evm_circuit/table.py:511-515) -> uint64[m, 5, 4]"""
+    """set of KeccakTableRow (evm_circuit/table.py:511-515) -> uint64[m, 5, 4]; rows already in wire
+    form (e.g. from engine.keccak_table) pass through"""
+    if isinstance(keccak_table, np.ndarray):
+        return np.ascontiguousarray(keccak_table, dtype=np.uint64).reshape(-1, KECCAK_NCELLS, 4)
     rows = sorted(set((_n(k.state_tag), _n(k.input_rlc), _n(k.input_len), _n(k.output.lo), _n(k.output.hi))
                       for k in _iter_table(keccak_table)))
     return rows_to_rowmajor([list(r) for r in rows], KECCAK_NCELLS)
