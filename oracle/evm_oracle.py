@@ -12,7 +12,7 @@ Pinned against the reference itself by oracle/gen_golden_evm.py (tests/golden/ev
 """
 from .codes import (ASSERT, CONSTRAINT, LOOKUP_AMBIGUOUS, LOOKUP_UNSAT, NAME_ERROR, NOT_IMPLEMENTED, OK, OVERFLOW_ERROR,
                     UNSUPPORTED, VALUE_ERROR, ZERO_DIVISION, Fail)
-from .codes import ATTRIBUTE_ERROR
+from .codes import ATTRIBUTE_ERROR, TYPE_ERROR
 from .wire import P
 from . import keccak as _keccak
 
@@ -2266,6 +2266,137 @@ def g_error_oog_precompile(i):  # precompiles/error_oog_precompile.py
     _oog_tail(i, gas_cost % P)
 
 
+def _tx_calldata(i, tx_id, n):  # [instruction.tx_calldata_lookup(tx_id, FQ(idx)) for idx in range(n)] (instruction.py:694-699)
+    data = []
+    for idx in range(n):  # stops at the first missing row (LookupUnsatFailure)
+        data.append(i.value_of(i.tx_lookup(tx_id, int(T.TxContextFieldTag.CallData), idx)))
+    return data
+
+
+def g_error_oog_create(i):  # error_oog_create.py
+    opcode = i.opcode_lookup(True)
+    is_create, is_create2 = int(opcode == OP.CREATE), int(opcode == OP.CREATE2)
+    i.constrain_equal(is_create + is_create2, 1)
+    offset_w = i.stack_lookup(0, 1)
+    size_w = i.stack_lookup(0, 2)
+    offset, size = i.memory_offset_and_length(offset_w, size_w)
+    is_root = i.call_context_lookup(CC.IsRoot)
+    if is_root == 1:
+        tx_id = i.call_context_lookup(CC.TxId)
+        data = _tx_calldata(i, tx_id, size)
+        nz = len([b for b in data if b != 0])
+        gas_cost = 53000 + nz * 16 + (len(data) - nz) * 4
+    else:
+        _, exp_gas = i.memory_expansion(offset, size)
+        gas_cost = 32000 + exp_gas
+    word_size, _ = i.constant_divmod(size + 31, 32, 4)
+    gas_cost += 2 * word_size
+    if is_create2 == 1:
+        gas_cost += 6 * word_size
+    exceeds, _ = i.compare(49152, size, 8)  # MAX_INIT_CODE_SIZE
+    insufficient, _ = i.compare(i.curr[S_GAS], gas_cost % P, 8)
+    i.require(insufficient + exceeds != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
+def _calc_mem_size64_with_uint(i, offset_w, length64):  # instruction.py:1316-1327
+    if length64 == 0:
+        return 0, 0
+    offset = i.word_to_fq(offset_w, 31)
+    if offset > MAX_U64:
+        return 0, 1
+    offset64 = i.word_to_fq(offset_w, 5)
+    val = (offset64 + length64) % P
+    return val, int(val < offset64)
+
+
+def _calc_mem_size64(i, offset_w, length_w):  # instruction.py:1307-1311
+    ln = i.word_to_fq(length_w, 31)
+    if ln > MAX_U64:
+        return 0, 1
+    return _calc_mem_size64_with_uint(i, offset_w, ln)
+
+
+def _memory_size(i, opcode):  # instruction.py:1198-1303; None for every other opcode
+    if opcode in (OP.SHA3, OP.RETURN, OP.REVERT, OP.LOG0, OP.LOG1, OP.LOG2, OP.LOG3, OP.LOG4):
+        a = i.stack_pop()
+        return _calc_mem_size64(i, a, i.stack_pop())
+    if opcode in (OP.CALLDATACOPY, OP.RETURNDATACOPY, OP.CODECOPY):
+        i.stack_pop()
+        a = i.stack_pop()
+        return _calc_mem_size64(i, a, i.stack_pop())
+    if opcode == OP.EXTCODECOPY:
+        i.stack_pop()
+        i.stack_pop()
+        a = i.stack_pop()
+        return _calc_mem_size64(i, a, i.stack_pop())
+    if opcode == OP.MLOAD:
+        return _calc_mem_size64_with_uint(i, i.stack_pop(), 32)
+    if opcode in (OP.MSTORE8, OP.MSTORE):
+        offset = i.stack_pop()
+        i.stack_pop()
+        return _calc_mem_size64_with_uint(i, offset, 32)
+    if opcode in (OP.CREATE, OP.CREATE2):
+        i.stack_pop()
+        offset = i.stack_pop()
+        size = i.stack_pop()
+        if opcode == OP.CREATE2:
+            i.stack_pop()
+        return _calc_mem_size64(i, offset, size)
+    if opcode in (OP.DELEGATECALL, OP.STATICCALL, OP.CALL, OP.CALLCODE):
+        if opcode in (OP.CALL, OP.CALLCODE):
+            i.stack_pop()
+        i.stack_pop()
+        i.stack_pop()
+        cd_offset = i.stack_pop()
+        cd_length = i.stack_pop()
+        a = i.stack_pop()
+        x, over = _calc_mem_size64(i, a, i.stack_pop())
+        if over == 1:
+            return 0, 1
+        y, over = _calc_mem_size64(i, cd_offset, cd_length)
+        if over == 1:
+            return 0, 1
+        return (x, 0) if x > y else (y, 0)
+    return None
+
+
+def g_error_gas_uint_overflow(i):  # error_gas_uint_overflow.py
+    opcode = i.opcode_lookup(True)
+    is_create = int(opcode == OP.CREATE) + int(opcode == OP.CREATE2)
+    calldata_gas_overflow = initcode_gas_overflow = 0
+    calldata_length = i.call_context_lookup(CC.CallDataLength)
+    tx_id = i.call_context_lookup(CC.TxId)
+    is_root = i.call_context_lookup(CC.IsRoot)
+    if is_root == 1:
+        data = _tx_calldata(i, tx_id, calldata_length)
+        if len(data) > 0:
+            nz = len([b for b in data if b != 0])
+            gas = 53000 if is_create == 1 else 21000
+            nz_over, _ = i.compare((MAX_U64 - gas) // 16, nz, 8)
+            gas += nz * 16
+            z_over = 0
+            if nz_over == 0:
+                z = len(data) - nz
+                z_over, _ = i.compare((MAX_U64 - gas) // 4, z, 8)
+                gas += z * 4
+            if is_create == 1:
+                len_words, _ = i.constant_divmod(len(data) + 31, 32, 8)
+                initcode_gas_overflow, _ = i.compare((MAX_U64 - gas) // 2, len_words, 8)
+            calldata_gas_overflow = nz_over + z_over
+    # `if is_dynamic_gas:` (:149) — an FQ is always truthy, so memory_size runs for every opcode and
+    # unpacking its None for the opcodes it does not list raises TypeError
+    ms = _memory_size(i, opcode)
+    if ms is None:
+        i.cp()
+        i.fail(TYPE_ERROR)
+    mem_size, size_overflow = ms
+    words = MAX_U64 // 32 + 1 if mem_size > MAX_U64 - 31 else (mem_size + 31) // 32  # to_word_size (:1333-1336)
+    mul_overflow = int(words * 32 > MAX_U64)
+    i.require(size_overflow + mul_overflow + calldata_gas_overflow + initcode_gas_overflow != 0)
+    _constrain_error_state(i, i.rw_off + i.curr[S_REV])
+
+
 def g_stop(i):  # stop.py
     code_hash = (i.curr[S_CH_LO], i.curr[S_CH_HI])
     code_length = i.bytecode_length(code_hash)
@@ -2300,7 +2431,8 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.DATACOPY: g_datacopy, ES.ErrorOutOfGasPrecompile: g_error_oog_precompile, ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
+    ES.DATACOPY: g_datacopy, ES.ErrorOutOfGasPrecompile: g_error_oog_precompile, ES.ErrorOutOfGasCREATE: g_error_oog_create,
+    ES.ErrorGasUintOverflow: g_error_gas_uint_overflow, ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,
     ES.ErrorOutOfGasConstant: g_error_oog_constant, ES.ErrorInvalidJump: g_error_invalid_jump, ES.STOP: g_stop, ES.JUMP: g_jump, ES.JUMPI: g_jumpi, ES.SLOAD: g_sload, ES.SSTORE: g_sstore,

@@ -29,7 +29,7 @@ calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_j
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
 error_return_data_out_of_bound error_write_protection logs return_revert
-error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom""".split()
+error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom error_oog_create error_gas_uint_overflow""".split()
 MAX_CASES_PER_FILE = 48
 
 

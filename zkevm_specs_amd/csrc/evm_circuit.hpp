@@ -3202,6 +3202,146 @@ ZK_HD void g_datacopy(Ins& I, Tail& T) {
     I.rw_off += 4 * fr_lo64(size);
     restore_context(I, fr_u(I.rw_off), fr_sub(ev_curr(I, S_GAS), gas_cost), fr_zero(), size, &caller_id);
 }
+// [tx_calldata_lookup(tx_id, FQ(idx)) for idx in range(n)] (instruction.py:694-699): number of bytes and of
+// non-zero bytes; ends at the first missing row (LookupUnsatFailure), so the walk is bounded by the tx table
+ZK_HD void tx_calldata_scan(Ins& I, const Fr& tx_id, const Fr& n, u64& len, u64& nz) {
+    len = 0;
+    nz = 0;
+    for (Fr idx = fr_zero(); fr_lt(idx, n); idx = fr_add_u64(idx, 1)) {
+        WordOrValue v; v = tx_lookup(I, tx_id, TXC_CallData, &idx); if (I.err) return;
+        Fr b; b = value_of(I, v); if (I.err) return;
+        len++;
+        if (!fr_is_zero(b)) nz++;
+    }
+}
+ZK_HD void g_error_oog_create(Ins& I, Tail& T) {  // error_oog_create.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const bool is_create2 = fr_eq_u64(opcode, OP_CREATE2);
+    ev_require(I, is_create2 || fr_eq_u64(opcode, OP_CREATE)); if (I.err) return;
+    Word ow, sw; ow = stack_lookup(I, 0, 1); sw = stack_lookup(I, 0, 2); if (I.err) return;
+    Fr offset, size; EV_TRY(memory_offset_and_length(I, ow, sw, offset, size));
+    Fr is_root; is_root = call_context_lookup(I, CC_IsRoot); if (I.err) return;
+    Fr gas_cost;
+    if (fr_eq_u64(is_root, 1)) {  // creation tx: 53000 + 16 / 4 per non-zero / zero calldata byte
+        Fr tx_id; tx_id = call_context_lookup(I, CC_TxId); if (I.err) return;
+        u64 len, nz; EV_TRY(tx_calldata_scan(I, tx_id, size, len, nz));
+        gas_cost = fr_u(53000u + nz * 16u + (len - nz) * 4u);
+    } else {
+        Fr next_size, gas; EV_TRY(memory_expansion(I, offset, size, next_size, gas));
+        gas_cost = fr_add_u64(gas, 32000);
+    }
+    Fr word_size; EV_TRY(word_size = constant_divmod_shift(I, fr_add_u64(size, 31), 5, 4));
+    gas_cost = fr_add(gas_cost, fr_mul_u64(word_size, is_create2 ? 8 : 2));  // EIP-3860 init-code words (+ CREATE2 hashing)
+    u32 exceeds, insufficient, eq;
+    EV_TRY(ev_compare(I, fr_u(49152), size, 8, exceeds, eq));  // MAX_INIT_CODE_SIZE
+    EV_TRY(ev_compare(I, ev_curr(I, S_GAS), gas_cost, 8, insufficient, eq));
+    ev_require(I, insufficient + exceeds != 0u); if (I.err) return;
+    T.err_tail = 1;
+}
+// calc_mem_size64_with_uint / calc_mem_size64 / memory_size (instruction.py:1198-1327)
+ZK_HD void calc_mem_size64_with_uint(Ins& I, const Word& offset_w, const Fr& length64, Fr& val, u32& over) {
+    val = fr_zero();
+    over = 0;
+    if (fr_is_zero(length64)) return;
+    Fr offset; EV_TRY(offset = word_to_fq(I, offset_w, 31));
+    if (!fr_fits64(offset)) { over = 1; return; }
+    Fr offset64; EV_TRY(offset64 = word_to_fq(I, offset_w, 5));
+    val = fr_add(offset64, length64);
+    over = fr_lt(val, offset64) ? 1u : 0u;
+}
+ZK_HD void calc_mem_size64(Ins& I, const Word& offset_w, const Word& length_w, Fr& val, u32& over) {
+    val = fr_zero();
+    over = 0;
+    Fr len; EV_TRY(len = word_to_fq(I, length_w, 31));
+    if (!fr_fits64(len)) { over = 1; return; }
+    calc_mem_size64_with_uint(I, offset_w, len, val, over);
+}
+// false: the opcode is not one memory_size knows (it returns None there)
+ZK_HD bool memory_size(Ins& I, u32 op, Fr& val, u32& over) {
+    val = fr_zero();
+    over = 0;
+    Word a, b;
+    switch (op) {
+    case OP_SHA3: case OP_RETURN: case OP_REVERT: case OP_LOG0: case OP_LOG0 + 1: case OP_LOG0 + 2: case OP_LOG0 + 3: case OP_LOG4:
+        a = stack_pop(I); b = stack_pop(I);
+        calc_mem_size64(I, a, b, val, over);
+        return true;
+    case OP_CALLDATACOPY: case OP_RETURNDATACOPY: case OP_CODECOPY:
+        stack_pop(I); a = stack_pop(I); b = stack_pop(I);
+        calc_mem_size64(I, a, b, val, over);
+        return true;
+    case OP_EXTCODECOPY:
+        stack_pop(I); stack_pop(I); a = stack_pop(I); b = stack_pop(I);
+        calc_mem_size64(I, a, b, val, over);
+        return true;
+    case OP_MLOAD:
+        a = stack_pop(I);
+        calc_mem_size64_with_uint(I, a, fr_u(32), val, over);
+        return true;
+    case OP_MSTORE: case OP_MSTORE8:
+        a = stack_pop(I); stack_pop(I);
+        calc_mem_size64_with_uint(I, a, fr_u(32), val, over);
+        return true;
+    case OP_CREATE: case OP_CREATE2:
+        stack_pop(I); a = stack_pop(I); b = stack_pop(I);
+        if (op == OP_CREATE2) stack_pop(I);
+        calc_mem_size64(I, a, b, val, over);
+        return true;
+    case OP_CALL: case OP_CALLCODE: case OP_DELEGATECALL: case OP_STATICCALL: {
+        if (op == OP_CALL || op == OP_CALLCODE) stack_pop(I);
+        stack_pop(I); stack_pop(I);
+        Word cd_off, cd_len; cd_off = stack_pop(I); cd_len = stack_pop(I);
+        a = stack_pop(I); b = stack_pop(I);
+        Fr x, y;
+        calc_mem_size64(I, a, b, x, over);
+        if (I.err || over) { val = fr_zero(); return true; }
+        calc_mem_size64(I, cd_off, cd_len, y, over);
+        if (I.err || over) { val = fr_zero(); return true; }
+        val = fr_lt(y, x) ? x : y;
+        return true;
+    }
+    default: return false;
+    }
+}
+ZK_HD void g_error_gas_uint_overflow(Ins& I, Tail& T) {  // error_gas_uint_overflow.py
+    Fr opcode; opcode = opcode_lookup(I, true);
+    const u32 op = fr_le_u64(opcode, 255) ? opcode.v[0] : 0x100u;
+    const bool is_create = op == OP_CREATE || op == OP_CREATE2;
+    Fr calldata_length, tx_id, is_root;
+    calldata_length = call_context_lookup(I, CC_CallDataLength);
+    tx_id = call_context_lookup(I, CC_TxId);
+    is_root = call_context_lookup(I, CC_IsRoot);
+    if (I.err) return;
+    u32 calldata_over = 0, initcode_over = 0, eq;
+    if (fr_eq_u64(is_root, 1)) {  // intrinsic gas of the tx calldata
+        u64 len, nz; EV_TRY(tx_calldata_scan(I, tx_id, calldata_length, len, nz));
+        if (len > 0) {
+            u64 gas = is_create ? 53000u : 21000u;
+            u32 nz_over, z_over = 0;
+            EV_TRY(ev_compare(I, fr_u((~0ull - gas) / 16u), fr_u(nz), 8, nz_over, eq));
+            gas += nz * 16u;
+            if (nz_over == 0u) {
+                const u64 z = len - nz;
+                EV_TRY(ev_compare(I, fr_u((~0ull - gas) / 4u), fr_u(z), 8, z_over, eq));
+                gas += z * 4u;
+            }
+            if (is_create) {
+                Fr len_words; EV_TRY(len_words = constant_divmod_shift(I, fr_u(len + 31u), 5, 8));
+                EV_TRY(ev_compare(I, fr_u((~0ull - gas) / 2u), len_words, 8, initcode_over, eq));
+            }
+            calldata_over = nz_over + z_over;
+        }
+    }
+    // `if is_dynamic_gas:` (:149): an FQ is always truthy, so memory_size runs for every opcode and unpacking
+    // its None for the opcodes it does not list raises TypeError
+    Fr mem; u32 size_over;
+    const bool listed = memory_size(I, op, mem, size_over); if (I.err) return;
+    if (!listed) { ev_require(I, false, ZK_TYPE_ERROR); return; }
+    // to_word_size + safe_mul (:1329-1336): words * 32 exceeds u64 exactly when mem_size > MAX_U64 - 31
+    const u32 mul_over = (!fr_fits64(mem) || fr_lo64(mem) > ~0ull - 31u) ? 1u : 0u;
+    ev_require(I, size_over + mul_over + calldata_over + initcode_over != 0u); if (I.err) return;
+    T.err_tail = 1;
+}
 ZK_HD void g_error_oog_precompile(Ins& I, Tail& T) {
     WordOrValue aw; aw = call_context_lookup_word(I, CC_CalleeAddress);
     Fr address; EV_TRY(address = word_to_fq(I, aw.w, 20));
@@ -3296,7 +3436,7 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
     case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: case ES_DATACOPY:
-    case ES_ErrorOutOfGasPrecompile: return EVM_GROUP_COLD;
+    case ES_ErrorOutOfGasPrecompile: case ES_ErrorOutOfGasCREATE: case ES_ErrorGasUintOverflow: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -3387,6 +3527,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
     case ES_DATACOPY: if (G == EVM_GROUP_COLD) { g_datacopy(I, T); } break;
     case ES_ErrorOutOfGasPrecompile: if (G == EVM_GROUP_COLD) { g_error_oog_precompile(I, T); } break;
+    case ES_ErrorOutOfGasCREATE: if (G == EVM_GROUP_COLD) { g_error_oog_create(I, T); } break;
+    case ES_ErrorGasUintOverflow: if (G == EVM_GROUP_COLD) { g_error_gas_uint_overflow(I, T); } break;
     case ES_CREATE: case ES_CREATE2: if (G == EVM_GROUP_COLD) { g_create(I, T); } break;
     case ES_ErrorOutOfGasSloadSstore: if (G == EVM_GROUP_COLD) { g_error_oog_sload_sstore(I, T); } break;
     case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;
