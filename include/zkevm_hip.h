@@ -195,6 +195,30 @@ int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint64_t* offse
                     const uint64_t* randomness, uint32_t mode, uint64_t* rows_out, uint32_t opts,
                     uint32_t* status_out, zk_result* result);
 
+/* ---- State-circuit witness assignment: replaces assign_state_circuit
+ *      (src/zkevm_specs/state_circuit.py:855-884: op2row :827-852 per op + the root back-fill :866-878) and
+ *      mpt_table_from_ops (:887-888, _mock_mpt_updates :904-934).
+ *      ops: COLUMN-major uint64[12][n][4], one slot per field of `Operation` (:616-630): rw_counter, rw, tag, id,
+ *      address, field_tag, storage_key as the op's 256-bit Python ints (NOT reduced mod p: `FQ(...)` happens on the
+ *      device, and `_mpt_key` compares the raw tag), then value lo/hi, initial_value lo/hi and
+ *      lexicographic_ordering_selector as field cells.  op_flags uint32[n]: bit0 value.is_word, bit1
+ *      initial_value.is_word, bit2 isinstance(field_tag, AccountFieldTag) (selects the account proof types, :915).
+ *      Outputs: rows uint64[57][n][4] + row_flags uint32[n] — exactly what zk_state_open takes — and the mock MPT
+ *      rows uint64[n_mpt][12][4] in first-occurrence order (capacity: n rows).  Per-op status: AssertionError (site 1
+ *      value / 2 initial_value: Word(x.int_value()) >= 2^256 inside _mock_mpt_updates, first op of a key only),
+ *      OverflowError (site 3: address wider than 160 bits in op2row); the reference raises the first site-1/2
+ *      failure if there is one, else the first site-3 failure.
+ *      With ZK_OPT_DEVICE_PTRS every pointer is a device pointer and rows_dev / row_flags_dev / mpt_dev (each
+ *      nullable: the session then owns the buffer) receive the outputs in place. */
+int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_dev,
+                         uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, zk_session** out);
+/* Copy the outputs of the last pass to HOST buffers (each nullable); n_mpt_out = number of MPT rows. */
+int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* mpt_host,
+                         uint64_t mpt_capacity_rows, uint64_t* n_mpt_out);
+int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_out,
+                    uint32_t* row_flags_out, uint64_t* mpt_out /* capacity n rows */, uint64_t* n_mpt_out,
+                    uint32_t opts, uint32_t* status_out, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

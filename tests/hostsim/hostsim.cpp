@@ -268,3 +268,33 @@ extern "C" int sim_sign_verify(const uint8_t* bytes, const u64* cells, const u32
     for (u64 i = 0; i < n; i++) status[i] = sign_check_unit(a, i);
     return 0;
 }
+
+// ---- State witness assignment: the per-op device functions of csrc/state_assign.hpp in a plain loop
+#include "../../zkevm_specs_amd/csrc/state_assign.hpp"
+extern "C" int sim_state_assign(const u64* ops, const u32* op_flags, u64 n, u64* rows, u32* row_flags, u64* mpt,
+                                u64* n_mpt, u32* status) {
+    AssignArgs a;
+    a.ops = ops; a.op_flags = op_flags; a.n = n; a.rows = rows; a.row_flags = row_flags; a.mpt = mpt;
+    u32 cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    std::vector<u32> slots(cap, ZK_EMPTY_SLOT), first(n, ASG_NONE), rank(n, 0);
+    a.slots = slots.data(); a.mask = cap - 1; a.first = first.data(); a.rank = rank.data();
+    a.nb = 0; a.blk_cnt = nullptr; a.blk_next = nullptr;
+    // ops are inserted in REVERSE order so that the "smallest index wins" rule is what makes the result right
+    for (u64 i = n; i-- > 0;)
+        if (asg_has_key(asg_slot(a, ASG_TAG, i))) asg_insert(a, (u32)i);
+    u32 r = 0;
+    for (u64 i = 0; i < n; i++) {
+        if (!asg_has_key(asg_slot(a, ASG_TAG, i))) continue;
+        first[i] = asg_find_first(a, (u32)i);
+        if (first[i] == (u32)i) { rank[i] = r; asg_write_mpt(a, i, r); r++; }
+    }
+    *n_mpt = r;
+    u32 nxt = ASG_NONE;
+    for (u64 i = n; i-- > 0;) {
+        const u64 root = 3ull + 5ull * (nxt == ASG_NONE ? r : rank[first[nxt]]);
+        status[i] = asg_write_row(a, i, root, first[i] == (u32)i);
+        if (first[i] != ASG_NONE) nxt = (u32)i;
+    }
+    return 0;
+}

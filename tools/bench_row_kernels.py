@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from zkevm_specs_amd import _lib, engine
-from zkevm_specs_amd.synth import synth_bytecode_witness, synth_exp_witness, synth_tx_witness
+from zkevm_specs_amd.synth import synth_bytecode_witness, synth_exp_witness, synth_state_ops, synth_tx_witness
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()
@@ -59,4 +59,12 @@ code_bytes = torch.from_numpy(nrng.integers(0, 256, size=n_codes * 24576, dtype=
 offs = torch.arange(0, (n_codes + 1) * 24576, 24576, dtype=torch.int64, device="cuda")
 rows_dev = torch.zeros((n_codes, 5, 4), dtype=torch.int64, device="cuda")
 run("keccak_table_24KiB", engine.open_keccak(code_bytes, offs, r, engine.KECCAK_MODE_CIRCUIT, rows_dev=rows_dev), n_codes, 24576 + 160)
+# State witness assignment (HBM-bound: 12 slots read + 57 cells written per op; the mock-MPT index, scans and MPT rows ride along)
+for kk in sorted({16, k}):
+    ops, oflags, *_ = synth_state_ops(1 << kk, seed=2)
+    d_ops, d_oflags = to_dev(ops), to_dev(oflags)
+    d_rows = torch.empty((57, 1 << kk, 4), dtype=torch.int64, device="cuda")
+    d_rflags = torch.empty(1 << kk, dtype=torch.int32, device="cuda")
+    d_mpt = torch.empty((1 << kk, 12, 4), dtype=torch.int64, device="cuda")
+    run(f"state_assign_2p{kk}", engine.open_state_assign(d_ops, d_oflags, d_rows, d_rflags, d_mpt), 1 << kk, (12 + 57) * 32 + 8)
 print(json.dumps(out))

@@ -14,6 +14,7 @@
 #include "copy_circuit.hpp"
 #include "sign_circuit.hpp"
 #include "keccak_table.hpp"
+#include "state_assign.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -285,6 +286,110 @@ __global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status
     }
     tally_commit(tally, i, code);
 }
+// ---------------------------------------------------------------------------------------
+// State-circuit witness assignment (state_assign.hpp): one lane per op.
+//   insert -> mark (first occurrences, per-block partials) -> scan (one block) -> rank + MPT rows -> rows
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASG_BLOCK) void assign_insert_kernel(AssignArgs a) {
+    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
+    if (i < a.n && asg_has_key(asg_slot(a, ASG_TAG, i))) asg_insert(a, (u32)i);
+}
+__global__ __launch_bounds__(ASG_BLOCK) void assign_mark_kernel(AssignArgs a) {
+    __shared__ u32 s_cnt[ASG_BLOCK / 64];
+    __shared__ u32 s_min[ASG_BLOCK / 64];
+    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool keyed = i < a.n && asg_has_key(asg_slot(a, ASG_TAG, i));
+    u32 f = ASG_NONE;
+    if (keyed) f = asg_find_first(a, (u32)i);
+    if (i < a.n) a.first[i] = f;
+    const unsigned long long bf = __ballot(keyed && f == (u32)i), bk = __ballot(keyed);
+    if (lane == 0) {
+        s_cnt[w] = (u32)__popcll(bf);
+        s_min[w] = bk ? (u32)i + (u32)__ffsll((long long)bk) - 1u : ASG_NONE;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 c = 0, m = ASG_NONE;
+        for (int k = 0; k < ASG_BLOCK / 64; k++) { c += s_cnt[k]; m = s_min[k] < m ? s_min[k] : m; }
+        a.blk_cnt[blockIdx.x] = c;
+        a.blk_next[blockIdx.x] = m;
+    }
+}
+// blk_cnt -> exclusive prefix (total in [nb]); blk_next -> min over the blocks after b.  One block.
+__global__ __launch_bounds__(1024) void assign_scan_kernel(AssignArgs a) {
+    __shared__ u32 s[1024];
+    const u32 t = threadIdx.x, nb = a.nb;
+    const u32 per = (nb + 1023u) / 1024u;
+    const u32 lo = t * per < nb ? t * per : nb, hi = lo + per < nb ? lo + per : nb;
+    u32 sum = 0;
+    for (u32 b = lo; b < hi; b++) sum += a.blk_cnt[b];
+    s[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u32 v = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    u32 run = s[t] - sum;
+    const u32 total = s[1023];
+    for (u32 b = lo; b < hi; b++) { const u32 c = a.blk_cnt[b]; a.blk_cnt[b] = run; run += c; }
+    if (t == 0) a.blk_cnt[nb] = total;
+    u32 m = ASG_NONE;
+    for (u32 b = lo; b < hi; b++) m = a.blk_next[b] < m ? a.blk_next[b] : m;
+    __syncthreads();
+    s[t] = m;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u32 v = t + d < 1024 ? s[t + d] : ASG_NONE;
+        __syncthreads();
+        s[t] = v < s[t] ? v : s[t];
+        __syncthreads();
+    }
+    u32 after = t + 1 < 1024 ? s[t + 1] : ASG_NONE;
+    for (u32 b = hi; b > lo; b--) { const u32 c = a.blk_next[b - 1]; a.blk_next[b - 1] = after; after = c < after ? c : after; }
+    if (t == 0) a.blk_next[nb] = ASG_NONE;
+}
+__global__ __launch_bounds__(ASG_BLOCK) void assign_rank_kernel(AssignArgs a) {
+    __shared__ u32 s_cnt[ASG_BLOCK / 64];
+    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool is_first = i < a.n && a.first[i] == (u32)i;
+    const unsigned long long bf = __ballot(is_first);
+    if (lane == 0) s_cnt[w] = (u32)__popcll(bf);
+    __syncthreads();
+    if (is_first) {
+        u32 r = a.blk_cnt[blockIdx.x] + (u32)__popcll(bf & ((1ull << lane) - 1ull));
+        for (u32 k = 0; k < w; k++) r += s_cnt[k];
+        a.rank[i] = r;
+        asg_write_mpt(a, i, r);
+    }
+}
+__global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u32* status, ZkTally* tally) {
+    __shared__ u32 s_min[ASG_BLOCK / 64];
+    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool in = i < a.n;
+    const u32 f = in ? a.first[i] : ASG_NONE;
+    const unsigned long long bk = __ballot(f != ASG_NONE);
+    const u32 wave_base = (u32)i - lane;
+    if (lane == 0) s_min[w] = bk ? wave_base + (u32)__ffsll((long long)bk) - 1u : ASG_NONE;
+    __syncthreads();
+    // first MPT-keyed op strictly after i: this wave, the later waves of the block, the later blocks
+    const unsigned long long above = lane == 63u ? 0ull : (bk >> (lane + 1u)) << (lane + 1u);
+    u32 nxt = above ? wave_base + (u32)__ffsll((long long)above) - 1u : ASG_NONE;
+    for (u32 k = w + 1; k < ASG_BLOCK / 64; k++)
+        if (nxt == ASG_NONE) nxt = s_min[k];
+    if (nxt == ASG_NONE) nxt = a.blk_next[blockIdx.x];
+    u32 code = 0;
+    if (in) {
+        const u64 root = 3ull + 5ull * (nxt == ASG_NONE ? a.blk_cnt[a.nb] : a.rank[a.first[nxt]]);
+        code = asg_write_row(a, i, root, f == (u32)i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 // Keccak table generation: one lane per message (keccak_table.hpp)
 __global__ void keccak_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
@@ -326,7 +431,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8 };
 
 struct zk_session {
     SessionKind kind;
@@ -343,6 +448,7 @@ struct zk_session {
     CopyArgs copy;
     SignArgs sign;
     KeccakGenArgs keccak_gen;
+    AssignArgs assign;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -854,6 +960,81 @@ extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint
     return rc;
 }
 
+// ---- State-circuit witness assignment
+extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_dev,
+                                    uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_state_assign_open: call zk_init first");
+    ARG_TRY(out && ops && op_flags && n > 0 && n < (1ull << 31), "zk_state_assign_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || (!rows_dev && !row_flags_dev && !mpt_dev), "zk_state_assign_open: output buffers need ZK_OPT_DEVICE_PTRS");
+    zk_session* s = new zk_session();
+    s->kind = SESSION_ASSIGN;
+    s->n = n;
+    AssignArgs& a = s->assign;
+    int rc = 0;
+    const void* p = nullptr;
+    u32 cap = 16;
+    if ((rc = stage(s, ops, (size_t)n * ASG_NSLOTS * 32, dev, &p))) goto fail;
+    a.ops = (const u64*)p;
+    if ((rc = stage(s, op_flags, (size_t)n * 4, dev, &p))) goto fail;
+    a.op_flags = (const u32*)p;
+    a.n = n;
+    a.nb = (u32)((n + ASG_BLOCK - 1) / ASG_BLOCK);
+    a.rows = rows_dev;
+    a.row_flags = row_flags_dev;
+    a.mpt = mpt_dev;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * ASG_ROW_NCELLS * 32))) goto fail;
+    if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)n * 4))) goto fail;
+    if (!a.mpt && (rc = dev_alloc(s, (void**)&a.mpt, (size_t)n * ASG_MPT_NCELLS * 32))) goto fail;
+    while (cap < 2 * n + 2) cap <<= 1;
+    a.mask = cap - 1;
+    if ((rc = dev_alloc(s, (void**)&a.slots, (size_t)cap * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.first, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.rank, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_cnt, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_next, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* mpt_host,
+                                    uint64_t mpt_capacity_rows, uint64_t* n_mpt_out) {
+    ARG_TRY(s && s->kind == SESSION_ASSIGN, "zk_state_assign_read: bad arguments");
+    const AssignArgs& a = s->assign;
+    u32 n_mpt = 0;
+    HIP_TRY(hipMemcpyAsync(&n_mpt, a.blk_cnt + a.nb, 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (n_mpt_out) *n_mpt_out = n_mpt;
+    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n * ASG_ROW_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
+    if (row_flags_host) HIP_TRY(hipMemcpyAsync(row_flags_host, a.row_flags, (size_t)a.n * 4, hipMemcpyDeviceToHost, g_stream));
+    if (mpt_host) {
+        ARG_TRY(mpt_capacity_rows >= n_mpt, "zk_state_assign_read: mpt buffer too small");
+        if (n_mpt) HIP_TRY(hipMemcpyAsync(mpt_host, a.mpt, (size_t)n_mpt * ASG_MPT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_out,
+                               uint32_t* row_flags_out, uint64_t* mpt_out, uint64_t* n_mpt_out, uint32_t opts,
+                               uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && n_mpt_out, "zk_state_assign: null output");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_state_assign_open(ops, op_flags, n, dev ? rows_out : nullptr, dev ? row_flags_out : nullptr,
+                                  dev ? mpt_out : nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = dev ? zk_state_assign_read(s, nullptr, nullptr, nullptr, 0, n_mpt_out)
+                      : zk_state_assign_read(s, rows_out, row_flags_out, mpt_out, n, n_mpt_out);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -984,6 +1165,17 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_KECCAK: {
         const u32 grid = (u32)((s->n + 255) / 256);
         hipLaunchKernelGGL(keccak_table_kernel, dim3(grid), dim3(256), 0, g_stream, s->keccak_gen, status, s->d_tally);
+        break;
+    }
+    case SESSION_ASSIGN: {
+        const AssignArgs& a = s->assign;
+        const u32 cap = a.mask + 1u;
+        hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, g_stream, a.slots, cap);
+        hipLaunchKernelGGL(assign_insert_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
+        hipLaunchKernelGGL(assign_mark_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
+        hipLaunchKernelGGL(assign_scan_kernel, dim3(1), dim3(1024), 0, g_stream, a);
+        hipLaunchKernelGGL(assign_rank_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
+        hipLaunchKernelGGL(assign_rows_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

@@ -277,6 +277,40 @@ def keccak_table(messages, randomness, mode=KECCAK_MODE_CIRCUIT, device=None):
         return s.rows()
 
 
+class AssignSession(Session):
+    """State-witness assignment session: launch()/collect() like the circuits; n_mpt()/read() for the outputs."""
+
+    def n_mpt(self):
+        m = ctypes.c_uint64()
+        check(_lib.load().zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read")
+        return int(m.value)
+
+    def read(self):
+        """-> (rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4]) on the host"""
+        m = self.n_mpt()
+        rows = np.empty((57, self.n, 4), dtype=np.uint64)
+        flags = np.empty(self.n, dtype=np.uint32)
+        mpt = np.empty((m, 12, 4), dtype=np.uint64)
+        got = ctypes.c_uint64()
+        check(_lib.load().zk_state_assign_read(self._h, _lib.ptr(rows), _lib.ptr(flags), _lib.ptr(mpt) if m else None, m,
+                                               ctypes.byref(got)), "zk_state_assign_read")
+        return rows, flags, mpt
+
+
+def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None):
+    """ops uint64[12, n, 4] (column-major Operation slots, include/zkevm_hip.h), op_flags uint32[n] -> AssignSession.
+    numpy inputs are staged to HBM; torch CUDA tensors are used in place, and rows_dev uint64[57, n, 4] /
+    row_flags_dev uint32[n] / mpt_dev uint64[n, 12, 4] (optional CUDA tensors) then receive the outputs, ready
+    to be handed to open_state()."""
+    lib = _lib.init(device)
+    (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([ops, op_flags, rows_dev, row_flags_dev, mpt_dev])
+    n = int(ops.shape[1])
+    h = ctypes.c_void_p()
+    check(lib.zk_state_assign_open(_lib.ptr(ops), _lib.ptr(op_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev),
+                                   _lib.ptr(mpt_dev), opts, ctypes.byref(h)), "zk_state_assign_open")
+    return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev))
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

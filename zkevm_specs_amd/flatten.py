@@ -357,3 +357,30 @@ def flatten_sig_witness(witness):
         "tx_rows": np.zeros((0, TX_NCELLS, 4), dtype=np.uint64),
         "tx_flags": np.zeros(0, dtype=np.uint32),
     }
+
+
+# ---- State-circuit witness assignment (ops wire) -----------------------------------------
+OP_NSLOTS = 12
+
+
+def state_op_slots(op):
+    """reference state_circuit.Operation (:616-630) -> 12 slots + flags.  Slots 0-6 (rw_counter, rw, tag, id,
+    address, field_tag, storage_key) are the op's Python ints as they are (U256, not reduced mod p); slots 7-11 are
+    the field cells of value / initial_value / lexicographic_ordering_selector."""
+    ints = [int(op.rw_counter), int(op.rw), int(op.tag), int(op.id), int(op.address), int(op.field_tag),
+            int(op.storage_key)]
+    for v in ints:
+        if not 0 <= v < (1 << 256):
+            raise OverflowError("state op field does not fit the 256-bit wire slot")
+    vlo, vhi, vw = _word_cells(op.value)
+    ilo, ihi, iw = _word_cells(op.initial_value)
+    # `isinstance(field_tag, AccountFieldTag)` (state_circuit.py:915) is what selects the account proof types
+    is_account_ft = type(op.field_tag).__name__ == "AccountFieldTag"
+    flags = (1 if vw else 0) | (2 if iw else 0) | (4 if is_account_ft else 0)
+    return ints + [vlo, vhi, ilo, ihi, _n(op.lexicographic_ordering_selector)], flags
+
+
+def flatten_state_ops(ops):
+    """-> (ops uint64[12, n, 4] column-major, flags uint32[n])"""
+    sf = [state_op_slots(op) for op in ops]
+    return rows_to_colmajor([s for s, _ in sf], OP_NSLOTS), np.array([f for _, f in sf], dtype=np.uint32)

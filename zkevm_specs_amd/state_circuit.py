@@ -11,7 +11,48 @@ decoded from the device status code (csrc/common.hpp ZkKind).
 """
 from . import engine
 from .errors import raise_for_code
-from .flatten import flatten_mpt_table, flatten_state_rows
+from .flatten import flatten_mpt_table, flatten_state_ops, flatten_state_rows
+
+
+class StateWitness(tuple):
+    """(cols uint64[57, n, 4], flags uint32[n]): the State-circuit rows in wire form, as `assign_state_circuit`
+    returns them and `verify_state_rows` accepts them."""
+
+    def __new__(cls, cols, flags):
+        return super().__new__(cls, (cols, flags))
+
+
+_MOCK_MPT_SITES = (1, 2, 4)  # csrc/state_assign.hpp: failures inside _mock_mpt_updates
+
+
+def _assign(ops, mpt_only):
+    from .errors import raise_for_code
+
+    wire_ops, wire_flags = ops if isinstance(ops, tuple) else flatten_state_ops(ops)
+    with engine.open_state_assign(wire_ops, wire_flags) as s:
+        res = s.run()
+        if not res.ok:
+            # `_mock_mpt_updates` runs over every op before the first `op2row` (state_circuit.py:856, :880-883)
+            status = s.read_status()
+            for sites in ((_MOCK_MPT_SITES,) if mpt_only else (_MOCK_MPT_SITES, (3,))):
+                for i in status.nonzero()[0]:
+                    if (int(status[i]) & 0xFFFFFF) in sites:
+                        raise_for_code(int(status[i]), f"state op {i}")
+        return s.read()
+
+
+def assign_state_circuit(ops):
+    """`assign_state_circuit(ops)` of the reference (state_circuit.py:855-884) on the GPU: ops = list of reference-style
+    `Operation`s (or the (ops, flags) wire arrays) -> StateWitness.  Raises what the reference raises (AssertionError
+    from `Word(...)` inside the mock MPT updates, OverflowError from `address.to_bytes(20)`)."""
+    rows, flags, _ = _assign(ops, mpt_only=False)
+    return StateWitness(rows, flags)
+
+
+def mpt_table_from_ops(ops):
+    """`mpt_table_from_ops(ops)` (state_circuit.py:887-888) on the GPU -> MPT rows uint64[m, 12, 4], one per distinct
+    (address, field_tag, storage_key) of the Account / Storage ops, in first-occurrence order."""
+    return _assign(ops, mpt_only=True)[2]
 
 
 def verify_state_rows(rows, tables, success=True, return_status=False):
@@ -22,8 +63,8 @@ def verify_state_rows(rows, tables, success=True, return_status=False):
     the exception the reference would raise there when `success` is True; when `success` is
     False it asserts that an AssertionError occurred (tests/test_state_circuit.py:17-38).
     """
-    cols, flags = flatten_state_rows(rows)
-    mpt = flatten_mpt_table(tables.mpt_table)
+    cols, flags = rows if isinstance(rows, StateWitness) else flatten_state_rows(rows)
+    mpt = tables.mpt_table if hasattr(tables.mpt_table, "shape") else flatten_mpt_table(tables.mpt_table)
     with engine.open_state(cols, flags, mpt) as s:
         res = s.run()
         status = s.read_status() if return_status else None

@@ -271,6 +271,30 @@ def synth_state_witness(n, seed=2):
     return cols, flags, mpt
 
 
+def synth_state_ops(n, seed=2):
+    """The ops behind an n-row State witness, in the wire form `zk_state_assign_open` takes
+    (ops uint64[12, n, 4] column-major, flags uint32[n]), plus the rows / flags / MPT table the reference's
+    `assign_state_circuit` / `mpt_table_from_ops` produce for them.  Storage and Account groups are read-only here
+    (value == committed value): the reference's mock MPT update takes the FIRST op's value (state_circuit.py:921-929)
+    while the circuit looks up the LAST access, so only such traces satisfy the circuit with the mock table."""
+    cols, flags, mpt = synth_state_witness(n, seed)
+    tag = cols[2, :, 0]
+    sa = (tag == T_STORAGE) | (tag == T_ACCOUNT)
+    cols[1, sa, 0] = 0
+    cols[50, sa] = cols[52, sa]
+    cols[51, sa] = cols[53, sa]
+    mpt[:, 8] = mpt[:, 10]
+    mpt[:, 9] = mpt[:, 11]
+    ops = np.zeros((12, n, 4), dtype=np.uint64)
+    ops[0:6] = cols[0:6]
+    ops[6, :, 0:2] = cols[6, :, 0:2]
+    ops[6, :, 2:4] = cols[7, :, 0:2]
+    ops[7:11] = cols[50:54]
+    ops[11] = cols[56]
+    op_flags = (flags | np.where(tag == T_ACCOUNT, 4, 0)).astype(np.uint32)
+    return ops, op_flags, cols, flags, mpt
+
+
 # ---- Bytecode circuit (config 1) ---------------------------------------------------------------
 EMPTY_HASH = 0xC5D2460186F7233C927E7DB2DCC703C0E500B653CA82273B7BFAD8045D85A470  # keccak256("")
 _FR_P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
