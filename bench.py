@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="evm", choices=["evm", "state"])
-    ap.add_argument("--log-rows", type=int, default=None, help="log2 rows per GPU (default: 18 evm, 16 state)")
+    ap.add_argument("--workload", default="evm", choices=["evm", "state", "super"])
+    ap.add_argument("--log-rows", type=int, default=None, help="log2 rows per GPU (default: 18 evm, 16 state, 20 super)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -43,7 +43,7 @@ def main():
 
     from zkevm_specs_amd import _lib, engine
 
-    log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "evm" else 16)
+    log_rows = args.log_rows if args.log_rows is not None else {"evm": 18, "state": 16, "super": 20}[args.workload]
     n = 1 << log_rows
     to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
     _lib.init(local_rank)
@@ -61,6 +61,22 @@ def main():
         workload = (f"EVM circuit, 2^{log_rows} execution steps per GPU, mixed-opcode synthetic trace "
                     f"(BASELINE configs[2]); RW table {meta['n_rw']} rows, bytecode table {meta['n_bytecode']} rows")
         extra_cfg = {"steps_per_gpu": n, "rw_rows": meta["n_rw"], "bytecode_rows": meta["n_bytecode"]}
+    elif args.workload == "super":
+        # BASELINE configs[4]: EVM + State + Bytecode + Tx kernels over one witness set of 2^log_rows rows per GPU
+        from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super
+
+        parts = synth_super(log_rows, seed=5 + rank)
+        super_meta = parts["meta"]
+        sess = SuperCircuit(parts, device=local_rank, to_device=to_dev)
+        units = sum(sess.rows.values())
+        tx_bytes = 8 * 32 + 288 + 2 * 5 * 32
+        super_bytes = {"evm": super_meta["algorithmic_bytes"], "state": sess.rows["state"] * 57 * 32,
+                       "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * tx_bytes}
+        algo_bytes = None  # per-circuit, resolved after the run (dominant kernel)
+        kernel_name = None
+        workload = (f"Super circuit, 2^{log_rows} rows per GPU (BASELINE configs[4]): " +
+                    ", ".join(f"{k} {v}" for k, v in sess.rows.items()) + " rows")
+        extra_cfg = {"rows_per_gpu": dict(sess.rows), "state_assign_ms": sess.assign_ms}
     else:
         from zkevm_specs_amd.synth import synth_state_witness
 
@@ -88,6 +104,23 @@ def main():
     res = sess.collect()
     barrier()
     dt = time.perf_counter() - t0
+    per_circuit = None
+    if args.workload == "super":
+        results, total_fail_local, first_local = res
+        per_circuit = {k: {"rows": sess.rows[k], "kernel_ms": r.kernel_ms,
+                           "algorithmic_GBps": super_bytes[k] / (r.kernel_ms / 1e3) / 1e9} for k, r in results.items()}
+        dom = max(results, key=lambda k: results[k].kernel_ms)
+        kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_kernel", "bytecode": "bytecode_rows_kernel",
+                       "tx": "sign_units_kernel"}[dom]
+        algo_bytes = super_bytes[dom]
+
+        class _Tally:
+            fail_count = total_fail_local
+            first_fail_row = None if first_local is None else first_local[1]
+            first_fail_code = 0 if first_local is None else first_local[2]
+            kernel_ms = results[dom].kernel_ms
+
+        res = _Tally
 
     from zkevm_specs_amd.distributed import reduce_tally
 
@@ -130,7 +163,26 @@ def main():
                          "kernel": kernel_name, "kernel_ms": res.kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if not args.no_cpu_baseline and args.workload == "evm":
+        if per_circuit is not None:
+            out["roofline"]["per_circuit"] = per_circuit
+        if not args.no_cpu_baseline and args.workload == "super":
+            from oracle import evm_oracle, state_oracle, assign_oracle, wire
+
+            ne = min(sess.rows["evm"], 1 << 15)
+            ns = min(sess.rows["state"], 1 << 15)
+            ev = parts["evm"]
+            W = evm_oracle.EvmWitness(wire.rowmajor_to_rows(ev["steps"][: ne + 1]), wire.rowmajor_to_rows(ev["rw"]),
+                                      ev["rw_flags"], wire.rowmajor_to_rows(ev["bytecode"]))
+            ops, oflags = parts["state_ops"]
+            tc = time.perf_counter()
+            assert not any(evm_oracle.verify_steps(W))
+            rows_i, rflags_i, mpt_i, _ = assign_oracle.assign(wire.colmajor_to_rows(np.ascontiguousarray(ops[:, :ns])), oflags[:ns].tolist())
+            state_oracle.verify_rows(rows_i, rflags_i, mpt_i)
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": (ne + ns) / tc, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ne} step pairs (oracle/evm_oracle.py) + assignment and evaluation of the first "
+                                             f"{ns} State ops (oracle/assign_oracle.py, state_oracle.py), pure Python, 1 thread"}
+        elif not args.no_cpu_baseline and args.workload == "evm":
             from oracle import evm_oracle, wire
 
             sample = min(units, 1 << 17)

@@ -1,0 +1,74 @@
+"""Super circuit (BASELINE config 5): the EVM, State, Bytecode and Tx kernels over one witness set.
+CPU: every part of the synthetic super witness satisfies its circuit according to the oracles; the contracts'
+keccak table ties the EVM trace, the Bytecode rows and the table builder together.  GPU (marked): the same
+through the C ABI, tally = sum over the circuits, tampering one cell per circuit is found where it was put."""
+import numpy as np
+import pytest
+
+from oracle import assign_oracle, keccak_table, row_oracles, sign_oracle, state_oracle, wire
+from tests.evm_cases import oracle_status
+from zkevm_specs_amd.super_circuit import CIRCUITS, synth_super
+
+
+def _oracle_keccak(codes, r):
+    return keccak_table.table_rows(codes, r, keccak_table.MODE_CIRCUIT)[0]
+
+
+def test_super_witness_parts_are_valid_and_consistent():
+    p = synth_super(13, seed=7, keccak_rows_of=_oracle_keccak)
+    assert sum(p["rows"].values()) == (1 << 13) - 1 and set(p["rows"]) == set(CIRCUITS)
+    # EVM trace (its bytecode table carries the keccak digests of the contracts)
+    assert not any(oracle_status(dict(p["evm"])))
+    bc_rows, keccak, r = p["bytecode"]
+    hashes = {tuple(wire.cells_to_ints(keccak[i, 3:5])) for i in range(keccak.shape[0])}
+    evm_hashes = {tuple(row[0:2]) for row in wire.rowmajor_to_rows(p["evm"]["bytecode"])}
+    assert evm_hashes == hashes
+    # Bytecode circuit over the same contracts, looking up the same keccak table
+    st = row_oracles.bytecode_verify_rows(wire.colmajor_to_rows(bc_rows), wire.rowmajor_to_rows(keccak), r)
+    assert not any(st)
+    # State rows: assigned from the op list, then checked
+    ops, flags = p["state_ops"]
+    rows, rflags, mpt, status = assign_oracle.assign(wire.colmajor_to_rows(ops), flags.tolist())
+    assert not any(status) and not any(state_oracle.verify_rows(rows, rflags, mpt))
+    # Tx units
+    tx, r_tx = p["tx"]
+    st = sign_oracle.verify_units(tx["bytes"], tx["cells"], tx["meta"], wire.rowmajor_to_rows(tx["keccak"]), r_tx, 0,
+                                  wire.rowmajor_to_rows(tx["tx_rows"]), tx["tx_flags"])
+    assert not any(st)
+
+
+@pytest.mark.gpu
+def test_super_circuit_on_device_and_tamper_localisation():
+    import torch
+
+    from zkevm_specs_amd.super_circuit import SuperCircuit
+
+    p = synth_super(16, seed=3)  # keccak table of the contracts built on the GPU
+    assert sum(p["rows"].values()) == (1 << 16) - 1
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    with SuperCircuit(p, to_device=dev) as sc:
+        assert sc.rows == p["rows"]
+        sc.launch()
+        results, total, first = sc.collect()
+        assert total == 0 and first is None and all(r.ok for r in results.values())
+    # the device-built keccak table equals the oracle's
+    assert np.array_equal(p["bytecode"][1], _oracle_keccak([bytes(c) for c in _codes(p)], p["bytecode"][2]))
+    # one tampered cell per circuit (host copies -> staged by the library)
+    p["evm"]["steps"][100, 7, 0] += np.uint64(1)                 # program counter of step 100
+    p["state_ops"][0][7, 50, 0] ^= np.uint64(1)                  # value.lo of op 50
+    p["bytecode"][0][6, 20, 0] ^= np.uint64(1)                   # byte value of bytecode row 20
+    p["tx"][0]["cells"][0, 5, 0] ^= np.uint64(1)                 # address of tx 5
+    with SuperCircuit(p) as sc:
+        sc.launch()
+        results, total, first = sc.collect()
+    assert not results["evm"].ok and results["evm"].first_fail_row in (99, 100)
+    assert not results["state"].ok and results["state"].first_fail_row in (50, 51)
+    assert not results["bytecode"].ok and results["bytecode"].first_fail_row in (19, 20)
+    assert not results["tx"].ok and results["tx"].first_fail_row == 5
+    assert total == sum(r.fail_count for r in results.values()) >= 4 and first[0] == "evm"
+
+
+def _codes(p):
+    from zkevm_specs_amd.synth_evm import synth_evm_codes
+
+    return synth_evm_codes(3, seg_len=640, n_contracts=16)

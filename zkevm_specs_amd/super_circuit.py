@@ -1,0 +1,122 @@
+"""Super-circuit driver (BASELINE config 5): the EVM, State, Bytecode and Tx circuit kernels evaluated over one
+witness set on one GPU; ranks hold independent shards and all-reduce the tally (distributed.py).
+
+The reference has no super-circuit driver: each circuit has its own `verify_*` entry and
+they are only related through the tables they share.  This module launches the same C-ABI sessions the per-circuit
+mirrors use, back to back on one stream, and sums their tallies.  What is shared in the synthetic witness:
+  * the contracts the EVM trace executes ARE the byte strings of the Bytecode circuit's rows, and their code hashes
+    are real keccak-256 digests taken from the keccak table the device builds from those byte strings
+    (`zk_keccak_table`, mode 0) — the same table the Bytecode circuit looks up;
+  * the State circuit's rows come out of the device-side witness assignment (`zk_state_assign`) of a synthetic op
+    list sized like the trace's RW table.  They are NOT derived from the EVM trace's RW table: the synthetic trace
+    does not model cross-step stack / memory consistency (synth_evm.py), which is exactly what the State circuit
+    checks, so such rows would not satisfy it;
+  * the Tx circuit's units are independent synthetic transactions (the trace has a single root call).
+The Copy and Exp circuits have no rows here: BASELINE config 3's opcode mix contains no copy / EXP steps.
+"""
+import numpy as np
+
+from . import engine
+from .synth import synth_bytecode_witness, synth_state_ops, synth_tx_witness
+from .synth_evm import synth_evm_codes, synth_evm_trace
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+CIRCUITS = ("evm", "state", "bytecode", "tx")
+
+
+def _digest_of_row(row):
+    lo = int.from_bytes(row[3].tobytes(), "little")
+    hi = int.from_bytes(row[4].tobytes(), "little")
+    return lo | (hi << 128)
+
+
+def synth_super(log_total=20, seed=5, keccak_rows_of=None):
+    """Witness parts of a 2^log_total-row super circuit: EVM 2^(log_total-2) steps, Bytecode rows of its contracts
+    (padded to a power of two), 2^(log_total-8) Tx units, and State rows for the remainder.
+    keccak_rows_of(codes, r) -> uint64[n, 5, 4] builds the keccak table of the contracts; default: on the GPU
+    (engine.keccak_table).  Returns dict(evm=wire, state_ops=(ops, flags), bytecode=(rows, keccak, r), tx=(wire, r),
+    rows={circuit: evaluated rows}, meta=...)."""
+    assert log_total >= 12
+    r = (0x1234567 * (seed + 1) ** 7 + 0x9E3779B97F4A7C15) % P
+    n_contracts = 16 if log_total >= 16 else 2
+    seg_len = 640 if log_total >= 16 else 96
+    codes = synth_evm_codes(seed, seg_len=seg_len, n_contracts=n_contracts)
+    if keccak_rows_of is None:
+        keccak_rows_of = lambda c, rr: engine.keccak_table(c, rr, engine.KECCAK_MODE_CIRCUIT)  # noqa: E731
+    keccak = keccak_rows_of(codes, r)
+    hashes = [_digest_of_row(keccak[i]) for i in range(len(codes))]
+    n_steps = 1 << (log_total - 2)
+    evm = synth_evm_trace(n_steps, seed=seed, seg_len=seg_len, n_contracts=n_contracts, code_hashes=hashes)
+    meta = evm.pop("meta")
+    n_code_rows = sum(len(c) + 1 for c in codes)
+    k = max(6, int(np.ceil(np.log2(n_code_rows + 1))))
+    digest = dict(zip(codes, hashes))
+    bc_rows, bc_keccak = synth_bytecode_witness(codes, k, r, digest=lambda c: digest[c])
+    # the generator's own keccak rows (python RLC + the digests above) must be the device-built table rows
+    dev_sorted = sorted(tuple(int.from_bytes(keccak[i, c].tobytes(), "little") for c in range(5)) for i in range(len(codes)))
+    gen_sorted = sorted(tuple(int.from_bytes(bc_keccak[i, c].tobytes(), "little") for c in range(5)) for i in range(bc_keccak.shape[0]))
+    assert dev_sorted == gen_sorted, "keccak table of the contracts: generator and table builder disagree"
+    n_tx = 1 << (log_total - 8)
+    tx = synth_tx_witness(n_tx, r, seed=seed + 1)
+    n_state = (1 << log_total) - n_steps - (1 << k) - n_tx
+    ops, op_flags, *_ = synth_state_ops(n_state, seed=seed + 2)
+    rows = {"evm": n_steps - 1, "state": n_state, "bytecode": 1 << k, "tx": n_tx}
+    return {"evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "tx": (tx, r), "rows": rows,
+            "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows)}
+
+
+class SuperCircuit:
+    """Sessions of the four circuits over one witness set; launch() enqueues one pass of each, collect() returns
+    ({circuit: Result}, total fail_count, first failing (circuit, row, code))."""
+
+    def __init__(self, parts, device=None, to_device=None):
+        dev = to_device if to_device is not None else (lambda x: x)
+        self._keep = []
+        ops, op_flags = (dev(a) for a in parts["state_ops"])
+        # State rows: assigned on the device from the op list, then evaluated from the same HBM buffers
+        if hasattr(ops, "is_cuda"):
+            import torch
+
+            n = int(ops.shape[1])
+            rows = torch.empty((57, n, 4), dtype=torch.int64, device=ops.device)
+            flags = torch.empty(n, dtype=torch.int32, device=ops.device)
+            mpt = torch.empty((n, 12, 4), dtype=torch.int64, device=ops.device)
+            with engine.open_state_assign(ops, op_flags, rows, flags, mpt, device=device) as a:
+                res = a.run()
+                m = a.n_mpt()
+            mpt = mpt[:m]
+        else:
+            with engine.open_state_assign(ops, op_flags, device=device) as a:
+                res = a.run()
+                rows, flags, mpt = a.read()
+        assert res.ok, f"state witness assignment failed: {res}"
+        self.assign_ms = res.kernel_ms
+        bc_rows, bc_keccak, r = parts["bytecode"]
+        tx, r_tx = parts["tx"]
+        self.sessions = {
+            "evm": engine.open_evm({k: dev(v) for k, v in parts["evm"].items()}, device=device),
+            "state": engine.open_state(rows, flags, mpt, device=device),
+            "bytecode": engine.open_bytecode(dev(bc_rows), dev(bc_keccak), r, device=device),
+            "tx": engine.open_sign({k: dev(v) for k, v in tx.items()}, r_tx, False, device=device),
+        }
+        self.rows = {k: s.n for k, s in self.sessions.items()}
+
+    def launch(self):
+        for s in self.sessions.values():
+            s.launch()
+
+    def collect(self):
+        results = {k: s.collect() for k, s in self.sessions.items()}
+        total = sum(r.fail_count for r in results.values())
+        first = next(((k, r.first_fail_row, r.first_fail_code) for k, r in results.items() if not r.ok), None)
+        return results, total, first
+
+    def close(self):
+        for s in self.sessions.values():
+            s.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -113,11 +113,24 @@ for _st, _ops in T.RESPONSIBLE.items():
         _STATE_OF[_o] = int(ES[_st])
 
 
-def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True, mix=None):
+def synth_evm_codes(seed=3, seg_len=640, n_contracts=16, mix=None):
+    """The contract byte strings synth_evm_trace(seed, ...) executes (they depend on the seed and the mix only)."""
+    rng = random.Random(seed)
+    return [_Contract(rng, seg_len - 1, mix).code for _ in range(n_contracts)]
+
+
+def synth_evm_trace(n_steps, seed=3, seg_len=640, n_contracts=16, as_wire=True, mix=None, code_hashes=None):
     """Build an n_steps-step trace (n_steps - 1 evaluated pairs).  Returns a dict with the wire
-    arrays `steps, rw, rw_flags, bytecode, tx, tx_flags, block, block_flags` plus `meta`."""
+    arrays `steps, rw, rw_flags, bytecode, tx, tx_flags, block, block_flags` plus `meta`.
+    code_hashes: optional list of 256-bit ints, the code hash of each contract (synth_evm_codes order) — e.g. their
+    keccak-256 digests when the bytecode / keccak tables of the same contracts are evaluated next to the trace
+    (super_circuit.py).  Default: a random 256-bit value (the EVM circuit only matches hashes, it never hashes code)."""
     rng = random.Random(seed)
     contracts = [_Contract(rng, seg_len - 1, mix) for _ in range(n_contracts)]
+    if code_hashes is not None:
+        assert len(code_hashes) == n_contracts
+        for c, h in zip(contracts, code_hashes):
+            c.hash = (h & M128, h >> 128)
     steps, rw, rw_flags = [], [], []
     looked_up_cells = 0  # algorithmic-bytes accounting: cells of rows the step pairs look up
     tx_id = 1
