@@ -52,7 +52,7 @@ def test_super_circuit_on_device_and_tamper_localisation():
         results, total, first = sc.collect()
         assert total == 0 and first is None and all(r.ok for r in results.values())
     # the device-built keccak table equals the oracle's
-    assert np.array_equal(p["bytecode"][1], _oracle_keccak([bytes(c) for c in _codes(p)], p["bytecode"][2]))
+    assert np.array_equal(p["bytecode"][1], _oracle_keccak(p["codes"], p["bytecode"][2]))
     # one tampered cell per circuit (host copies -> staged by the library)
     p["evm"]["steps"][100, 7, 0] += np.uint64(1)                 # program counter of step 100
     p["state_ops"][0][7, 50, 0] ^= np.uint64(1)                  # value.lo of op 50
@@ -66,9 +66,3 @@ def test_super_circuit_on_device_and_tamper_localisation():
     assert not results["bytecode"].ok and results["bytecode"].first_fail_row in (19, 20)
     assert not results["tx"].ok and results["tx"].first_fail_row == 5
     assert total == sum(r.fail_count for r in results.values()) >= 4 and first[0] == "evm"
-
-
-def _codes(p):
-    from zkevm_specs_amd.synth_evm import synth_evm_codes
-
-    return synth_evm_codes(3, seg_len=640, n_contracts=16)

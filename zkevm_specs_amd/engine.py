@@ -97,6 +97,18 @@ def _prep(arrs):
     return out, (OPT_DEVICE_PTRS if is_dev else 0)
 
 
+def _randomness_cells(randomness, like):
+    """int -> one canonical cell (uint64[4]), on the device when `like` is a CUDA tensor"""
+    if not isinstance(randomness, int):
+        return randomness
+    cells = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    if _is_device(like):
+        import torch
+
+        return torch.from_numpy(cells.view(np.int64)).to(like.device)
+    return cells
+
+
 def open_state(rows, flags, mpt, device=None):
     """rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4] -> Session"""
     lib = _lib.init(device)
@@ -151,8 +163,7 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
 def open_bytecode(rows, keccak, randomness, device=None):
     """rows uint64[12, n, 4], keccak uint64[m, 5, 4], randomness uint64[4] (or an int) -> Session"""
     lib = _lib.init(device)
-    if isinstance(randomness, int):
-        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    randomness = _randomness_cells(randomness, rows)
     (rows, keccak, randomness), opts = _prep([rows, keccak, randomness])
     n = rows.shape[1]
     m = keccak.shape[0] if keccak is not None else 0
@@ -174,8 +185,7 @@ def open_exp(rows, device=None):
 def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags, device=None, generic_index=False):
     """Copy circuit session: rows uint64[20, n, 4] + flags, randomness (int or uint64[4]), EVM-format tables."""
     lib = _lib.init(device)
-    if isinstance(randomness, int):
-        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    randomness = _randomness_cells(randomness, rows)
     arrs, opts = _prep([rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags])
     rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags = arrs
 
@@ -199,8 +209,7 @@ def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags,
 def open_sign(wire, randomness, is_sig, device=None):
     """Tx / Sig circuit session over `wire` = dict(bytes, cells, meta, keccak, tx_rows, tx_flags)."""
     lib = _lib.init(device)
-    if isinstance(randomness, int):
-        randomness = np.frombuffer(int(randomness).to_bytes(32, "little"), dtype="<u8").copy()
+    randomness = _randomness_cells(randomness, wire.get("bytes"))
     names = ["bytes", "cells", "meta", "keccak", "tx_rows", "tx_flags"]
     arrs, opts = _prep([wire.get(k) for k in names] + [randomness])
     a = dict(zip(names + ["r"], arrs))

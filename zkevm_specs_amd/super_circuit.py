@@ -35,10 +35,11 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
     (padded to a power of two), 2^(log_total-8) Tx units, and State rows for the remainder.
     keccak_rows_of(codes, r) -> uint64[n, 5, 4] builds the keccak table of the contracts; default: on the GPU
     (engine.keccak_table).  Returns dict(evm=wire, state_ops=(ops, flags), bytecode=(rows, keccak, r), tx=(wire, r),
-    rows={circuit: evaluated rows}, meta=...)."""
+    rows={circuit: evaluated rows}, codes=[bytes], meta=...)."""
     assert log_total >= 12
     r = (0x1234567 * (seed + 1) ** 7 + 0x9E3779B97F4A7C15) % P
-    n_contracts = 16 if log_total >= 16 else 2
+    # contracts sized so that their Bytecode-circuit rows take at most 1/16 of the total
+    n_contracts = min(16, 1 << (log_total - 16)) if log_total >= 16 else 2
     seg_len = 640 if log_total >= 16 else 96
     codes = synth_evm_codes(seed, seg_len=seg_len, n_contracts=n_contracts)
     if keccak_rows_of is None:
@@ -61,7 +62,8 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
     n_state = (1 << log_total) - n_steps - (1 << k) - n_tx
     ops, op_flags, *_ = synth_state_ops(n_state, seed=seed + 2)
     rows = {"evm": n_steps - 1, "state": n_state, "bytecode": 1 << k, "tx": n_tx}
-    return {"evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "tx": (tx, r), "rows": rows,
+    assert n_state >= 64
+    return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "tx": (tx, r), "rows": rows,
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows)}
 
 
