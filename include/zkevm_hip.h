@@ -164,7 +164,7 @@ int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out,
  *      msg_hash_bytes, pub_key_hash, ecdsa sig_r LE, ecdsa sig_s LE); cells: column-major uint64[8][n][4]
  *      (address, msg_hash lo, hi, sig_v, sig_r lo, hi, sig_s lo, hi); meta: uint32[n][4] (ecdsa_status: 0
  *      verified / 1 not verified / (kind<<24) exception of the third-party secp256k1 call, expected is_valid,
- *      malformed-attribute mask, 0); keccak: uint64[m][5][4] (is_enabled, input_rlc, input_len, output lo, hi;
+ *      malformed-attribute mask, the ECDSA chip's v for Sig units); keccak: uint64[m][5][4] (is_enabled, input_rlc, input_len, output lo, hi;
  *      tx_circuit.py:38-61); tx_rows: uint64[rows][5][4] + flags (Tx circuit only). */
 typedef struct zk_sign_units {
     const uint8_t* bytes;       const uint64_t* cells;       const uint32_t* meta;      uint64_t n_units;
@@ -217,6 +217,26 @@ int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags
                          uint64_t mpt_capacity_rows, uint64_t* n_mpt_out);
 int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_out,
                     uint32_t* row_flags_out, uint64_t* mpt_out /* capacity n rows */, uint64_t* n_mpt_out,
+                    uint32_t opts, uint32_t* status_out, zk_result* result);
+
+/* ---- secp256k1 ECDSA verification: computes the `ecdsa_status` column of the Tx / Sig units
+ *      on the device instead of taking it from the host.  Replaces `ECDSAVerifyChip.verify`
+ *      (src/zkevm_specs/tx_circuit.py:147-158, util/ec.py:109-117), i.e. eth-keys 0.4.0's
+ *      `KeyAPI.Signature(vrs=...)` validation + `KeyAPI().ecdsa_verify(msg_hash, signature, public_key)`.
+ *      bytes: layout 0 = packed uint8[n][5][32]: pk_x LE, pk_y LE, msg_hash BE, sig_r LE, sig_s LE;
+ *             layout 1 / 2 = the byte rows uint8[n][9][32] of the Tx / Sig units of zk_sign_units (rows 2, 3, 5, 7, 8
+ *             are those five; the Tx chip keeps msg_hash little-endian, tx_circuit.py:131, the Sig chip big-endian,
+ *             util/ec.py:93).
+ *      v: optional recovery ids, v[i * v_stride] (the Sig circuit's chip builds Signature(vrs=[v, r, s]) — for Sig
+ *      units pass meta + 3 with stride 4; NULL = the Tx circuit's fixed 0).  Status per signature: 0 verified, 1 not verified, (ZK_KIND_UNSUPPORTED << 24) | 1 = eth_keys
+ *      BadSignature (v outside {0, 1}, r or s >= N), (ZK_KIND_UNSUPPORTED << 24) | 2 = a public-key coordinate >= P
+ *      (outside the engine's domain), (ZK_KIND_VALUE_ERROR << 24) | 3 = pow(0, -1, P) in the final point addition.
+ *      out_dev (DEVICE pointer, optional): out_dev[i * out_stride] = status, e.g. meta + 0 with stride 4 to fill the
+ *      units' meta column in place.  zk_launch / zk_collect / zk_read_status as for the circuits (the tally counts
+ *      the signatures that did not verify). */
+int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
+                  uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out);
+int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                     uint32_t opts, uint32_t* status_out, zk_result* result);
 
 /* ---- Session protocol shared by every circuit.

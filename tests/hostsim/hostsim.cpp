@@ -298,3 +298,15 @@ extern "C" int sim_state_assign(const u64* ops, const u32* op_flags, u64 n, u64*
     }
     return 0;
 }
+
+// ---- secp256k1 ECDSA: the per-signature device function of csrc/secp256k1.hpp in a plain loop
+#include "../../zkevm_specs_amd/csrc/secp256k1.hpp"
+extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
+    static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
+    EcdsaArgs a;
+    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.out = nullptr; a.out_stride = 0;
+    a.msg_be = layout != 1u;
+    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
+    for (u64 i = 0; i < n; i++) status[i] = ecdsa_verify_one(a, i);
+    return 0;
+}

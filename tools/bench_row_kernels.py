@@ -67,4 +67,13 @@ for kk in sorted({16, k}):
     d_rflags = torch.empty(1 << kk, dtype=torch.int32, device="cuda")
     d_mpt = torch.empty((1 << kk, 12, 4), dtype=torch.int64, device="cuda")
     run(f"state_assign_2p{kk}", engine.open_state_assign(d_ops, d_oflags, d_rows, d_rflags, d_mpt), 1 << kk, (12 + 57) * 32 + 8)
+# secp256k1 ECDSA verification (integer-ALU bound: ~8.6 k 256-bit Montgomery products per signature)
+from zkevm_specs_amd.synth import synth_signatures
+n_sig = 1 << 14
+sigs = synth_signatures(n_sig, 9)
+packed = np.frombuffer(b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") + z.to_bytes(32, "big") + rr.to_bytes(32, "little") +
+                                ss.to_bytes(32, "little") for x, y, z, rr, ss in sigs), dtype=np.uint8).reshape(n_sig, 5, 32).copy()
+for reps in (1, 8):
+    d = torch.from_numpy(np.tile(packed, (reps, 1, 1))).cuda()
+    run(f"ecdsa_verify_{n_sig * reps}", engine.open_ecdsa(d), n_sig * reps, 160 + 4)
 print(json.dumps(out))

@@ -1,0 +1,252 @@
+// secp256k1 ECDSA verification on the device: produces the `ecdsa_status` column the
+// Tx / Sig kernels consume (sign_circuit.hpp) instead of taking it pre-computed from the host.
+//
+// Reference call sites: `ECDSAVerifyChip.verify` src/zkevm_specs/tx_circuit.py:147-158 and util/ec.py:109-117 —
+// `KeyAPI.Signature(vrs=[v, r, s])`, `KeyAPI.PublicKey(x_be + y_be)`, `KeyAPI().ecdsa_verify(msg_hash, sig, pk)`.
+// The arithmetic lives in third-party eth-keys 0.4.0 (setup.cfg:24; not under /root/reference): its native backend's
+// `ecdsa_raw_verify` — w = s^-1 mod N, u1 = z w, u2 = r w, R = u1 G + u2 Q, accept iff R != O and R.x mod N == r —
+// with `Signature` rejecting v outside {0, 1} and r, s outside [0, N) (BadSignature), restated by
+// oracle/ecdsa_oracle.py.  The scalar multiplications are the same LSB-first double-and-add and the point
+// addition makes the same case analysis as the affine formulas there (x1 == x2: y1 + y2 == 0 -> O, else the
+// tangent at p1), so that the verdict also agrees for public keys that are not on the curve (the group-law
+// formulas never use b).
+//
+// Field elements: 8 x u32 limbs, Montgomery form (R = 2^256) for both the base field P and the scalar field N;
+// points: Jacobian (X, Y, Z) over P with an explicit infinity flag.
+#pragma once
+#include "common.hpp"
+#include "secp_constants.h"
+
+#if defined(ZK_HOSTSIM)
+#define SP_MEMBER static inline
+#else
+#define SP_MEMBER __device__ __forceinline__ static
+#endif
+#define SP_CONST(name, limbs) SP_MEMBER Fr name() { Fr r = {limbs}; return r; }
+struct SecpP {
+    static constexpr u32 inv32 = SECP_P_INV32;
+    SP_CONST(mod, SECP_P_LIMBS) SP_CONST(one, SECP_P_ONE_LIMBS) SP_CONST(r2, SECP_P_R2_LIMBS) SP_CONST(m2, SECP_P_M2_LIMBS)
+};
+struct SecpN {
+    static constexpr u32 inv32 = SECP_N_INV32;
+    SP_CONST(mod, SECP_N_LIMBS) SP_CONST(one, SECP_N_ONE_LIMBS) SP_CONST(r2, SECP_N_R2_LIMBS) SP_CONST(m2, SECP_N_M2_LIMBS)
+};
+FR_CONST_ARR(secp_gx_m, SECP_GX_M_LIMBS)
+FR_CONST_ARR(secp_gy_m, SECP_GY_M_LIMBS)
+
+// Montgomery product a*b*R^-1 mod m (CIOS); a, b < m; result < m.
+template <class M>
+ZK_NOINLINE Fr sp_mont(Fr a, Fr b) {
+    const Fr m = M::mod();
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+        const u32 bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * bi + t[j];
+            t[j] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (u32)c;
+        t[9] = (u32)(c >> 32);
+        const u32 q = t[0] * M::inv32;
+        c = (u64)q * m.v[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (u64)q * m.v[j] + t[j];
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (u32)c;
+        t[8] = t[9] + (u32)(c >> 32);
+    }
+    Fr r, s;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    const u32 bw = u256_sub(s, r, m);
+    const bool take = t[8] || !bw;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = take ? s.v[i] : r.v[i];
+    return r;
+}
+template <class M>
+ZK_HD Fr sp_add(const Fr& a, const Fr& b) {
+    Fr s, t;
+    const u32 carry = u256_add(s, a, b);
+    const u32 bw = u256_sub(t, s, M::mod());
+    const bool take = carry || !bw;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = take ? t.v[i] : s.v[i];
+    return s;
+}
+template <class M>
+ZK_HD Fr sp_sub(const Fr& a, const Fr& b) {
+    Fr d, t;
+    const u32 bw = u256_sub(d, a, b);
+    u256_add(t, d, M::mod());
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.v[i] = bw ? t.v[i] : d.v[i];
+    return d;
+}
+template <class M>
+ZK_HD Fr sp_reduce_once(const Fr& x) {  // x < 2^256 < 2m
+    Fr t, r = x;
+    const u32 bw = u256_sub(t, x, M::mod());
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = bw ? x.v[i] : t.v[i];
+    return r;
+}
+template <class M>
+ZK_HD Fr sp_to_mont(const Fr& a) { return sp_mont<M>(a, M::r2()); }
+template <class M>
+ZK_HD Fr sp_from_mont(const Fr& aM) { return sp_mont<M>(aM, fr_from_u64(1)); }
+// aM^(m-2) in Montgomery form (Fermat inverse; m prime, a != 0)
+template <class M>
+ZK_NOINLINE Fr sp_inv(Fr aM) {
+    Fr e = M::m2();
+    Fr acc = M::one();
+    for (int i = 0; i < 256; i++) {
+        acc = sp_mont<M>(acc, acc);
+        if (e.v[7] >> 31) acc = sp_mont<M>(acc, aM);
+#pragma unroll
+        for (int j = 7; j > 0; j--) e.v[j] = (e.v[j] << 1) | (e.v[j - 1] >> 31);
+        e.v[0] <<= 1;
+    }
+    return acc;
+}
+
+struct SpPoint {
+    Fr X, Y, Z;  // Montgomery form mod P
+    u32 inf;
+};
+ZK_HD SpPoint sp_infinity() {
+    SpPoint p;
+    p.X = fr_zero(); p.Y = fr_zero(); p.Z = fr_zero();
+    p.inf = 1;
+    return p;
+}
+// 2p ("dbl-2009-l", a = 0).  y == 0 -> O (the affine code sees x1 == x2 and y1 + y2 == 0).
+ZK_NOINLINE SpPoint sp_dbl(SpPoint p) {
+    if (p.inf || fr_is_zero(p.Y)) return sp_infinity();
+    typedef SecpP F;
+    const Fr A = sp_mont<F>(p.X, p.X), B = sp_mont<F>(p.Y, p.Y), C = sp_mont<F>(B, B);
+    Fr t = sp_add<F>(p.X, B);
+    t = sp_sub<F>(sp_sub<F>(sp_mont<F>(t, t), A), C);
+    const Fr D = sp_add<F>(t, t), E = sp_add<F>(sp_add<F>(A, A), A), Fq = sp_mont<F>(E, E);
+    SpPoint r;
+    r.X = sp_sub<F>(Fq, sp_add<F>(D, D));
+    Fr c8 = sp_add<F>(C, C);
+    c8 = sp_add<F>(c8, c8);
+    c8 = sp_add<F>(c8, c8);
+    r.Y = sp_sub<F>(sp_mont<F>(E, sp_sub<F>(D, r.X)), c8);
+    const Fr yz = sp_mont<F>(p.Y, p.Z);
+    r.Z = sp_add<F>(yz, yz);
+    r.inf = 0;
+    return r;
+}
+// p + q with the case analysis of the affine formulas: O + q = q, p + O = p; x1 == x2: y1 + y2 == 0 -> O, else the
+// tangent at p (y1 == 0 there means inverting 0: `value_error`); otherwise the chord.
+ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q, u32& value_error) {
+    if (p.inf) return q;
+    if (q.inf) return p;
+    typedef SecpP F;
+    const Fr z1z1 = sp_mont<F>(p.Z, p.Z), z2z2 = sp_mont<F>(q.Z, q.Z);
+    const Fr u1 = sp_mont<F>(p.X, z2z2), u2 = sp_mont<F>(q.X, z1z1);
+    const Fr s1 = sp_mont<F>(sp_mont<F>(p.Y, q.Z), z2z2), s2 = sp_mont<F>(sp_mont<F>(q.Y, p.Z), z1z1);
+    if (fr_eq(u1, u2)) {
+        if (fr_is_zero(sp_add<F>(s1, s2))) return sp_infinity();
+        if (fr_is_zero(p.Y)) { value_error = 1; return sp_infinity(); }
+        return sp_dbl(p);
+    }
+    const Fr h = sp_sub<F>(u2, u1), rr = sp_sub<F>(s2, s1);
+    const Fr hh = sp_mont<F>(h, h), hhh = sp_mont<F>(h, hh), v = sp_mont<F>(u1, hh);
+    SpPoint r;
+    r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
+    r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(s1, hhh));
+    r.Z = sp_mont<F>(sp_mont<F>(p.Z, q.Z), h);
+    r.inf = 0;
+    return r;
+}
+// k * pt, k < N canonical: acc += pt for every set bit from the least significant one, pt doubling in between
+ZK_NOINLINE SpPoint sp_scalar_mul(SpPoint pt, Fr k) {
+    SpPoint acc = sp_infinity();
+    u32 ve = 0;
+    while (!fr_is_zero(k)) {
+        if (k.v[0] & 1u) acc = sp_add_points(acc, pt, ve);
+        pt = sp_dbl(pt);
+#pragma unroll
+        for (int j = 0; j < 7; j++) k.v[j] = (k.v[j] >> 1) | (k.v[j + 1] << 31);
+        k.v[7] >>= 1;
+    }
+    return acc;
+}
+
+ZK_HD Fr sp_load_le(const uint8_t* p) {  // 32 little-endian bytes, 4-byte aligned
+    Fr r;
+    const u32* w = (const u32*)p;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = w[j];
+    return r;
+}
+ZK_HD Fr sp_load_be(const uint8_t* p) {
+    Fr r;
+    const u32* w = (const u32*)p;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u32 x = w[7 - j];
+        r.v[j] = (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24);
+    }
+    return r;
+}
+
+enum { ECDSA_OK = 0, ECDSA_NOT_VERIFIED = 1 };
+#define ECDSA_BAD_SIGNATURE ZK_CODE(ZK_UNSUPPORTED, 1)   // eth_keys BadSignature: no class of its own on the wire
+#define ECDSA_KEY_RANGE ZK_CODE(ZK_UNSUPPORTED, 2)       // public-key coordinate >= P: outside the engine's domain
+#define ECDSA_VALUE_ERROR ZK_CODE(ZK_VALUE_ERROR, 3)     // pow(0, -1, P) in the final addition
+
+struct EcdsaArgs {
+    const uint8_t* bytes;  // per signature: pk_x LE, pk_y LE, msg_hash (BE or LE), sig_r LE, sig_s LE (32 bytes each)
+    u64 stride;            // bytes between signatures
+    u32 off[5];            // byte offsets of the five fields
+    u32 msg_be;            // 1: msg_hash bytes are big-endian (util/ec.py:93), 0: little-endian (tx_circuit.py:131)
+    const u32* v;          // optional recovery ids, v[i * v_stride] (Sig circuit): outside {0, 1} -> BadSignature
+    u32 v_stride;
+    u64 n;
+    u32* out;              // optional: out[i * out_stride] = status (e.g. the sign units' meta column)
+    u32 out_stride;
+};
+
+// `ecdsa_status` of signature i: 0 verified, 1 not verified, else the status code of the exception
+ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i) {
+    const uint8_t* base = a.bytes + i * a.stride;
+    const Fr pkx = sp_load_le(base + a.off[0]), pky = sp_load_le(base + a.off[1]);
+    const Fr z = a.msg_be ? sp_load_be(base + a.off[2]) : sp_load_le(base + a.off[2]);
+    const Fr r = sp_load_le(base + a.off[3]), s = sp_load_le(base + a.off[4]);
+    const Fr n = SecpN::mod(), p = SecpP::mod();
+    if (a.v && a.v[i * a.v_stride] > 1u) return ECDSA_BAD_SIGNATURE;
+    if (!fr_lt(r, n) || !fr_lt(s, n)) return ECDSA_BAD_SIGNATURE;
+    if (!fr_lt(pkx, p) || !fr_lt(pky, p)) return ECDSA_KEY_RANGE;
+    if (fr_is_zero(r) || fr_is_zero(s)) return ECDSA_NOT_VERIFIED;
+    const Fr wM = sp_inv<SecpN>(sp_to_mont<SecpN>(s));
+    const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
+    const Fr u2 = sp_mont<SecpN>(r, wM);
+    SpPoint g, q;
+    g.X = secp_gx_m(); g.Y = secp_gy_m(); g.Z = SecpP::one(); g.inf = 0;
+    q.X = sp_to_mont<SecpP>(pkx); q.Y = sp_to_mont<SecpP>(pky); q.Z = SecpP::one(); q.inf = 0;
+    const SpPoint A = sp_scalar_mul(g, u1);
+    const SpPoint B = sp_scalar_mul(q, u2);
+    u32 ve = 0;
+    const SpPoint C = sp_add_points(A, B, ve);
+    if (ve) return ECDSA_VALUE_ERROR;
+    if (C.inf) return ECDSA_NOT_VERIFIED;
+    const Fr zi = sp_inv<SecpP>(C.Z);
+    const Fr x = sp_from_mont<SecpP>(sp_mont<SecpP>(C.X, sp_mont<SecpP>(zi, zi)));
+    return fr_eq(sp_reduce_once<SecpN>(x), r) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
+}

@@ -15,6 +15,7 @@
 #include "sign_circuit.hpp"
 #include "keccak_table.hpp"
 #include "state_assign.hpp"
+#include "secp256k1.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -390,6 +391,17 @@ __global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u3
     }
     tally_commit(tally, i, code);
 }
+// secp256k1 ECDSA verification: one lane per signature (secp256k1.hpp); integer-ALU bound
+__global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.n) {
+        code = ecdsa_verify_one(a, i);
+        if (status) status[i] = code;
+        if (a.out) a.out[i * a.out_stride] = code;
+    }
+    tally_commit(tally, i, code);
+}
 // Keccak table generation: one lane per message (keccak_table.hpp)
 __global__ void keccak_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
@@ -431,7 +443,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9 };
 
 struct zk_session {
     SessionKind kind;
@@ -449,6 +461,7 @@ struct zk_session {
     SignArgs sign;
     KeccakGenArgs keccak_gen;
     AssignArgs assign;
+    EcdsaArgs ecdsa;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -1035,6 +1048,53 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
     return rc;
 }
 
+// ---- secp256k1 ECDSA verification
+extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
+                             uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_ecdsa_open: call zk_init first");
+    ARG_TRY(out && bytes && n > 0 && n < (1ull << 32) && layout <= 2u && (!v || v_stride >= 1), "zk_ecdsa_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || !out_dev, "zk_ecdsa_open: out_dev needs ZK_OPT_DEVICE_PTRS");
+    ARG_TRY(!out_dev || out_stride >= 1, "zk_ecdsa_open: out_stride must be >= 1");
+    zk_session* s = new zk_session();
+    s->kind = SESSION_ECDSA;
+    s->n = n;
+    EcdsaArgs& a = s->ecdsa;
+    int rc = 0;
+    const void* p = nullptr;
+    // layout 0: packed uint8[n][5][32] (msg_hash big-endian); 1 / 2: the Tx / Sig units' byte rows uint8[n][9][32]
+    // (rows 2, 3, 5, 7, 8; the Tx chip keeps msg_hash little-endian, the Sig chip big-endian)
+    static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
+    a.stride = layout ? 288 : 160;
+    a.msg_be = layout != 1u;
+    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
+    if ((rc = stage(s, bytes, (size_t)n * a.stride, dev, &p))) goto fail;
+    a.bytes = (const uint8_t*)p;
+    a.v = nullptr;
+    a.v_stride = v_stride;
+    if (v) {
+        if ((rc = stage(s, v, (size_t)n * 4 * v_stride, dev, &p))) goto fail;
+        a.v = (const u32*)p;
+    }
+    a.n = n;
+    a.out = out_dev;
+    a.out_stride = out_stride;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
+                               uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_ecdsa_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_ecdsa_open(bytes, layout, v, v_stride, n, nullptr, 0, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -1176,6 +1236,12 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         hipLaunchKernelGGL(assign_scan_kernel, dim3(1), dim3(1024), 0, g_stream, a);
         hipLaunchKernelGGL(assign_rank_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
         hipLaunchKernelGGL(assign_rows_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a, status, s->d_tally);
+        break;
+    }
+    case SESSION_ECDSA: {
+        // 64-lane blocks: 2^14 signatures are only 256 wavefronts, one per CU
+        const u32 grid = (u32)((s->n + 63) / 64);
+        hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(grid), dim3(64), 0, g_stream, s->ecdsa, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

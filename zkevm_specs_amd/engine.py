@@ -320,6 +320,31 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev))
 
 
+ECDSA_LAYOUT_PACKED = 0  # uint8[n, 5, 32]: pk_x LE, pk_y LE, msg_hash BE, sig_r LE, sig_s LE
+ECDSA_LAYOUT_TX_UNITS = 1   # uint8[n, 9, 32]: the Tx units' byte rows (open_sign's wire["bytes"]; msg_hash little-endian)
+ECDSA_LAYOUT_SIG_UNITS = 2  # the Sig units' byte rows (msg_hash big-endian; v = meta[:, 3])
+
+
+def open_ecdsa(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, out_dev=None, out_stride=1, device=None, v_stride=1):
+    """secp256k1 ECDSA verification session: status per signature = the `ecdsa_status` column of the Tx / Sig units
+    (0 verified, 1 not verified, else the exception's code; include/zkevm_hip.h).  out_dev: optional CUDA uint32
+    tensor receiving status i at element i * out_stride (e.g. the units' meta tensor with stride 4)."""
+    lib = _lib.init(device)
+    (sig_bytes, v, out_dev), opts = _prep([sig_bytes, v, out_dev])
+    n = int(sig_bytes.shape[0])
+    h = ctypes.c_void_p()
+    check(lib.zk_ecdsa_open(_lib.ptr(sig_bytes), int(layout), _lib.ptr(v), int(v_stride), n, _lib.ptr(out_dev),
+                            int(out_stride), opts, ctypes.byref(h)), "zk_ecdsa_open")
+    return Session(h, n, (sig_bytes, v, out_dev))
+
+
+def ecdsa_status(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, device=None, v_stride=1):
+    """-> uint32[n] ecdsa_status computed on the GPU"""
+    with open_ecdsa(sig_bytes, v, layout, device=device, v_stride=v_stride) as s:
+        s.run()
+        return s.read_status()
+
+
 def fr_op(op, a, b):
     """Vector Fr op on the device (host numpy in/out): a, b uint64[n, 4]."""
     lib = _lib.init()

@@ -294,6 +294,13 @@ def _byte_rows(fields):
     return rows, malformed
 
 
+def _le_bytes_or_zero(get):
+    try:
+        return get().to_le_bytes()
+    except Exception:  # noqa: BLE001 - tampered chips: the pre-computed ecdsa_status column carries the outcome
+        return bytes(32)
+
+
 def _ecdsa_status(call, returns_bool):
     """Outcome of the reference-style ECDSA chip's verify(): 0 verified, 1 not verified (returned False /
     asserted), otherwise (kind << 24) of the exception it raised — the pre-computed `ecdsa_status` column."""
@@ -319,8 +326,11 @@ def flatten_tx_witness(witness, max_txs):
     bts, cells, meta = [], [], []
     for sv in witness.sign_verifications[:max_txs]:
         e = sv.ecdsa_chip
+        # rows 7, 8: the ECDSA chip's (r, s) as it hands them to eth_keys (tx_circuit.py:149-150); the Tx kernel does
+        # not read them, the device ECDSA pass (zk_ecdsa_open, layout 1) does
         rows_, bad = _byte_rows([sv.pub_key_x_bytes, sv.pub_key_y_bytes, e.pub_key_x_bytes, e.pub_key_y_bytes,
-                                 sv.msg_hash_bytes, e.msg_hash_bytes, sv.pub_key_hash, bytes(32), bytes(32)])
+                                 sv.msg_hash_bytes, e.msg_hash_bytes, sv.pub_key_hash,
+                                 _le_bytes_or_zero(lambda e=e: e.signature[0]), _le_bytes_or_zero(lambda e=e: e.signature[1])])
         bts.append(rows_)
         cells.append([_n(sv.address), _n(sv.msg_hash.lo), _n(sv.msg_hash.hi), 0, 0, 0, 0, 0])
         meta.append([_ecdsa_status(lambda e=e: e.verify(""), False), 1, bad, 0])
@@ -348,7 +358,10 @@ def flatten_sig_witness(witness):
         bts.append(rows_)
         cells.append([_n(row.recovered_addr), _n(row.msg_hash.lo), _n(row.msg_hash.hi), _n(row.sig_v), _n(row.sig_r.lo),
                       _n(row.sig_r.hi), _n(row.sig_s.lo), _n(row.sig_s.hi)])
-        meta.append([_ecdsa_status(lambda e=e: e.verify(), True), int(bool(row.is_valid)), bad, 0])
+        # meta[3]: the v the chip hands to eth_keys (util/ec.py:110; the Row's own sig_v cell can be tampered separately)
+        chip_v = _le_bytes_or_zero(lambda e=e: e.sig_v)
+        meta.append([_ecdsa_status(lambda e=e: e.verify(), True), int(bool(row.is_valid)), bad,
+                     min(int.from_bytes(chip_v, "little"), 0xFFFFFFFF)])
     return {
         "bytes": np.array(bts, dtype=np.uint8).reshape(-1, SIGN_NBYTES_ROWS, 32),
         "cells": rows_to_colmajor(cells, SIGN_NCELLS),

@@ -387,11 +387,65 @@ def synth_exp_witness(n_rows, seed=5):
 
 
 # ---- Tx circuit (config 4) ------------------------------------------------------------------------
-def synth_tx_witness(n_txs, r, seed=4, padding=0):
-    """n_txs transaction slots (+ `padding` zero slots) for the Tx circuit's SignVerify path: random
-    64-byte public keys, a synthetic 32-byte digest as pub_key_hash (the circuit checks keccak-table
-    membership of (RLC(pk), 64, hash), not the hash function), address = low 20 bytes, random message
-    hashes, ecdsa_status = 0 (the secp256k1 verdict is a pre-computed input column).  Returns the wire dict."""
+_SECP_P = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F
+_SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+_SECP_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+           0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+
+
+def _secp_add(p1, p2):
+    if p1 is None or p2 is None:
+        return p2 if p1 is None else p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % _SECP_P == 0:
+            return None
+        m = 3 * x1 * x1 * pow(2 * y1, -1, _SECP_P) % _SECP_P
+    else:
+        m = (y2 - y1) * pow(x2 - x1, -1, _SECP_P) % _SECP_P
+    x3 = (m * m - x1 - x2) % _SECP_P
+    return x3, (m * (x1 - x3) - y1) % _SECP_P
+
+
+def _secp_mul(pt, k):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _secp_add(acc, pt)
+        pt, k = _secp_add(pt, pt), k >> 1
+    return acc
+
+
+def synth_signatures(n, seed):
+    """n valid secp256k1 (pk_x, pk_y, z, r, s) tuples for synthetic witnesses.  Private keys d_i = d_0 + i and nonces
+    k_i = k_0 + i, so that every further key pair and signature costs two affine additions of G instead of two scalar
+    multiplications (2^14 of them in seconds of pure Python).  Test data only."""
+    import random
+
+    rng = random.Random(seed)
+    d, k = rng.randrange(1, _SECP_N - n), rng.randrange(1, _SECP_N - n)
+    Q, R = _secp_mul(_SECP_G, d), _secp_mul(_SECP_G, k)
+    out = []
+    for _ in range(n):
+        z = rng.getrandbits(256)
+        r = R[0] % _SECP_N
+        s = pow(k, -1, _SECP_N) * (z + r * d) % _SECP_N
+        out.append((Q[0], Q[1], z, r, s))
+        d, k, Q, R = d + 1, k + 1, _secp_add(Q, _SECP_G), _secp_add(R, _SECP_G)
+    return out
+
+
+ECDSA_STATUS_PENDING = 0xFFFFFFFF  # meta[:, 0] placeholder: the Tx kernel fails every unit until the ECDSA pass filled it
+
+
+def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False):
+    """n_txs transaction slots (+ `padding` zero slots) for the Tx circuit's SignVerify path: 64-byte public
+    keys, a synthetic 32-byte digest as pub_key_hash (the circuit checks keccak-table membership of
+    (RLC(pk), 64, hash), not the hash function), address = low 20 bytes, message hashes.
+    signed=False: random bytes as keys, ecdsa_status = 0 (the secp256k1 verdict as a pre-computed input column).
+    signed=True: real key pairs and valid signatures (byte rows 7, 8 = r, s); ecdsa_status is left PENDING for the
+    device ECDSA pass (engine.open_ecdsa(..., layout=ECDSA_LAYOUT_TX_UNITS, out_dev=meta, out_stride=4)).
+    Returns the wire dict."""
     import hashlib
     import random
 
@@ -400,12 +454,20 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0):
     rng = random.Random(seed)
     bts, cells, meta, rows, flags = [], [], [], [], []
     keccak = {(0, 0, 0, 0, 0)}
+    sigs = synth_signatures(n_txs + 1, seed) if signed else None  # the last one: the padding slots' dummy (tx_circuit.py:463-475)
     for i in range(n_txs + padding):
+        sig_r = sig_s = bytes(32)
         if i < n_txs:
-            pk_x = bytes(rng.getrandbits(8) for _ in range(32))  # little-endian limbs, as in the chip
-            pk_y = bytes(rng.getrandbits(8) for _ in range(32))
+            if signed:
+                qx, qy, z, sr, ss = sigs[i]
+                pk_x, pk_y = qx.to_bytes(32, "little"), qy.to_bytes(32, "little")
+                msg = z.to_bytes(32, "little")  # the Tx chip's msg_hash_bytes are little-endian (tx_circuit.py:131)
+                sig_r, sig_s = sr.to_bytes(32, "little"), ss.to_bytes(32, "little")
+            else:
+                pk_x = bytes(rng.getrandbits(8) for _ in range(32))  # little-endian limbs, as in the chip
+                pk_y = bytes(rng.getrandbits(8) for _ in range(32))
+                msg = bytes(rng.getrandbits(8) for _ in range(32))
             h = hashlib.blake2b(pk_x + pk_y, digest_size=32).digest()
-            msg = bytes(rng.getrandbits(8) for _ in range(32))
             acc = 0
             for b in reversed(pk_y + pk_x):
                 acc = (acc * r + b) % _FR_P
@@ -416,9 +478,13 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0):
         else:
             pk_x = pk_y = h = msg = bytes(32)
             addr = m_lo = m_hi = 0
-        bts.append([list(pk_x), list(pk_y), list(pk_x), list(pk_y), list(msg), list(msg), list(h), [0] * 32, [0] * 32])
+            if signed:
+                qx, qy, z, sr, ss = sigs[n_txs]
+                pk_x, pk_y, msg = qx.to_bytes(32, "little"), qy.to_bytes(32, "little"), z.to_bytes(32, "little")
+                sig_r, sig_s = sr.to_bytes(32, "little"), ss.to_bytes(32, "little")
+        bts.append([list(pk_x), list(pk_y), list(pk_x), list(pk_y), list(msg), list(msg), list(h), list(sig_r), list(sig_s)])
         cells.append([addr, m_lo, m_hi, 0, 0, 0, 0, 0])
-        meta.append([0, 1, 0, 0])
+        meta.append([ECDSA_STATUS_PENDING if signed else 0, 1, 0, 0])
         for tag in range(1, 13):  # Nonce .. TxSignHash (TxContextFieldTag, table.py:147-166)
             lo, hi, w = 0, 0, 0
             if tag == 4:
