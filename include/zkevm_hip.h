@@ -109,13 +109,23 @@ typedef struct zk_evm_tables {
     const uint64_t* copy;       uint64_t n_copy;
     const uint64_t* keccak;     uint64_t n_keccak;
     const uint64_t* exp;        uint64_t n_exp;
-    /* StepState.aux_data (step.py:44), optional (NULL = absent for every step): aux uint64[n_steps][2][4] and
-     * aux_kind uint32[n_steps]: 0 none, 1 Word (lo, hi), 2 int < 2^256 (lo, hi), 3 pair of field values,
-     * 4 not representable (a gadget that reads it reports ZK_UNSUPPORTED). */
+    /* StepState.aux_data (step.py:44), optional (NULL = absent for every step): aux uint64[n_steps][aux_cells][4] and
+     * aux_kind uint32[n_steps]: 0 none, 1 Word (lo, hi), 2 int < 2^256 (lo, hi), 3 pair of ints < p (CALL into a
+     * precompile: input / return length), 4 not representable (a gadget that reads it reports ZK_UNSUPPORTED),
+     * 5 ecRecover [PrecompileAuxData, randomness]: msg_hash, sig_v, sig_r, sig_s as lo/hi, recovered_addr, input_rlc,
+     * output_rlc, keccak_randomness (12 cells, ecrecover.py:15-44), 6 ecAdd [px, py, qx, qy, outx, outy] (10 cells),
+     * 7 ecMul [px, py, s, outx, outy] (8 cells), 8 ecPairing [input_rlc, input_pairs, is_valid_input, output] (4). */
     const uint64_t* aux;        const uint32_t* aux_kind;
     /* Tables.withdrawal_table (WithdrawalTableRow, table.py:430-434: id, validator_id, address, amount), optional:
      * uint64[n][4][4], sorted by id (the order end_block.py:152 walks them in).  Only EndBlock's last step reads it. */
     const uint64_t* withdrawals; uint64_t n_withdrawals;
+    /* Tables.sig_table / ecc_table (table.py:552-575), optional: sig uint64[n][9][4] (msg_hash lo/hi, sig_v, sig_r lo/hi,
+     * sig_s lo/hi, recovered_addr, is_valid); ecc uint64[n][13][4] (op_type, px lo/hi, py lo/hi, qx lo/hi, qy lo/hi,
+     * input_rlc, out_x, out_y, is_valid).  Only the ecRecover / ecAdd / ecMul / ecPairing precompile states read them. */
+    const uint64_t* sig;        uint64_t n_sig;
+    const uint64_t* ecc;        uint64_t n_ecc;
+    uint32_t aux_cells;         /* cells per step in `aux`: 0 = 2 (kinds 0-3), 12 when kinds 5-8 are present */
+    uint32_t reserved;
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
 #define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */

@@ -57,7 +57,7 @@ class EvmWitness:
     """Flattened tables as Python ints + the indices the lookups use."""
 
     def __init__(self, steps, rw, rw_flags, bytecode, tx=(), tx_flags=(), block=(), block_flags=(), copy=(),
-                 keccak=(), exp=(), aux=None, aux_kind=None, withdrawals=()):
+                 keccak=(), exp=(), aux=None, aux_kind=None, withdrawals=(), sig=(), ecc=()):
         self.steps = steps
         self.rw = [tuple(r) for r in rw]
         self.rw_flags = list(rw_flags)
@@ -93,6 +93,14 @@ class EvmWitness:
             self.keccak_idx.setdefault((r[2], r[1]), []).append(i)
         for i, r in enumerate(self.exp):
             self.exp_idx.setdefault(r[1], []).append(i)
+        # sig table (9 cells, table.py:552-558) and ecc table (13 cells, :562-575): every lookup gives all the fields
+        self.sig = [tuple(r) for r in sig]
+        self.ecc = [tuple(r) for r in ecc]
+        self.sig_idx, self.ecc_idx = {}, {}
+        for i, r in enumerate(self.sig):
+            self.sig_idx.setdefault(r, []).append(i)
+        for i, r in enumerate(self.ecc):
+            self.ecc_idx.setdefault(r, []).append(i)
 
 
 def _distinct_match(rows, cands, query):
@@ -333,6 +341,22 @@ class Ins:
         q = [(0, 2), (2, length % P), (1, value_rlc % P)]
         r = self.w.keccak[self._lookup(self.w.keccak, self.w.keccak_idx.get((length % P, value_rlc % P), ()), q)]
         return (r[3], r[4])
+
+    def sig_lookup(self, msg_hash, sig_v, sig_r, sig_s, recovered_addr, is_valid):  # table.py:816-833
+        row = (msg_hash[0] % P, msg_hash[1] % P, sig_v % P, sig_r[0] % P, sig_r[1] % P, sig_s[0] % P, sig_s[1] % P,
+               recovered_addr % P, is_valid % P)
+        self._lookup(self.w.sig, self.w.sig_idx.get(row, ()), list(enumerate(row)))
+
+    def ecc_lookup(self, op_type, px, py, qx, qy, input_rlc, outx, outy, is_valid):  # table.py:835-858
+        row = (op_type % P, px[0] % P, px[1] % P, py[0] % P, py[1] % P, qx[0] % P, qx[1] % P, qy[0] % P, qy[1] % P,
+               input_rlc % P, outx % P, outy % P, is_valid % P)
+        self._lookup(self.w.ecc, self.w.ecc_idx.get(row, ()), list(enumerate(row)))
+
+    def aux_cells(self, kind):
+        """StepState.aux_data of the current step in its wide wire form; other shapes are not evaluated"""
+        if self.w.aux_kind[self.idx] != kind:
+            raise Fail(UNSUPPORTED, self.seq)
+        return self.w.aux[self.idx]
 
     def exp_lookup(self, identifier, is_last, base_limbs, exponent):
         q = [(0, 1), (1, identifier % P), (2, is_last % P)] + [(3 + k, base_limbs[k] % P) for k in range(4)] + \
@@ -2030,8 +2054,59 @@ def g_callop(i):  # callop.py (precompile callees read StepState.aux_data: not e
         i.transition(S_IS_ROOT, "same")
         i.transition(S_IS_CREATE, "same")
         i.require(i.next[S_CH_LO] == i.curr[S_CH_LO] and i.next[S_CH_HI] == i.curr[S_CH_HI])
-    elif is_precompile == 1:
-        raise Fail(UNSUPPORTED, i.seq)  # precompile_input_len / return_length come from StepState.aux_data
+    elif is_precompile == 1:  # callop.py:154-276
+        input_len, return_len = i.aux_cells(3)[:2]  # Python ints < p (flatten_step_aux)
+        min_rd_copy_size = min(return_len, call.rd_length)
+        i.constrain_equal(no_callee_code, 1)
+        i.constrain_equal(is_warm, 1)
+        for tag, want in ((CC.IsSuccess, (call.is_success, 0)), (CC.CalleeAddress, callee_address_w), (CC.CallerId, (i.curr[S_CALL_ID], 0)),
+                          (CC.CallDataOffset, (call.cd_offset, 0)), (CC.CallDataLength, (call.cd_length, 0)),
+                          (CC.ReturnDataOffset, (call.rd_offset, 0)), (CC.ReturnDataLength, (call.rd_length, 0))):
+            got, _ = i.call_context_lookup_word(tag, rw=1, call_id=callee_call_id)
+            i.constrain_equal_word(got, want)
+        for tag, want in ((CC.ProgramCounter, i.curr[S_PC] + 1), (CC.StackPointer, i.curr[S_SP] + sp_delta),
+                          (CC.GasLeft, i.curr[S_GAS] - gas_cost - callee_gas_left), (CC.MemorySize, call.next_memory_size),
+                          (CC.ReversibleWriteCounter, i.curr[S_REV] + 1), (CC.LastCalleeId, callee_call_id),
+                          (CC.LastCalleeReturnDataOffset, 0), (CC.LastCalleeReturnDataLength, return_len)):
+            i.constrain_equal(i.call_context_lookup(tag, rw=1), want)
+        rwc_inc = i.rw_off
+        if input_len % P != 0:
+            inc, _ = i.copy_lookup((i.curr[S_CALL_ID], 0), CDT_MEMORY, (callee_call_id, 0), CDT_RLCACC, call.cd_offset,
+                                   call.cd_offset + input_len, 0, input_len, i.curr[S_RWC] + rwc_inc)
+            rwc_inc += inc
+        if call.is_success % P == 1 and return_len % P != 0:
+            inc, _ = i.copy_lookup((callee_call_id, 0), CDT_MEMORY, (callee_call_id, 0), CDT_RLCACC, 0, return_len, 0, return_len,
+                                   i.curr[S_RWC] + rwc_inc)
+            rwc_inc += inc
+            inc, _ = i.copy_lookup((callee_call_id, 0), CDT_MEMORY, (i.curr[S_CALL_ID], 0), CDT_MEMORY, 0, min_rd_copy_size,
+                                   call.rd_offset, min_rd_copy_size, i.curr[S_RWC] + rwc_inc)
+            rwc_inc += inc
+        mem_words, _ = i.constant_divmod(min_rd_copy_size + 31, 32, 4)
+        callee_gas_left = (callee_gas_left + call.has_value * 2300) % P
+        i.transition(S_RWC, "delta", rwc_inc)
+        i.transition(S_CALL_ID, "to", callee_call_id)
+        i.transition(S_IS_ROOT, "to", 0)
+        i.transition(S_IS_CREATE, "to", 0)
+        i.require(i.next[S_CH_LO] == EMPTY_HASH & M128 and i.next[S_CH_HI] == EMPTY_HASH >> 128)
+        i.transition(S_GAS, "to", callee_gas_left)
+        i.transition(S_REV, "to", 2)
+        i.transition(S_PC, "delta", 1)
+        i.transition(S_SP, "same")
+        i.transition(S_MWS, "to", mem_words)
+        i.transition(S_LOG, "same")
+        # PrecompileGadget (util/precompile_gadget.py:9-41)
+        i.constrain_equal(int(1 <= call.callee_address <= 9), 1)
+        addr = call.callee_address
+        if addr == 4:
+            i.constrain_equal(return_len, call.cd_length)
+        elif addr == 1:
+            i.constrain_equal(int(return_len % P == 32) + int(return_len % P == 0), 1)
+        elif addr == 6:
+            i.constrain_equal(call.cd_length, 128)
+        elif addr == 7:
+            i.constrain_equal(call.cd_length, 96)
+        elif addr == 8:
+            i.constrain_equal((call.cd_length % P) % 192, 0)
     else:
         for tag, want in ((CC.ProgramCounter, i.curr[S_PC] + 1), (CC.StackPointer, i.curr[S_SP] + sp_delta),
                           (CC.GasLeft, i.curr[S_GAS] - gas_cost - callee_gas_left), (CC.MemorySize, call.next_memory_size),
@@ -2247,6 +2322,90 @@ def g_datacopy(i):  # dataCopy.py (the identity precompile)
     i.rw_off += 4 * (size % P)
     _restore_context(i, i.rw_off, (i.curr[S_GAS] - gas_cost) % P, 0, size, caller_id=caller_id)
 
+SECP256K1N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def _horner(data, r):
+    acc = 0
+    for b in data:
+        acc = (acc * r + b) % P
+    return acc
+
+
+def _precompile_prelude(i, base_gas, with_calldata_len=False):
+    is_success = i.call_context_lookup(CC.IsSuccess)
+    calldata_len = i.call_context_lookup(CC.CallDataLength) if with_calldata_len else None
+    addr_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
+    address = i.word_to_fq(addr_w, 20)
+    i.fixed_lookup(T.FixedTableTag.PrecompileInfo, i.curr[S_STATE], address, base_gas)
+    return is_success, calldata_len
+
+
+def g_ecrecover(i):  # precompiles/ecrecover.py:26-94
+    is_success, _ = _precompile_prelude(i, 3000)
+    a = i.aux_cells(5)
+    msg_hash, sig_v, sig_r, sig_s = (a[0], a[1]), (a[2], a[3]), (a[4], a[5]), (a[6], a[7])
+    recovered_addr, aux_input_rlc, aux_output_rlc, rand = a[8], a[9], a[10], a[11]
+    is_recovered = int(recovered_addr % P != 0)
+    input_bytes = b"".join(i.int_value(w).to_bytes(32, "little") for w in (msg_hash, sig_v, sig_r, sig_s))
+    i.constrain_equal(aux_input_rlc, _horner(input_bytes, rand))
+    i.constrain_equal(aux_output_rlc, _horner(recovered_addr.to_bytes(32, "little"), rand))
+    i.constrain_equal(is_success, 1)
+    n_word = (SECP256K1N & M128, SECP256K1N >> 128)
+    r_ub, _ = i.compare_word(sig_r, n_word)
+    s_ub, _ = i.compare_word(sig_s, n_word)
+    r_nz, s_nz = 1 - i.is_zero_word(sig_r), 1 - i.is_zero_word(sig_s)
+    valid_r_s = int((r_ub + s_ub + r_nz + s_nz - 4) % P == 0)
+    valid_v = int((i.is_equal_word(sig_v, (27, 0)) + i.is_equal_word(sig_v, (28, 0)) - 1) % P == 0)
+    if valid_r_s + valid_v == 2:
+        i.sig_lookup(msg_hash, sig_v[0] - 27, sig_r, sig_s, recovered_addr, is_recovered)
+    else:
+        i.constrain_zero(is_recovered)
+        i.constrain_zero(recovered_addr)
+    _restore_context(i, i.rw_off, (i.curr[S_GAS] - 3000) % P, 0, 32 if is_recovered == 1 else 0)
+
+
+def g_ecadd(i):  # precompiles/ecadd.py:10-48
+    is_success, _ = _precompile_prelude(i, 150)
+    a = i.aux_cells(6)
+    px, py, qx, qy, outx, outy = (a[0], a[1]), (a[2], a[3]), (a[4], a[5]), (a[6], a[7]), a[8], a[9]
+    if is_success % P == 0:
+        i.constrain_zero(outx)
+        i.constrain_zero(outy)
+    i.ecc_lookup(1, px, py, qx, qy, 0, outx, outy, is_success)
+    ok = is_success % P == 1
+    _restore_context(i, i.rw_off, (i.curr[S_GAS] - 150) % P if ok else 0, 0, 64 if ok else 0)
+
+
+def g_ecmul(i):  # precompiles/ecmul.py:10-55
+    is_success, _ = _precompile_prelude(i, 6000)
+    a = i.aux_cells(7)
+    px, py, sc, outx, outy = (a[0], a[1]), (a[2], a[3]), (a[4], a[5]), a[6], a[7]
+    if is_success % P == 0 or sc == (0, 0) or (px == (0, 0) and py == (0, 0)):  # int_value() == 0 <=> both cells are 0
+        i.constrain_zero(outx)
+        i.constrain_zero(outy)
+    i.ecc_lookup(2, px, py, sc, (0, 0), 0, outx, outy, is_success)
+    ok = is_success % P == 1
+    _restore_context(i, i.rw_off, (i.curr[S_GAS] - 6000) % P if ok else 0, 0, 64 if ok else 0)
+
+
+def g_ecpairing(i):  # precompiles/ecpairing.py:13-78
+    is_success, calldata_len = _precompile_prelude(i, 45000, with_calldata_len=True)
+    input_rlc, input_pairs, is_valid_input, output = i.aux_cells(8)[:4]
+    i.constrain_equal(is_success, is_valid_input)
+    if (calldata_len % P) % 192 != 0:
+        i.constrain_equal(output, 0)
+        i.constrain_equal(is_valid_input, 0)
+    else:
+        i.constrain_equal(calldata_len, input_pairs * 192)
+        if calldata_len % P == 0:
+            i.constrain_zero(input_pairs)
+            i.constrain_zero(input_rlc)
+            i.constrain_equal(output, 1)
+    i.ecc_lookup(3, (0, 0), (0, 0), (0, 0), (0, 0), input_rlc, 0, output, is_valid_input)
+    gas_left = (i.curr[S_GAS] - 45000 - input_pairs * 34000) % P if is_success % P == 1 else 0
+    _restore_context(i, i.rw_off, gas_left, 0, 32 if is_valid_input % P == 1 else 0)
+
 
 def g_error_oog_precompile(i):  # precompiles/error_oog_precompile.py
     addr_w, _ = i.call_context_lookup_word(CC.CalleeAddress)
@@ -2431,7 +2590,8 @@ GADGETS = {
     ES.ErrorOutOfGasAccountAccess: g_error_oog_account_access, ES.ErrorOutOfGasLOG: g_error_oog_log,
     ES.ErrorOutOfGasEXP: g_error_oog_exp, ES.ErrorOutOfGasSHA3: g_error_oog_sha3,
     ES.ErrorReturnDataOutOfBound: g_error_return_data_oob, ES.ErrorWriteProtection: g_error_write_protection,
-    ES.DATACOPY: g_datacopy, ES.ErrorOutOfGasPrecompile: g_error_oog_precompile, ES.ErrorOutOfGasCREATE: g_error_oog_create,
+    ES.DATACOPY: g_datacopy, ES.ECRECOVER: g_ecrecover, ES.BN254_ADD: g_ecadd, ES.BN254_SCALAR_MUL: g_ecmul,
+    ES.BN254_PAIRING: g_ecpairing, ES.ErrorOutOfGasPrecompile: g_error_oog_precompile, ES.ErrorOutOfGasCREATE: g_error_oog_create,
     ES.ErrorGasUintOverflow: g_error_gas_uint_overflow, ES.CREATE: g_create, ES.CREATE2: g_create, ES.ErrorOutOfGasSloadSstore: g_error_oog_sload_sstore, ES.CALL_OP: g_callop, ES.ErrorOutOfGasCall: g_error_oog_call, ES.BeginTx: g_begin_tx, ES.EndTx: g_end_tx, ES.RETURN: g_return, ES.ErrorInvalidCreationCode: g_error_invalid_creation_code,
     ES.ErrorMaxCodeSizeExceeded: g_error_code_store, ES.ErrorOutOfGasCodeStore: g_error_code_store, ES.EndBlock: g_end_block,
     ES.ErrorInvalidOpcode: g_error_invalid_opcode, ES.ErrorStack: g_error_stack,

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import codes, evm_oracle as eo, wire  # noqa: E402
-from oracle.gen_golden_evm import REF_TESTS, TEST_FILES, Harvest, fuzz_wire, ref_step_outcomes, unflatten  # noqa: E402
+from oracle.gen_golden_evm import PRECOMPILE_TESTS, REF_TESTS, TEST_FILES, Harvest, fuzz_wire, ref_step_outcomes, unflatten  # noqa: E402
 
 
 def to_witness(w):
@@ -24,7 +24,8 @@ def to_witness(w):
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
                          wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
-                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]))
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]),
+                         wire.rowmajor_to_rows(w["sig"]), wire.rowmajor_to_rows(w["ecc"]))
 
 
 def main():
@@ -48,7 +49,7 @@ def main():
         else:
             h = Harvest()
             rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null",
-                              os.path.join(REF_TESTS, f"test_{name}.py")], plugins=[h])
+                              os.path.join(REF_TESTS, "precompiles" if name in PRECOMPILE_TESTS else "", f"test_{name}.py")], plugins=[h])
             assert rc == 0
             all_cases = h.cases
         cases = all_cases if len(all_cases) <= 60 else rng.sample(all_cases, 60)

@@ -29,7 +29,8 @@ calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_j
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
 error_return_data_out_of_bound error_write_protection logs return_revert
-error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom error_oog_create error_gas_uint_overflow""".split()
+error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom error_oog_create error_gas_uint_overflow ecRecover ecAdd ecMul ecPairing""".split()
+PRECOMPILE_TESTS = ("ecRecover", "ecAdd", "ecMul", "ecPairing")  # tests/evm/precompiles/
 MAX_CASES_PER_FILE = 48
 
 
@@ -98,7 +99,19 @@ def unflatten(wire):
         for s, a, k in zip(steps, rowmajor_to_rows(wire["aux"]), wire["aux_kind"]):
             k = int(k)
             assert k != 4, "aux_data kind that the wire format cannot carry"
-            s.aux_data = None if k == 0 else (W(a[0], a[1]) if k == 1 else (a[0] | (a[1] << 128) if k == 2 else [FQ(a[0]), FQ(a[1])]))
+            if k == 5:
+                from zkevm_specs.evm_circuit.execution.precompiles.ecrecover import PrecompileAuxData
+
+                s.aux_data = [PrecompileAuxData(W(a[0], a[1]), W(a[2], a[3]), W(a[4], a[5]), W(a[6], a[7]), FQ(a[8]), FQ(a[9]),
+                                                FQ(a[10])), FQ(a[11])]
+            elif k == 6:
+                s.aux_data = [W(a[0], a[1]), W(a[2], a[3]), W(a[4], a[5]), W(a[6], a[7]), FQ(a[8]), FQ(a[9])]
+            elif k == 7:
+                s.aux_data = [W(a[0], a[1]), W(a[2], a[3]), W(a[4], a[5]), FQ(a[6]), FQ(a[7])]
+            elif k == 8:
+                s.aux_data = [FQ(a[0]), FQ(a[1]), FQ(a[2]), FQ(a[3])]
+            else:
+                s.aux_data = None if k == 0 else (W(a[0], a[1]) if k == 1 else (a[0] | (a[1] << 128) if k == 2 else [a[0], a[1]]))
     rw = set()
     for c, f in zip(rowmajor_to_rows(wire["rw"]), wire["rw_flags"]):
         rw.add(RWTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), W(c[6], c[7]),
@@ -120,6 +133,14 @@ def unflatten(wire):
     tables.keccak_table = set(KeccakTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), W(c[3], c[4])) for c in rowmajor_to_rows(wire["keccak"]))
     tables.exp_table = set(ExpTableRow(FQ(c[0]), FQ(c[1]), FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), FQ(c[6]), W(c[7], c[8]),
                                        W(c[9], c[10])) for c in rowmajor_to_rows(wire["exp"]))
+    from zkevm_specs.evm_circuit.table import EccTableRow, SigTableRow
+
+    if "sig" in wire:
+        tables.sig_table = set(SigTableRow(W(c[0], c[1]), FQ(c[2]), W(c[3], c[4]), W(c[5], c[6]), FQ(c[7]), FQ(c[8]))
+                               for c in rowmajor_to_rows(wire["sig"]))
+    if "ecc" in wire:
+        tables.ecc_table = set(EccTableRow(FQ(c[0]), W(c[1], c[2]), W(c[3], c[4]), W(c[5], c[6]), W(c[7], c[8]), FQ(c[9]), FQ(c[10]),
+                                           FQ(c[11]), FQ(c[12])) for c in rowmajor_to_rows(wire["ecc"]))
     return tables, steps
 
 
@@ -136,8 +157,14 @@ def fuzz_wire(wire, rng):
 
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
-        aux = [k for k in ("copy", "keccak", "exp") if k in w and w[k].shape[0]]
-        if aux and rng.random() < 0.25:
+        aux = [k for k in ("copy", "keccak", "exp", "sig", "ecc") if k in w and w[k].shape[0]]
+        wide = "aux" in w and w["aux"].shape[1] > 2
+        if wide and rng.random() < 0.3:  # precompile gadgets read most of their inputs from aux_data
+            i = rng.choice([j for j in range(w["aux"].shape[0]) if w["aux_kind"][j]] or [0])
+            c = rng.randrange(w["aux"].shape[1])
+            old = cur(w["aux"], (i, c))
+            put(w["aux"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(128)), 27, 28]))
+        elif aux and rng.random() < 0.25:
             k = rng.choice(aux)
             i, c = rng.randrange(w[k].shape[0]), rng.randrange(w[k].shape[1])
             old = cur(w[k], (i, c))
@@ -255,7 +282,7 @@ def main():
         elif name == "error_oog_precompile_custom":
             cases = error_oog_precompile_cases()
         else:
-            path = os.path.join(REF_TESTS, f"test_{name}.py")
+            path = os.path.join(REF_TESTS, "precompiles" if name in PRECOMPILE_TESTS else "", f"test_{name}.py")
             h = Harvest()
             rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null", path], plugins=[h])
             assert rc == 0, (name, rc)

@@ -8,8 +8,8 @@ import numpy as np
 from oracle import evm_oracle as eo, wire
 
 FIELDS = ("steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
-          "aux_kind", "withdrawals")
-_OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11, "withdrawals": 4}  # tables only some gadgets need; absent = empty
+          "aux_kind", "withdrawals", "sig", "ecc")
+_OPTIONAL = {"copy": 14, "keccak": 5, "exp": 11, "withdrawals": 4, "sig": 9, "ecc": 13}  # tables only some gadgets need; absent = empty
 
 
 def with_defaults(w):
@@ -42,7 +42,8 @@ def to_witness(w):
                          wire.rowmajor_to_rows(w["bytecode"]), wire.rowmajor_to_rows(w["tx"]), w["tx_flags"],
                          wire.rowmajor_to_rows(w["block"]), w["block_flags"], wire.rowmajor_to_rows(w["copy"]),
                          wire.rowmajor_to_rows(w["keccak"]), wire.rowmajor_to_rows(w["exp"]),
-                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]))
+                         wire.rowmajor_to_rows(w["aux"]), w["aux_kind"], wire.rowmajor_to_rows(w["withdrawals"]),
+                         wire.rowmajor_to_rows(w["sig"]), wire.rowmajor_to_rows(w["ecc"]))
 
 
 def oracle_status(w, opts=(0, 0)):
@@ -61,7 +62,8 @@ def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
                        u64(a["tx"].shape[0]), vp(a["block"]), vp(a["block_flags"]), u64(a["block"].shape[0]),
                        vp(a["copy"]), u64(a["copy"].shape[0]), vp(a["keccak"]), u64(a["keccak"].shape[0]),
                        vp(a["exp"]), u64(a["exp"].shape[0]), vp(a["aux"]), vp(a["aux_kind"]),
-                       vp(a["withdrawals"]), u64(a["withdrawals"].shape[0]),
+                       vp(a["withdrawals"]), u64(a["withdrawals"].shape[0]), vp(a["sig"]), u64(a["sig"].shape[0]),
+                       vp(a["ecc"]), u64(a["ecc"].shape[0]), ctypes.c_uint32(a["aux"].shape[1]),
                        ctypes.c_uint32(int(opts[0]) | (int(opts[1]) << 1) | (4 if generic_index else 0)), vp(st))
     return st[: n - 1].tolist()
 
@@ -79,8 +81,13 @@ def fuzz_wire(w, rng):
 
     for _ in range(rng.choice([1, 1, 2, 3])):
         which = rng.choice(["steps", "steps", "rw", "rw", "rw", "bytecode", "flags"])
-        aux = [k for k in ("copy", "keccak", "exp") if k in w and w[k].shape[0]]
-        if aux and rng.random() < 0.25:
+        aux = [k for k in ("copy", "keccak", "exp", "sig", "ecc") if k in w and w[k].shape[0]]
+        if "aux" in w and w["aux"].shape[1] > 2 and rng.random() < 0.3:  # precompile gadgets read their inputs from aux_data
+            i = rng.choice([j for j in range(w["aux"].shape[0]) if w["aux_kind"][j]] or [0])
+            c = rng.randrange(w["aux"].shape[1])
+            old = cur(w["aux"], (i, c))
+            put(w["aux"], (i, c), rng.choice([old + 1, old - 1, 0, 1, rng.randrange(P), old ^ (1 << rng.randrange(128)), 27, 28]))
+        elif aux and rng.random() < 0.25:
             k = rng.choice(aux)
             i, c = rng.randrange(w[k].shape[0]), rng.randrange(w[k].shape[1])
             old = cur(w[k], (i, c))

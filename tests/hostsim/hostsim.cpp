@@ -85,7 +85,8 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
                               const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
                               const u64* block, const u32* block_flags, u64 n_blk, const u64* copy, u64 n_copy,
                               const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, const u64* aux, const u32* aux_kind,
-                              const u64* wds, u64 n_wds, u32 opts, u32* status) {
+                              const u64* wds, u64 n_wds, const u64* sig, u64 n_sig, const u64* ecc, u64 n_ecc, u32 aux_cells,
+                              u32 opts, u32* status) {
     EvmArgs a;
     a.steps = steps;
     a.n_steps = n_steps;
@@ -95,6 +96,12 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     host_table(texp, exp, nullptr, n_exp, EXP_T_NCELLS, expt_key_hash);
     a.aux = aux;
     a.aux_kind = aux_kind;
+    a.aux_cells = aux_cells ? aux_cells : 2u;
+    HostTable tsig, tecc;
+    host_table(tsig, sig, nullptr, n_sig, SIG_T_NCELLS, sig_key_hash);
+    host_table(tecc, ecc, nullptr, n_ecc, ECC_T_NCELLS, ecc_key_hash);
+    a.sig = tsig.t;
+    a.ecc = tecc.t;
     HostTable twd;
     host_table(twd, wds, nullptr, n_wds, 4, blk_key_hash);  // iterated in order: the index is unused
     a.withdrawals = twd.t;

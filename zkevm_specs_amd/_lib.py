@@ -42,6 +42,9 @@ class ZkEvmTables(ctypes.Structure):
         ("exp", ctypes.c_void_p), ("n_exp", ctypes.c_uint64),
         ("aux", ctypes.c_void_p), ("aux_kind", ctypes.c_void_p),
         ("withdrawals", ctypes.c_void_p), ("n_withdrawals", ctypes.c_uint64),
+        ("sig", ctypes.c_void_p), ("n_sig", ctypes.c_uint64),
+        ("ecc", ctypes.c_void_p), ("n_ecc", ctypes.c_uint64),
+        ("aux_cells", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
     ]
 
 

@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "evm_tables.h"
 #include "keccak.hpp"
+#include "secp_constants.h"
 
 enum { S_STATE = 0, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, S_PC, S_SP, S_GAS, S_MWS, S_REV, S_LOG, STEP_NCELLS };
 enum { R_RWC = 0, R_RW, R_TAG, R_ID, R_ADDR, R_FT, R_KEY_LO, R_KEY_HI, R_VAL_LO, R_VAL_HI, R_PREV_LO, R_PREV_HI, R_AUX_LO, R_AUX_HI, RW_NCELLS };
@@ -34,6 +35,9 @@ enum { CT_IS_FIRST = 0, CT_SRC_ID_LO, CT_SRC_ID_HI, CT_SRC_TAG, CT_DST_ID_LO, CT
        CT_SRC_ADDR_END, CT_DST_ADDR, CT_LENGTH, CT_RLC_ACC, CT_RWC, CT_RWC_INC, COPY_T_NCELLS };
 enum { XT_IS_STEP = 0, XT_ID, XT_IS_LAST, XT_BASE0, XT_BASE1, XT_BASE2, XT_BASE3, XT_EXP_LO, XT_EXP_HI, XT_RES_LO, XT_RES_HI,
        EXP_T_NCELLS };
+// SigTableRow (table.py:552-558) and EccTableRow (:562-575): every lookup gives all the fields
+enum { SIG_T_NCELLS = 9, ECC_T_NCELLS = 13 };
+enum { AUX_PAIR = 3, AUX_ECRECOVER = 5, AUX_ECADD = 6, AUX_ECMUL = 7, AUX_ECPAIRING = 8 };  // flatten_step_aux kinds
 enum { CDT_Bytecode = 1, CDT_Memory, CDT_TxCalldata, CDT_TxLog, CDT_RlcAcc };  // CopyDataTypeTag (table.py:336-353)
 
 struct EvmArgs {
@@ -41,11 +45,13 @@ struct EvmArgs {
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
+    ZkTable sig, ecc;           // optional (only the ecRecover / ecAdd / ecMul / ecPairing precompile states read them)
     ZkTable withdrawals;        // optional WithdrawalTableRow rows (id, validator_id, address, amount), sorted by id
     // whole-table aggregates EndBlock's last step needs (end_block.py:55-91), computed once per session on the host
     u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
-    const u64* aux;             // optional StepState.aux_data: [n_steps][2][4] cells ...
-    const u32* aux_kind;        // ... and kinds (0 none, 1 Word, 2 int, 3 pair, 4 not representable)
+    const u64* aux;             // optional StepState.aux_data: [n_steps][aux_cells][4] cells ...
+    const u32* aux_kind;        // ... and kinds (0 none, 1 Word, 2 int, 3 pair, 4 not representable, 5-8 precompile inputs)
+    u32 aux_cells;              // cells per step in `aux` (2, or 12 when a precompile state is present)
     u32 rw_dense;     // 1: the RW rows are sorted with consecutive rw_counters (row = rw_counter - rw_base); 0: generic index
     u64 rw_base;
     const u64* rw_keys;  // optional [n_rw][4]: packed (rw, tag, field_tag, id, address) of every row, see rw_pack_row
@@ -173,6 +179,15 @@ ZK_HD u32 is_zero_word(const Word& w) { return fr_is_zero(fr_add(w.lo, w.hi)); }
 ZK_HD u32 is_equal_word(const Word& a, const Word& b) {
     return fr_is_zero(fr_add(fr_sub(a.lo, b.lo), fr_sub(a.hi, b.hi)));
 }
+// x mod m for a small modulus (x is a canonical cell: `.n % m`)
+ZK_HD u32 fr_mod_small(const Fr& x, u32 m) {
+    u64 rem = 0;
+    for (int k = 7; k >= 0; k--) rem = ((rem << 32) | x.v[k]) % m;
+    return (u32)rem;
+}
+ZK_HD Word evm_empty_code_hash() {  // util/hash.py:13 (keccak256(""))
+    return word_of(fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+}
 // word_to_fq (instruction.py:480-484)
 ZK_HD Fr word_to_fq(Ins& I, const Word& w, int n_bytes) {
     U256 v = to_u256(I, w);
@@ -205,6 +220,14 @@ ZK_HD u64 blk_key_hash(const ZkTable& t, u32 r) { return blk_key_hash_cells(zk_t
 ZK_HD u64 copy_key_hash_cells(const Fr& rwc, const Fr& src_addr) { return zk_hash_cell(zk_hash_cell(0xc09fu, rwc), src_addr); }
 ZK_HD u64 copy_key_hash(const ZkTable& t, u32 r) { return copy_key_hash_cells(zk_table_cell(t, r, CT_RWC), zk_table_cell(t, r, CT_SRC_ADDR)); }
 ZK_HD u64 expt_key_hash_cells(const Fr& id, const Fr& is_last) { return zk_hash_cell(zk_hash_cell(0xe4b7u, id), is_last); }
+ZK_HD u64 sig_key_hash_cells(const Fr& msg_lo, const Fr& r_lo, const Fr& s_lo) { return zk_hash_cell(zk_hash_cell(zk_hash_cell(0x516u, msg_lo), r_lo), s_lo); }
+ZK_HD u64 sig_key_hash(const ZkTable& t, u32 r) { return sig_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 3), zk_table_cell(t, r, 5)); }
+ZK_HD u64 ecc_key_hash_cells(const Fr& op, const Fr& px_lo, const Fr& qx_lo, const Fr& input_rlc) {
+    return zk_hash_cell(zk_hash_cell(zk_hash_cell(zk_hash_cell(0xecc0u, op), px_lo), qx_lo), input_rlc);
+}
+ZK_HD u64 ecc_key_hash(const ZkTable& t, u32 r) {
+    return ecc_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1), zk_table_cell(t, r, 5), zk_table_cell(t, r, 9));
+}
 ZK_HD u64 expt_key_hash(const ZkTable& t, u32 r) { return expt_key_hash_cells(zk_table_cell(t, r, XT_ID), zk_table_cell(t, r, XT_IS_LAST)); }
 
 ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
@@ -520,6 +543,22 @@ ZK_HD Word exp_lookup(Ins& I, const Fr& identifier, const Fr& is_last, const u64
     q[XT_EXP_LO] = exponent.lo; q[XT_EXP_HI] = exponent.hi; q[XT_RES_LO] = fr_zero(); q[XT_RES_HI] = fr_zero();
     u32 r = table_lookup<EXP_T_NCELLS>(I, I.a->exp, expt_key_hash_cells(identifier, is_last), q, 0x1ffu);
     return word_of(zk_table_cell(I.a->exp, r, XT_RES_LO), zk_table_cell(I.a->exp, r, XT_RES_HI));
+}
+
+// Tables.sig_lookup (table.py:816-833) and ecc_lookup (:835-858): the query names every field of the row
+ZK_HD void sig_lookup(Ins& I, const Word& msg_hash, const Fr& sig_v, const Word& sig_r, const Word& sig_s, const Fr& recovered_addr,
+                      const Fr& is_valid) {
+    Fr q[SIG_T_NCELLS];
+    q[0] = msg_hash.lo; q[1] = msg_hash.hi; q[2] = sig_v; q[3] = sig_r.lo; q[4] = sig_r.hi; q[5] = sig_s.lo; q[6] = sig_s.hi;
+    q[7] = recovered_addr; q[8] = is_valid;
+    table_lookup<SIG_T_NCELLS>(I, I.a->sig, sig_key_hash_cells(msg_hash.lo, sig_r.lo, sig_s.lo), q, (1u << SIG_T_NCELLS) - 1u);
+}
+ZK_HD void ecc_lookup(Ins& I, u32 op_type, const Word& px, const Word& py, const Word& qx, const Word& qy, const Fr& input_rlc,
+                      const Fr& outx, const Fr& outy, const Fr& is_valid) {
+    Fr q[ECC_T_NCELLS];
+    q[0] = fr_u(op_type); q[1] = px.lo; q[2] = px.hi; q[3] = py.lo; q[4] = py.hi; q[5] = qx.lo; q[6] = qx.hi; q[7] = qy.lo; q[8] = qy.hi;
+    q[9] = input_rlc; q[10] = outx; q[11] = outy; q[12] = is_valid;
+    table_lookup<ECC_T_NCELLS>(I, I.a->ecc, ecc_key_hash_cells(q[0], px.lo, qx.lo, input_rlc), q, (1u << ECC_T_NCELLS) - 1u);
 }
 
 // Fixed-table membership in closed form (table.py:37-103, 673-688): exact 4-tuple semantics,
@@ -2758,6 +2797,16 @@ ZK_HD void balance_move(Ins& I, const Fr& address, const Word& value, Reversion&
     constrain_equal_word(I, subtract ? prev : bal, sum);
     constrain_zero(I, carry);
 }
+// StepState.aux_data of the current step (EvmArgs::aux): kind and the two cells
+ZK_HD u32 aux_kind(const Ins& I) { return I.a->aux_kind ? I.a->aux_kind[I.idx] : 0u; }
+ZK_HD Fr aux_cell(const Ins& I, u32 k) { return fr_load(I.a->aux + (I.idx * I.a->aux_cells + k) * 4); }
+ZK_HD Word aux_word(const Ins& I, u32 k = 0) { return word_of(aux_cell(I, k), aux_cell(I, k + 1)); }
+// aux_data of the shape a precompile gadget expects (flatten_step_aux); anything else is not evaluated
+ZK_HD bool aux_expect(Ins& I, u32 kind, u32 n_cells) {
+    if (aux_kind(I) == kind && I.a->aux_cells >= n_cells) return true;
+    if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+    return false;
+}
 ZK_HD void g_callop(Ins& I, Tail& T) {  // callop.py; precompile callees (StepState.aux_data) -> ZK_UNSUPPORTED
     Fr opcode; opcode = opcode_lookup(I, true);
     const u32 ov = fr_le_u64(opcode, 255) ? opcode.v[0] : 0u;
@@ -2859,7 +2908,92 @@ ZK_HD void g_callop(Ins& I, Tail& T) {  // callop.py; precompile callees (StepSt
         ev_require(I, fr_eq(ev_next(I, S_CH_LO), ev_curr(I, S_CH_LO)) && fr_eq(ev_next(I, S_CH_HI), ev_curr(I, S_CH_HI)));
         return;
     }
-    if (is_precompile) { if (I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq); return; }
+    if (is_precompile) {  // callop.py:154-276
+        if (!aux_expect(I, AUX_PAIR, 2)) return;
+        const Fr input_len = aux_cell(I, 0), return_len = aux_cell(I, 1);  // Python ints < p on the host
+        const Fr min_rd_copy_size = fr_lt(C.rd_length, return_len) ? C.rd_length : return_len;
+        ev_require(I, no_callee_code == 1u); if (I.err) return;
+        constrain_equal(I, is_warm, fr_u(1)); if (I.err) return;
+        {
+            const u32 tags[7] = {CC_IsSuccess, CC_CalleeAddress, CC_CallerId, CC_CallDataOffset, CC_CallDataLength, CC_ReturnDataOffset,
+                                 CC_ReturnDataLength};
+            for (int k = 0; k < 7; k++) {
+                Word want;
+                switch (k) {
+                case 0: want = word_value(C.is_success); break;
+                case 1: want = callee_address_w; break;
+                case 2: want = word_value(I.call_id); break;
+                case 3: want = word_value(C.cd_offset); break;
+                case 4: want = word_value(C.cd_length); break;
+                case 5: want = word_value(C.rd_offset); break;
+                default: want = word_value(C.rd_length); break;
+                }
+                WordOrValue got; got = call_context_lookup_word(I, tags[k], 1, &callee_call_id);
+                constrain_equal_word(I, got.w, want); if (I.err) return;
+            }
+        }
+        {
+            const u32 tags[8] = {CC_ProgramCounter, CC_StackPointer, CC_GasLeft, CC_MemorySize, CC_ReversibleWriteCounter, CC_LastCalleeId,
+                                 CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength};
+            for (int k = 0; k < 8; k++) {
+                Fr want;
+                switch (k) {
+                case 0: want = fr_add_u64(I.pc, 1); break;
+                case 1: want = fr_add_u64(I.sp, (u64)sp_delta); break;
+                case 2: want = fr_sub(fr_sub(ev_curr(I, S_GAS), gas_cost), callee_gas_left); break;
+                case 3: want = C.next_memory_size; break;
+                case 4: want = fr_add_u64(ev_curr(I, S_REV), 1); break;
+                case 5: want = callee_call_id; break;
+                case 6: want = fr_zero(); break;
+                default: want = return_len; break;
+                }
+                Fr v; v = call_context_lookup(I, tags[k], 1);
+                constrain_equal(I, v, want); if (I.err) return;
+            }
+        }
+        Fr rwc_inc = fr_u(I.rw_off);
+        if (!fr_is_zero(input_len)) {
+            CopyRes cr;
+            EV_TRY(cr = copy_lookup(I, word_value(I.call_id), CDT_Memory, word_value(callee_call_id), CDT_RlcAcc, C.cd_offset,
+                                    fr_add(C.cd_offset, input_len), fr_zero(), input_len, fr_add(I.rwc, rwc_inc)));
+            rwc_inc = fr_add(rwc_inc, cr.rwc_inc);
+        }
+        if (success && !fr_is_zero(return_len)) {
+            CopyRes cr;
+            EV_TRY(cr = copy_lookup(I, word_value(callee_call_id), CDT_Memory, word_value(callee_call_id), CDT_RlcAcc, fr_zero(), return_len,
+                                    fr_zero(), return_len, fr_add(I.rwc, rwc_inc)));
+            rwc_inc = fr_add(rwc_inc, cr.rwc_inc);
+            EV_TRY(cr = copy_lookup(I, word_value(callee_call_id), CDT_Memory, word_value(I.call_id), CDT_Memory, fr_zero(), min_rd_copy_size,
+                                    C.rd_offset, min_rd_copy_size, fr_add(I.rwc, rwc_inc)));
+            rwc_inc = fr_add(rwc_inc, cr.rwc_inc);
+        }
+        Fr mem_words; EV_TRY(mem_words = constant_divmod_shift(I, fr_add_u64(min_rd_copy_size, 31), 5, 4));
+        if (C.has_value) callee_gas_left = fr_add_u64(callee_gas_left, 2300);
+        transition(I, S_RWC, t_delta(rwc_inc));
+        transition(I, S_CALL_ID, t_to(callee_call_id));
+        transition(I, S_IS_ROOT, t_to(fr_zero()));
+        transition(I, S_IS_CREATE, t_to(fr_zero()));
+        {
+            const Word empty = evm_empty_code_hash();
+            ev_require(I, fr_eq(ev_next(I, S_CH_LO), empty.lo) && fr_eq(ev_next(I, S_CH_HI), empty.hi));
+        }
+        transition(I, S_GAS, t_to(callee_gas_left));
+        transition(I, S_REV, t_to(fr_u(2)));
+        transition(I, S_PC, t_delta_i(1));
+        transition(I, S_SP, t_same());
+        transition(I, S_MWS, t_to(mem_words));
+        transition(I, S_LOG, t_same());
+        if (I.err) return;
+        // PrecompileGadget (util/precompile_gadget.py:9-41); the address is 1..9 here
+        ev_require(I, true);
+        const u64 addr = fr_lo64(C.callee_address);
+        if (addr == 4) constrain_equal(I, return_len, C.cd_length);
+        else if (addr == 1) ev_require(I, fr_eq_u64(return_len, 32) || fr_is_zero(return_len));
+        else if (addr == 6) constrain_equal(I, C.cd_length, fr_u(128));
+        else if (addr == 7) constrain_equal(I, C.cd_length, fr_u(96));
+        else if (addr == 8) ev_require(I, fr_mod_small(C.cd_length, 192) == 0u);
+        return;
+    }
     {   // save the caller's call state
         const u32 tags[5] = {CC_ProgramCounter, CC_StackPointer, CC_GasLeft, CC_MemorySize, CC_ReversibleWriteCounter};
         for (int k = 0; k < 5; k++) {
@@ -2916,9 +3050,6 @@ ZK_HD void g_callop(Ins& I, Tail& T) {  // callop.py; precompile callees (StepSt
     transition(I, S_MWS, t_to(fr_zero()));
 }
 
-// StepState.aux_data of the current step (EvmArgs::aux): kind and the two cells
-ZK_HD u32 aux_kind(const Ins& I) { return I.a->aux_kind ? I.a->aux_kind[I.idx] : 0u; }
-ZK_HD Word aux_word(const Ins& I) { return word_of(fr_load(I.a->aux + I.idx * 8), fr_load(I.a->aux + I.idx * 8 + 4)); }
 ZK_HD void g_error_oog_sload_sstore(Ins& I, Tail& T) {  // error_oog_sload_sstore.py
     Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_sstore = fr_eq_u64(opcode, OP_SSTORE), is_sload = fr_eq_u64(opcode, OP_SLOAD);
@@ -3202,6 +3333,99 @@ ZK_HD void g_datacopy(Ins& I, Tail& T) {
     I.rw_off += 4 * fr_lo64(size);
     restore_context(I, fr_u(I.rw_off), fr_sub(ev_curr(I, S_GAS), gas_cost), fr_zero(), size, &caller_id);
 }
+// ---- precompile states reading the sig / ecc tables (execution/precompiles/*.py)
+// RLC(bytes(reversed(data)), r, n_bytes = len(data)).expr() == Horner over `data` front to back
+struct RlcAcc {
+    Fr acc, rM;
+};
+ZK_HD RlcAcc rlc_begin(const Fr& r) {
+    RlcAcc a;
+    a.acc = fr_zero();
+    a.rM = fr_to_mont(r);
+    return a;
+}
+ZK_HD void rlc_le_bytes32(RlcAcc& a, const U256& v) {  // the 32 little-endian bytes of v, in order
+    for (int k = 0; k < 32; k++) a.acc = fr_add(fr_mulc(a.acc, a.rM), fr_u(fr_byte(v, k)));
+}
+ZK_HD void precompile_prelude(Ins& I, u64 base_gas, Fr& is_success, Fr* calldata_len) {
+    is_success = call_context_lookup(I, CC_IsSuccess);
+    if (calldata_len) *calldata_len = call_context_lookup(I, CC_CallDataLength);
+    WordOrValue aw; aw = call_context_lookup_word(I, CC_CalleeAddress);
+    if (I.err) return;
+    Fr address; address = word_to_fq(I, aw.w, 20); if (I.err) return;
+    fixed_lookup(I, FX_PrecompileInfo, ev_curr(I, S_STATE), address, fr_u(base_gas));
+}
+ZK_HD void g_ecrecover(Ins& I, Tail& T) {  // precompiles/ecrecover.py:26-94
+    Fr is_success; precompile_prelude(I, 3000, is_success, nullptr); if (I.err) return;
+    if (!aux_expect(I, AUX_ECRECOVER, 12)) return;
+    const Word msg_hash = aux_word(I, 0), sig_v = aux_word(I, 2), sig_r = aux_word(I, 4), sig_s = aux_word(I, 6);
+    const Fr recovered_addr = aux_cell(I, 8), rand = aux_cell(I, 11);
+    const bool is_recovered = !fr_is_zero(recovered_addr);
+    RlcAcc in = rlc_begin(rand);
+    {
+        const Word* ws[4] = {&msg_hash, &sig_v, &sig_r, &sig_s};
+        U256 vals[4];
+        for (int k = 0; k < 4; k++) { vals[k] = int_value(I, *ws[k]); if (I.err) return; }  // int_value().to_bytes(32, "little")
+        for (int k = 0; k < 4; k++) rlc_le_bytes32(in, vals[k]);
+    }
+    constrain_equal(I, aux_cell(I, 9), in.acc); if (I.err) return;
+    RlcAcc out = rlc_begin(rand);
+    rlc_le_bytes32(out, recovered_addr);
+    constrain_equal(I, aux_cell(I, 10), out.acc); if (I.err) return;
+    constrain_equal(I, is_success, fr_u(1)); if (I.err) return;
+    const Fr n_limbs = {SECP_N_LIMBS};
+    const Word n_word = word_from_u256(n_limbs);
+    u32 r_ub, s_ub, eq;
+    compare_word(I, sig_r, n_word, r_ub, eq); if (I.err) return;
+    compare_word(I, sig_s, n_word, s_ub, eq); if (I.err) return;
+    const u32 r_nz = 1u - is_zero_word(sig_r), s_nz = 1u - is_zero_word(sig_s);
+    const bool valid_r_s = r_ub + s_ub + r_nz + s_nz == 4u;
+    const bool valid_v = is_equal_word(sig_v, word_value(fr_u(27))) + is_equal_word(sig_v, word_value(fr_u(28))) == 1u;
+    if (valid_r_s && valid_v) {
+        sig_lookup(I, msg_hash, fr_sub_u64(sig_v.lo, 27), sig_r, sig_s, recovered_addr, fr_u(is_recovered ? 1 : 0)); if (I.err) return;
+    } else {
+        ev_require(I, !is_recovered); if (I.err) return;
+        constrain_zero(I, recovered_addr); if (I.err) return;
+    }
+    restore_context(I, fr_u(I.rw_off), fr_sub_u64(ev_curr(I, S_GAS), 3000), fr_zero(), fr_u(is_recovered ? 32 : 0));
+}
+ZK_HD void g_ecadd_ecmul(Ins& I, Tail& T, bool is_mul) {  // precompiles/ecadd.py:10-48, ecmul.py:10-55
+    const u64 gas = is_mul ? 6000 : 150;
+    Fr is_success; precompile_prelude(I, gas, is_success, nullptr); if (I.err) return;
+    if (!aux_expect(I, is_mul ? AUX_ECMUL : AUX_ECADD, is_mul ? 8 : 10)) return;
+    const Word px = aux_word(I, 0), py = aux_word(I, 2), qx = aux_word(I, 4);  // qx: the scalar for ecMul
+    const Word qy = is_mul ? word_zero() : aux_word(I, 6);
+    const Fr outx = aux_cell(I, is_mul ? 6 : 8), outy = aux_cell(I, is_mul ? 7 : 9);
+    const bool zero_word = [](const Word& w) { return fr_is_zero(w.lo) && fr_is_zero(w.hi); }(qx);
+    const bool p_inf = fr_is_zero(px.lo) && fr_is_zero(px.hi) && fr_is_zero(py.lo) && fr_is_zero(py.hi);
+    if (fr_is_zero(is_success) || (is_mul && (zero_word || p_inf))) {
+        constrain_zero(I, outx); if (I.err) return;
+        constrain_zero(I, outy); if (I.err) return;
+    }
+    ecc_lookup(I, is_mul ? 2u : 1u, px, py, qx, qy, fr_zero(), outx, outy, is_success); if (I.err) return;
+    const bool ok = fr_eq_u64(is_success, 1);
+    restore_context(I, fr_u(I.rw_off), ok ? fr_sub_u64(ev_curr(I, S_GAS), gas) : fr_zero(), fr_zero(), fr_u(ok ? 64 : 0));
+}
+ZK_HD void g_ecpairing(Ins& I, Tail& T) {  // precompiles/ecpairing.py:13-78
+    Fr is_success, calldata_len; precompile_prelude(I, 45000, is_success, &calldata_len); if (I.err) return;
+    if (!aux_expect(I, AUX_ECPAIRING, 4)) return;
+    const Fr input_rlc = aux_cell(I, 0), input_pairs = aux_cell(I, 1), is_valid_input = aux_cell(I, 2), output = aux_cell(I, 3);
+    constrain_equal(I, is_success, is_valid_input); if (I.err) return;
+    if (fr_mod_small(calldata_len, 192) != 0u) {
+        constrain_equal(I, output, fr_zero()); if (I.err) return;
+        constrain_equal(I, is_valid_input, fr_zero()); if (I.err) return;
+    } else {
+        constrain_equal(I, calldata_len, fr_mul_u64(input_pairs, 192)); if (I.err) return;
+        if (fr_is_zero(calldata_len)) {
+            constrain_zero(I, input_pairs); if (I.err) return;
+            constrain_zero(I, input_rlc); if (I.err) return;
+            constrain_equal(I, output, fr_u(1)); if (I.err) return;
+        }
+    }
+    ecc_lookup(I, 3u, word_zero(), word_zero(), word_zero(), word_zero(), input_rlc, fr_zero(), output, is_valid_input); if (I.err) return;
+    const Fr gas_left = fr_eq_u64(is_success, 1) ? fr_sub(fr_sub_u64(ev_curr(I, S_GAS), 45000), fr_mul_u64(input_pairs, 34000)) : fr_zero();
+    restore_context(I, fr_u(I.rw_off), gas_left, fr_zero(), fr_u(fr_eq_u64(is_valid_input, 1) ? 32 : 0));
+}
 // [tx_calldata_lookup(tx_id, FQ(idx)) for idx in range(n)] (instruction.py:694-699): number of bytes and of
 // non-zero bytes; ends at the first missing row (LookupUnsatFailure), so the walk is bounded by the tx table
 ZK_HD void tx_calldata_scan(Ins& I, const Fr& tx_id, const Fr& n, u64& len, u64& nz) {
@@ -3436,7 +3660,8 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
     case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: case ES_DATACOPY:
-    case ES_ErrorOutOfGasPrecompile: case ES_ErrorOutOfGasCREATE: case ES_ErrorGasUintOverflow: return EVM_GROUP_COLD;
+    case ES_ErrorOutOfGasPrecompile: case ES_ErrorOutOfGasCREATE: case ES_ErrorGasUintOverflow: case ES_ECRECOVER: case ES_BN254_ADD:
+    case ES_BN254_SCALAR_MUL: case ES_BN254_PAIRING: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -3526,6 +3751,10 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
     case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
     case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
     case ES_DATACOPY: if (G == EVM_GROUP_COLD) { g_datacopy(I, T); } break;
+    case ES_ECRECOVER: if (G == EVM_GROUP_COLD) { g_ecrecover(I, T); } break;
+    case ES_BN254_ADD: if (G == EVM_GROUP_COLD) { g_ecadd_ecmul(I, T, false); } break;
+    case ES_BN254_SCALAR_MUL: if (G == EVM_GROUP_COLD) { g_ecadd_ecmul(I, T, true); } break;
+    case ES_BN254_PAIRING: if (G == EVM_GROUP_COLD) { g_ecpairing(I, T); } break;
     case ES_ErrorOutOfGasPrecompile: if (G == EVM_GROUP_COLD) { g_error_oog_precompile(I, T); } break;
     case ES_ErrorOutOfGasCREATE: if (G == EVM_GROUP_COLD) { g_error_oog_create(I, T); } break;
     case ES_ErrorGasUintOverflow: if (G == EVM_GROUP_COLD) { g_error_gas_uint_overflow(I, T); } break;

@@ -589,8 +589,10 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     ARG_TRY(g_device >= 0, "zk_evm_open: call zk_init first");
     ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
     ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31) &&
-            t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31) && t->n_withdrawals < (1ull << 31),
+            t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31) && t->n_withdrawals < (1ull << 31) &&
+            t->n_sig < (1ull << 31) && t->n_ecc < (1ull << 31),
             "zk_evm_open: table too large");
+    ARG_TRY(t->aux_cells == 0 || (t->aux_cells >= 2 && t->aux_cells <= 64), "zk_evm_open: aux_cells must be 0 (= 2) or 2..64");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     zk_session* s = new zk_session();
     s->kind = SESSION_EVM;
@@ -611,6 +613,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = table_stage(s, s->evm.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.sig, t->sig, nullptr, t->n_sig, SIG_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, s->evm.ecc, t->ecc, nullptr, t->n_ecc, ECC_T_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->evm.withdrawals, t->withdrawals, nullptr, t->n_withdrawals, 4, dev))) goto fail;
     s->evm.withdrawals.slots = nullptr;
     s->evm.withdrawals.mask = 0;
@@ -639,8 +643,9 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     }
     s->evm.aux = nullptr;
     s->evm.aux_kind = nullptr;
+    s->evm.aux_cells = t->aux_cells ? t->aux_cells : 2u;
     if (t->aux && t->aux_kind) {
-        if ((rc = stage(s, t->aux, (size_t)t->n_steps * 2 * 32, dev, &p))) goto fail;
+        if ((rc = stage(s, t->aux, (size_t)t->n_steps * s->evm.aux_cells * 32, dev, &p))) goto fail;
         s->evm.aux = (const u64*)p;
         if ((rc = stage(s, t->aux_kind, (size_t)t->n_steps * 4, dev, &p))) goto fail;
         s->evm.aux_kind = (const u32*)p;
@@ -648,6 +653,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = build_index<copy_key_hash>(s, s->evm.copy))) goto fail;
     if ((rc = build_index<keccak_key_hash>(s, s->evm.keccak))) goto fail;
     if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;
+    if ((rc = build_index<sig_key_hash>(s, s->evm.sig))) goto fail;
+    if ((rc = build_index<ecc_key_hash>(s, s->evm.ecc))) goto fail;
     s->evm.rw_dense = 0;
     s->evm.rw_base = 0;
     s->evm.rw_keys = nullptr;

@@ -124,11 +124,12 @@ def open_state(rows, flags, mpt, device=None):
 def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
              generic_index=False):
     """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
-    and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4]
+    and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4], sig uint64[m, 9, 4], ecc uint64[m, 13, 4],
+    aux uint64[n, 2 or 12, 4] + aux_kind, withdrawals uint64[m, 4, 4]
     (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
     lib = _lib.init(device)
     names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
-             "aux_kind", "withdrawals"]
+             "aux_kind", "withdrawals", "sig", "ecc"]
     arrs, opts = _prep([wire.get(k) for k in names])
     a = dict(zip(names, arrs))
 
@@ -150,7 +151,10 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         p(a["keccak"]) if rows(a["keccak"]) else None, rows(a["keccak"]),
         p(a["exp"]) if rows(a["exp"]) else None, rows(a["exp"]),
         p(a["aux"]) if rows(a["aux"]) else None, p(a["aux_kind"]) if rows(a["aux"]) else None,
-        p(a["withdrawals"]) if rows(a["withdrawals"]) else None, rows(a["withdrawals"]))
+        p(a["withdrawals"]) if rows(a["withdrawals"]) else None, rows(a["withdrawals"]),
+        p(a["sig"]) if rows(a["sig"]) else None, rows(a["sig"]),
+        p(a["ecc"]) if rows(a["ecc"]) else None, rows(a["ecc"]),
+        int(a["aux"].shape[1]) if rows(a["aux"]) else 0, 0)
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:

@@ -165,29 +165,89 @@ def flatten_exp_table(exp_table):
 AUX_NONE, AUX_WORD, AUX_INT, AUX_PAIR, AUX_OTHER = 0, 1, 2, 3, 4
 
 
+AUX_ECRECOVER, AUX_ECADD, AUX_ECMUL, AUX_ECPAIRING = 5, 6, 7, 8
+AUX_WIDE_CELLS = 12
+
+
+def _is_word_obj(x):
+    return hasattr(x, "lo") and hasattr(x, "hi")
+
+
+def _is_fq_obj(x):
+    return hasattr(x, "n") and not _is_word_obj(x)
+
+
 def flatten_step_aux(steps):
-    """StepState.aux_data (step.py:44, "auxiliary witness data needed by gadgets") -> two cells + a kind per
-    step: 1 = a Word (CREATE: init-code hash), 2 = a non-negative int < 2^256 (ErrorOutOfGasSloadSstore:
-    original value, lo/hi split), 3 = a pair of field values (CALL into a precompile: input / return
-    length), 4 = anything else (precompile states: not representable, gadgets that read it report
-    ZK_UNSUPPORTED), 0 = absent."""
+    """StepState.aux_data (step.py:44, "auxiliary witness data needed by gadgets") -> cells + a kind per step:
+    1 = a Word (CREATE: init-code hash), 2 = a non-negative int < 2^256 (ErrorOutOfGasSloadSstore: original value,
+    lo/hi split), 3 = a pair of Python ints < p (CALL into a precompile: input / return length, callop.py:155-156),
+    5 = ecRecover's [PrecompileAuxData, keccak_randomness] (ecrecover.py:15-23,38-44: msg_hash, sig_v, sig_r, sig_s as
+    lo/hi, recovered_addr, input_rlc, output_rlc, randomness = 12 cells), 6 = ecAdd's [px, py, qx, qy, outx, outy]
+    (ecadd.py:22-27, 10 cells), 7 = ecMul's [px, py, s, outx, outy] (ecmul.py:22-26, 8 cells), 8 = ecPairing's
+    [input_rlc, input_pairs, is_valid_input, output] (ecpairing.py:26-29, 4 cells), 4 = anything else (gadgets that
+    read it report ZK_UNSUPPORTED), 0 = absent.  Two cells per step unless a step needs the wide form (12 cells)."""
     cells, kinds = [], []
     for st in steps:
         a = getattr(st, "aux_data", None)
         c, k = [0, 0], AUX_NONE
         if a is None:
             pass
-        elif hasattr(a, "lo") and hasattr(a, "hi"):
+        elif _is_word_obj(a):
             c, k = [_n(a.lo), _n(a.hi)], AUX_WORD
         elif isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 256):
             c, k = [a & ((1 << 128) - 1), a >> 128], AUX_INT
-        elif isinstance(a, (list, tuple)) and len(a) == 2 and all(hasattr(x, "n") or isinstance(x, int) for x in a):
-            c, k = [_n(a[0]), _n(a[1])], AUX_PAIR
+        elif isinstance(a, (list, tuple)):
+            words = [_is_word_obj(x) for x in a]
+            fqs = [_is_fq_obj(x) for x in a]
+            if len(a) == 2 and all(isinstance(x, int) and not isinstance(x, bool) and 0 <= x < FR_MODULUS for x in a):
+                c, k = [int(a[0]), int(a[1])], AUX_PAIR
+            elif len(a) == 2 and hasattr(a[0], "msg_hash") and fqs[1]:
+                d = a[0]
+                if all(_is_word_obj(getattr(d, f)) for f in ("msg_hash", "sig_v", "sig_r", "sig_s")) and \
+                        all(_is_fq_obj(getattr(d, f)) for f in ("recovered_addr", "input_rlc", "output_rlc")):
+                    c = [_n(d.msg_hash.lo), _n(d.msg_hash.hi), _n(d.sig_v.lo), _n(d.sig_v.hi), _n(d.sig_r.lo), _n(d.sig_r.hi),
+                         _n(d.sig_s.lo), _n(d.sig_s.hi), _n(d.recovered_addr), _n(d.input_rlc), _n(d.output_rlc), _n(a[1])]
+                    k = AUX_ECRECOVER
+                else:
+                    k = AUX_OTHER
+            elif len(a) == 6 and words == [True] * 4 + [False] * 2 and fqs[4] and fqs[5]:
+                c = [v for w in a[:4] for v in (_n(w.lo), _n(w.hi))] + [_n(a[4]), _n(a[5])]
+                k = AUX_ECADD
+            elif len(a) == 5 and words == [True] * 3 + [False] * 2 and fqs[3] and fqs[4]:
+                c = [v for w in a[:3] for v in (_n(w.lo), _n(w.hi))] + [_n(a[3]), _n(a[4])]
+                k = AUX_ECMUL
+            elif len(a) == 4 and all(fqs):
+                c, k = [_n(x) for x in a], AUX_ECPAIRING
+            else:
+                k = AUX_OTHER
         else:
             k = AUX_OTHER
         cells.append(c)
         kinds.append(k)
-    return {"aux": rows_to_rowmajor(cells, 2), "aux_kind": np.array(kinds, dtype=np.uint32)}
+    width = AUX_WIDE_CELLS if any(len(c) > 2 for c in cells) else 2
+    cells = [c + [0] * (width - len(c)) for c in cells]
+    return {"aux": rows_to_rowmajor(cells, width), "aux_kind": np.array(kinds, dtype=np.uint32)}
+
+
+SIG_NCELLS = 9
+ECC_NCELLS = 13
+
+
+def flatten_sig_table(sig_table):
+    """set of SigTableRow (evm_circuit/table.py:552-558) -> uint64[m, 9, 4]: msg_hash lo/hi, sig_v, sig_r lo/hi, sig_s lo/hi,
+    recovered_addr, is_valid"""
+    rows, _ = _dedup([([_n(r.msg_hash.lo), _n(r.msg_hash.hi), _n(r.sig_v), _n(r.sig_r.lo), _n(r.sig_r.hi), _n(r.sig_s.lo),
+                        _n(r.sig_s.hi), _n(r.recovered_addr), _n(r.is_valid)], 0) for r in _iter_table(sig_table)])
+    return rows_to_rowmajor(rows, SIG_NCELLS)
+
+
+def flatten_ecc_table(ecc_table):
+    """set of EccTableRow (evm_circuit/table.py:562-575) -> uint64[m, 13, 4]: op_type, px lo/hi, py lo/hi, qx lo/hi, qy lo/hi,
+    input_rlc, out_x, out_y, is_valid"""
+    rows, _ = _dedup([([_n(r.op_type), _n(r.px.lo), _n(r.px.hi), _n(r.py.lo), _n(r.py.hi), _n(r.qx.lo), _n(r.qx.hi),
+                        _n(r.qy.lo), _n(r.qy.hi), _n(r.input_rlc), _n(r.out_x), _n(r.out_y), _n(r.is_valid)], 0)
+                      for r in _iter_table(ecc_table)])
+    return rows_to_rowmajor(rows, ECC_NCELLS)
 
 
 def flatten_withdrawal_table(withdrawal_table):
@@ -215,6 +275,8 @@ def flatten_evm(tables, steps):
         "copy": flatten_copy_table(getattr(tables, "copy_table", None)),
         "keccak": flatten_keccak_table(getattr(tables, "keccak_table", None)),
         "exp": flatten_exp_table(getattr(tables, "exp_table", None)),
+        "sig": flatten_sig_table(getattr(tables, "sig_table", None)),
+        "ecc": flatten_ecc_table(getattr(tables, "ecc_table", None)),
     }
 
 
