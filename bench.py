@@ -36,11 +36,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # test hooks (single-GPU dry run of the N > 1 path): ZK_BENCH_DEVICE pins every rank to one GPU, ZK_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device
+    if os.environ.get("ZK_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["ZK_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from zkevm_specs_amd import _lib, engine
 
