@@ -62,6 +62,16 @@ struct EvmArgs {
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
 };
 
+// LDS staging of the step pair (hot kernel): slots 0-12 curr cells, 13-25 next cells (low 64 bits), 26-29 bits 64-127 of the
+// four code-hash cells.  One u64 per slot and lane, lane-major (conflict-free ds_read_b64 / ds_write_b64).
+#define EVM_STAGE_LANES 256
+#define EVM_STAGE_SLOTS 30
+#if defined(ZK_HOSTSIM)
+typedef const u64* EVM_LDS_PTR;
+#else
+typedef const __attribute__((address_space(3))) u64* EVM_LDS_PTR;
+#endif
+
 struct Word {
     Fr lo, hi;
 };
@@ -84,6 +94,9 @@ struct Ins {
     // 2 = hash absent from the table, 3 = use the generic index
     u32 code_state, code_header_row, code_byte_base, code_n_bytes, code_header_ok;
     u64 code_header_value;
+    // the 26 cells of (curr, next) staged in LDS by the hot kernel (evm_stage_steps): lane's slot k at stage[k * EVM_STAGE_LANES];
+    // nullptr = read the step rows from HBM (cold kernel, hostsim, or a lane whose cells exceed the staged widths)
+    EVM_LDS_PTR stage;
 };
 
 #if defined(ZK_HOSTSIM)
@@ -104,8 +117,20 @@ ZK_HD void ev_require(Ins& I, bool cond, u32 kind = ZK_ASSERT) {
 #define EV_TRYV(stmt, ret) do { stmt; if (I.err) return ret; } while (0)
 
 ZK_HD Fr ev_step_cell(const EvmArgs& a, u64 step, int c) { return fr_load(a.steps + (step * STEP_NCELLS + c) * 4); }
-ZK_HD Fr ev_curr(const Ins& I, int c) { return ev_step_cell(*I.a, I.idx, c); }
-ZK_HD Fr ev_next(const Ins& I, int c) { return ev_step_cell(*I.a, I.idx + 1, c); }
+ZK_HD Fr ev_staged_cell(const Ins& I, int slot, int c) {
+    Fr r = fr_zero();
+    const u64 lo = I.stage[slot * EVM_STAGE_LANES];
+    r.v[0] = (u32)lo;
+    r.v[1] = (u32)(lo >> 32);
+    if (c == S_CH_LO || c == S_CH_HI) {
+        const u64 hi = I.stage[(26 + (slot >= 13 ? 2 : 0) + (c - S_CH_LO)) * EVM_STAGE_LANES];
+        r.v[2] = (u32)hi;
+        r.v[3] = (u32)(hi >> 32);
+    }
+    return r;
+}
+ZK_HD Fr ev_curr(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, c, c) : ev_step_cell(*I.a, I.idx, c); }
+ZK_HD Fr ev_next(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 13 + c, c) : ev_step_cell(*I.a, I.idx + 1, c); }
 ZK_HD Fr fr_u(u64 x) { return fr_from_u64(x); }
 ZK_HD Word word_of(const Fr& lo, const Fr& hi) {
     Word w;
@@ -829,12 +854,27 @@ ZK_HD MulT mul_terms(const Limbs64& a, const Limbs64& b) {
 // mul_add_words (instruction.py:599-632): constrains a*b + c == d (mod 2^256), returns overflow.
 // The two constrain_equal calls (:629-630) are identities of the field (carry is *defined* as
 // (lhs - d)/2^128), so they only advance the checkpoint counter.
+// (pos - sub) / 2^128 in the field, for a value that goes straight into range_check(., 9).  With sub < 2^200 the field
+// quotient is below 2^72 exactly when pos - sub is a non-negative integer multiple of 2^128 with a quotient below 2^72
+// (r * 2^128 < 2^200 < p pins (pos - sub) mod p = r * 2^128; a negative difference would need sub > p - 2^200): the
+// integer shift gives the same value then, and any other numerator only has to fail the range check like the field
+// quotient does.  No Montgomery product on the way.
+ZK_HD Fr div_2p128_for_range9(const Fr& pos, const Fr& sub) {
+    if ((sub.v[7] | (sub.v[6] >> 8)) != 0u) return fr_mulc(fr_sub(pos, sub), frm_inv_2p128());
+    Fr n;
+    const u32 bw = u256_sub(n, pos, sub);
+    const bool exact = !bw && (n.v[0] | n.v[1] | n.v[2] | n.v[3]) == 0u;
+    Fr r = fr_zero();
+    r.v[0] = n.v[4]; r.v[1] = n.v[5]; r.v[2] = n.v[6]; r.v[3] = n.v[7];
+    if (!exact) r.v[7] = 0x20000000u;
+    return r;
+}
 ZK_HD Fr mul_add_words(Ins& I, const Word& a, const Word& b, const Word& c, const Word& d) {
     Limbs64 a64 = to_64s(I, a);
     Limbs64 b64 = to_64s(I, b);
     MulT t = mul_terms(a64, b64);
-    Fr carry_lo = fr_mulc(fr_sub(fr_add(t.lo, c.lo), d.lo), frm_inv_2p128());
-    Fr carry_hi = fr_mulc(fr_sub(fr_add(fr_add(t.mid, c.hi), carry_lo), d.hi), frm_inv_2p128());
+    Fr carry_lo = div_2p128_for_range9(fr_add(t.lo, c.lo), d.lo);
+    Fr carry_hi = div_2p128_for_range9(fr_add(fr_add(t.mid, c.hi), carry_lo), d.hi);
     Fr overflow = fr_add(carry_hi, t.ovf);
     range_check(I, carry_lo, 9);
     range_check(I, carry_hi, 9);
@@ -846,9 +886,9 @@ ZK_HD void mul_add_words_512(Ins& I, const Word& a, const Word& b, const Word& c
     Limbs64 a64 = to_64s(I, a);
     Limbs64 b64 = to_64s(I, b);
     MulT t = mul_terms(a64, b64);
-    Fr c0 = fr_mulc(fr_sub(fr_add(t.lo, c.lo), e.lo), frm_inv_2p128());
-    Fr c1 = fr_mulc(fr_sub(fr_add(fr_add(t.mid, c.hi), c0), e.hi), frm_inv_2p128());
-    Fr c2 = fr_mulc(fr_sub(fr_add(t.hi, c1), d.lo), frm_inv_2p128());
+    Fr c0 = div_2p128_for_range9(fr_add(t.lo, c.lo), e.lo);
+    Fr c1 = div_2p128_for_range9(fr_add(fr_add(t.mid, c.hi), c0), e.hi);
+    Fr c2 = div_2p128_for_range9(fr_add(t.hi, c1), d.lo);
     range_check(I, c0, 9);
     range_check(I, c1, 9);
     range_check(I, c2, 9);
@@ -905,7 +945,65 @@ ZK_HD void set_tail3(Tail& T, const Fr& opcode, int rwc, int pc, int sp) {
     set_tail(T, opcode, rwc, t_delta_i(pc), sp, t_same(), 0, fr_zero());
 }
 ZK_HD Trans t_int(int d) { return d == 0 ? t_same() : t_delta_i(d); }
+#if !defined(ZK_HOSTSIM)
+// next == curr + d in the field for two cells known to fit 64 bits and a small signed d: the sum leaves [0, 2^64) exactly
+// when the field value does (curr + d >= 2^64, or p - |curr + d|), and then it cannot equal `next`
+ZK_HD bool stage_delta_ok(u64 c, u64 n, long long d) {
+    if (d >= 0) {
+        const u64 e = c + (u64)d;
+        return e >= c && e == n;
+    }
+    const u64 m = (u64)(-d);
+    return c >= m && c - m == n;
+}
+ZK_HD bool stage_trans_ok(u64 c, u64 n, u32 kind, const Fr& v) {  // v fits 64 bits when kind == 1 (caller-checked)
+    if (kind == 0u) return n == c;
+    if (kind == 1u) {
+        const u64 e = c + fr_lo64(v);
+        return e >= c && e == n;
+    }
+    return fr_fits64(v) && fr_lo64(v) == n;
+}
+// same_context on the LDS-staged pair: every cell is known to fit 64 bits (128 for the code hash), so the eleven
+// transitions are 64-bit compares instead of 256-bit field additions.  Same checkpoints, same order, same verdicts.
+ZK_HD void same_context_staged(Ins& I, const Tail& T, u64 dyn_gas) {
+    static const uint32_t opinfo[256] = ZK_OPINFO_INIT;
+    const Fr& opcode = T.opcode;
+    const bool op_byte = fr_le_u64(opcode, 255);
+    const u32 info = opinfo[opcode.v[0] & 0xff];
+#define STG(slot) (I.stage[(slot) * EVM_STAGE_LANES])
+    const u64 st = STG(S_STATE);
+    I.seq++;
+    if (!(op_byte && st != 0u && (u64)(info & 0xffu) == st)) ev_fail(I, ZK_LOOKUP_UNSAT);
+    const bool op_ok = op_byte && ((info >> 8) & 1u);
+    ev_require(I, op_ok, ZK_VALUE_ERROR);
+    const u64 gas_cost = (u64)(op_ok ? (info >> 16) : 0u) + dyn_gas;  // caller: no 64-bit overflow
+    const u64 c_gas = STG(S_GAS);
+    ev_require(I, c_gas >= gas_cost, ZK_CONSTRAINT);  // range_check(gas_left - gas_cost, 8)
+    if (T.rwc_mode == 0u) ev_require(I, stage_delta_ok(STG(S_RWC), STG(13 + S_RWC), T.rw_delta));
+    else ev_require(I, T.rwc_mode == 1u);
+    ev_require(I, stage_trans_ok(STG(S_PC), STG(13 + S_PC), T.pc_kind, T.pc_val));
+    ev_require(I, stage_delta_ok(STG(S_SP), STG(13 + S_SP), T.sp_delta));
+    ev_require(I, c_gas >= gas_cost && c_gas - gas_cost == STG(13 + S_GAS));
+    ev_require(I, stage_trans_ok(STG(S_MWS), STG(13 + S_MWS), T.mws_kind, T.mws_val));
+    ev_require(I, stage_delta_ok(STG(S_REV), STG(13 + S_REV), T.rev_delta));
+    if (T.log_mode == 0u) ev_require(I, STG(S_LOG) == STG(13 + S_LOG));
+    else ev_require(I, T.log_mode == 1u);
+    ev_require(I, STG(S_CALL_ID) == STG(13 + S_CALL_ID));
+    ev_require(I, STG(S_IS_ROOT) == STG(13 + S_IS_ROOT));
+    ev_require(I, STG(S_IS_CREATE) == STG(13 + S_IS_CREATE));
+    ev_require(I, STG(S_CH_LO) == STG(13 + S_CH_LO) && STG(S_CH_HI) == STG(13 + S_CH_HI) && STG(26) == STG(28) && STG(27) == STG(29));
+#undef STG
+}
+#endif
 ZK_HD void same_context(Ins& I, const Tail& T) {
+#if !defined(ZK_HOSTSIM)
+    if (I.stage && fr_fits64(T.dyn_gas) && fr_lo64(T.dyn_gas) < (1ull << 62) && (T.pc_kind != 1u || fr_fits64(T.pc_val)) &&
+        (T.mws_kind != 1u || fr_fits64(T.mws_val))) {
+        same_context_staged(I, T, fr_lo64(T.dyn_gas));
+        return;
+    }
+#endif
     const Fr& opcode = T.opcode;
     // responsible-opcode membership (success states: (state, opcode, 0) rows, table.py:71-79), opcode
     // validity and the constant gas come from ONE packed table word
@@ -980,14 +1078,28 @@ ZK_HD void g_add_sub(Ins& I, Tail& T) {  // add_sub.py
     set_tail3(T, opcode, 3, 1, 1);
 }
 
+// x * s in the field; `is01` = s is known to be 0 or 1 (then the product is a select, no Montgomery multiplication)
+ZK_HD Fr fr_sel01(const Fr& x, const Fr& s, bool is01) {
+    if (is01) return fr_is_zero(s) ? fr_zero() : x;
+    return fr_mul(x, s);
+}
 ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
     Fr opcode; opcode = opcode_lookup(I, true);
     // is_mul/is_div/is_mod are field expressions of the opcode (:14-16)
-    Fr op_m2 = fr_sub_u64(opcode, 2), op_m4 = fr_sub_u64(opcode, 4);
-    Fr f4_op = fr_sub(fr_u(4), opcode), f6_op = fr_sub(fr_u(6), opcode);
-    Fr is_mul = fr_mulc(fr_mul(f4_op, f6_op), frm_inv8());
-    Fr is_div = fr_mulc(fr_mul(op_m2, f6_op), frm_inv4());
-    Fr is_mod = fr_mulc(fr_mul(op_m2, op_m4), frm_inv8());
+    // for the three opcodes the gadget is responsible for they are exactly 0 / 1, and every product with them below is a select
+    const bool op_known = fr_eq_u64(opcode, OP_MUL) || fr_eq_u64(opcode, OP_DIV) || fr_eq_u64(opcode, OP_MOD);
+    Fr is_mul, is_div, is_mod;
+    if (op_known) {
+        is_mul = fr_u(fr_eq_u64(opcode, OP_MUL) ? 1 : 0);
+        is_div = fr_u(fr_eq_u64(opcode, OP_DIV) ? 1 : 0);
+        is_mod = fr_u(fr_eq_u64(opcode, OP_MOD) ? 1 : 0);
+    } else {
+        Fr op_m2 = fr_sub_u64(opcode, 2), op_m4 = fr_sub_u64(opcode, 4);
+        Fr f4_op = fr_sub(fr_u(4), opcode), f6_op = fr_sub(fr_u(6), opcode);
+        is_mul = fr_mulc(fr_mul(f4_op, f6_op), frm_inv8());
+        is_div = fr_mulc(fr_mul(op_m2, f6_op), frm_inv4());
+        is_mod = fr_mulc(fr_mul(op_m2, op_m4), frm_inv8());
+    }
     Word pop1, pop2, push;
     pop1 = stack_pop(I);
     pop2 = stack_pop(I);
@@ -1024,21 +1136,22 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
     constrain_equal_word(I, pop1, sel ? a : d);
     constrain_equal_word(I, pop2, b);
     Fr nz = fr_u(1 - dz);
-    Fr s1 = fr_mul(is_div, nz), s2 = fr_mul(is_mod, nz);
-    Word w1 = word_checked(I, fr_mul(d.lo, is_mul), fr_mul(d.hi, is_mul));
-    Word w2 = word_checked(I, fr_mul(a.lo, s1), fr_mul(a.hi, s1));
+    Fr s1 = fr_sel01(is_div, nz, op_known), s2 = fr_sel01(is_mod, nz, op_known);
+    const bool sel_known = op_known;  // then s1, s2 are 0 / 1 too
+    Word w1 = word_checked(I, fr_sel01(d.lo, is_mul, op_known), fr_sel01(d.hi, is_mul, op_known));
+    Word w2 = word_checked(I, fr_sel01(a.lo, s1, sel_known), fr_sel01(a.hi, s1, sel_known));
     Word w12 = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
-    Word w3 = word_checked(I, fr_mul(c.lo, s2), fr_mul(c.hi, s2));
+    Word w3 = word_checked(I, fr_sel01(c.lo, s2, sel_known), fr_sel01(c.hi, s2, sel_known));
     Word rhs = word_checked(I, fr_add(w12.lo, w3.lo), fr_add(w12.hi, w3.hi));
     constrain_equal_word(I, push, rhs);
     U256 cb = to_u256(I, c); if (I.err) return;
     u32 csum = 0;
     for (int k = 0; k < 32; k++) csum += fr_byte(cb, k);
-    constrain_zero(I, fr_mul(is_mul, fr_u(csum)));
+    constrain_zero(I, fr_sel01(fr_u(csum), is_mul, op_known));
     u32 lt, eq; compare_word(I, c, b, lt, eq); if (I.err) return;
     Fr one_m_mul = fr_sub(fr_u(1), is_mul);
-    constrain_zero(I, fr_mul(fr_mul(one_m_mul, nz), fr_u(1 - lt)));
-    constrain_zero(I, fr_mul(one_m_mul, overflow));
+    constrain_zero(I, fr_sel01(fr_sel01(nz, one_m_mul, op_known), fr_u(1 - lt), true));
+    constrain_zero(I, fr_sel01(overflow, one_m_mul, op_known));
     set_tail3(T, opcode, 3, 1, 1);
 }
 
@@ -3670,10 +3783,39 @@ ZK_HD u32 evm_state_bin(u32 state) { return (u32)evm_state_group(state) * 128u +
 #define EVM_N_BINS (EVM_N_GROUPS * 128)
 
 // verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
+#if !defined(ZK_HOSTSIM)
+// Load the 26 cells of the pair (52 independent 16-byte loads, issued before any gadget code needs registers) and keep
+// them in LDS: low 64 bits per cell, 128 for the code-hash cells.  Returns false when a cell is wider than that
+// (malformed witnesses only): the lane then reads the step rows from HBM as before.
+ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_space(3))) u64* stage) {
+    const uint4* p = (const uint4*)(a.steps + idx * (STEP_NCELLS * 4));
+    uint4 lo[2 * STEP_NCELLS], hi[2 * STEP_NCELLS];
+#pragma unroll
+    for (int k = 0; k < 2 * STEP_NCELLS; k++) {
+        lo[k] = p[2 * k];
+        hi[k] = p[2 * k + 1];
+    }
+    u32 wide = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * STEP_NCELLS; k++) {
+        const int c = k % STEP_NCELLS;
+        stage[k * EVM_STAGE_LANES] = (u64)lo[k].x | ((u64)lo[k].y << 32);
+        if (c == S_CH_LO || c == S_CH_HI) {
+            stage[(26 + (k >= STEP_NCELLS ? 2 : 0) + (c - S_CH_LO)) * EVM_STAGE_LANES] = (u64)lo[k].z | ((u64)lo[k].w << 32);
+        } else {
+            wide |= lo[k].z | lo[k].w;
+        }
+        wide |= hi[k].x | hi[k].y | hi[k].z | hi[k].w;
+    }
+    return wide == 0u;
+}
+#endif
+
 template <int G>
-ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx) {
+ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr) {
     Ins I;
     I.a = &a;
+    I.stage = stage;
     I.idx = idx;
     I.err = 0;
     I.seq = 0;

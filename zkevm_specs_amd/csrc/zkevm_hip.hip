@@ -149,12 +149,16 @@ __global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u3
         else hi = group_start[EVM_GROUP_COLD];
     }
     u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ u64 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_SLOTS * EVM_STAGE_LANES : 1];
     if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
         u32 code = 0;
         u64 idx = t;
         if (t < (u64)hi) {
             if (a.perm) idx = a.perm[t];
-            code = evm_check_step<G>(a, idx);
+            // both steps of the pair go to LDS first (52 loads in flight at once); the gadgets read them from there
+            __attribute__((address_space(3))) u64* my = (__attribute__((address_space(3))) u64*)s_stage + threadIdx.x;
+            const bool staged = evm_stage_steps(a, idx, my);
+            code = evm_check_step<G>(a, idx, staged ? (EVM_LDS_PTR)my : (EVM_LDS_PTR) nullptr);
             if (code == ZK_NOT_MINE) code = 0;
             else if (status) status[idx] = code;
         }
