@@ -66,6 +66,10 @@ struct EvmArgs {
 // four code-hash cells.  One u64 per slot and lane, lane-major (conflict-free ds_read_b64 / ds_write_b64).
 #define EVM_STAGE_LANES 256
 #define EVM_STAGE_SLOTS 30
+#define EVM_DIR_MAX_SLOTS 128   // directory mirrored in LDS when it has at most this many slots ...
+#define EVM_DIR_MAX_ENTRIES 32  // ... and entries (96 B each)
+#define EVM_DIR_SLOT_U64 (EVM_DIR_MAX_SLOTS / 2)
+#define EVM_DIR_LDS_U64 (EVM_DIR_SLOT_U64 + EVM_DIR_MAX_ENTRIES * 12)
 #if defined(ZK_HOSTSIM)
 typedef const u64* EVM_LDS_PTR;
 #else
@@ -97,6 +101,9 @@ struct Ins {
     // the 26 cells of (curr, next) staged in LDS by the hot kernel (evm_stage_steps): lane's slot k at stage[k * EVM_STAGE_LANES];
     // nullptr = read the step rows from HBM (cold kernel, hostsim, or a lane whose cells exceed the staged widths)
     EVM_LDS_PTR stage;
+    // the hot kernel's LDS mirror of the bytecode directory (slots as u32 pairs in the first EVM_DIR_SLOT_U64 words, then
+    // the entries, 12 u64 each); nullptr = probe the directory in HBM
+    EVM_LDS_PTR dir_lds;
 };
 
 #if defined(ZK_HOSTSIM)
@@ -418,6 +425,32 @@ ZK_HD void code_dir_resolve(Ins& I, const Word& code_hash) {
     if (I.code_state != 0) return;
     const ZkCodeDir& dir = I.a->codes;
     I.code_state = 3;
+#if !defined(ZK_HOSTSIM)
+    static_assert(sizeof(ZkCodeEntry) == 96, "LDS mirror layout: 12 u64 per directory entry");
+    if (dir.n != 0 && I.dir_lds && fr_fits128(code_hash.lo) && fr_fits128(code_hash.hi)) {  // same probe sequence over the LDS mirror
+        u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
+        I.code_state = 2;
+        const u64 h0 = fr_lo64(code_hash.lo), h1 = fr_hi64of128(code_hash.lo), h4 = fr_lo64(code_hash.hi), h5 = fr_hi64of128(code_hash.hi);
+        for (u32 probes = 0; probes <= dir.mask; probes++) {
+            const u64 pair = I.dir_lds[slot >> 1];
+            const u32 k = (slot & 1u) ? (u32)(pair >> 32) : (u32)pair;
+            if (k == ZK_EMPTY_SLOT) break;
+            EVM_LDS_PTR c = I.dir_lds + EVM_DIR_SLOT_U64 + k * 12;
+            if (c[0] == h0 && c[1] == h1 && (c[2] | c[3]) == 0ull && c[4] == h4 && c[5] == h5 && (c[6] | c[7]) == 0ull) {
+                const u64 w8 = c[8], w9 = c[9], w11 = c[11];
+                I.code_state = (u32)(w9 >> 32) ? 1 : 3;  // regular
+                I.code_header_row = (u32)w8;
+                I.code_byte_base = (u32)(w8 >> 32);
+                I.code_n_bytes = (u32)w9;
+                I.code_header_value = c[10];
+                I.code_header_ok = (u32)w11;
+                break;
+            }
+            slot = (slot + 1) & dir.mask;
+        }
+        return;
+    }
+#endif
     if (dir.n != 0) {
         u32 slot = (u32)zk_code_hash_key(code_hash.lo, code_hash.hi) & dir.mask;
         I.code_state = 2;
@@ -1208,13 +1241,26 @@ ZK_HD void g_iszero(Ins& I, Tail& T) {  // iszero.py
     set_tail3(T, opcode, 2, 1, 0);
 }
 
+// 32 byte-wise fixed lookups (BitwiseAnd / Or / Xor, table.py:56-69) over three 256-bit words at once: `diff` has a non-zero
+// byte k exactly where lookup k misses; the checkpoints are those of the 32 one-by-one lookups (first miss wins)
+ZK_HD void bitwise_lookups32(Ins& I, const U256& diff) {
+    int first = -1;
+    for (int k = 31; k >= 0; k--)
+        if (fr_byte(diff, k) != 0u) first = k;
+    if (first >= 0 && I.err == 0u) I.err = ZK_CODE(ZK_LOOKUP_UNSAT, I.seq + (u32)first + 1u);
+    I.seq += 32;
+}
 ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
     Fr opcode; opcode = opcode_lookup(I, true);
     Word a; a = stack_pop(I);
     U256 a8; EV_TRY(a8 = to_u256(I, a));
     Word b; b = stack_push(I);
     U256 b8; EV_TRY(b8 = to_u256(I, b));
-    for (int k = 0; k < 32; k++) fixed_lookup(I, FX_BitwiseXor, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(255));
+    {   // (a_byte, b_byte, 255) in BitwiseXor for every byte  <=>  a ^ b == 0xff..ff
+        U256 d;
+        for (int k = 0; k < 8; k++) d.v[k] = ~(a8.v[k] ^ b8.v[k]);
+        bitwise_lookups32(I, d);
+    }
     if (I.err) return;
     set_tail3(T, opcode, 2, 1, 0);
 }
@@ -1236,7 +1282,16 @@ ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
     }
     ev_require(I, tag_ok, ZK_VALUE_ERROR); if (I.err) return;
     const u32 tag = tagf.v[0];
-    for (int k = 0; k < 32; k++) fixed_lookup(I, tag, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(fr_byte(c8, k)));
+    if (tag == FX_BitwiseAnd || tag == FX_BitwiseOr || tag == FX_BitwiseXor) {
+        U256 d;
+        for (int k = 0; k < 8; k++) {
+            const u32 x = a8.v[k], y = b8.v[k];
+            d.v[k] = (tag == FX_BitwiseAnd ? (x & y) : (tag == FX_BitwiseOr ? (x | y) : (x ^ y))) ^ c8.v[k];
+        }
+        bitwise_lookups32(I, d);
+    } else {
+        for (int k = 0; k < 32; k++) fixed_lookup(I, tag, fr_u(fr_byte(a8, k)), fr_u(fr_byte(b8, k)), fr_u(fr_byte(c8, k)));
+    }
     if (I.err) return;
     set_tail3(T, opcode, 3, 1, 1);
 }
@@ -1273,6 +1328,36 @@ ZK_HD void g_signextend(Ins& I, Tail& T) {  // signextend.py (is_equal results a
     set_tail3(T, opcode, 3, 1, 1);
 }
 
+// constrain_zero on bytes [lo, hi) of v, one checkpoint each (first non-zero byte wins), byte positions static
+ZK_HD void push_zero_run(Ins& I, const U256& v, u32 lo, u32 hi) {
+    int first = -1;
+#pragma unroll
+    for (int k = 31; k >= 0; k--)
+        if ((u32)k >= lo && (u32)k < hi && fr_byte(v, k) != 0u) first = k;
+    if (first >= 0 && I.err == 0u) I.err = ZK_CODE(ZK_ASSERT, I.seq + ((u32)first - lo) + 1u);
+    I.seq += hi - lo;
+}
+// v >> (8 * n), n <= 32
+ZK_HD U256 u256_shr_bytes(const U256& v, u32 n) {
+    U256 r = v;
+#pragma unroll
+    for (int bit = 0; bit < 5; bit++) {  // shift by 1, 2, 4, 8, 16 bytes
+        const bool on = (n >> bit) & 1u;
+        const int bytes = 1 << bit;
+        U256 t;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int src = j + bytes / 4;
+            const u32 lo_w = src < 8 ? r.v[src] : 0u, hi_w = src + 1 < 8 ? r.v[src + 1] : 0u;
+            const int sh = 8 * (bytes % 4);
+            t.v[j] = sh ? ((lo_w >> sh) | (hi_w << (32 - sh))) : lo_w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) r.v[j] = on ? t.v[j] : r.v[j];
+    }
+    if (n >= 32u) r = fr_zero();
+    return r;
+}
 ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
     Fr opcode; opcode = opcode_lookup(I, true);
     Fr num_pushed = fr_sub_u64(opcode, OP_PUSH0);
@@ -1283,14 +1368,33 @@ ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
     Fr num_padding = oob ? fr_sub(num_pushed, left) : fr_zero();
     Word value; value = stack_push(I);
     U256 vb; EV_TRY(vb = to_u256(I, value));
-    for (int k = 0; k < 32; k++) {
-        const bool pushed = fr_lt(fr_u((u64)k), num_pushed), padding = fr_lt(fr_u((u64)k), num_padding);
-        if (pushed && !padding) {
-            Fr index = fr_sub_u64(fr_add(pc, num_pushed), (u64)k);
-            Fr byte = opcode_lookup_at(I, index, false);
-            constrain_equal(I, fr_u(fr_byte(vb, k)), byte);
-        } else {
-            constrain_zero(I, fr_u(fr_byte(vb, k)));
+    if (fr_fits64(num_pushed) && fr_fits64(num_padding) && fr_fits64(pc) && fr_lo64(num_pushed) <= 32 && fr_lo64(pc) < (1ull << 62)) {
+        // the usual case: byte counts and the program counter are small integers.  In byte order the loop of push.py:27-36 is
+        // [0, pad) constrain_zero, [pad, np) bytecode lookup + constrain_equal, [np, 32) constrain_zero: the two zero runs
+        // are scanned with static byte positions, the lookups walk a shifted copy (no dynamically indexed registers)
+        const u32 np = (u32)fr_lo64(num_pushed);
+        const u32 pad = fr_lo64(num_padding) < (u64)np ? (u32)fr_lo64(num_padding) : np;
+        const u64 base = fr_lo64(pc) + np;
+        push_zero_run(I, vb, 0, pad);
+        U256 cur = u256_shr_bytes(vb, pad);
+        for (u32 k = pad; k < np; k++) {
+            Fr byte = opcode_lookup_at(I, fr_u(base - (u64)k), false);
+            constrain_equal(I, fr_u(cur.v[0] & 0xffu), byte);
+#pragma unroll
+            for (int j = 0; j < 7; j++) cur.v[j] = (cur.v[j] >> 8) | (cur.v[j + 1] << 24);
+            cur.v[7] >>= 8;
+        }
+        push_zero_run(I, vb, np, 32);
+    } else {
+        for (int k = 0; k < 32; k++) {
+            const bool pushed = fr_lt(fr_u((u64)k), num_pushed), padding = fr_lt(fr_u((u64)k), num_padding);
+            if (pushed && !padding) {
+                Fr index = fr_sub_u64(fr_add(pc, num_pushed), (u64)k);
+                Fr byte = opcode_lookup_at(I, index, false);
+                constrain_equal(I, fr_u(fr_byte(vb, k)), byte);
+            } else {
+                constrain_zero(I, fr_u(fr_byte(vb, k)));
+            }
         }
     }
     set_tail(T, opcode, 1, t_delta(fr_add_u64(num_pushed, 1)), -1, t_same(), 0, fr_zero());
@@ -1308,6 +1412,7 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
     pop1 = stack_pop(I); pop2 = stack_pop(I); push = stack_push(I);
     // gen_witness (:103-127)
     Fr is_shl = fr_sub(fr_u(OP_SHR), opcode);
+    const bool op_known = fr_eq_u64(opcode, OP_SHL) || fr_eq_u64(opcode, OP_SHR);  // is_shl, is_shr are 0 / 1: products below are selects
     Word shift = pop1;
     U256 sb; EV_TRY(sb = to_u256(I, shift));
     const u32 shf0 = fr_byte(sb, 0);
@@ -1335,15 +1440,15 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
     const u32 dz = is_zero_word(divisor);
     constrain_equal_word(I, pop1, shift);
     {
-        Word w1 = word_checked(I, fr_mul(quotient.lo, is_shl), fr_mul(quotient.hi, is_shl));
-        Word w2 = word_checked(I, fr_mul(dividend.lo, is_shr), fr_mul(dividend.hi, is_shr));
+        Word w1 = word_checked(I, fr_sel01(quotient.lo, is_shl, op_known), fr_sel01(quotient.hi, is_shl, op_known));
+        Word w2 = word_checked(I, fr_sel01(dividend.lo, is_shr, op_known), fr_sel01(dividend.hi, is_shr, op_known));
         Word s = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
         constrain_equal_word(I, pop2, s);
     }
     {
-        Fr s = fr_mul(is_shr, fr_u(1 - dz));
-        Word w1 = word_checked(I, fr_mul(dividend.lo, is_shl), fr_mul(dividend.hi, is_shl));
-        Word w2 = word_checked(I, fr_mul(quotient.lo, s), fr_mul(quotient.hi, s));
+        Fr s = fr_sel01(is_shr, fr_u(1 - dz), true);
+        Word w1 = word_checked(I, fr_sel01(dividend.lo, is_shl, op_known), fr_sel01(dividend.hi, is_shl, op_known));
+        Word w2 = word_checked(I, fr_sel01(quotient.lo, s, op_known), fr_sel01(quotient.hi, s, op_known));
         Word sum = word_checked(I, fr_add(w1.lo, w2.lo), fr_add(w1.hi, w2.hi));
         constrain_equal_word(I, push, sum);
     }
@@ -1360,7 +1465,7 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
     constrain_zero(I, is_zero_word(remainder) ? fr_zero() : is_shl);
     if (I.err) return;
     Fr overflow; EV_TRY(overflow = mul_add_words(I, quotient, divisor, remainder, dividend));
-    constrain_zero(I, fr_mul(is_shr, overflow));
+    constrain_zero(I, fr_sel01(overflow, is_shr, op_known));
     if (dz == 0) fixed_lookup(I, FX_Pow2, fr_u(shf0), divisor.lo, divisor.hi);
     if (I.err) return;
     set_tail3(T, opcode, 3, 1, 1);
@@ -3812,10 +3917,11 @@ ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_spa
 #endif
 
 template <int G>
-ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr) {
+ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr, EVM_LDS_PTR dir_lds = nullptr) {
     Ins I;
     I.a = &a;
     I.stage = stage;
+    I.dir_lds = dir_lds;
     I.idx = idx;
     I.err = 0;
     I.seq = 0;

@@ -150,7 +150,21 @@ __global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u3
     }
     u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ u64 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_SLOTS * EVM_STAGE_LANES : 1];
+    __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
     if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
+        // small bytecode directories (the usual case: a handful of contracts) are mirrored in LDS by the whole block, so that
+        // resolving curr.code_hash costs no dependent HBM round trips
+        const bool dir_in_lds = a.codes.n != 0 && a.codes.n <= EVM_DIR_MAX_ENTRIES && a.codes.mask < EVM_DIR_MAX_SLOTS;
+        if (dir_in_lds) {
+            const u32 n_slots = a.codes.mask + 1u;
+            for (u32 k = threadIdx.x; k < EVM_DIR_SLOT_U64; k += blockDim.x) {
+                const u32 s0 = 2 * k < n_slots ? a.codes.slots[2 * k] : ZK_EMPTY_SLOT, s1 = 2 * k + 1 < n_slots ? a.codes.slots[2 * k + 1] : ZK_EMPTY_SLOT;
+                s_dir[k] = (u64)s0 | ((u64)s1 << 32);
+            }
+            const u64* e = (const u64*)a.codes.entries;
+            for (u32 k = threadIdx.x; k < a.codes.n * 12u; k += blockDim.x) s_dir[EVM_DIR_SLOT_U64 + k] = e[k];
+            __syncthreads();
+        }
         u32 code = 0;
         u64 idx = t;
         if (t < (u64)hi) {
@@ -158,7 +172,8 @@ __global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u3
             // both steps of the pair go to LDS first (52 loads in flight at once); the gadgets read them from there
             __attribute__((address_space(3))) u64* my = (__attribute__((address_space(3))) u64*)s_stage + threadIdx.x;
             const bool staged = evm_stage_steps(a, idx, my);
-            code = evm_check_step<G>(a, idx, staged ? (EVM_LDS_PTR)my : (EVM_LDS_PTR) nullptr);
+            code = evm_check_step<G>(a, idx, staged ? (EVM_LDS_PTR)my : (EVM_LDS_PTR) nullptr,
+                                     dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
             if (code == ZK_NOT_MINE) code = 0;
             else if (status) status[idx] = code;
         }
