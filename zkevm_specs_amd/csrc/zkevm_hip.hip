@@ -213,60 +213,68 @@ __global__ void rw_pack_kernel(ZkTable t, u64* keys) {
 }
 
 // Counting sort of the step pairs by (group, state): histogram, scan, scatter.
-__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, ZkTally* tally) {
+__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
     __shared__ u32 local[EVM_N_BINS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
-        tally->fail_count = 0ull;
-        tally->first_fail = ~0ull;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
+            tally->fail_count = 0ull;
+            tally->first_fail = ~0ull;
+        }
+        for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) taken[k] = 0;  // the scatter's per-bin cursors
     }
     for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
     __syncthreads();
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pairs) {
-        u32 st = (u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4];
-        atomicAdd(&local[evm_state_bin(st)], 1u);
+        const u32 bin = evm_state_bin((u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4]);
+        bin16[i] = (uint16_t)bin;  // the scatter reads this compact copy instead of the 416-byte-strided state cells
+        atomicAdd(&local[bin], 1u);
     }
     __syncthreads();
     for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
         if (local[k]) atomicAdd(&hist[k], local[k]);
 }
-// Exclusive scan of the bins (histogram -> per-bin cursors) + the group boundaries; one block of
-// EVM_N_BINS threads, Hillis-Steele in LDS.  Also clears the histogram copy for the next pass.
-__global__ void evm_state_scan_kernel(u32* hist, u32* cursor, u32* group_start) {
-    __shared__ u32 a[EVM_N_BINS], b[EVM_N_BINS];
+// Scatter with block-level aggregation.  Every block scans the (complete) histogram itself — 512 bins, Hillis-Steele in
+// LDS — instead of waiting for a separate one-block scan launch; block 0 publishes the group boundaries and clears the
+// OTHER histogram buffer for the next pass (the two alternate).  Ranks inside a block come from LDS atomics, one global
+// atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
+__global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
+                                                                 u32* taken, u32* group_start, u32* perm) {
+    __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
+    __shared__ u32 local[EVM_N_BINS];
+    __shared__ u32 base[EVM_N_BINS];
     const u32 k = threadIdx.x;
-    const u32 c = hist[k];
-    hist[k] = 0;  // ready for the next pass's histogram
-    a[k] = c;
+    u32 c = 0;
+    if (k < EVM_N_BINS) {
+        c = hist[k];
+        sa[k] = c;
+        local[k] = 0;
+        if (blockIdx.x == 0) hist_next[k] = 0;
+    }
     __syncthreads();
-    u32* src = a;
-    u32* dst = b;
+    u32* src = sa;
+    u32* dst = sb;
     for (u32 off = 1; off < EVM_N_BINS; off <<= 1) {
-        dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
+        if (k < EVM_N_BINS) dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
         __syncthreads();
         u32* t = src; src = dst; dst = t;
     }
-    const u32 excl = src[k] - c;
-    cursor[k] = excl;
-    if ((k & 127u) == 0) group_start[k >> 7] = excl;
-    if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
-}
-// Scatter with block-level aggregation: ranks inside a block come from LDS atomics, one global
-// atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
-__global__ void evm_state_scatter_kernel(const u64* steps, u32 n_pairs, u32* cursor, u32* perm) {
-    __shared__ u32 local[EVM_N_BINS];
-    __shared__ u32 base[EVM_N_BINS];
-    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
-    __syncthreads();
+    u32 excl = 0;
+    if (k < EVM_N_BINS) {
+        excl = src[k] - c;
+        if (blockIdx.x == 0) {
+            if ((k & 127u) == 0) group_start[k >> 7] = excl;
+            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
+        }
+    }
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u32 bin = 0, rank = 0;
     if (i < n_pairs) {
-        bin = evm_state_bin((u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4]);
+        bin = bin16[i];
         rank = atomicAdd(&local[bin], 1u);
     }
     __syncthreads();
-    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
-        if (local[k]) base[k] = atomicAdd(&cursor[k], local[k]);
+    if (k < EVM_N_BINS && local[k]) base[k] = excl + atomicAdd(&taken[k], local[k]);
     __syncthreads();
     if (i < n_pairs) perm[base[bin] + rank] = i;
 }
@@ -482,7 +490,10 @@ struct zk_session {
     AssignArgs assign;
     EcdsaArgs ecdsa;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
-    u32* d_cursor = nullptr; // EVM: scanned bins (scatter cursors)
+    u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
+    u32* d_hist2 = nullptr;  // EVM: the other histogram buffer (the two alternate between passes)
+    uint16_t* d_bin16 = nullptr;  // EVM: sort bin of every pair, written by the histogram pass
+    u32 evm_pass = 0;
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
 };
@@ -596,10 +607,13 @@ static int table_stage(zk_session* s, ZkTable& t, const uint64_t* cells, const u
 // (Re)build the state-sorted permutation of the step pairs.
 static int evm_build_perm(zk_session* s) {
     const u32 n = s->evm.n_pairs;
-    // d_hist is zero on entry (cleared at open and by every scan)
-    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->evm.steps, n, s->d_hist, s->d_tally);
-    hipLaunchKernelGGL(evm_state_scan_kernel, dim3(1), dim3(EVM_N_BINS), 0, g_stream, s->d_hist, s->d_cursor, s->d_group_start);
-    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->evm.steps, n, s->d_cursor, s->d_perm);
+    // the histogram buffer of this pass is zero on entry: cleared at open, then by the previous pass's scatter
+    u32* h_cur = (s->evm_pass & 1u) ? s->d_hist2 : s->d_hist;
+    u32* h_next = (s->evm_pass & 1u) ? s->d_hist : s->d_hist2;
+    s->evm_pass++;
+    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->evm.steps, n, h_cur, s->d_cursor, s->d_bin16, s->d_tally);
+    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->d_bin16, n, h_cur, h_next, s->d_cursor,
+                       s->d_group_start, s->d_perm);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -736,7 +750,10 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     s->evm.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
     if ((rc = dev_alloc(s, (void**)&s->d_hist, EVM_N_BINS * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
-    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess) { rc = -2; goto fail; }
+    if ((rc = dev_alloc(s, (void**)&s->d_hist2, EVM_N_BINS * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)s->evm.n_pairs * sizeof(uint16_t)))) goto fail;
+    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess ||
+        hipMemsetAsync(s->d_hist2, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess) { rc = -2; goto fail; }
     if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
     s->evm.prof = nullptr;
