@@ -181,6 +181,9 @@ def main():
             "config": dict({"workload": workload, "sharding": f"rows x{world}, tally all-reduce"}, **extra_cfg),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         # HBM-side bytes actually moved per launch (PMC passes) over the live kernel time: what the
+                         # memory system sees, next to the algorithmic (work-per-byte-budget) figure above
+                         "traffic_GBps": None if traffic is None else traffic / kernel_s / 1e9,
                          "kernel": kernel_name, "kernel_ms": res.kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "cold_cache": None if cold_ms is None else {
