@@ -77,6 +77,25 @@ def test_synthetic_trace_matches_oracle(state_sort, generic_index):
     assert res.fail_count >= 10
 
 
+def test_many_contracts_bypass_the_lds_directory_mirror():
+    """40 contracts: more than the hot kernel mirrors in LDS (32), so code hashes resolve through the directory in HBM;
+    wide step cells (>= 2^64) additionally take a lane off the LDS-staged step pair.  Both paths vs the oracle."""
+    w = synth_evm_trace(6000, seed=33, seg_len=120, n_contracts=40)
+    w = {k: v for k, v in w.items() if k != "meta"}
+    res, status = _run(w)
+    assert res.ok and not any(status)
+    rng = random.Random(9)
+    for _ in range(30):
+        w = fuzz_wire(w, rng)
+    w["steps"][777, 9, 2] = np.uint64(1)   # gas_left >= 2^128: the pair cannot be staged
+    w["steps"][2048, 2, 1] = np.uint64(5)  # call_id >= 2^64
+    res, status = _run(w)
+    exp = oracle_status(w)
+    assert status == exp
+    _check_tally(res, exp)
+    assert res.fail_count >= 8
+
+
 def test_full_size_trace_properties():
     """BASELINE config 3 size (2^18 steps): the valid trace passes; tampering k cells makes exactly
     the pairs that look at those cells fail (oracle evaluated on the affected pairs only);

@@ -111,7 +111,10 @@ __global__ void index_build_kernel(ZkTable t, u32* slots) {
 // access test) is re-read through L1/L2 by the few rows that need it.
 // ---------------------------------------------------------------------------------------
 #define ST_ROWS_PER_WAVE 63
-__global__ __launch_bounds__(256) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
+#ifndef ZK_STATE_OCC
+#define ZK_STATE_OCC 2  // waves per SIMD the State kernel is compiled for (3 was measured: 168 VGPRs + 32 B scratch, 2^20 rows 0.423 vs 0.404 ms)
+#endif
+__global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;  // first row this wavefront evaluates
