@@ -249,6 +249,23 @@ int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint
 int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                     uint32_t opts, uint32_t* status_out, zk_result* result);
 
+/* ---- Bytecode-circuit witness assignment: replaces assign_bytecode_circuit(k, bytecodes,
+ *      keccak_randomness) (src/zkevm_specs/bytecode_circuit.py:104-167: push-data tracking, running value_rlc, length,
+ *      q_first / q_last, truncation at 2^k rows, EMPTY_HASH padding).
+ *      in_rows: the BytecodeTableRows of the UnrolledBytecodes (:31-33) back to back, ROW-major uint64[n_rows][6][4]
+ *      (hash lo/hi, tag, index, is_code, value — the EVM circuit's bytecode-table layout, in input order);
+ *      offsets uint64[n_codes + 1]: first row of every bytecode (offsets[0] = 0, offsets[n_codes] = n_rows);
+ *      lengths uint64[n_codes]: len(bytecode.bytes).  Output: COLUMN-major uint64[12][2^k][4], what zk_bytecode_open
+ *      takes.  With ZK_OPT_DEVICE_PTRS rows_dev (nullable: the session then owns the rows) receives them in place.
+ *      The assignment itself cannot fail: the tally is always clean. */
+int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
+                            uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_dev, uint32_t opts,
+                            zk_session** out);
+int zk_bytecode_assign_read(zk_session* s, uint64_t* rows_host /* uint64[12][2^k][4] */);
+int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
+                       uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_out, uint32_t opts,
+                       zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

@@ -7,7 +7,7 @@ that loop as one device pass.  A failing row raises AssertionError like the refe
 """
 from . import engine
 from .errors import KIND_ASSERT, exception_for_code, raise_for_code
-from .flatten import _n, flatten_bytecode_rows, flatten_keccak_table
+from .flatten import _n, flatten_bytecode_rows, flatten_keccak_table, flatten_unrolled_bytecodes
 
 
 def assign_keccak_table(bytecodes, keccak_randomness):
@@ -17,9 +17,19 @@ def assign_keccak_table(bytecodes, keccak_randomness):
     return engine.keccak_table([bytes(b) for b in bytecodes], _n(keccak_randomness), engine.KECCAK_MODE_CIRCUIT)
 
 
+def assign_bytecode_circuit(k, bytecodes, keccak_randomness):
+    """`assign_bytecode_circuit(k, bytecodes, keccak_randomness)` (bytecode_circuit.py:104-167) on the device: bytecodes =
+    sequence of reference-style UnrolledBytecode (or the (rows, offsets, lengths) wire arrays) -> the 2^k circuit rows
+    in wire form uint64[12, 2^k, 4] (what verify_bytecode_rows / engine.open_bytecode take)."""
+    in_rows, offsets, lengths = bytecodes if isinstance(bytecodes, tuple) else flatten_unrolled_bytecodes(bytecodes)
+    with engine.open_bytecode_assign(in_rows, offsets, lengths, k, _n(keccak_randomness)) as s:
+        s.run()
+        return s.rows()
+
+
 def verify_bytecode_rows(rows, keccak_table, keccak_randomness, success=True):
-    cols = flatten_bytecode_rows(rows)
-    kt = flatten_keccak_table(keccak_table)
+    cols = rows if hasattr(rows, "shape") else flatten_bytecode_rows(rows)
+    kt = keccak_table if hasattr(keccak_table, "shape") else flatten_keccak_table(keccak_table)
     with engine.open_bytecode(cols, kt, _n(keccak_randomness)) as s:
         res = s.run()
     exception = None

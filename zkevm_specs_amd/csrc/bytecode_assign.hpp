@@ -1,0 +1,133 @@
+// Bytecode-circuit witness assignment on the device.
+//
+// Replaces the reference's `assign_bytecode_circuit(k, bytecodes, keccak_randomness)`
+// (src/zkevm_specs/bytecode_circuit.py:104-167): per bytecode the push-data tracking (`push_data_left`,
+// `push_data_size`; get_push_size, evm_circuit/opcode.py:427-433) and the running `value_rlc = value_rlc * r + value`
+// over the byte rows, then q_first / q_last, `length`, truncation at 2^k rows and the EMPTY_HASH padding rows.
+// Input: the unrolled BytecodeTableRows of all bytecodes back to back (row-major, 6 cells: hash lo/hi, tag, index,
+// is_code, value) + row offsets and byte lengths per bytecode; output: the 12-cell circuit rows column-major, exactly
+// what zk_bytecode_open takes.
+//
+// The two per-bytecode recurrences are sequential in the reference.  Here:
+//   bca_track_code   one lane per bytecode walks its rows with integers only (push_data_left <= 32): 2 bytes per row
+//   bca_chunk        one lane per 64-row chunk: Horner over the chunk from 0  -> (acc, number of byte rows m)
+//   bca_prefix_code  one lane per bytecode: incoming value_rlc of every chunk, running = running * r^m + acc
+//   bca_rlc_chunk    one lane per chunk: value_rlc of each of its rows from the incoming value
+//   bca_write_row    one lane per OUTPUT row (coalesced 32 B/lane stores of the 12 cells), padding rows included
+// so a 24,576-byte contract costs ~2 x 64 + 384 dependent Montgomery products per lane instead of 24,576.
+#pragma once
+#include "common.hpp"
+
+enum { BCA_IN_NCELLS = 6, BCA_OUT_NCELLS = 12, BCA_CHUNK = 64, BCA_RPOW_ROWS = BCA_CHUNK + 1 };
+
+struct BcaChunk {
+    u32 code;   // bytecode index
+    u32 start;  // first global input row of the chunk
+    u32 count;  // rows in the chunk (<= BCA_CHUNK)
+    u32 first;  // 1: the chunk starts at the bytecode's first row (idx 0, the Header row: it does not feed value_rlc)
+};
+
+struct BcaArgs {
+    const u64* in_rows;     // [n_in][6][4]
+    const u64* offsets;     // [n_codes + 1]
+    const u64* lengths;     // [n_codes]
+    u64 n_in, n_codes, n_out;  // n_out = 2^k
+    const u64* rpow;        // [65][4]: r^m in Montgomery form, m = 0..64 (row 1 = the randomness itself)
+    const BcaChunk* chunks; // [n_chunks]
+    const u32* code_chunk0; // [n_codes + 1]: first chunk of every bytecode
+    u64 n_chunks;
+    uint8_t* track;         // [n_in][2]: push_data_left, push_data_size
+    u64* chunk_acc;         // [n_chunks][4] Horner of the chunk from 0
+    u32* chunk_m;           // [n_chunks] byte rows in the chunk
+    u64* chunk_in;          // [n_chunks][4] incoming value_rlc
+    u64* rlc;               // [n_in][4] value_rlc per input row
+    u32* row_code;          // [n_in] bytecode of every input row (written by bca_rlc_chunk)
+    u64* rows;              // out [12][n_out][4]
+};
+
+ZK_HD Fr bca_in_cell(const BcaArgs& a, u64 row, int c) { return fr_load(a.in_rows + (row * BCA_IN_NCELLS + c) * 4); }
+ZK_HD void bca_store(u64* out, const Fr& x) {
+    for (int j = 0; j < 4; j++) out[j] = (u64)x.v[2 * j] | ((u64)x.v[2 * j + 1] << 32);
+}
+// get_push_size(row.value): PUSH1..PUSH32 -> 1..32, anything else (incl. values >= 256) -> 0
+ZK_HD u32 bca_push_size(const Fr& v) { return (fr_fits32(v) && v.v[0] >= 0x60u && v.v[0] <= 0x7fu) ? v.v[0] - 0x5fu : 0u; }
+
+ZK_HD void bca_fill_rpow(const Fr& r, u64* out) {  // single lane, once per session
+    const Fr rM = fr_to_mont(r);
+    Fr acc = frm_one();
+    for (int m = 0; m < BCA_RPOW_ROWS; m++) {
+        bca_store(out + 4 * m, acc);
+        acc = fr_mont(acc, rM);
+    }
+}
+ZK_HD void bca_track_code(const BcaArgs& a, u64 j) {
+    u32 next = 0;
+    const u64 lo = a.offsets[j], hi = a.offsets[j + 1];
+    for (u64 g = lo; g < hi; g++) {
+        const u32 left = next;
+        u32 size = 0;
+        if (g > lo) {
+            size = bca_push_size(bca_in_cell(a, g, 5));
+            next = left == 0u ? size : left - 1u;
+        }
+        a.track[2 * g] = (uint8_t)left;
+        a.track[2 * g + 1] = (uint8_t)size;
+    }
+}
+ZK_HD void bca_chunk(const BcaArgs& a, u64 c) {
+    const BcaChunk ch = a.chunks[c];
+    const Fr rM = fr_load(a.rpow + 4);
+    Fr acc = fr_zero();
+    u32 m = 0;
+    for (u32 t = 0; t < ch.count; t++) {
+        if (ch.first && t == 0) continue;
+        acc = fr_add(fr_mont(acc, rM), bca_in_cell(a, (u64)ch.start + t, 5));
+        m++;
+    }
+    bca_store(a.chunk_acc + 4 * c, acc);
+    a.chunk_m[c] = m;
+}
+ZK_HD void bca_prefix_code(const BcaArgs& a, u64 j) {
+    Fr running = fr_zero();
+    for (u32 c = a.code_chunk0[j]; c < a.code_chunk0[j + 1]; c++) {
+        bca_store(a.chunk_in + 4 * (u64)c, running);
+        running = fr_add(fr_mont(running, fr_load(a.rpow + 4 * a.chunk_m[c])), fr_load(a.chunk_acc + 4 * (u64)c));
+    }
+}
+ZK_HD void bca_rlc_chunk(const BcaArgs& a, u64 c) {
+    const BcaChunk ch = a.chunks[c];
+    const Fr rM = fr_load(a.rpow + 4);
+    Fr rlc = fr_load(a.chunk_in + 4 * c);
+    for (u32 t = 0; t < ch.count; t++) {
+        const u64 g = (u64)ch.start + t;
+        if (!(ch.first && t == 0)) rlc = fr_add(fr_mont(rlc, rM), bca_in_cell(a, g, 5));
+        bca_store(a.rlc + 4 * g, rlc);
+        a.row_code[g] = ch.code;
+    }
+}
+// Output row i (bytecode_circuit.Row: q_first, q_last, hash lo, hi, tag, index, value, is_code, push_data_left, value_rlc,
+// length, push_data_size)
+ZK_HD void bca_write_row(const BcaArgs& a, u64 i) {
+    const u64 n = a.n_out;
+#define BCA_OUT(c) (a.rows + ((u64)(c) * n + i) * 4)
+    bca_store(BCA_OUT(0), fr_from_u64(i == 0 ? 1 : 0));
+    bca_store(BCA_OUT(1), fr_from_u64(i == n - 1 ? 1 : 0));
+    if (i < a.n_in) {
+        bca_store(BCA_OUT(2), bca_in_cell(a, i, 0));
+        bca_store(BCA_OUT(3), bca_in_cell(a, i, 1));
+        bca_store(BCA_OUT(4), bca_in_cell(a, i, 2));
+        bca_store(BCA_OUT(5), bca_in_cell(a, i, 3));
+        bca_store(BCA_OUT(6), bca_in_cell(a, i, 5));
+        bca_store(BCA_OUT(7), bca_in_cell(a, i, 4));
+        bca_store(BCA_OUT(8), fr_from_u64(a.track[2 * i]));
+        bca_store(BCA_OUT(9), fr_load(a.rlc + 4 * i));
+        bca_store(BCA_OUT(10), fr_from_u64(a.lengths[a.row_code[i]]));
+        bca_store(BCA_OUT(11), fr_from_u64(a.track[2 * i + 1]));
+    } else {  // padding (:150-165): Header rows of the empty bytecode
+        bca_store(BCA_OUT(2), fr_from_u128(0x7bfad8045d85a470ull, 0xe500b653ca82273bull));
+        bca_store(BCA_OUT(3), fr_from_u128(0x927e7db2dcc703c0ull, 0xc5d2460186f7233cull));
+        bca_store(BCA_OUT(4), fr_from_u64(1));
+        for (int c = 5; c < BCA_OUT_NCELLS; c++) bca_store(BCA_OUT(c), fr_zero());
+    }
+#undef BCA_OUT
+}

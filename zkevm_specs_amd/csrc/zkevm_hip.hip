@@ -16,6 +16,7 @@
 #include "keccak_table.hpp"
 #include "state_assign.hpp"
 #include "secp256k1.hpp"
+#include "bytecode_assign.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -432,6 +433,34 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     }
     tally_commit(tally, i, code);
 }
+// Bytecode-circuit witness assignment (bytecode_assign.hpp)
+__global__ void bca_rpow_kernel(Fr r, u64* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) bca_fill_rpow(r, out);
+}
+__global__ void bca_track_kernel(BcaArgs a) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.n_codes) bca_track_code(a, j);
+}
+__global__ void bca_chunk_kernel(BcaArgs a) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n_chunks) bca_chunk(a, c);
+}
+__global__ void bca_prefix_kernel(BcaArgs a) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.n_codes) bca_prefix_code(a, j);
+}
+__global__ void bca_rlc_kernel(BcaArgs a) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n_chunks) bca_rlc_chunk(a, c);
+}
+__global__ __launch_bounds__(256) void bca_rows_kernel(BcaArgs a, u32* status, ZkTally* tally) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n_out) {
+        bca_write_row(a, i);
+        if (status) status[i] = 0;  // the assignment has no failure modes of its own
+    }
+    tally_commit(tally, i, 0);
+}
 // Keccak table generation: one lane per message (keccak_table.hpp)
 __global__ void keccak_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
@@ -473,7 +502,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9 };
+enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
 
 struct zk_session {
     SessionKind kind;
@@ -492,6 +521,7 @@ struct zk_session {
     KeccakGenArgs keccak_gen;
     AssignArgs assign;
     EcdsaArgs ecdsa;
+    BcaArgs bca;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
     u32* d_hist2 = nullptr;  // EVM: the other histogram buffer (the two alternate between passes)
@@ -1141,6 +1171,114 @@ extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint
     return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
 }
 
+// ---- Bytecode-circuit witness assignment
+extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
+                                       uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_dev, uint32_t opts,
+                                       zk_session** out) {
+    ARG_TRY(g_device >= 0, "zk_bytecode_assign_open: call zk_init first");
+    ARG_TRY(out && randomness && k >= 1 && k <= 28 && n_rows < (1ull << 31) && n_codes < (1ull << 31) && (n_codes == 0 || (offsets && lengths)) &&
+            (n_rows == 0 || in_rows), "zk_bytecode_assign_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || !rows_dev, "zk_bytecode_assign_open: rows_dev needs ZK_OPT_DEVICE_PTRS");
+    zk_session* s = new zk_session();
+    s->kind = SESSION_BCA;
+    s->n = 1ull << k;
+    BcaArgs& a = s->bca;
+    int rc = 0;
+    const void* p = nullptr;
+    std::vector<u64> h_off((size_t)n_codes + 1, 0);
+    std::vector<BcaChunk> chunks;
+    std::vector<u32> code_chunk0((size_t)n_codes + 1, 0);
+    u64 rh[4];
+    Fr r;
+    // the chunk table is index plumbing over the row offsets (not witness data): built on the host
+    if (n_codes) {
+        if (dev) {
+            if (hipMemcpy(h_off.data(), offsets, (n_codes + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "offsets download failed"; goto fail; }
+        } else {
+            memcpy(h_off.data(), offsets, (n_codes + 1) * 8);
+        }
+    }
+    for (u64 j = 0; j < n_codes; j++) {
+        if (h_off[j] > h_off[j + 1] || h_off[j + 1] > n_rows) { rc = -1; g_err = "zk_bytecode_assign_open: offsets must be non-decreasing and within the rows"; goto fail; }
+        code_chunk0[j] = (u32)chunks.size();
+        for (u64 g = h_off[j]; g < h_off[j + 1]; g += BCA_CHUNK) {
+            BcaChunk c;
+            c.code = (u32)j; c.start = (u32)g;
+            c.count = (u32)((h_off[j + 1] - g < BCA_CHUNK) ? h_off[j + 1] - g : BCA_CHUNK);
+            c.first = g == h_off[j] ? 1u : 0u;
+            chunks.push_back(c);
+        }
+    }
+    code_chunk0[n_codes] = (u32)chunks.size();
+    if (n_codes && (h_off[0] != 0 || h_off[n_codes] != n_rows)) { rc = -1; g_err = "zk_bytecode_assign_open: offsets must cover every row"; goto fail; }
+    if ((rc = stage(s, in_rows, (size_t)n_rows * BCA_IN_NCELLS * 32, dev, &p))) goto fail;
+    a.in_rows = (const u64*)p;
+    if ((rc = stage(s, n_codes ? offsets : nullptr, (size_t)(n_codes + 1) * 8, dev, &p))) goto fail;
+    a.offsets = (const u64*)p;
+    if ((rc = stage(s, lengths, (size_t)n_codes * 8, dev, &p))) goto fail;
+    a.lengths = (const u64*)p;
+    a.n_in = n_rows; a.n_codes = n_codes; a.n_out = 1ull << k; a.n_chunks = chunks.size();
+    if (dev) {
+        if (hipMemcpy(rh, randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, randomness, 32);
+    }
+    for (int q = 0; q < 4; q++) { r.v[2 * q] = (u32)rh[q]; r.v[2 * q + 1] = (u32)(rh[q] >> 32); }
+    {
+        u64* d_rpow = nullptr;
+        void* d = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_rpow, BCA_RPOW_ROWS * 32))) goto fail;
+        hipLaunchKernelGGL(bca_rpow_kernel, dim3(1), dim3(64), 0, g_stream, r, d_rpow);
+        a.rpow = d_rpow;
+        if ((rc = stage(s, chunks.empty() ? nullptr : chunks.data(), chunks.size() * sizeof(BcaChunk), false, &p))) goto fail;
+        a.chunks = (const BcaChunk*)p;
+        if ((rc = stage(s, code_chunk0.data(), code_chunk0.size() * 4, false, &p))) goto fail;
+        a.code_chunk0 = (const u32*)p;
+        HIP_TRY(hipStreamSynchronize(g_stream));  // the host vectors above go out of scope with this call
+        if ((rc = dev_alloc(s, &d, (size_t)n_rows * 2))) goto fail;
+        a.track = (uint8_t*)d;
+        if ((rc = dev_alloc(s, &d, chunks.size() * 32))) goto fail;
+        a.chunk_acc = (u64*)d;
+        if ((rc = dev_alloc(s, &d, chunks.size() * 4))) goto fail;
+        a.chunk_m = (u32*)d;
+        if ((rc = dev_alloc(s, &d, chunks.size() * 32))) goto fail;
+        a.chunk_in = (u64*)d;
+        if ((rc = dev_alloc(s, &d, (size_t)n_rows * 32))) goto fail;
+        a.rlc = (u64*)d;
+        if ((rc = dev_alloc(s, &d, (size_t)n_rows * 4))) goto fail;
+        a.row_code = (u32*)d;
+    }
+    a.rows = rows_dev;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)a.n_out * BCA_OUT_NCELLS * 32))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_bytecode_assign_read(zk_session* s, uint64_t* rows_host) {
+    ARG_TRY(s && rows_host && s->kind == SESSION_BCA, "zk_bytecode_assign_read: bad arguments");
+    HIP_TRY(hipMemcpyAsync(rows_host, s->bca.rows, (size_t)s->bca.n_out * BCA_OUT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
+}
+extern "C" int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
+                                  uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_out, uint32_t opts,
+                                  zk_result* result) {
+    ARG_TRY(result && rows_out, "zk_bytecode_assign: null output");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_bytecode_assign_open(in_rows, n_rows, offsets, lengths, n_codes, k, randomness, dev ? rows_out : nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && !dev) rc = zk_bytecode_assign_read(s, rows_out);
+    zk_close(s);
+    return rc;
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -1288,6 +1426,18 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         // 64-lane blocks: 2^14 signatures are only 256 wavefronts, one per CU
         const u32 grid = (u32)((s->n + 63) / 64);
         hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(grid), dim3(64), 0, g_stream, s->ecdsa, status, s->d_tally);
+        break;
+    }
+    case SESSION_BCA: {
+        const BcaArgs& a = s->bca;
+        const u32 gc = (u32)((a.n_codes + 63) / 64), gk = (u32)((a.n_chunks + 63) / 64);
+        if (a.n_codes) {
+            hipLaunchKernelGGL(bca_track_kernel, dim3(gc), dim3(64), 0, g_stream, a);
+            hipLaunchKernelGGL(bca_chunk_kernel, dim3(gk ? gk : 1), dim3(64), 0, g_stream, a);
+            hipLaunchKernelGGL(bca_prefix_kernel, dim3(gc), dim3(64), 0, g_stream, a);
+            hipLaunchKernelGGL(bca_rlc_kernel, dim3(gk ? gk : 1), dim3(64), 0, g_stream, a);
+        }
+        hipLaunchKernelGGL(bca_rows_kernel, dim3((u32)((a.n_out + 255) / 256)), dim3(256), 0, g_stream, a, status, s->d_tally);
         break;
     }
     case SESSION_EXP: {

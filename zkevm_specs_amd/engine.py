@@ -324,6 +324,30 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev))
 
 
+class BytecodeAssignSession(Session):
+    """Bytecode-witness assignment session: launch()/collect() like the circuits; rows() for the 2^k circuit rows."""
+
+    def rows(self):
+        out = np.empty((12, self.n, 4), dtype=np.uint64)
+        check(_lib.load().zk_bytecode_assign_read(self._h, _lib.ptr(out)), "zk_bytecode_assign_read")
+        return out
+
+
+def open_bytecode_assign(in_rows, offsets, lengths, k, randomness, rows_dev=None, device=None):
+    """in_rows uint64[n, 6, 4] (unrolled BytecodeTableRows, input order), offsets uint64[m + 1], lengths uint64[m], k,
+    randomness (int or uint64[4]) -> BytecodeAssignSession over the 2^k circuit rows; rows_dev: optional CUDA tensor
+    uint64[12, 2^k, 4] receiving them in place (ready for open_bytecode)."""
+    lib = _lib.init(device)
+    randomness = _randomness_cells(randomness, in_rows)
+    (in_rows, offsets, lengths, randomness, rows_dev), opts = _prep([in_rows, offsets, lengths, randomness, rows_dev])
+    n_rows, n_codes = int(in_rows.shape[0]), int(lengths.shape[0])
+    h = ctypes.c_void_p()
+    check(lib.zk_bytecode_assign_open(_lib.ptr(in_rows) if n_rows else None, n_rows, _lib.ptr(offsets), _lib.ptr(lengths) if n_codes else None,
+                                      n_codes, int(k), _lib.ptr(randomness), _lib.ptr(rows_dev), opts, ctypes.byref(h)),
+          "zk_bytecode_assign_open")
+    return BytecodeAssignSession(h, 1 << int(k), (in_rows, offsets, lengths, randomness, rows_dev))
+
+
 ECDSA_LAYOUT_PACKED = 0  # uint8[n, 5, 32]: pk_x LE, pk_y LE, msg_hash BE, sig_r LE, sig_s LE
 ECDSA_LAYOUT_TX_UNITS = 1   # uint8[n, 9, 32]: the Tx units' byte rows (open_sign's wire["bytes"]; msg_hash little-endian)
 ECDSA_LAYOUT_SIG_UNITS = 2  # the Sig units' byte rows (msg_hash big-endian; v = meta[:, 3])

@@ -459,3 +459,17 @@ def flatten_state_ops(ops):
     """-> (ops uint64[12, n, 4] column-major, flags uint32[n])"""
     sf = [state_op_slots(op) for op in ops]
     return rows_to_colmajor([s for s, _ in sf], OP_NSLOTS), np.array([f for _, f in sf], dtype=np.uint32)
+
+
+# ---- Bytecode-circuit witness assignment (unrolled bytecodes wire) -----------------------
+def flatten_unrolled_bytecodes(bytecodes):
+    """Sequence of reference UnrolledBytecode (bytecode_circuit.py:31-33: `bytes` + the BytecodeTableRows of
+    `Bytecode.table_assignments()`) -> (rows uint64[n, 6, 4] row-major in input order: hash lo/hi, tag, index, is_code,
+    value; offsets uint64[m + 1] row offsets per bytecode; lengths uint64[m] = len(bytecode.bytes))."""
+    cells, offsets, lengths = [], [0], []
+    for b in bytecodes:
+        for r in b.rows:
+            cells.append([_n(r.bytecode_hash.lo), _n(r.bytecode_hash.hi), _n(r.field_tag), _n(r.index), _n(r.is_code), _n(r.value)])
+        offsets.append(len(cells))
+        lengths.append(len(b.bytes))
+    return (rows_to_rowmajor(cells, BYTECODE_NCELLS), np.array(offsets, dtype=np.uint64), np.array(lengths, dtype=np.uint64))
