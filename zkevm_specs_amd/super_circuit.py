@@ -4,9 +4,11 @@ witness set on one GPU; ranks hold independent shards and all-reduce the tally (
 The reference has no super-circuit driver: each circuit has its own `verify_*` entry and
 they are only related through the tables they share.  This module launches the same C-ABI sessions the per-circuit
 mirrors use, back to back on one stream, and sums their tallies.  What is shared in the synthetic witness:
-  * the contracts the EVM trace executes ARE the byte strings of the Bytecode circuit's rows, and their code hashes
-    are real keccak-256 digests taken from the keccak table the device builds from those byte strings
-    (`zk_keccak_table`, mode 0) — the same table the Bytecode circuit looks up;
+  * the contracts the EVM trace executes ARE the byte strings of the Bytecode circuit's rows: the circuit rows are assigned
+    on the device (`zk_bytecode_assign`) from the very bytecode table the EVM circuit looks up (its rows, sorted by
+    hash / tag / index, are the unrolled bytecodes), and the code hashes are real keccak-256 digests taken from the
+    keccak table the device builds from those byte strings (`zk_keccak_table`, mode 0) — the same table the Bytecode
+    circuit looks up;
   * the State circuit's rows come out of the device-side witness assignment (`zk_state_assign`) of a synthetic op
     list sized like the trace's RW table.  They are NOT derived from the EVM trace's RW table: the synthetic trace
     does not model cross-step stack / memory consistency (synth_evm.py), which is exactly what the State circuit
@@ -61,9 +63,16 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
     tx = synth_tx_witness(n_tx, r, seed=seed + 1)
     n_state = (1 << log_total) - n_steps - (1 << k) - n_tx
     ops, op_flags, *_ = synth_state_ops(n_state, seed=seed + 2)
+    # the EVM circuit's bytecode table (sorted by hash, tag, index) read as unrolled bytecodes: one group of rows per hash
+    bt = evm["bytecode"].copy()
+    n_bt = bt.shape[0]
+    starts = [0] + [i for i in range(1, n_bt) if not np.array_equal(bt[i, 0:2], bt[i - 1, 0:2])] + [n_bt]
+    offsets = np.array(starts, dtype=np.uint64)
+    lengths = (offsets[1:] - offsets[:-1] - np.uint64(1)).astype(np.uint64)
     rows = {"evm": n_steps - 1, "state": n_state, "bytecode": 1 << k, "tx": n_tx}
     assert n_state >= 64
-    return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "tx": (tx, r), "rows": rows,
+    return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r),
+            "bytecode_unrolled": (bt, offsets, lengths, k), "tx": (tx, r), "rows": rows,
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows)}
 
 
@@ -93,12 +102,27 @@ class SuperCircuit:
                 rows, flags, mpt = a.read()
         assert res.ok, f"state witness assignment failed: {res}"
         self.assign_ms = res.kernel_ms
-        bc_rows, bc_keccak, r = parts["bytecode"]
+        _, bc_keccak, r = parts["bytecode"]
+        # Bytecode circuit rows: assigned on the device from the EVM circuit's own bytecode table
+        ub_rows, ub_off, ub_len, k = parts["bytecode_unrolled"]
+        d_ub = dev(ub_rows)
+        if hasattr(d_ub, "is_cuda"):
+            import torch
+
+            bc_rows = torch.empty((12, 1 << k, 4), dtype=torch.int64, device=d_ub.device)
+            with engine.open_bytecode_assign(d_ub, dev(ub_off), dev(ub_len), k, r, rows_dev=bc_rows, device=device) as a:
+                res = a.run()
+        else:
+            with engine.open_bytecode_assign(d_ub, ub_off, ub_len, k, r, device=device) as a:
+                res = a.run()
+                bc_rows = a.rows()
+        assert res.ok
+        dev_rows = bc_rows
         tx, r_tx = parts["tx"]
         self.sessions = {
             "evm": engine.open_evm({k: dev(v) for k, v in parts["evm"].items()}, device=device),
             "state": engine.open_state(rows, flags, mpt, device=device),
-            "bytecode": engine.open_bytecode(dev(bc_rows), dev(bc_keccak), r, device=device),
+            "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign({k: dev(v) for k, v in tx.items()}, r_tx, False, device=device),
         }
         self.rows = {k: s.n for k, s in self.sessions.items()}
