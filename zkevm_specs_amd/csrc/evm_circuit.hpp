@@ -1080,7 +1080,9 @@ ZK_HD Fr constant_divmod_shift(Ins& I, const Fr& num, int shift, int n_bytes) {
     return q;
 }
 ZK_HD Fr memory_gas_cost(Ins& I, const Fr& size) {  // instruction.py:1122-1129
-    Fr q = constant_divmod_shift(I, fr_mul(size, size), 9, 8);
+    // size * size in the field; a word count below 2^32 squares inside 64 bits (no Montgomery products)
+    const Fr sq = fr_fits32(size) ? fr_u((u64)size.v[0] * (u64)size.v[0]) : fr_mul(size, size);
+    Fr q = constant_divmod_shift(I, sq, 9, 8);
     return fr_add(q, fr_add(fr_add(size, size), size));
 }
 ZK_HD void memory_expansion(Ins& I, const Fr& offset, const Fr& length, Fr& next_size, Fr& gas) {  // :1131-1148
