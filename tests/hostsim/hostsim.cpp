@@ -207,6 +207,7 @@ extern "C" void sim_divmod(int wide, const u64* n, const u64* d, u64* q, u64* r,
 
 extern "C" int sim_bytecode_verify(const u64* cells, u64 n, const u64* keccak, u64 n_keccak, const u64* r, u32* status) {
     BytecodeArgs a;
+    a.r_mont = nullptr;
     a.rows.cells = cells;
     a.rows.flags = nullptr;
     a.rows.n = n;

@@ -115,3 +115,19 @@ struct ZkCols {
     u64 n;
 };
 ZK_HD Fr zk_col(const ZkCols& w, u32 c, u64 i) { return fr_load(w.cells + ((u64)c * w.n + i) * 4); }
+
+// (pos - sub) / 2^128 in the field, for a value that goes straight into range_check(., 9).  With sub < 2^200 the field
+// quotient is below 2^72 exactly when pos - sub is a non-negative integer multiple of 2^128 with a quotient below 2^72
+// (r * 2^128 < 2^200 < p pins (pos - sub) mod p = r * 2^128; a negative difference would need sub > p - 2^200): the
+// integer shift gives the same value then, and any other numerator only has to fail the range check like the field
+// quotient does.  No Montgomery product on the way.
+ZK_HD Fr div_2p128_for_range9(const Fr& pos, const Fr& sub) {
+    if ((sub.v[7] | (sub.v[6] >> 8)) != 0u) return fr_mulc(fr_sub(pos, sub), frm_inv_2p128());
+    Fr n;
+    const u32 bw = u256_sub(n, pos, sub);
+    const bool exact = !bw && (n.v[0] | n.v[1] | n.v[2] | n.v[3]) == 0u;
+    Fr r = fr_zero();
+    r.v[0] = n.v[4]; r.v[1] = n.v[5]; r.v[2] = n.v[6]; r.v[3] = n.v[7];
+    if (!exact) r.v[7] = 0x20000000u;
+    return r;
+}

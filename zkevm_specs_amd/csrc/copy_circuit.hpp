@@ -86,7 +86,9 @@ ZK_HD u32 copy_check_row(const CopyArgs& a, u64 i) {
         CP_ZERO(cz, fr_eq(fr_add_u64(addr, 1), zk_col(w, CP_ADDR, i2)), 12);
         CP_ZERO(cz, fr_eq(src_end, zk_col(w, CP_SRC_END, i2)), 13);
     }
-    const Fr rw_diff = fr_mul(fr_sub(one, is_pad), fr_add(is_memory, is_tx_log));
+    // (1 - is_pad) * (is_memory + is_tx_log): a select when is_pad is 0 / 1 (the usual case)
+    const Fr rw_diff = fr_is_zero(is_pad) ? fr_add(is_memory, is_tx_log)
+                                          : (fr_eq(is_pad, one) ? fr_zero() : fr_mul(fr_sub(one, is_pad), fr_add(is_memory, is_tx_log)));
     {
         const bool cz = fr_eq(is_last, one);  // 1 - is_last == 0
         CP_ZERO(cz, fr_eq(fr_add(rwc, rw_diff), zk_col(w, CP_RWC, i1)), 14);

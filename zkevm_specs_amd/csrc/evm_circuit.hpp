@@ -887,21 +887,6 @@ ZK_HD MulT mul_terms(const Limbs64& a, const Limbs64& b) {
 // mul_add_words (instruction.py:599-632): constrains a*b + c == d (mod 2^256), returns overflow.
 // The two constrain_equal calls (:629-630) are identities of the field (carry is *defined* as
 // (lhs - d)/2^128), so they only advance the checkpoint counter.
-// (pos - sub) / 2^128 in the field, for a value that goes straight into range_check(., 9).  With sub < 2^200 the field
-// quotient is below 2^72 exactly when pos - sub is a non-negative integer multiple of 2^128 with a quotient below 2^72
-// (r * 2^128 < 2^200 < p pins (pos - sub) mod p = r * 2^128; a negative difference would need sub > p - 2^200): the
-// integer shift gives the same value then, and any other numerator only has to fail the range check like the field
-// quotient does.  No Montgomery product on the way.
-ZK_HD Fr div_2p128_for_range9(const Fr& pos, const Fr& sub) {
-    if ((sub.v[7] | (sub.v[6] >> 8)) != 0u) return fr_mulc(fr_sub(pos, sub), frm_inv_2p128());
-    Fr n;
-    const u32 bw = u256_sub(n, pos, sub);
-    const bool exact = !bw && (n.v[0] | n.v[1] | n.v[2] | n.v[3]) == 0u;
-    Fr r = fr_zero();
-    r.v[0] = n.v[4]; r.v[1] = n.v[5]; r.v[2] = n.v[6]; r.v[3] = n.v[7];
-    if (!exact) r.v[7] = 0x20000000u;
-    return r;
-}
 ZK_HD Fr mul_add_words(Ins& I, const Word& a, const Word& b, const Word& c, const Word& d) {
     Limbs64 a64 = to_64s(I, a);
     Limbs64 b64 = to_64s(I, b);

@@ -25,6 +25,7 @@ struct BytecodeArgs {
     ZkCols rows;
     ZkTable keccak;
     Fr r;  // keccak randomness (canonical)
+    const u64* r_mont;  // optional: the same in Montgomery form, computed once per session (one product per row instead of two)
 };
 
 
@@ -91,7 +92,7 @@ ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
                 RC_ASSERT(fr_eq(zk_col(w, BC_LENGTH, in), length), 13);
                 RC_ASSERT(fr_eq(zk_col(w, BC_INDEX, in), fr_add_u64(index, 1)), 14);
                 RC_ASSERT(fr_eq(zk_col(w, BC_HASH_LO, in), hash_lo) && fr_eq(zk_col(w, BC_HASH_HI, in), hash_hi), 15);
-                const Fr want_rlc = fr_add(fr_mul(value_rlc, a.r), zk_col(w, BC_VALUE, in));
+                const Fr want_rlc = fr_add(a.r_mont ? fr_mulc(value_rlc, fr_load(a.r_mont)) : fr_mul(value_rlc, a.r), zk_col(w, BC_VALUE, in));
                 RC_ASSERT(fr_eq(zk_col(w, BC_VALUE_RLC, in), want_rlc), 16);
                 const Fr nleft = zk_col(w, BC_PUSH_LEFT, in);
                 if (fr_eq_u64(is_code, 1)) RC_ASSERT(fr_eq(nleft, push_size), 17);
@@ -175,8 +176,9 @@ ZK_HD void ex_mul_add_carries(const ExWord& a, const ExWord& b, const ExWord& c,
     ex_acc_mul64(mid, a64[1], b64[2], 1);
     ex_acc_mul64(mid, a64[2], b64[1], 1);
     ex_acc_mul64(mid, a64[3], b64[0], 1);
-    carry_lo = fr_mulc(fr_sub(fr_add(lo, c.lo), d.lo), frm_inv_2p128());
-    carry_hi = fr_mulc(fr_sub(fr_add(fr_add(mid, c.hi), carry_lo), d.hi), frm_inv_2p128());
+    // both carries only go into nine-byte range checks: integer shift instead of a Montgomery product (common.hpp)
+    carry_lo = div_2p128_for_range9(fr_add(lo, c.lo), d.lo);
+    carry_hi = div_2p128_for_range9(fr_add(fr_add(mid, c.hi), carry_lo), d.hi);
 }
 
 #define EX_FAIL(kind, site) code = (code == 0u) ? ZK_CODE(kind, site) : code
@@ -210,10 +212,10 @@ ZK_HD u32 exp_check_row(const ExpArgs& a, u64 i) {
     }
     // every step (:27-52); constrain_bool: cond * value in {0, 1}
     {
-        const Fr p1 = fr_mul(is_step, is_last);
-        RC_ASSERT(fr_le_u64(p1, 1), 4);
-        const Fr p2 = fr_mul(is_step, r);
-        RC_ASSERT(fr_le_u64(p2, 1), 5);
+        // cond * value in {0, 1}: trivially so when both factors are 0 / 1 (the usual case), else the field product decides
+        const bool step01 = fr_le_u64(is_step, 1);
+        RC_ASSERT((step01 && fr_le_u64(is_last, 1)) || fr_le_u64(fr_mul(is_step, is_last), 1), 4);
+        RC_ASSERT((step01 && fr_le_u64(r, 1)) || fr_le_u64(fr_mul(is_step, r), 1), 5);
         if (!fr_fits128(A.lo) || !fr_fits128(A.hi)) EX_FAIL(ZK_OVERFLOW_ERROR, 6);  // a.to_64s()
         if (!fr_fits128(B.lo) || !fr_fits128(B.hi)) EX_FAIL(ZK_OVERFLOW_ERROR, 7);  // b.to_64s()
         Fr clo, chi;

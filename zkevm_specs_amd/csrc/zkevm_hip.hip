@@ -287,6 +287,12 @@ __global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t*
 // Bytecode / Exp circuit kernels: one lane per row, column-major witness (coalesced), next row
 // re-read through L1/L2 (wraps modulo n).
 // ---------------------------------------------------------------------------------------
+__global__ void fr_to_mont_kernel(Fr x, u64* out) {  // one cell to Montgomery form (per-session constants)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const Fr m = fr_to_mont(x);
+        for (int j = 0; j < 4; j++) out[j] = (u64)m.v[2 * j] | ((u64)m.v[2 * j + 1] << 32);
+    }
+}
 __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
@@ -842,6 +848,12 @@ extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t
         memcpy(rh, randomness, 32);
     }
     for (int k = 0; k < 4; k++) { s->bytecode.r.v[2 * k] = (u32)rh[k]; s->bytecode.r.v[2 * k + 1] = (u32)(rh[k] >> 32); }
+    {
+        u64* d_rm = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_rm, 32))) goto fail;
+        hipLaunchKernelGGL(fr_to_mont_kernel, dim3(1), dim3(64), 0, g_stream, s->bytecode.r, d_rm);
+        s->bytecode.r_mont = d_rm;
+    }
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
