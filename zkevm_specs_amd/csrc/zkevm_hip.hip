@@ -1,5 +1,6 @@
 // libzkevm_hip.so — HIP kernels (gfx950) + C ABI (include/zkevm_hip.h).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -1397,7 +1398,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     if (!(s->kind == SESSION_EVM && s->evm.perm))
         hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
     u32* status = status_dev ? status_dev : s->d_status;
-    if (timed) HIP_TRY(hipEventRecord(e0, g_stream));
+    // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
+    // no separate event packets between the sort passes and the evaluation kernels
+    const bool evm_ext_events = timed && s->kind == SESSION_EVM && s->evm.perm;
+    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, g_stream));
     switch (s->kind) {
     case SESSION_STATE: {
         const int block = 256;
@@ -1462,17 +1466,25 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     }
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
-        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed) HIP_TRY(hipEventRecord(e0, g_stream)); }
+        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, g_stream)); }
         const int block = 256;
         const u32 grid = (u32)((s->n + block - 1) / block);
-        // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        // the rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(s->evm.perm ? (grid < 256u ? grid : 256u) : grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        const u32 cold_grid = s->evm.perm ? (grid < 256u ? grid : 256u) : grid;
+        // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first); then the
+        // rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces
+        if (evm_ext_events) {
+            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, e0, nullptr, 0,
+                                  s->evm, (const u32*)s->d_group_start, status, s->d_tally);
+            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(cold_grid), dim3(block), 0, g_stream, nullptr, e1, 0,
+                                  s->evm, (const u32*)s->d_group_start, status, s->d_tally);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(cold_grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
+        }
         break;
     }
     }
-    if (timed) HIP_TRY(hipEventRecord(e1, g_stream));
+    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e1, g_stream));
     HIP_TRY(hipGetLastError());
     s->launches++;
     return 0;
