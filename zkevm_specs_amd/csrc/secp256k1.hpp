@@ -6,16 +6,17 @@
 // The arithmetic lives in third-party eth-keys 0.4.0 (setup.cfg:24; not under /root/reference): its native backend's
 // `ecdsa_raw_verify` — w = s^-1 mod N, u1 = z w, u2 = r w, R = u1 G + u2 Q, accept iff R != O and R.x mod N == r —
 // with `Signature` rejecting v outside {0, 1} and r, s outside [0, N) (BadSignature), restated by
-// oracle/ecdsa_oracle.py.  The scalar multiplications are the same LSB-first double-and-add and the point
-// addition makes the same case analysis as the affine formulas there (x1 == x2: y1 + y2 == 0 -> O, else the
-// tangent at p1), so that the verdict also agrees for public keys that are not on the curve (the group-law
-// formulas never use b).
+// oracle/ecdsa_oracle.py.  u2 * Q is the same LSB-first double-and-add and the point addition makes the same case
+// analysis as the affine formulas there (x1 == x2: y1 + y2 == 0 -> O, else the tangent at p1), so that the verdict
+// also agrees for public keys that are not on the curve (the group-law formulas never use b); u1 * G (G is on the
+// curve: any correct method yields the same point) uses a fixed-base table of 64 four-bit windows.
 //
 // Field elements: 8 x u32 limbs, Montgomery form (R = 2^256) for both the base field P and the scalar field N;
 // points: Jacobian (X, Y, Z) over P with an explicit infinity flag.
 #pragma once
 #include "common.hpp"
 #include "secp_constants.h"
+#include "secp_g_table.h"
 
 #if defined(ZK_HOSTSIM)
 #define SP_MEMBER static inline
@@ -174,6 +175,50 @@ ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q, u32& value_error) {
     r.inf = 0;
     return r;
 }
+// p + (x2, y2): Jacobian + affine (Montgomery form), the fixed-base table's addition ("madd-2007-bl" without the
+// doubling tricks: 8M + 3S).  Same case analysis as sp_add_points.
+ZK_NOINLINE SpPoint sp_add_affine(SpPoint p, Fr x2, Fr y2) {
+    typedef SecpP F;
+    if (p.inf) {
+        SpPoint r;
+        r.X = x2; r.Y = y2; r.Z = F::one(); r.inf = 0;
+        return r;
+    }
+    const Fr z1z1 = sp_mont<F>(p.Z, p.Z);
+    const Fr u2 = sp_mont<F>(x2, z1z1), s2 = sp_mont<F>(sp_mont<F>(y2, p.Z), z1z1);
+    if (fr_eq(p.X, u2)) {
+        if (fr_is_zero(sp_add<F>(p.Y, s2))) return sp_infinity();
+        return sp_dbl(p);
+    }
+    const Fr h = sp_sub<F>(u2, p.X), rr = sp_sub<F>(s2, p.Y);
+    const Fr hh = sp_mont<F>(h, h), hhh = sp_mont<F>(h, hh), v = sp_mont<F>(p.X, hh);
+    SpPoint r;
+    r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
+    r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(p.Y, hhh));
+    r.Z = sp_mont<F>(p.Z, h);
+    r.inf = 0;
+    return r;
+}
+// k * G, k < N: sixty-four 4-bit windows over the precomputed multiples d * 16^j * G (secp_g_table.h) — 64 mixed additions
+// instead of 256 doublings + ~128 additions.  G is on the curve, so this is the same group element the LSB-first
+// double-and-add of the restated algorithm produces.
+ZK_NOINLINE SpPoint sp_scalar_mul_g(Fr k) {
+    SpPoint acc = sp_infinity();
+    for (int j = 0; j < 64; j++) {
+        const u32 d = k.v[0] & 15u;
+        if (d) {
+            const uint32_t* e = secp_g_table[15 * j + (int)d - 1];
+            Fr x, y;
+#pragma unroll
+            for (int q = 0; q < 8; q++) { x.v[q] = e[q]; y.v[q] = e[8 + q]; }
+            acc = sp_add_affine(acc, x, y);
+        }
+#pragma unroll
+        for (int q = 0; q < 7; q++) k.v[q] = (k.v[q] >> 4) | (k.v[q + 1] << 28);
+        k.v[7] >>= 4;
+    }
+    return acc;
+}
 // k * pt, k < N canonical: acc += pt for every set bit from the least significant one, pt doubling in between
 ZK_NOINLINE SpPoint sp_scalar_mul(SpPoint pt, Fr k) {
     SpPoint acc = sp_infinity();
@@ -237,10 +282,9 @@ ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i) {
     const Fr wM = sp_inv<SecpN>(sp_to_mont<SecpN>(s));
     const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
     const Fr u2 = sp_mont<SecpN>(r, wM);
-    SpPoint g, q;
-    g.X = secp_gx_m(); g.Y = secp_gy_m(); g.Z = SecpP::one(); g.inf = 0;
+    SpPoint q;
     q.X = sp_to_mont<SecpP>(pkx); q.Y = sp_to_mont<SecpP>(pky); q.Z = SecpP::one(); q.inf = 0;
-    const SpPoint A = sp_scalar_mul(g, u1);
+    const SpPoint A = sp_scalar_mul_g(u1);
     const SpPoint B = sp_scalar_mul(q, u2);
     u32 ve = 0;
     const SpPoint C = sp_add_points(A, B, ve);
