@@ -2119,7 +2119,8 @@ ZK_HD void g_gas(Ins& I, Tail& T) {  // gas.py
 }
 ZK_HD void g_msize(Ins& I, Tail& T) {  // msize.py
     Fr opcode; opcode = opcode_lookup(I, true);
-    g_push_lo(I, T, opcode, fr_mulc(ev_curr(I, S_MWS), fr_to_mont(fr_u(32))));
+    const Fr mws = ev_curr(I, S_MWS);
+    g_push_lo(I, T, opcode, fr_fits32(mws) ? fr_u((u64)mws.v[0] * 32ull) : fr_mulc(mws, fr_to_mont(fr_u(32))));
 }
 ZK_HD void g_codesize(Ins& I, Tail& T) {  // codesize.py
     Fr opcode; opcode = opcode_lookup(I, true);
