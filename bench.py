@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="evm", choices=["evm", "state", "super"])
+    ap.add_argument("--workload", default="evm", choices=["evm", "state", "super", "tx"])
     ap.add_argument("--log-rows", type=int, default=None, help="log2 rows per GPU (default: 18 evm, 16 state, 20 super)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
@@ -52,7 +52,7 @@ def main():
 
     from zkevm_specs_amd import _lib, engine
 
-    log_rows = args.log_rows if args.log_rows is not None else {"evm": 18, "state": 16, "super": 20}[args.workload]
+    log_rows = args.log_rows if args.log_rows is not None else {"evm": 18, "state": 16, "super": 20, "tx": 14}[args.workload]
     n = 1 << log_rows
     to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
     _lib.init(local_rank)
@@ -70,6 +70,42 @@ def main():
         workload = (f"EVM circuit, 2^{log_rows} execution steps per GPU, mixed-opcode synthetic trace "
                     f"(BASELINE configs[2]); RW table {meta['n_rw']} rows, bytecode table {meta['n_bytecode']} rows")
         extra_cfg = {"steps_per_gpu": n, "rw_rows": meta["n_rw"], "bytecode_rows": meta["n_bytecode"]}
+    elif args.workload == "tx":
+        # BASELINE configs[3]: Tx circuit over 2^log_rows signed synthetic txs per GPU; a pass = secp256k1 ECDSA verification of
+        # every signature (fills the units' ecdsa_status column in HBM) + the SignVerify / copy-constraint kernel.  The public-key
+        # hashes are keccak-256 digests built by the device table builder once per witness.
+        from zkevm_specs_amd.synth import device_keccak_digests, synth_tx_witness
+
+        r_tx = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221 + rank
+        w_tx = synth_tx_witness(n, r_tx, seed=4 + rank, signed=True, digests_of=device_keccak_digests(r_tx))
+        d_tx = {k: to_dev(v) if v.dtype != np.uint8 else torch.from_numpy(v).cuda() for k, v in w_tx.items()}
+
+        class _TxPass:
+            def __init__(self):
+                self.ecdsa = engine.open_ecdsa(d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4,
+                                               device=local_rank)
+                self.sign = engine.open_sign(d_tx, r_tx, False, device=local_rank)
+
+            def launch(self):
+                self.ecdsa.launch()
+                self.sign.launch()
+
+            def collect(self):
+                re_, rs_ = self.ecdsa.collect(), self.sign.collect()
+                rs_.ecdsa_ms = re_.kernel_ms
+                rs_.fail_count += 0 if re_.ok else 0  # a signature that does not verify fails its unit in the Tx kernel already
+                return rs_
+
+            def close(self):
+                self.ecdsa.close()
+                self.sign.close()
+
+        sess = _TxPass()
+        units = n
+        algo_bytes = n * (8 * 32 + 288 + 2 * 5 * 32)
+        kernel_name = "sign_units_kernel"
+        workload = (f"Tx circuit, 2^{log_rows} signed synthetic txs per GPU (BASELINE configs[3]): ECDSA verification + SignVerify kernel per pass")
+        extra_cfg = {"txs_per_gpu": n}
     elif args.workload == "super":
         # BASELINE configs[4]: EVM + State + Bytecode + Tx kernels over one witness set of 2^log_rows rows per GPU
         from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super
@@ -135,7 +171,7 @@ def main():
     # witness, so page-table lines and part of the rows are still in L2 / Infinity Cache from the previous pass; a
     # fresh witness is evaluated once.  Here every pass is preceded by a read-only stream over 2 GiB of unrelated data.
     cold_ms = None
-    if not args.no_cold_leg and args.workload != "super":
+    if not args.no_cold_leg and args.workload not in ("super", "tx"):
         flush = torch.zeros(1 << 29, dtype=torch.int32, device="cuda")
         for _ in range(8):
             flush.sum()
@@ -193,7 +229,13 @@ def main():
         }
         if per_circuit is not None:
             out["roofline"]["per_circuit"] = per_circuit
-        if not args.no_cpu_baseline and args.workload == "super":
+        if args.workload == "tx":
+            out["roofline"]["ecdsa_verify_kernel_ms"] = res.ecdsa_ms
+            out["roofline"]["note"] = ("the pass is dominated by ecdsa_verify_kernel (integer-ALU bound, no HBM roofline); the roofline block "
+                                       "describes the SignVerify kernel")
+        if args.workload == "tx":
+            pass  # no CPU leg: the oracle's ECDSA is test infrastructure sized for a few hundred signatures
+        elif not args.no_cpu_baseline and args.workload == "super":
             from oracle import evm_oracle, state_oracle, assign_oracle, wire
 
             ne = min(sess.rows["evm"], 1 << 15)

@@ -131,8 +131,15 @@ def test_config4_signed_txs_end_to_end_on_device():
 
     from zkevm_specs_amd import engine
 
+    from zkevm_specs_amd.synth import device_keccak_digests
+
     n, r = 1 << 14, 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
-    w = synth_tx_witness(n, r, seed=4, signed=True)
+    # public-key hashes: keccak-256 through the device table builder, so nothing of the unit is a host-computed stand-in
+    w = synth_tx_witness(n, r, seed=4, signed=True, digests_of=device_keccak_digests(r))
+    from oracle import keccak as K
+    for i in (0, 5000, n - 1):
+        pk = bytes(w["bytes"][i, 0][::-1].tolist()) + bytes(w["bytes"][i, 1][::-1].tolist())
+        assert bytes(w["bytes"][i, 6].tolist()) == K.keccak256(pk)
     assert (w["meta"][:, 0] == ECDSA_STATUS_PENDING).all()
     w["bytes"][777, 8, 0] ^= 1  # forge s of tx 777
     dev = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v.view(np.int32) if v.dtype == np.uint32 else v).cuda()

@@ -435,16 +435,30 @@ def synth_signatures(n, seed):
     return out
 
 
+def device_keccak_digests(r):
+    """digests_of for synth_tx_witness: keccak-256 of the public keys through the device table builder (zk_keccak_table,
+    mode 1 = KeccakTable.add rows: output Word(digest bytes), lo = bytes 0..15 little-endian)"""
+    def digests(messages):
+        from . import engine
+
+        rows = engine.keccak_table(messages, r, engine.KECCAK_MODE_TABLE)
+        return [rows[i, 3].tobytes()[:16] + rows[i, 4].tobytes()[:16] for i in range(len(messages))]
+
+    return digests
+
+
 ECDSA_STATUS_PENDING = 0xFFFFFFFF  # meta[:, 0] placeholder: the Tx kernel fails every unit until the ECDSA pass filled it
 
 
-def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False):
+def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False, digests_of=None):
     """n_txs transaction slots (+ `padding` zero slots) for the Tx circuit's SignVerify path: 64-byte public
     keys, a synthetic 32-byte digest as pub_key_hash (the circuit checks keccak-table membership of
     (RLC(pk), 64, hash), not the hash function), address = low 20 bytes, message hashes.
     signed=False: random bytes as keys, ecdsa_status = 0 (the secp256k1 verdict as a pre-computed input column).
     signed=True: real key pairs and valid signatures (byte rows 7, 8 = r, s); ecdsa_status is left PENDING for the
     device ECDSA pass (engine.open_ecdsa(..., layout=ECDSA_LAYOUT_TX_UNITS, out_dev=meta, out_stride=4)).
+    digests_of (signed=True only): callable(list of 64-byte public keys, big-endian x || y) -> list of 32-byte digests,
+    e.g. keccak-256 through the device table builder (device_keccak_digests below); default: a synthetic digest.
     Returns the wire dict."""
     import hashlib
     import random
@@ -455,6 +469,10 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False):
     bts, cells, meta, rows, flags = [], [], [], [], []
     keccak = {(0, 0, 0, 0, 0)}
     sigs = synth_signatures(n_txs + 1, seed) if signed else None  # the last one: the padding slots' dummy (tx_circuit.py:463-475)
+    real = None
+    if digests_of is not None:
+        assert signed, "digests_of needs the key pairs up front (signed=True)"
+        real = digests_of([sigs[i][0].to_bytes(32, "big") + sigs[i][1].to_bytes(32, "big") for i in range(n_txs)])
     for i in range(n_txs + padding):
         sig_r = sig_s = bytes(32)
         if i < n_txs:
@@ -467,7 +485,7 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False):
                 pk_x = bytes(rng.getrandbits(8) for _ in range(32))  # little-endian limbs, as in the chip
                 pk_y = bytes(rng.getrandbits(8) for _ in range(32))
                 msg = bytes(rng.getrandbits(8) for _ in range(32))
-            h = hashlib.blake2b(pk_x + pk_y, digest_size=32).digest()
+            h = real[i] if real is not None else hashlib.blake2b(pk_x + pk_y, digest_size=32).digest()
             acc = 0
             for b in reversed(pk_y + pk_x):
                 acc = (acc * r + b) % _FR_P
