@@ -354,3 +354,15 @@ extern "C" int sim_bytecode_assign(const u64* in_rows, u64 n_rows, const u64* of
     for (u64 i = 0; i < a.n_out; i++) bca_write_row(a, i);
     return 0;
 }
+// secp256k1 field products (unit-test hook): which = 0 base field (plain residues), 1 scalar field (Montgomery product)
+extern "C" void sim_secp_mul(int which, const u64* a, const u64* b, u64* out, u64 n) {
+    for (u64 i = 0; i < n; i++) {
+        Fr x, y;
+        for (int q = 0; q < 4; q++) {
+            x.v[2 * q] = (u32)a[4 * i + q]; x.v[2 * q + 1] = (u32)(a[4 * i + q] >> 32);
+            y.v[2 * q] = (u32)b[4 * i + q]; y.v[2 * q + 1] = (u32)(b[4 * i + q] >> 32);
+        }
+        const Fr r = which == 0 ? sp_mont<SecpP>(x, y) : sp_mont<SecpN>(x, y);
+        for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)r.v[2 * q] | ((u64)r.v[2 * q + 1] << 32);
+    }
+}

@@ -66,6 +66,28 @@ def _hostile_cases(seed, n):
     return E.pack(cases), np.array(vs, dtype=np.uint32)
 
 
+def test_field_products_known_answers(hostsim):
+    """the folded product mod P = 2^256 - 2^32 - 977 (carry-out and final-subtraction paths included) and the Montgomery
+    product mod N against Python integers"""
+    import random
+
+    from oracle import wire
+
+    rng = random.Random(1)
+    for which, m in ((0, E.P), (1, E.N)):
+        edge = [0, 1, 2, m - 1, m - 2, 977, 2**32 + 977, 2**255, 2**128 - 1, 2**128, m >> 1, (1 << 256) - (1 << 224) - 1, 2**32 - 1,
+                2**224 - 1, m - 2**32, m - 978]
+        edge = [e % m for e in edge]
+        pairs = [(a, b) for a in edge for b in edge] + [(rng.randrange(m), rng.randrange(m)) for _ in range(3000)]
+        a = wire.ints_to_cells([x for x, _ in pairs])
+        b = wire.ints_to_cells([y for _, y in pairs])
+        out = np.zeros_like(a)
+        hostsim.sim_secp_mul(ctypes.c_int(which), vp(a), vp(b), vp(out), ctypes.c_uint64(len(pairs)))
+        rinv = pow(1 << 256, -1, m)
+        exp = [x * y % m if which == 0 else x * y * rinv % m for x, y in pairs]
+        assert wire.cells_to_ints(out) == exp, which
+
+
 def test_oracle_matches_reference_chips(golden_dir):
     g = np.load(os.path.join(golden_dir, "ecdsa_cases.npz"))
     assert _same(E.verify_packed(g["sigs"], g["v"]), g["util_status"].tolist())   # util/ec.py:109-117, Signature(vrs=[v, r, s])

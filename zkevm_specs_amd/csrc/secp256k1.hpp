@@ -11,7 +11,8 @@
 // also agrees for public keys that are not on the curve (the group-law formulas never use b); u1 * G (G is on the
 // curve: any correct method yields the same point) uses a fixed-base table of 64 four-bit windows.
 //
-// Field elements: 8 x u32 limbs, Montgomery form (R = 2^256) for both the base field P and the scalar field N;
+// Field elements: 8 x u32 limbs; the scalar field N in Montgomery form (R = 2^256), the base field P as plain residues
+// (its special form makes the folded product cheaper than a Montgomery one);
 // points: Jacobian (X, Y, Z) over P with an explicit infinity flag.
 #pragma once
 #include "common.hpp"
@@ -25,19 +26,82 @@
 #endif
 #define SP_CONST(name, limbs) SP_MEMBER Fr name() { Fr r = {limbs}; return r; }
 struct SecpP {
+    static constexpr bool plain = true;  // P = 2^256 - 2^32 - 977: plain residues, products folded with 2^32 + 977
     static constexpr u32 inv32 = SECP_P_INV32;
     SP_CONST(mod, SECP_P_LIMBS) SP_CONST(one, SECP_P_ONE_LIMBS) SP_CONST(r2, SECP_P_R2_LIMBS) SP_CONST(m2, SECP_P_M2_LIMBS)
 };
 struct SecpN {
+    static constexpr bool plain = false;  // Montgomery form, R = 2^256
     static constexpr u32 inv32 = SECP_N_INV32;
     SP_CONST(mod, SECP_N_LIMBS) SP_CONST(one, SECP_N_ONE_LIMBS) SP_CONST(r2, SECP_N_R2_LIMBS) SP_CONST(m2, SECP_N_M2_LIMBS)
 };
 FR_CONST_ARR(secp_gx_m, SECP_GX_M_LIMBS)
 FR_CONST_ARR(secp_gy_m, SECP_GY_M_LIMBS)
 
-// Montgomery product a*b*R^-1 mod m (CIOS); a, b < m; result < m.
+// a * b mod P for P = 2^256 - 2^32 - 977 (plain residues, a, b < P, result < P): 8 x 8 schoolbook product, then the high
+// half is folded twice with 2^256 = 2^32 + 977 (mod P) — 72 multiply-adds instead of the 128 of a Montgomery product
+ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
+    u32 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+        const u32 bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * bi + t[i + j];
+            t[i + j] = (u32)c;
+            c >>= 32;
+        }
+        t[i + 8] = (u32)c;
+    }
+    // r = lo + hi * 977 + (hi << 32): ten limbs, r[9] <= 1
+    u32 r[10];
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        c += (u64)t[k] + (u64)t[8 + k] * 977ull + (k > 0 ? (u64)t[8 + k - 1] : 0ull);
+        r[k] = (u32)c;
+        c >>= 32;
+    }
+    c += t[15];
+    r[8] = (u32)c;
+    r[9] = (u32)(c >> 32);
+    // second fold: v = r[8..9] < 2^33, v * (2^32 + 977) < 2^67
+    const u64 v = (u64)r[8] | ((u64)r[9] << 32);
+    const u64 m977 = v * 977ull;
+    Fr s;
+    c = (u64)r[0] + (u32)m977;
+    s.v[0] = (u32)c; c >>= 32;
+    c += (u64)r[1] + (m977 >> 32) + (u32)v;
+    s.v[1] = (u32)c; c >>= 32;
+    c += (u64)r[2] + (v >> 32);
+    s.v[2] = (u32)c; c >>= 32;
+#pragma unroll
+    for (int k = 3; k < 8; k++) {
+        c += r[k];
+        s.v[k] = (u32)c;
+        c >>= 32;
+    }
+    if (c) {  // wrapped past 2^256 (s is tiny then): once more + (2^32 + 977), no further carry
+        u64 d = (u64)s.v[0] + 977ull;
+        s.v[0] = (u32)d; d >>= 32;
+        d += (u64)s.v[1] + 1ull;
+        s.v[1] = (u32)d; d >>= 32;
+#pragma unroll
+        for (int k = 2; k < 8; k++) { d += s.v[k]; s.v[k] = (u32)d; d >>= 32; }
+    }
+    Fr q;
+    const u32 bw = u256_sub(q, s, SecpP::mod());
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = bw ? s.v[i] : q.v[i];
+    return s;
+}
+// Montgomery product a*b*R^-1 mod m (CIOS); a, b < m; result < m.  (Base field: the plain product above.)
 template <class M>
 ZK_NOINLINE Fr sp_mont(Fr a, Fr b) {
+    if constexpr (M::plain) return sp_mul_p(a, b);
     const Fr m = M::mod();
     u32 t[10];
 #pragma unroll
@@ -124,7 +188,7 @@ ZK_NOINLINE Fr sp_inv(Fr aM) {
 }
 
 struct SpPoint {
-    Fr X, Y, Z;  // Montgomery form mod P
+    Fr X, Y, Z;  // residues mod P
     u32 inf;
 };
 ZK_HD SpPoint sp_infinity() {
