@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wide differential fuzz of the HIP EVM path against the oracle (GPU box): every golden case, N fuzzed variants each,
 biased towards the step cells (the LDS-staged pair and the 64-bit transition tail are GPU-only code).
-usage: python tools/gpu_fuzz_evm.py [N=20] [seed=1]"""
+usage: python tests/gpu_fuzz_evm.py [N=20] [seed=1]"""
 import os
 import random
 import sys
