@@ -3871,8 +3871,27 @@ ZK_HD int evm_state_group(u32 state) {
     default: return EVM_GROUP_LIGHT;
     }
 }
-// sort bin of a state: group-major, state-minor (128 bins per group)
-ZK_HD u32 evm_state_bin(u32 state) { return (u32)evm_state_group(state) * 128u + (state & 127u); }
+// sort bin of a state: group-major (128 bins per group); inside a group the states whose wavefronts run longest come first
+// (measured per-wavefront times, tools/evm_phase_prof.py), so that the kernel's tail is made of the short ones — a
+// longest-processing-time-first schedule over the 2 x 1024 wavefront slots
+ZK_HD u32 evm_state_bin(u32 state) {
+    u32 key = (state & 127u) + 16u;  // ES_COUNT = 95: below 127 for every real state;
+    if (key > 126u) key = 126u;      // arbitrary cell values (malformed witnesses) must stay inside the group's 128 bins
+    switch (state) {
+    case ES_PUSH: case ES_ADDMOD: case ES_MEMORY: key = 0; break;
+    case ES_BITWISE: case ES_MULMOD: case ES_SLOAD: key = 1; break;
+    case ES_CMP: case ES_MUL: case ES_SSTORE: key = 2; break;
+    case ES_SCMP: case ES_SHL_SHR: key = 3; break;
+    case ES_ADD: key = 4; break;
+    case ES_BYTE: key = 5; break;
+    case ES_SIGNEXTEND: key = 6; break;
+    case ES_NOT: key = 7; break;
+    case ES_ISZERO: key = 8; break;
+    case ES_POP: case ES_STOP: key = 127; break;
+    default: break;
+    }
+    return (u32)evm_state_group(state) * 128u + key;
+}
 #define EVM_N_BINS (EVM_N_GROUPS * 128)
 
 // verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
