@@ -3871,26 +3871,35 @@ ZK_HD int evm_state_group(u32 state) {
     default: return EVM_GROUP_LIGHT;
     }
 }
-// sort bin of a state: group-major (128 bins per group); inside a group the states whose wavefronts run longest come first
-// (measured per-wavefront times, tools/evm_phase_prof.py), so that the kernel's tail is made of the short ones — a
-// longest-processing-time-first schedule over the 2 x 1024 wavefront slots
+// sort bin of a state.  The cold states keep their own 128 bins at the end (the cold kernel's lane range starts at
+// group_start[EVM_GROUP_COLD]); the hot kernel evaluates every other state, so the first 384 bins are ONE list ordered by
+// measured wavefront time, longest first (tools/evm_phase_prof.py): a longest-processing-time-first schedule over the
+// 2 x 1024 wavefront slots, with the short POP / STOP wavefronts making the kernel's tail.
 ZK_HD u32 evm_state_bin(u32 state) {
-    u32 key = (state & 127u) + 16u;  // ES_COUNT = 95: below 127 for every real state;
-    if (key > 126u) key = 126u;      // arbitrary cell values (malformed witnesses) must stay inside the group's 128 bins
+    if (evm_state_group(state) == EVM_GROUP_COLD) return (u32)EVM_GROUP_COLD * 128u + (state & 127u);
+    u32 key = (state & 127u) + 32u;  // everything not listed below, in state order (arbitrary cell values stay below 384)
     switch (state) {
-    case ES_PUSH: case ES_ADDMOD: case ES_MEMORY: key = 0; break;
-    case ES_BITWISE: case ES_MULMOD: case ES_SLOAD: key = 1; break;
-    case ES_CMP: case ES_MUL: case ES_SSTORE: key = 2; break;
-    case ES_SCMP: case ES_SHL_SHR: key = 3; break;
-    case ES_ADD: key = 4; break;
-    case ES_BYTE: key = 5; break;
-    case ES_SIGNEXTEND: key = 6; break;
-    case ES_NOT: key = 7; break;
-    case ES_ISZERO: key = 8; break;
-    case ES_POP: case ES_STOP: key = 127; break;
+    case ES_STOP: key = 0; break;  // non-root STOP restores the caller's context: a dozen lookups, the longest wavefronts
+    case ES_ADDMOD: key = 1; break;
+    case ES_MULMOD: key = 2; break;
+    case ES_MEMORY: key = 3; break;
+    case ES_SSTORE: key = 4; break;
+    case ES_SLOAD: key = 5; break;
+    case ES_MUL: key = 6; break;
+    case ES_SHL_SHR: key = 7; break;
+    case ES_PUSH: key = 8; break;
+    case ES_BITWISE: key = 9; break;
+    case ES_CMP: key = 10; break;
+    case ES_SCMP: key = 11; break;
+    case ES_ADD: key = 12; break;
+    case ES_BYTE: key = 13; break;
+    case ES_SIGNEXTEND: key = 14; break;
+    case ES_NOT: key = 15; break;
+    case ES_ISZERO: key = 16; break;
+    case ES_POP: key = 383; break;
     default: break;
     }
-    return (u32)evm_state_group(state) * 128u + key;
+    return key;
 }
 #define EVM_N_BINS (EVM_N_GROUPS * 128)
 
