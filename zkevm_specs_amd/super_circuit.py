@@ -126,20 +126,46 @@ class SuperCircuit:
             "tx": engine.open_sign({k: dev(v) for k, v in tx.items()}, r_tx, False, device=device),
         }
         self.rows = {k: s.n for k, s in self.sessions.items()}
+        # one HIP stream per circuit: the kernels are independent and bound by different things (the State kernel streams
+        # HBM, the EVM kernel is latency / issue bound), so their passes overlap on the device
+        self._streams = None
+        if hasattr(ops, "is_cuda"):
+            import torch
+
+            self._main = torch.cuda.current_stream().cuda_stream
+            self._streams = {k: torch.cuda.Stream() for k in self.sessions}
+
+    def _on(self, k):
+        if self._streams is not None:
+            from . import _lib
+            _lib.check(_lib.load().zk_set_stream(self._streams[k].cuda_stream), "zk_set_stream")
+
+    def _back(self):
+        if self._streams is not None:
+            from . import _lib
+            _lib.check(_lib.load().zk_set_stream(self._main), "zk_set_stream")
 
     def launch(self):
-        for s in self.sessions.values():
+        for k, s in self.sessions.items():
+            self._on(k)
             s.launch()
+        self._back()
 
     def collect(self):
-        results = {k: s.collect() for k, s in self.sessions.items()}
+        results = {}
+        for k, s in self.sessions.items():
+            self._on(k)
+            results[k] = s.collect()
+        self._back()
         total = sum(r.fail_count for r in results.values())
         first = next(((k, r.first_fail_row, r.first_fail_code) for k, r in results.items() if not r.ok), None)
         return results, total, first
 
     def close(self):
-        for s in self.sessions.values():
+        for k, s in self.sessions.items():
+            self._on(k)
             s.close()
+        self._back()
 
     def __enter__(self):
         return self
