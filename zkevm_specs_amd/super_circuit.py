@@ -134,6 +134,7 @@ class SuperCircuit:
 
             self._main = torch.cuda.current_stream().cuda_stream
             self._streams = {k: torch.cuda.Stream() for k in self.sessions}
+            torch.cuda.synchronize()  # witness uploads / open-time packing ran on the main stream
 
     def _on(self, k):
         if self._streams is not None:
