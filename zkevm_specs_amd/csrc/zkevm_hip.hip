@@ -77,9 +77,20 @@ extern "C" int zk_set_stream(void* s) {
 // tally + index kernels
 // ---------------------------------------------------------------------------------------
 __global__ void tally_reset_kernel(ZkTally* t) {
-    t->fail_count = 0ull;
-    t->first_fail = ~0ull;
+    t[threadIdx.x].fail_count = 0ull;
+    t[threadIdx.x].first_fail = ~0ull;
 }
+// The single-kernel row sessions keep two tallies and alternate between them: a pass accumulates into one and its first
+// lane clears the other for the pass after it, so that no reset kernel sits in front of every evaluation kernel (a kernel
+// boundary costs ~10 us of the 77 us State pass at 2^16 rows).  `tally` and its twin are 16 B apart in one 32 B-aligned block.
+__device__ __forceinline__ void tally_clear_twin(ZkTally* tally) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ZkTally* twin = (ZkTally*)((uintptr_t)tally ^ (uintptr_t)sizeof(ZkTally));
+        twin->fail_count = 0ull;
+        twin->first_fail = ~0ull;
+    }
+}
+static_assert(sizeof(ZkTally) == 16, "tally_clear_twin assumes 16-byte tallies");
 
 // One wave-level ballot, then at most one counter atomic per wave and one atomicMin per
 // failing lane (failures are rare on real witnesses; the hot path issues no atomics at all).
@@ -117,6 +128,7 @@ __global__ void index_build_kernel(ZkTable t, u32* slots) {
 #define ZK_STATE_OCC 2  // waves per SIMD the State kernel is compiled for (3 was measured: 168 VGPRs + 32 B scratch, 2^20 rows 0.423 vs 0.404 ms)
 #endif
 __global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;  // first row this wavefront evaluates
@@ -295,6 +307,7 @@ __global__ void fr_to_mont_kernel(Fr x, u64* out) {  // one cell to Montgomery f
     }
 }
 __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     if (i < a.rows.n) {
@@ -304,6 +317,7 @@ __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32*
     tally_commit(tally, i, code);
 }
 __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     if (i < a.rows.n) {
@@ -317,6 +331,7 @@ __global__ void sign_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) sign_fill_rpow(r, out);
 }
 __global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     if (i < a.cells.n) {
@@ -482,6 +497,7 @@ __global__ __launch_bounds__(256) void keccak_table_kernel(KeccakGenArgs g, u32*
     tally_commit(tally, i, code);
 }
 __global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     if (i < a.rows.n) {
@@ -519,6 +535,8 @@ struct zk_session {
     u32* d_status = nullptr;        // internal per-row status (always kept for zk_read_status)
     std::vector<hipEvent_t> ev;     // start/stop pairs
     u32 launches = 0;               // since last collect
+    u32 tally_pass = 0;             // passes of a twin-tally session since open
+    ZkTally* tally_last = nullptr;  // the tally the latest pass accumulated into
     StateArgs state;
     EvmArgs evm;
     BytecodeArgs bytecode;
@@ -584,8 +602,10 @@ static int build_index(zk_session* s, ZkTable& t) {
 }
 
 static int session_common_init(zk_session* s) {
-    int rc = dev_alloc(s, (void**)&s->d_tally, sizeof(ZkTally));
+    int rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally));
     if (rc) return rc;
+    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(2), 0, g_stream, s->d_tally);
+    s->tally_last = s->d_tally;
     rc = dev_alloc(s, (void**)&s->d_status, (size_t)s->n * sizeof(u32));
     return rc;
 }
@@ -1395,7 +1415,11 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         e0 = s->ev[2 * s->launches];
         e1 = s->ev[2 * s->launches + 1];
     }
-    if (!(s->kind == SESSION_EVM && s->evm.perm))
+    const bool twin_tally = s->kind == SESSION_STATE || s->kind == SESSION_BYTECODE || s->kind == SESSION_COPY ||
+                            s->kind == SESSION_SIGN || s->kind == SESSION_EXP;
+    ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
+    s->tally_last = tally;
+    if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
         hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
@@ -1407,22 +1431,22 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const int block = 256;
         const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
         const u32 grid = (u32)((s->state.eval_hi - s->state.eval_lo + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, s->d_tally);
+        hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, tally);
         break;
     }
     case SESSION_BYTECODE: {
         const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->bytecode, status, s->d_tally);
+        hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->bytecode, status, tally);
         break;
     }
     case SESSION_COPY: {
         const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->copy, status, s->d_tally);
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->copy, status, tally);
         break;
     }
     case SESSION_SIGN: {
         const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(sign_units_kernel, dim3(grid), dim3(256), 0, g_stream, s->sign, status, s->d_tally);
+        hipLaunchKernelGGL(sign_units_kernel, dim3(grid), dim3(256), 0, g_stream, s->sign, status, tally);
         break;
     }
     case SESSION_KECCAK: {
@@ -1461,7 +1485,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     }
     case SESSION_EXP: {
         const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(exp_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->exp, status, s->d_tally);
+        hipLaunchKernelGGL(exp_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->exp, status, tally);
         break;
     }
     case SESSION_EVM: {
@@ -1493,7 +1517,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
 extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ARG_TRY(s && r, "zk_collect: bad arguments");
     ZkTally t;
-    HIP_TRY(hipMemcpyAsync(&t, s->d_tally, sizeof t, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     double ms = 0;
     u32 timed = s->launches < (u32)MAX_EVENT_PAIRS ? s->launches : (u32)MAX_EVENT_PAIRS;
