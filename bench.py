@@ -56,7 +56,11 @@ def main():
     n = 1 << log_rows
     to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
     _lib.init(local_rank)
-    _lib.check(_lib.load().zk_set_stream(torch.cuda.current_stream().cuda_stream), "zk_set_stream")
+    # one real (non-default) stream shared by torch and the engine: uploads, the passes and the cold leg's flush kernel are
+    # ordered on it (torch's default stream is handle 0, which the engine reads as "use your own stream")
+    bench_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(bench_stream)
+    _lib.check(_lib.load().zk_set_stream(bench_stream.cuda_stream), "zk_set_stream")
     if args.workload == "evm":
         from zkevm_specs_amd.synth_evm import synth_evm_trace
 

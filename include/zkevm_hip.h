@@ -15,7 +15,13 @@
  * Errors: every function returns 0 on success and a negative code on infrastructure errors
  * (bad arguments, HIP failures — text via zk_last_error()); constraint failures are NOT
  * errors, they are reported in zk_result.  Nothing throws across this boundary.
- * Threading: one engine per process/device, calls from one thread at a time.
+ * Threading / re-entrancy: a session (zk_session*) is the context.  It captures the device and the stream that are
+ * current for the calling thread when it is opened, owns its buffers, events and tally, and every later call on it
+ * (zk_launch / zk_collect / zk_read_status / zk_close) works on that device and stream whatever other sessions or
+ * threads do in between.  Different sessions may be driven from different threads concurrently; one session is driven
+ * by one thread at a time.  zk_init / zk_set_stream select the *calling thread's* current device / stream,
+ * zk_last_error returns the calling thread's last error text.  The only process-wide state is one lazily created
+ * stream per device.
  */
 #ifndef ZKEVM_HIP_H
 #define ZKEVM_HIP_H
@@ -56,10 +62,13 @@ typedef struct zk_result {
 
 #define ZK_OPT_DEVICE_PTRS 1u  /* every data pointer is a device (HBM) pointer */
 
-/* Select the GPU (HIP ordinal) and create the engine's stream/events.  Idempotent. */
+/* Select the GPU (HIP ordinal) for the calling thread; creates that device's engine stream on first use.  Idempotent.
+ * Selecting another device drops a stream set with zk_set_stream (it belongs to the previous device). */
 int zk_init(int device);
 void zk_shutdown(void);
-/* Launch on the caller's HIP stream (e.g. torch's current stream); NULL = engine's own. */
+/* Sessions opened by this thread from now on run on the caller's HIP stream (e.g. torch's current stream);
+ * NULL = the engine's own (non-blocking) stream of the device.  NOTE: HIP's legacy default stream is handle 0 = NULL
+ * here, i.e. "engine's own": to order the engine with work of another library, hand over a real (non-default) stream. */
 int zk_set_stream(void* hip_stream);
 const char* zk_last_error(void);
 /* BN254-Fr vector ops on the device for tests: op 0 add, 1 sub, 2 mul, 3 montmul, 4 neg.
@@ -273,8 +282,11 @@ int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t*
  *         time over the passes since the previous collect. */
 int zk_launch(zk_session* s, uint32_t* status_dev);
 int zk_collect(zk_session* s, zk_result* result);
-/* Copy the per-row status of the last pass into a HOST buffer (n entries). */
+/* Copy the per-row status of the last pass into a HOST buffer (n entries).  Fails when that pass wrote its statuses
+ * to a caller-provided status_dev (they are the caller's then); all zero before the first pass. */
 int zk_read_status(zk_session* s, uint32_t* status_host);
+/* Re-bind a session to another stream of its device (NULL = the engine's own); waits for its enqueued passes first. */
+int zk_session_set_stream(zk_session* s, void* hip_stream);
 int zk_close(zk_session* s);
 
 #ifdef __cplusplus

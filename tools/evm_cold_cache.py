@@ -24,7 +24,9 @@ ap.add_argument("--clean", action="store_true", help="flush with reads only (no 
 args = ap.parse_args()
 to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()  # noqa: E731
 _lib.init(0)
-_lib.check(_lib.load().zk_set_stream(torch.cuda.current_stream().cuda_stream), "zk_set_stream")
+_st = torch.cuda.Stream()  # a real stream shared with torch: the flush and the pass are ordered on it
+torch.cuda.set_stream(_st)
+_lib.check(_lib.load().zk_set_stream(_st.cuda_stream), "zk_set_stream")
 w = synth_evm_trace(1 << args.log_rows, seed=3)
 meta = w.pop("meta")
 dev_w = {k: to_dev(v) for k, v in w.items()}

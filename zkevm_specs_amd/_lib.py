@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 
 EXPORTED_SYMBOLS = [
-    "zk_init", "zk_shutdown", "zk_set_stream", "zk_last_error", "zk_fr_op",
+    "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
     "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
     "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
@@ -99,6 +99,7 @@ def load():
     vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
     lib.zk_init.argtypes = [ctypes.c_int]
     lib.zk_set_stream.argtypes = [vp]
+    lib.zk_session_set_stream.argtypes = [vp, vp]
     lib.zk_last_error.restype = ctypes.c_char_p
     lib.zk_fr_op.argtypes = [ctypes.c_int, vp, vp, vp, u64, u32]
     lib.zk_state_open.argtypes = [vp, vp, u64, vp, u64, u32, ctypes.POINTER(vp)]
@@ -145,9 +146,10 @@ def init(device=None):
     lib = load()
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    if _inited_device != device:
-        check(lib.zk_init(int(device)), "zk_init")
-        _inited_device = device
+    # zk_init is idempotent and its selection is per thread: always forward it (a cached "already initialised" flag would
+    # be wrong for a second thread or after another device was selected in between)
+    check(lib.zk_init(int(device)), "zk_init")
+    _inited_device = device
     return lib
 
 

@@ -1,10 +1,25 @@
 #!/bin/bash
-# Build libzkevm_hip.so for gfx950 (cross-compiles without a GPU).
+# Build libzkevm_hip.so for gfx950 (cross-compiles without a GPU).  The translation units are independent (each k_*.hip
+# defines its kernels + a host launcher, kernels.hpp), so they compile in parallel; no relocatable device code.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wall -Wno-unused-function \
-    -Rpass-analysis=kernel-resource-usage $ZK_EXTRA_FLAGS \
-    -o ../libzkevm_hip.so zkevm_hip.hip 2> build.log || { cat build.log; exit 1; }
-grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" build.log | paste - - - - - - | sed 's/remark: [^ ]* //g' > resource_usage.txt || true
+OUT=${ZK_BUILD_DIR:-build}
+mkdir -p "$OUT"
+UNITS="zkevm_hip k_state k_evm_hot k_evm_cold k_rows k_assign k_ecdsa"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage $ZK_EXTRA_FLAGS"
+pids=()
+for u in $UNITS; do
+    # rebuild a unit only when one of the sources is newer than its object (headers are shared: any header change rebuilds all)
+    if [ ! -f "$OUT/$u.o" ] || [ -n "$(find . -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name "$u.hip" -o -name build.sh \) -newer "$OUT/$u.o" | head -1)" ] || [ -n "$ZK_EXTRA_FLAGS" ] || [ -f "$OUT/.extra_flags" ]; then
+        ( $HIPCC $FLAGS -c -o "$OUT/$u.o" "$u.hip" 2> "$OUT/$u.log" || { cat "$OUT/$u.log"; exit 1; } ) &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+if [ -n "$ZK_EXTRA_FLAGS" ]; then touch "$OUT/.extra_flags"; else rm -f "$OUT/.extra_flags"; fi
+OBJS=""
+for u in $UNITS; do OBJS="$OBJS $OUT/$u.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libzkevm_hip.so $OBJS
+cat $OUT/*.log | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | paste - - - - - - | sed 's/remark: [^ ]* //g; s/\[-Rpass-analysis=kernel-resource-usage\]//g' > "$OUT/resource_usage.txt" || true
 echo "built $(ls -la ../libzkevm_hip.so)"

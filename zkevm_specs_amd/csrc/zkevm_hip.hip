@@ -7,25 +7,24 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "../../include/zkevm_hip.h"
-#include "state_circuit.hpp"
-#include "evm_circuit.hpp"
+#include "kernels.hpp"
 #include "host_index.hpp"
-#include "row_circuits.hpp"
-#include "copy_circuit.hpp"
-#include "sign_circuit.hpp"
-#include "keccak_table.hpp"
-#include "state_assign.hpp"
-#include "secp256k1.hpp"
-#include "bytecode_assign.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
 // ---------------------------------------------------------------------------------------
-static int g_device = -1;
-static hipStream_t g_own_stream = nullptr;
-static hipStream_t g_stream = nullptr;
-static std::string g_err;
+// Process-wide state is limited to one lazily created stream per device (immutable once created).  Everything else is
+// per thread (the "current" device / stream that zk_*_open captures, the error text) or per session (device, stream,
+// buffers, events): sessions are independent contexts, calls on different sessions may come from different threads.
+#define ZK_MAX_DEVICES 64
+static std::mutex g_dev_mutex;
+static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
+static thread_local int t_device = -1;              // device selected by this thread's last zk_init
+static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
+static thread_local std::string g_err;
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -51,26 +50,41 @@ extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
 extern "C" int zk_init(int device) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
-    ARG_TRY(device >= 0 && device < count, "zk_init: no such HIP device");
+    ARG_TRY(device >= 0 && device < count && device < ZK_MAX_DEVICES, "zk_init: no such HIP device");
     HIP_TRY(hipSetDevice(device));
-    if (g_device != device || !g_own_stream) {
-        if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
-        HIP_TRY(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking));
-        g_device = device;
+    hipStream_t own;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (!g_own_stream[device]) HIP_TRY(hipStreamCreateWithFlags(&g_own_stream[device], hipStreamNonBlocking));
+        own = g_own_stream[device];
     }
-    if (!g_stream) g_stream = g_own_stream;
+    // a stream set by zk_set_stream belongs to the device it was set on: re-selecting the same device keeps it, selecting
+    // another device falls back to that device's own stream (never a handle of the previous device)
+    if (t_device != device || !t_stream) t_stream = own;
+    t_device = device;
     return 0;
 }
 extern "C" void zk_shutdown(void) {
-    if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
-    g_own_stream = nullptr;
-    g_stream = nullptr;
-    g_device = -1;
+    // sessions own their buffers (zk_close); the per-device streams are released here.  Callers close sessions first.
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    for (int d = 0; d < ZK_MAX_DEVICES; d++)
+        if (g_own_stream[d]) {
+            if (hipSetDevice(d) == hipSuccess) (void)hipStreamDestroy(g_own_stream[d]);
+            g_own_stream[d] = nullptr;
+        }
+    t_stream = nullptr;
+    t_device = -1;
 }
-extern "C" int zk_set_stream(void* s) {
-    ARG_TRY(g_device >= 0, "zk_set_stream: call zk_init first");
-    g_stream = s ? (hipStream_t)s : g_own_stream;
+extern "C" int zk_set_stream(void* st) {
+    ARG_TRY(t_device >= 0, "zk_set_stream: call zk_init first");
+    t_stream = st ? (hipStream_t)st : g_own_stream[t_device];
     return 0;
+}
+struct zk_session;
+static int session_rebind_stream(zk_session* s, hipStream_t st);
+extern "C" int zk_session_set_stream(zk_session* s, void* st) {
+    ARG_TRY(s, "zk_session_set_stream: null session");
+    return session_rebind_stream(s, (hipStream_t)st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -80,28 +94,7 @@ __global__ void tally_reset_kernel(ZkTally* t) {
     t[threadIdx.x].fail_count = 0ull;
     t[threadIdx.x].first_fail = ~0ull;
 }
-// The single-kernel row sessions keep two tallies and alternate between them: a pass accumulates into one and its first
-// lane clears the other for the pass after it, so that no reset kernel sits in front of every evaluation kernel (a kernel
-// boundary costs ~10 us of the 77 us State pass at 2^16 rows).  `tally` and its twin are 16 B apart in one 32 B-aligned block.
-__device__ __forceinline__ void tally_clear_twin(ZkTally* tally) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ZkTally* twin = (ZkTally*)((uintptr_t)tally ^ (uintptr_t)sizeof(ZkTally));
-        twin->fail_count = 0ull;
-        twin->first_fail = ~0ull;
-    }
-}
-static_assert(sizeof(ZkTally) == 16, "tally_clear_twin assumes 16-byte tallies");
 
-// One wave-level ballot, then at most one counter atomic per wave and one atomicMin per
-// failing lane (failures are rare on real witnesses; the hot path issues no atomics at all).
-__device__ __forceinline__ void tally_commit(ZkTally* tally, u64 row, u32 code) {
-    const unsigned long long ballot = __ballot(code != 0u);
-    if (ballot != 0ull) {
-        if (code != 0u) atomicMin(&tally->first_fail, (row << 32) | (unsigned long long)code);
-        const int lane = threadIdx.x & 63;
-        if (lane == __ffsll((long long)ballot) - 1) atomicAdd(&tally->fail_count, (unsigned long long)__popcll(ballot));
-    }
-}
 
 __global__ void slots_fill_kernel(u32* slots, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,98 +108,6 @@ __global__ void index_build_kernel(ZkTable t, u32* slots) {
     u32 s = (u32)HASH(t, r) & t.mask;
     while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
 }
-
-// ---------------------------------------------------------------------------------------
-// State circuit kernel.  Column-major cells make every cell load a fully coalesced 32 B/lane
-// access (2 x dwordx4).  A lane loads ONLY its own row; what the checks need from the previous
-// row arrives from lane - 1 through DPP moves, so every wavefront evaluates 63 rows and its
-// lane 0 holds the (read-only) row in front of them.  The next row (Storage / Account last-
-// access test) is re-read through L1/L2 by the few rows that need it.
-// ---------------------------------------------------------------------------------------
-#define ST_ROWS_PER_WAVE 63
-#ifndef ZK_STATE_OCC
-#define ZK_STATE_OCC 2  // waves per SIMD the State kernel is compiled for (3 was measured: 168 VGPRs + 32 B scratch, 2^20 rows 0.423 vs 0.404 ms)
-#endif
-__global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
-    tally_clear_twin(tally);
-    const u32 lane = threadIdx.x & 63u;
-    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;  // first row this wavefront evaluates
-    const u64 n = a.rows.n;
-    // lane l holds row first + l - 1 (lane 0: the predecessor of `first`, wrapping to n - 1)
-    u64 i = lane == 0 ? (first == 0 ? n - 1 : first - 1) : first + lane - 1;
-    const bool evaluate = lane != 0 && i < a.eval_hi;
-    if (i >= n) i = n - 1;  // lanes past the range still take part in the DPP moves: keep their loads in bounds
-    StRow C;
-    u32 code = 0;
-    state_load_row(a.rows, i, C, code);
-    code = state_check_loaded(a, i, C, C, code);
-    if (!evaluate) code = 0;
-    else if (status) status[i] = code;
-    tally_commit(tally, i, code);
-}
-
-// ---------------------------------------------------------------------------------------
-// EVM circuit kernels: one lane per step pair (curr, next).  Lanes are assigned through a
-// permutation sorted by (kernel group, execution state) so that a 64-lane wavefront runs ONE
-// gadget body instead of serialising the ~10 different execution states a window of consecutive
-// steps contains; each group has its own kernel instantiation (evm_circuit.hpp).
-// group_start[g] .. group_start[g+1] is the lane range of group g inside `perm`.
-// ---------------------------------------------------------------------------------------
-#ifndef ZK_HOT_OCC
-#define ZK_HOT_OCC 2  // waves per SIMD the hot EVM kernel is compiled for
-#endif
-template <int G, int OCC>
-__global__ __launch_bounds__(256, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
-    // lane range: with the state-sorted mapping the hot instantiation owns [0, group_start[COLD]) and the
-    // cold one [group_start[COLD], n); without it both walk all pairs and skip the other's states
-    u32 lo = 0, hi = a.n_pairs;
-    if (a.perm) {
-        if (G == EVM_GROUP_COLD) lo = group_start[EVM_GROUP_COLD];
-        else hi = group_start[EVM_GROUP_COLD];
-    }
-    u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ u64 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_SLOTS * EVM_STAGE_LANES : 1];
-    __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
-    if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
-        // small bytecode directories (the usual case: a handful of contracts) are mirrored in LDS by the whole block, so that
-        // resolving curr.code_hash costs no dependent HBM round trips
-        const bool dir_in_lds = a.codes.n != 0 && a.codes.n <= EVM_DIR_MAX_ENTRIES && a.codes.mask < EVM_DIR_MAX_SLOTS;
-        if (dir_in_lds) {
-            const u32 n_slots = a.codes.mask + 1u;
-            for (u32 k = threadIdx.x; k < EVM_DIR_SLOT_U64; k += blockDim.x) {
-                const u32 s0 = 2 * k < n_slots ? a.codes.slots[2 * k] : ZK_EMPTY_SLOT, s1 = 2 * k + 1 < n_slots ? a.codes.slots[2 * k + 1] : ZK_EMPTY_SLOT;
-                s_dir[k] = (u64)s0 | ((u64)s1 << 32);
-            }
-            const u64* e = (const u64*)a.codes.entries;
-            for (u32 k = threadIdx.x; k < a.codes.n * 12u; k += blockDim.x) s_dir[EVM_DIR_SLOT_U64 + k] = e[k];
-            __syncthreads();
-        }
-        u32 code = 0;
-        u64 idx = t;
-        if (t < (u64)hi) {
-            if (a.perm) idx = a.perm[t];
-            // both steps of the pair go to LDS first (52 loads in flight at once); the gadgets read them from there
-            __attribute__((address_space(3))) u64* my = (__attribute__((address_space(3))) u64*)s_stage + threadIdx.x;
-            const bool staged = evm_stage_steps(a, idx, my);
-            code = evm_check_step<G>(a, idx, staged ? (EVM_LDS_PTR)my : (EVM_LDS_PTR) nullptr,
-                                     dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
-            if (code == ZK_NOT_MINE) code = 0;
-            else if (status) status[idx] = code;
-        }
-        tally_commit(tally, idx, code);
-    } else {  // small grid, grid-stride loop
-        const u64 stride = (u64)gridDim.x * blockDim.x;
-        for (; t < (u64)hi; t += stride) {
-            const u64 idx = a.perm ? (u64)a.perm[t] : t;
-            u32 code = evm_check_step<G>(a, idx);
-            if (code == ZK_NOT_MINE) code = 0;
-            else if (status) status[idx] = code;
-            tally_commit(tally, idx, code);  // ballot over the lanes still in the loop
-        }
-    }
-}
-
 // RW-table density check (see ZkRwMeta): meta->dense must be pre-set to 1.
 __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,218 +196,6 @@ __global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t*
     __syncthreads();
     if (i < n_pairs) perm[base[bin] + rank] = i;
 }
-
-// ---------------------------------------------------------------------------------------
-// Bytecode / Exp circuit kernels: one lane per row, column-major witness (coalesced), next row
-// re-read through L1/L2 (wraps modulo n).
-// ---------------------------------------------------------------------------------------
-__global__ void fr_to_mont_kernel(Fr x, u64* out) {  // one cell to Montgomery form (per-session constants)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const Fr m = fr_to_mont(x);
-        for (int j = 0; j < 4; j++) out[j] = (u64)m.v[2 * j] | ((u64)m.v[2 * j + 1] << 32);
-    }
-}
-__global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32* status, ZkTally* tally) {
-    tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < a.rows.n) {
-        code = bytecode_check_row(a, i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-__global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status, ZkTally* tally) {
-    tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < a.rows.n) {
-        code = copy_check_row(a, i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-// Tx / Sig circuits: one lane per tx slot / signature row (units are independent: no halo).
-__global__ void sign_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) sign_fill_rpow(r, out);
-}
-__global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status, ZkTally* tally) {
-    tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < a.cells.n) {
-        code = sign_check_unit(a, i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-// ---------------------------------------------------------------------------------------
-// State-circuit witness assignment (state_assign.hpp): one lane per op.
-//   insert -> mark (first occurrences, per-block partials) -> scan (one block) -> rank + MPT rows -> rows
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ASG_BLOCK) void assign_insert_kernel(AssignArgs a) {
-    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
-    if (i < a.n && asg_has_key(asg_slot(a, ASG_TAG, i))) asg_insert(a, (u32)i);
-}
-__global__ __launch_bounds__(ASG_BLOCK) void assign_mark_kernel(AssignArgs a) {
-    __shared__ u32 s_cnt[ASG_BLOCK / 64];
-    __shared__ u32 s_min[ASG_BLOCK / 64];
-    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const bool keyed = i < a.n && asg_has_key(asg_slot(a, ASG_TAG, i));
-    u32 f = ASG_NONE;
-    if (keyed) f = asg_find_first(a, (u32)i);
-    if (i < a.n) a.first[i] = f;
-    const unsigned long long bf = __ballot(keyed && f == (u32)i), bk = __ballot(keyed);
-    if (lane == 0) {
-        s_cnt[w] = (u32)__popcll(bf);
-        s_min[w] = bk ? (u32)i + (u32)__ffsll((long long)bk) - 1u : ASG_NONE;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 c = 0, m = ASG_NONE;
-        for (int k = 0; k < ASG_BLOCK / 64; k++) { c += s_cnt[k]; m = s_min[k] < m ? s_min[k] : m; }
-        a.blk_cnt[blockIdx.x] = c;
-        a.blk_next[blockIdx.x] = m;
-    }
-}
-// blk_cnt -> exclusive prefix (total in [nb]); blk_next -> min over the blocks after b.  One block.
-__global__ __launch_bounds__(1024) void assign_scan_kernel(AssignArgs a) {
-    __shared__ u32 s[1024];
-    const u32 t = threadIdx.x, nb = a.nb;
-    const u32 per = (nb + 1023u) / 1024u;
-    const u32 lo = t * per < nb ? t * per : nb, hi = lo + per < nb ? lo + per : nb;
-    u32 sum = 0;
-    for (u32 b = lo; b < hi; b++) sum += a.blk_cnt[b];
-    s[t] = sum;
-    __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        const u32 v = t >= d ? s[t - d] : 0u;
-        __syncthreads();
-        s[t] += v;
-        __syncthreads();
-    }
-    u32 run = s[t] - sum;
-    const u32 total = s[1023];
-    for (u32 b = lo; b < hi; b++) { const u32 c = a.blk_cnt[b]; a.blk_cnt[b] = run; run += c; }
-    if (t == 0) a.blk_cnt[nb] = total;
-    u32 m = ASG_NONE;
-    for (u32 b = lo; b < hi; b++) m = a.blk_next[b] < m ? a.blk_next[b] : m;
-    __syncthreads();
-    s[t] = m;
-    __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        const u32 v = t + d < 1024 ? s[t + d] : ASG_NONE;
-        __syncthreads();
-        s[t] = v < s[t] ? v : s[t];
-        __syncthreads();
-    }
-    u32 after = t + 1 < 1024 ? s[t + 1] : ASG_NONE;
-    for (u32 b = hi; b > lo; b--) { const u32 c = a.blk_next[b - 1]; a.blk_next[b - 1] = after; after = c < after ? c : after; }
-    if (t == 0) a.blk_next[nb] = ASG_NONE;
-}
-__global__ __launch_bounds__(ASG_BLOCK) void assign_rank_kernel(AssignArgs a) {
-    __shared__ u32 s_cnt[ASG_BLOCK / 64];
-    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const bool is_first = i < a.n && a.first[i] == (u32)i;
-    const unsigned long long bf = __ballot(is_first);
-    if (lane == 0) s_cnt[w] = (u32)__popcll(bf);
-    __syncthreads();
-    if (is_first) {
-        u32 r = a.blk_cnt[blockIdx.x] + (u32)__popcll(bf & ((1ull << lane) - 1ull));
-        for (u32 k = 0; k < w; k++) r += s_cnt[k];
-        a.rank[i] = r;
-        asg_write_mpt(a, i, r);
-    }
-}
-__global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u32* status, ZkTally* tally) {
-    __shared__ u32 s_min[ASG_BLOCK / 64];
-    const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
-    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const bool in = i < a.n;
-    const u32 f = in ? a.first[i] : ASG_NONE;
-    const unsigned long long bk = __ballot(f != ASG_NONE);
-    const u32 wave_base = (u32)i - lane;
-    if (lane == 0) s_min[w] = bk ? wave_base + (u32)__ffsll((long long)bk) - 1u : ASG_NONE;
-    __syncthreads();
-    // first MPT-keyed op strictly after i: this wave, the later waves of the block, the later blocks
-    const unsigned long long above = lane == 63u ? 0ull : (bk >> (lane + 1u)) << (lane + 1u);
-    u32 nxt = above ? wave_base + (u32)__ffsll((long long)above) - 1u : ASG_NONE;
-    for (u32 k = w + 1; k < ASG_BLOCK / 64; k++)
-        if (nxt == ASG_NONE) nxt = s_min[k];
-    if (nxt == ASG_NONE) nxt = a.blk_next[blockIdx.x];
-    u32 code = 0;
-    if (in) {
-        const u64 root = 3ull + 5ull * (nxt == ASG_NONE ? a.blk_cnt[a.nb] : a.rank[a.first[nxt]]);
-        code = asg_write_row(a, i, root, f == (u32)i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-// secp256k1 ECDSA verification: one lane per signature (secp256k1.hpp); integer-ALU bound
-__global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* status, ZkTally* tally) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < a.n) {
-        code = ecdsa_verify_one(a, i);
-        if (status) status[i] = code;
-        if (a.out) a.out[i * a.out_stride] = code;
-    }
-    tally_commit(tally, i, code);
-}
-// Bytecode-circuit witness assignment (bytecode_assign.hpp)
-__global__ void bca_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) bca_fill_rpow(r, out);
-}
-__global__ void bca_track_kernel(BcaArgs a) {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < a.n_codes) bca_track_code(a, j);
-}
-__global__ void bca_chunk_kernel(BcaArgs a) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < a.n_chunks) bca_chunk(a, c);
-}
-__global__ void bca_prefix_kernel(BcaArgs a) {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < a.n_codes) bca_prefix_code(a, j);
-}
-__global__ void bca_rlc_kernel(BcaArgs a) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < a.n_chunks) bca_rlc_chunk(a, c);
-}
-__global__ __launch_bounds__(256) void bca_rows_kernel(BcaArgs a, u32* status, ZkTally* tally) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n_out) {
-        bca_write_row(a, i);
-        if (status) status[i] = 0;  // the assignment has no failure modes of its own
-    }
-    tally_commit(tally, i, 0);
-}
-// Keccak table generation: one lane per message (keccak_table.hpp)
-__global__ void keccak_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
-}
-__global__ __launch_bounds__(256) void keccak_table_kernel(KeccakGenArgs g, u32* status, ZkTally* tally) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < g.n) {
-        code = keccak_table_row(g, i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-__global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
-    tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < a.rows.n) {
-        code = exp_check_row(a, i);
-        if (status) status[i] = code;
-    }
-    tally_commit(tally, i, code);
-}
-
 __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -529,10 +218,13 @@ enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SES
 
 struct zk_session {
     SessionKind kind;
+    int device = t_device;            // captured at open: the session is its own context from here on
+    hipStream_t stream = t_stream;
     u64 n = 0;                      // rows per pass
     std::vector<void*> owned;       // device allocations to free at close
     ZkTally* d_tally = nullptr;
-    u32* d_status = nullptr;        // internal per-row status (always kept for zk_read_status)
+    u32* d_status = nullptr;        // internal per-row status (zeroed at open; what zk_read_status copies)
+    bool status_external = false;   // the last pass wrote to the caller's status_dev instead
     std::vector<hipEvent_t> ev;     // start/stop pairs
     u32 launches = 0;               // since last collect
     u32 tally_pass = 0;             // passes of a twin-tally session since open
@@ -558,6 +250,17 @@ struct zk_session {
 
 static const int MAX_EVENT_PAIRS = 256;
 
+// Move a session to another stream of its device (NULL = the device's own stream).  Work already enqueued on the old
+// stream is waited for first, so the passes of one session stay ordered.
+static int session_rebind_stream(zk_session* s, hipStream_t st) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (!st) st = g_own_stream[s->device];
+    if (st == s->stream) return 0;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->stream = st;
+    return 0;
+}
+
 static int dev_alloc(zk_session* s, void** p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
     s->owned.push_back(*p);
@@ -570,7 +273,7 @@ static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs,
         void* z = nullptr;
         int rc0 = dev_alloc(s, &z, 512);
         if (rc0) return rc0;
-        HIP_TRY(hipMemsetAsync(z, 0, 512, g_stream));
+        HIP_TRY(hipMemsetAsync(z, 0, 512, s->stream));
         *out = z;
         return 0;
     }
@@ -581,7 +284,7 @@ static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs,
     void* d = nullptr;
     int rc = dev_alloc(s, &d, bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s->stream));
     *out = d;
     return 0;
 }
@@ -595,8 +298,8 @@ static int build_index(zk_session* s, ZkTable& t) {
     if (rc) return rc;
     t.mask = cap - 1;
     t.slots = slots;
-    hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, g_stream, slots, cap);
-    if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, g_stream, t, slots);
+    hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, s->stream, slots, cap);
+    if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -604,15 +307,18 @@ static int build_index(zk_session* s, ZkTable& t) {
 static int session_common_init(zk_session* s) {
     int rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally));
     if (rc) return rc;
-    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(2), 0, g_stream, s->d_tally);
+    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(2), 0, s->stream, s->d_tally);
     s->tally_last = s->d_tally;
     rc = dev_alloc(s, (void**)&s->d_status, (size_t)s->n * sizeof(u32));
-    return rc;
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, (size_t)s->n * sizeof(u32), s->stream));
+    return 0;
 }
 
 extern "C" int zk_close(zk_session* s) {
     if (!s) return 0;
-    (void)hipStreamSynchronize(g_stream);
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
     for (void* p : s->owned) (void)hipFree(p);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
@@ -621,7 +327,8 @@ extern "C" int zk_close(zk_session* s) {
 
 extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n, const uint64_t* mpt,
                              uint64_t n_mpt, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_state_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_state_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_state_open: bad arguments");
     ARG_TRY(n_mpt < (1ull << 31), "zk_state_open: MPT table too large");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
@@ -674,15 +381,16 @@ static int evm_build_perm(zk_session* s) {
     u32* h_cur = (s->evm_pass & 1u) ? s->d_hist2 : s->d_hist;
     u32* h_next = (s->evm_pass & 1u) ? s->d_hist : s->d_hist2;
     s->evm_pass++;
-    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + ZK_HIST_BLOCK - 1) / ZK_HIST_BLOCK), dim3(ZK_HIST_BLOCK), 0, g_stream, s->evm.steps, n, h_cur, s->d_cursor, s->d_bin16, s->d_tally);
-    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, g_stream, s->d_bin16, n, h_cur, h_next, s->d_cursor,
+    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + ZK_HIST_BLOCK - 1) / ZK_HIST_BLOCK), dim3(ZK_HIST_BLOCK), 0, s->stream, s->evm.steps, n, h_cur, s->d_cursor, s->d_bin16, s->d_tally);
+    hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, s->stream, s->d_bin16, n, h_cur, h_next, s->d_cursor,
                        s->d_group_start, s->d_perm);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_evm_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_evm_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
     ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31) && t->n_block < (1ull << 31) &&
             t->n_copy < (1ull << 31) && t->n_keccak < (1ull << 31) && t->n_exp < (1ull << 31) && t->n_withdrawals < (1ull << 31) &&
@@ -764,20 +472,20 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         init.dense = t->n_rw ? 1u : 0u;
         init.pad = 0;
         init.base = 0;
-        if (hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, g_stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
+        if (hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
         if (t->n_rw)
-            hipLaunchKernelGGL(rw_dense_check_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, g_stream, s->evm.rw, d_meta);
+            hipLaunchKernelGGL(rw_dense_check_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, s->stream, s->evm.rw, d_meta);
         {   // the verdict travels as kernel arguments: no per-lookup metadata loads
             ZkRwMeta h_meta;
-            if (hipMemcpyAsync(&h_meta, d_meta, sizeof h_meta, hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
-                hipStreamSynchronize(g_stream) != hipSuccess) { rc = -2; g_err = "meta download failed"; goto fail; }
+            if (hipMemcpyAsync(&h_meta, d_meta, sizeof h_meta, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "meta download failed"; goto fail; }
             s->evm.rw_dense = h_meta.dense;
             s->evm.rw_base = h_meta.base;
         }
         if (s->evm.rw_dense && t->n_rw) {
             u64* d_keys = nullptr;
             if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
-            hipLaunchKernelGGL(rw_pack_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, g_stream, s->evm.rw, d_keys);
+            hipLaunchKernelGGL(rw_pack_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, s->stream, s->evm.rw, d_keys);
             s->evm.rw_keys = d_keys;
         }
         // bytecode directory: built on the host (the table is small), then uploaded
@@ -815,8 +523,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_hist2, EVM_N_BINS * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)s->evm.n_pairs * sizeof(uint16_t)))) goto fail;
-    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess ||
-        hipMemsetAsync(s->d_hist2, 0, EVM_N_BINS * sizeof(u32), g_stream) != hipSuccess) { rc = -2; goto fail; }
+    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess ||
+        hipMemsetAsync(s->d_hist2, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess) { rc = -2; goto fail; }
     if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
     s->evm.prof = nullptr;
@@ -848,7 +556,8 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
 
 extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak,
                                 const uint64_t* randomness, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_bytecode_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_bytecode_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && rows && randomness && n > 0 && n < (1ull << 32) && n_keccak < (1ull << 31), "zk_bytecode_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     zk_session* s = new zk_session();
@@ -872,7 +581,7 @@ extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t
     {
         u64* d_rm = nullptr;
         if ((rc = dev_alloc(s, (void**)&d_rm, 32))) goto fail;
-        hipLaunchKernelGGL(fr_to_mont_kernel, dim3(1), dim3(64), 0, g_stream, s->bytecode.r, d_rm);
+        zk_launch_fr_to_mont(s->stream, s->bytecode.r, d_rm);
         s->bytecode.r_mont = d_rm;
     }
     if ((rc = session_common_init(s))) goto fail;
@@ -884,7 +593,8 @@ fail:
 }
 
 extern "C" int zk_exp_open(const uint64_t* rows, uint64_t n, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_exp_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_exp_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_exp_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     zk_session* s = new zk_session();
@@ -913,15 +623,16 @@ static int build_rw_meta(zk_session* s, const ZkTable& rw, const ZkRwMeta** out)
     init.dense = rw.n ? 1u : 0u;
     init.pad = 0;
     init.base = 0;
-    HIP_TRY(hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));  // `init` lives on this stack frame
-    if (rw.n) hipLaunchKernelGGL(rw_dense_check_kernel, dim3((rw.n + 255) / 256), dim3(256), 0, g_stream, rw, d_meta);
+    HIP_TRY(hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // `init` lives on this stack frame
+    if (rw.n) hipLaunchKernelGGL(rw_dense_check_kernel, dim3((rw.n + 255) / 256), dim3(256), 0, s->stream, rw, d_meta);
     *out = d_meta;
     return 0;
 }
 
 extern "C" int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_copy_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_copy_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(t && out && t->rows && t->randomness && t->n_rows > 0 && t->n_rows < (1ull << 32), "zk_copy_open: bad arguments");
     ARG_TRY(t->n_rw < (1ull << 31) && t->n_bytecode < (1ull << 31) && t->n_tx < (1ull << 31), "zk_copy_open: table too large");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
@@ -960,7 +671,8 @@ fail:
 
 static int one_shot(zk_session* s, bool dev, uint32_t* status_out, zk_result* result);
 extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_sign_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_sign_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(t && out && t->bytes && t->cells && t->meta && t->randomness && t->n_units > 0 && t->n_units < (1ull << 32),
             "zk_sign_open: bad arguments");
     ARG_TRY(t->n_keccak < (1ull << 31) && t->n_tx_rows < (1ull << 32), "zk_sign_open: table too large");
@@ -994,7 +706,7 @@ extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** 
     {
         u64* d_rpow = nullptr;
         if ((rc = dev_alloc(s, (void**)&d_rpow, 64 * 4 * sizeof(u64)))) goto fail;
-        hipLaunchKernelGGL(sign_rpow_kernel, dim3(1), dim3(64), 0, g_stream, s->sign.r, d_rpow);
+        zk_launch_sign_rpow(s->stream, s->sign.r, d_rpow);
         s->sign.rpow = d_rpow;
     }
     if ((rc = session_common_init(s))) goto fail;
@@ -1015,7 +727,8 @@ extern "C" int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* s
 // ---- Keccak table generation
 extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
                               const uint64_t* randomness, uint32_t mode, uint64_t* rows_dev, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_keccak_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_keccak_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && offsets && randomness && n_msgs > 0 && n_msgs < (1ull << 32) && (data || n_bytes == 0) && mode <= 1u,
             "zk_keccak_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
@@ -1046,7 +759,7 @@ extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint6
     {
         u64* d_rpow = nullptr;
         if ((rc = dev_alloc(s, (void**)&d_rpow, KT_RPOW_ROWS * 4 * sizeof(u64)))) goto fail;
-        hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(64), 0, g_stream, r, d_rpow);
+        zk_launch_keccak_rpow(s->stream, r, d_rpow);
         s->keccak_gen.rpow = d_rpow;
     }
     if (rows_dev) {
@@ -1065,8 +778,8 @@ fail:
 }
 extern "C" int zk_keccak_read_rows(zk_session* s, uint64_t* rows_host) {
     ARG_TRY(s && rows_host && s->kind == SESSION_KECCAK, "zk_keccak_read_rows: bad arguments");
-    HIP_TRY(hipMemcpyAsync(rows_host, s->keccak_gen.rows, (size_t)s->n * KT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(rows_host, s->keccak_gen.rows, (size_t)s->n * KT_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs,
@@ -1088,7 +801,8 @@ extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint
 // ---- State-circuit witness assignment
 extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_dev,
                                     uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_state_assign_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_state_assign_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && ops && op_flags && n > 0 && n < (1ull << 31), "zk_state_assign_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     ARG_TRY(dev || (!rows_dev && !row_flags_dev && !mpt_dev), "zk_state_assign_open: output buffers need ZK_OPT_DEVICE_PTRS");
@@ -1130,16 +844,16 @@ extern "C" int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t
     ARG_TRY(s && s->kind == SESSION_ASSIGN, "zk_state_assign_read: bad arguments");
     const AssignArgs& a = s->assign;
     u32 n_mpt = 0;
-    HIP_TRY(hipMemcpyAsync(&n_mpt, a.blk_cnt + a.nb, 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(&n_mpt, a.blk_cnt + a.nb, 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     if (n_mpt_out) *n_mpt_out = n_mpt;
-    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n * ASG_ROW_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
-    if (row_flags_host) HIP_TRY(hipMemcpyAsync(row_flags_host, a.row_flags, (size_t)a.n * 4, hipMemcpyDeviceToHost, g_stream));
+    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n * ASG_ROW_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (row_flags_host) HIP_TRY(hipMemcpyAsync(row_flags_host, a.row_flags, (size_t)a.n * 4, hipMemcpyDeviceToHost, s->stream));
     if (mpt_host) {
         ARG_TRY(mpt_capacity_rows >= n_mpt, "zk_state_assign_read: mpt buffer too small");
-        if (n_mpt) HIP_TRY(hipMemcpyAsync(mpt_host, a.mpt, (size_t)n_mpt * ASG_MPT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
+        if (n_mpt) HIP_TRY(hipMemcpyAsync(mpt_host, a.mpt, (size_t)n_mpt * ASG_MPT_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
     }
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_out,
@@ -1163,7 +877,8 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
 // ---- secp256k1 ECDSA verification
 extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                              uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_ecdsa_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_ecdsa_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && bytes && n > 0 && n < (1ull << 32) && layout <= 2u && (!v || v_stride >= 1), "zk_ecdsa_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     ARG_TRY(dev || !out_dev, "zk_ecdsa_open: out_dev needs ZK_OPT_DEVICE_PTRS");
@@ -1211,7 +926,8 @@ extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint
 extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
                                        uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_dev, uint32_t opts,
                                        zk_session** out) {
-    ARG_TRY(g_device >= 0, "zk_bytecode_assign_open: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_bytecode_assign_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(out && randomness && k >= 1 && k <= 28 && n_rows < (1ull << 31) && n_codes < (1ull << 31) && (n_codes == 0 || (offsets && lengths)) &&
             (n_rows == 0 || in_rows), "zk_bytecode_assign_open: bad arguments");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
@@ -1265,13 +981,13 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
         u64* d_rpow = nullptr;
         void* d = nullptr;
         if ((rc = dev_alloc(s, (void**)&d_rpow, BCA_RPOW_ROWS * 32))) goto fail;
-        hipLaunchKernelGGL(bca_rpow_kernel, dim3(1), dim3(64), 0, g_stream, r, d_rpow);
+        zk_launch_bca_rpow(s->stream, r, d_rpow);
         a.rpow = d_rpow;
         if ((rc = stage(s, chunks.empty() ? nullptr : chunks.data(), chunks.size() * sizeof(BcaChunk), false, &p))) goto fail;
         a.chunks = (const BcaChunk*)p;
         if ((rc = stage(s, code_chunk0.data(), code_chunk0.size() * 4, false, &p))) goto fail;
         a.code_chunk0 = (const u32*)p;
-        HIP_TRY(hipStreamSynchronize(g_stream));  // the host vectors above go out of scope with this call
+        HIP_TRY(hipStreamSynchronize(s->stream));  // the host vectors above go out of scope with this call
         if ((rc = dev_alloc(s, &d, (size_t)n_rows * 2))) goto fail;
         a.track = (uint8_t*)d;
         if ((rc = dev_alloc(s, &d, chunks.size() * 32))) goto fail;
@@ -1296,8 +1012,8 @@ fail:
 }
 extern "C" int zk_bytecode_assign_read(zk_session* s, uint64_t* rows_host) {
     ARG_TRY(s && rows_host && s->kind == SESSION_BCA, "zk_bytecode_assign_read: bad arguments");
-    HIP_TRY(hipMemcpyAsync(rows_host, s->bca.rows, (size_t)s->bca.n_out * BCA_OUT_NCELLS * 32, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(rows_host, s->bca.rows, (size_t)s->bca.n_out * BCA_OUT_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 extern "C" int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths,
@@ -1351,14 +1067,14 @@ extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_h
     ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_state_set_range: bad range");
     s->state.eval_lo = row_lo;
     s->state.eval_hi = row_hi;
-    HIP_TRY(hipMemsetAsync(s->d_status, 0, (size_t)s->n * sizeof(u32), g_stream));
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, (size_t)s->n * sizeof(u32), s->stream));
     return 0;
 }
 
 // tuning aid (not part of the public ABI): copy the phase timestamps of the last pass
 extern "C" int zk_debug_read_prof(zk_session* s, unsigned long long* out) {
     if (!s || !s->evm.prof) return -1;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(out, s->evm.prof, 512 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1385,14 +1101,14 @@ extern "C" int zk_debug_calib_gather(uint64_t nbytes, uint32_t lane_bytes, float
     u32* sink = nullptr;
     HIP_TRY(hipMalloc(&buf, n_rec * lane_bytes));
     HIP_TRY(hipMalloc(&sink, 64));
-    HIP_TRY(hipMemsetAsync(buf, 0x5a, n_rec * lane_bytes, g_stream));
+    HIP_TRY(hipMemsetAsync(buf, 0x5a, n_rec * lane_bytes, t_stream));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, g_stream));
-    calib_gather_kernel<<<dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, g_stream>>>(buf, n_rec, lane_bytes / 16, sink);
-    HIP_TRY(hipEventRecord(e1, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipEventRecord(e0, t_stream));
+    calib_gather_kernel<<<dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, t_stream>>>(buf, n_rec, lane_bytes / 16, sink);
+    HIP_TRY(hipEventRecord(e1, t_stream));
+    HIP_TRY(hipStreamSynchronize(t_stream));
     if (ms_out) HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
     hipEventDestroy(e0);
     hipEventDestroy(e1);
@@ -1403,6 +1119,8 @@ extern "C" int zk_debug_calib_gather(uint64_t nbytes, uint32_t lane_bytes, float
 
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
+    HIP_TRY(hipSetDevice(s->device));
+    s->status_external = status_dev != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = s->launches < (u32)MAX_EVENT_PAIRS;
     if (timed) {
@@ -1420,95 +1138,36 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
-        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, g_stream, s->d_tally);
+        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, s->stream, s->d_tally);
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
     // no separate event packets between the sort passes and the evaluation kernels
     const bool evm_ext_events = timed && s->kind == SESSION_EVM && s->evm.perm;
-    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, g_stream));
+    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, s->stream));
     switch (s->kind) {
-    case SESSION_STATE: {
-        const int block = 256;
-        const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
-        const u32 grid = (u32)((s->state.eval_hi - s->state.eval_lo + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, g_stream, s->state, status, tally);
-        break;
-    }
-    case SESSION_BYTECODE: {
-        const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->bytecode, status, tally);
-        break;
-    }
-    case SESSION_COPY: {
-        const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->copy, status, tally);
-        break;
-    }
-    case SESSION_SIGN: {
-        const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(sign_units_kernel, dim3(grid), dim3(256), 0, g_stream, s->sign, status, tally);
-        break;
-    }
-    case SESSION_KECCAK: {
-        const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(keccak_table_kernel, dim3(grid), dim3(256), 0, g_stream, s->keccak_gen, status, s->d_tally);
-        break;
-    }
-    case SESSION_ASSIGN: {
-        const AssignArgs& a = s->assign;
-        const u32 cap = a.mask + 1u;
-        hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, g_stream, a.slots, cap);
-        hipLaunchKernelGGL(assign_insert_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
-        hipLaunchKernelGGL(assign_mark_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
-        hipLaunchKernelGGL(assign_scan_kernel, dim3(1), dim3(1024), 0, g_stream, a);
-        hipLaunchKernelGGL(assign_rank_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a);
-        hipLaunchKernelGGL(assign_rows_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, g_stream, a, status, s->d_tally);
-        break;
-    }
-    case SESSION_ECDSA: {
-        // 64-lane blocks: 2^14 signatures are only 256 wavefronts, one per CU
-        const u32 grid = (u32)((s->n + 63) / 64);
-        hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(grid), dim3(64), 0, g_stream, s->ecdsa, status, s->d_tally);
-        break;
-    }
-    case SESSION_BCA: {
-        const BcaArgs& a = s->bca;
-        const u32 gc = (u32)((a.n_codes + 63) / 64), gk = (u32)((a.n_chunks + 63) / 64);
-        if (a.n_codes) {
-            hipLaunchKernelGGL(bca_track_kernel, dim3(gc), dim3(64), 0, g_stream, a);
-            hipLaunchKernelGGL(bca_chunk_kernel, dim3(gk ? gk : 1), dim3(64), 0, g_stream, a);
-            hipLaunchKernelGGL(bca_prefix_kernel, dim3(gc), dim3(64), 0, g_stream, a);
-            hipLaunchKernelGGL(bca_rlc_kernel, dim3(gk ? gk : 1), dim3(64), 0, g_stream, a);
-        }
-        hipLaunchKernelGGL(bca_rows_kernel, dim3((u32)((a.n_out + 255) / 256)), dim3(256), 0, g_stream, a, status, s->d_tally);
-        break;
-    }
-    case SESSION_EXP: {
-        const u32 grid = (u32)((s->n + 255) / 256);
-        hipLaunchKernelGGL(exp_rows_kernel, dim3(grid), dim3(256), 0, g_stream, s->exp, status, tally);
-        break;
-    }
+    case SESSION_STATE: zk_launch_state_rows(s->stream, s->state, status, tally); break;
+    case SESSION_BYTECODE: zk_launch_bytecode_rows(s->stream, s->bytecode, status, tally); break;
+    case SESSION_COPY: zk_launch_copy_rows(s->stream, s->copy, status, tally); break;
+    case SESSION_SIGN: zk_launch_sign_units(s->stream, s->sign, status, tally); break;
+    case SESSION_EXP: zk_launch_exp_rows(s->stream, s->exp, status, tally); break;
+    case SESSION_KECCAK: zk_launch_keccak_table(s->stream, s->keccak_gen, status, s->d_tally); break;
+    case SESSION_ASSIGN: zk_launch_state_assign(s->stream, s->assign, status, s->d_tally); break;
+    case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
+    case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
-        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, g_stream)); }
-        const int block = 256;
-        const u32 grid = (u32)((s->n + block - 1) / block);
+        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; }
+        const u32 grid = (u32)((s->n + 255) / 256);
         const u32 cold_grid = s->evm.perm ? (grid < 256u ? grid : 256u) : grid;
         // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first); then the
-        // rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces
-        if (evm_ext_events) {
-            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, e0, nullptr, 0,
-                                  s->evm, (const u32*)s->d_group_start, status, s->d_tally);
-            hipExtLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(cold_grid), dim3(block), 0, g_stream, nullptr, e1, 0,
-                                  s->evm, (const u32*)s->d_group_start, status, s->d_tally);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_ALL, ZK_HOT_OCC>), dim3(grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_COLD, 1>), dim3(cold_grid), dim3(block), 0, g_stream, s->evm, s->d_group_start, status, s->d_tally);
-        }
+        // rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces.  With the sorted
+        // mapping the two timing events ride on the dispatches themselves (no event packets between the kernels).
+        zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr);
+        zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
         break;
     }
     }
-    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e1, g_stream));
+    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e1, s->stream));
     HIP_TRY(hipGetLastError());
     s->launches++;
     return 0;
@@ -1516,9 +1175,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
 
 extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ARG_TRY(s && r, "zk_collect: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
     ZkTally t;
-    HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     double ms = 0;
     u32 timed = s->launches < (u32)MAX_EVENT_PAIRS ? s->launches : (u32)MAX_EVENT_PAIRS;
     for (u32 k = 0; k < timed; k++) {
@@ -1538,8 +1198,10 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
 
 extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
     ARG_TRY(s && status_host, "zk_read_status: bad arguments");
-    HIP_TRY(hipMemcpyAsync(status_host, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    ARG_TRY(!s->status_external, "zk_read_status: the last pass wrote its statuses to the caller's status_dev buffer, not the session's");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(status_host, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -1558,7 +1220,8 @@ extern "C" int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint
 }
 
 extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts) {
-    ARG_TRY(g_device >= 0, "zk_fr_op: call zk_init first");
+    ARG_TRY(t_device >= 0, "zk_fr_op: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
     ARG_TRY(a && b && out, "zk_fr_op: null pointer");
     if (n == 0) return 0;
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
@@ -1569,17 +1232,17 @@ extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* 
         HIP_TRY(hipMalloc(&ta, n * 32));
         HIP_TRY(hipMalloc(&tb, n * 32));
         HIP_TRY(hipMalloc(&to, n * 32));
-        HIP_TRY(hipMemcpyAsync(ta, a, n * 32, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(tb, b, n * 32, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(ta, a, n * 32, hipMemcpyHostToDevice, t_stream));
+        HIP_TRY(hipMemcpyAsync(tb, b, n * 32, hipMemcpyHostToDevice, t_stream));
         da = (const u64*)ta;
         db = (const u64*)tb;
         dout = (u64*)to;
     }
-    hipLaunchKernelGGL(fr_op_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, g_stream, op, da, db, dout, n);
+    hipLaunchKernelGGL(fr_op_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, t_stream, op, da, db, dout, n);
     HIP_TRY(hipGetLastError());
     if (!dev) {
-        HIP_TRY(hipMemcpyAsync(out, to, n * 32, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpyAsync(out, to, n * 32, hipMemcpyDeviceToHost, t_stream));
+        HIP_TRY(hipStreamSynchronize(t_stream));
         (void)hipFree(ta);
         (void)hipFree(tb);
         (void)hipFree(to);

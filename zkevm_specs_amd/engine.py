@@ -43,6 +43,10 @@ class Session:
         self._keep = keepalive
 
     def launch(self, status_dev=None):
+        if status_dev is not None:
+            _expect(status_dev, "status_dev", 4, (self.n,))
+            if not _is_contiguous(status_dev):
+                raise ValueError("status_dev must be contiguous")
         check(_lib.load().zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch")
 
     def collect(self):
@@ -53,6 +57,12 @@ class Session:
     def run(self):
         self.launch()
         return self.collect()
+
+    def set_stream(self, stream):
+        """Bind the session to another HIP stream of its device (a torch.cuda.Stream, a raw handle, or None = the
+        engine's own stream); passes already enqueued are waited for first."""
+        h = getattr(stream, "cuda_stream", stream)
+        check(_lib.load().zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream")
 
     def set_range(self, row_lo, row_hi):
         """State sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
@@ -81,15 +91,42 @@ class Session:
             pass
 
 
-def _prep(arrs):
+def _is_contiguous(a):
+    return a.is_contiguous() if hasattr(a, "is_contiguous") else a.flags["C_CONTIGUOUS"]
+
+
+def _itemsize(a):
+    return a.element_size() if hasattr(a, "element_size") else a.dtype.itemsize
+
+
+def _expect(a, name, itemsize, shape):
+    """Wire-format check of one argument: element size (uint64 cells travel as int64 tensors on the device, so the size
+    is what is checked, plus 'integer') and shape (None = any extent).  The kernels index these buffers blindly."""
+    if a is None:
+        return
+    kind_ok = (not a.dtype.is_floating_point and not a.dtype.is_complex) if hasattr(a, "is_cuda") else a.dtype.kind in "iu"
+    if not kind_ok or _itemsize(a) != itemsize:
+        raise TypeError(f"{name}: expected {itemsize}-byte integers, got {a.dtype}")
+    if len(a.shape) != len(shape) or any(e is not None and int(d) != e for d, e in zip(a.shape, shape)):
+        raise ValueError(f"{name}: expected shape {tuple('n' if e is None else e for e in shape)}, got {tuple(a.shape)}")
+
+
+def _prep(arrs, outputs=()):
+    """Host arrays are made C-contiguous (a copy is fine: they are staged anyway); device tensors are used in place.
+    `outputs`: indices of buffers the device WRITES — those must already be contiguous (a silent copy would swallow
+    the results)."""
     dev = [_is_device(a) for a in arrs if a is not None]
     if any(dev) and not all(dev):
         raise ValueError("mix of host and device buffers")
     is_dev = bool(dev) and all(dev)
     out = []
-    for a in arrs:
+    for k, a in enumerate(arrs):
         if a is None:
             out.append(None)
+        elif k in outputs:
+            if not _is_contiguous(a):
+                raise ValueError("output buffer must be contiguous")
+            out.append(a)
         elif is_dev:
             out.append(a.contiguous())
         else:
@@ -112,6 +149,9 @@ def _randomness_cells(randomness, like):
 def open_state(rows, flags, mpt, device=None):
     """rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4] -> Session"""
     lib = _lib.init(device)
+    _expect(rows, "state rows", 8, (57, None, 4))
+    _expect(flags, "state flags", 4, (rows.shape[1],))
+    _expect(mpt, "mpt", 8, (None, 12, 4))
     (rows, flags, mpt), opts = _prep([rows, flags, mpt])
     n = rows.shape[1]
     m = mpt.shape[0] if mpt is not None else 0
@@ -130,6 +170,13 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
     lib = _lib.init(device)
     names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
              "aux_kind", "withdrawals", "sig", "ecc"]
+    cells = {"steps": 13, "rw": 14, "bytecode": 6, "tx": 5, "block": 4, "copy": 14, "keccak": 5, "exp": 11, "withdrawals": 4,
+             "sig": 9, "ecc": 13, "aux": None}
+    for k, nc in cells.items():
+        _expect(wire.get(k), k, 8, (None, nc, 4))
+    for k, of in (("rw_flags", "rw"), ("tx_flags", "tx"), ("block_flags", "block"), ("aux_kind", "steps")):
+        if wire.get(k) is not None and wire.get(of) is not None:
+            _expect(wire[k], k, 4, (wire[of].shape[0],))
     arrs, opts = _prep([wire.get(k) for k in names])
     a = dict(zip(names, arrs))
 
@@ -168,6 +215,9 @@ def open_bytecode(rows, keccak, randomness, device=None):
     """rows uint64[12, n, 4], keccak uint64[m, 5, 4], randomness uint64[4] (or an int) -> Session"""
     lib = _lib.init(device)
     randomness = _randomness_cells(randomness, rows)
+    _expect(rows, "bytecode rows", 8, (12, None, 4))
+    _expect(keccak, "keccak", 8, (None, 5, 4))
+    _expect(randomness, "randomness", 8, (4,))
     (rows, keccak, randomness), opts = _prep([rows, keccak, randomness])
     n = rows.shape[1]
     m = keccak.shape[0] if keccak is not None else 0
@@ -180,6 +230,7 @@ def open_bytecode(rows, keccak, randomness, device=None):
 def open_exp(rows, device=None):
     """rows uint64[21, n, 4] -> Session"""
     lib = _lib.init(device)
+    _expect(rows, "exp rows", 8, (21, None, 4))
     (rows,), opts = _prep([rows])
     h = ctypes.c_void_p()
     check(lib.zk_exp_open(_lib.ptr(rows), rows.shape[1], opts, ctypes.byref(h)), "zk_exp_open")
@@ -190,6 +241,11 @@ def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags,
     """Copy circuit session: rows uint64[20, n, 4] + flags, randomness (int or uint64[4]), EVM-format tables."""
     lib = _lib.init(device)
     randomness = _randomness_cells(randomness, rows)
+    _expect(rows, "copy rows", 8, (20, None, 4))
+    _expect(row_flags, "copy row_flags", 4, (rows.shape[1],))
+    _expect(rw, "rw", 8, (None, 14, 4))
+    _expect(bytecode, "bytecode", 8, (None, 6, 4))
+    _expect(tx, "tx", 8, (None, 5, 4))
     arrs, opts = _prep([rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags])
     rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags = arrs
 
@@ -215,6 +271,11 @@ def open_sign(wire, randomness, is_sig, device=None):
     lib = _lib.init(device)
     randomness = _randomness_cells(randomness, wire.get("bytes"))
     names = ["bytes", "cells", "meta", "keccak", "tx_rows", "tx_flags"]
+    _expect(wire.get("bytes"), "sign bytes", 1, (None, 9, 32))
+    _expect(wire.get("cells"), "sign cells", 8, (8, wire["bytes"].shape[0], 4))
+    _expect(wire.get("meta"), "sign meta", 4, (wire["bytes"].shape[0], 4))
+    _expect(wire.get("keccak"), "keccak", 8, (None, 5, 4))
+    _expect(wire.get("tx_rows"), "tx_rows", 8, (None, 5, 4))
     arrs, opts = _prep([wire.get(k) for k in names] + [randomness])
     a = dict(zip(names + ["r"], arrs))
 
@@ -266,7 +327,10 @@ def open_keccak(data, offsets, randomness, mode=KECCAK_MODE_CIRCUIT, rows_dev=No
         if _is_device(data):
             import torch
             randomness = torch.from_numpy(randomness.view(np.int64)).to(data.device)
-    (data, offsets, randomness, rows_dev), opts = _prep([data, offsets, randomness, rows_dev])
+    _expect(data, "keccak data", 1, (None,))
+    _expect(offsets, "keccak offsets", 8, (None,))
+    _expect(rows_dev, "keccak rows_dev", 8, (int(offsets.shape[0]) - 1, 5, 4))
+    (data, offsets, randomness, rows_dev), opts = _prep([data, offsets, randomness, rows_dev], outputs=(3,))
     n = int(offsets.shape[0]) - 1
     n_bytes = int(data.shape[0]) if data is not None else 0
     h = ctypes.c_void_p()
@@ -316,8 +380,14 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     row_flags_dev uint32[n] / mpt_dev uint64[n, 12, 4] (optional CUDA tensors) then receive the outputs, ready
     to be handed to open_state()."""
     lib = _lib.init(device)
-    (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([ops, op_flags, rows_dev, row_flags_dev, mpt_dev])
+    _expect(ops, "state ops", 8, (12, None, 4))
     n = int(ops.shape[1])
+    _expect(op_flags, "op_flags", 4, (n,))
+    _expect(rows_dev, "rows_dev", 8, (57, n, 4))
+    _expect(row_flags_dev, "row_flags_dev", 4, (n,))
+    _expect(mpt_dev, "mpt_dev", 8, (n, 12, 4))
+    (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([ops, op_flags, rows_dev, row_flags_dev, mpt_dev],
+                                                                    outputs=(2, 3, 4))
     h = ctypes.c_void_p()
     check(lib.zk_state_assign_open(_lib.ptr(ops), _lib.ptr(op_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev),
                                    _lib.ptr(mpt_dev), opts, ctypes.byref(h)), "zk_state_assign_open")
@@ -339,7 +409,12 @@ def open_bytecode_assign(in_rows, offsets, lengths, k, randomness, rows_dev=None
     uint64[12, 2^k, 4] receiving them in place (ready for open_bytecode)."""
     lib = _lib.init(device)
     randomness = _randomness_cells(randomness, in_rows)
-    (in_rows, offsets, lengths, randomness, rows_dev), opts = _prep([in_rows, offsets, lengths, randomness, rows_dev])
+    _expect(in_rows, "unrolled bytecode rows", 8, (None, 6, 4))
+    _expect(offsets, "offsets", 8, (int(lengths.shape[0]) + 1,))
+    _expect(lengths, "lengths", 8, (None,))
+    _expect(rows_dev, "rows_dev", 8, (12, 1 << int(k), 4))
+    (in_rows, offsets, lengths, randomness, rows_dev), opts = _prep([in_rows, offsets, lengths, randomness, rows_dev],
+                                                                    outputs=(4,))
     n_rows, n_codes = int(in_rows.shape[0]), int(lengths.shape[0])
     h = ctypes.c_void_p()
     check(lib.zk_bytecode_assign_open(_lib.ptr(in_rows) if n_rows else None, n_rows, _lib.ptr(offsets), _lib.ptr(lengths) if n_codes else None,
@@ -358,7 +433,8 @@ def open_ecdsa(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, out_dev=None, out_
     (0 verified, 1 not verified, else the exception's code; include/zkevm_hip.h).  out_dev: optional CUDA uint32
     tensor receiving status i at element i * out_stride (e.g. the units' meta tensor with stride 4)."""
     lib = _lib.init(device)
-    (sig_bytes, v, out_dev), opts = _prep([sig_bytes, v, out_dev])
+    _expect(sig_bytes, "signature bytes", 1, (None, 5 if layout == ECDSA_LAYOUT_PACKED else 9, 32))
+    (sig_bytes, v, out_dev), opts = _prep([sig_bytes, v, out_dev], outputs=(2,))
     n = int(sig_bytes.shape[0])
     h = ctypes.c_void_p()
     check(lib.zk_ecdsa_open(_lib.ptr(sig_bytes), int(layout), _lib.ptr(v), int(v_stride), n, _lib.ptr(out_dev),

@@ -3,7 +3,7 @@ witness set on one GPU; ranks hold independent shards and all-reduce the tally (
 
 The reference has no super-circuit driver: each circuit has its own `verify_*` entry and
 they are only related through the tables they share.  This module launches the same C-ABI sessions the per-circuit
-mirrors use, back to back on one stream, and sums their tallies.  What is shared in the synthetic witness:
+mirrors use, each session bound to its own HIP stream (zk_session_set_stream), and sums their tallies.  What is shared in the synthetic witness:
   * the contracts the EVM trace executes ARE the byte strings of the Bytecode circuit's rows: the circuit rows are assigned
     on the device (`zk_bytecode_assign`) from the very bytecode table the EVM circuit looks up (its rows, sorted by
     hash / tag / index, are the unrolled bytecodes), and the code hashes are real keccak-256 digests taken from the
@@ -132,41 +132,24 @@ class SuperCircuit:
         if hasattr(ops, "is_cuda"):
             import torch
 
-            self._main = torch.cuda.current_stream().cuda_stream
+            torch.cuda.synchronize()  # witness uploads / open-time packing ran on the stream the sessions were opened on
             self._streams = {k: torch.cuda.Stream() for k in self.sessions}
-            torch.cuda.synchronize()  # witness uploads / open-time packing ran on the main stream
-
-    def _on(self, k):
-        if self._streams is not None:
-            from . import _lib
-            _lib.check(_lib.load().zk_set_stream(self._streams[k].cuda_stream), "zk_set_stream")
-
-    def _back(self):
-        if self._streams is not None:
-            from . import _lib
-            _lib.check(_lib.load().zk_set_stream(self._main), "zk_set_stream")
+            for k, s in self.sessions.items():
+                s.set_stream(self._streams[k])
 
     def launch(self):
-        for k, s in self.sessions.items():
-            self._on(k)
+        for s in self.sessions.values():
             s.launch()
-        self._back()
 
     def collect(self):
-        results = {}
-        for k, s in self.sessions.items():
-            self._on(k)
-            results[k] = s.collect()
-        self._back()
+        results = {k: s.collect() for k, s in self.sessions.items()}
         total = sum(r.fail_count for r in results.values())
         first = next(((k, r.first_fail_row, r.first_fail_code) for k, r in results.items() if not r.ok), None)
         return results, total, first
 
     def close(self):
-        for k, s in self.sessions.items():
-            self._on(k)
+        for s in self.sessions.values():
             s.close()
-        self._back()
 
     def __enter__(self):
         return self
