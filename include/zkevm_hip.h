@@ -248,8 +248,9 @@ int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, u
  *             util/ec.py:93).
  *      v: optional recovery ids, v[i * v_stride] (the Sig circuit's chip builds Signature(vrs=[v, r, s]) — for Sig
  *      units pass meta + 3 with stride 4; NULL = the Tx circuit's fixed 0).  Status per signature: 0 verified, 1 not verified, (ZK_KIND_UNSUPPORTED << 24) | 1 = eth_keys
- *      BadSignature (v outside {0, 1}, r or s >= N), (ZK_KIND_UNSUPPORTED << 24) | 2 = a public-key coordinate >= P
- *      (outside the engine's domain), (ZK_KIND_VALUE_ERROR << 24) | 3 = pow(0, -1, P) in the final point addition.
+ *      BadSignature (v outside {0, 1}, r or s outside (0, N)), (ZK_KIND_UNSUPPORTED << 24) | 2 = a public-key coordinate >= P
+ *      (outside the engine's domain).  Public keys that are not on the curve are evaluated with eth-keys' Jacobian case
+ *      analysis (a Y == 0 point is the point at infinity, inv(0) == 0), so their verdicts are reproducible too.
  *      out_dev (DEVICE pointer, optional): out_dev[i * out_stride] = status, e.g. meta + 0 with stride 4 to fill the
  *      units' meta column in place.  zk_launch / zk_collect / zk_read_status as for the circuits (the tally counts
  *      the signatures that did not verify). */

@@ -1,5 +1,19 @@
 """Stand-in for eth-keys 0.4.0 (pure-Python secp256k1; API surface of SURVEY.md Appendix B).
 
+Verification restates the package's published native backend (eth_keys/backends/native/ecdsa.py + jacobian.py, the
+backend a plain install of the reference uses: coincurve is not a dependency) as faithfully as it can be written down
+without the source at hand:
+  * `Signature(vrs=...)`: v in {0, 1}; r and s must satisfy 0 < value < N (`validate_signature_r_or_s`: `validate_gt(value, 0)`
+    + `validate_lt_secpk1n`), violations raise BadSignature;
+  * `ecdsa_raw_verify`: w = inv(s, N); u1 = z w mod N; u2 = r w mod N; (x, y) = fast_add(fast_multiply(G, u1),
+    fast_multiply(Q, u2)); return r == x (NOT x mod N) and r mod N != 0 and s mod N != 0;
+  * `inv(0, n) == 0` (extended Euclid with an early return), so the point at infinity (0, 0, 1) / (0, 0, 0) maps to (0, 0);
+  * Jacobian arithmetic with the case analysis of jacobian.py: a point whose Y is 0 IS the point at infinity for
+    `jacobian_add`; doubling it gives (0, 0, 0); equal X with different Y gives (0, 0, 1); MSB-first double-and-add.
+  For keys on the curve every correct group law gives the same verdict; the case analysis only matters for public keys
+  that are not on the curve (the reference never checks), e.g. a key with y = 0 is ignored altogether.
+tests/golden/ecdsa_openssl.npz pins the verdicts on curve points independently (signatures made by the image's OpenSSL).
+
 `KeyAPI.Signature(vrs=...)`, `.v/.r/.s`, `.recover_public_key_from_msg_hash`,
 `KeyAPI.PublicKey(bytes64)` with `.to_bytes/.to_canonical_address/.to_address`,
 `KeyAPI().ecdsa_verify`, `keys.PrivateKey(b32).sign_msg_hash` (RFC-6979) and `.public_key`.
@@ -92,7 +106,7 @@ class Signature:
             v = signature_bytes[64]
         if v not in (0, 1):
             raise BadSignature("v must be 0 or 1")
-        if not (0 <= r < N and 0 <= s < N):
+        if not (0 < r < N and 0 < s < N):  # validate_signature_r_or_s: validate_gt(value, 0), validate_lt_secpk1n(value)
             raise BadSignature("r/s out of range")
         self._v, self._r, self._s = v, r, s
 
@@ -124,14 +138,86 @@ def _recover(msg_hash, sig):
     return PublicKey(q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big"))
 
 
+def _nat_inv(a, n):
+    if a == 0:
+        return 0
+    lm, hm = 1, 0
+    low, high = a % n, n
+    while low > 1:
+        r = high // low
+        nm, new = hm - lm * r, high - low * r
+        lm, low, hm, high = nm, new, lm, low
+    return lm % n
+
+
+def _jac_double(p):
+    if not p[1]:
+        return (0, 0, 0)
+    ysq = (p[1] ** 2) % P
+    S = (4 * p[0] * ysq) % P
+    M = (3 * p[0] ** 2) % P  # curve parameter A = 0
+    nx = (M ** 2 - 2 * S) % P
+    ny = (M * (S - nx) - 8 * ysq ** 2) % P
+    nz = (2 * p[1] * p[2]) % P
+    return (nx, ny, nz)
+
+
+def _jac_add(p, q):
+    if not p[1]:
+        return q
+    if not q[1]:
+        return p
+    U1 = (p[0] * q[2] ** 2) % P
+    U2 = (q[0] * p[2] ** 2) % P
+    S1 = (p[1] * q[2] ** 3) % P
+    S2 = (q[1] * p[2] ** 3) % P
+    if U1 == U2:
+        if S1 != S2:
+            return (0, 0, 1)
+        return _jac_double(p)
+    H = U2 - U1
+    R = S2 - S1
+    H2 = (H * H) % P
+    H3 = (H * H2) % P
+    U1H2 = (U1 * H2) % P
+    nx = (R ** 2 - H3 - 2 * U1H2) % P
+    ny = (R * (U1H2 - nx) - S1 * H3) % P
+    nz = (H * p[2] * q[2]) % P
+    return (nx, ny, nz)
+
+
+def _from_jac(p):
+    z = _nat_inv(p[2], P)
+    return ((p[0] * z ** 2) % P, (p[1] * z ** 3) % P)
+
+
+def _jac_mul(a, n):
+    if a[1] == 0 or n == 0:
+        return (0, 0, 1)
+    if n == 1:
+        return a
+    if n < 0 or n >= N:
+        return _jac_mul(a, n % N)
+    if (n % 2) == 0:
+        return _jac_double(_jac_mul(a, n // 2))
+    return _jac_add(_jac_double(_jac_mul(a, n // 2)), a)
+
+
+def _fast_multiply(a, n):
+    return _from_jac(_jac_mul((a[0], a[1], 1), n))
+
+
+def _fast_add(a, b):
+    return _from_jac(_jac_add((a[0], a[1], 1), (b[0], b[1], 1)))
+
+
 def _verify(msg_hash, sig, pk):
     r, s = sig.r, sig.s
-    if not (1 <= r < N and 1 <= s < N):
-        return False
+    w = _nat_inv(s, N)
     z = int.from_bytes(msg_hash, "big")
-    w = _inv(s, N)
-    pt = _add(_mul(G, z * w % N), _mul(pk._point(), r * w % N))
-    return pt is not None and pt[0] % N == r
+    u1, u2 = z * w % N, r * w % N
+    x, _y = _fast_add(_fast_multiply(G, u1), _fast_multiply(pk._point(), u2))
+    return bool(r == x and (r % N) and (s % N))
 
 
 def _rfc6979(msg_hash, sk):

@@ -95,6 +95,48 @@ def test_oracle_matches_reference_chips(golden_dir):
     assert (g["util_status"] == 0).sum() >= 40 and (g["util_status"] == 1).sum() >= 15 and (g["util_status"] > 1).sum() >= 5
 
 
+def _openssl(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ecdsa_openssl.npz"))
+    return np.ascontiguousarray(g["sigs"]), g["verdict"].tolist()
+
+
+def _offcurve_cases():
+    """Public keys that are NOT on the curve, where eth-keys' case analysis decides: a key with y == 0 counts as the point
+    at infinity, so the signature is accepted iff r == (u1 G).x whatever x is; a key on another curve y^2 = x^3 + b' just
+    has to go through the same MSB-first chain.  (z, r, s) are built so that u1 G has x == r: z = k s, r = (k G).x."""
+    import random
+
+    rng = random.Random(77)
+    cases = []
+    for i in range(24):
+        k, s = rng.randrange(1, E.N), rng.randrange(1, E.N)
+        r = E.mul(E.G, k)[0]
+        if not 0 < r < E.N:
+            continue
+        z = k * s % E.N
+        x = rng.randrange(E.P)
+        cases.append((x, 0, z, r, s))                      # y == 0: ignored -> verified
+        cases.append((x, rng.randrange(1, E.P), z, r, s))  # off-curve, y != 0: garbage point added -> not verified
+        cases.append((x, 0, z ^ 1, r, s))                  # y == 0, wrong digest -> not verified
+    return E.pack(cases)
+
+
+def test_oracle_matches_openssl(golden_dir):
+    """the restated eth-keys algorithm agrees with OpenSSL's own verdict on every OpenSSL-made vector (curve points)"""
+    sigs, verdict = _openssl(golden_dir)
+    assert len(verdict) >= 256 and 100 <= sum(verdict) <= len(verdict) - 100
+    assert E.verify_packed(sigs, None) == verdict
+    st = E.verify_packed(_offcurve_cases(), None)
+    assert st[0::3] == [0] * (len(st) // 3) and st[1::3] == [1] * (len(st) // 3) and st[2::3] == [1] * (len(st) // 3)
+
+
+def test_kernel_logic_matches_openssl_and_offcurve_cases(golden_dir, hostsim):
+    sigs, verdict = _openssl(golden_dir)
+    assert _hostsim(hostsim, sigs, None, 0) == verdict
+    off = _offcurve_cases()
+    assert _hostsim(hostsim, off, None, 0) == E.verify_packed(off, None)
+
+
 def test_kernel_logic_matches_oracle(golden_dir, hostsim):
     g = np.load(os.path.join(golden_dir, "ecdsa_cases.npz"))
     v = np.ascontiguousarray(g["v"])
@@ -130,6 +172,20 @@ def test_unit_layout_reproduces_the_recorded_ecdsa_column(golden_dir, hostsim):
 
 
 # ---- GPU --------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_matches_openssl_vectors(golden_dir):
+    """the device verdicts on signatures made and judged by OpenSSL (nothing of this repository in the loop), through
+    both C entries (session and one-shot), and the off-curve keys where eth-keys' case analysis decides"""
+    from zkevm_specs_amd import engine, oneshot
+
+    sigs, verdict = _openssl(golden_dir)
+    assert engine.ecdsa_status(sigs).tolist() == verdict
+    res, status = oneshot.ecdsa_verify(sigs)
+    assert status.tolist() == verdict and res.fail_count == sum(verdict)
+    off = _offcurve_cases()
+    assert engine.ecdsa_status(off).tolist() == E.verify_packed(off, None)
+
+
 @pytest.mark.gpu
 def test_hip_matches_oracle(golden_dir):
     from zkevm_specs_amd import engine

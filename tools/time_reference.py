@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Time the REFERENCE ITSELF on the workloads bench.py measures (build container only: needs /root/reference and the
+dependency stand-ins under oracle/refshim; the GPU box has neither, so the result is committed under profiles/ and
+bench.py attaches it to `cpu_baseline.reference`).
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=oracle/refshim:/root/reference/src python3 tools/time_reference.py \
+        > profiles/r02_cpu_reference.json
+
+What is timed, single process, one core (the reference has no parallelism):
+  * EVM circuit: `verify_steps(tables, steps)` (evm_circuit/main.py:14) on prefixes of bench.py's own config-3 trace
+    (synth_evm_trace(2^18, seed=3)) with N = 2^4, 2^6, 2^8 step pairs; each prefix carries the RW / bytecode rows its steps
+    touch (the reference's lookups scan the whole table, table.py:864-884, so the table size is part of the cost).  The
+    cost model t = steps * (a + b * table_rows) is fitted by least squares and extrapolated to the full 2^18-step trace
+    with its full tables — EXTRAPOLATED, NOT MEASURED (the full run would take months).
+  * State circuit: `check_state_row` over all 2^16 rows of bench.py's config-2 witness (state_circuit.py:492).
+  * Bytecode circuit: `check_bytecode_row` over config 1 (256-byte contract, k = 9).
+  * Exp circuit: `verify_exp_circuit` over 2^12 rows.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def evm_prefix(w, n_pairs):
+    """the first n_pairs step pairs of the trace with only the table rows those steps can look up"""
+    steps = w["steps"][: n_pairs + 1]
+    rwc_lo = int(steps[0, 1, 0])
+    rwc_hi = int(steps[-1, 1, 0])
+    rwc = w["rw"][:, 0, 0].astype(np.int64)
+    keep = (rwc >= rwc_lo) & (rwc < max(rwc_hi, rwc_lo + 1) + 64)  # + the pair's own lookups past next.rw_counter
+    # bytecode rows: the contracts those steps execute (whole contracts: opcode / push-data lookups index into them)
+    hashes = {tuple(steps[i, 5:7].reshape(-1).tolist()) for i in range(steps.shape[0])}
+    bk = np.array([tuple(r[0:2].reshape(-1).tolist()) in hashes for r in w["bytecode"]])
+    out = {k: v for k, v in w.items()}
+    out["aux"], out["aux_kind"] = w["aux"][: n_pairs + 1], w["aux_kind"][: n_pairs + 1]
+    out["steps"], out["rw"], out["rw_flags"], out["bytecode"] = steps, w["rw"][keep], w["rw_flags"][keep], w["bytecode"][bk]
+    return out
+
+
+def time_evm():
+    from oracle.gen_golden_evm import unflatten
+    from zkevm_specs.evm_circuit.main import verify_steps
+    from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+    from tests.evm_cases import with_defaults
+
+    w = synth_evm_trace(1 << 18, seed=3)
+    meta = w.pop("meta")
+    w = with_defaults(w)
+    pts = []
+    for log_n in (4, 6, 8):
+        n = 1 << log_n
+        pw = evm_prefix(w, n)
+        tables, steps = unflatten(pw)
+        t0 = time.perf_counter()
+        verify_steps(tables, steps)  # raises on any failing pair: the trace must be valid for the reference too
+        dt = time.perf_counter() - t0
+        pts.append({"step_pairs": n, "rw_rows": int(pw["rw"].shape[0]), "bytecode_rows": int(pw["bytecode"].shape[0]),
+                    "seconds": dt, "pairs_per_s": n / dt})
+        print(f"evm 2^{log_n}: {dt:.2f} s", file=sys.stderr, flush=True)
+    # t / steps = a + b * (rw_rows + bytecode_rows): two-parameter least squares over the three sizes
+    x = np.array([p["rw_rows"] + p["bytecode_rows"] for p in pts], dtype=np.float64)
+    y = np.array([p["seconds"] / p["step_pairs"] for p in pts])
+    A = np.stack([np.ones_like(x), x], axis=1)
+    (a, b), *_ = np.linalg.lstsq(A, y, rcond=None)
+    full_tables = meta["n_rw"] + meta["n_bytecode"]
+    per_step = a + b * full_tables
+    return {"measured": pts,
+            "fit": {"model": "seconds_per_step_pair = a + b * (rw_rows + bytecode_rows)", "a": float(a), "b": float(b)},
+            "extrapolated_2p18": {"step_pairs": (1 << 18) - 1, "table_rows": int(full_tables), "seconds": float(per_step * ((1 << 18) - 1)),
+                                  "pairs_per_s": float(1.0 / per_step), "note": "EXTRAPOLATED from the fit, not measured"}}
+
+
+def time_state():
+    from zkevm_specs.evm_circuit.table import MPTTableRow
+    from zkevm_specs.state_circuit import Row, Tables, check_state_row
+    from zkevm_specs.util import FQ, Word, WordOrValue
+
+    from oracle import wire
+    from zkevm_specs_amd.synth import synth_state_witness
+
+    n = 1 << 16
+    cols, flags, mpt = synth_state_witness(n, seed=2)
+    W = lambda lo, hi: Word((FQ(lo), FQ(hi)), check=False)  # noqa: E731
+
+    def wov(lo, hi, is_word):
+        if is_word:
+            return WordOrValue(W(lo, hi))
+        v = WordOrValue(FQ(lo))
+        v.hi = FQ(hi)
+        return v
+
+    rows = []
+    for c, f in zip(wire.colmajor_to_rows(cols), flags):
+        rows.append(Row(FQ(c[0]), FQ(c[1]), (FQ(c[2]), FQ(c[3]), FQ(c[4]), FQ(c[5]), W(c[6], c[7])), tuple(FQ(x) for x in c[8:18]),
+                        tuple(FQ(x) for x in c[18:50]), wov(c[50], c[51], f & 1), wov(c[52], c[53], f & 2), W(c[54], c[55]), FQ(c[56])))
+    tables = Tables(set(MPTTableRow(FQ(m[0]), FQ(m[1]), W(m[2], m[3]), W(m[4], m[5]), W(m[6], m[7]), W(m[8], m[9]), W(m[10], m[11]))
+                        for m in wire.rowmajor_to_rows(mpt)))
+    t0 = time.perf_counter()
+    for i, row in enumerate(rows):
+        check_state_row(row, rows[(i - 1) % n], rows[(i + 1) % n], tables)
+    dt = time.perf_counter() - t0
+    return {"rows": n, "mpt_rows": int(mpt.shape[0]), "seconds": dt, "rows_per_s": n / dt}
+
+
+def time_bytecode():
+    from zkevm_specs.bytecode_circuit import assign_push_table, check_bytecode_row
+    from zkevm_specs.util import FQ
+
+    from oracle.gen_golden_rows import unflatten_bytecode
+    from zkevm_specs_amd.synth import synth_bytecode_witness
+
+    code = bytes(np.random.default_rng(1).integers(0, 256, 256, dtype=np.uint8))
+    r = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % (1 << 253)
+    cols, keccak = synth_bytecode_witness([code], 9, r)
+    rows, keccak_table = unflatten_bytecode(cols, keccak)
+    push_table = assign_push_table()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for i, row in enumerate(rows):
+            check_bytecode_row(row, rows[(i + 1) % len(rows)], push_table, keccak_table, FQ(r))
+    dt = (time.perf_counter() - t0) / reps
+    return {"rows": len(rows), "seconds": dt, "rows_per_s": len(rows) / dt, "config": "256-byte contract, k = 9 (BASELINE configs[0])"}
+
+
+def time_exp():
+    from zkevm_specs.exp_circuit import verify_exp_circuit
+
+    from oracle.gen_golden_rows import unflatten_exp
+    from zkevm_specs_amd.synth import synth_exp_witness
+
+    cols = synth_exp_witness(1 << 12, seed=5)
+    rows = unflatten_exp(cols)
+
+    class Circuit:
+        def table(self):
+            return rows
+
+    t0 = time.perf_counter()
+    verify_exp_circuit(Circuit())
+    dt = time.perf_counter() - t0
+    return {"rows": len(rows), "seconds": dt, "rows_per_s": len(rows) / dt}
+
+
+def main():
+    import platform
+
+    out = {"what": "the unmodified reference (/root/reference, tag 2024_08_07) on oracle/refshim dependency stand-ins, pure Python, 1 process / 1 core",
+           "host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+                    "cores_total": os.cpu_count(), "cores_used": 1, "python": platform.python_version()}}
+    out["bytecode"] = time_bytecode()
+    out["exp"] = time_exp()
+    out["state"] = time_state()
+    out["evm"] = time_evm()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rp
 pids=()
 for u in $UNITS; do
     # rebuild a unit only when one of the sources is newer than its object (headers are shared: any header change rebuilds all)
-    if [ ! -f "$OUT/$u.o" ] || [ -n "$(find . -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name "$u.hip" -o -name build.sh \) -newer "$OUT/$u.o" | head -1)" ] || [ -n "$ZK_EXTRA_FLAGS" ] || [ -f "$OUT/.extra_flags" ]; then
+    if [ ! -f "$OUT/$u.o" ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name "$u.hip" -o -name build.sh \) -newer "$OUT/$u.o" | head -1)" ] || [ -n "$ZK_EXTRA_FLAGS" ] || [ -f "$OUT/.extra_flags" ]; then
         ( $HIPCC $FLAGS -c -o "$OUT/$u.o" "$u.hip" 2> "$OUT/$u.log" || { cat "$OUT/$u.log"; exit 1; } ) &
         pids+=($!)
     fi

@@ -1,0 +1,145 @@
+// Device-side construction of the bytecode directory (ZkCodeDir, common.hpp) from the row-major bytecode table: the
+// same directory host_index.hpp's build_code_dir builds on the CPU (which the CPU logic harness keeps using), as a
+// handful of one-lane-per-row kernels, so that opening an EVM session over device-resident tables moves no table data
+// to the host and the open-time work is all device work that can be timed (bench.py `fresh_witness`).
+//
+// A code (= the rows of one bytecode hash) is "regular" when it has exactly one Header row (tag 1, index 0) and its Byte
+// rows (tag 2) are stored contiguously with indices 0..k-1 in increasing order — what Bytecode.table_assignments produces
+// (evm_circuit/typing.py:390-405).  Regular codes are addressed directly (header_row / byte_base + index); anything else
+// goes through the generic open-addressing index.  The order of the directory entries is whatever the atomics produce;
+// lookups only ever reach an entry through the slot table, by hash.
+#pragma once
+#include "common.hpp"
+
+struct DirBuild {
+    const u64* rows;   // [n][6][4]: hash lo, hi, field_tag, index, is_code, value
+    u32 n;
+    u32* big_slots;    // open addressing over the ROWS keyed by the hash cells: smallest row index of each group
+    u32* slot_entry;   // directory entry of the group that owns a big slot
+    u32 big_mask;
+    ZkCodeEntry* entries;
+    u32* n_entries;    // device counter
+    u32* e_headers;    // per entry: number of Header rows
+    u32* e_first;      // per entry: smallest Byte row
+    u32* e_last;       // per entry: largest Byte row
+    u32* e_bad;        // per entry: a row that rules out "regular"
+    u32* small_slots;  // the directory's own slot table (ZkCodeDir::slots)
+    u32 small_mask;
+    uint16_t* packed;  // ZkCodeDir::packed
+};
+
+__device__ __forceinline__ bool dirb_small(const u64* rows, u32 r, int c, u64& v) {
+    const u64* p = rows + ((u64)r * 6 + c) * 4;
+    v = p[0];
+    return (p[1] | p[2] | p[3]) == 0ull;
+}
+__device__ __forceinline__ bool dirb_same_hash(const u64* rows, u32 a, u32 b) {
+    const u64* p = rows + (u64)a * 24;
+    const u64* q = rows + (u64)b * 24;
+    bool eq = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) eq = eq && p[k] == q[k];
+    return eq;
+}
+__device__ __forceinline__ u32 dirb_hash_of_row(const u64* rows, u32 r) {
+    return (u32)zk_code_hash_key(fr_load(rows + (u64)r * 24), fr_load(rows + (u64)r * 24 + 4));
+}
+// slot of row r's group (the group must have been inserted)
+__device__ __forceinline__ u32 dirb_find(const DirBuild& d, u32 r) {
+    u32 s = dirb_hash_of_row(d.rows, r) & d.big_mask;
+    while (true) {
+        const u32 rep = d.big_slots[s];
+        if (rep != ZK_EMPTY_SLOT && dirb_same_hash(d.rows, rep, r)) return s;
+        s = (s + 1) & d.big_mask;
+    }
+}
+__global__ void dirb_insert_kernel(DirBuild d) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    u32 s = dirb_hash_of_row(d.rows, r) & d.big_mask;
+    while (true) {
+        u32 cur = d.big_slots[s];
+        if (cur == ZK_EMPTY_SLOT) {
+            cur = atomicCAS(&d.big_slots[s], ZK_EMPTY_SLOT, r);
+            if (cur == ZK_EMPTY_SLOT) return;
+        }
+        if (dirb_same_hash(d.rows, cur, r)) {  // same group: the slot keeps the smallest row index
+            atomicMin(&d.big_slots[s], r);
+            return;
+        }
+        s = (s + 1) & d.big_mask;
+    }
+}
+__global__ void dirb_leaders_kernel(DirBuild d) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    const u32 s = dirb_find(d, r);
+    if (d.big_slots[s] != r) return;
+    d.slot_entry[s] = atomicAdd(d.n_entries, 1u);
+}
+// the entries array is sized from the group count the leaders pass produced
+__global__ void dirb_init_kernel(DirBuild d) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    const u32 s = dirb_find(d, r);
+    if (d.big_slots[s] != r) return;
+    const u32 k = d.slot_entry[s];
+    ZkCodeEntry e;
+#pragma unroll
+    for (int q = 0; q < 8; q++) e.hash[q] = d.rows[(u64)r * 24 + q];
+    e.header_row = e.byte_base = e.n_bytes = e.regular = 0;
+    e.header_value = 0;
+    e.header_ok = e.pad = 0;
+    d.entries[k] = e;
+    d.e_headers[k] = 0;
+    d.e_first[k] = 0xffffffffu;
+    d.e_last[k] = 0;
+    d.e_bad[k] = 0;
+}
+__global__ void dirb_accumulate_kernel(DirBuild d) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    const u32 k = d.slot_entry[dirb_find(d, r)];
+    u64 tag, index, is_code, value;
+    const bool small = dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index);
+    if (!small || (tag != 1 && tag != 2) || (tag == 1 && index != 0)) {
+        d.e_bad[k] = 1;
+    } else if (tag == 1) {
+        atomicAdd(&d.e_headers[k], 1u);
+        d.entries[k].header_row = r;  // exactly one writer when the code turns out regular
+    } else {
+        atomicMin(&d.e_first[k], r);
+        atomicMax(&d.e_last[k], r);
+        atomicAdd(&d.entries[k].n_bytes, 1u);
+    }
+    uint16_t p = 0;
+    if (dirb_small(d.rows, r, 4, is_code) && dirb_small(d.rows, r, 5, value) && is_code < 2 && value < 256)
+        p = (uint16_t)(0x8000u | (u32)(is_code << 8) | (u32)value);
+    d.packed[r] = p;
+}
+// Byte rows must sit at first_byte + index
+__global__ void dirb_check_kernel(DirBuild d) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.n) return;
+    u64 tag, index;
+    if (!(dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index)) || tag != 2) return;
+    const u32 k = d.slot_entry[dirb_find(d, r)];
+    if (index != (u64)(r - d.e_first[k])) d.e_bad[k] = 1;
+}
+__global__ void dirb_finalize_kernel(DirBuild d) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *d.n_entries) return;
+    ZkCodeEntry& e = d.entries[k];
+    const u32 nb = e.n_bytes;
+    const bool regular = !d.e_bad[k] && d.e_headers[k] == 1u && (nb == 0 || d.e_last[k] - d.e_first[k] + 1u == nb);
+    if (regular) {
+        u64 hv, hc;
+        e.byte_base = nb ? d.e_first[k] : 0u;
+        if (dirb_small(d.rows, e.header_row, 5, hv) & dirb_small(d.rows, e.header_row, 4, hc) && hc == 0) { e.header_value = hv; e.header_ok = 1; }
+        e.regular = 1;
+    } else {
+        e.header_row = e.byte_base = e.n_bytes = 0;
+    }
+    u32 s = (u32)zk_code_hash_key(fr_load(e.hash), fr_load(e.hash + 4)) & d.small_mask;
+    while (atomicCAS(&d.small_slots[s], ZK_EMPTY_SLOT, k) != ZK_EMPTY_SLOT) s = (s + 1) & d.small_mask;
+}

@@ -4,16 +4,17 @@
 // Reference call sites: `ECDSAVerifyChip.verify` src/zkevm_specs/tx_circuit.py:147-158 and util/ec.py:109-117 —
 // `KeyAPI.Signature(vrs=[v, r, s])`, `KeyAPI.PublicKey(x_be + y_be)`, `KeyAPI().ecdsa_verify(msg_hash, sig, pk)`.
 // The arithmetic lives in third-party eth-keys 0.4.0 (setup.cfg:24; not under /root/reference): its native backend's
-// `ecdsa_raw_verify` — w = s^-1 mod N, u1 = z w, u2 = r w, R = u1 G + u2 Q, accept iff R != O and R.x mod N == r —
-// with `Signature` rejecting v outside {0, 1} and r, s outside [0, N) (BadSignature), restated by
-// oracle/ecdsa_oracle.py.  u2 * Q is the same LSB-first double-and-add and the point addition makes the same case
-// analysis as the affine formulas there (x1 == x2: y1 + y2 == 0 -> O, else the tangent at p1), so that the verdict
-// also agrees for public keys that are not on the curve (the group-law formulas never use b); u1 * G (G is on the
-// curve: any correct method yields the same point) uses a fixed-base table of 64 four-bit windows.
+// `ecdsa_raw_verify` — w = inv(s, N), u1 = z w, u2 = r w, (x, y) = fast_add(fast_multiply(G, u1), fast_multiply(Q, u2)),
+// accept iff r == x — with `Signature` rejecting v outside {0, 1} and r, s outside (0, N) (BadSignature), restated by
+// oracle/ecdsa_oracle.py and pinned on curve points by OpenSSL-made vectors (tests/golden/ecdsa_openssl.npz).
+// u2 * Q is the same MSB-first double-and-add with the same case analysis (Y == 0 is the point at infinity, equal X
+// with different Y gives (0, 0, 1), inv(0) == 0), so that the verdict also agrees for public keys that are not on the
+// curve (the formulas never use b); u1 * G (G is on the curve: any correct method yields the same point) uses a
+// fixed-base table of 64 four-bit windows.
 //
 // Field elements: 8 x u32 limbs; the scalar field N in Montgomery form (R = 2^256), the base field P as plain residues
 // (its special form makes the folded product cheaper than a Montgomery one);
-// points: Jacobian (X, Y, Z) over P with an explicit infinity flag.
+// points: Jacobian (X, Y, Z) over P, infinity = "Y == 0".
 #pragma once
 #include "common.hpp"
 #include "secp_constants.h"
@@ -187,19 +188,27 @@ ZK_NOINLINE Fr sp_inv(Fr aM) {
     return acc;
 }
 
+// Jacobian points (X, Y, Z) over P with eth-keys' conventions (jacobian.py): a point whose Y is 0 IS the point at
+// infinity for every operation — (0, 0, 1) is what a multiplication by zero returns, (0, 0, 0) what doubling a Y == 0
+// point returns — and Z == 0 only ever occurs in (0, 0, 0).  For points of the curve no finite point has Y == 0 (the group
+// order is odd), so these conventions are an ordinary group law there; for public keys that are not on the curve they are
+// what makes the verdict reproducible.
 struct SpPoint {
     Fr X, Y, Z;  // residues mod P
-    u32 inf;
 };
-ZK_HD SpPoint sp_infinity() {
+ZK_HD SpPoint sp_infinity() {  // (0, 0, 1)
     SpPoint p;
-    p.X = fr_zero(); p.Y = fr_zero(); p.Z = fr_zero();
-    p.inf = 1;
+    p.X = fr_zero(); p.Y = fr_zero(); p.Z = SecpP::one();
     return p;
 }
-// 2p ("dbl-2009-l", a = 0).  y == 0 -> O (the affine code sees x1 == x2 and y1 + y2 == 0).
+// jacobian_double: Y == 0 -> (0, 0, 0); else "dbl-2009-l" with a = 0 (any Jacobian doubling formula yields a representative
+// of the same point; only the Y == 0 / X-equality tests and the final X / Z^2 are observable)
 ZK_NOINLINE SpPoint sp_dbl(SpPoint p) {
-    if (p.inf || fr_is_zero(p.Y)) return sp_infinity();
+    if (fr_is_zero(p.Y)) {
+        SpPoint o;
+        o.X = fr_zero(); o.Y = fr_zero(); o.Z = fr_zero();
+        return o;
+    }
     typedef SecpP F;
     const Fr A = sp_mont<F>(p.X, p.X), B = sp_mont<F>(p.Y, p.Y), C = sp_mont<F>(B, B);
     Fr t = sp_add<F>(p.X, B);
@@ -213,21 +222,18 @@ ZK_NOINLINE SpPoint sp_dbl(SpPoint p) {
     r.Y = sp_sub<F>(sp_mont<F>(E, sp_sub<F>(D, r.X)), c8);
     const Fr yz = sp_mont<F>(p.Y, p.Z);
     r.Z = sp_add<F>(yz, yz);
-    r.inf = 0;
     return r;
 }
-// p + q with the case analysis of the affine formulas: O + q = q, p + O = p; x1 == x2: y1 + y2 == 0 -> O, else the
-// tangent at p (y1 == 0 there means inverting 0: `value_error`); otherwise the chord.
-ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q, u32& value_error) {
-    if (p.inf) return q;
-    if (q.inf) return p;
+// jacobian_add: p.Y == 0 -> q; q.Y == 0 -> p; U1 == U2: S1 != S2 -> (0, 0, 1), else double(p); otherwise the chord
+ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q) {
+    if (fr_is_zero(p.Y)) return q;
+    if (fr_is_zero(q.Y)) return p;
     typedef SecpP F;
     const Fr z1z1 = sp_mont<F>(p.Z, p.Z), z2z2 = sp_mont<F>(q.Z, q.Z);
     const Fr u1 = sp_mont<F>(p.X, z2z2), u2 = sp_mont<F>(q.X, z1z1);
     const Fr s1 = sp_mont<F>(sp_mont<F>(p.Y, q.Z), z2z2), s2 = sp_mont<F>(sp_mont<F>(q.Y, p.Z), z1z1);
     if (fr_eq(u1, u2)) {
-        if (fr_is_zero(sp_add<F>(s1, s2))) return sp_infinity();
-        if (fr_is_zero(p.Y)) { value_error = 1; return sp_infinity(); }
+        if (!fr_eq(s1, s2)) return sp_infinity();
         return sp_dbl(p);
     }
     const Fr h = sp_sub<F>(u2, u1), rr = sp_sub<F>(s2, s1);
@@ -236,22 +242,20 @@ ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q, u32& value_error) {
     r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
     r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(s1, hhh));
     r.Z = sp_mont<F>(sp_mont<F>(p.Z, q.Z), h);
-    r.inf = 0;
     return r;
 }
-// p + (x2, y2): Jacobian + affine (Montgomery form), the fixed-base table's addition ("madd-2007-bl" without the
-// doubling tricks: 8M + 3S).  Same case analysis as sp_add_points.
+// p + (x2, y2, 1): the fixed-base table's addition (8M + 3S); same case analysis (table entries are curve points: y2 != 0)
 ZK_NOINLINE SpPoint sp_add_affine(SpPoint p, Fr x2, Fr y2) {
     typedef SecpP F;
-    if (p.inf) {
+    if (fr_is_zero(p.Y)) {
         SpPoint r;
-        r.X = x2; r.Y = y2; r.Z = F::one(); r.inf = 0;
+        r.X = x2; r.Y = y2; r.Z = F::one();
         return r;
     }
     const Fr z1z1 = sp_mont<F>(p.Z, p.Z);
     const Fr u2 = sp_mont<F>(x2, z1z1), s2 = sp_mont<F>(sp_mont<F>(y2, p.Z), z1z1);
     if (fr_eq(p.X, u2)) {
-        if (fr_is_zero(sp_add<F>(p.Y, s2))) return sp_infinity();
+        if (!fr_eq(p.Y, s2)) return sp_infinity();
         return sp_dbl(p);
     }
     const Fr h = sp_sub<F>(u2, p.X), rr = sp_sub<F>(s2, p.Y);
@@ -260,12 +264,10 @@ ZK_NOINLINE SpPoint sp_add_affine(SpPoint p, Fr x2, Fr y2) {
     r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
     r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(p.Y, hhh));
     r.Z = sp_mont<F>(p.Z, h);
-    r.inf = 0;
     return r;
 }
-// k * G, k < N: sixty-four 4-bit windows over the precomputed multiples d * 16^j * G (secp_g_table.h) — 64 mixed additions
-// instead of 256 doublings + ~128 additions.  G is on the curve, so this is the same group element the LSB-first
-// double-and-add of the restated algorithm produces.
+// k * G, k < N: sixty-four 4-bit windows over the precomputed multiples d * 16^j * G (secp_g_table.h) — 64 mixed additions.
+// G is on the curve, so this is the group element eth-keys' double-and-add produces (k == 0: a Y == 0 point).
 ZK_NOINLINE SpPoint sp_scalar_mul_g(Fr k) {
     SpPoint acc = sp_infinity();
     for (int j = 0; j < 64; j++) {
@@ -283,16 +285,16 @@ ZK_NOINLINE SpPoint sp_scalar_mul_g(Fr k) {
     }
     return acc;
 }
-// k * pt, k < N canonical: acc += pt for every set bit from the least significant one, pt doubling in between
+// jacobian_multiply(pt, k), k < N: pt.Y == 0 or k == 0 -> (0, 0, 1); else MSB-first double-and-add (the recursion
+// n -> n // 2 unrolled: start from pt at the top bit, then double, and add pt where the bit is set)
 ZK_NOINLINE SpPoint sp_scalar_mul(SpPoint pt, Fr k) {
-    SpPoint acc = sp_infinity();
-    u32 ve = 0;
-    while (!fr_is_zero(k)) {
-        if (k.v[0] & 1u) acc = sp_add_points(acc, pt, ve);
-        pt = sp_dbl(pt);
-#pragma unroll
-        for (int j = 0; j < 7; j++) k.v[j] = (k.v[j] >> 1) | (k.v[j + 1] << 31);
-        k.v[7] >>= 1;
+    if (fr_is_zero(pt.Y) || fr_is_zero(k)) return sp_infinity();
+    int top = 255;
+    while (!((k.v[top >> 5] >> (top & 31)) & 1u)) top--;
+    SpPoint acc = pt;
+    for (int b = top - 1; b >= 0; b--) {
+        acc = sp_dbl(acc);
+        if ((k.v[b >> 5] >> (b & 31)) & 1u) acc = sp_add_points(acc, pt);
     }
     return acc;
 }
@@ -318,7 +320,6 @@ ZK_HD Fr sp_load_be(const uint8_t* p) {
 enum { ECDSA_OK = 0, ECDSA_NOT_VERIFIED = 1 };
 #define ECDSA_BAD_SIGNATURE ZK_CODE(ZK_UNSUPPORTED, 1)   // eth_keys BadSignature: no class of its own on the wire
 #define ECDSA_KEY_RANGE ZK_CODE(ZK_UNSUPPORTED, 2)       // public-key coordinate >= P: outside the engine's domain
-#define ECDSA_VALUE_ERROR ZK_CODE(ZK_VALUE_ERROR, 3)     // pow(0, -1, P) in the final addition
 
 struct EcdsaArgs {
     const uint8_t* bytes;  // per signature: pk_x LE, pk_y LE, msg_hash (BE or LE), sig_r LE, sig_s LE (32 bytes each)
@@ -340,21 +341,19 @@ ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i) {
     const Fr r = sp_load_le(base + a.off[3]), s = sp_load_le(base + a.off[4]);
     const Fr n = SecpN::mod(), p = SecpP::mod();
     if (a.v && a.v[i * a.v_stride] > 1u) return ECDSA_BAD_SIGNATURE;
-    if (!fr_lt(r, n) || !fr_lt(s, n)) return ECDSA_BAD_SIGNATURE;
+    // validate_signature_r_or_s: 0 < value < N
+    if (!fr_lt(r, n) || !fr_lt(s, n) || fr_is_zero(r) || fr_is_zero(s)) return ECDSA_BAD_SIGNATURE;
     if (!fr_lt(pkx, p) || !fr_lt(pky, p)) return ECDSA_KEY_RANGE;
-    if (fr_is_zero(r) || fr_is_zero(s)) return ECDSA_NOT_VERIFIED;
     const Fr wM = sp_inv<SecpN>(sp_to_mont<SecpN>(s));
     const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
     const Fr u2 = sp_mont<SecpN>(r, wM);
     SpPoint q;
-    q.X = sp_to_mont<SecpP>(pkx); q.Y = sp_to_mont<SecpP>(pky); q.Z = SecpP::one(); q.inf = 0;
+    q.X = pkx; q.Y = pky; q.Z = SecpP::one();
     const SpPoint A = sp_scalar_mul_g(u1);
     const SpPoint B = sp_scalar_mul(q, u2);
-    u32 ve = 0;
-    const SpPoint C = sp_add_points(A, B, ve);
-    if (ve) return ECDSA_VALUE_ERROR;
-    if (C.inf) return ECDSA_NOT_VERIFIED;
-    const Fr zi = sp_inv<SecpP>(C.Z);
-    const Fr x = sp_from_mont<SecpP>(sp_mont<SecpP>(C.X, sp_mont<SecpP>(zi, zi)));
-    return fr_eq(sp_reduce_once<SecpN>(x), r) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
+    // fast_add(from_jacobian(A), from_jacobian(B)): the case analysis is projective, so A and B are added as they are
+    const SpPoint C = sp_add_points(A, B);
+    // r == from_jacobian(C).x with inv(0) == 0: Z == 0 gives x = 0 != r; else r == X / Z^2  <=>  r Z^2 == X (r < N < P)
+    if (fr_is_zero(C.Z)) return ECDSA_NOT_VERIFIED;
+    return fr_eq(sp_mont<SecpP>(r, sp_mont<SecpP>(C.Z, C.Z)), C.X) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
 }

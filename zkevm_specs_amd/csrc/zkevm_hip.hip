@@ -12,6 +12,7 @@
 #include "../../include/zkevm_hip.h"
 #include "kernels.hpp"
 #include "host_index.hpp"
+#include "code_dir_build.hpp"
 
 // ---------------------------------------------------------------------------------------
 // engine state
@@ -488,33 +489,46 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             hipLaunchKernelGGL(rw_pack_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, s->stream, s->evm.rw, d_keys);
             s->evm.rw_keys = d_keys;
         }
-        // bytecode directory: built on the host (the table is small), then uploaded
+        // bytecode directory: built on the device from the table where it lies (code_dir_build.hpp)
         if (t->n_bytecode) {
-            std::vector<u64> host_rows;
-            const u64* rows = t->bytecode;
-            if (dev) {
-                host_rows.resize((size_t)t->n_bytecode * BYTECODE_NCELLS * 4);
-                if (hipMemcpy(host_rows.data(), t->bytecode, host_rows.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "bytecode download failed"; goto fail; }
-                rows = host_rows.data();
-            }
-            HostCodeDir dir;
-            build_code_dir(rows, t->n_bytecode, dir);
-            ZkCodeEntry* d_entries = nullptr;
-            u32* d_slots = nullptr;
-            if ((rc = dev_alloc(s, (void**)&d_entries, dir.entries.size() * sizeof(ZkCodeEntry)))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d_slots, dir.slots.size() * sizeof(u32)))) goto fail;
-            if (hipMemcpy(d_entries, dir.entries.data(), dir.entries.size() * sizeof(ZkCodeEntry), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(d_slots, dir.slots.data(), dir.slots.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; g_err = "directory upload failed"; goto fail; }
-            s->evm.codes.entries = d_entries;
-            s->evm.codes.slots = d_slots;
-            s->evm.codes.mask = dir.mask;
-            s->evm.codes.n = (u32)dir.entries.size();
-            {
-                uint16_t* d_packed = nullptr;
-                if ((rc = dev_alloc(s, (void**)&d_packed, dir.packed.size() * sizeof(uint16_t)))) goto fail;
-                if (hipMemcpy(d_packed, dir.packed.data(), dir.packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { rc = -2; g_err = "directory upload failed"; goto fail; }
-                s->evm.codes.packed = d_packed;
-            }
+            DirBuild d;
+            memset(&d, 0, sizeof d);
+            d.rows = s->evm.bytecode.cells;
+            d.n = (u32)t->n_bytecode;
+            u32 cap = 16;
+            while (cap < 2 * d.n + 2) cap <<= 1;
+            d.big_mask = cap - 1;
+            if ((rc = dev_alloc(s, (void**)&d.big_slots, (size_t)cap * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.slot_entry, (size_t)cap * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.n_entries, 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.packed, (size_t)d.n * sizeof(uint16_t)))) goto fail;
+            if (hipMemsetAsync(d.n_entries, 0, 4, s->stream) != hipSuccess) { rc = -2; g_err = "directory counter reset failed"; goto fail; }
+            const dim3 rows_grid((d.n + 255) / 256), blk(256);
+            hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), blk, 0, s->stream, d.big_slots, cap);
+            hipLaunchKernelGGL(dirb_insert_kernel, rows_grid, blk, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_leaders_kernel, rows_grid, blk, 0, s->stream, d);
+            u32 n_entries = 0;
+            if (hipMemcpyAsync(&n_entries, d.n_entries, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "directory size download failed"; goto fail; }
+            u32 scap = 16;
+            while (scap < 2 * n_entries + 2) scap <<= 1;
+            d.small_mask = scap - 1;
+            if ((rc = dev_alloc(s, (void**)&d.entries, (size_t)n_entries * sizeof(ZkCodeEntry)))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.small_slots, (size_t)scap * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.e_headers, (size_t)n_entries * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.e_first, (size_t)n_entries * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.e_last, (size_t)n_entries * 4))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&d.e_bad, (size_t)n_entries * 4))) goto fail;
+            hipLaunchKernelGGL(slots_fill_kernel, dim3((scap + 255) / 256), blk, 0, s->stream, d.small_slots, scap);
+            hipLaunchKernelGGL(dirb_init_kernel, rows_grid, blk, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_accumulate_kernel, rows_grid, blk, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_check_kernel, rows_grid, blk, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_finalize_kernel, dim3((n_entries + 255) / 256), blk, 0, s->stream, d);
+            s->evm.codes.entries = d.entries;
+            s->evm.codes.slots = d.small_slots;
+            s->evm.codes.mask = d.small_mask;
+            s->evm.codes.n = n_entries;
+            s->evm.codes.packed = d.packed;
         }
     }
     s->evm.n_pairs = (u32)(t->n_steps - 1);

@@ -2,9 +2,9 @@
 
 The path shards embarrassingly: contiguous row ranges per rank with a read-only
 halo (State: one row before and after, modulo n; EVM: the step after the last pair), lookup
-tables replicated.  The only collective is one all-reduce of the tally — SUM of the fail counts,
-MIN of (first failing global row, its status code) — 16 bytes over RCCL/xGMI (`nccl` backend) or
-gloo in the CPU tests.
+tables replicated.  The only collective is one all-gather of the tally — (fail count, first failing global row,
+its status code) per rank, 24 bytes over RCCL/xGMI (`nccl` backend) or gloo in the CPU tests — reduced locally
+(SUM of the counts, MIN of the rows).
 """
 import numpy as np
 
@@ -39,23 +39,25 @@ def shard_evm(wire, rank, world, begin_with_first_step=False, end_with_last_step
 
 
 def reduce_tally(fail_count, first_fail_row, first_fail_code, row_offset, device=None, group=None):
-    """All-reduce the per-rank tally.  `first_fail_row` is local (None = no failure).  Returns
-    (total_fail_count, first_fail_global_row or None, its status code)."""
+    """Exchange the per-rank tallies: ONE collective (an all-gather of three words per rank: fail count, first failing
+    GLOBAL row, its status code — 24 bytes, latency-bound), no host synchronisation before the single read-back at the end.
+    SUM and lexicographic MIN are then taken locally, identically on every rank.  `first_fail_row` is local (None = no
+    failure).  Returns (total_fail_count, first_fail_global_row or None, its status code)."""
     import torch
     import torch.distributed as dist
 
     none = 1 << 62
-    # MIN over the global row; the winner's status code travels in a second (MAX) reduction
-    t_cnt = torch.tensor([int(fail_count)], dtype=torch.int64, device=device)
-    t_row = torch.tensor([none if first_fail_row is None else int(first_fail_row) + int(row_offset)], dtype=torch.int64, device=device)
+    mine = torch.tensor([int(fail_count), none if first_fail_row is None else int(first_fail_row) + int(row_offset),
+                         0 if first_fail_row is None else int(first_fail_code)], dtype=torch.int64, device=device)
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(t_row, op=dist.ReduceOp.MIN, group=group)
-    winner = int(t_row.item())
-    mine = first_fail_row is not None and int(first_fail_row) + int(row_offset) == winner
-    t_code = torch.tensor([int(first_fail_code) if mine else 0], dtype=torch.int64, device=device)
-    if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(t_code, op=dist.ReduceOp.MAX, group=group)
-    if winner == none:
-        return int(t_cnt.item()), None, 0
-    return int(t_cnt.item()), winner, int(t_code.item())
+        world = dist.get_world_size(group)
+        every = torch.empty(world * 3, dtype=torch.int64, device=device)  # flat: gloo's allgather wants a 1-d output
+        dist.all_gather_into_tensor(every, mine, group=group)
+    else:
+        every = mine
+    every = every.reshape(-1, 3).cpu().tolist()  # the only synchronisation
+    total = sum(r[0] for r in every)
+    row, code = min((r[1], r[2]) for r in every)
+    if row == none:
+        return total, None, 0
+    return total, row, code

@@ -3,24 +3,15 @@
 Reference seam: `zkevm_specs.evm_circuit.verify_steps(tables, steps, begin_with_first_step=False,
 end_with_last_step=False, success=True)` (evm_circuit/main.py:14-44), which loops
 `verify_step(Instruction(tables, curr, next, ...))` over consecutive step pairs.  Here the loop
-is one device pass; arguments, the dummy EndBlock step and the error behaviour are the same:
+is one device pass (`zk_evm_verify`); arguments, the dummy EndBlock step and the error behaviour are the same:
 the first failing pair decides — an AssertionError there is swallowed and re-raised iff `success`
 (main.py:36-44), any other exception class propagates as is.
 """
-from . import engine
+from . import oneshot
 from .errors import KIND_ASSERT, exception_for_code
 from .evm_tables import ExecutionState
 from .flatten import flatten_evm
-
-
-class Word:
-    """256-bit word as lo/hi 128-bit halves (util/arithmetic.py:99-123), enough for step fields."""
-
-    def __init__(self, value=0):
-        if isinstance(value, tuple):
-            self.lo, self.hi = value
-        else:
-            self.lo, self.hi = value & ((1 << 128) - 1), value >> 128
+from .objects import Word  # noqa: F401  (re-exported: callers build code hashes with it)
 
 
 class StepState:
@@ -51,9 +42,10 @@ def _dummy_step():
 def verify_steps(tables, steps, begin_with_first_step=False, end_with_last_step=False, success=True):
     if end_with_last_step:
         steps.append(_dummy_step())  # the reference mutates the caller's list too (main.py:21-22)
-    wire = flatten_evm(tables, steps)
-    with engine.open_evm(wire, begin_with_first_step, end_with_last_step) as s:
-        res = s.run()
+    if len(steps) < 2:
+        assert success  # no pair, no exception (main.py:40-44)
+        return None
+    res, _ = oneshot.evm_verify(flatten_evm(tables, steps), begin_with_first_step, end_with_last_step)
     exception = None
     if not res.ok:
         exc = exception_for_code(res.first_fail_code, f"EVM circuit step {res.first_fail_row}")
@@ -72,7 +64,4 @@ def verify_steps_status(tables, steps, begin_with_first_step=False, end_with_las
     """Diagnostic form: per-pair status codes of every step pair (no early stop)."""
     if end_with_last_step:
         steps = list(steps) + [_dummy_step()]
-    wire = flatten_evm(tables, steps)
-    with engine.open_evm(wire, begin_with_first_step, end_with_last_step) as s:
-        res = s.run()
-        return res, s.read_status()
+    return oneshot.evm_verify(flatten_evm(tables, steps), begin_with_first_step, end_with_last_step)

@@ -1,5 +1,5 @@
-"""Host-side mirror of `zkevm_specs.exp_circuit.verify_exp_circuit` (exp_circuit.py:88-97)."""
-from . import engine
+"""Host-side mirror of `zkevm_specs.exp_circuit.verify_exp_circuit` (exp_circuit.py:88-97), on the MI355X (`zk_exp_verify`)."""
+from . import oneshot
 from .errors import raise_for_code
 from .flatten import flatten_exp_rows
 
@@ -10,7 +10,6 @@ def verify_exp_circuit(exp_circuit):
     rows = list(exp_circuit.table())
     if not rows:
         return None
-    with engine.open_exp(flatten_exp_rows(rows)) as s:
-        res = s.run()
+    res, _ = oneshot.exp_verify(flatten_exp_rows(rows))
     raise_for_code(res.first_fail_code, f"Exp circuit row {res.first_fail_row}")
     return res

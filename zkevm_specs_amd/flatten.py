@@ -377,16 +377,68 @@ def _ecdsa_status(call, returns_bool):
         return kind_for_exception(e) << 24
 
 
+ECDSA_STATUS_PENDING = 0xFFFFFFFF  # meta[:, 0] placeholder of a verdict still to be computed: the kernel fails every unit left pending
+
+
+def _b32_of(get):
+    b = get()
+    if not isinstance(b, (bytes, bytearray)) or len(b) != 32:
+        raise ValueError("not a 32-byte string")
+    return bytes(b)
+
+
+def _chip_inputs_tx(e):
+    """what `tx_circuit.ECDSAVerifyChip.verify` hands to eth_keys (tx_circuit.py:147-158): the chip's LIMBS (not its
+    `*_bytes` attributes), as the packed layout of zk_ecdsa_verify (pk_x LE, pk_y LE, msg_hash BE, r LE, s LE); v = 0"""
+    return [_b32_of(e.pub_key[0].to_le_bytes), _b32_of(e.pub_key[1].to_le_bytes), bytes(reversed(_b32_of(e.msg_hash.to_le_bytes))),
+            _b32_of(e.signature[0].to_le_bytes), _b32_of(e.signature[1].to_le_bytes)], 0
+
+
+def _chip_inputs_sig(e):
+    """what `util.ec.ECDSAVerifyChip.verify` hands to eth_keys (util/ec.py:109-117)"""
+    v = int.from_bytes(_b32_of(e.sig_v.to_le_bytes), "little")
+    if v > 0xFFFFFFFF:
+        raise ValueError("v does not fit the wire")
+    return [bytes(reversed(_b32_of(e.pub_key[0].to_be_bytes))), bytes(reversed(_b32_of(e.pub_key[1].to_be_bytes))),
+            _b32_of(e.msg_hash.to_be_bytes), _b32_of(e.sig_r.to_le_bytes), _b32_of(e.sig_s.to_le_bytes)], v
+
+
+def _ecdsa_column(chips, inputs_of, host_call, returns_bool, on_device):
+    """-> (status list, packed uint8[n, 5, 32], v uint32[n], deferred bool[n]).  With `on_device` the verdict of every chip
+    whose five inputs can be read is left PENDING for the device pass (zk_ecdsa_verify over `packed`); chips whose
+    attributes are malformed (the reference's tamper tests) are evaluated by calling them, as the reference does."""
+    status, packed, vs, deferred = [], [], [], []
+    for e in chips:
+        rows, v, ok = [bytes(32)] * 5, 0, False
+        if on_device:
+            try:
+                rows, v = inputs_of(e)
+                ok = True
+            except Exception:  # noqa: BLE001 - malformed chip: fall through to the chip's own verify()
+                ok = False
+        status.append(ECDSA_STATUS_PENDING if ok else _ecdsa_status(lambda e=e: host_call(e), returns_bool))
+        packed.append([list(r) for r in rows])
+        vs.append(v)
+        deferred.append(ok)
+    return (status, np.array(packed, dtype=np.uint8).reshape(-1, 5, 32), np.array(vs, dtype=np.uint32),
+            np.array(deferred, dtype=bool))
+
+
 def flatten_keccak_tuples(table):
     """tx_circuit.KeccakTable.table: set of (is_enabled, input_rlc, input_len, output Word) -> uint64[m, 5, 4]"""
     rows = sorted(set((_n(t[0]), _n(t[1]), _n(t[2]), _n(t[3].lo), _n(t[3].hi)) for t in table))
     return rows_to_rowmajor([list(r) for r in rows], KECCAK_NCELLS)
 
 
-def flatten_tx_witness(witness, max_txs):
-    """tx_circuit.Witness (rows, keccak_table, sign_verifications) -> dict of wire arrays"""
+def flatten_tx_witness(witness, max_txs, ecdsa_on_device=False):
+    """tx_circuit.Witness (rows, keccak_table, sign_verifications) -> dict of wire arrays.  ecdsa_on_device: leave the
+    `ecdsa_status` column PENDING and return the chips' inputs (`ecdsa_packed`, `ecdsa_v`, `ecdsa_deferred`) instead of
+    calling every chip's verify() on the host."""
     bts, cells, meta = [], [], []
-    for sv in witness.sign_verifications[:max_txs]:
+    svs = witness.sign_verifications[:max_txs]
+    col, packed, vs, deferred = _ecdsa_column([sv.ecdsa_chip for sv in svs], _chip_inputs_tx, lambda e: e.verify(""), False,
+                                              ecdsa_on_device)
+    for sv, st in zip(svs, col):
         e = sv.ecdsa_chip
         # rows 7, 8: the ECDSA chip's (r, s) as it hands them to eth_keys (tx_circuit.py:149-150); the Tx kernel does
         # not read them, the device ECDSA pass (zk_ecdsa_open, layout 1) does
@@ -395,7 +447,7 @@ def flatten_tx_witness(witness, max_txs):
                                  _le_bytes_or_zero(lambda e=e: e.signature[0]), _le_bytes_or_zero(lambda e=e: e.signature[1])])
         bts.append(rows_)
         cells.append([_n(sv.address), _n(sv.msg_hash.lo), _n(sv.msg_hash.hi), 0, 0, 0, 0, 0])
-        meta.append([_ecdsa_status(lambda e=e: e.verify(""), False), 1, bad, 0])
+        meta.append([st, 1, bad, 0])
     pairs = []
     for r in witness.rows:
         lo, hi, w = _word_cells(r.value)
@@ -407,13 +459,16 @@ def flatten_tx_witness(witness, max_txs):
         "keccak": flatten_keccak_tuples(witness.keccak_table.table),
         "tx_rows": rows_to_rowmajor([c for c, _ in pairs], TX_NCELLS),
         "tx_flags": np.array([f for _, f in pairs], dtype=np.uint32),
+        "ecdsa_packed": packed, "ecdsa_v": None, "ecdsa_deferred": deferred,
     }
 
 
-def flatten_sig_witness(witness):
-    """sig_circuit.Witness (rows, keccak_table) -> dict of wire arrays"""
+def flatten_sig_witness(witness, ecdsa_on_device=False):
+    """sig_circuit.Witness (rows, keccak_table) -> dict of wire arrays (ecdsa_on_device: see flatten_tx_witness)"""
     bts, cells, meta = [], [], []
-    for row in witness.rows:
+    col, packed, vs, deferred = _ecdsa_column([row.ecdsa_chip for row in witness.rows], _chip_inputs_sig, lambda e: e.verify(), True,
+                                              ecdsa_on_device)
+    for row, st in zip(witness.rows, col):
         e = row.ecdsa_chip
         rows_, bad = _byte_rows([row.pub_key_x_bytes, row.pub_key_y_bytes, e.pub_key_x_bytes, e.pub_key_y_bytes,
                                  row.msg_hash_bytes, e.msg_hash_bytes, row.pub_key_hash, e.sig_r.le_bytes, e.sig_s.le_bytes])
@@ -422,8 +477,7 @@ def flatten_sig_witness(witness):
                       _n(row.sig_r.hi), _n(row.sig_s.lo), _n(row.sig_s.hi)])
         # meta[3]: the v the chip hands to eth_keys (util/ec.py:110; the Row's own sig_v cell can be tampered separately)
         chip_v = _le_bytes_or_zero(lambda e=e: e.sig_v)
-        meta.append([_ecdsa_status(lambda e=e: e.verify(), True), int(bool(row.is_valid)), bad,
-                     min(int.from_bytes(chip_v, "little"), 0xFFFFFFFF)])
+        meta.append([st, int(bool(row.is_valid)), bad, min(int.from_bytes(chip_v, "little"), 0xFFFFFFFF)])
     return {
         "bytes": np.array(bts, dtype=np.uint8).reshape(-1, SIGN_NBYTES_ROWS, 32),
         "cells": rows_to_colmajor(cells, SIGN_NCELLS),
@@ -431,6 +485,7 @@ def flatten_sig_witness(witness):
         "keccak": flatten_keccak_tuples(witness.keccak_table.table),
         "tx_rows": np.zeros((0, TX_NCELLS, 4), dtype=np.uint64),
         "tx_flags": np.zeros(0, dtype=np.uint32),
+        "ecdsa_packed": packed, "ecdsa_v": vs, "ecdsa_deferred": deferred,
     }
 
 

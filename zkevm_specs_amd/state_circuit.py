@@ -9,7 +9,7 @@ Error behaviour matches the reference: a failing `assert` raises AssertionError,
 MPT row raises LookupUnsatFailure, an invalid tag/field tag raises ValueError — the class is
 decoded from the device status code (csrc/common.hpp ZkKind).
 """
-from . import engine
+from . import oneshot
 from .errors import raise_for_code
 from .flatten import flatten_mpt_table, flatten_state_ops, flatten_state_rows
 
@@ -29,16 +29,14 @@ def _assign(ops, mpt_only):
     from .errors import raise_for_code
 
     wire_ops, wire_flags = ops if isinstance(ops, tuple) else flatten_state_ops(ops)
-    with engine.open_state_assign(wire_ops, wire_flags) as s:
-        res = s.run()
-        if not res.ok:
-            # `_mock_mpt_updates` runs over every op before the first `op2row` (state_circuit.py:856, :880-883)
-            status = s.read_status()
-            for sites in ((_MOCK_MPT_SITES,) if mpt_only else (_MOCK_MPT_SITES, (3,))):
-                for i in status.nonzero()[0]:
-                    if (int(status[i]) & 0xFFFFFF) in sites:
-                        raise_for_code(int(status[i]), f"state op {i}")
-        return s.read()
+    res, status, rows, flags, mpt = oneshot.state_assign(wire_ops, wire_flags)  # zk_state_assign
+    if not res.ok:
+        # `_mock_mpt_updates` runs over every op before the first `op2row` (state_circuit.py:856, :880-883)
+        for sites in ((_MOCK_MPT_SITES,) if mpt_only else (_MOCK_MPT_SITES, (3,))):
+            for i in status.nonzero()[0]:
+                if (int(status[i]) & 0xFFFFFF) in sites:
+                    raise_for_code(int(status[i]), f"state op {i}")
+    return rows, flags, mpt
 
 
 def assign_state_circuit(ops):
@@ -65,9 +63,7 @@ def verify_state_rows(rows, tables, success=True, return_status=False):
     """
     cols, flags = rows if isinstance(rows, StateWitness) else flatten_state_rows(rows)
     mpt = tables.mpt_table if hasattr(tables.mpt_table, "shape") else flatten_mpt_table(tables.mpt_table)
-    with engine.open_state(cols, flags, mpt) as s:
-        res = s.run()
-        status = s.read_status() if return_status else None
+    res, status = oneshot.state_verify(cols, flags, mpt)  # zk_state_verify
     if return_status:
         return res, status
     if res.ok:
@@ -82,7 +78,5 @@ def check_state_row(row, row_prev, row_next, tables):
     """Single-row form with the reference's signature (three-row window on the device)."""
     cols, flags = flatten_state_rows([row_prev, row, row_next])
     mpt = flatten_mpt_table(tables.mpt_table)
-    with engine.open_state(cols, flags, mpt) as s:
-        s.run()
-        status = s.read_status()
+    _, status = oneshot.state_verify(cols, flags, mpt)
     raise_for_code(int(status[1]), "State circuit row")

@@ -447,7 +447,7 @@ def device_keccak_digests(r):
     return digests
 
 
-ECDSA_STATUS_PENDING = 0xFFFFFFFF  # meta[:, 0] placeholder: the Tx kernel fails every unit until the ECDSA pass filled it
+from .flatten import ECDSA_STATUS_PENDING  # noqa: E402,F401  meta[:, 0] placeholder: the Tx kernel fails every unit until the ECDSA pass filled it
 
 
 def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False, digests_of=None):
