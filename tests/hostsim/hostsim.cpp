@@ -315,7 +315,30 @@ extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, 
     a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.out = nullptr; a.out_stride = 0;
     a.msg_be = layout != 1u;
     for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
-    for (u64 i = 0; i < n; i++) status[i] = ecdsa_verify_one(a, i);
+    std::vector<u32> tab(15 * 24 * 2);
+    a.qtab = tab.data(); a.qtab_lanes = 1; a.lanes_per_sig = 1;
+    for (u64 i = 0; i < n; i++) status[i] = ecdsa_verify_one(a, i, tab.data(), 1);
+    return 0;
+}
+// the lane-pair form of the kernel (k_ecdsa.hip, L = 2) in a plain loop: two partial sums, added at the end
+extern "C" int sim_ecdsa_verify_pairs(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
+    static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
+    EcdsaArgs a;
+    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.out = nullptr; a.out_stride = 0;
+    a.msg_be = layout != 1u;
+    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
+    std::vector<u32> tab(15 * 24 * 2);
+    a.qtab = tab.data(); a.qtab_lanes = 2; a.lanes_per_sig = 2;
+    for (u64 i = 0; i < n; i++) {
+        EcdsaPrep pr0, pr1;
+        const u32 st0 = ecdsa_prepare(a, i, pr0, true), st1 = ecdsa_prepare(a, i, pr1, false);
+        if (st0 != ECDSA_PENDING) { status[i] = st0; continue; }
+        if (st1 != ECDSA_PENDING) return -1;
+        SpPoint p0 = ecdsa_partial(pr0, 0, 0, tab.data(), 2);
+        const SpPoint p1 = ecdsa_partial(pr1, 1, 1, tab.data() + 1, 2);
+        sp_add_ip(p0, p1);
+        status[i] = ecdsa_verdict(pr0, p0);
+    }
     return 0;
 }
 
@@ -362,7 +385,7 @@ extern "C" void sim_secp_mul(int which, const u64* a, const u64* b, u64* out, u6
             x.v[2 * q] = (u32)a[4 * i + q]; x.v[2 * q + 1] = (u32)(a[4 * i + q] >> 32);
             y.v[2 * q] = (u32)b[4 * i + q]; y.v[2 * q + 1] = (u32)(b[4 * i + q] >> 32);
         }
-        const Fr r = which == 0 ? sp_mont<SecpP>(x, y) : sp_mont<SecpN>(x, y);
+        const Fr r = which == 0 ? sp_mont<SecpP>(x, y) : (which == 2 ? sp_sqr_p(x) : sp_mont<SecpN>(x, y));
         for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)r.v[2 * q] | ((u64)r.v[2 * q + 1] << 32);
     }
 }

@@ -20,10 +20,13 @@ def _same(a, b):
 
 
 def _hostsim(lib, sig_bytes, v, layout, v_stride=1):
+    """both forms of the kernel: one lane per signature, and the lane-pair form (two partial sums added at the end)"""
     sig_bytes = np.ascontiguousarray(sig_bytes)
     n = sig_bytes.shape[0]
-    st = np.zeros(n, dtype=np.uint32)
+    st, st2 = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
     lib.sim_ecdsa_verify(vp(sig_bytes), ctypes.c_uint32(layout), vp(v), ctypes.c_uint32(v_stride), ctypes.c_uint64(n), vp(st))
+    assert lib.sim_ecdsa_verify_pairs(vp(sig_bytes), ctypes.c_uint32(layout), vp(v), ctypes.c_uint32(v_stride), ctypes.c_uint64(n), vp(st2)) == 0
+    assert st.tolist() == st2.tolist()
     return st.tolist()
 
 
@@ -86,6 +89,43 @@ def test_field_products_known_answers(hostsim):
         rinv = pow(1 << 256, -1, m)
         exp = [x * y % m if which == 0 else x * y * rinv % m for x, y in pairs]
         assert wire.cells_to_ints(out) == exp, which
+        if which == 0:  # the dedicated squaring
+            hostsim.sim_secp_mul(ctypes.c_int(2), vp(a), vp(a), vp(out), ctypes.c_uint64(len(pairs)))
+            assert wire.cells_to_ints(out) == [x * x % m for x, _ in pairs]
+
+
+def _group_law_edge_cases():
+    """curve keys that drive the joint multiplication through its special cases: Q = +-G, Q = lambda G, u1 or u2 with zero
+    windows, R = infinity (u1 G = -u2 Q), acc == table entry (doubling inside an addition)"""
+    import random
+
+    rng = random.Random(31)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    cases = []
+    G = E.G
+    for d in (1, E.N - 1, 2, lam, E.N - lam, 16, 1 << 128, (1 << 128) - 1, 3, 5):
+        Q = E.mul(G, d)
+        for _ in range(3):
+            k, z = rng.randrange(1, E.N), rng.getrandbits(256)
+            r = E.mul(G, k)[0] % E.N
+            s = pow(k, -1, E.N) * (z + r * d) % E.N
+            if r and s:
+                cases.append((Q[0], Q[1], z, r, s))                 # valid
+                cases.append((Q[0], Q[1], z, r, (s + 1) % E.N or 1))  # invalid
+        # u1 G + u2 Q = infinity: z + r d = 0 (mod N) -> pick r, then z = -r d
+        r = rng.randrange(1, E.N)
+        cases.append((Q[0], Q[1], (-r * d) % E.N, r, rng.randrange(1, E.N)))
+        # sparse scalars: s = 1 -> u1 = z, u2 = r with many zero windows
+        cases.append((Q[0], Q[1], 1 << 200, 1 << 64, 1))
+        cases.append((Q[0], Q[1], 0, 1, 1))
+    return E.pack(cases)
+
+
+def test_kernel_logic_group_law_edge_cases(hostsim):
+    sigs = _group_law_edge_cases()
+    exp = E.verify_packed(sigs, None)
+    assert _hostsim(hostsim, sigs, None, 0) == exp
+    assert sum(1 for e in exp if e == 0) >= 25 and sum(1 for e in exp if e == 1) >= 25
 
 
 def test_oracle_matches_reference_chips(golden_dir):
@@ -184,6 +224,15 @@ def test_hip_matches_openssl_vectors(golden_dir):
     assert status.tolist() == verdict and res.fail_count == sum(verdict)
     off = _offcurve_cases()
     assert engine.ecdsa_status(off).tolist() == E.verify_packed(off, None)
+    edge = _group_law_edge_cases()
+    for lanes in ("1", "2"):  # one lane per signature / lane pairs (the library picks by batch size; both forms on every vector here)
+        os.environ["ZK_ECDSA_LANES"] = lanes
+        try:
+            assert engine.ecdsa_status(edge).tolist() == E.verify_packed(edge, None)
+            assert engine.ecdsa_status(sigs).tolist() == verdict
+            assert engine.ecdsa_status(off).tolist() == E.verify_packed(off, None)
+        finally:
+            del os.environ["ZK_ECDSA_LANES"]
 
 
 @pytest.mark.gpu

@@ -96,15 +96,49 @@ __global__ void dirb_init_kernel(DirBuild d) {
     d.e_last[k] = 0;
     d.e_bad[k] = 0;
 }
+// Rows of one code sit next to each other (the flattener sorts by hash), so a wavefront usually works on ONE directory
+// entry: it then reduces its 64 rows with ballots and issues at most five atomics instead of 64 x 3 on the same words
+// (43,913 rows of 16 contracts: 525 us with per-lane atomics).
 __global__ void dirb_accumulate_kernel(DirBuild d) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= d.n) return;
-    const u32 k = d.slot_entry[dirb_find(d, r)];
-    u64 tag, index, is_code, value;
-    const bool small = dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index);
-    if (!small || (tag != 1 && tag != 2) || (tag == 1 && index != 0)) {
+    const bool in = r < d.n;
+    u32 k = 0xffffffffu;
+    u32 cat = 3;  // 0 rules out "regular", 1 Header row, 2 Byte row, 3 lane past the table
+    if (in) {
+        k = d.slot_entry[dirb_find(d, r)];
+        u64 tag, index, is_code, value;
+        const bool small = dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index);
+        cat = (!small || (tag != 1 && tag != 2) || (tag == 1 && index != 0)) ? 0u : (u32)tag;
+        uint16_t p = 0;
+        if (dirb_small(d.rows, r, 4, is_code) && dirb_small(d.rows, r, 5, value) && is_code < 2 && value < 256)
+            p = (uint16_t)(0x8000u | (u32)(is_code << 8) | (u32)value);
+        d.packed[r] = p;
+    }
+    const unsigned long long active = __ballot(in);
+    if (active == 0ull) return;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 k0 = __shfl(k, __ffsll((long long)active) - 1);
+    if (__ballot(in && k != k0) == 0ull) {  // one entry for the whole wavefront
+        const unsigned long long bad = __ballot(cat == 0), hdr = __ballot(cat == 1), byt = __ballot(cat == 2);
+        const u32 wave_row0 = r - lane;
+        if (lane == (u32)__ffsll((long long)active) - 1u) {
+            if (bad) d.e_bad[k0] = 1;
+            if (hdr) {
+                atomicAdd(&d.e_headers[k0], (u32)__popcll(hdr));
+                d.entries[k0].header_row = wave_row0 + (u32)__ffsll((long long)hdr) - 1u;
+            }
+            if (byt) {
+                atomicMin(&d.e_first[k0], wave_row0 + (u32)__ffsll((long long)byt) - 1u);
+                atomicMax(&d.e_last[k0], wave_row0 + 63u - (u32)__clzll((long long)byt));
+                atomicAdd(&d.entries[k0].n_bytes, (u32)__popcll(byt));
+            }
+        }
+        return;
+    }
+    if (!in) return;
+    if (cat == 0) {
         d.e_bad[k] = 1;
-    } else if (tag == 1) {
+    } else if (cat == 1) {
         atomicAdd(&d.e_headers[k], 1u);
         d.entries[k].header_row = r;  // exactly one writer when the code turns out regular
     } else {
@@ -112,10 +146,6 @@ __global__ void dirb_accumulate_kernel(DirBuild d) {
         atomicMax(&d.e_last[k], r);
         atomicAdd(&d.entries[k].n_bytes, 1u);
     }
-    uint16_t p = 0;
-    if (dirb_small(d.rows, r, 4, is_code) && dirb_small(d.rows, r, 5, value) && is_code < 2 && value < 256)
-        p = (uint16_t)(0x8000u | (u32)(is_code << 8) | (u32)value);
-    d.packed[r] = p;
 }
 // Byte rows must sit at first_byte + index
 __global__ void dirb_check_kernel(DirBuild d) {

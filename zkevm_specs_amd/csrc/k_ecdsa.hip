@@ -1,18 +1,44 @@
 // secp256k1 ECDSA verification kernel (secp256k1.hpp)
 #include "kernels.hpp"
 
-// secp256k1 ECDSA verification: one lane per signature (secp256k1.hpp); integer-ALU bound
+// One lane per signature (L = 1) or a lane pair per signature (L = 2: each lane runs one half of the GLV split with its own
+// 128-doubling chain, the partial sums meet through one DPP-free cross-lane exchange at the end).  Integer-ALU bound.
+template <int L>
 __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* status, ZkTally* tally) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = gid / L;
+    const int role = (int)(gid % L);
+    const bool valid = i < a.n;
+    u32* tab = a.qtab + gid;
+    EcdsaPrep pr;
+    u32 st = ECDSA_NOT_VERIFIED;
+    SpPoint part = sp_infinity();
+    if (valid) {
+        st = ecdsa_prepare(a, i, pr, role == 0);
+        if (st == ECDSA_PENDING) part = ecdsa_partial(pr, L == 1 ? 0 : role, L == 1 ? 1 : role, tab, a.qtab_lanes);
+    }
+    if (L == 2) {  // every lane takes part in the exchange; lane 2i receives the partial sum of lane 2i + 1
+        SpPoint other;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            other.X.v[w] = (u32)__shfl_xor((int)part.X.v[w], 1);
+            other.Y.v[w] = (u32)__shfl_xor((int)part.Y.v[w], 1);
+            other.Z.v[w] = (u32)__shfl_xor((int)part.Z.v[w], 1);
+        }
+        if (valid && role == 0 && st == ECDSA_PENDING) sp_add_ip(part, other);
+    }
     u32 code = 0;
-    if (i < a.n) {
-        code = ecdsa_verify_one(a, i);
+    if (valid && role == 0) {
+        code = st == ECDSA_PENDING ? ecdsa_verdict(pr, part) : st;
         if (status) status[i] = code;
         if (a.out) a.out[i * a.out_stride] = code;
     }
     tally_commit(tally, i, code);
 }
+
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally) {
-    // 64-lane blocks: 2^14 signatures are only 256 wavefronts, one per CU
-    hipLaunchKernelGGL(ecdsa_verify_kernel, dim3((u32)((a.n + 63) / 64)), dim3(64), 0, st, a, status, tally);
+    // 64-lane blocks: 2^14 signatures are only 256 (512 as lane pairs) wavefronts
+    const u32 grid = (u32)((a.n * a.lanes_per_sig + 63) / 64);
+    if (a.lanes_per_sig == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<2>), dim3(grid), dim3(64), 0, st, a, status, tally);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<1>), dim3(grid), dim3(64), 0, st, a, status, tally);
 }

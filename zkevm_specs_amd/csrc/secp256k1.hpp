@@ -39,24 +39,8 @@ struct SecpN {
 FR_CONST_ARR(secp_gx_m, SECP_GX_M_LIMBS)
 FR_CONST_ARR(secp_gy_m, SECP_GY_M_LIMBS)
 
-// a * b mod P for P = 2^256 - 2^32 - 977 (plain residues, a, b < P, result < P): 8 x 8 schoolbook product, then the high
-// half is folded twice with 2^256 = 2^32 + 977 (mod P) — 72 multiply-adds instead of the 128 of a Montgomery product
-ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
-    u32 t[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 c = 0;
-        const u32 bi = b.v[i];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (u64)a.v[j] * bi + t[i + j];
-            t[i + j] = (u32)c;
-            c >>= 32;
-        }
-        t[i + 8] = (u32)c;
-    }
+// 512-bit t -> t mod P for P = 2^256 - 2^32 - 977 (result < P): the high half is folded twice with 2^256 = 2^32 + 977 (mod P)
+ZK_HD Fr sp_fold_p(const u32* t) {
     // r = lo + hi * 977 + (hi << 32): ten limbs, r[9] <= 1
     u32 r[10];
     u64 c = 0;
@@ -98,6 +82,59 @@ ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
 #pragma unroll
     for (int i = 0; i < 8; i++) s.v[i] = bw ? s.v[i] : q.v[i];
     return s;
+}
+// a * b mod P for P = 2^256 - 2^32 - 977 (plain residues, a, b < P, result < P): 8 x 8 schoolbook product, then the high
+// half is folded twice with 2^256 = 2^32 + 977 (mod P) — 72 multiply-adds instead of the 128 of a Montgomery product
+ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
+    u32 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+        const u32 bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * bi + t[i + j];
+            t[i + j] = (u32)c;
+            c >>= 32;
+        }
+        t[i + 8] = (u32)c;
+    }
+    return sp_fold_p(t);
+}
+// a^2 mod P: the 28 cross products once, doubled, plus the 8 squares (36 multiply-adds instead of 64), then the same fold
+ZK_NOINLINE Fr sp_sqr_p(Fr a) {
+    u32 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        u64 c = 0;
+        const u32 ai = a.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 8; j++) {
+            c += (u64)a.v[j] * ai + t[i + j];
+            t[i + j] = (u32)c;
+            c >>= 32;
+        }
+        t[i + 8] = (u32)c;
+    }
+#pragma unroll
+    for (int k = 15; k > 0; k--) t[k] = (t[k] << 1) | (t[k - 1] >> 31);
+    t[0] = 0;
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 sq = (u64)a.v[i] * a.v[i];
+        c += (u64)t[2 * i] + (u32)sq;
+        t[2 * i] = (u32)c;
+        c >>= 32;
+        c += (u64)t[2 * i + 1] + (sq >> 32);
+        t[2 * i + 1] = (u32)c;
+        c >>= 32;
+    }
+    return sp_fold_p(t);
 }
 // Montgomery product a*b*R^-1 mod m (CIOS); a, b < m; result < m.  (Base field: the plain product above.)
 template <class M>
@@ -196,88 +233,88 @@ ZK_NOINLINE Fr sp_inv(Fr aM) {
 struct SpPoint {
     Fr X, Y, Z;  // residues mod P
 };
+ZK_HD Fr spf_mul(const Fr& a, const Fr& b) { return sp_mul_p(a, b); }
+ZK_HD Fr spf_sqr(const Fr& a) { return sp_sqr_p(a); }
+ZK_HD Fr spf_add(const Fr& a, const Fr& b) { return sp_add<SecpP>(a, b); }
+ZK_HD Fr spf_sub(const Fr& a, const Fr& b) { return sp_sub<SecpP>(a, b); }
 ZK_HD SpPoint sp_infinity() {  // (0, 0, 1)
     SpPoint p;
     p.X = fr_zero(); p.Y = fr_zero(); p.Z = SecpP::one();
     return p;
 }
-// jacobian_double: Y == 0 -> (0, 0, 0); else "dbl-2009-l" with a = 0 (any Jacobian doubling formula yields a representative
-// of the same point; only the Y == 0 / X-equality tests and the final X / Z^2 are observable)
-ZK_NOINLINE SpPoint sp_dbl(SpPoint p) {
+// jacobian_double: Y == 0 -> (0, 0, 0); else "dbl-2009-l" with a = 0, 2M + 5S (any Jacobian doubling formula yields a
+// representative of the same point; only the Y == 0 / X-equality tests and the final X / Z^2 are observable)
+ZK_HD void sp_dbl_ip(SpPoint& p) {
     if (fr_is_zero(p.Y)) {
-        SpPoint o;
-        o.X = fr_zero(); o.Y = fr_zero(); o.Z = fr_zero();
-        return o;
+        p.X = fr_zero(); p.Z = fr_zero();
+        return;
     }
-    typedef SecpP F;
-    const Fr A = sp_mont<F>(p.X, p.X), B = sp_mont<F>(p.Y, p.Y), C = sp_mont<F>(B, B);
-    Fr t = sp_add<F>(p.X, B);
-    t = sp_sub<F>(sp_sub<F>(sp_mont<F>(t, t), A), C);
-    const Fr D = sp_add<F>(t, t), E = sp_add<F>(sp_add<F>(A, A), A), Fq = sp_mont<F>(E, E);
-    SpPoint r;
-    r.X = sp_sub<F>(Fq, sp_add<F>(D, D));
-    Fr c8 = sp_add<F>(C, C);
-    c8 = sp_add<F>(c8, c8);
-    c8 = sp_add<F>(c8, c8);
-    r.Y = sp_sub<F>(sp_mont<F>(E, sp_sub<F>(D, r.X)), c8);
-    const Fr yz = sp_mont<F>(p.Y, p.Z);
-    r.Z = sp_add<F>(yz, yz);
-    return r;
+    const Fr A = spf_sqr(p.X), B = spf_sqr(p.Y), C = spf_sqr(B);
+    Fr t = spf_add(p.X, B);
+    t = spf_sub(spf_sub(spf_sqr(t), A), C);
+    const Fr D = spf_add(t, t), E = spf_add(spf_add(A, A), A), Fq = spf_sqr(E);
+    const Fr yz = spf_mul(p.Y, p.Z);
+    p.X = spf_sub(Fq, spf_add(D, D));
+    Fr c8 = spf_add(C, C);
+    c8 = spf_add(c8, c8);
+    c8 = spf_add(c8, c8);
+    p.Y = spf_sub(spf_mul(E, spf_sub(D, p.X)), c8);
+    p.Z = spf_add(yz, yz);
 }
-// jacobian_add: p.Y == 0 -> q; q.Y == 0 -> p; U1 == U2: S1 != S2 -> (0, 0, 1), else double(p); otherwise the chord
-ZK_NOINLINE SpPoint sp_add_points(SpPoint p, SpPoint q) {
-    if (fr_is_zero(p.Y)) return q;
-    if (fr_is_zero(q.Y)) return p;
-    typedef SecpP F;
-    const Fr z1z1 = sp_mont<F>(p.Z, p.Z), z2z2 = sp_mont<F>(q.Z, q.Z);
-    const Fr u1 = sp_mont<F>(p.X, z2z2), u2 = sp_mont<F>(q.X, z1z1);
-    const Fr s1 = sp_mont<F>(sp_mont<F>(p.Y, q.Z), z2z2), s2 = sp_mont<F>(sp_mont<F>(q.Y, p.Z), z1z1);
+// jacobian_add: p.Y == 0 -> q; q.Y == 0 -> p; U1 == U2: S1 != S2 -> (0, 0, 1), else double(p); otherwise the chord (12M + 4S)
+ZK_HD void sp_add_ip(SpPoint& p, const SpPoint& q) {
+    if (fr_is_zero(p.Y)) { p = q; return; }
+    if (fr_is_zero(q.Y)) return;
+    const Fr z1z1 = spf_sqr(p.Z), z2z2 = spf_sqr(q.Z);
+    const Fr u1 = spf_mul(p.X, z2z2), u2 = spf_mul(q.X, z1z1);
+    const Fr s1 = spf_mul(spf_mul(p.Y, q.Z), z2z2), s2 = spf_mul(spf_mul(q.Y, p.Z), z1z1);
     if (fr_eq(u1, u2)) {
-        if (!fr_eq(s1, s2)) return sp_infinity();
-        return sp_dbl(p);
+        if (!fr_eq(s1, s2)) p = sp_infinity();
+        else sp_dbl_ip(p);
+        return;
     }
-    const Fr h = sp_sub<F>(u2, u1), rr = sp_sub<F>(s2, s1);
-    const Fr hh = sp_mont<F>(h, h), hhh = sp_mont<F>(h, hh), v = sp_mont<F>(u1, hh);
-    SpPoint r;
-    r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
-    r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(s1, hhh));
-    r.Z = sp_mont<F>(sp_mont<F>(p.Z, q.Z), h);
-    return r;
+    const Fr h = spf_sub(u2, u1), rr = spf_sub(s2, s1);
+    const Fr hh = spf_sqr(h), hhh = spf_mul(h, hh), v = spf_mul(u1, hh);
+    const Fr zz = spf_mul(p.Z, q.Z);
+    p.X = spf_sub(spf_sub(spf_sqr(rr), hhh), spf_add(v, v));
+    p.Y = spf_sub(spf_mul(rr, spf_sub(v, p.X)), spf_mul(s1, hhh));
+    p.Z = spf_mul(zz, h);
 }
-// p + (x2, y2, 1): the fixed-base table's addition (8M + 3S); same case analysis (table entries are curve points: y2 != 0)
-ZK_NOINLINE SpPoint sp_add_affine(SpPoint p, Fr x2, Fr y2) {
-    typedef SecpP F;
+// p + (x2, y2, 1), y2 != 0: the fixed-base tables' addition (8M + 3S); same case analysis
+ZK_HD void sp_add_affine_ip(SpPoint& p, const Fr& x2, const Fr& y2) {
     if (fr_is_zero(p.Y)) {
-        SpPoint r;
-        r.X = x2; r.Y = y2; r.Z = F::one();
-        return r;
+        p.X = x2; p.Y = y2; p.Z = SecpP::one();
+        return;
     }
-    const Fr z1z1 = sp_mont<F>(p.Z, p.Z);
-    const Fr u2 = sp_mont<F>(x2, z1z1), s2 = sp_mont<F>(sp_mont<F>(y2, p.Z), z1z1);
+    const Fr z1z1 = spf_sqr(p.Z);
+    const Fr u2 = spf_mul(x2, z1z1), s2 = spf_mul(spf_mul(y2, p.Z), z1z1);
     if (fr_eq(p.X, u2)) {
-        if (!fr_eq(p.Y, s2)) return sp_infinity();
-        return sp_dbl(p);
+        if (!fr_eq(p.Y, s2)) p = sp_infinity();
+        else sp_dbl_ip(p);
+        return;
     }
-    const Fr h = sp_sub<F>(u2, p.X), rr = sp_sub<F>(s2, p.Y);
-    const Fr hh = sp_mont<F>(h, h), hhh = sp_mont<F>(h, hh), v = sp_mont<F>(p.X, hh);
-    SpPoint r;
-    r.X = sp_sub<F>(sp_sub<F>(sp_mont<F>(rr, rr), hhh), sp_add<F>(v, v));
-    r.Y = sp_sub<F>(sp_mont<F>(rr, sp_sub<F>(v, r.X)), sp_mont<F>(p.Y, hhh));
-    r.Z = sp_mont<F>(p.Z, h);
-    return r;
+    const Fr h = spf_sub(u2, p.X), rr = spf_sub(s2, p.Y);
+    const Fr hh = spf_sqr(h), hhh = spf_mul(h, hh), v = spf_mul(p.X, hh);
+    const Fr y1hhh = spf_mul(p.Y, hhh);
+    p.X = spf_sub(spf_sub(spf_sqr(rr), hhh), spf_add(v, v));
+    p.Y = spf_sub(spf_mul(rr, spf_sub(v, p.X)), y1hhh);
+    p.Z = spf_mul(p.Z, h);
+}
+ZK_HD void sp_load_affine(const uint32_t* e, Fr& x, Fr& y) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) { x.v[q] = e[q]; y.v[q] = e[8 + q]; }
 }
 // k * G, k < N: sixty-four 4-bit windows over the precomputed multiples d * 16^j * G (secp_g_table.h) — 64 mixed additions.
 // G is on the curve, so this is the group element eth-keys' double-and-add produces (k == 0: a Y == 0 point).
+// (Only the case-exact path of off-curve keys uses this; curve keys go through ecdsa_partial below.)
 ZK_NOINLINE SpPoint sp_scalar_mul_g(Fr k) {
     SpPoint acc = sp_infinity();
     for (int j = 0; j < 64; j++) {
         const u32 d = k.v[0] & 15u;
         if (d) {
-            const uint32_t* e = secp_g_table[15 * j + (int)d - 1];
             Fr x, y;
-#pragma unroll
-            for (int q = 0; q < 8; q++) { x.v[q] = e[q]; y.v[q] = e[8 + q]; }
-            acc = sp_add_affine(acc, x, y);
+            sp_load_affine(secp_g_table[15 * j + (int)d - 1], x, y);
+            sp_add_affine_ip(acc, x, y);
         }
 #pragma unroll
         for (int q = 0; q < 7; q++) k.v[q] = (k.v[q] >> 4) | (k.v[q + 1] << 28);
@@ -293,8 +330,8 @@ ZK_NOINLINE SpPoint sp_scalar_mul(SpPoint pt, Fr k) {
     while (!((k.v[top >> 5] >> (top & 31)) & 1u)) top--;
     SpPoint acc = pt;
     for (int b = top - 1; b >= 0; b--) {
-        acc = sp_dbl(acc);
-        if ((k.v[b >> 5] >> (b & 31)) & 1u) acc = sp_add_points(acc, pt);
+        sp_dbl_ip(acc);
+        if ((k.v[b >> 5] >> (b & 31)) & 1u) sp_add_ip(acc, pt);
     }
     return acc;
 }
@@ -320,6 +357,7 @@ ZK_HD Fr sp_load_be(const uint8_t* p) {
 enum { ECDSA_OK = 0, ECDSA_NOT_VERIFIED = 1 };
 #define ECDSA_BAD_SIGNATURE ZK_CODE(ZK_UNSUPPORTED, 1)   // eth_keys BadSignature: no class of its own on the wire
 #define ECDSA_KEY_RANGE ZK_CODE(ZK_UNSUPPORTED, 2)       // public-key coordinate >= P: outside the engine's domain
+#define ECDSA_PENDING 0xfffffffeu                        // internal: the verdict comes out of the joint multiplication
 
 struct EcdsaArgs {
     const uint8_t* bytes;  // per signature: pk_x LE, pk_y LE, msg_hash (BE or LE), sig_r LE, sig_s LE (32 bytes each)
@@ -331,10 +369,135 @@ struct EcdsaArgs {
     u64 n;
     u32* out;              // optional: out[i * out_stride] = status (e.g. the sign units' meta column)
     u32 out_stride;
+    u32* qtab;             // per-lane tables of the key's multiples, word w of entry e of lane l at qtab[(e * 24 + w) * qtab_lanes + l]
+    u64 qtab_lanes;
+    u32 lanes_per_sig;     // 1: one lane runs both halves of the GLV split; 2: a lane pair, one half each
 };
 
-// `ecdsa_status` of signature i: 0 verified, 1 not verified, else the status code of the exception
-ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Joint multiplication u1 G + u2 Q for keys ON the curve (there every correct group law gives eth-keys' point).
+//   * GLV: u2 = k1 + k2 lambda with |k1|, |k2| < 2^128 and lambda (x, y) = (beta x, y), so u2 Q = k1 Q + k2 Q' with
+//     Q' = (beta Qx, Qy): 128 doublings instead of 256;  u1 = lo + 2^128 hi goes with the fixed points G and 2^128 G.
+//   * 4-bit windows, most significant first: 32 steps of 4 doublings + one addition per (scalar, base) pair: the key's
+//     multiples 1..15 from a per-lane table in HBM (laid out so that a wavefront's loads coalesce; each entry is requested
+//     before the four doublings that precede its use), G's from two 15-entry constant tables (mixed additions).
+//   * "role" h = 0: (k1, Q) and (lo, G); h = 1: (k2, Q') and (hi, 2^128 G).  One lane runs both roles in one loop, or a
+//     lane pair runs one role each and the two partial sums are added at the end (half the dependent chain per lane: the
+//     small batches of the Tx circuit are latency-bound, not throughput-bound).
+//   * no inversion at the end: r == X / Z^2  <=>  r Z^2 == X.
+// ---------------------------------------------------------------------------------------------------------------------
+FR_CONST_ARR(secp_beta, SECP_BETA_LIMBS)
+FR_CONST_ARR(secp_glv_a1, SECP_GLV_A1_LIMBS)
+FR_CONST_ARR(secp_glv_mb1, SECP_GLV_MB1_LIMBS)
+FR_CONST_ARR(secp_glv_a2, SECP_GLV_A2_LIMBS)
+FR_CONST_ARR(secp_glv_b2, SECP_GLV_B2_LIMBS)
+FR_CONST_ARR(secp_glv_g1, SECP_GLV_G1_LIMBS)
+FR_CONST_ARR(secp_glv_g2, SECP_GLV_G2_LIMBS)
+
+// round(a * g / 2^384) for 256-bit a, g (the result has at most 128 bits)
+ZK_NOINLINE Fr sp_mul_shift384(Fr a, Fr g) {
+    u32 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+        const u32 gi = g.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * gi + t[i + j];
+            t[i + j] = (u32)c;
+            c >>= 32;
+        }
+        t[i + 8] = (u32)c;
+    }
+    Fr r = fr_zero();
+    u64 c = t[11] >> 31;  // rounding bit 383
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        c += t[12 + k];
+        r.v[k] = (u32)c;
+        c >>= 32;
+    }
+    r.v[4] = (u32)c;
+    return r;
+}
+// low 256 bits of a * b for a < 2^160, b < 2^160 (five limbs each; two's-complement arithmetic does the rest)
+ZK_HD Fr sp_mul_lo_5x5(const Fr& a, const Fr& b) {
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            c += (u64)a.v[j] * b.v[i] + t[i + j];
+            t[i + j] = (u32)c;
+            c >>= 32;
+        }
+        t[i + 5] = (u32)c;
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return r;
+}
+// k (< N) -> |k1|, |k2| (128 bits each) and their signs; false if a magnitude does not fit 128 bits (never for k < N, but the
+// caller then takes the plain path instead of trusting a bound)
+ZK_HD bool sp_glv_split(const Fr& k, Fr& k1, u32& neg1, Fr& k2, u32& neg2) {
+    const Fr c1 = sp_mul_shift384(k, secp_glv_g1()), c2 = sp_mul_shift384(k, secp_glv_g2());
+    Fr t, u;
+    u256_sub(t, k, sp_mul_lo_5x5(c1, secp_glv_a1()));       // mod 2^256, two's complement
+    u256_sub(k1, t, sp_mul_lo_5x5(c2, secp_glv_a2()));
+    u = sp_mul_lo_5x5(c1, secp_glv_mb1());
+    u256_sub(k2, u, sp_mul_lo_5x5(c2, secp_glv_b2()));
+    neg1 = k1.v[7] >> 31;
+    neg2 = k2.v[7] >> 31;
+    const Fr z = fr_zero();
+    if (neg1) { Fr m; u256_sub(m, z, k1); k1 = m; }
+    if (neg2) { Fr m; u256_sub(m, z, k2); k2 = m; }
+    return (k1.v[4] | k1.v[5] | k1.v[6] | k1.v[7] | k2.v[4] | k2.v[5] | k2.v[6] | k2.v[7]) == 0u;
+}
+
+// s^-1 mod N in Montgomery form (s != 0): Fermat with the exponent N - 2 = (2^127 - 1) 2^129 + low, where the run of 127
+// ones costs 126 squarings + 10 products (x^(2^k - 1) ladder) and the low 129 bits go in 2-bit windows over {x, x^2, x^3}
+ZK_NOINLINE Fr sp_inv_n(Fr xM) {
+    typedef SecpN M;
+    auto sqn = [](Fr a, int n) { for (int i = 0; i < n; i++) a = sp_mont<M>(a, a); return a; };
+    const Fr x2 = sp_mont<M>(sqn(xM, 1), xM);          // 2 ones
+    const Fr x3 = sp_mont<M>(sqn(x2, 1), xM);          // 3
+    const Fr x6 = sp_mont<M>(sqn(x3, 3), x3);
+    const Fr x12 = sp_mont<M>(sqn(x6, 6), x6);
+    const Fr x24 = sp_mont<M>(sqn(x12, 12), x12);
+    const Fr x48 = sp_mont<M>(sqn(x24, 24), x24);
+    const Fr x96 = sp_mont<M>(sqn(x48, 48), x48);
+    const Fr x120 = sp_mont<M>(sqn(x96, 24), x24);
+    const Fr x126 = sp_mont<M>(sqn(x120, 6), x6);
+    Fr acc = sp_mont<M>(sqn(x126, 1), xM);             // 127 ones
+    const Fr xx = sp_mont<M>(xM, xM), xxx = sp_mont<M>(xx, xM);
+    const Fr e = M::m2();
+    acc = sp_mont<M>(acc, acc);                          // bit 128 of N - 2 is 0
+    for (int w = 63; w >= 0; w--) {                      // bits 127..0
+        acc = sqn(acc, 2);
+        const u32 d = (e.v[w >> 4] >> ((w & 15) * 2)) & 3u;
+        if (d) acc = sp_mont<M>(acc, d == 1u ? xM : (d == 2u ? xx : xxx));
+    }
+    return acc;
+}
+
+struct EcdsaPrep {
+    Fr r;           // signature r (canonical)
+    Fr qx, qy;      // public key
+    Fr kq[2];       // |k1|, |k2|
+    Fr kg[2];       // u1 mod 2^128, u1 >> 128
+    u32 neg[2];
+};
+ZK_HD u32 sp_digit4(const Fr& k, int w) { return (k.v[w >> 3] >> ((w & 7) * 4)) & 15u; }
+
+// Validation + scalars.  ECDSA_PENDING: the key is on the curve and `pr` is filled for ecdsa_partial; any other value is
+// the final status (the case-exact path ran here).
+ZK_HD u32 ecdsa_prepare(const EcdsaArgs& a, u64 i, EcdsaPrep& pr, bool run_exact_path) {
     const uint8_t* base = a.bytes + i * a.stride;
     const Fr pkx = sp_load_le(base + a.off[0]), pky = sp_load_le(base + a.off[1]);
     const Fr z = a.msg_be ? sp_load_be(base + a.off[2]) : sp_load_le(base + a.off[2]);
@@ -344,16 +507,107 @@ ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i) {
     // validate_signature_r_or_s: 0 < value < N
     if (!fr_lt(r, n) || !fr_lt(s, n) || fr_is_zero(r) || fr_is_zero(s)) return ECDSA_BAD_SIGNATURE;
     if (!fr_lt(pkx, p) || !fr_lt(pky, p)) return ECDSA_KEY_RANGE;
-    const Fr wM = sp_inv<SecpN>(sp_to_mont<SecpN>(s));
+    const Fr wM = sp_inv_n(sp_to_mont<SecpN>(s));
     const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
     const Fr u2 = sp_mont<SecpN>(r, wM);
+    // y^2 == x^3 + 7 ?
+    Fr seven = fr_zero();
+    seven.v[0] = 7u;
+    const bool on_curve = fr_eq(spf_sqr(pky), spf_add(spf_mul(spf_sqr(pkx), pkx), seven));
+    pr.r = r; pr.qx = pkx; pr.qy = pky;
+    if (on_curve && sp_glv_split(u2, pr.kq[0], pr.neg[0], pr.kq[1], pr.neg[1])) {
+        pr.kg[0] = fr_zero(); pr.kg[1] = fr_zero();
+#pragma unroll
+        for (int q = 0; q < 4; q++) { pr.kg[0].v[q] = u1.v[q]; pr.kg[1].v[q] = u1.v[4 + q]; }
+        return ECDSA_PENDING;
+    }
+    if (!run_exact_path) return ECDSA_NOT_VERIFIED;  // the partner lane of a pair: lane 0 carries the verdict
+    // public key not on the curve: eth-keys' own chain, step by step
     SpPoint q;
     q.X = pkx; q.Y = pky; q.Z = SecpP::one();
-    const SpPoint A = sp_scalar_mul_g(u1);
+    SpPoint C = sp_scalar_mul_g(u1);
     const SpPoint B = sp_scalar_mul(q, u2);
     // fast_add(from_jacobian(A), from_jacobian(B)): the case analysis is projective, so A and B are added as they are
-    const SpPoint C = sp_add_points(A, B);
+    sp_add_ip(C, B);
     // r == from_jacobian(C).x with inv(0) == 0: Z == 0 gives x = 0 != r; else r == X / Z^2  <=>  r Z^2 == X (r < N < P)
     if (fr_is_zero(C.Z)) return ECDSA_NOT_VERIFIED;
-    return fr_eq(sp_mont<SecpP>(r, sp_mont<SecpP>(C.Z, C.Z)), C.X) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
+    return fr_eq(spf_mul(r, spf_sqr(C.Z)), C.X) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
+}
+
+ZK_HD void sp_tab_store(u32* tab, u64 stride, int e, const SpPoint& p) {
+    u32* t = tab + (u64)e * 24 * stride;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        t[(u64)w * stride] = p.X.v[w];
+        t[(u64)(8 + w) * stride] = p.Y.v[w];
+        t[(u64)(16 + w) * stride] = p.Z.v[w];
+    }
+}
+ZK_HD SpPoint sp_tab_load(const u32* tab, u64 stride, int e) {
+    const u32* t = tab + (u64)e * 24 * stride;
+    SpPoint p;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        p.X.v[w] = t[(u64)w * stride];
+        p.Y.v[w] = t[(u64)(8 + w) * stride];
+        p.Z.v[w] = t[(u64)(16 + w) * stride];
+    }
+    return p;
+}
+// Partial sum of the roles [h_lo, h_hi] (0-0, 1-1 or 0-1).  `tab`: this lane's table (15 entries x 24 words, stride apart).
+// The table holds the multiples of the FIRST role's base with that role's sign; the second role of a one-lane run derives
+// its entries from it (X times beta, Y negated when the two signs differ).
+ZK_HD SpPoint ecdsa_partial(const EcdsaPrep& pr, int h_lo, int h_hi, u32* tab, u64 stride) {
+    const Fr beta = secp_beta();
+    {   // entry e - 1 = e * base: 2k = double(k), 2k + 1 = 2k + base (mixed)
+        Fr bx = h_lo == 1 ? spf_mul(pr.qx, beta) : pr.qx;
+        Fr by = pr.neg[h_lo] ? spf_sub(fr_zero(), pr.qy) : pr.qy;
+        SpPoint b;
+        b.X = bx; b.Y = by; b.Z = SecpP::one();
+        sp_tab_store(tab, stride, 0, b);
+        for (int k = 1; k <= 7; k++) {
+            SpPoint d = sp_tab_load(tab, stride, k - 1);
+            sp_dbl_ip(d);
+            sp_tab_store(tab, stride, 2 * k - 1, d);
+            sp_add_affine_ip(d, bx, by);
+            sp_tab_store(tab, stride, 2 * k, d);
+        }
+    }
+    const bool flip = h_hi != h_lo && pr.neg[0] != pr.neg[1];
+    SpPoint acc = sp_infinity();
+    for (int w = 31; w >= 0; w--) {
+        if (w != 31) {
+            for (int k = 0; k < 4; k++) sp_dbl_ip(acc);
+        }
+        for (int h = h_lo; h <= h_hi; h++) {
+            const u32 d = sp_digit4(pr.kq[h], w);
+            if (d) {
+                SpPoint t = sp_tab_load(tab, stride, (int)d - 1);
+                if (h != h_lo) {
+                    t.X = spf_mul(t.X, beta);
+                    if (flip) t.Y = spf_sub(fr_zero(), t.Y);
+                }
+                sp_add_ip(acc, t);
+            }
+            const u32 g = sp_digit4(pr.kg[h], w);
+            if (g) {
+                Fr x, y;
+                sp_load_affine(secp_g_small[h][g - 1], x, y);
+                sp_add_affine_ip(acc, x, y);
+            }
+        }
+    }
+    return acc;
+}
+ZK_HD u32 ecdsa_verdict(const EcdsaPrep& pr, const SpPoint& C) {
+    if (fr_is_zero(C.Z)) return ECDSA_NOT_VERIFIED;
+    return fr_eq(spf_mul(pr.r, spf_sqr(C.Z)), C.X) ? ECDSA_OK : ECDSA_NOT_VERIFIED;
+}
+
+// `ecdsa_status` of signature i with one lane: 0 verified, 1 not verified, else the status code of the exception
+ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i, u32* tab, u64 stride) {
+    EcdsaPrep pr;
+    const u32 st = ecdsa_prepare(a, i, pr, true);
+    if (st != ECDSA_PENDING) return st;
+    return ecdsa_verdict(pr, ecdsa_partial(pr, 0, 1, tab, stride));
 }

@@ -920,6 +920,12 @@ extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32
     a.n = n;
     a.out = out_dev;
     a.out_stride = out_stride;
+    // lane pairs while the batch cannot fill the chip anyway (the pass is then bound by one lane's dependent chain: halve it);
+    // one lane per signature beyond that (less total work).  ZK_ECDSA_LANES=1|2 overrides (tuning / tests).
+    a.lanes_per_sig = n <= (1ull << 16) ? 2u : 1u;
+    if (const char* e = getenv("ZK_ECDSA_LANES")) a.lanes_per_sig = atoi(e) == 2 ? 2u : 1u;
+    a.qtab_lanes = ((n * a.lanes_per_sig + 63) / 64) * 64;
+    if ((rc = dev_alloc(s, (void**)&a.qtab, (size_t)a.qtab_lanes * 15 * 24 * sizeof(u32)))) goto fail;
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
