@@ -276,6 +276,37 @@ int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t*
                        uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_out, uint32_t opts,
                        zk_result* result);
 
+/* ---- Copy-circuit witness assignment: replaces `CopyCircuit.copy(r, rw_dict, src_id, src_tag, dst_id,
+ *      dst_tag, src_addr, src_addr_end, dst_addr, copy_length, src_data, log_id)` (src/zkevm_specs/evm_circuit/typing.py:
+ *      1010-1091, _append_row :1093-1151), the RW rows it appends to the RWDictionary (memory_read / memory_write /
+ *      tx_log_write, :482-492, :532-556) and the copy-table row `Tables._convert_copy_circuit_to_table` derives
+ *      (evm_circuit/table.py:627-651).  One event = one call of copy():
+ *      events ROW-major uint64[n][12][4]: src_id lo, hi, src_tag, dst_id lo, hi, dst_tag (CopyDataTypeTag, table.py:308-315),
+ *             src_addr, src_addr_end, dst_addr, copy_length, log_id, rw_counter (rw_dict.rw_counter when copy() is called);
+ *      flags uint32[n]: bit0 src_id is a Word, bit1 dst_id is a Word (WordOrValue type bits of the rows' id);
+ *      data uint16[]: per event the source bytes read below src_addr_end (i < copy_length with src_addr + i < src_addr_end),
+ *             value | is_code << 8, events back to back; data_offsets uint64[n + 1].
+ *      Domain: source values are bytes, addresses / lengths / counters are below 2^62, TxLog is never a source (the
+ *      reference asserts that) — anything else is rejected with an error code, never guessed.
+ *      Outputs: rows COLUMN-major uint64[20][n_rows][4] + row_flags uint32[n_rows] (n_rows = 2 * sum of the lengths: what
+ *      zk_copy_open takes), table uint64[n_table][14][4] (what zk_evm_tables.copy takes; one row per event that copies
+ *      something, in event order), rw uint64[n_rw][14][4] + rw_flags uint32[n_rw] (the RW rows, in rw_counter order per
+ *      event).  zk_copy_assign_sizes computes the three counts (host arithmetic over the events).  With
+ *      ZK_OPT_DEVICE_PTRS every pointer is a device pointer and the outputs land in the caller's buffers (each nullable:
+ *      the session then owns it), ready for zk_copy_open / zk_evm_open without leaving the device. */
+typedef struct zk_copy_events {
+    const uint64_t* events;     const uint32_t* flags;       uint64_t n_events;
+    const uint16_t* data;       const uint64_t* data_offsets;
+    const uint64_t* randomness;
+} zk_copy_events;
+int zk_copy_assign_sizes(const zk_copy_events* ev, uint32_t opts, uint64_t* n_rows, uint64_t* n_table, uint64_t* n_rw);
+int zk_copy_assign_open(const zk_copy_events* ev, uint64_t* rows_dev, uint32_t* row_flags_dev, uint64_t* table_dev,
+                        uint64_t* rw_dev, uint32_t* rw_flags_dev, uint32_t opts, zk_session** out);
+int zk_copy_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* table_host,
+                        uint64_t* rw_host, uint32_t* rw_flags_host);
+int zk_copy_assign(const zk_copy_events* ev, uint64_t* rows_out, uint32_t* row_flags_out, uint64_t* table_out,
+                   uint64_t* rw_out, uint32_t* rw_flags_out, uint32_t opts, zk_result* result);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.

@@ -389,3 +389,47 @@ extern "C" void sim_secp_mul(int which, const u64* a, const u64* b, u64* out, u6
         for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)r.v[2 * q] | ((u64)r.v[2 * q + 1] << 32);
     }
 }
+
+// ---- Copy-circuit witness assignment: the per-piece device functions of csrc/copy_assign.hpp in plain loops
+#include "../../zkevm_specs_amd/csrc/copy_assign.hpp"
+extern "C" int sim_copy_assign(const u64* events, const u32* flags, u64 n, const uint16_t* data, const u64* offsets, const u64* r4,
+                               u64* rows, u32* row_flags, u64* table, u64* rw, u32* rw_flags, u64 n_rows) {
+    std::vector<CpaEvent> ev(n);
+    std::vector<u64> row0(n + 1, 0);
+    std::vector<CpaChunk> chunks;
+    u64 nr = 0, nt = 0, nw = 0, nl = 0;
+    for (u64 e = 0; e < n; e++) {
+        CpaEvent& x = ev[e];
+        const u64* c = events + e * CPA_EV_NCELLS * 4;
+        x.src_tag = (u32)c[2 * 4]; x.dst_tag = (u32)c[5 * 4]; x.src_addr = c[6 * 4]; x.src_end = c[7 * 4]; x.dst_addr = c[8 * 4];
+        x.length = c[9 * 4]; x.log_id = c[10 * 4]; x.rwc = c[11 * 4]; x.flags = flags[e];
+        const u64 n_real = cpa_n_real(x);
+        x.row0 = nr; x.rw0 = nw; x.data0 = offsets[e]; x.table_idx = x.length ? (u32)nt++ : CPA_NONE;
+        x.rlc0 = 0; x.chunk0 = (u32)chunks.size(); x.n_chunks = 0;
+        if (x.dst_tag == CPA_RLC_ACC) {
+            x.rlc0 = nl; nl += x.length;
+            for (u64 g = 0; g < x.length; g += CPA_CHUNK) {
+                CpaChunk ch; ch.event = (u32)e; ch.start = (u32)g; ch.count = (u32)(x.length - g < CPA_CHUNK ? x.length - g : CPA_CHUNK); ch.pad = 0;
+                chunks.push_back(ch); x.n_chunks++;
+            }
+        }
+        row0[e] = nr;
+        nr += 2 * x.length;
+        nw += (x.src_tag == CPA_MEMORY ? n_real : 0) + ((x.dst_tag == CPA_MEMORY || x.dst_tag == CPA_TX_LOG) ? x.length : 0);
+    }
+    row0[n] = nr;
+    if (nr != n_rows) return -1;
+    std::vector<u64> rpow(CPA_RPOW_ROWS * 4), chunk_acc(chunks.size() * 4 + 4), chunk_in(chunks.size() * 4 + 4), ev_rlc(n * 4 + 4), rlc(nl * 4 + 4);
+    Fr r;
+    for (int q = 0; q < 4; q++) { r.v[2 * q] = (u32)r4[q]; r.v[2 * q + 1] = (u32)(r4[q] >> 32); }
+    cpa_fill_rpow(r, rpow.data());
+    CpaArgs a;
+    a.events = events; a.ev = ev.data(); a.row0 = row0.data(); a.n_events = n; a.n_rows = nr; a.data = data; a.rpow = rpow.data();
+    a.chunks = chunks.data(); a.n_chunks = chunks.size(); a.chunk_acc = chunk_acc.data(); a.chunk_in = chunk_in.data(); a.ev_rlc = ev_rlc.data();
+    a.rlc = rlc.data(); a.rows = rows; a.row_flags = row_flags; a.table = table; a.rw = rw; a.rw_flags = rw_flags;
+    for (u64 c = 0; c < chunks.size(); c++) cpa_chunk(a, c);
+    for (u64 e = 0; e < n; e++) cpa_prefix_event(a, e);
+    for (u64 c = 0; c < chunks.size(); c++) cpa_rlc_chunk(a, c);
+    for (u64 j = 0; j < nr; j++) cpa_write_row(a, j);
+    return 0;
+}

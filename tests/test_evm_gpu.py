@@ -77,6 +77,27 @@ def test_synthetic_trace_matches_oracle(state_sort, generic_index):
     assert res.fail_count >= 10
 
 
+def test_all_pairs_vs_oracle_at_2p16_steps():
+    """2^16-step trace with ~400 tampered cells (steps, RW rows, bytecode, type bits): EVERY pair's status against the
+    oracle, not just the failing ones, in state-sorted and trace order; one-shot C entry too."""
+    from zkevm_specs_amd import oneshot
+
+    n = 1 << 16
+    w = synth_evm_trace(n, seed=17)
+    w = {k: v for k, v in w.items() if k != "meta"}
+    rng = random.Random(23)
+    for _ in range(260):
+        w = fuzz_wire(w, rng)
+    exp = oracle_status(w)
+    assert len(exp) == n - 1 and sum(1 for c in exp if c) >= 150
+    res, status = _run(w)
+    assert status == exp
+    _check_tally(res, exp)
+    assert _run(w, state_sort=False)[1] == exp
+    res1, st1 = oneshot.evm_verify(w)
+    assert st1.tolist() == exp and res1.fail_count == res.fail_count
+
+
 def test_many_contracts_bypass_the_lds_directory_mirror():
     """40 contracts: more than the hot kernel mirrors in LDS (32), so code hashes resolve through the directory in HBM;
     wide step cells (>= 2^64) additionally take a lane off the LDS-staged step pair.  Both paths vs the oracle."""

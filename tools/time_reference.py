@@ -69,10 +69,12 @@ def time_evm():
     y = np.array([p["seconds"] / p["step_pairs"] for p in pts])
     A = np.stack([np.ones_like(x), x], axis=1)
     (a, b), *_ = np.linalg.lstsq(A, y, rcond=None)
+    if a < 0:  # a per-step cost cannot be negative: refit through the origin
+        a, b = 0.0, float((x * y).sum() / (x * x).sum())
     full_tables = meta["n_rw"] + meta["n_bytecode"]
     per_step = a + b * full_tables
     return {"measured": pts,
-            "fit": {"model": "seconds_per_step_pair = a + b * (rw_rows + bytecode_rows)", "a": float(a), "b": float(b)},
+            "fit": {"model": "seconds_per_step_pair = a + b * (rw_rows + bytecode_rows), a >= 0", "a": float(a), "b": float(b)},
             "extrapolated_2p18": {"step_pairs": (1 << 18) - 1, "table_rows": int(full_tables), "seconds": float(per_step * ((1 << 18) - 1)),
                                   "pairs_per_s": float(1.0 / per_step), "note": "EXTRAPOLATED from the fit, not measured"}}
 

@@ -16,7 +16,9 @@ for u in $UNITS; do
         pids+=($!)
     fi
 done
-for p in "${pids[@]}"; do wait "$p"; done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+if [ $fail -ne 0 ]; then echo "build failed (see $OUT/*.log)"; exit 1; fi
 if [ -n "$ZK_EXTRA_FLAGS" ]; then touch "$OUT/.extra_flags"; else rm -f "$OUT/.extra_flags"; fi
 OBJS=""
 for u in $UNITS; do OBJS="$OBJS $OUT/$u.o"; done

@@ -171,6 +171,37 @@ void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, Zk
     }
     hipLaunchKernelGGL(bca_rows_kernel, dim3((u32)((a.n_out + 255) / 256)), dim3(256), 0, st, a, status, tally);
 }
+// Copy-circuit witness assignment (copy_assign.hpp)
+__global__ void cpa_rpow_kernel(Fr r, u64* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cpa_fill_rpow(r, out);
+}
+__global__ void cpa_chunk_kernel(CpaArgs a) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n_chunks) cpa_chunk(a, c);
+}
+__global__ void cpa_prefix_kernel(CpaArgs a) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.n_events) cpa_prefix_event(a, j);
+}
+__global__ void cpa_rlc_kernel(CpaArgs a) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n_chunks) cpa_rlc_chunk(a, c);
+}
+__global__ __launch_bounds__(256) void cpa_rows_kernel(CpaArgs a, u32* status, ZkTally* tally) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.n_rows) {
+        cpa_write_row(a, j);
+        if (status) status[j] = 0;  // the assignment has no failure modes of its own (domain checks happen at open)
+    }
+    tally_commit(tally, j, 0);
+}
+void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(cpa_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }
+void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally) {
+    if (a.n_chunks) hipLaunchKernelGGL(cpa_chunk_kernel, dim3((u32)((a.n_chunks + 63) / 64)), dim3(64), 0, st, a);
+    if (a.n_events) hipLaunchKernelGGL(cpa_prefix_kernel, dim3((u32)((a.n_events + 63) / 64)), dim3(64), 0, st, a);
+    if (a.n_chunks) hipLaunchKernelGGL(cpa_rlc_kernel, dim3((u32)((a.n_chunks + 63) / 64)), dim3(64), 0, st, a);
+    if (a.n_rows) hipLaunchKernelGGL(cpa_rows_kernel, dim3((u32)((a.n_rows + 255) / 256)), dim3(256), 0, st, a, status, tally);
+}
 void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }
 void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status, ZkTally* tally) {
     hipLaunchKernelGGL(keccak_table_kernel, dim3((u32)((g.n + 255) / 256)), dim3(256), 0, st, g, status, tally);

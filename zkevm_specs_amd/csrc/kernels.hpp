@@ -13,6 +13,7 @@
 #include "state_assign.hpp"
 #include "secp256k1.hpp"
 #include "bytecode_assign.hpp"
+#include "copy_assign.hpp"
 
 // The single-kernel row sessions keep two tallies and alternate between them: a pass accumulates into one and its first
 // lane clears the other for the pass after it, so that no reset kernel sits in front of every evaluation kernel (a kernel
@@ -55,4 +56,6 @@ void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status,
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally);
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally);
+void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out);
+void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally);

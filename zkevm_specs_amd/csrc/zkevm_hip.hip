@@ -215,7 +215,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
+enum SessionKind { SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
 
 struct zk_session {
     SessionKind kind;
@@ -240,6 +240,8 @@ struct zk_session {
     AssignArgs assign;
     EcdsaArgs ecdsa;
     BcaArgs bca;
+    CpaArgs cpa;
+    u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
     u32* d_hist2 = nullptr;  // EVM: the other histogram buffer (the two alternate between passes)
@@ -1051,6 +1053,181 @@ extern "C" int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, cons
     return rc;
 }
 
+
+// ---- Copy-circuit witness assignment
+struct CpaPlan {
+    std::vector<CpaEvent> ev;
+    std::vector<u64> row0;
+    std::vector<CpaChunk> chunks;
+    u64 n_rows = 0, n_table = 0, n_rw = 0, n_rlc = 0, n_data = 0;
+};
+// index plumbing over the event cells (integers only): offsets of every event's rows / RW rows / table row / Horner chunks
+static int cpa_plan(const u64* ev_cells, const u32* flags, const u64* data_offsets, u64 n, CpaPlan& pl) {
+    pl.ev.resize(n);
+    pl.row0.assign(n + 1, 0);
+    auto small = [&](u64 e, int c, u64& v) {
+        const u64* p = ev_cells + (e * CPA_EV_NCELLS + c) * 4;
+        v = p[0];
+        return (p[1] | p[2] | p[3]) == 0 && v < (1ull << 62);
+    };
+    for (u64 e = 0; e < n; e++) {
+        CpaEvent& x = pl.ev[e];
+        u64 st, dt;
+        ARG_TRY(small(e, 2, st) && small(e, 5, dt) && small(e, 6, x.src_addr) && small(e, 7, x.src_end) && small(e, 8, x.dst_addr) &&
+                small(e, 9, x.length) && small(e, 10, x.log_id) && small(e, 11, x.rwc),
+                "zk_copy_assign: an event field is outside the wire's domain (addresses, lengths, counters below 2^62)");
+        ARG_TRY(st >= 1 && st <= 5 && dt >= 1 && dt <= 5 && st != CPA_TX_LOG && x.log_id < (1ull << 14) && x.length < (1ull << 31),
+                "zk_copy_assign: bad copy data type tag / log id / length");
+        x.src_tag = (u32)st; x.dst_tag = (u32)dt; x.flags = flags ? flags[e] : 0u;
+        const u64 room = x.src_end > x.src_addr ? x.src_end - x.src_addr : 0;  // cpa_n_real on the host
+        const u64 n_real = room < x.length ? room : x.length;
+        x.row0 = pl.n_rows; x.rw0 = pl.n_rw; x.data0 = data_offsets[e];
+        ARG_TRY(data_offsets[e + 1] >= data_offsets[e] && data_offsets[e + 1] - data_offsets[e] >= n_real, "zk_copy_assign: too few source bytes for an event");
+        x.table_idx = x.length ? (u32)pl.n_table++ : CPA_NONE;
+        x.rlc0 = 0; x.chunk0 = (u32)pl.chunks.size(); x.n_chunks = 0;
+        if (x.dst_tag == CPA_RLC_ACC) {
+            x.rlc0 = pl.n_rlc;
+            pl.n_rlc += x.length;
+            for (u64 g = 0; g < x.length; g += CPA_CHUNK) {
+                CpaChunk c;
+                c.event = (u32)e; c.start = (u32)g; c.count = (u32)(x.length - g < CPA_CHUNK ? x.length - g : CPA_CHUNK); c.pad = 0;
+                pl.chunks.push_back(c);
+                x.n_chunks++;
+            }
+        }
+        pl.row0[e] = pl.n_rows;
+        pl.n_rows += 2 * x.length;
+        pl.n_rw += (x.src_tag == CPA_MEMORY ? n_real : 0) + ((x.dst_tag == CPA_MEMORY || x.dst_tag == CPA_TX_LOG) ? x.length : 0);
+        ARG_TRY(pl.n_rows < (1ull << 32) && pl.n_rw < (1ull << 32), "zk_copy_assign: too many rows");
+    }
+    pl.row0[n] = pl.n_rows;
+    pl.n_data = n ? data_offsets[n] : 0;
+    return 0;
+}
+// host copies of the event arrays when the caller's are device pointers
+static int cpa_fetch(const zk_copy_events* t, bool dev, std::vector<u64>& cells, std::vector<u32>& flags, std::vector<u64>& offs,
+                     const u64** pc, const u32** pf, const u64** po) {
+    *pc = t->events; *pf = t->flags; *po = t->data_offsets;
+    if (!dev) return 0;
+    cells.resize((size_t)t->n_events * CPA_EV_NCELLS * 4);
+    flags.resize((size_t)t->n_events);
+    offs.resize((size_t)t->n_events + 1);
+    HIP_TRY(hipMemcpy(cells.data(), t->events, cells.size() * 8, hipMemcpyDeviceToHost));
+    if (t->flags) HIP_TRY(hipMemcpy(flags.data(), t->flags, flags.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(offs.data(), t->data_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
+    *pc = cells.data(); *pf = t->flags ? flags.data() : nullptr; *po = offs.data();
+    return 0;
+}
+extern "C" int zk_copy_assign_sizes(const zk_copy_events* t, uint32_t opts, uint64_t* n_rows, uint64_t* n_table, uint64_t* n_rw) {
+    ARG_TRY(t && t->n_events > 0 && t->events && t->data_offsets, "zk_copy_assign_sizes: bad arguments");
+    std::vector<u64> cells, offs;
+    std::vector<u32> flags;
+    const u64 *pc, *po;
+    const u32* pf;
+    int rc = cpa_fetch(t, opts & ZK_OPT_DEVICE_PTRS, cells, flags, offs, &pc, &pf, &po);
+    if (rc) return rc;
+    CpaPlan pl;
+    if ((rc = cpa_plan(pc, pf, po, t->n_events, pl))) return rc;
+    if (n_rows) *n_rows = pl.n_rows;
+    if (n_table) *n_table = pl.n_table;
+    if (n_rw) *n_rw = pl.n_rw;
+    return 0;
+}
+extern "C" int zk_copy_assign_open(const zk_copy_events* t, uint64_t* rows_dev, uint32_t* row_flags_dev, uint64_t* table_dev,
+                                   uint64_t* rw_dev, uint32_t* rw_flags_dev, uint32_t opts, zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_copy_assign_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(t && out && t->n_events > 0 && t->n_events < (1ull << 31) && t->events && t->data_offsets && t->randomness, "zk_copy_assign_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || (!rows_dev && !row_flags_dev && !table_dev && !rw_dev && !rw_flags_dev), "zk_copy_assign_open: output buffers need ZK_OPT_DEVICE_PTRS");
+    std::vector<u64> cells, offs;
+    std::vector<u32> flags;
+    const u64 *pc, *po;
+    const u32* pf;
+    int rc = cpa_fetch(t, dev, cells, flags, offs, &pc, &pf, &po);
+    if (rc) return rc;
+    CpaPlan pl;
+    if ((rc = cpa_plan(pc, pf, po, t->n_events, pl))) return rc;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_CPA;
+    s->n = pl.n_rows;
+    s->cpa_n_table = pl.n_table;
+    s->cpa_n_rw = pl.n_rw;
+    CpaArgs& a = s->cpa;
+    const void* p = nullptr;
+    void* d = nullptr;
+    u64 rh[4];
+    Fr r;
+    if ((rc = stage(s, t->events, (size_t)t->n_events * CPA_EV_NCELLS * 32, dev, &p))) goto fail;
+    a.events = (const u64*)p;
+    if ((rc = stage(s, t->data, (size_t)pl.n_data * 2, dev, &p))) goto fail;
+    a.data = (const uint16_t*)p;
+    if ((rc = stage(s, pl.ev.data(), pl.ev.size() * sizeof(CpaEvent), false, &p))) goto fail;
+    a.ev = (const CpaEvent*)p;
+    if ((rc = stage(s, pl.row0.data(), pl.row0.size() * 8, false, &p))) goto fail;
+    a.row0 = (const u64*)p;
+    if ((rc = stage(s, pl.chunks.empty() ? nullptr : pl.chunks.data(), pl.chunks.size() * sizeof(CpaChunk), false, &p))) goto fail;
+    a.chunks = (const CpaChunk*)p;
+    a.n_events = t->n_events; a.n_rows = pl.n_rows; a.n_chunks = pl.chunks.size();
+    if (dev) {
+        if (hipMemcpy(rh, t->randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
+    } else {
+        memcpy(rh, t->randomness, 32);
+    }
+    for (int q = 0; q < 4; q++) { r.v[2 * q] = (u32)rh[q]; r.v[2 * q + 1] = (u32)(rh[q] >> 32); }
+    if ((rc = dev_alloc(s, &d, CPA_RPOW_ROWS * 32))) goto fail;
+    a.rpow = (const u64*)d;
+    zk_launch_cpa_rpow(s->stream, r, (u64*)d);
+    HIP_TRY(hipStreamSynchronize(s->stream));  // the plan vectors go out of scope with this call
+    if ((rc = dev_alloc(s, &d, pl.chunks.size() * 32))) goto fail;
+    a.chunk_acc = (u64*)d;
+    if ((rc = dev_alloc(s, &d, pl.chunks.size() * 32))) goto fail;
+    a.chunk_in = (u64*)d;
+    if ((rc = dev_alloc(s, &d, (size_t)t->n_events * 32))) goto fail;
+    a.ev_rlc = (u64*)d;
+    if ((rc = dev_alloc(s, &d, (size_t)pl.n_rlc * 32))) goto fail;
+    a.rlc = (u64*)d;
+    a.rows = rows_dev; a.row_flags = row_flags_dev; a.table = table_dev; a.rw = rw_dev; a.rw_flags = rw_flags_dev;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)pl.n_rows * CPA_ROW_NCELLS * 32))) goto fail;
+    if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)pl.n_rows * 4))) goto fail;
+    if (!a.table && (rc = dev_alloc(s, (void**)&a.table, (size_t)pl.n_table * CPA_TABLE_NCELLS * 32))) goto fail;
+    if (!a.rw && (rc = dev_alloc(s, (void**)&a.rw, (size_t)pl.n_rw * CPA_RW_NCELLS * 32))) goto fail;
+    if (!a.rw_flags && (rc = dev_alloc(s, (void**)&a.rw_flags, (size_t)pl.n_rw * 4))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_copy_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* table_host,
+                                   uint64_t* rw_host, uint32_t* rw_flags_host) {
+    ARG_TRY(s && s->kind == SESSION_CPA, "zk_copy_assign_read: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    const CpaArgs& a = s->cpa;
+    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n_rows * CPA_ROW_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (row_flags_host) HIP_TRY(hipMemcpyAsync(row_flags_host, a.row_flags, (size_t)a.n_rows * 4, hipMemcpyDeviceToHost, s->stream));
+    if (table_host && s->cpa_n_table) HIP_TRY(hipMemcpyAsync(table_host, a.table, (size_t)s->cpa_n_table * CPA_TABLE_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (rw_host && s->cpa_n_rw) HIP_TRY(hipMemcpyAsync(rw_host, a.rw, (size_t)s->cpa_n_rw * CPA_RW_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (rw_flags_host && s->cpa_n_rw) HIP_TRY(hipMemcpyAsync(rw_flags_host, a.rw_flags, (size_t)s->cpa_n_rw * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+extern "C" int zk_copy_assign(const zk_copy_events* t, uint64_t* rows_out, uint32_t* row_flags_out, uint64_t* table_out,
+                              uint64_t* rw_out, uint32_t* rw_flags_out, uint32_t opts, zk_result* result) {
+    ARG_TRY(result && rows_out && row_flags_out, "zk_copy_assign: null output");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_copy_assign_open(t, dev ? rows_out : nullptr, dev ? row_flags_out : nullptr, dev ? table_out : nullptr,
+                                 dev ? rw_out : nullptr, dev ? rw_flags_out : nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && !dev) rc = zk_copy_assign_read(s, rows_out, row_flags_out, table_out, rw_out, rw_flags_out);
+    zk_close(s);
+    return rc;
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -1174,6 +1351,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_ASSIGN: zk_launch_state_assign(s->stream, s->assign, status, s->d_tally); break;
     case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
     case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
+    case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
         if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; }

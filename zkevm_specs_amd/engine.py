@@ -423,6 +423,69 @@ def open_bytecode_assign(in_rows, offsets, lengths, k, randomness, rows_dev=None
     return BytecodeAssignSession(h, 1 << int(k), (in_rows, offsets, lengths, randomness, rows_dev))
 
 
+def _copy_events_struct(events, flags, data, offsets, randomness):
+    def p(x):
+        v = _lib.ptr(x)
+        return v.value if v is not None else None
+
+    return _lib.ZkCopyEvents(p(events), p(flags), int(events.shape[0]), p(data) if data is not None and int(data.shape[0]) else None,
+                             p(offsets), p(randomness))
+
+
+def copy_assign_sizes(events, flags, data, offsets, device=None):
+    """(n_rows, n_table, n_rw) a list of copy events expands to (host arithmetic over the events)"""
+    lib = _lib.init(device)
+    _expect(events, "copy events", 8, (None, 12, 4))
+    (events, flags, data, offsets), opts = _prep([events, flags, data, offsets])
+    t = _copy_events_struct(events, flags, data, offsets, None)
+    a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib.zk_copy_assign_sizes(ctypes.byref(t), opts, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "zk_copy_assign_sizes")
+    return int(a.value), int(b.value), int(c.value)
+
+
+class CopyAssignSession(Session):
+    """Copy-circuit witness assignment session: launch()/collect() like the circuits; read() for the outputs."""
+
+    def read(self):
+        """-> (rows uint64[20, n, 4], row_flags uint32[n], table uint64[m, 14, 4], rw uint64[k, 14, 4], rw_flags uint32[k]) on the host"""
+        rows, rf = np.empty((20, self.n, 4), dtype=np.uint64), np.empty(self.n, dtype=np.uint32)
+        table = np.empty((self.n_table, 14, 4), dtype=np.uint64)
+        rw, rwf = np.empty((self.n_rw, 14, 4), dtype=np.uint64), np.empty(self.n_rw, dtype=np.uint32)
+        check(_lib.load().zk_copy_assign_read(self._h, _lib.ptr(rows), _lib.ptr(rf), _lib.ptr(table) if self.n_table else None,
+                                              _lib.ptr(rw) if self.n_rw else None, _lib.ptr(rwf) if self.n_rw else None), "zk_copy_assign_read")
+        return rows, rf, table, rw, rwf
+
+
+def open_copy_assign(events, flags, data, offsets, randomness, rows_dev=None, row_flags_dev=None, table_dev=None, rw_dev=None,
+                     rw_flags_dev=None, device=None):
+    """events uint64[n, 12, 4] (row-major copy events, include/zkevm_hip.h), flags uint32[n], data uint16[total], offsets
+    uint64[n + 1], randomness (int or uint64[4]) -> CopyAssignSession.  numpy inputs are staged to HBM; torch CUDA tensors are
+    used in place and the optional *_dev tensors (sized with copy_assign_sizes) receive the outputs, ready for open_copy /
+    open_evm."""
+    lib = _lib.init(device)
+    randomness = _randomness_cells(randomness, events)
+    _expect(events, "copy events", 8, (None, 12, 4))
+    _expect(flags, "copy event flags", 4, (events.shape[0],))
+    _expect(data, "copy source data", 2, (None,))
+    _expect(offsets, "copy data offsets", 8, (int(events.shape[0]) + 1,))
+    n_rows, n_table, n_rw = copy_assign_sizes(events, flags, data, offsets, device)
+    _expect(rows_dev, "rows_dev", 8, (20, n_rows, 4))
+    _expect(row_flags_dev, "row_flags_dev", 4, (n_rows,))
+    _expect(table_dev, "table_dev", 8, (n_table, 14, 4))
+    _expect(rw_dev, "rw_dev", 8, (n_rw, 14, 4))
+    _expect(rw_flags_dev, "rw_flags_dev", 4, (n_rw,))
+    arrs, opts = _prep([events, flags, data, offsets, randomness, rows_dev, row_flags_dev, table_dev, rw_dev, rw_flags_dev],
+                       outputs=(5, 6, 7, 8, 9))
+    events, flags, data, offsets, randomness, rows_dev, row_flags_dev, table_dev, rw_dev, rw_flags_dev = arrs
+    t = _copy_events_struct(events, flags, data, offsets, randomness)
+    h = ctypes.c_void_p()
+    check(lib.zk_copy_assign_open(ctypes.byref(t), _lib.ptr(rows_dev), _lib.ptr(row_flags_dev), _lib.ptr(table_dev), _lib.ptr(rw_dev),
+                                  _lib.ptr(rw_flags_dev), opts, ctypes.byref(h)), "zk_copy_assign_open")
+    s = CopyAssignSession(h, n_rows, arrs)
+    s.n_table, s.n_rw = n_table, n_rw
+    return s
+
+
 ECDSA_LAYOUT_PACKED = 0  # uint8[n, 5, 32]: pk_x LE, pk_y LE, msg_hash BE, sig_r LE, sig_s LE
 ECDSA_LAYOUT_TX_UNITS = 1   # uint8[n, 9, 32]: the Tx units' byte rows (open_sign's wire["bytes"]; msg_hash little-endian)
 ECDSA_LAYOUT_SIG_UNITS = 2  # the Sig units' byte rows (msg_hash big-endian; v = meta[:, 3])

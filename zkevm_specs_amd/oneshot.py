@@ -188,3 +188,21 @@ def ecdsa_verify(sig_bytes, v=None, layout=0, v_stride=1, device=None):
     status, r = np.zeros(n, dtype=np.uint32), ZkResult()
     check(lib.zk_ecdsa_verify(_p(sig_bytes), int(layout), _p(v), int(v_stride), n, 0, _p(status), ctypes.byref(r)), "zk_ecdsa_verify")
     return Result(r), status
+
+
+def copy_assign(events, flags, data, offsets, randomness, device=None):
+    """zk_copy_assign -> (Result, rows uint64[20, n, 4], row_flags uint32[n], table uint64[m, 14, 4], rw uint64[k, 14, 4], rw_flags)"""
+    from .engine import _copy_events_struct, copy_assign_sizes
+
+    lib = _lib.init(device)
+    events, flags, data, offsets = _c(events), _c(flags, np.uint32), _c(data, np.uint16), _c(offsets, np.uint64)
+    rc = _c(_randomness_cells(randomness, None))
+    _expect(events, "copy events", 8, (None, 12, 4))
+    n_rows, n_table, n_rw = copy_assign_sizes(events, flags, data, offsets, device)
+    rows, rf = np.zeros((20, n_rows, 4), dtype=np.uint64), np.zeros(n_rows, dtype=np.uint32)
+    table = np.zeros((n_table, 14, 4), dtype=np.uint64)
+    rw, rwf = np.zeros((n_rw, 14, 4), dtype=np.uint64), np.zeros(n_rw, dtype=np.uint32)
+    t = _copy_events_struct(events, flags, data, offsets, rc)
+    r = ZkResult()
+    check(lib.zk_copy_assign(ctypes.byref(t), _p(rows), _p(rf), _p(table, n_table), _p(rw, n_rw), _p(rwf, n_rw), 0, ctypes.byref(r)), "zk_copy_assign")
+    return Result(r), rows, rf, table, rw, rwf

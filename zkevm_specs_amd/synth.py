@@ -518,3 +518,89 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False, digests_of=None)
         "meta": np.array(meta, dtype=np.uint32), "keccak": rows_to_rowmajor([list(k) for k in sorted(keccak)], 5),
         "tx_rows": rows_to_rowmajor(rows, 5), "tx_flags": np.array(flags, dtype=np.uint32),
     }
+
+
+# ---- Copy circuit: synthetic copy events (the inputs of zk_copy_assign) ------------------------------------------------
+def synth_copy_events(target_rows, seed=6, max_len=192):
+    """Random copy events of every source / destination kind the reference's gadgets produce — CODECOPY / EXTCODECOPY
+    (Bytecode -> Memory), CALLDATACOPY in a root call (TxCalldata -> Memory), CALLDATACOPY / RETURNDATACOPY in an internal
+    call (Memory -> Memory), LOG (Memory -> TxLog), SHA3 (Memory -> RlcAcc), RETURN of a deployment (Memory -> Bytecode) —
+    about `target_rows` circuit rows in total, with reads running past `src_addr_end` (padding) in a third of the events.
+    Returns dict(events uint64[n, 12, 4], flags, data uint16[], offsets, r, bytecode uint64[m, 6, 4], tx uint64[k, 5, 4],
+    tx_flags): the bytecode / tx tables hold exactly the rows the copy rows look up; the RW rows come out of the assignment."""
+    rng = np.random.default_rng(seed)
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    r = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % P
+    n_codes, n_txs = 6, 5
+    codes = []
+    for c in range(n_codes):
+        ln = int(rng.integers(200, 900))
+        codes.append((int(rng.integers(1, 1 << 62)) | (c << 64), int(rng.integers(1, 1 << 62)), rng.integers(0, 256, ln, dtype=np.uint16),
+                      rng.integers(0, 2, ln, dtype=np.uint16)))
+    calldata = [rng.integers(0, 256, int(rng.integers(64, 600)), dtype=np.uint16) for _ in range(n_txs)]
+    events, flags, data, offsets = [], [], [], [0]
+    deployed = []  # bytecode rows of the codes that Memory -> Bytecode events write (RETURN of a deployment)
+    rwc, rows = 1, 0
+    while rows < target_rows:
+        kind = int(rng.integers(0, 6))
+        length = int(rng.integers(1, max_len))
+        call_id, dst_call = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        dst_addr = int(rng.integers(0, 1 << 16))
+        log_id = 0
+        fl = 0
+        if kind == 0:    # Bytecode -> Memory
+            c = codes[int(rng.integers(0, n_codes))]
+            avail = len(c[2])
+            src_addr = int(rng.integers(0, avail))
+            src_end = avail
+            src = (c[0], c[1], 1)
+            dst = (dst_call, 0, 2)
+            fl = 1
+            src_bytes = lambda a, c=c: int(c[2][a]) | (int(c[3][a]) << 8)  # noqa: E731
+        elif kind == 1:  # TxCalldata -> Memory
+            t = int(rng.integers(0, n_txs))
+            avail = len(calldata[t])
+            src_addr, src_end = int(rng.integers(0, avail)), avail
+            src, dst = (t + 1, 0, 3), (dst_call, 0, 2)
+            src_bytes = lambda a, t=t: int(calldata[t][a])  # noqa: E731
+        else:            # Memory -> Memory / TxLog / RlcAcc / Bytecode
+            src_addr = int(rng.integers(0, 1 << 16))
+            src_end = src_addr + (length if rng.random() < 0.66 else int(rng.integers(0, length + 1)))
+            mem = rng.integers(0, 256, max(src_end - src_addr, 0) + 1, dtype=np.uint16)
+            src = (call_id, 0, 2)
+            if kind == 2:
+                dst = (dst_call, 0, 2)
+            elif kind == 3:
+                dst, log_id, dst_addr = (int(rng.integers(1, n_txs + 1)), 0, 4), int(rng.integers(0, 8)), int(rng.integers(0, 1 << 12))
+            elif kind == 4:
+                dst, dst_addr = (call_id, 0, 5), 0
+            else:
+                dst, dst_addr = (int(rng.integers(1, 1 << 62)), int(rng.integers(1, 1 << 62)), 1), 0
+                fl = 2
+            is_code = rng.integers(0, 2, len(mem), dtype=np.uint16) if kind == 5 else None
+            src_bytes = lambda a, mem=mem, base=src_addr, ic=is_code: int(mem[a - base]) | ((int(ic[a - base]) << 8) if ic is not None else 0)  # noqa: E731
+        if rng.random() < 0.33 and kind in (0, 1):
+            length = max(length, src_end - src_addr + int(rng.integers(1, 16)))  # read past the end: padding rows
+        n_real = max(0, min(length, src_end - src_addr))
+        if kind == 5:
+            deployed.append([dst[0], dst[1], 1, 0, 0, length])
+            for i in range(length):
+                b = src_bytes(src_addr + i) if i < n_real else 0
+                deployed.append([dst[0], dst[1], 2, dst_addr + i, b >> 8, b & 0xFF])
+        data.extend(src_bytes(src_addr + i) for i in range(n_real))
+        offsets.append(len(data))
+        events.append([src[0], src[1], src[2], dst[0], dst[1], dst[2], src_addr, src_end, dst_addr, length, log_id, rwc])
+        flags.append(fl)
+        rwc += (n_real if src[2] == 2 else 0) + (length if dst[2] in (2, 4) else 0)
+        rows += 2 * length
+    from .wire import rows_to_rowmajor
+
+    bc_rows = []
+    for c in codes:
+        bc_rows.append([c[0], c[1], 1, 0, 0, len(c[2])])
+        bc_rows.extend([c[0], c[1], 2, i, int(c[3][i]), int(c[2][i])] for i in range(len(c[2])))
+    bc_rows.extend(deployed)
+    tx_rows = [[t + 1, 13, i, int(calldata[t][i]), 0] for t in range(n_txs) for i in range(len(calldata[t]))]
+    return {"events": rows_to_rowmajor(events, 12), "flags": np.array(flags, dtype=np.uint32), "data": np.array(data, dtype=np.uint16),
+            "offsets": np.array(offsets, dtype=np.uint64), "r": r, "bytecode": rows_to_rowmajor(sorted(bc_rows), 6),
+            "tx": rows_to_rowmajor(tx_rows, 5), "tx_flags": np.zeros(len(tx_rows), dtype=np.uint32), "n_rows": rows}
