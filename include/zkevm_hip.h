@@ -276,6 +276,22 @@ int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t*
                        uint64_t n_codes, uint32_t k, const uint64_t* randomness, uint64_t* rows_out, uint32_t opts,
                        zk_result* result);
 
+/* ---- Public-inputs (PI) circuit: replaces the `for i: check_row(rows[i], rows[(i + 1) % n], ...)` loop of
+ *      pi_circuit.verify_circuit (src/zkevm_specs/pi_circuit.py:447-459; check_row :150-322).  rows: COLUMN-major
+ *      uint64[24][n][4] (pi_circuit.Row :104-134 flattened: q_bytes_last, q_tx_table, q_tx_calldata, q_tx_calldata_start,
+ *      q_rpi_keccak_lookup, q_rpi_value_start, tx_id_inv, tx_value_lo_inv, tx_id_diff_inv, calldata_gas_cost, is_final,
+ *      q_withdrawal_table, rpi_bytes, rpi_bytes_keccakrlc, rpi_value_lc, rpi_digest_word lo, hi, q_rpi_byte_enable,
+ *      tx_table.tx_id, .tag, .index, .value.lo, withdrawal_table.id, .amount); keccak: uint64[m][5][4] (is_enabled, input_rlc,
+ *      input_len, output lo, hi; KeccakTable :74-101); gas: uint64[k][3][4] (TxCallDataGasCostAccRow :64-68: tx_id, is_final,
+ *      gas_cost_acc); circuit_len (Witness.circuit_len); keccak_rand / byte_pow_base: one cell each (the module constants
+ *      :834-836).  The fixed u16 table (:351) is a range check.  The copy constraints of verify_circuit (:355-445) compare
+ *      table cells with byte strings of the witness on the host (zkevm_specs_amd/pi_circuit.py). */
+int zk_pi_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+               uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts, zk_session** out);
+int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+                 uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts,
+                 uint32_t* status_out, zk_result* result);
+
 /* ---- Copy-circuit witness assignment: replaces `CopyCircuit.copy(r, rw_dict, src_id, src_tag, dst_id,
  *      dst_tag, src_addr, src_addr_end, dst_addr, copy_length, src_data, log_id)` (src/zkevm_specs/evm_circuit/typing.py:
  *      1010-1091, _append_row :1093-1151), the RW rows it appends to the RWDictionary (memory_read / memory_write /

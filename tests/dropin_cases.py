@@ -397,3 +397,64 @@ def mirror_tx_sig():
         n += 1
         n_dev += "tamper" not in name
     assert n >= 30 and n_dev >= 10
+
+
+def pi_witness_from_driver_fixture():
+    """the PI witness of the reference's own test configuration, rebuilt as objects from tests/golden/pi_driver.npz"""
+    from types import SimpleNamespace
+
+    g = np.load(os.path.join(GOLDEN, "pi_driver.npz"))
+    ints = lambda a: wire.cells_to_ints(a)  # noqa: E731
+    kt = SimpleNamespace(table=[(objects.FQ(x[0]), objects.FQ(x[1]), objects.FQ(x[2]), objects.Word(x[3], x[4])) for x in wire.rowmajor_to_rows(g["keccak"])])
+    cc, off = [], 0
+    raw = g["copy_constrains"].tobytes()
+    for ln in g["copy_lengths"].tolist():
+        cc.append(raw[off:off + ln])
+        off += ln
+    blk = [objects.WordOrValue(*ints(b)) for b in g["block_table"]]
+    txs = []
+    for t in g["tx_table"]:
+        v = ints(t)
+        txs.append(SimpleNamespace(tx_id=objects.FQ(v[0]), tag=objects.FQ(v[1]), index=objects.FQ(v[2]), value=objects.WordOrValue(v[3], v[4], v[5])))
+    wds = []
+    for t in g["withdrawal_table"]:
+        v = ints(t)
+        wds.append(SimpleNamespace(id=objects.FQ(v[0]), validator_id=objects.FQ(v[1]), address=objects.Word(v[2], v[3]), amount=objects.FQ(v[4])))
+    pis = [objects.Word(*ints(x)) for x in g["public_inputs"]]
+    gas = [SimpleNamespace(tx_id=objects.FQ(x[0]), is_final=objects.FQ(x[1]), gas_cost_acc=objects.FQ(x[2])) for x in wire.rowmajor_to_rows(g["gas"])]
+    w = SimpleNamespace(rows=objects.pi_rows_from_wire(g["rows"], kt), keccak_table=kt, calldata_gas_cost_table=gas,
+                        public_inputs=SimpleNamespace(pi_keccak=pis[0], block_hash=pis[1], state_root=pis[2], state_root_prev=pis[3]),
+                        block_table=SimpleNamespace(table=blk), tx_table=SimpleNamespace(table=txs), withdrawal_table=SimpleNamespace(table=wds),
+                        circuit_len=int(g["circuit_len"][0]), copy_constrains=cc)
+    return w, tuple(int(x) for x in g["shape"]), [str(x) for x in g["tamper_names"]], g["driver_kind"].tolist()
+
+
+def mirror_pi_verify_circuit():
+    """`pi_circuit.verify_circuit(witness, MAX_TXS, MAX_CALLDATA_BYTES, MAX_WITHDRAWALS)` on the reference's own test witness and
+    its seven tampering tests (tests/test_public_inputs.py:150-207), plus gate failures from tampered row cells"""
+    import copy
+
+    from zkevm_specs_amd import pi_circuit
+
+    w0, shape, names, kinds = pi_witness_from_driver_fixture()
+    word123 = objects.WordOrValue(123, 0, True)
+    tampers = {"valid": lambda w: None,
+               "bad_block_table": lambda w: w.block_table.table.__setitem__(5, word123),
+               "bad_tx_table_tx_id": lambda w: setattr(w.tx_table.table[5], "tx_id", objects.FQ(123)),
+               "bad_tx_table_index": lambda w: setattr(w.tx_table.table[5], "index", objects.FQ(123)),
+               "bad_tx_table_value": lambda w: setattr(w.tx_table.table[5], "value", word123),
+               "bad_keccak_digest": lambda w: setattr(w.public_inputs, "pi_keccak", objects.Word(123, 0)),
+               "bad_state_root": lambda w: setattr(w.public_inputs, "state_root", objects.Word(123, 0)),
+               "bad_state_root_prev": lambda w: setattr(w.public_inputs, "state_root_prev", objects.Word(123, 0))}
+    for name, kind in zip(names, kinds):
+        w = copy.deepcopy(w0)
+        tampers[name](w)
+        expect_outcome(kind, lambda: pi_circuit.verify_circuit(w, *shape))  # noqa: B023
+    # a gate failure: break the keccak-RLC chain in the middle -> AssertionError from the device pass
+    w = copy.deepcopy(w0)
+    w.rows[len(w.rows) // 2].rpi_bytes_keccakrlc = objects.FQ(7)
+    expect_outcome(codes.ASSERT, lambda: pi_circuit.verify_circuit(w, *shape))
+    # a lookup failure: the CallDataLength row's gas cost is not in the gas-cost table -> LookupUnsatFailure
+    w = copy.deepcopy(w0)
+    w.calldata_gas_cost_table = w.calldata_gas_cost_table[:1]
+    expect_outcome(codes.LOOKUP_UNSAT, lambda: pi_circuit.verify_circuit(w, *shape))

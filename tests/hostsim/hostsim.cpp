@@ -433,3 +433,24 @@ extern "C" int sim_copy_assign(const u64* events, const u32* flags, u64 n, const
     for (u64 j = 0; j < nr; j++) cpa_write_row(a, j);
     return 0;
 }
+
+// ---- Public-inputs circuit
+#include "../../zkevm_specs_amd/csrc/pi_circuit.hpp"
+extern "C" int sim_pi_verify(const u64* rows, u64 n, const u64* keccak, u64 n_keccak, const u64* gas, u64 n_gas, u64 circuit_len,
+                             const u64* keccak_rand, const u64* byte_pow_base, u32* status) {
+    PiArgs a;
+    a.rows.cells = rows; a.rows.flags = nullptr; a.rows.n = n;
+    HostTable tk, tg;
+    host_table(tk, keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    host_table(tg, gas, nullptr, n_gas, PI_GAS_NCELLS, pi_gas_key_hash);
+    a.keccak = tk.t; a.gas = tg.t;
+    Fr kr, bp;
+    for (int k = 0; k < 4; k++) {
+        kr.v[2 * k] = (u32)keccak_rand[k]; kr.v[2 * k + 1] = (u32)(keccak_rand[k] >> 32);
+        bp.v[2 * k] = (u32)byte_pow_base[k]; bp.v[2 * k + 1] = (u32)(byte_pow_base[k] >> 32);
+    }
+    a.keccak_rand_m = fr_to_mont(kr); a.byte_pow_base_m = fr_to_mont(bp);
+    a.circuit_len = fr_from_u64(circuit_len);
+    for (u64 i = 0; i < n; i++) status[i] = pi_check_row(a, i);
+    return 0;
+}

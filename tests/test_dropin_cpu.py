@@ -70,6 +70,20 @@ def oracle_backend(monkeypatch):
         rows = bytecode_assign_oracle.assign(int(k), wire.rowmajor_to_rows(in_rows), offsets, lengths, _r(randomness))
         return _result([0] * (1 << int(k))), wire.rows_to_colmajor(rows)
 
+    def pi_verify(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255, device=None):
+        from oracle import pi_oracle
+
+        st = pi_oracle.verify_rows(wire.colmajor_to_rows(rows), wire.rowmajor_to_rows(gas), wire.rowmajor_to_rows(keccak), circuit_len,
+                                   keccak_rand, byte_pow_base)
+        return _result(st), np.array(st, dtype=np.uint32)
+
+    def copy_assign(events, flags, data, offsets, randomness, device=None):
+        from oracle import copy_assign_oracle as CA
+
+        rows, rf, table, rw, rwf = CA.assign(wire.rowmajor_to_rows(np.asarray(events)), [int(f) for f in flags], data, offsets, _r(randomness))
+        return (_result([0] * len(rows)), wire.rows_to_colmajor(rows) if rows else np.zeros((20, 0, 4), np.uint64), np.array(rf, dtype=np.uint32),
+                wire.rows_to_rowmajor(table, 14), wire.rows_to_rowmajor(rw, 14), np.array(rwf, dtype=np.uint32))
+
     def ecdsa_verify(sig_bytes, v=None, layout=0, v_stride=1, device=None):
         assert layout == 0
         st = ecdsa_oracle.verify_packed(np.asarray(sig_bytes), v)
@@ -85,7 +99,7 @@ def test_every_oneshot_entry_has_a_stand_in(oracle_backend):
 
     real = [n for n, f in vars(oneshot).items() if inspect.isfunction(f) and f.__module__ == __name__]
     assert sorted(real) == sorted(["state_verify", "evm_verify", "bytecode_verify", "exp_verify", "copy_verify", "sign_verify",
-                                   "keccak_table", "state_assign", "bytecode_assign", "ecdsa_verify"])
+                                   "keccak_table", "state_assign", "bytecode_assign", "ecdsa_verify", "pi_verify", "copy_assign"])
 
 
 def test_mirror_verify_steps_host_logic(oracle_backend):
@@ -106,6 +120,33 @@ def test_mirror_copy_exp_host_logic(oracle_backend):
 
 def test_mirror_tx_sig_host_logic(oracle_backend):
     D.mirror_tx_sig()
+
+
+def test_mirror_pi_verify_circuit_host_logic(oracle_backend):
+    D.mirror_pi_verify_circuit()
+
+
+def test_copy_events_builder_host_logic(oracle_backend, golden_dir):
+    """CopyEvents.copy() takes the reference's arguments and reproduces the rows of its `CopyCircuit.copy` calls"""
+    import os
+
+    from zkevm_specs_amd.copy_circuit import CopyEvents
+
+    g = np.load(os.path.join(golden_dir, "copy_assign_cases.npz"))
+    for i in range(0, len(g["names"]), 7):
+        k = f"c{i:04d}"
+        ev = wire.rowmajor_to_rows(g[k + "_event"])[0]
+        fl = int(g[k + "_flags"][0])
+        data = g[k + "_data"].tolist()
+        n_real = max(0, min(ev[9], ev[7] - ev[6]))
+        src_data = {ev[6] + j: ((data[j] & 0xFF, data[j] >> 8) if (ev[2] == 1 or ev[5] == 1) else data[j] & 0xFF) for j in range(n_real)}
+        mk = lambda lo, hi, w: D.objects.Word(lo, hi) if w else lo  # noqa: E731
+        b = CopyEvents(wire.cells_to_ints(g[k + "_r"])[0])
+        end = b.copy(ev[11], mk(ev[0], ev[1], fl & 1), ev[2], mk(ev[3], ev[4], fl & 2), ev[5], ev[6], ev[7], ev[8], ev[9], src_data, ev[10])
+        rows, rf, table, rw, rwf = b.assign()
+        assert np.array_equal(rows, g[k + "_rows"]) and np.array_equal(rf, g[k + "_row_flags"])
+        assert np.array_equal(rw, g[k + "_rw"]) and np.array_equal(table, g[k + "_table"])
+        assert end == ev[11] + rw.shape[0]
 
 
 def test_state_assign_mirror_host_logic(oracle_backend, golden_dir):

@@ -47,6 +47,10 @@ def test_mirror_tx_and_sig_verify_circuit():
     D.mirror_tx_sig()
 
 
+def test_mirror_pi_verify_circuit():
+    D.mirror_pi_verify_circuit()
+
+
 def test_sessions_are_independent_contexts():
     """two sessions on two streams driven from two threads; zk_read_status refuses a pass whose statuses went elsewhere"""
     import threading

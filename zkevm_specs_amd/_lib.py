@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
     "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
-    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
+    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -134,6 +134,8 @@ def load():
     lib.zk_bytecode_assign_open.argtypes = [vp, u64, vp, vp, u64, u32, vp, vp, u32, ctypes.POINTER(vp)]
     lib.zk_bytecode_assign_read.argtypes = [vp, vp]
     lib.zk_bytecode_assign.argtypes = [vp, u64, vp, vp, u64, u32, vp, vp, u32, ctypes.POINTER(ZkResult)]
+    lib.zk_pi_open.argtypes = [vp, u64, vp, u64, vp, u64, u64, vp, vp, u32, ctypes.POINTER(vp)]
+    lib.zk_pi_verify.argtypes = [vp, u64, vp, u64, vp, u64, u64, vp, vp, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_copy_assign_sizes.argtypes = [ctypes.POINTER(ZkCopyEvents), u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.zk_copy_assign_open.argtypes = [ctypes.POINTER(ZkCopyEvents), vp, vp, vp, vp, vp, u32, ctypes.POINTER(vp)]
     lib.zk_copy_assign_read.argtypes = [vp, vp, vp, vp, vp, vp]

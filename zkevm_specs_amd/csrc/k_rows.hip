@@ -56,6 +56,16 @@ __global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, Z
     tally_commit(tally, i, code);
 }
 
+__global__ __launch_bounds__(256) void pi_rows_kernel(PiArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.rows.n) {
+        code = pi_check_row(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 static inline u32 grid256(u64 n) { return (u32)((n + 255) / 256); }
 void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u32* status, ZkTally* tally) {
     hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
@@ -68,6 +78,9 @@ void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u32* status, ZkTall
 }
 void zk_launch_exp_rows(hipStream_t st, const ExpArgs& a, u32* status, ZkTally* tally) {
     hipLaunchKernelGGL(exp_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
+}
+void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(pi_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
 }
 void zk_launch_fr_to_mont(hipStream_t st, const Fr& x, u64* out) { hipLaunchKernelGGL(fr_to_mont_kernel, dim3(1), dim3(64), 0, st, x, out); }
 void zk_launch_sign_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(sign_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }

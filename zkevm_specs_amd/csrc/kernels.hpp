@@ -14,6 +14,7 @@
 #include "secp256k1.hpp"
 #include "bytecode_assign.hpp"
 #include "copy_assign.hpp"
+#include "pi_circuit.hpp"
 
 // The single-kernel row sessions keep two tallies and alternate between them: a pass accumulates into one and its first
 // lane clears the other for the pass after it, so that no reset kernel sits in front of every evaluation kernel (a kernel
@@ -56,6 +57,7 @@ void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status,
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally);
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally);
+void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u32* status, ZkTally* tally);
 void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally);

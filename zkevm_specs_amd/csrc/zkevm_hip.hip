@@ -215,7 +215,7 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
+enum SessionKind { SESSION_PI = 12, SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
 
 struct zk_session {
     SessionKind kind;
@@ -241,6 +241,7 @@ struct zk_session {
     EcdsaArgs ecdsa;
     BcaArgs bca;
     CpaArgs cpa;
+    PiArgs pi;
     u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
@@ -1228,6 +1229,72 @@ extern "C" int zk_copy_assign(const zk_copy_events* t, uint64_t* rows_out, uint3
     return rc;
 }
 
+// ---- Public-inputs circuit
+extern "C" int zk_pi_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+                          uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts, zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_pi_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(out && rows && keccak_rand && byte_pow_base && n > 0 && n < (1ull << 32) && n_keccak < (1ull << 31) && n_gas < (1ull << 31), "zk_pi_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_PI;
+    s->n = n;
+    int rc = 0;
+    const void* p = nullptr;
+    u64 rh[8];
+    if ((rc = stage(s, rows, (size_t)n * PI_NCELLS * 32, dev, &p))) goto fail;
+    s->pi.rows.cells = (const u64*)p;
+    s->pi.rows.flags = nullptr;
+    s->pi.rows.n = n;
+    if ((rc = table_stage(s, s->pi.keccak, keccak, nullptr, n_keccak, KECCAK_NCELLS, dev))) goto fail;
+    if ((rc = build_index<keccak_key_hash>(s, s->pi.keccak))) goto fail;
+    if ((rc = table_stage(s, s->pi.gas, gas, nullptr, n_gas, PI_GAS_NCELLS, dev))) goto fail;
+    if ((rc = build_index<pi_gas_key_hash>(s, s->pi.gas))) goto fail;
+    if (dev) {
+        if (hipMemcpy(rh, keccak_rand, 32, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(rh + 4, byte_pow_base, 32, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = -2; g_err = "randomness download failed"; goto fail;
+        }
+    } else {
+        memcpy(rh, keccak_rand, 32);
+        memcpy(rh + 4, byte_pow_base, 32);
+    }
+    {
+        Fr kr, bp;
+        for (int k = 0; k < 4; k++) {
+            kr.v[2 * k] = (u32)rh[k]; kr.v[2 * k + 1] = (u32)(rh[k] >> 32);
+            bp.v[2 * k] = (u32)rh[4 + k]; bp.v[2 * k + 1] = (u32)(rh[4 + k] >> 32);
+        }
+        u64* d_m = nullptr;
+        u64 hm[8];
+        if ((rc = dev_alloc(s, (void**)&d_m, 64))) goto fail;
+        zk_launch_fr_to_mont(s->stream, kr, d_m);
+        zk_launch_fr_to_mont(s->stream, bp, d_m + 4);
+        if (hipMemcpyAsync(hm, d_m, 64, hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
+            rc = -2; g_err = "constant download failed"; goto fail;
+        }
+        for (int k = 0; k < 4; k++) {
+            s->pi.keccak_rand_m.v[2 * k] = (u32)hm[k]; s->pi.keccak_rand_m.v[2 * k + 1] = (u32)(hm[k] >> 32);
+            s->pi.byte_pow_base_m.v[2 * k] = (u32)hm[4 + k]; s->pi.byte_pow_base_m.v[2 * k + 1] = (u32)(hm[4 + k] >> 32);
+        }
+    }
+    s->pi.circuit_len = Fr{{(u32)circuit_len, (u32)(circuit_len >> 32), 0, 0, 0, 0, 0, 0}};
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+                            uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts,
+                            uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_pi_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_pi_open(rows, n, keccak, n_keccak, gas, n_gas, circuit_len, keccak_rand, byte_pow_base, opts, &s);
+    if (rc) return rc;
+    return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
+}
+
 extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_copy_verify: result is null");
     zk_session* s = nullptr;
@@ -1331,7 +1398,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         e1 = s->ev[2 * s->launches + 1];
     }
     const bool twin_tally = s->kind == SESSION_STATE || s->kind == SESSION_BYTECODE || s->kind == SESSION_COPY ||
-                            s->kind == SESSION_SIGN || s->kind == SESSION_EXP;
+                            s->kind == SESSION_SIGN || s->kind == SESSION_EXP || s->kind == SESSION_PI;
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
@@ -1351,6 +1418,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_ASSIGN: zk_launch_state_assign(s->stream, s->assign, status, s->d_tally); break;
     case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
     case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
+    case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, status, tally); break;
     case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass

@@ -423,6 +423,21 @@ def open_bytecode_assign(in_rows, offsets, lengths, k, randomness, rows_dev=None
     return BytecodeAssignSession(h, 1 << int(k), (in_rows, offsets, lengths, randomness, rows_dev))
 
 
+def open_pi(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255, device=None):
+    """Public-inputs circuit session: rows uint64[24, n, 4], keccak uint64[m, 5, 4], gas uint64[k, 3, 4] (include/zkevm_hip.h)"""
+    lib = _lib.init(device)
+    kr, bp = _randomness_cells(int(keccak_rand), rows), _randomness_cells(int(byte_pow_base), rows)
+    _expect(rows, "pi rows", 8, (24, None, 4))
+    _expect(keccak, "keccak", 8, (None, 5, 4))
+    _expect(gas, "gas-cost table", 8, (None, 3, 4))
+    (rows, keccak, gas, kr, bp), opts = _prep([rows, keccak, gas, kr, bp])
+    n, m, k = int(rows.shape[1]), int(keccak.shape[0]) if keccak is not None else 0, int(gas.shape[0]) if gas is not None else 0
+    h = ctypes.c_void_p()
+    check(lib.zk_pi_open(_lib.ptr(rows), n, _lib.ptr(keccak) if m else None, m, _lib.ptr(gas) if k else None, k, int(circuit_len), _lib.ptr(kr),
+                         _lib.ptr(bp), opts, ctypes.byref(h)), "zk_pi_open")
+    return Session(h, n, (rows, keccak, gas, kr, bp))
+
+
 def _copy_events_struct(events, flags, data, offsets, randomness):
     def p(x):
         v = _lib.ptr(x)

@@ -528,3 +528,23 @@ def flatten_unrolled_bytecodes(bytecodes):
         offsets.append(len(cells))
         lengths.append(len(b.bytes))
     return (rows_to_rowmajor(cells, BYTECODE_NCELLS), np.array(offsets, dtype=np.uint64), np.array(lengths, dtype=np.uint64))
+
+
+# ---- Public-inputs (PI) circuit ------------------------------------------------------------------------
+PI_NCELLS = 24
+
+
+def flatten_pi_rows(rows):
+    """pi_circuit.Row (pi_circuit.py:104-134) -> uint64[24, n, 4] column-major (cell order: oracle/pi_oracle.py)"""
+    cells = [[_n(r.q_bytes_last), _n(r.q_tx_table), _n(r.q_tx_calldata), _n(r.q_tx_calldata_start), _n(r.q_rpi_keccak_lookup),
+              _n(r.q_rpi_value_start), _n(r.tx_id_inv), _n(r.tx_value_lo_inv), _n(r.tx_id_diff_inv), _n(r.calldata_gas_cost), _n(r.is_final),
+              _n(r.q_withdrawal_table), _n(r.rpi_bytes), _n(r.rpi_bytes_keccakrlc), _n(r.rpi_value_lc), _n(r.rpi_digest_word.lo),
+              _n(r.rpi_digest_word.hi), _n(r.q_rpi_byte_enable), _n(r.tx_table.tx_id), _n(r.tx_table.tag), _n(r.tx_table.index),
+              _n(r.tx_table.value.lo), _n(r.withdrawal_table.id), _n(r.withdrawal_table.amount)] for r in rows]
+    return rows_to_colmajor(cells, PI_NCELLS)
+
+
+def flatten_pi_gas_table(table):
+    """set of TxCallDataGasCostAccRow (pi_circuit.py:64-68) -> uint64[m, 3, 4]"""
+    rows = sorted(set((_n(g.tx_id), _n(g.is_final), _n(g.gas_cost_acc)) for g in table))
+    return rows_to_rowmajor([list(r) for r in rows], 3)

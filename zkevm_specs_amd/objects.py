@@ -216,3 +216,17 @@ class CircuitRows:
 
     def table(self):
         return self.rows
+
+
+def pi_rows_from_wire(cols, keccak_table=None):
+    """uint64[24, n, 4] -> pi_circuit.Row-like objects (pi_circuit.py:104-134)"""
+    out = []
+    for c in _cols(cols):
+        out.append(SimpleNamespace(
+            q_bytes_last=FQ(c[0]), q_tx_table=FQ(c[1]), q_tx_calldata=FQ(c[2]), q_tx_calldata_start=FQ(c[3]), q_rpi_keccak_lookup=FQ(c[4]),
+            q_rpi_value_start=FQ(c[5]), tx_id_inv=FQ(c[6]), tx_value_lo_inv=FQ(c[7]), tx_id_diff_inv=FQ(c[8]), calldata_gas_cost=FQ(c[9]),
+            is_final=FQ(c[10]), q_withdrawal_table=FQ(c[11]), rpi_bytes=FQ(c[12]), rpi_bytes_keccakrlc=FQ(c[13]), rpi_value_lc=FQ(c[14]),
+            rpi_digest_word=Word(c[15], c[16]), q_rpi_byte_enable=FQ(c[17]), keccak_table=keccak_table,
+            tx_table=SimpleNamespace(tx_id=FQ(c[18]), tag=FQ(c[19]), index=FQ(c[20]), value=WordOrValue(c[21], 0, False)),
+            withdrawal_table=SimpleNamespace(id=FQ(c[22]), validator_id=FQ(0), address=Word(0, 0), amount=FQ(c[23]))))
+    return out

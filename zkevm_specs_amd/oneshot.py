@@ -206,3 +206,18 @@ def copy_assign(events, flags, data, offsets, randomness, device=None):
     r = ZkResult()
     check(lib.zk_copy_assign(ctypes.byref(t), _p(rows), _p(rf), _p(table, n_table), _p(rw, n_rw), _p(rwf, n_rw), 0, ctypes.byref(r)), "zk_copy_assign")
     return Result(r), rows, rf, table, rw, rwf
+
+
+def pi_verify(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255, device=None):
+    """zk_pi_verify -> (Result, status uint32[n])"""
+    lib = _lib.init(device)
+    rows, keccak, gas = _c(rows), _c(keccak), _c(gas)
+    kr, bp = _c(_randomness_cells(int(keccak_rand), None)), _c(_randomness_cells(int(byte_pow_base), None))
+    _expect(rows, "pi rows", 8, (24, None, 4))
+    _expect(keccak, "keccak", 8, (None, 5, 4))
+    _expect(gas, "gas-cost table", 8, (None, 3, 4))
+    n, m, k = int(rows.shape[1]), 0 if keccak is None else int(keccak.shape[0]), 0 if gas is None else int(gas.shape[0])
+    status, r = np.zeros(n, dtype=np.uint32), ZkResult()
+    check(lib.zk_pi_verify(_p(rows), n, _p(keccak, m), m, _p(gas, k), k, int(circuit_len), _p(kr), _p(bp), 0, _p(status), ctypes.byref(r)),
+          "zk_pi_verify")
+    return Result(r), status
