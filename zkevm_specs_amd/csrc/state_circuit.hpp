@@ -213,21 +213,29 @@ ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
 #define ST_PREV_U32(x) (P.x)
 #define ST_PREV_FR(f) (P.f)
 #else
-// value of the same expression in lane - 1 (gfx9 DPP wave_shr:1; lane 0 is the halo and unused)
-ZK_HD u32 st_shr_u32(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+// value of the same expression in the lane that holds the previous row: lane - 1 with one lane per row (gfx9 DPP wave_shr:1),
+// lane - 4 with a lane quad per row (ds_bpermute through __shfl_up; no LDS memory involved).  The first row's lanes are the
+// halo and unused.
+template <int SHIFT>
+ZK_HD u32 st_shr_u32(u32 v) {
+    if constexpr (SHIFT == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    else return (u32)__shfl_up((int)v, SHIFT);
+}
+template <int SHIFT>
 ZK_HD Fr st_shr_fr(const Fr& x) {
     Fr r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = st_shr_u32(x.v[k]);
+    for (int k = 0; k < 8; k++) r.v[k] = st_shr_u32<SHIFT>(x.v[k]);
     return r;
 }
-#define ST_PREV_U32(x) st_shr_u32(C.x)
-#define ST_PREV_FR(f) st_shr_fr(C.f)
+#define ST_PREV_U32(x) st_shr_u32<SHIFT>(C.x)
+#define ST_PREV_FR(f) st_shr_fr<SHIFT>(C.f)
 #endif
 
 // Checks of row i that involve the previous row (sites 9..13) and the per-tag rules; C = this
 // row, P = previous row (host build only; the device takes it from the neighbouring lane).
 // Must be called by every lane of the wavefront (the DPP moves read the neighbour's registers).
+template <int SHIFT = 1>
 ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const StRow& P, u32 code) {
     (void)P;
     const ZkCols& w = a.rows;
@@ -437,6 +445,100 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
     }
     return code;
 }
+
+#ifndef ZK_HOSTSIM
+// ---- A lane QUAD per row.  The 56 cells a row's own checks read are dealt round-robin to the four lanes (cell c goes to
+// lane c & 3: fourteen 32-byte loads per lane instead of 56, all of them in flight at once), each lane range-checks and packs
+// the limb / byte cells it holds, the partial packings are OR-reduced across the quad with two DPP quad_perm steps and the
+// wide cells are broadcast from their owner lane — after which every lane of the quad holds the full StRow and lane 0 of the
+// quad carries the verdict.  A wavefront covers 16 rows (15 evaluated + the halo row in front of them), so a launch has four
+// times the wavefronts of the one-lane-per-row form and a quarter of its per-lane dependent work: that is what the
+// latency-bound small batches (BASELINE config 2: 2^16 rows) and the load-issue-bound large ones both want.
+template <int K>
+ZK_HD u32 st_quad_bcast_u32(u32 v) {  // value of lane K of this lane's quad
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false);
+}
+template <int K>
+ZK_HD Fr st_quad_bcast(const Fr& x) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = st_quad_bcast_u32<K>(x.v[k]);
+    return r;
+}
+ZK_HD u32 st_quad_or(u32 v) {
+    v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+    v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+    return v;
+}
+ZK_HD void state_load_row_quad(const ZkCols& w, u64 i, u32 q, StRow& R, u32& code) {
+    R.flags = w.flags ? w.flags[i] : 0u;
+    Fr mine[14];  // cell q + 4 k
+#pragma unroll
+    for (int k = 0; k < 14; k++) mine[k] = zk_col(w, q + 4u * (u32)k, i);
+    // limb cells 8..17 and key-byte cells 18..49 held by this lane: range flags + their bits of the packed values
+    u32 lc[5] = {0, 0, 0, 0, 0}, key[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bad_limb = 0, bad_byte = 0;
+#pragma unroll
+    for (int k = 2; k < 13; k++) {
+        const u32 c = q + 4u * (u32)k;  // 8 .. 51
+        const Fr& x = mine[k];
+        if (c < (u32)ST_BYTE0) {
+            const u32 l = c - (u32)ST_LIMB0;
+            bad_limb |= fr_le_u64(x, 65535) ? 0u : 1u;
+            lc[l >> 1] |= (x.v[0] & 0xffffu) << (16u * (l & 1u));
+        } else if (c < (u32)ST_VAL_LO) {
+            const u32 b = c - (u32)ST_BYTE0;
+            bad_byte |= fr_le_u64(x, 255) ? 0u : 1u;
+            key[b >> 2] |= (x.v[0] & 0xffu) << (8u * (b & 3u));
+        }
+    }
+    bad_limb = st_quad_or(bad_limb);
+    bad_byte = st_quad_or(bad_byte);
+    U256 lcv = fr_zero(), keyv;
+#pragma unroll
+    for (int k = 0; k < 5; k++) lcv.v[k] = st_quad_or(lc[k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) keyv.v[k] = st_quad_or(key[k]);
+    // the wide cells, from their owner lanes
+    R.rwc = st_quad_bcast<0>(mine[0]);
+    const Fr is_write = st_quad_bcast<1>(mine[0]);
+    R.tag = st_quad_bcast<2>(mine[0]);
+    R.id = st_quad_bcast<3>(mine[0]);
+    R.addr = st_quad_bcast<0>(mine[1]);
+    R.ftag = st_quad_bcast<1>(mine[1]);
+    R.key_lo = st_quad_bcast<2>(mine[1]);
+    R.key_hi = st_quad_bcast<3>(mine[1]);
+    R.val_lo = st_quad_bcast<2>(mine[12]);
+    R.val_hi = st_quad_bcast<3>(mine[12]);
+    R.init_lo = st_quad_bcast<0>(mine[13]);
+    R.init_hi = st_quad_bcast<1>(mine[13]);
+    R.root_lo = st_quad_bcast<2>(mine[13]);
+    R.root_hi = st_quad_bcast<3>(mine[13]);
+    // sites 1..8 exactly as state_load_row
+    ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
+    ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
+    ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
+    ST_ASSERT(!bad_limb, 4);
+    ST_ASSERT(fr_eq(R.addr, lcv), 5);
+    R.pack_ok = bad_byte ? 0u : 1u;
+    ST_ASSERT(!bad_byte, 6);
+    ST_ASSERT(fr_eq(R.key_lo, u256_lo(keyv)) && fr_eq(R.key_hi, u256_hi(keyv)), 7);
+    ST_ASSERT(fr_le_u64(is_write, 1), 8);
+    R.is_write01 = fr_is_zero(is_write) ? 0u : (fr_eq_u64(is_write, 1) ? 1u : 2u);
+    {
+        Big18 out;
+        for (int k = 0; k < 18; k++) out.v[k] = 0;
+        big_shl_add(out, 0, 0, R.tag);
+        big_shl_add(out, 0, 28, R.id);
+        big_shl_add(out, 5, 0, R.addr);
+        big_shl_add(out, 0, 16, R.ftag);
+        big_shl_add(out, 1, 0, keyv);
+        big_shl_add(out, 1, 0, R.rwc);
+        out.v[15] &= 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 16; k++) R.pack[k] = out.v[k];
+    }
+}
+#endif
 
 #ifdef ZK_HOSTSIM
 // Evaluate row i against prev = (i-1) mod n and next = (i+1) mod n (host build: both rows loaded).
