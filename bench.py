@@ -103,6 +103,8 @@ def main():
     def to_dev(x):
         if x.dtype == np.uint8:
             return torch.from_numpy(x).cuda()
+        if x.dtype.itemsize == 2:
+            return torch.from_numpy(x.view(np.int16)).cuda()
         return torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
 
     h2d = {"bytes": 0, "seconds": 0.0}
@@ -203,20 +205,22 @@ def main():
         extra_cfg = {"txs_per_gpu": n}
     elif args.workload == "super":
         # BASELINE configs[4]: EVM + State + Bytecode + Tx kernels over one witness set of 2^log_rows rows per GPU
-        from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super
+        from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
 
-        parts = synth_super(log_rows, seed=5 + rank)
+        # ONE consistent witness: the State rows are the EVM trace's RW table (synth_block.py), Copy / Exp circuits included
+        parts = synth_super_block(log_rows, seed=5 + rank)
         super_meta = parts["meta"]
         sess = SuperCircuit(parts, device=local_rank, to_device=to_dev)
         units, row_offset = sum(sess.rows.values()), rank * sum(sess.rows.values())
         total_units = units * world
         tx_bytes = 8 * 32 + 288 + 2 * 5 * 32
         super_bytes = {"evm": super_meta["algorithmic_bytes"], "state": sess.rows["state"] * 57 * 32,
-                       "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * tx_bytes}
+                       "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * tx_bytes,
+                       "copy": sess.rows.get("copy", 0) * (20 + 14) * 32, "exp": sess.rows.get("exp", 0) * 21 * 32}
         algo_bytes = None  # per-circuit, resolved after the run (dominant kernel)
         kernel_name, kernel_needle = None, None
-        workload = (f"Super circuit, 2^{log_rows} rows per GPU (BASELINE configs[4]): " +
-                    ", ".join(f"{k} {v}" for k, v in sess.rows.items()) + " rows")
+        workload = (f"Super circuit, ~2^{log_rows} rows per GPU over ONE consistent witness (BASELINE configs[4]; State rows = the EVM trace's RW "
+                    "table re-keyed and re-sorted): " + ", ".join(f"{k} {v}" for k, v in sess.rows.items()) + " rows")
         extra_cfg = {"rows_per_gpu": dict(sess.rows), "state_assign_ms": sess.assign_ms}
     else:
         from zkevm_specs_amd.synth import synth_state_witness
@@ -272,7 +276,7 @@ def main():
                            "algorithmic_GBps": super_bytes[k] / (r.kernel_ms / 1e3) / 1e9} for k, r in results.items()}
         dom = max(results, key=lambda k: results[k].kernel_ms)
         kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_kernel", "bytecode": "bytecode_rows_kernel",
-                       "tx": "sign_units_kernel"}[dom]
+                       "tx": "sign_units_kernel", "copy": "copy_rows_kernel", "exp": "exp_rows_kernel"}[dom]
         kernel_needle = (kernel_name,) + (("-1",) if dom == "evm" else ())
         algo_bytes = super_bytes[dom]
 
@@ -348,7 +352,7 @@ def main():
         traffic = valu = None
         if kc and "pmc" in kc:
             pmc = kc["pmc"]
-            corr = FETCH_STREAM_CORRECTION if kernel_name == "state_rows_kernel" else FETCH_GATHER_CORRECTION
+            corr = FETCH_GATHER_CORRECTION if kernel_name == "evm_steps_kernel" else FETCH_STREAM_CORRECTION
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = pmc["FETCH_SIZE"]["avg_per_dispatch"] * 1024.0 * corr + pmc["WRITE_SIZE"]["avg_per_dispatch"] * 1024.0
             if "SQ_ACTIVE_INST_VALU" in pmc:
@@ -405,6 +409,15 @@ def main():
                                 "rows_per_s_including_h2d": units / (h2d["seconds"] + dt / args.steps),
                                 "note": "pageable host arrays -> HBM (torch .cuda()); never part of `value`"}
         if per_circuit is not None:
+            # per-circuit HBM-side traffic from the committed counter passes of this workload (when there are any)
+            names = {"evm": ("evm_steps_kernel", "-1"), "state": ("state_rows",), "bytecode": ("bytecode_rows_kernel",), "tx": ("sign_units_kernel",),
+                     "copy": ("copy_rows_kernel",), "exp": ("exp_rows_kernel",)}
+            for k, v in per_circuit.items():
+                kc2 = kernel_counters(profile, names[k])
+                if kc2 and "pmc" in kc2 and "FETCH_SIZE" in kc2["pmc"]:
+                    corr = FETCH_STREAM_CORRECTION if k != "evm" else FETCH_GATHER_CORRECTION
+                    v["traffic_bytes"] = kc2["pmc"]["FETCH_SIZE"]["avg_per_dispatch"] * 1024.0 * corr + kc2["pmc"].get("WRITE_SIZE", {}).get("avg_per_dispatch", 0) * 1024.0
+                    v["traffic_GBps"] = v["traffic_bytes"] / (v["kernel_ms"] / 1e3) / 1e9
             out["roofline"]["per_circuit"] = per_circuit
         if args.workload == "tx":
             out["roofline"]["ecdsa_verify_kernel_ms"] = res.ecdsa_ms

@@ -70,3 +70,59 @@ def test_super_circuit_on_device_and_tamper_localisation():
     assert not results["bytecode"].ok  # the re-assigned value_rlc no longer matches the keccak table at the end of that contract
     assert not results["tx"].ok and results["tx"].first_fail_row == 5
     assert total == sum(r.fail_count for r in results.values()) >= 4 and first[0] == "evm"
+
+
+def test_block_witness_is_one_consistent_witness():
+    """config 5 as stated: the State rows ARE the EVM trace's RW table (re-keyed, re-sorted) and satisfy the State circuit; the trace
+    satisfies the EVM circuit; the Bytecode rows are the executed contracts; copy events expand to a valid Copy witness"""
+    from oracle import copy_assign_oracle, copy_oracle
+    from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, synth_super_block
+
+    p = synth_super_block(13, seed=7, keccak_rows_of=_oracle_keccak)
+    assert set(p["rows"]) == set(BLOCK_CIRCUITS) and 0.85 * (1 << 13) < sum(p["rows"].values()) < 1.15 * (1 << 13)
+    assert not any(oracle_status(dict(p["evm"])))
+    ops, flags = p["state_ops"]
+    assert ops.shape[1] == p["evm"]["rw"].shape[0] + 1 - int((p["evm"]["rw"][:, 2, 0] == 7).astype(int) @ (p["evm"]["rw"][:, 4, 0] > 24).astype(int))
+    rows, rflags, mpt, status = assign_oracle.assign(wire.colmajor_to_rows(ops), flags.tolist())
+    assert not any(status) and not any(state_oracle.verify_rows(rows, rflags, mpt))
+    # every RW row of the trace is in the State witness under its State key (rw_counter is unique)
+    by_rwc = {r[0]: r for r in rows}
+    for c in wire.rowmajor_to_rows(p["evm"]["rw"][:: 37]):
+        if c[2] == 7 and c[4] > 24:
+            continue
+        s_row = by_rwc[c[0]]
+        assert s_row[1] == c[1] and (s_row[50], s_row[51]) == (c[8], c[9])
+    bc_rows, keccak, r = p["bytecode"]
+    assert not any(row_oracles.bytecode_verify_rows(wire.colmajor_to_rows(bc_rows), wire.rowmajor_to_rows(keccak), r))
+    ce = p["copy_events"]
+    c_rows, c_rf, _, c_rw, c_rwf = copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"], ce["offsets"], ce["r"])
+    T = copy_oracle.CopyTables(c_rw, c_rwf, wire.rowmajor_to_rows(ce["bytecode"]), wire.rowmajor_to_rows(ce["tx"]), ce["tx_flags"])
+    assert not any(copy_oracle.verify_rows(c_rows, c_rf, T, ce["r"]))
+    assert not any(row_oracles.exp_verify_rows(wire.colmajor_to_rows(p["exp_rows"])))
+
+
+@pytest.mark.gpu
+def test_block_super_circuit_on_device():
+    import torch
+
+    from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, SuperCircuit, synth_super_block
+
+    p = synth_super_block(16, seed=3)
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    with SuperCircuit(p, to_device=dev) as sc:
+        assert set(sc.rows) == set(BLOCK_CIRCUITS) and sc.rows == p["rows"]
+        sc.launch()
+        results, total, first = sc.collect()
+        assert total == 0 and first is None and all(r.ok for r in results.values()), {k: (r.fail_count, r.first_fail_row, r.first_fail_code) for k, r in results.items()}
+    # tamper the SHARED data: one RW value cell.  The EVM circuit (the step that looks the row up) and the State circuit (the
+    # row's read consistency) must both notice
+    rw = p["evm"]["rw"]
+    i = next(j for j in range(2000, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)  # a Stack read
+    rw[i, 8, 0] ^= np.uint64(1)
+    from zkevm_specs_amd.synth_block import rw_to_state_ops
+
+    p["state_ops"] = rw_to_state_ops(rw, p["evm"]["rw_flags"])
+    with SuperCircuit(p) as sc:
+        sc.launch()
+        results, total, first = sc.collect()
+    assert not results["evm"].ok and not results["state"].ok and results["bytecode"].ok and results["copy"].ok and results["exp"].ok

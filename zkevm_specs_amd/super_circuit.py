@@ -24,6 +24,7 @@ from .synth_evm import synth_evm_codes, synth_evm_trace
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 CIRCUITS = ("evm", "state", "bytecode", "tx")
+BLOCK_CIRCUITS = CIRCUITS + ("copy", "exp")
 
 
 def _digest_of_row(row):
@@ -76,6 +77,51 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows)}
 
 
+def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
+    """BASELINE config 5 over ONE consistent witness (synth_block.py): the State circuit's rows ARE the EVM trace's RW table
+    (re-keyed with the explicit Target -> Tag / key-slot mapping of synth_block.rw_to_state_ops and re-sorted), the Bytecode
+    circuit's rows are the contracts the trace executes (their code hashes the keccak digests of the device-built keccak
+    table), plus a Copy circuit (copy events expanded on the device, zk_copy_assign) and an Exp circuit — about 2^log_total
+    rows in total: the EVM share is sized so that its RW table (about 2.9 rows per step) fits.  Returns the dict
+    SuperCircuit takes; `rows` has the six circuits."""
+    from .synth import synth_copy_events, synth_exp_witness
+    from .synth_block import rw_to_state_ops, synth_block_codes, synth_block_trace
+
+    assert log_total >= 12
+    total = 1 << log_total
+    r = (0x1234567 * (seed + 1) ** 7 + 0x9E3779B97F4A7C15) % P
+    n_contracts = min(16, 1 << (log_total - 16)) if log_total >= 16 else 2
+    seg_len = 640 if log_total >= 16 else 96
+    codes = synth_block_codes(seed, seg_len=seg_len, n_contracts=n_contracts)
+    if keccak_rows_of is None:
+        keccak_rows_of = lambda c, rr: engine.keccak_table(c, rr, engine.KECCAK_MODE_CIRCUIT)  # noqa: E731
+    keccak = keccak_rows_of(codes, r)
+    hashes = [_digest_of_row(keccak[i]) for i in range(len(codes))]
+    n_code_rows = sum(len(c) + 1 for c in codes)
+    k = max(6, int(np.ceil(np.log2(n_code_rows + 1))))
+    n_tx = 1 << max(log_total - 8, 2)
+    n_copy_target = 1 << max(log_total - 5, 6)
+    n_exp = 1 << max(log_total - 8, 4)
+    n_steps = int((total - (1 << k) - n_tx - n_copy_target - n_exp) / 3.95)
+    evm = synth_block_trace(n_steps, seed=seed, seg_len=seg_len, n_contracts=n_contracts, code_hashes=hashes)
+    meta = evm.pop("meta")
+    ops, op_flags = rw_to_state_ops(evm["rw"], evm["rw_flags"])
+    digest = dict(zip(codes, hashes))
+    bc_rows, bc_keccak = synth_bytecode_witness(codes, k, r, digest=lambda c: digest[c])
+    tx = synth_tx_witness(n_tx, r, seed=seed + 1)
+    bt = evm["bytecode"].copy()
+    n_bt = bt.shape[0]
+    starts = [0] + [i for i in range(1, n_bt) if not np.array_equal(bt[i, 0:2], bt[i - 1, 0:2])] + [n_bt]
+    offsets = np.array(starts, dtype=np.uint64)
+    lengths = (offsets[1:] - offsets[:-1] - np.uint64(1)).astype(np.uint64)
+    copy_ev = synth_copy_events(n_copy_target, seed=seed + 3)
+    exp_rows = synth_exp_witness(n_exp, seed=seed + 4)
+    rows = {"evm": n_steps - 1, "state": int(ops.shape[1]), "bytecode": 1 << k, "tx": n_tx, "copy": int(copy_ev["n_rows"]), "exp": n_exp}
+    return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "bytecode_unrolled": (bt, offsets, lengths, k),
+            "tx": (tx, r), "copy_events": copy_ev, "exp_rows": exp_rows, "rows": rows,
+            "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True)}
+
+
 class SuperCircuit:
     """Sessions of the four circuits over one witness set; launch() enqueues one pass of each, collect() returns
     ({circuit: Result}, total fail_count, first failing (circuit, row, code))."""
@@ -125,6 +171,28 @@ class SuperCircuit:
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign({k: dev(v) for k, v in tx.items()}, r_tx, False, device=device),
         }
+        # Copy circuit: events expanded on the device (rows + their RW rows), then evaluated from the same HBM buffers
+        if "copy_events" in parts:
+            ce = parts["copy_events"]
+            ev, fl, da, of = dev(ce["events"]), dev(ce["flags"]), (dev(ce["data"].view(np.int16)) if hasattr(ops, "is_cuda") else ce["data"]), dev(ce["offsets"])
+            if hasattr(ops, "is_cuda"):
+                import torch
+
+                n_rows, n_table, n_rw = engine.copy_assign_sizes(ce["events"], ce["flags"], ce["data"], ce["offsets"], device)
+                c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device=ops.device)
+                c_rf = torch.empty(n_rows, dtype=torch.int32, device=ops.device)
+                c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=ops.device)
+                c_rwf = torch.empty(n_rw, dtype=torch.int32, device=ops.device)
+                with engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, None, c_rw, c_rwf, device=device) as a:
+                    assert a.run().ok
+            else:
+                with engine.open_copy_assign(ce["events"], ce["flags"], ce["data"], ce["offsets"], ce["r"], device=device) as a:
+                    assert a.run().ok
+                    c_rows, c_rf, _, c_rw, c_rwf = a.read()
+            self.sessions["copy"] = engine.open_copy(c_rows, c_rf, ce["r"], c_rw, c_rwf, dev(ce["bytecode"]), dev(ce["tx"]), dev(ce["tx_flags"]),
+                                                     device=device)
+        if "exp_rows" in parts:
+            self.sessions["exp"] = engine.open_exp(dev(parts["exp_rows"]), device=device)
         self.rows = {k: s.n for k, s in self.sessions.items()}
         # one HIP stream per circuit: the kernels are independent and bound by different things (the State kernel streams
         # HBM, the EVM kernel is latency / issue bound), so their passes overlap on the device
