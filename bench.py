@@ -421,6 +421,15 @@ def main():
             out["roofline"]["per_circuit"] = per_circuit
         if args.workload == "tx":
             out["roofline"]["ecdsa_verify_kernel_ms"] = res.ecdsa_ms
+            ke = kernel_counters(profile, ("ecdsa_verify_kernel",))
+            if ke and "pmc" in ke and "SQ_ACTIVE_INST_VALU" in ke["pmc"]:
+                act = ke["pmc"]["SQ_ACTIVE_INST_VALU"]["avg_per_dispatch"] * 4.0
+                out["roofline"]["ecdsa_valu"] = {
+                    "insts_valu_per_launch": ke["pmc"]["SQ_INSTS_VALU"]["avg_per_dispatch"], "active_valu_cycles_per_launch": act,
+                    "wavefronts": ke["pmc"].get("SQ_WAVES", {}).get("avg_per_dispatch"),
+                    "frac_of_issue_peak": act / ((res.ecdsa_ms / 1e3) * SHADER_CLOCK_HZ * N_SIMD),
+                    "note": "the pass is VALU-issue bound: one wavefront per SIMD issues one VALU instruction per ~4 cycles (half the "
+                            f"2-cycle SIMD rate, profiles/r02_valu_issue_rates.txt); counters from {profile_src}"}
             out["roofline"]["note"] = ("the pass is dominated by ecdsa_verify_kernel (integer-ALU bound, no HBM roofline); the roofline block "
                                        "describes the SignVerify kernel")
         if not args.no_cpu_baseline and args.workload != "tx":
