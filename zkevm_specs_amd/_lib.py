@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkevm_hip.so")
+LIB_PATH = os.environ.get("ZK_HIP_LIB") or os.path.join(_HERE, "libzkevm_hip.so")  # ZK_HIP_LIB: tuning builds (tools/)
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",

@@ -62,18 +62,40 @@ struct EvmArgs {
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
 };
 
-// LDS staging of the step pair (hot kernel): slots 0-12 curr cells, 13-25 next cells (low 64 bits), 26-29 bits 64-127 of the
-// four code-hash cells.  One u64 per slot and lane, lane-major (conflict-free ds_read_b64 / ds_write_b64).
-#define EVM_STAGE_LANES 256
-#define EVM_STAGE_SLOTS 30
+// LDS staging of the step pair (hot kernel), one u32 entry per lane, lane-major (conflict-free ds_read_b32 / ds_write_b32).
+// Per step s (0 curr, 1 next) 12 entries at s * 12: the ten cells that are small integers in every well-formed witness
+// (state, rw_counter, call_id, is_root, is_create, pc, sp, memory_word_size, reversible_write_counter, log_id) as 32 bits
+// each, gas_left as 64; then the two code-hash cells as 128 bits each at 24 + s * 8.  40 entries = 160 B per lane (it was
+// 240 B with one u64 per cell): 40 KB per 256-lane block, so three blocks share a CU's 160 KB instead of two.  A pair with
+// a cell wider than its entry (malformed witnesses only) is not staged: that lane reads its step rows from HBM.
+// Lanes per workgroup of the hot kernel.  A workgroup is dispatched when all of its wavefronts find a slot, and wavefronts
+// of one group finish far apart (execution states differ 10x in length): with 4-wavefront groups the chip ran 1600-1800 of
+// its 2048 slots in mid-kernel, with 2-wavefront groups it stays full (kernel 83.4 -> 80.6 us at 2^18 steps); 1-wavefront
+// groups pay the LDS directory mirror per wavefront and were slower (88.5 us).
+#ifndef EVM_HOT_BLOCK
+#define EVM_HOT_BLOCK 128
+#endif
+#define EVM_STAGE_LANES EVM_HOT_BLOCK
+// tuning aid: slot of this wavefront in EvmArgs::prof (the first 4096 wavefronts of the grid)
+#define EV_PROF_WAVE ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)
+#define EV_PROF_ON(a) ((a).prof && (threadIdx.x & 63) == 0 && EV_PROF_WAVE < 4096u)
+#define EVM_STAGE_STRIDE EVM_STAGE_LANES  // u32 words between a lane's consecutive entries
+#define EVM_STAGE_ENTRIES 40
+#define EVM_STAGE_GAS 10  // entry pair of gas_left within a step's 12
+ZK_HD constexpr int evm_stage_entry(int s, int c) {
+    return c == S_CH_LO || c == S_CH_HI ? 24 + s * 8 + (c - S_CH_LO) * 4
+           : s * 12 + (c < S_CH_LO ? c : c == S_PC ? 5 : c == S_SP ? 6 : c == S_MWS ? 7 : c == S_REV ? 8 : c == S_LOG ? 9 : EVM_STAGE_GAS);
+}
 #define EVM_DIR_MAX_SLOTS 128   // directory mirrored in LDS when it has at most this many slots ...
 #define EVM_DIR_MAX_ENTRIES 32  // ... and entries (96 B each)
 #define EVM_DIR_SLOT_U64 (EVM_DIR_MAX_SLOTS / 2)
 #define EVM_DIR_LDS_U64 (EVM_DIR_SLOT_U64 + EVM_DIR_MAX_ENTRIES * 12)
 #if defined(ZK_HOSTSIM)
 typedef const u64* EVM_LDS_PTR;
+typedef const u32* EVM_LDS32_PTR;
 #else
 typedef const __attribute__((address_space(3))) u64* EVM_LDS_PTR;
+typedef const __attribute__((address_space(3))) u32* EVM_LDS32_PTR;
 #endif
 
 struct Word {
@@ -98,18 +120,22 @@ struct Ins {
     // 2 = hash absent from the table, 3 = use the generic index
     u32 code_state, code_header_row, code_byte_base, code_n_bytes, code_header_ok;
     u64 code_header_value;
-    // the 26 cells of (curr, next) staged in LDS by the hot kernel (evm_stage_steps): lane's slot k at stage[k * EVM_STAGE_LANES];
+    // the 26 cells of (curr, next) staged in LDS by the hot kernel (evm_stage_steps): lane's entry e at stage[e * EVM_STAGE_STRIDE];
     // nullptr = read the step rows from HBM (cold kernel, hostsim, or a lane whose cells exceed the staged widths)
-    EVM_LDS_PTR stage;
+    EVM_LDS32_PTR stage;
     // the hot kernel's LDS mirror of the bytecode directory (slots as u32 pairs in the first EVM_DIR_SLOT_U64 words, then
     // the entries, 12 u64 each); nullptr = probe the directory in HBM
     EVM_LDS_PTR dir_lds;
+    // requested ahead of the gadget (evm_prefetch): the packed bytecode record at curr.program_counter.  opcode_lookup takes
+    // it instead of issuing its own dependent load; the checks are unchanged.
+    u32 pre_op;
+    bool pre_op_ok;
 };
 
 #if defined(ZK_HOSTSIM)
 #define EV_PROF(I, k) do { } while (0)
 #else
-#define EV_PROF(I, k) do { if ((I).a->prof && (threadIdx.x & 63) == 0 && blockIdx.x < 512) (I).a->prof[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define EV_PROF(I, k) do { if (EV_PROF_ON(*(I).a)) (I).a->prof[EV_PROF_WAVE * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #endif
 
 // ---- checkpoints --------------------------------------------------------------------------
@@ -124,20 +150,16 @@ ZK_HD void ev_require(Ins& I, bool cond, u32 kind = ZK_ASSERT) {
 #define EV_TRYV(stmt, ret) do { stmt; if (I.err) return ret; } while (0)
 
 ZK_HD Fr ev_step_cell(const EvmArgs& a, u64 step, int c) { return fr_load(a.steps + (step * STEP_NCELLS + c) * 4); }
-ZK_HD Fr ev_staged_cell(const Ins& I, int slot, int c) {
+ZK_HD Fr ev_staged_cell(const Ins& I, int s, int c) {
     Fr r = fr_zero();
-    const u64 lo = I.stage[slot * EVM_STAGE_LANES];
-    r.v[0] = (u32)lo;
-    r.v[1] = (u32)(lo >> 32);
-    if (c == S_CH_LO || c == S_CH_HI) {
-        const u64 hi = I.stage[(26 + (slot >= 13 ? 2 : 0) + (c - S_CH_LO)) * EVM_STAGE_LANES];
-        r.v[2] = (u32)hi;
-        r.v[3] = (u32)(hi >> 32);
-    }
+    const int e = evm_stage_entry(s, c);
+    const int n = (c == S_CH_LO || c == S_CH_HI) ? 4 : c == S_GAS ? 2 : 1;
+#pragma unroll
+    for (int w = 0; w < n; w++) r.v[w] = I.stage[(e + w) * EVM_STAGE_STRIDE];
     return r;
 }
-ZK_HD Fr ev_curr(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, c, c) : ev_step_cell(*I.a, I.idx, c); }
-ZK_HD Fr ev_next(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 13 + c, c) : ev_step_cell(*I.a, I.idx + 1, c); }
+ZK_HD Fr ev_curr(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 0, c) : ev_step_cell(*I.a, I.idx, c); }
+ZK_HD Fr ev_next(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 1, c) : ev_step_cell(*I.a, I.idx + 1, c); }
 ZK_HD Fr fr_u(u64 x) { return fr_from_u64(x); }
 ZK_HD Word word_of(const Fr& lo, const Fr& hi) {
     Word w;
@@ -353,8 +375,28 @@ ZK_HD RwKey rw_pack_row(const ZkTable& t, u32 r) {
     k.w[0] |= (u64)((t.flags ? t.flags[r] : 3u) & 3u) << 56;
     return k;
 }
-// Instruction.rw_lookup (instruction.py:792-824); rw_counter = curr.rw_counter + offset unless given
-ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
+// row of the dense RW table a lookup at `rwc` addresses (row 0 when out of range: tables keep one zero row when empty)
+ZK_HD u32 rw_dense_row(const EvmArgs& a, const Fr& rwc, bool& ok) {
+    const u64 off = fr_lo64(rwc) - a.rw_base;
+    ok = fr_fits64(rwc) && fr_lo64(rwc) >= a.rw_base && off < (u64)a.rw.n;
+    return ok ? (u32)off : 0u;
+}
+// An RW row requested ahead of its lookup (rw_rows_fetch): the packed key record and the two value cells a stack lookup
+// returns.  The lookups of a gadget's opening run sit at consecutive rw_counters, so their rows are known before the first
+// one is checked; fetched one lookup at a time each costs a dependent HBM round trip (~2.5 us under load, and a SIMD holds
+// only two wavefronts to hide it).
+struct RwRow {
+    uint4 k01, k23;
+    Fr v_lo, v_hi;
+};
+template <int N>
+struct RwRows {
+    bool valid;  // dense RW table with packed key records; otherwise the lookups fetch for themselves
+    RwRow row[N];
+};
+// Instruction.rw_lookup (instruction.py:792-824); rw_counter = curr.rw_counter + offset unless given.  `pre` = the row's
+// key record, fetched ahead (it must be the row this lookup addresses: rw_rows_fetch at the same running offset).
+ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr, const RwRow* pre = nullptr) {
     if (rw_counter) {
         Q.q[R_RWC] = *rw_counter;
     } else {
@@ -362,19 +404,23 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
         I.rw_off++;
     }
     if (I.a->rw_dense) {
-        const u64 rw_base = I.a->rw_base;
         // direct index: the only row with this rw_counter is row (rw_counter - base)
         I.seq++;
-        const Fr& rwc = Q.q[R_RWC];
-        const u64 off = fr_lo64(rwc) - rw_base;
-        bool ok = fr_fits64(rwc) && fr_lo64(rwc) >= rw_base && off < (u64)I.a->rw.n;
-        const u32 r = ok ? (u32)off : 0u;  // row 0 always exists (tables keep one zero row when empty)
+        bool ok;
+        const u32 r = rw_dense_row(*I.a, Q.q[R_RWC], ok);
         // branch-free compare: the row loads do not depend on earlier lookups' outcomes, so the
         // loads of consecutive lookups (MLOAD: 32 rows, PUSH32: 33 rows) overlap in flight
         bool key_cells = true;  // compare cells 1..5 one by one (no packed record, or the row does not fit it)
         if (I.a->rw_keys) {
-            const uint4* kp = reinterpret_cast<const uint4*>(I.a->rw_keys + (u64)r * 4);
-            const uint4 k01 = kp[0], k23 = kp[1];
+            uint4 k01, k23;
+            if (pre) {
+                k01 = pre->k01;
+                k23 = pre->k23;
+            } else {
+                const uint4* kp = reinterpret_cast<const uint4*>(I.a->rw_keys + (u64)r * 4);
+                k01 = kp[0];
+                k23 = kp[1];
+            }
             const u64 w0 = (u64)k01.x | ((u64)k01.y << 32), w1 = (u64)k01.z | ((u64)k01.w << 32);
             const u64 w2 = (u64)k23.x | ((u64)k23.y << 32), w3 = (u64)k23.z | ((u64)k23.w << 32);
             if (w0 >> 63) {  // the row's key cells fit the packed widths: a queried cell matches iff it fits and is equal
@@ -403,6 +449,23 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr) {
         return r;
     }
     return table_lookup<RW_NCELLS>(I, I.a->rw, rw_key_hash_cell(Q.q[R_RWC]), Q.q, Q.mask);
+}
+// Request the rows of the next N lookups at the running counter (no checkpoint, no state change).
+template <int N>
+ZK_HD void rw_rows_fetch(const Ins& I, RwRows<N>& R) {
+    const EvmArgs& a = *I.a;
+    R.valid = a.rw_dense && a.rw_keys != nullptr;
+    if (!R.valid) return;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        bool ok;
+        const u32 r = rw_dense_row(a, fr_add_u64(I.rwc, I.rw_off + (u64)k), ok);
+        const uint4* kp = reinterpret_cast<const uint4*>(a.rw_keys + (u64)r * 4);
+        R.row[k].k01 = kp[0];
+        R.row[k].k23 = kp[1];
+        R.row[k].v_lo = zk_table_cell(a.rw, r, R_VAL_LO);
+        R.row[k].v_hi = zk_table_cell(a.rw, r, R_VAL_LO + 1);
+    }
 }
 ZK_HD Fr rw_cell(const Ins& I, u32 row, int c) { return zk_table_cell(I.a->rw, row, c); }
 ZK_HD Word rw_word(const Ins& I, u32 row, int c) { return word_of(rw_cell(I, row, c), rw_cell(I, row, c + 1)); }
@@ -531,6 +594,12 @@ ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instructi
     return bytecode_value(I, 2, index, is_code ? 1 : 0);
 }
 ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
+    if (I.pc_off == 0u && I.pre_op_ok && (I.pre_op >> 15)) {  // the record at curr.program_counter, requested ahead: bytecode_value's packed form
+        I.pc_off++;
+        I.seq++;
+        if (((I.pre_op >> 8) & 1u) != (is_code ? 1u : 0u)) ev_fail(I, ZK_LOOKUP_UNSAT);
+        return fr_u(I.pre_op & 0xffu);
+    }
     Fr index = fr_add_u64(I.pc, I.pc_off);
     I.pc_off++;
     return opcode_lookup_at(I, index, is_code);
@@ -704,6 +773,29 @@ ZK_HD Word stack_pop(Ins& I) {
 ZK_HD Word stack_push(Ins& I) {
     I.sp_off--;
     return stack_lookup(I, 1, I.sp_off);
+}
+// The same lookups on a row requested ahead (rw_rows_fetch at the offset this lookup runs at)
+ZK_HD Word stack_lookup_row(Ins& I, u32 rw, int off, const RwRow& row) {
+    RwQ Q;
+    rwq_init(Q, rw, TG_Stack);
+    rwq_set(Q, R_ID, I.call_id);
+    const Fr& sp = I.sp;
+    rwq_set(Q, R_ADDR, off >= 0 ? fr_add_u64(sp, (u64)off) : fr_sub_u64(sp, (u64)(-off)));
+    rw_lookup(I, Q, nullptr, &row);
+    return word_of(row.v_lo, row.v_hi);
+}
+template <int N>
+ZK_HD Word stack_pop(Ins& I, const RwRows<N>& R, int k) {
+    if (!R.valid) return stack_pop(I);
+    int off = I.sp_off;
+    I.sp_off++;
+    return stack_lookup_row(I, 0, off, R.row[k]);
+}
+template <int N>
+ZK_HD Word stack_push(Ins& I, const RwRows<N>& R, int k) {
+    if (!R.valid) return stack_push(I);
+    I.sp_off--;
+    return stack_lookup_row(I, 1, I.sp_off, R.row[k]);
 }
 ZK_HD Fr memory_lookup(Ins& I, u32 rw, const Fr& addr, const Fr* call_id = nullptr) {
     RwQ Q;
@@ -989,28 +1081,33 @@ ZK_HD void same_context_staged(Ins& I, const Tail& T, u64 dyn_gas) {
     const Fr& opcode = T.opcode;
     const bool op_byte = fr_le_u64(opcode, 255);
     const u32 info = opinfo[opcode.v[0] & 0xff];
-#define STG(slot) (I.stage[(slot) * EVM_STAGE_LANES])
-    const u64 st = STG(S_STATE);
+#define STG(s, c) ((u64)I.stage[evm_stage_entry(s, c) * EVM_STAGE_STRIDE])
+#define STG_GAS(s) (STG(s, S_GAS) | ((u64)I.stage[(evm_stage_entry(s, S_GAS) + 1) * EVM_STAGE_STRIDE] << 32))
+    const u64 st = STG(0, S_STATE);
     I.seq++;
     if (!(op_byte && st != 0u && (u64)(info & 0xffu) == st)) ev_fail(I, ZK_LOOKUP_UNSAT);
     const bool op_ok = op_byte && ((info >> 8) & 1u);
     ev_require(I, op_ok, ZK_VALUE_ERROR);
     const u64 gas_cost = (u64)(op_ok ? (info >> 16) : 0u) + dyn_gas;  // caller: no 64-bit overflow
-    const u64 c_gas = STG(S_GAS);
+    const u64 c_gas = STG_GAS(0);
     ev_require(I, c_gas >= gas_cost, ZK_CONSTRAINT);  // range_check(gas_left - gas_cost, 8)
-    if (T.rwc_mode == 0u) ev_require(I, stage_delta_ok(STG(S_RWC), STG(13 + S_RWC), T.rw_delta));
+    if (T.rwc_mode == 0u) ev_require(I, stage_delta_ok(STG(0, S_RWC), STG(1, S_RWC), T.rw_delta));
     else ev_require(I, T.rwc_mode == 1u);
-    ev_require(I, stage_trans_ok(STG(S_PC), STG(13 + S_PC), T.pc_kind, T.pc_val));
-    ev_require(I, stage_delta_ok(STG(S_SP), STG(13 + S_SP), T.sp_delta));
-    ev_require(I, c_gas >= gas_cost && c_gas - gas_cost == STG(13 + S_GAS));
-    ev_require(I, stage_trans_ok(STG(S_MWS), STG(13 + S_MWS), T.mws_kind, T.mws_val));
-    ev_require(I, stage_delta_ok(STG(S_REV), STG(13 + S_REV), T.rev_delta));
-    if (T.log_mode == 0u) ev_require(I, STG(S_LOG) == STG(13 + S_LOG));
+    ev_require(I, stage_trans_ok(STG(0, S_PC), STG(1, S_PC), T.pc_kind, T.pc_val));
+    ev_require(I, stage_delta_ok(STG(0, S_SP), STG(1, S_SP), T.sp_delta));
+    ev_require(I, c_gas >= gas_cost && c_gas - gas_cost == STG_GAS(1));
+    ev_require(I, stage_trans_ok(STG(0, S_MWS), STG(1, S_MWS), T.mws_kind, T.mws_val));
+    ev_require(I, stage_delta_ok(STG(0, S_REV), STG(1, S_REV), T.rev_delta));
+    if (T.log_mode == 0u) ev_require(I, STG(0, S_LOG) == STG(1, S_LOG));
     else ev_require(I, T.log_mode == 1u);
-    ev_require(I, STG(S_CALL_ID) == STG(13 + S_CALL_ID));
-    ev_require(I, STG(S_IS_ROOT) == STG(13 + S_IS_ROOT));
-    ev_require(I, STG(S_IS_CREATE) == STG(13 + S_IS_CREATE));
-    ev_require(I, STG(S_CH_LO) == STG(13 + S_CH_LO) && STG(S_CH_HI) == STG(13 + S_CH_HI) && STG(26) == STG(28) && STG(27) == STG(29));
+    ev_require(I, STG(0, S_CALL_ID) == STG(1, S_CALL_ID));
+    ev_require(I, STG(0, S_IS_ROOT) == STG(1, S_IS_ROOT));
+    ev_require(I, STG(0, S_IS_CREATE) == STG(1, S_IS_CREATE));
+    bool same_hash = true;
+#pragma unroll
+    for (int w = 0; w < 8; w++) same_hash = same_hash & (I.stage[(24 + w) * EVM_STAGE_STRIDE] == I.stage[(32 + w) * EVM_STAGE_STRIDE]);
+    ev_require(I, same_hash);
+#undef STG_GAS
 #undef STG
 }
 #endif
@@ -1084,12 +1181,13 @@ ZK_HD void memory_expansion(Ins& I, const Fr& offset, const Fr& length, Fr& next
 
 // ---- gadgets (evm_circuit/execution/*.py) --------------------------------------------------------
 ZK_HD void g_add_sub(Ins& I, Tail& T) {  // add_sub.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_sub = fr_eq_u64(opcode, OP_SUB);
     Word a, b, c;
-    a = stack_pop(I);
-    b = stack_pop(I);
-    c = stack_push(I);
+    a = stack_pop(I, R, 0);
+    b = stack_pop(I, R, 1);
+    c = stack_push(I, R, 2);
     Word x = ev_select_b(I, is_sub) ? c : a;
     Fr carry;
     Word res = add_words2(I, x, b, carry);
@@ -1104,6 +1202,7 @@ ZK_HD Fr fr_sel01(const Fr& x, const Fr& s, bool is01) {
     return fr_mul(x, s);
 }
 ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     // is_mul/is_div/is_mod are field expressions of the opcode (:14-16)
     // for the three opcodes the gadget is responsible for they are exactly 0 / 1, and every product with them below is a select
@@ -1121,9 +1220,9 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
         is_mod = fr_mulc(fr_mul(op_m2, op_m4), frm_inv8());
     }
     Word pop1, pop2, push;
-    pop1 = stack_pop(I);
-    pop2 = stack_pop(I);
-    push = stack_push(I);
+    pop1 = stack_pop(I, R, 0);
+    pop2 = stack_pop(I, R, 1);
+    push = stack_push(I, R, 2);
     Word a, b, c, d;
     if (fr_eq_u64(is_mul, 1)) {
         a = pop1; b = pop2; c = word_from_int(I, fr_zero()); d = push;
@@ -1176,10 +1275,11 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
 }
 
 ZK_HD void g_cmp(Ins& I, Tail& T) {  // comparator.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_eq = fr_eq_u64(opcode, OP_EQ), is_gt = fr_eq_u64(opcode, OP_GT);
     Word a, b, c;
-    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); c = stack_push(I, R, 2);
     Word aa = is_gt ? b : a, bb = is_gt ? a : b;
     u32 lt_lo, eq_lo, lt_hi, eq_hi;
     ev_compare(I, aa.lo, bb.lo, 16, lt_lo, eq_lo);
@@ -1202,10 +1302,11 @@ ZK_HD u32 lt_u256_sel(Ins& I, const Word& a, const Word& b) {
 }
 
 ZK_HD void g_scmp(Ins& I, Tail& T) {  // slt_sgt.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     const bool is_sgt = fr_eq_u64(opcode, OP_SGT);
     Word a, b, c;
-    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); c = stack_push(I, R, 2);
     Word aa = is_sgt ? b : a, bb = is_sgt ? a : b;
     U256 a8, b8, c8;
     EV_TRY(a8 = to_u256(I, aa)); EV_TRY(b8 = to_u256(I, bb)); EV_TRY(c8 = to_u256(I, c));
@@ -1220,10 +1321,11 @@ ZK_HD void g_scmp(Ins& I, Tail& T) {  // slt_sgt.py
 }
 
 ZK_HD void g_iszero(Ins& I, Tail& T) {  // iszero.py
+    RwRows<2> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
-    Word value; value = stack_pop(I);
+    Word value; value = stack_pop(I, R, 0);
     Word z = word_checked(I, fr_u(is_zero_word(value)), fr_zero());
-    Word push; push = stack_push(I);
+    Word push; push = stack_push(I, R, 1);
     constrain_equal_word(I, z, push);
     set_tail3(T, opcode, 2, 1, 0);
 }
@@ -1238,10 +1340,11 @@ ZK_HD void bitwise_lookups32(Ins& I, const U256& diff) {
     I.seq += 32;
 }
 ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
+    RwRows<2> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
-    Word a; a = stack_pop(I);
+    Word a; a = stack_pop(I, R, 0);
     U256 a8; EV_TRY(a8 = to_u256(I, a));
-    Word b; b = stack_push(I);
+    Word b; b = stack_push(I, R, 1);
     U256 b8; EV_TRY(b8 = to_u256(I, b));
     {   // (a_byte, b_byte, 255) in BitwiseXor for every byte  <=>  a ^ b == 0xff..ff
         U256 d;
@@ -1253,9 +1356,10 @@ ZK_HD void g_not(Ins& I, Tail& T) {  // not_.py
 }
 
 ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     Word a, b, c;
-    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); c = stack_push(I, R, 2);
     U256 a8, b8, c8;
     EV_TRY(a8 = to_u256(I, a)); EV_TRY(b8 = to_u256(I, b)); EV_TRY(c8 = to_u256(I, c));
     // tag = BitwiseAnd + (opcode.n - AND) as a Python int, then FixedTableTag(tag)
@@ -1284,9 +1388,10 @@ ZK_HD void g_bitwise(Ins& I, Tail& T) {  // bitwise.py
 }
 
 ZK_HD void g_byte(Ins& I, Tail& T) {  // byte.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     Word a, b, c;
-    a = stack_pop(I); b = stack_pop(I); c = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); c = stack_push(I, R, 2);
     U256 index, value;
     EV_TRY(index = to_u256(I, a)); EV_TRY(value = to_u256(I, b));
     bool msb_zero = true;
@@ -1300,9 +1405,10 @@ ZK_HD void g_byte(Ins& I, Tail& T) {  // byte.py
 }
 
 ZK_HD void g_signextend(Ins& I, Tail& T) {  // signextend.py (is_equal results are discarded there)
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     Word index, value, result;
-    index = stack_pop(I); value = stack_pop(I); result = stack_push(I);
+    index = stack_pop(I, R, 0); value = stack_pop(I, R, 1); result = stack_push(I, R, 2);
     U256 ib, vb, rb;
     EV_TRY(ib = to_u256(I, index)); EV_TRY(vb = to_u256(I, value)); EV_TRY(rb = to_u256(I, result));
     bool msb_zero = true;
@@ -1345,7 +1451,31 @@ ZK_HD U256 u256_shr_bytes(const U256& v, u32 n) {
     if (n >= 32u) r = fr_zero();
     return r;
 }
+ZK_HD u32 zk_brev32(u32 x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+    return (x >> 16) | (x << 16);
+}
 ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
+    // The pushed bytes of a regular code are the 2-byte packed records right after the program counter: request all 32 before
+    // anything else is waited for (independent loads, in flight together with the opcode record and the stack row) instead
+    // of one dependent lookup per byte.  A record beyond the code's end reads as 0 = "does not fit the packed form".
+    RwRows<1> R; rw_rows_fetch(I, R);
+    u32 raw[32];
+    bool run_ok = false;
+    {
+        code_dir_resolve(I, curr_code_hash(I));
+        const uint16_t* packed = I.a->codes.packed;
+        if (I.code_state == 1u && packed != nullptr && fr_fits64(I.pc) && fr_lo64(I.pc) < (1ull << 62)) {
+            run_ok = true;
+            const u64 first = fr_lo64(I.pc) + 1, nb = (u64)I.code_n_bytes;
+            const uint16_t* src = packed + (u64)I.code_byte_base + first;
+#pragma unroll
+            for (int i = 0; i < 32; i++) raw[i] = first + (u64)i < nb ? (u32)src[i] : 0u;
+        }
+    }
     Fr opcode; opcode = opcode_lookup(I, true);
     Fr num_pushed = fr_sub_u64(opcode, OP_PUSH0);
     Fr code_length; code_length = bytecode_length(I, curr_code_hash(I));
@@ -1353,7 +1483,7 @@ ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
     Fr left = fr_sub_u64(fr_sub(code_length, pc), 1);
     u32 oob, eq; ev_compare(I, left, num_pushed, 8, oob, eq); if (I.err) return;
     Fr num_padding = oob ? fr_sub(num_pushed, left) : fr_zero();
-    Word value; value = stack_push(I);
+    Word value; value = stack_push(I, R, 0);
     U256 vb; EV_TRY(vb = to_u256(I, value));
     if (fr_fits64(num_pushed) && fr_fits64(num_padding) && fr_fits64(pc) && fr_lo64(num_pushed) <= 32 && fr_lo64(pc) < (1ull << 62)) {
         // the usual case: byte counts and the program counter are small integers.  In byte order the loop of push.py:27-36 is
@@ -1363,13 +1493,45 @@ ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
         const u32 pad = fr_lo64(num_padding) < (u64)np ? (u32)fr_lo64(num_padding) : np;
         const u64 base = fr_lo64(pc) + np;
         push_zero_run(I, vb, 0, pad);
-        U256 cur = u256_shr_bytes(vb, pad);
-        for (u32 k = pad; k < np; k++) {
-            Fr byte = opcode_lookup_at(I, fr_u(base - (u64)k), false);
-            constrain_equal(I, fr_u(cur.v[0] & 0xffu), byte);
+        // value byte k in [pad, np) is looked up at index pc + np - k, i.e. record i = np - 1 - k of the run fetched above
+        const u32 cnt = np - pad;
+        const u32 need = cnt >= 32u ? 0xffffffffu : ((1u << cnt) - 1u);
+        u32 fits_i = 0, code_i = 0;
+        if (run_ok) {
 #pragma unroll
-            for (int j = 0; j < 7; j++) cur.v[j] = (cur.v[j] >> 8) | (cur.v[j + 1] << 24);
-            cur.v[7] >>= 8;
+            for (int i = 0; i < 32; i++) {
+                fits_i |= ((raw[i] >> 15) & 1u) << i;
+                code_i |= ((raw[i] >> 8) & 1u) << i;
+            }
+        }
+        if (run_ok && cnt != 0u && (fits_i & need) == need) {
+            // every record fits: run the cnt (lookup, constrain_equal) checkpoint pairs on bit masks.  The lookup of byte k
+            // fails when the record is an opcode byte (is_code = 0 is queried: LookupUnsatFailure), constrain_equal when
+            // the values differ; the first failing checkpoint in loop order is reported, as the byte-by-byte loop does.
+            U256 rev = fr_zero();  // byte 31 - i = record i's value
+#pragma unroll
+            for (int i = 0; i < 32; i++) rev.v[(31 - i) >> 2] |= (raw[i] & 0xffu) << (8 * ((31 - i) & 3));
+            const U256 want = u256_shr_bytes(rev, 32u - np);  // byte k = record np - 1 - k
+            const u32 code_k = zk_brev32(code_i) >> (32u - np);
+            u32 neq_k = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) neq_k |= (fr_byte(vb, k) != fr_byte(want, k) ? 1u : 0u) << k;
+            const u32 range = (np >= 32u ? 0xffffffffu : ((1u << np) - 1u)) & ~((1u << pad) - 1u);
+            const u32 bad = (code_k | neq_k) & range;
+            if (bad != 0u && I.err == 0u) {
+                const u32 k = (u32)__builtin_ctz(bad);
+                I.err = ((code_k >> k) & 1u) ? ZK_CODE(ZK_LOOKUP_UNSAT, I.seq + 2u * (k - pad) + 1u) : ZK_CODE(ZK_ASSERT, I.seq + 2u * (k - pad) + 2u);
+            }
+            I.seq += 2u * cnt;
+        } else {
+            U256 cur = u256_shr_bytes(vb, pad);
+            for (u32 k = pad; k < np; k++) {
+                Fr byte = opcode_lookup_at(I, fr_u(base - (u64)k), false);
+                constrain_equal(I, fr_u(cur.v[0] & 0xffu), byte);
+#pragma unroll
+                for (int j = 0; j < 7; j++) cur.v[j] = (cur.v[j] >> 8) | (cur.v[j + 1] << 24);
+                cur.v[7] >>= 8;
+            }
         }
         push_zero_run(I, vb, np, 32);
     } else {
@@ -1388,15 +1550,17 @@ ZK_HD void g_push(Ins& I, Tail& T) {  // push.py
 }
 
 ZK_HD void g_pop(Ins& I, Tail& T) {  // pop.py
+    RwRows<1> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
-    stack_pop(I);
+    stack_pop(I, R, 0);
     set_tail3(T, opcode, 1, 1, 1);
 }
 
 ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     Word pop1, pop2, push;
-    pop1 = stack_pop(I); pop2 = stack_pop(I); push = stack_push(I);
+    pop1 = stack_pop(I, R, 0); pop2 = stack_pop(I, R, 1); push = stack_push(I, R, 2);
     // gen_witness (:103-127)
     Fr is_shl = fr_sub(fr_u(OP_SHR), opcode);
     const bool op_known = fr_eq_u64(opcode, OP_SHL) || fr_eq_u64(opcode, OP_SHR);  // is_shl, is_shr are 0 / 1: products below are selects
@@ -1462,9 +1626,10 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
 // check_witness (:53-151) except `b64s[idx] == bytes_to_fq(b_le_bytes[..])` is an identity of
 // gen_witness's own outputs (:154-199): those only advance the checkpoint counter.
 ZK_HD void g_sar(Ins& I, Tail& T) {
+    RwRows<3> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     Word shift, a, b;
-    shift = stack_pop(I); a = stack_pop(I); b = stack_push(I);
+    shift = stack_pop(I, R, 0); a = stack_pop(I, R, 1); b = stack_push(I, R, 2);
     U256 av; EV_TRY(av = int_value(I, a));
     U256 sb; EV_TRY(sb = to_u256(I, shift));
     I.seq++;  // a.to_64s(): the cells fit (int_value passed)
@@ -1574,10 +1739,11 @@ ZK_HD void g_sdiv_smod(Ins& I, Tail& T) {  // sdiv_smod.py
 ZK_HD void divmod_512(const U512& num, const U256& den, U512& q, U256& r) { u512_divmod(num, den, q, r, 512); }
 
 ZK_HD void g_addmod(Ins& I, Tail& T) {  // addmod.py
+    RwRows<4> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_ADDMOD));
     Word a, b, n, pushed_r;
-    a = stack_pop(I); b = stack_pop(I); n = stack_pop(I); pushed_r = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); n = stack_pop(I, R, 2); pushed_r = stack_push(I, R, 3);
     U256 av, bv, nv;
     EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n));
     const bool n_zero = fr_is_zero(nv);
@@ -1645,10 +1811,11 @@ ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r, const
 }
 
 ZK_HD void g_mulmod(Ins& I, Tail& T) {  // mulmod.py
+    RwRows<4> R; rw_rows_fetch(I, R);  // the stack rows, in flight together with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_MULMOD));
     Word a, b, n, r;
-    a = stack_pop(I); b = stack_pop(I); n = stack_pop(I); r = stack_push(I);
+    a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); n = stack_pop(I, R, 2); r = stack_push(I, R, 3);
     U256 av, bv, nv, rv;
     EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
     U256 a_red = fr_zero(), k = fr_zero(), q0 = fr_zero();
@@ -3902,13 +4069,31 @@ ZK_HD u32 evm_state_bin(u32 state) {
     return key;
 }
 #define EVM_N_BINS (EVM_N_GROUPS * 128)
+#define EVM_NO_PAIR 0xffffffffu                   // a pad lane of the sorted mapping (hot bins are padded to whole wavefronts)
+#define EVM_PERM_PAD (64u * EVM_GROUP_COLD * 128u)  // upper bound of the padding
+
+// Request the packed bytecode record at curr.program_counter (every hot gadget's opcode_lookup) before the common checks
+// and the gadget prologue run, so that its HBM round trip overlaps them.  (Requesting the leading RW rows the same way was
+// tried in round 2: three rows are 72 registers held across the gadget switch, and the merged kernel has none to spare.)
+ZK_HD void evm_prefetch(Ins& I) {
+    const EvmArgs& a = *I.a;
+    code_dir_resolve(I, curr_code_hash(I));
+    const uint16_t* packed = a.codes.packed;
+    if (I.code_state == 1u && packed != nullptr && fr_fits64(I.pc) && fr_lo64(I.pc) < (u64)I.code_n_bytes) {
+        I.pre_op = packed[I.code_byte_base + (u32)fr_lo64(I.pc)];
+        I.pre_op_ok = true;
+    }
+}
 
 // verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
 #if !defined(ZK_HOSTSIM)
 // Load the 26 cells of the pair (52 independent 16-byte loads, issued before any gadget code needs registers) and keep
-// them in LDS: low 64 bits per cell, 128 for the code-hash cells.  Returns false when a cell is wider than that
-// (malformed witnesses only): the lane then reads the step rows from HBM as before.
-ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_space(3))) u64* stage) {
+// their low words in LDS (layout: EVM_STAGE_ENTRIES).  Returns false when a cell is wider than its entry (malformed
+// witnesses only): the lane then reads the step rows from HBM as before.
+// (Round 2 also tried fetching the wavefront's 64 pairs in address order — lane l taking chunk (64 i + l) % 52 of pair
+// (64 i + l) / 52, nine cache lines per instruction instead of 64 — with the transposition done by the LDS writes: the
+// loads themselves completed in ~5k cycles, but the fully unrolled address / scatter code around them cost 140k.)
+ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_space(3))) u32* stage) {
     const uint4* p = (const uint4*)(a.steps + idx * (STEP_NCELLS * 4));
     uint4 lo[2 * STEP_NCELLS], hi[2 * STEP_NCELLS];
 #pragma unroll
@@ -3919,12 +4104,17 @@ ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_spa
     u32 wide = 0;
 #pragma unroll
     for (int k = 0; k < 2 * STEP_NCELLS; k++) {
-        const int c = k % STEP_NCELLS;
-        stage[k * EVM_STAGE_LANES] = (u64)lo[k].x | ((u64)lo[k].y << 32);
+        const int c = k % STEP_NCELLS, e = evm_stage_entry(k / STEP_NCELLS, c);
+        stage[e * EVM_STAGE_STRIDE] = lo[k].x;
         if (c == S_CH_LO || c == S_CH_HI) {
-            stage[(26 + (k >= STEP_NCELLS ? 2 : 0) + (c - S_CH_LO)) * EVM_STAGE_LANES] = (u64)lo[k].z | ((u64)lo[k].w << 32);
-        } else {
+            stage[(e + 1) * EVM_STAGE_STRIDE] = lo[k].y;
+            stage[(e + 2) * EVM_STAGE_STRIDE] = lo[k].z;
+            stage[(e + 3) * EVM_STAGE_STRIDE] = lo[k].w;
+        } else if (c == S_GAS) {
+            stage[(e + 1) * EVM_STAGE_STRIDE] = lo[k].y;
             wide |= lo[k].z | lo[k].w;
+        } else {
+            wide |= lo[k].y | lo[k].z | lo[k].w;
         }
         wide |= hi[k].x | hi[k].y | hi[k].z | hi[k].w;
     }
@@ -3933,7 +4123,7 @@ ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_spa
 #endif
 
 template <int G>
-ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr, EVM_LDS_PTR dir_lds = nullptr) {
+ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullptr, EVM_LDS_PTR dir_lds = nullptr) {
     Ins I;
     I.a = &a;
     I.stage = stage;
@@ -3945,6 +4135,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr,
     I.pc_off = 0;
     I.sp_off = 0;
     I.code_state = 0;
+    I.pre_op = 0;
+    I.pre_op_ok = false;
     EV_PROF(I, 0);
     I.rwc = ev_curr(I, S_RWC);
     I.call_id = ev_curr(I, S_CALL_ID);
@@ -3956,6 +4148,9 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr,
     const u32 state = statef.v[0];
     const u32 next_state = ev_next(I, S_STATE).v[0];  // loaded with the first batch (used unless is_last)
     if ((G == EVM_GROUP_COLD) != (evm_state_group(state) == EVM_GROUP_COLD)) return ZK_NOT_MINE;
+#if !defined(ZK_HOSTSIM)
+    if (EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 4] = state;
+#endif
     if (is_first) {
         ev_require(I, state == ES_BeginTx || state == ES_EndBlock);
         constrain_equal(I, ev_curr(I, S_RWC), fr_u(1));
@@ -3968,6 +4163,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS_PTR stage = nullptr,
         ev_fail(I, ZK_NOT_IMPLEMENTED);
         return I.err;
     }
+    if (G != EVM_GROUP_COLD) evm_prefetch(I);
     EV_PROF(I, 1);
     Tail T;
     T.enabled = false;

@@ -157,15 +157,19 @@ __global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, 
 // LDS — instead of waiting for a separate one-block scan launch; block 0 publishes the group boundaries and clears the
 // OTHER histogram buffer for the next pass (the two alternate).  Ranks inside a block come from LDS atomics, one global
 // atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
+// Every hot bin's lane range is padded to a multiple of 64 (pad lanes = EVM_NO_PAIR): a wavefront never holds two execution
+// states.  A mixed wavefront runs both gadget bodies one after the other, and with the longest states sorted first those
+// boundary wavefronts (STOP + ADDMOD, MEMORY + SSTORE: 190k cycles against a 118k median) were the last to leave the kernel.
 __global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
                                                                  u32* taken, u32* group_start, u32* perm) {
     __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
     __shared__ u32 local[EVM_N_BINS];
     __shared__ u32 base[EVM_N_BINS];
     const u32 k = threadIdx.x;
-    u32 c = 0;
+    u32 c = 0, c_real = 0;
     if (k < EVM_N_BINS) {
-        c = hist[k];
+        c_real = hist[k];
+        c = k < (u32)EVM_GROUP_COLD * 128u ? ((c_real + 63u) & ~63u) : c_real;
         sa[k] = c;
         local[k] = 0;
         if (blockIdx.x == 0) hist_next[k] = 0;
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t*
         if (blockIdx.x == 0) {
             if ((k & 127u) == 0) group_start[k >> 7] = excl;
             if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
+            for (u32 j = c_real; j < c; j++) perm[excl + j] = EVM_NO_PAIR;
         }
     }
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,11 +548,11 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess ||
         hipMemsetAsync(s->d_hist2, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess) { rc = -2; goto fail; }
     if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_perm, (size_t)s->evm.n_pairs * sizeof(u32)))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)s->evm.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
     s->evm.prof = nullptr;
     if (getenv("ZK_EVM_PROF")) {
-        if ((rc = dev_alloc(s, (void**)&s->evm.prof, 512 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
-        if (hipMemset(s->evm.prof, 0, 512 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) { rc = -2; goto fail; }
+        if ((rc = dev_alloc(s, (void**)&s->evm.prof, 1024 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
+        if (hipMemset(s->evm.prof, 0, 1024 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) { rc = -2; goto fail; }
     }
     s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
     if ((rc = session_common_init(s))) goto fail;
@@ -1339,7 +1344,7 @@ extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_h
 extern "C" int zk_debug_read_prof(zk_session* s, unsigned long long* out) {
     if (!s || !s->evm.prof) return -1;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(out, s->evm.prof, 512 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, s->evm.prof, 1024 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1423,8 +1428,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
         if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; }
-        const u32 grid = (u32)((s->n + 255) / 256);
-        const u32 cold_grid = s->evm.perm ? (grid < 256u ? grid : 256u) : grid;
+        // with the sorted mapping the hot lane range is padded per state (EVM_PERM_PAD bounds the padding); blocks past its end exit
+        const u32 grid = (u32)((s->n + (s->evm.perm ? EVM_PERM_PAD : 0) + EVM_HOT_BLOCK - 1) / EVM_HOT_BLOCK);
+        const u32 all_grid = (u32)((s->n + 255) / 256);
+        const u32 cold_grid = s->evm.perm ? (all_grid < 256u ? all_grid : 256u) : all_grid;
         // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first); then the
         // rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces.  With the sorted
         // mapping the two timing events ride on the dispatches themselves (no event packets between the kernels).
