@@ -4091,8 +4091,10 @@ ZK_HD void evm_prefetch(Ins& I) {
 // their low words in LDS (layout: EVM_STAGE_ENTRIES).  Returns false when a cell is wider than its entry (malformed
 // witnesses only): the lane then reads the step rows from HBM as before.
 // (Round 2 also tried fetching the wavefront's 64 pairs in address order — lane l taking chunk (64 i + l) % 52 of pair
-// (64 i + l) / 52, nine cache lines per instruction instead of 64 — with the transposition done by the LDS writes: the
-// loads themselves completed in ~5k cycles, but the fully unrolled address / scatter code around them cost 140k.)
+// (64 i + l) / 52, nine cache lines per instruction instead of 64 — with the transposition done by the LDS writes.  The
+// loads themselves then complete in ~5k cycles, but the per-chunk address and scatter arithmetic is ~110 instructions
+// x 52 chunks per wavefront, and at two wavefronts per SIMD this kernel retires an instruction every ~10 cycles: the
+// phase took 40-55k cycles in two half batches (140k with all 52 loads in one batch, which spills), against 13-31k here.)
 ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_space(3))) u32* stage) {
     const uint4* p = (const uint4*)(a.steps + idx * (STEP_NCELLS * 4));
     uint4 lo[2 * STEP_NCELLS], hi[2 * STEP_NCELLS];
