@@ -4140,15 +4140,26 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     I.pre_op = 0;
     I.pre_op_ok = false;
     EV_PROF(I, 0);
-    I.rwc = ev_curr(I, S_RWC);
-    I.call_id = ev_curr(I, S_CALL_ID);
-    I.sp = ev_curr(I, S_SP);
-    I.pc = ev_curr(I, S_PC);
+    Fr statef, next_statef;
+    if (I.stage) {  // one branch and one batch of LDS reads for the cells every step needs (not one of each per cell)
+        I.rwc = ev_staged_cell(I, 0, S_RWC);
+        I.call_id = ev_staged_cell(I, 0, S_CALL_ID);
+        I.sp = ev_staged_cell(I, 0, S_SP);
+        I.pc = ev_staged_cell(I, 0, S_PC);
+        statef = ev_staged_cell(I, 0, S_STATE);
+        next_statef = ev_staged_cell(I, 1, S_STATE);
+    } else {
+        I.rwc = ev_step_cell(a, idx, S_RWC);
+        I.call_id = ev_step_cell(a, idx, S_CALL_ID);
+        I.sp = ev_step_cell(a, idx, S_SP);
+        I.pc = ev_step_cell(a, idx, S_PC);
+        statef = ev_step_cell(a, idx, S_STATE);
+        next_statef = ev_step_cell(a, idx + 1, S_STATE);
+    }
     const bool is_first = (a.opts & 1u) && idx == 0;
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
-    const Fr statef = ev_curr(I, S_STATE);
     const u32 state = statef.v[0];
-    const u32 next_state = ev_next(I, S_STATE).v[0];  // loaded with the first batch (used unless is_last)
+    const u32 next_state = next_statef.v[0];  // used unless is_last
     if ((G == EVM_GROUP_COLD) != (evm_state_group(state) == EVM_GROUP_COLD)) return ZK_NOT_MINE;
 #if !defined(ZK_HOSTSIM)
     if (EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 4] = state;
