@@ -33,7 +33,13 @@ __global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs
 
 // The lane-quad form (state_load_row_quad): 16 rows per wavefront, 15 of them evaluated.
 #define ST_QUAD_ROWS_PER_WAVE 15
-__global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_quad_kernel(StateArgs a, u32* status, ZkTally* tally) {
+#ifndef ZK_STATE_QUAD_OCC
+#define ZK_STATE_QUAD_OCC 2
+#endif
+#ifndef ZK_STATE_QUAD_BLOCK
+#define ZK_STATE_QUAD_BLOCK 256
+#endif
+__global__ __launch_bounds__(ZK_STATE_QUAD_BLOCK, ZK_STATE_QUAD_OCC) void state_rows_quad_kernel(StateArgs a, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
     const u32 lane = threadIdx.x & 63u, q = lane & 3u, slot = lane >> 2;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -67,9 +73,9 @@ static int state_lanes_per_row(u64 rows) {
 void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
     const int block = 256;
     if (state_lanes_per_row(a.eval_hi - a.eval_lo) == 4) {
-        const u64 rows_per_block = (u64)(block / 64) * ST_QUAD_ROWS_PER_WAVE;
+        const u64 rows_per_block = (u64)(ZK_STATE_QUAD_BLOCK / 64) * ST_QUAD_ROWS_PER_WAVE;
         const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(state_rows_quad_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);
+        hipLaunchKernelGGL(state_rows_quad_kernel, dim3(grid), dim3(ZK_STATE_QUAD_BLOCK), 0, st, a, status, tally);
         return;
     }
     const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
