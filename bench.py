@@ -408,6 +408,8 @@ def main():
             out["host_path"] = {"h2d_bytes": h2d["bytes"], "h2d_seconds": h2d["seconds"], "h2d_GBps": h2d["bytes"] / h2d["seconds"] / 1e9,
                                 "rows_per_s_including_h2d": units / (h2d["seconds"] + dt / args.steps),
                                 "note": "pageable host arrays -> HBM (torch .cuda()); never part of `value`"}
+        if args.workload == "evm" and wire_h is not None and "host_path" in out and not args.no_cpu_baseline:
+            out["host_path"]["marshalling"] = marshalling_sample(wire_h)
         if per_circuit is not None:
             # per-circuit HBM-side traffic from the committed counter passes of this workload (when there are any)
             names = {"evm": ("evm_steps_kernel", "-1"), "state": ("state_rows",), "bytecode": ("bytecode_rows_kernel",), "tx": ("sign_units_kernel",),
@@ -438,6 +440,29 @@ def main():
     sess.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def marshalling_sample(wire_h, n_steps=1 << 10):
+    """flatten_evm (reference-shaped Python objects -> wire arrays, zkevm_specs_amd/flatten.py) timed on a bounded prefix of this run's
+    trace: the objects are rebuilt from the wire first (zkevm_specs_amd/objects.py), which is not part of the figure."""
+    import numpy as np
+
+    from zkevm_specs_amd import flatten, objects
+
+    w = {k: v for k, v in wire_h.items()}
+    w["steps"] = np.ascontiguousarray(w["steps"][: n_steps + 1])
+    hi = int(w["steps"][-1, 1, 0]) + 64  # rw_counter of the last sampled step: the RW rows the prefix can look up
+    base = int(w["rw"][0, 0, 0])
+    w["rw"] = np.ascontiguousarray(w["rw"][: max(hi - base, 1)])
+    w["rw_flags"] = np.ascontiguousarray(w["rw_flags"][: len(w["rw"])])
+    tables, steps = objects.evm_from_wire(w)
+    t = time.perf_counter()
+    out = flatten.flatten_evm(tables, steps)
+    dt = time.perf_counter() - t
+    cells = sum(int(v.size) // 4 for v in out.values() if hasattr(v, "dtype") and v.dtype == np.uint64)
+    return {"steps": n_steps, "cells": cells, "seconds": dt, "steps_per_s": n_steps / dt, "cells_per_s": cells / dt, "cores": 1,
+            "note": "per-cell Python (`x.expr().n` -> 4 x u64); a caller that keeps its witness in wire arrays (device-side assignment, "
+                    "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
 
 
 def cpu_baseline(workload, units, wire_h, env):
