@@ -47,6 +47,20 @@ n_tx = 1 << min(k, 17)
 w = synth_tx_witness(n_tx, r, seed=4)
 run("tx_sign", engine.open_sign(w, r, False), n_tx,
     8 * 32 + 288 + 2 * 5 * 32)
+# Copy circuit: events expanded on the device (zk_copy_assign), then evaluated from the same HBM buffers (zk_copy_open)
+from zkevm_specs_amd.synth import synth_copy_events
+for kk in sorted({15, min(k, 19)}):
+    ce = synth_copy_events(1 << kk, seed=6)
+    ev, fl, da, of = to_dev(ce["events"]), to_dev(ce["flags"]), torch.from_numpy(ce["data"].view(np.int16)).cuda(), to_dev(ce["offsets"])
+    n_rows, n_table, n_rw = engine.copy_assign_sizes(ce["events"], ce["flags"], ce["data"], ce["offsets"])
+    c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device="cuda")
+    c_rf = torch.empty(n_rows, dtype=torch.int32, device="cuda")
+    c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device="cuda")
+    c_rwf = torch.empty(n_rw, dtype=torch.int32, device="cuda")
+    # per output row: 20 circuit cells + the RW row of every second row, written; the events and bytes read are negligible
+    run(f"copy_assign_2p{kk}", engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, None, c_rw, c_rwf), n_rows, 20 * 32 + 4 + 7 * 32)
+    run(f"copy_rows_2p{kk}", engine.open_copy(c_rows, c_rf, ce["r"], c_rw, c_rwf, to_dev(ce["bytecode"]), to_dev(ce["tx"]), to_dev(ce["tx_flags"])),
+        n_rows, 20 * 32 + 14 * 32)
 # keccak table generation (integer-ALU bound: ~3.6 k VALU ops per 136-byte block + ~25 per RLC byte)
 n_keys = 1 << k
 nrng = np.random.default_rng(6)

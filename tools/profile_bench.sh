@@ -14,6 +14,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cmd="python $root/bench.py --no-cpu-baseline --no-cold-leg --no-fresh-leg $*"
+if [ -n "${PROFILE_CMD:-}" ]; then cmd="$PROFILE_CMD"; fi  # e.g. PROFILE_CMD="python tools/bench_row_kernels.py" (run from the repo root)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $cmd > "$out/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- $cmd > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- $cmd > "$out/pmc_write.log" 2>&1
@@ -44,7 +45,7 @@ for name in ("fetch", "write", "sq"):
             g.write(f"\"{k}\",{c},{n},{s},{s/n}\n")
             summary["kernels"].setdefault(k, {}).setdefault("pmc", {})[c] = {"dispatches": n, "avg_per_dispatch": s / n}
 # keep the kernels that matter (>= 1 % of the traced time) to keep the file small
-summary["kernels"] = {k: v for k, v in summary["kernels"].items() if v.get("trace", {}).get("pct", 0) >= 1.0}
+summary["kernels"] = {k: v for k, v in summary["kernels"].items() if v.get("trace", {}).get("pct", 0) >= (0.2 if "row_kernels" in tag else 1.0)}
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 PY
 tail -1 "$out/trace.log"

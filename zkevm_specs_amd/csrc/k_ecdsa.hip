@@ -9,13 +9,22 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     const u64 i = gid / L;
     const int role = (int)(gid % L);
     const bool valid = i < a.n;
-    u32* tab = a.qtab + gid;
+#if ZK_ECDSA_TAB_INTERLEAVED
+    u32* tab = a.qtab + gid;  // word w of entry e at (e * 24 + w) * lanes + lane
+    const u64 tab_stride = a.qtab_lanes;
+#else
+    // each lane's 15 x 96 B table is contiguous: the window digit is data dependent, so the lanes of a wavefront read
+    // different entries, and with the lane-interleaved layout every 4-byte word came out of a different 64-byte sector
+    // (FETCH_SIZE 5.2 GB per 2^17-signature launch, profiles/r02_row_kernels_profile.json)
+    u32* tab = a.qtab + gid * (15u * 24u);
+    const u64 tab_stride = 1;
+#endif
     EcdsaPrep pr;
     u32 st = ECDSA_NOT_VERIFIED;
     SpPoint part = sp_infinity();
     if (valid) {
         st = ecdsa_prepare(a, i, pr, role == 0);
-        if (st == ECDSA_PENDING) part = ecdsa_partial(pr, L == 1 ? 0 : role, L == 1 ? 1 : role, tab, a.qtab_lanes);
+        if (st == ECDSA_PENDING) part = ecdsa_partial(pr, L == 1 ? 0 : role, L == 1 ? 1 : role, tab, tab_stride);
     }
     if (L == 2) {  // every lane takes part in the exchange; lane 2i receives the partial sum of lane 2i + 1
         SpPoint other;
