@@ -4040,7 +4040,7 @@ ZK_HD int evm_state_group(u32 state) {
 }
 // sort bin of a state.  The cold states keep their own 128 bins at the end (the cold kernel's lane range starts at
 // group_start[EVM_GROUP_COLD]); the hot kernel evaluates every other state, so the first 384 bins are ONE list ordered by
-// measured wavefront time, longest first (tools/evm_phase_prof.py): a longest-processing-time-first schedule over the
+// measured wavefront time, longest first (tools/evm_wave_timeline.py): a longest-processing-time-first schedule over the
 // 2 x 1024 wavefront slots, with the short POP / STOP wavefronts making the kernel's tail.
 ZK_HD u32 evm_state_bin(u32 state) {
     if (evm_state_group(state) == EVM_GROUP_COLD) return (u32)EVM_GROUP_COLD * 128u + (state & 127u);
