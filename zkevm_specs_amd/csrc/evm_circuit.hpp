@@ -142,9 +142,12 @@ struct Ins {
 ZK_HD void ev_fail(Ins& I, u32 kind) {
     if (I.err == 0u) I.err = ZK_CODE(kind, I.seq);
 }
+// branch-free (a select on two flags): hundreds of these sit in straight-line gadget code, and as `if (!cond) ev_fail()` each
+// became a compare + exec-mask save + branch, whose scalar dependency stalls cost more than the select
 ZK_HD void ev_require(Ins& I, bool cond, u32 kind = ZK_ASSERT) {
     I.seq++;
-    if (!cond) ev_fail(I, kind);
+    const u32 take = (cond ? 0u : 1u) & (I.err == 0u ? 1u : 0u);
+    I.err = take ? ZK_CODE(kind, I.seq) : I.err;
 }
 #define EV_TRY(stmt) do { stmt; if (I.err) return; } while (0)
 #define EV_TRYV(stmt, ret) do { stmt; if (I.err) return ret; } while (0)
