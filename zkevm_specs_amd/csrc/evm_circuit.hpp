@@ -79,7 +79,7 @@ struct EvmArgs {
 // tuning aid: slot of this wavefront in EvmArgs::prof (the first 4096 wavefronts of the grid)
 #define EV_PROF_WAVE ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)
 #define EV_PROF_ON(a) ((a).prof && (threadIdx.x & 63) == 0 && EV_PROF_WAVE < 4096u)
-#define EVM_STAGE_STRIDE EVM_STAGE_LANES  // u32 words between a lane's consecutive entries
+#define EVM_STAGE_STRIDE (EVM_STAGE_LANES + 1)  // u32 words between a lane's consecutive entries: odd, so that a quad's writes of one pair's entries hit different banks
 #define EVM_STAGE_ENTRIES 40
 #define EVM_STAGE_GAS 10  // entry pair of gas_left within a step's 12
 ZK_HD constexpr int evm_stage_entry(int s, int c) {
@@ -4090,40 +4090,73 @@ ZK_HD void evm_prefetch(Ins& I) {
 
 // verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
 #if !defined(ZK_HOSTSIM)
-// Load the 26 cells of the pair (52 independent 16-byte loads, issued before any gadget code needs registers) and keep
-// their low words in LDS (layout: EVM_STAGE_ENTRIES).  Returns false when a cell is wider than its entry (malformed
-// witnesses only): the lane then reads the step rows from HBM as before.
-// (Round 2 also tried fetching the wavefront's 64 pairs in address order — lane l taking chunk (64 i + l) % 52 of pair
-// (64 i + l) / 52, nine cache lines per instruction instead of 64 — with the transposition done by the LDS writes.  The
-// loads themselves then complete in ~5k cycles, but the per-chunk address and scatter arithmetic is ~110 instructions
-// x 52 chunks per wavefront, and at two wavefronts per SIMD this kernel retires an instruction every ~10 cycles: the
-// phase took 40-55k cycles in two half batches (140k with all 52 loads in one batch, which spills), against 13-31k here.)
-ZK_HD bool evm_stage_steps(const EvmArgs& a, u64 idx, __attribute__((address_space(3))) u32* stage) {
-    const uint4* p = (const uint4*)(a.steps + idx * (STEP_NCELLS * 4));
-    uint4 lo[2 * STEP_NCELLS], hi[2 * STEP_NCELLS];
+// Fill the wavefront's LDS stage (layout: EVM_STAGE_ENTRIES) with its 64 lanes' step pairs, by lane quads.  A pair is 832
+// contiguous bytes of the step table = 52 16-byte chunks.  The four lanes of a quad fetch one pair together: lane r takes
+// chunks r, r + 4, … r + 48, so each load of the quad is 64 contiguous bytes = one request to the vector memory path (a lane
+// fetching its own pair makes every 16-byte load its own request: 3,328 per wavefront instead of 832); a wavefront serves its
+// 64 pairs in four rounds of sixteen, the per-load address is the round's base plus an immediate, and all 52 loads are in
+// flight together.  Lane r then holds the low (r even) or high (r odd) halves of cells r/2, r/2 + 2, …: the even lanes write
+// the low words into the pair's column of the stage, the odd ones only have to see zeros.  Returns whether this lane's own
+// pair has a cell wider than its entry (malformed witnesses only): that lane then reads its step rows from HBM.
+// Measured (2^18 steps): kernel 78.8 -> 76.9 us against the lane-by-lane fill.  What it does not change is the kernel's
+// first round: all 2,048 resident wavefronts ask for their 53 KB at t = 0 — 109 MB, half the step table — and that takes
+// ~37k cycles = 16 us whichever way it is requested: HBM rate.  Later wavefronts stage in ~13k.
+// (Also tried in round 2: the wavefront walking its 64 x 832 B in address order, lane l taking chunk (64 i + l) % 52 of pair
+// (64 i + l) / 52 — ~110 instructions of address / scatter arithmetic per chunk, 40-55k cycles in two half batches, 140k
+// with all 52 loads in one batch (spills).)
+ZK_HD u32 evm_quad_or(u32 v) {
+    v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
+    v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+    return v;
+}
+ZK_HD bool evm_stage_steps_quad(const EvmArgs& a, u32 idx, bool mine, __attribute__((address_space(3))) u32* wave_stage) {
+    const u32 lane = threadIdx.x & 63u, q = lane >> 2, r = lane & 3u, r2 = r >> 1;
+    const bool hi_half = (r & 1u) != 0u;
+    u32 wide_rounds = 0;  // bit it: the pair this quad fetched in round it is wide
+    // all 52 loads first (round it: the quad's pair is 16 it + q), then the scatter: one dependent round trip for the lot
+    uint4 v[4][STEP_NCELLS];
 #pragma unroll
-    for (int k = 0; k < 2 * STEP_NCELLS; k++) {
-        lo[k] = p[2 * k];
-        hi[k] = p[2 * k + 1];
+    for (int it = 0; it < 4; it++) {
+        const u32 p = 16u * (u32)it + q;
+        const u32 idx_p = (u32)__shfl((int)idx, (int)p);
+        const bool on = __shfl(mine ? 1 : 0, (int)p) != 0;  // a lane without a pair: fetch pair 0, nobody reads that column
+        const uint4* src = (const uint4*)(a.steps + (u64)(on ? idx_p : 0u) * (STEP_NCELLS * 4)) + r;
+#pragma unroll
+        for (int k = 0; k < STEP_NCELLS; k++) v[it][k] = src[4 * k];
     }
-    u32 wide = 0;
 #pragma unroll
-    for (int k = 0; k < 2 * STEP_NCELLS; k++) {
-        const int c = k % STEP_NCELLS, e = evm_stage_entry(k / STEP_NCELLS, c);
-        stage[e * EVM_STAGE_STRIDE] = lo[k].x;
-        if (c == S_CH_LO || c == S_CH_HI) {
-            stage[(e + 1) * EVM_STAGE_STRIDE] = lo[k].y;
-            stage[(e + 2) * EVM_STAGE_STRIDE] = lo[k].z;
-            stage[(e + 3) * EVM_STAGE_STRIDE] = lo[k].w;
-        } else if (c == S_GAS) {
-            stage[(e + 1) * EVM_STAGE_STRIDE] = lo[k].y;
-            wide |= lo[k].z | lo[k].w;
-        } else {
-            wide |= lo[k].y | lo[k].z | lo[k].w;
+    for (int it = 0; it < 4; it++) {
+        const u32 p = 16u * (u32)it + q;  // the pair (stage column) of this quad in this round
+        u32 bad = 0;
+#pragma unroll
+        for (int k = 0; k < STEP_NCELLS; k++) {
+            const uint4 x = v[it][k];
+            if (hi_half) {
+                bad |= x.x | x.y | x.z | x.w;
+            } else {
+                // cell 2k + r2 of the pair (0..12 curr, 13..25 next): both candidates are compile-time, r2 selects
+                const int cA = 2 * k, cB = 2 * k + 1;
+                const int eA = evm_stage_entry(cA / STEP_NCELLS, cA % STEP_NCELLS), eB = evm_stage_entry(cB / STEP_NCELLS, cB % STEP_NCELLS);
+                const bool chA = cA % STEP_NCELLS == S_CH_LO || cA % STEP_NCELLS == S_CH_HI, chB = cB % STEP_NCELLS == S_CH_LO || cB % STEP_NCELLS == S_CH_HI;
+                const bool gasA = cA % STEP_NCELLS == S_GAS, gasB = cB % STEP_NCELLS == S_GAS;
+                const u32 e = r2 ? (u32)eB : (u32)eA;
+                const bool is_ch = r2 ? chB : chA, is_gas = r2 ? gasB : gasA;
+                __attribute__((address_space(3))) u32* dst = wave_stage + e * EVM_STAGE_STRIDE + p;
+                dst[0] = x.x;
+                if (is_ch || is_gas) dst[EVM_STAGE_STRIDE] = x.y;
+                if (is_ch) {
+                    dst[2 * EVM_STAGE_STRIDE] = x.z;
+                    dst[3 * EVM_STAGE_STRIDE] = x.w;
+                }
+                bad |= is_ch ? 0u : ((is_gas ? 0u : x.y) | x.z | x.w);
+            }
         }
-        wide |= hi[k].x | hi[k].y | hi[k].z | hi[k].w;
+        if (evm_quad_or(bad) != 0u) wide_rounds |= 1u << it;
     }
-    return wide == 0u;
+    const u32 theirs = (u32)__shfl((int)wide_rounds, (int)(4u * (lane & 15u)));  // the quad that fetched this lane's pair
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ((theirs >> (lane >> 4)) & 1u) != 0u;
 }
 #endif
 

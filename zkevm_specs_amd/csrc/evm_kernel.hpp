@@ -41,16 +41,17 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
             }
             const u64* e = (const u64*)a.codes.entries;
             for (u32 k = threadIdx.x; k < a.codes.n * 12u; k += blockDim.x) s_dir[EVM_DIR_SLOT_U64 + k] = e[k];
-            __syncthreads();
         }
         u32 code = 0;
         u64 idx = t;
         if (t < (u64)hi && a.perm) idx = a.perm[t];
-        if (t < (u64)hi && idx != (u64)EVM_NO_PAIR) {
-            // both steps of the pair go to LDS first (52 loads in flight at once); the gadgets read them from there
-            __attribute__((address_space(3))) u32* my = (__attribute__((address_space(3))) u32*)s_stage + threadIdx.x;
-            const bool staged = evm_stage_steps(a, idx, my);
-            code = evm_check_step<G>(a, idx, staged ? (EVM_LDS32_PTR)my : (EVM_LDS32_PTR) nullptr,
+        const bool mine = t < (u64)hi && idx != (u64)EVM_NO_PAIR;
+        // both steps of every pair of the wavefront go to LDS first (lane quads fetch them); the gadgets read them from there
+        __attribute__((address_space(3))) u32* my = (__attribute__((address_space(3))) u32*)s_stage + threadIdx.x;
+        const bool wide = evm_stage_steps_quad(a, (u32)idx, mine, my - (threadIdx.x & 63u));
+        if (dir_in_lds) __syncthreads();
+        if (mine) {
+            code = evm_check_step<G>(a, idx, wide ? (EVM_LDS32_PTR) nullptr : (EVM_LDS32_PTR)my,
                                      dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
             if (code == ZK_NOT_MINE) code = 0;
             else if (status) status[idx] = code;
