@@ -31,19 +31,21 @@ __global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs
     tally_commit(tally, i, code);
 }
 
-// The lane-quad form (state_load_row_quad): 16 rows per wavefront, 15 of them evaluated.
-#define ST_QUAD_ROWS_PER_WAVE 15
+// The lane-group forms (state_load_row_group<L>): L = 4 lanes per row = 16 rows per wavefront, L = 2 = 32 rows; the first
+// row of a wavefront is the halo row in front of the evaluated ones.
 #ifndef ZK_STATE_QUAD_OCC
 #define ZK_STATE_QUAD_OCC 2
 #endif
 #ifndef ZK_STATE_QUAD_BLOCK
 #define ZK_STATE_QUAD_BLOCK 256
 #endif
-__global__ __launch_bounds__(ZK_STATE_QUAD_BLOCK, ZK_STATE_QUAD_OCC) void state_rows_quad_kernel(StateArgs a, u32* status, ZkTally* tally) {
+template <int L>
+__global__ __launch_bounds__(ZK_STATE_QUAD_BLOCK, ZK_STATE_QUAD_OCC) void state_rows_group_kernel(StateArgs a, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u32 lane = threadIdx.x & 63u, q = lane & 3u, slot = lane >> 2;
+    constexpr u32 ROWS = 64u / L - 1u;  // evaluated rows per wavefront
+    const u32 lane = threadIdx.x & 63u, q = lane & (u32)(L - 1), slot = lane / (u32)L;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const u64 first = a.eval_lo + wave * ST_QUAD_ROWS_PER_WAVE;
+    const u64 first = a.eval_lo + wave * ROWS;
     const u64 n = a.rows.n;
     // slot s holds row first + s - 1 (slot 0: the predecessor of `first`, wrapping to n - 1)
     u64 i = slot == 0 ? (first == 0 ? n - 1 : first - 1) : first + slot - 1;
@@ -51,13 +53,16 @@ __global__ __launch_bounds__(ZK_STATE_QUAD_BLOCK, ZK_STATE_QUAD_OCC) void state_
     if (i >= n) i = n - 1;  // lanes past the range still take part in the cross-lane moves: keep their loads in bounds
     StRow C;
     u32 code = 0;
-    state_load_row_quad(a.rows, i, q, C, code);
-    code = state_check_loaded<4>(a, i, C, C, code);
+    state_load_row_group<L>(a.rows, i, q, C, code);
+    code = state_check_loaded<L>(a, i, C, C, code);
     if (!evaluate) code = 0;
     else if (status) status[i] = code;
     tally_commit(tally, i, code);
 }
 
+#ifndef ZK_STATE_SMALL_LANES
+#define ZK_STATE_SMALL_LANES 4  // lanes per row below 2^18 rows
+#endif
 // Measured (profiles/r02_state_lanes.txt): 2^16 rows 67.6 us (quad) vs 81.6 us (one lane per row); 2^20 rows 555 us vs 415 us —
 // the quad form wins while one wavefront per SIMD is all a launch has, the one-lane form once the chip is full (a quarter of
 // the cross-lane traffic and of the redundant per-quad checks).  ZK_STATE_LANES=1|4 overrides (tuning / tests).
@@ -65,19 +70,22 @@ static int state_lanes_per_row(u64 rows) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("ZK_STATE_LANES");
-        forced = e ? (atoi(e) == 1 ? 1 : 4) : 0;
+        forced = e ? (atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4) : 0;
     }
     if (forced) return forced;
-    return rows < (1ull << 18) ? 4 : 1;
+    return rows < (1ull << 18) ? ZK_STATE_SMALL_LANES : 1;
+}
+template <int L>
+static void launch_group(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
+    const u64 rows_per_block = (u64)(ZK_STATE_QUAD_BLOCK / 64) * (64 / L - 1);
+    const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(state_rows_group_kernel<L>), dim3(grid), dim3(ZK_STATE_QUAD_BLOCK), 0, st, a, status, tally);
 }
 void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
     const int block = 256;
-    if (state_lanes_per_row(a.eval_hi - a.eval_lo) == 4) {
-        const u64 rows_per_block = (u64)(ZK_STATE_QUAD_BLOCK / 64) * ST_QUAD_ROWS_PER_WAVE;
-        const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(state_rows_quad_kernel, dim3(grid), dim3(ZK_STATE_QUAD_BLOCK), 0, st, a, status, tally);
-        return;
-    }
+    const int lanes = state_lanes_per_row(a.eval_hi - a.eval_lo);
+    if (lanes == 4) { launch_group<4>(st, a, status, tally); return; }
+    if (lanes == 2) { launch_group<2>(st, a, status, tally); return; }
     const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
     const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);

@@ -454,32 +454,40 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
 // quad carries the verdict.  A wavefront covers 16 rows (15 evaluated + the halo row in front of them), so a launch has four
 // times the wavefronts of the one-lane-per-row form and a quarter of its per-lane dependent work: that is what the
 // latency-bound small batches (BASELINE config 2: 2^16 rows) and the load-issue-bound large ones both want.
-template <int K>
-ZK_HD u32 st_quad_bcast_u32(u32 v) {  // value of lane K of this lane's quad
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false);
+// L = 4 (a quad per row) or 2 (a lane pair per row: cell c goes to lane c & 1, 28 loads per lane, 32 rows per wavefront — at
+// 2^16 rows that is one resident round of wavefronts instead of two).
+template <int L, int K>
+ZK_HD u32 st_group_bcast_u32(u32 v) {  // value of lane K of this lane's group of L (groups are aligned inside quads)
+    if constexpr (L == 4) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false);
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6), 0xf, 0xf, false);
 }
-template <int K>
-ZK_HD Fr st_quad_bcast(const Fr& x) {
+template <int L, int K>
+ZK_HD Fr st_group_bcast(const Fr& x) {
     Fr r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = st_quad_bcast_u32<K>(x.v[k]);
+    for (int k = 0; k < 8; k++) r.v[k] = st_group_bcast_u32<L, K>(x.v[k]);
     return r;
 }
-ZK_HD u32 st_quad_or(u32 v) {
+template <int L>
+ZK_HD u32 st_group_or(u32 v) {
     v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
-    v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
+    if constexpr (L == 4) v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
     return v;
 }
-ZK_HD void state_load_row_quad(const ZkCols& w, u64 i, u32 q, StRow& R, u32& code) {
+// cell C of the row, from the lane of the group that loaded it (cell c sits in slot c / L of lane c % L)
+#define ST_GROUP_CELL(C) st_group_bcast<L, (C) % L>(mine[(C) / L])
+template <int L>
+ZK_HD void state_load_row_group(const ZkCols& w, u64 i, u32 q, StRow& R, u32& code) {
     R.flags = w.flags ? w.flags[i] : 0u;
-    Fr mine[14];  // cell q + 4 k
+    constexpr int NS = 56 / L;
+    Fr mine[NS];  // cell q + L k
 #pragma unroll
-    for (int k = 0; k < 14; k++) mine[k] = zk_col(w, q + 4u * (u32)k, i);
+    for (int k = 0; k < NS; k++) mine[k] = zk_col(w, q + (u32)L * (u32)k, i);
     // limb cells 8..17 and key-byte cells 18..49 held by this lane: range flags + their bits of the packed values
     u32 lc[5] = {0, 0, 0, 0, 0}, key[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bad_limb = 0, bad_byte = 0;
 #pragma unroll
-    for (int k = 2; k < 13; k++) {
-        const u32 c = q + 4u * (u32)k;  // 8 .. 51
+    for (int k = 8 / L; k < 52 / L; k++) {
+        const u32 c = q + (u32)L * (u32)k;  // 8 .. 51
         const Fr& x = mine[k];
         if (c < (u32)ST_BYTE0) {
             const u32 l = c - (u32)ST_LIMB0;
@@ -491,28 +499,28 @@ ZK_HD void state_load_row_quad(const ZkCols& w, u64 i, u32 q, StRow& R, u32& cod
             key[b >> 2] |= (x.v[0] & 0xffu) << (8u * (b & 3u));
         }
     }
-    bad_limb = st_quad_or(bad_limb);
-    bad_byte = st_quad_or(bad_byte);
+    bad_limb = st_group_or<L>(bad_limb);
+    bad_byte = st_group_or<L>(bad_byte);
     U256 lcv = fr_zero(), keyv;
 #pragma unroll
-    for (int k = 0; k < 5; k++) lcv.v[k] = st_quad_or(lc[k]);
+    for (int k = 0; k < 5; k++) lcv.v[k] = st_group_or<L>(lc[k]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) keyv.v[k] = st_quad_or(key[k]);
+    for (int k = 0; k < 8; k++) keyv.v[k] = st_group_or<L>(key[k]);
     // the wide cells, from their owner lanes
-    R.rwc = st_quad_bcast<0>(mine[0]);
-    const Fr is_write = st_quad_bcast<1>(mine[0]);
-    R.tag = st_quad_bcast<2>(mine[0]);
-    R.id = st_quad_bcast<3>(mine[0]);
-    R.addr = st_quad_bcast<0>(mine[1]);
-    R.ftag = st_quad_bcast<1>(mine[1]);
-    R.key_lo = st_quad_bcast<2>(mine[1]);
-    R.key_hi = st_quad_bcast<3>(mine[1]);
-    R.val_lo = st_quad_bcast<2>(mine[12]);
-    R.val_hi = st_quad_bcast<3>(mine[12]);
-    R.init_lo = st_quad_bcast<0>(mine[13]);
-    R.init_hi = st_quad_bcast<1>(mine[13]);
-    R.root_lo = st_quad_bcast<2>(mine[13]);
-    R.root_hi = st_quad_bcast<3>(mine[13]);
+    R.rwc = ST_GROUP_CELL(0);
+    const Fr is_write = ST_GROUP_CELL(1);
+    R.tag = ST_GROUP_CELL(2);
+    R.id = ST_GROUP_CELL(3);
+    R.addr = ST_GROUP_CELL(4);
+    R.ftag = ST_GROUP_CELL(5);
+    R.key_lo = ST_GROUP_CELL(6);
+    R.key_hi = ST_GROUP_CELL(7);
+    R.val_lo = ST_GROUP_CELL(50);
+    R.val_hi = ST_GROUP_CELL(51);
+    R.init_lo = ST_GROUP_CELL(52);
+    R.init_hi = ST_GROUP_CELL(53);
+    R.root_lo = ST_GROUP_CELL(54);
+    R.root_hi = ST_GROUP_CELL(55);
     // sites 1..8 exactly as state_load_row
     ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
     ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
