@@ -455,14 +455,14 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr, const RwRow*
 }
 // Request the rows of the next N lookups at the running counter (no checkpoint, no state change).
 template <int N>
-ZK_HD void rw_rows_fetch(const Ins& I, RwRows<N>& R) {
+ZK_HD void rw_rows_fetch_at(const Ins& I, RwRows<N>& R, u64 off) {  // rows of the lookups at offsets off .. off + N - 1
     const EvmArgs& a = *I.a;
     R.valid = a.rw_dense && a.rw_keys != nullptr;
     if (!R.valid) return;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         bool ok;
-        const u32 r = rw_dense_row(a, fr_add_u64(I.rwc, I.rw_off + (u64)k), ok);
+        const u32 r = rw_dense_row(a, fr_add_u64(I.rwc, off + (u64)k), ok);
         const uint4* kp = reinterpret_cast<const uint4*>(a.rw_keys + (u64)r * 4);
         R.row[k].k01 = kp[0];
         R.row[k].k23 = kp[1];
@@ -470,6 +470,8 @@ ZK_HD void rw_rows_fetch(const Ins& I, RwRows<N>& R) {
         R.row[k].v_hi = zk_table_cell(a.rw, r, R_VAL_LO + 1);
     }
 }
+template <int N>
+ZK_HD void rw_rows_fetch(const Ins& I, RwRows<N>& R) { rw_rows_fetch_at(I, R, I.rw_off); }
 ZK_HD Fr rw_cell(const Ins& I, u32 row, int c) { return zk_table_cell(I.a->rw, row, c); }
 ZK_HD Word rw_word(const Ins& I, u32 row, int c) { return word_of(rw_cell(I, row, c), rw_cell(I, row, c + 1)); }
 ZK_HD WordOrValue rw_value(const Ins& I, u32 row) {
@@ -866,6 +868,20 @@ ZK_HD WordOrValue call_context_lookup_word(Ins& I, u32 field_tag, u32 rw = 0, co
     u32 r = rw_lookup(I, Q);
     return rw_value(I, r);
 }
+// the same lookup on a row requested ahead (rw_rows_fetch_at at the offset this lookup runs at): the value cells and the
+// value's type bit (bit 56 of the packed key record, rw_pack_row) come with the row
+ZK_HD WordOrValue call_context_lookup_word_row(Ins& I, u32 field_tag, u32 rw, const Fr* call_id, const RwRow& row) {
+    RwQ Q;
+    rwq_init(Q, rw, TG_CallContext);
+    rwq_set(Q, R_ID, call_id ? *call_id : I.call_id);
+    rwq_set(Q, R_ADDR, fr_u(field_tag));
+    const u32 r = rw_lookup(I, Q, nullptr, &row);
+    WordOrValue v;
+    v.w = word_of(row.v_lo, row.v_hi);
+    const u64 w0 = (u64)row.k01.x | ((u64)row.k01.y << 32);
+    v.is_word = (w0 >> 63) ? (((w0 >> 56) & 1ull) != 0ull) : (I.a->rw.flags ? (I.a->rw.flags[r] & 1u) : true);
+    return v;
+}
 ZK_HD Fr call_context_lookup(Ins& I, u32 field_tag, u32 rw = 0, const Fr* call_id = nullptr) {
     WordOrValue v = call_context_lookup_word(I, field_tag, rw, call_id);
     return value_of(I, v);
@@ -878,6 +894,24 @@ ZK_HD Reversion reversion_info(Ins& I, const Fr* call_id = nullptr) {  // instru
     rv.end = call_context_lookup(I, CC_RwCounterEndOfReversion, 0, call_id);
     rv.persistent = call_context_lookup(I, CC_IsPersistent, 0, call_id);
     rv.rwc = call_id ? fr_zero() : ev_curr(I, S_REV);
+    return rv;
+}
+// call-context reads of the current call on rows requested ahead (R.row[k] must be the row the lookup runs at)
+template <int N>
+ZK_HD WordOrValue call_context_word(Ins& I, u32 field_tag, const RwRows<N>& R, int k) {
+    return R.valid ? call_context_lookup_word_row(I, field_tag, 0, nullptr, R.row[k]) : call_context_lookup_word(I, field_tag);
+}
+template <int N>
+ZK_HD Fr call_context_value(Ins& I, u32 field_tag, const RwRows<N>& R, int k) {
+    WordOrValue v = call_context_word(I, field_tag, R, k);
+    return value_of(I, v);
+}
+template <int N>
+ZK_HD Reversion reversion_info(Ins& I, const RwRows<N>& R, int k) {  // instruction.py:901-913 on rows k, k + 1
+    Reversion rv;
+    rv.end = call_context_value(I, CC_RwCounterEndOfReversion, R, k);
+    rv.persistent = call_context_value(I, CC_IsPersistent, R, k + 1);
+    rv.rwc = ev_curr(I, S_REV);
     return rv;
 }
 // state_write (instruction.py:826-863): the write plus, when not persistent, its reversion row
@@ -2317,13 +2351,15 @@ ZK_HD void g_jumpi(Ins& I, Tail& T) {  // jumpi.py: `if is_zero_word(cond)` is a
 }
 
 ZK_HD void g_sload(Ins& I, Tail& T) {  // storage.py:15-47
+    RwRows<4> A; rw_rows_fetch(I, A);          // tx id, the two reversion fields, callee address ...
+    RwRows<1> P; rw_rows_fetch_at(I, P, I.rw_off + 4);  // ... and the key's stack row, in flight with the opcode record
     Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_SLOAD));
-    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
-    Reversion rv; EV_TRY(rv = reversion_info(I));
-    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
+    Fr tx_id; tx_id = call_context_value(I, CC_TxId, A, 0);
+    Reversion rv; EV_TRY(rv = reversion_info(I, A, 1));
+    WordOrValue cw; cw = call_context_word(I, CC_CalleeAddress, A, 3);
     Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
-    Word key; key = stack_pop(I);
+    Word key; key = stack_pop(I, P, 0);
     RwQ Q;
     rwq_init(Q, 0, TG_AccountStorage);
     rwq_set(Q, R_ID, tx_id);
@@ -2346,16 +2382,18 @@ ZK_HD void g_sload(Ins& I, Tail& T) {  // storage.py:15-47
 }
 
 ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
+    RwRows<4> A; rw_rows_fetch(I, A);                   // tx id, is_static, the two reversion fields ...
+    RwRows<3> B; rw_rows_fetch_at(I, B, I.rw_off + 4);  // ... callee address, the two stack rows
     Fr opcode; opcode = opcode_lookup(I, true);
     constrain_equal(I, opcode, fr_u(OP_SSTORE));
-    Fr tx_id; tx_id = call_context_lookup(I, CC_TxId);
-    Fr is_static; is_static = call_context_lookup(I, CC_IsStatic);
+    Fr tx_id; tx_id = call_context_value(I, CC_TxId, A, 0);
+    Fr is_static; is_static = call_context_value(I, CC_IsStatic, A, 1);
     constrain_equal(I, fr_zero(), is_static);
-    Reversion rv; EV_TRY(rv = reversion_info(I));
-    WordOrValue cw; cw = call_context_lookup_word(I, CC_CalleeAddress);
+    Reversion rv; EV_TRY(rv = reversion_info(I, A, 2));
+    WordOrValue cw; cw = call_context_word(I, CC_CalleeAddress, B, 0);
     Fr callee; EV_TRY(callee = word_to_fq(I, cw.w, 20));
     Word key, sval;
-    key = stack_pop(I); sval = stack_pop(I);
+    key = stack_pop(I, B, 1); sval = stack_pop(I, B, 2);
     RwQ Q;
     rwq_init(Q, 1, TG_AccountStorage);
     rwq_set(Q, R_ID, tx_id);
@@ -2399,24 +2437,49 @@ ZK_HD void g_sstore(Ins& I, Tail& T) {  // storage.py:50-153
     set_tail(T, opcode, 10, t_delta_i(1), 2, t_same(), 3, fr_u(warm ? warm_case : warm_case + 2100));
 }
 
-// step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form
+// step_state_transition_to_restored_context (instruction.py:292-363), caller_id=None form.
+// Its eleven (twelve with the caller-id read) call-context lookups sit at consecutive rw_counters: their rows are requested
+// in batches of four, two batches in flight, instead of one dependent round trip (or two) per lookup — a non-root STOP
+// wavefront was 145k cycles, the longest of the hot kernel.  Same checks, same checkpoints.
+ZK_HD RwRow rc_row(const RwRows<4>& A, const RwRows<4>& B, const RwRows<4>& C, int j) {
+    switch (j) {
+    case 0: return A.row[0]; case 1: return A.row[1]; case 2: return A.row[2]; case 3: return A.row[3];
+    case 4: return B.row[0]; case 5: return B.row[1]; case 6: return B.row[2]; case 7: return B.row[3];
+    case 8: return C.row[0]; case 9: return C.row[1]; case 10: return C.row[2]; default: return C.row[3];
+    }
+}
 ZK_HD void restore_context(Ins& I, const Fr& rw_counter_delta_in, const Fr& gas_left, const Fr& rd_offset = fr_zero(),
                            const Fr& rd_length = fr_zero(), const Fr* caller_id_in = nullptr) {
     const Fr rw_counter_delta = fr_add_u64(rw_counter_delta_in, caller_id_in ? 11 : 12);
+    const int o = caller_id_in ? 0 : 1;  // the lookups of this transition: [caller id], 8 saved fields, 3 last-callee writes
+    const u64 base = I.rw_off;
+    RwRows<4> A, B, C;
+    rw_rows_fetch_at(I, A, base);
+    rw_rows_fetch_at(I, B, base + 4);
+    C.valid = false;
+    const bool rows = A.valid;
     Fr caller_id;
     if (caller_id_in) caller_id = *caller_id_in;
-    else caller_id = call_context_lookup(I, CC_CallerId);
+    else caller_id = rows ? value_of(I, call_context_lookup_word_row(I, CC_CallerId, 0, nullptr, A.row[0])) : call_context_lookup(I, CC_CallerId);
     const u32 tags[8] = {CC_IsRoot, CC_IsCreate, CC_CodeHash, CC_ProgramCounter, CC_StackPointer, CC_GasLeft,
                          CC_MemorySize, CC_ReversibleWriteCounter};
     WordOrValue saved[8];
-    for (int k = 0; k < 8; k++) EV_TRY(saved[k] = call_context_lookup_word(I, tags[k], 0, &caller_id));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (rows && o + k == 4) rw_rows_fetch_at(I, C, base + 8);  // the third batch, once the first is consumed
+        if (rows) EV_TRY(saved[k] = call_context_lookup_word_row(I, tags[k], 0, &caller_id, rc_row(A, B, C, o + k)));
+        else EV_TRY(saved[k] = call_context_lookup_word(I, tags[k], 0, &caller_id));
+    }
     {
-        Fr v; v = call_context_lookup(I, CC_LastCalleeId, 1, &caller_id);
-        constrain_equal(I, v, ev_curr(I, S_CALL_ID));
-        v = call_context_lookup(I, CC_LastCalleeReturnDataOffset, 1, &caller_id);
-        constrain_equal(I, v, rd_offset);
-        v = call_context_lookup(I, CC_LastCalleeReturnDataLength, 1, &caller_id);
-        constrain_equal(I, v, rd_length);
+        const u32 ltags[3] = {CC_LastCalleeId, CC_LastCalleeReturnDataOffset, CC_LastCalleeReturnDataLength};
+        const Fr want[3] = {ev_curr(I, S_CALL_ID), rd_offset, rd_length};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Fr v;
+            if (rows) v = value_of(I, call_context_lookup_word_row(I, ltags[k], 1, &caller_id, rc_row(A, B, C, o + 8 + k)));
+            else v = call_context_lookup(I, ltags[k], 1, &caller_id);
+            constrain_equal(I, v, want[k]);
+        }
     }
     const u32 st = ev_curr(I, S_STATE).v[0];
     const bool halts_ok = st == ES_STOP || st == ES_RETURN || st == ES_SELFDESTRUCT;
