@@ -335,14 +335,34 @@ ZK_HD void zk_divmod_limbs(const u32* n, const U256& d, u32* q /*NL limbs*/, U25
         for (int k = NL + 8; k >= 0; k--) u[k] = on ? (k >= w ? u[k - w] : 0u) : u[k];
     }
     const u64 vtop = v[7], vsec = v[6];
+    // The NL trial quotients all divide by the same normalised top limb (2^31 <= vtop < 2^32): one real division for its
+    // reciprocal dinv = floor((2^64 - 1) / vtop) - 2^32, then every 64-by-32 quotient is two multiplications and two
+    // corrections (Moeller & Granlund, "Improved division by invariant integers", algorithm 4) instead of a 64-bit
+    // division of ~100 instructions each.
+    const u32 dtop = v[7];
+    const u32 dinv = (u32)(~0ull / (u64)dtop - (1ull << 32));
 #pragma unroll
     for (int j = NL - 1; j >= 0; j--) {
-        const u64 num = ((u64)u[j + 8] << 32) | u[j + 7];
-        u64 qhat = num / vtop, rhat = num - qhat * vtop;
+        const u32 u1 = u[j + 8], u0 = u[j + 7];
+        // branch-free: the reciprocal form needs u1 < vtop; u1 == vtop (the partial remainder is below v * 2^32, so u1 cannot
+        // exceed it) caps the trial quotient at 2^32 - 1 with remainder u0 + vtop
+        const bool cap = u1 >= dtop;
+        const u32 u1s = cap ? 0u : u1;
+        const u64 qq = (u64)dinv * u1s + (((u64)u1s << 32) | u0);
+        u32 q1 = (u32)(qq >> 32) + 1u;
+        u32 r = u0 - q1 * dtop;
+        const bool fix1 = r > (u32)qq;
+        q1 -= fix1 ? 1u : 0u;
+        r += fix1 ? dtop : 0u;
+        const bool fix2 = r >= dtop;
+        q1 += fix2 ? 1u : 0u;
+        r -= fix2 ? dtop : 0u;
+        u64 qhat = cap ? 0xffffffffull : (u64)q1;
+        u64 rhat = cap ? (u64)u0 + vtop : (u64)r;
         // at most two corrections (Knuth D3)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            if (qhat >> 32 || (rhat >> 32 == 0 && qhat * vsec > ((rhat << 32) | u[j + 6]))) {
+            if (rhat >> 32 == 0 && qhat * vsec > ((rhat << 32) | u[j + 6])) {
                 qhat--;
                 rhat += vtop;
             }
