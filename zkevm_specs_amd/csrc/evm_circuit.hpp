@@ -130,6 +130,9 @@ struct Ins {
     // it instead of issuing its own dependent load; the checks are unchanged.
     u32 pre_op;
     bool pre_op_ok;
+    // the opcode's packed (responsible state, validity, constant gas) word, requested when the opcode byte arrives so that the
+    // shared transition tail does not start with a dependent table load; valid for opcode byte op_info_byte (0x100 = none)
+    u32 op_info, op_info_byte;
 };
 
 #if defined(ZK_HOSTSIM)
@@ -595,6 +598,10 @@ ZK_HD Fr bytecode_value(Ins& I, u32 tag, const Fr& index, int is_code) {
     u32 r = bytecode_lookup(I, curr_code_hash(I), tag, index, is_code);
     return zk_table_cell(I.a->bytecode, r, B_VALUE);
 }
+ZK_HD u32 zk_opinfo(u32 opcode_byte) {  // responsible state | valid << 8 | constant gas << 16 of an opcode (evm_tables.h)
+    static const uint32_t opinfo[256] = ZK_OPINFO_INIT;
+    return opinfo[opcode_byte & 0xffu];
+}
 ZK_HD Fr opcode_lookup_at(Ins& I, const Fr& index, bool is_code) {  // instruction.py:789-790
     return bytecode_value(I, 2, index, is_code ? 1 : 0);
 }
@@ -603,6 +610,8 @@ ZK_HD Fr opcode_lookup(Ins& I, bool is_code) {  // instruction.py:784-787
         I.pc_off++;
         I.seq++;
         if (((I.pre_op >> 8) & 1u) != (is_code ? 1u : 0u)) ev_fail(I, ZK_LOOKUP_UNSAT);
+        I.op_info_byte = I.pre_op & 0xffu;
+        I.op_info = zk_opinfo(I.op_info_byte);
         return fr_u(I.pre_op & 0xffu);
     }
     Fr index = fr_add_u64(I.pc, I.pc_off);
@@ -1114,10 +1123,9 @@ ZK_HD bool stage_trans_ok(u64 c, u64 n, u32 kind, const Fr& v) {  // v fits 64 b
 // same_context on the LDS-staged pair: every cell is known to fit 64 bits (128 for the code hash), so the eleven
 // transitions are 64-bit compares instead of 256-bit field additions.  Same checkpoints, same order, same verdicts.
 ZK_HD void same_context_staged(Ins& I, const Tail& T, u64 dyn_gas) {
-    static const uint32_t opinfo[256] = ZK_OPINFO_INIT;
     const Fr& opcode = T.opcode;
     const bool op_byte = fr_le_u64(opcode, 255);
-    const u32 info = opinfo[opcode.v[0] & 0xff];
+    const u32 info = (opcode.v[0] & 0xffu) == I.op_info_byte ? I.op_info : zk_opinfo(opcode.v[0]);
 #define STG(s, c) ((u64)I.stage[evm_stage_entry(s, c) * EVM_STAGE_STRIDE])
 #define STG_GAS(s) (STG(s, S_GAS) | ((u64)I.stage[(evm_stage_entry(s, S_GAS) + 1) * EVM_STAGE_STRIDE] << 32))
     const u64 st = STG(0, S_STATE);
@@ -4238,6 +4246,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     I.code_state = 0;
     I.pre_op = 0;
     I.pre_op_ok = false;
+    I.op_info = 0;
+    I.op_info_byte = 0x100u;
     EV_PROF(I, 0);
     Fr statef, next_statef;
     if (I.stage) {  // one branch and one batch of LDS reads for the cells every step needs (not one of each per cell)
