@@ -68,10 +68,10 @@ def hostsim_status(lib, w, opts=(0, 0), generic_index=False):
     return st[: n - 1].tolist()
 
 
-def fuzz_wire(w, rng):
-    """Overwrite 1..3 random cells of the steps / rw / bytecode tables (canonical values)."""
+def fuzz_wire(w, rng, copy=True):
+    """Overwrite 1..3 random cells of the steps / rw / bytecode tables (canonical values); copy=False: in place (large traces)."""
     P = wire.P
-    w = {k: v.copy() for k, v in w.items() if k in FIELDS}
+    w = {k: (v.copy() if copy else v) for k, v in w.items() if k in FIELDS}
 
     def put(arr, idx, val):
         arr[idx] = np.frombuffer(int(val % P).to_bytes(32, "little"), dtype="<u8")

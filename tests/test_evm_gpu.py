@@ -148,3 +148,24 @@ def test_full_size_trace_properties():
         j = int(np.searchsorted(step_rwc, c, side="right") - 1)
         if j < n - 1:
             assert eo.verify_step(W, j) == st1[j]
+
+
+def test_full_size_all_pairs_vs_logic_harness(hostsim):
+    """BASELINE config 3 size (2^18 steps), ~1,200 tampered cells: the status of EVERY pair against the C++ logic harness (the
+    kernels' own gadget sources in a plain host loop, tests/hostsim; the CPU suite pins it to the oracle case by case, and the
+    2^16 test above pins the GPU to the oracle directly) — what this adds at full size is the device machinery around the
+    gadgets: the by-state sort with its padded bins, the quad-staged step pairs, the LDS directory, the batched row requests."""
+    from tests.evm_cases import hostsim_status
+
+    n = 1 << 18
+    w = synth_evm_trace(n, seed=3)
+    w = {k: v for k, v in w.items() if k != "meta"}
+    rng = random.Random(41)
+    for _ in range(600):
+        w = fuzz_wire(w, rng, copy=False)
+    exp = hostsim_status(hostsim, w)
+    assert len(exp) == n - 1 and sum(1 for c in exp if c) >= 400
+    res, status = _run(w)
+    assert status == exp
+    _check_tally(res, exp)
+
