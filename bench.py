@@ -3,27 +3,33 @@
 
 A "step" is one evaluation pass of the circuit kernel(s) over the rank's witness shard, with all inputs already resident
 in HBM.  `--scaling weak` (default): every rank holds its own 2^log_rows-row witness.  `--scaling strong`: ONE global
-witness — rank 0 builds it, the lookup tables are replicated with a broadcast (RCCL), the rows are sharded with a halo
-(zkevm_specs_amd/distributed.py).  The only collective inside the timed region's result path is the tally exchange
-(one all-gather of three words per rank).
+witness — rank 0 builds it, its arrays are replicated with broadcasts (RCCL), every circuit's rows are cut into
+contiguous ranges with that circuit's halo (zkevm_specs_amd/distributed.py), lookup tables stay whole on every rank.  The
+only collective in the result path is the tally exchange (one all-gather of three words per rank).
+
+`python bench.py --gpus N` with no torchrun environment starts its N ranks itself (re-exec under torch.distributed.run on
+127.0.0.1); under torchrun (RANK / WORLD_SIZE set) it is one rank.
 
 The JSON line carries, next to the contract's fields:
   roofline        `achieved` / `frac` are PHYSICAL: HBM-side bytes per launch from the committed rocprofv3 counter passes
-                  (profiles/r02_*_profile.json, tools/profile_bench.sh) over this run's live kernel time; the algorithmic
-                  figure (SURVEY.md §8d bytes / kernel time) is reported beside it as `algorithmic`; `valu` is the
-                  VALU-issue roofline of the same kernel (SQ counters), the resource that actually binds this path.
+                  (profiles/r*_<workload>_2p<log>_profile.json, tools/profile_bench.sh) over this run's live kernel time; the
+                  algorithmic figure (SURVEY.md §8d bytes / kernel time) is reported beside it as `algorithmic`; `valu` is the
+                  VALU-issue roofline of the same kernel (SQ counters).  `bound` names what binds the kernel.
   fresh_witness   what a verifier pays for a witness it sees once: session open (index / packed-key / directory builds on
-                  the device, inputs resident) + one pass over cold caches.
+                  the device, inputs resident) + one pass over cold caches, and the one-shot C entry (zk_evm_verify).
   cpu_baseline    `port` (oracle/, pure Python, dict-indexed lookups), `hostsim` (the kernels' own sources built for the CPU,
                   tests/hostsim: the "optimised CPU" line) — both timed here on a bounded sample — and `reference`: the
-                  unmodified reference timed in the build container (tools/time_reference.py -> profiles/r02_cpu_reference.json;
-                  /root/reference does not exist on the GPU box).
+                  unmodified reference timed in the build container (tools/time_reference.py -> profiles/r*_cpu_reference.json;
+                  /root/reference does not exist on the GPU box, so this leg is a CROSS-BOX figure and says so).
   host_path       marshalling (Python objects -> wire arrays, flatten.py) and H2D staging, reported separately.
+  other_configs   (default N = 1 run only) BASELINE configs[1], [3], [4] measured after the headline on the same clock:
+                  State 2^16, Tx + Sig 2^14, Super 2^20 — ms / pass, dominant kernel, physical and algorithmic fractions, CPU legs.
 """
 import argparse
 import glob
 import json
 import os
+import socket
 import sys
 import time
 
@@ -35,6 +41,9 @@ N_SIMD = 1024                # 256 CUs x 4 SIMDs
 SHADER_CLOCK_HZ = 2.4e9      # nominal; profiled passes run lower (guide: 1.9 - 2.3 GHz effective)
 FETCH_GATHER_CORRECTION = 1.0 / 0.95  # profiles/r01_fetch_size_calibration.txt: per-lane 416 / 448-byte record gathers
 FETCH_STREAM_CORRECTION = 2.0         # guide: wide coalesced streaming reads report half the bytes
+DEFAULT_LOG_ROWS = {"evm": 18, "state": 16, "super": 20, "tx": 14}
+TX_UNIT_BYTES = 8 * 32 + 288 + 2 * 5 * 32   # 8 cells + 288 B of byte rows + 2 tx-table rows
+SIG_UNIT_BYTES = 8 * 32 + 288
 
 
 def load_profile(workload, log_rows):
@@ -44,12 +53,478 @@ def load_profile(workload, log_rows):
 
 
 def kernel_counters(profile, needle):
-    if not profile:
+    if not profile or not needle:
         return None
     for name, k in profile["kernels"].items():
         if all(n in name for n in needle):
             return dict(k, name=name)
     return None
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run ... bench.py <same args>` (one rank
+    per GPU, rendezvous on 127.0.0.1 — the container hostname may not resolve).  Rank 0's JSON line goes to the same stdout."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+class Ctx:
+    """per-process plumbing: rank, device, process group, upload / replicate helpers"""
+
+    def __init__(self, args):
+        import numpy as np
+        import torch
+
+        self.np, self.torch, self.args = np, torch, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, f"WORLD_SIZE={self.world} but --gpus {args.gpus}"
+        # test hooks (single-GPU dry run of the N > 1 path): ZK_BENCH_DEVICE pins every rank to one GPU, ZK_BENCH_BACKEND=gloo
+        # replaces RCCL, which refuses two ranks on one device
+        if os.environ.get("ZK_BENCH_DEVICE") is not None:
+            self.local_rank = int(os.environ["ZK_BENCH_DEVICE"])
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.dist = dist
+            backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
+        self.h2d = {"bytes": 0, "seconds": 0.0}
+
+    def to_dev(self, x):
+        np, torch = self.np, self.torch
+        if x.dtype == np.uint8:
+            return torch.from_numpy(x).cuda()
+        if x.dtype.itemsize == 2:
+            return torch.from_numpy(x.view(np.int16)).cuda()
+        return torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
+
+    def upload(self, arrays):
+        """numpy dict -> device tensors, timed (pageable host memory, the path a ctypes caller takes)"""
+        self.torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = {k: self.to_dev(v) for k, v in arrays.items()}
+        self.torch.cuda.synchronize()
+        self.h2d["seconds"] += time.perf_counter() - t
+        self.h2d["bytes"] += sum(int(v.nbytes) for v in arrays.values())
+        return out
+
+    def replicate(self, arrays, src=0):
+        """strong scaling: rank `src`'s arrays on every rank (shapes first, then one broadcast per array: RCCL over xGMI)"""
+        torch, dist = self.torch, self.dist
+        names = sorted(arrays) if self.rank == src else None
+        meta = [[(k, tuple(arrays[k].shape), str(arrays[k].dtype)) for k in names]] if self.rank == src else [None]
+        dist.broadcast_object_list(meta, src=src)
+        out = {}
+        for k, shape, dt in meta[0]:
+            if self.rank == src:
+                t = self.to_dev(arrays[k])
+            else:
+                tdt = torch.uint8 if dt == "uint8" else (torch.int16 if dt in ("uint16", "int16") else (torch.int64 if dt == "uint64" else torch.int32))
+                t = torch.empty(shape, dtype=tdt, device="cuda")
+            if t.numel():
+                dist.broadcast(t, src=src)
+            out[k] = t
+        return out
+
+    def replicate_tree(self, obj, src=0, big=1 << 16):
+        """a nested dict / tuple / list of numpy arrays and plain values from rank `src` on every rank: arrays of `big` bytes
+        or more travel as device broadcasts (and stay device tensors), the rest as one pickled object (host values)"""
+        np = self.np
+        flat = {}
+
+        def strip(x, path):
+            if isinstance(x, np.ndarray) and x.nbytes >= big:
+                flat[path] = x
+                return ("__dev__", path)
+            if isinstance(x, dict):
+                return {k: strip(v, f"{path}/{k}") for k, v in x.items()}
+            if isinstance(x, (tuple, list)):
+                return type(x)(strip(v, f"{path}/{i}") for i, v in enumerate(x))
+            return x
+
+        box = [strip(obj, "") if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        dev = self.replicate(flat if self.rank == src else {}, src=src)
+
+        def fill(x):
+            if isinstance(x, tuple) and len(x) == 2 and x[0] == "__dev__":
+                return dev[x[1]]
+            if isinstance(x, dict):
+                return {k: fill(v) for k, v in x.items()}
+            if isinstance(x, (tuple, list)):
+                return type(x)(fill(v) for v in x)
+            return x
+
+        return fill(box[0])
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+class Workload:
+    """what the timed loop and the report need to know about one configuration"""
+    sess = None
+    fresh = None          # open_fn of the fresh-witness leg (None: no such leg)
+    oneshot = None        # callable running the one-shot C entry over the resident witness -> Result
+    units = total_units = row_offset = 0
+    algo_bytes = None
+    kernel_name = kernel_needle = None
+    workload = ""
+    extra_cfg = None
+    wire_h = None         # host wire of the EVM trace (CPU legs / marshalling sample)
+    env = None            # host arrays the CPU legs read
+    profile_key = None
+
+
+def build_evm(ctx, log_rows, strong):
+    from zkevm_specs_amd import distributed, engine
+    from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+    n, w = 1 << log_rows, Workload()
+    if strong:
+        w.wire_h = synth_evm_trace(n, seed=3) if ctx.rank == 0 else None
+        meta_box = [w.wire_h.pop("meta") if ctx.rank == 0 else None]
+        ctx.dist.broadcast_object_list(meta_box, src=0)
+        meta = meta_box[0]
+        full = ctx.replicate(w.wire_h if ctx.rank == 0 else {})
+        lo, hi = distributed.shard_bounds(n - 1, ctx.rank, ctx.world)
+        wire_d = dict(full, steps=full["steps"][lo: hi + 1].contiguous())
+        w.units, w.row_offset, w.total_units = hi - lo, lo, n - 1
+        w.algo_bytes = meta["algorithmic_bytes"] * w.units / (n - 1)
+    else:
+        w.wire_h = synth_evm_trace(n, seed=3 + ctx.rank)
+        meta = w.wire_h.pop("meta")
+        wire_d = ctx.upload(w.wire_h)
+        w.units, w.row_offset = n - 1, ctx.rank * (n - 1)
+        w.total_units = w.units * ctx.world
+        w.algo_bytes = meta["algorithmic_bytes"]
+    w.fresh = lambda: engine.open_evm(wire_d, device=ctx.local_rank)  # noqa: E731
+    w.oneshot = lambda status=None: engine.evm_verify(wire_d, status_dev=status, device=ctx.local_rank)  # noqa: E731
+    w.sess = w.fresh()
+    w.kernel_name, w.kernel_needle = "evm_steps_kernel", ("evm_steps_kernel", "-1")
+    w.workload = (f"EVM circuit, 2^{log_rows} execution steps {'in total' if strong else 'per GPU'}, mixed-opcode synthetic trace "
+                  f"(BASELINE configs[2]); RW table {meta['n_rw']} rows, bytecode table {meta['n_bytecode']} rows")
+    w.extra_cfg = {"steps_per_gpu": w.units + 1, "rw_rows": meta["n_rw"], "bytecode_rows": meta["n_bytecode"]}
+    w.profile_key = ("evm", log_rows)
+    return w
+
+
+def build_state(ctx, log_rows, strong):
+    from zkevm_specs_amd import distributed, engine
+    from zkevm_specs_amd.synth import synth_state_witness
+
+    n, w = 1 << log_rows, Workload()
+    if strong:
+        host = None
+        if ctx.rank == 0:
+            cols, flags, mpt = synth_state_witness(n, seed=2)
+            host = {"cols": cols, "flags": flags, "mpt": mpt}
+            w.env = host
+        full = ctx.replicate(host if ctx.rank == 0 else {})
+        d_cols, d_flags, elo, ehi, lo = distributed.shard_rows(full["cols"], full["flags"], ctx.rank, ctx.world, "state")
+        d_mpt = full["mpt"]
+        w.units, w.row_offset, w.total_units = ehi - elo, lo, n
+
+        def open_fn():
+            s = engine.open_state(d_cols, d_flags, d_mpt, device=ctx.local_rank)
+            s.set_range(elo, ehi)
+            return s
+    else:
+        cols, flags, mpt = synth_state_witness(n, seed=2 + ctx.rank)
+        w.env = {"cols": cols, "flags": flags, "mpt": mpt}
+        d = ctx.upload(w.env)
+        d_cols, d_flags, d_mpt = d["cols"], d["flags"], d["mpt"]
+        w.units, w.row_offset = n, ctx.rank * n
+        w.total_units = w.units * ctx.world
+        open_fn = lambda: engine.open_state(d_cols, d_flags, d_mpt, device=ctx.local_rank)  # noqa: E731
+    w.sess = open_fn()
+    w.fresh = open_fn
+    w.algo_bytes = w.units * 57 * 32  # SURVEY.md §8(d): every witness cell counted once
+    w.kernel_name, w.kernel_needle = "state_rows_kernel", ("state_rows",)
+    w.workload = f"State circuit, 2^{log_rows} RW rows {'in total' if strong else 'per GPU'} (BASELINE configs[1])"
+    w.extra_cfg = {"rows_per_gpu": w.units, "mpt_rows": int(d_mpt.shape[0])}
+    w.profile_key = ("state", log_rows)
+    return w
+
+
+class TxSigPass:
+    """BASELINE configs[3]: one pass = the Tx circuit (tx_circuit.py:253-291) AND the Sig circuit (sig_circuit.py:113-122) over
+    the same 2^k signed transactions, each circuit verifying its own chips' signatures as the reference does: secp256k1 ECDSA
+    verification (fills the units' ecdsa_status column in HBM) + the SignVerify / Row.verify kernel.  The two circuits are
+    independent, so they run on two streams."""
+
+    def __init__(self, ctx, d_tx, d_sig, r):
+        from zkevm_specs_amd import engine
+
+        torch, dev = ctx.torch, ctx.local_rank
+        self.n = int(d_tx["bytes"].shape[0])
+        self.ecdsa_tx = engine.open_ecdsa(d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4, device=dev)
+        self.tx = engine.open_sign(d_tx, r, False, device=dev)
+        self.ecdsa_sig = engine.open_ecdsa(d_sig["bytes"], v=d_sig["meta"][:, 3], layout=engine.ECDSA_LAYOUT_SIG_UNITS, out_dev=d_sig["meta"],
+                                           out_stride=4, v_stride=4, device=dev) if d_sig is not None else None
+        self.sig = engine.open_sign(d_sig, r, True, device=dev) if d_sig is not None else None
+        torch.cuda.synchronize()
+        self._side = torch.cuda.Stream() if d_sig is not None else None
+        if self._side is not None:
+            self.ecdsa_sig.set_stream(self._side)
+            self.sig.set_stream(self._side)
+
+    def launch(self):
+        self.ecdsa_tx.launch()
+        if self.ecdsa_sig is not None:
+            self.ecdsa_sig.launch()
+        self.tx.launch()
+        if self.sig is not None:
+            self.sig.launch()
+
+    def collect(self):
+        re_, rs_ = self.ecdsa_tx.collect(), self.tx.collect()
+        rs_.ecdsa_ms = re_.kernel_ms  # a signature that does not verify fails its unit in the Tx kernel already
+        rs_.sig_ms = rs_.sig_ecdsa_ms = None
+        if self.sig is not None:
+            r2e, r2 = self.ecdsa_sig.collect(), self.sig.collect()
+            rs_.sig_ms, rs_.sig_ecdsa_ms = r2.kernel_ms, r2e.kernel_ms
+            if not r2.ok and rs_.ok:
+                rs_.first_fail_row, rs_.first_fail_code = r2.first_fail_row, r2.first_fail_code
+            rs_.fail_count += r2.fail_count
+        return rs_
+
+    def close(self):
+        for s in (self.ecdsa_tx, self.tx, self.ecdsa_sig, self.sig):
+            if s is not None:
+                s.close()
+
+
+def build_tx(ctx, log_rows, strong):
+    from zkevm_specs_amd import distributed
+    from zkevm_specs_amd.synth import device_keccak_digests, synth_sig_witness, synth_tx_witness
+
+    n, w = 1 << log_rows, Workload()
+    seed = 4 if strong else 4 + ctx.rank
+    r_tx = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221 + (0 if strong else ctx.rank)
+    if strong:
+        host = None
+        if ctx.rank == 0:
+            host = {"tx": synth_tx_witness(n, r_tx, seed=seed, signed=True, digests_of=device_keccak_digests(r_tx)),
+                    "sig": synth_sig_witness(n, r_tx, seed=seed, digests_of=device_keccak_digests(r_tx))}
+            w.env = host
+        full = ctx.replicate_tree(host, big=0)
+        d_tx, lo = distributed.shard_units(full["tx"], ctx.rank, ctx.world)
+        d_sig, _ = distributed.shard_units(full["sig"], ctx.rank, ctx.world)
+        w.units, w.row_offset, w.total_units = int(d_tx["bytes"].shape[0]), lo, n
+    else:
+        w.env = {"tx": synth_tx_witness(n, r_tx, seed=seed, signed=True, digests_of=device_keccak_digests(r_tx)),
+                 "sig": synth_sig_witness(n, r_tx, seed=seed, digests_of=device_keccak_digests(r_tx))}
+        d_tx, d_sig = ctx.upload(w.env["tx"]), ctx.upload(w.env["sig"])
+        w.units, w.row_offset = n, ctx.rank * n
+        w.total_units = w.units * ctx.world
+    w.sess = TxSigPass(ctx, d_tx, d_sig, r_tx)
+    w.algo_bytes = w.units * TX_UNIT_BYTES
+    w.kernel_name, w.kernel_needle = "sign_units_kernel", ("sign_units_kernel",)
+    w.workload = (f"Tx + Sig circuits, 2^{log_rows} signed synthetic txs {'in total' if strong else 'per GPU'} (BASELINE configs[3]): per pass, ECDSA "
+                  "verification + SignVerify kernel of the Tx circuit and ECDSA verification + Row.verify kernel of the Sig circuit")
+    w.extra_cfg = {"txs_per_gpu": w.units, "circuits": ["tx", "sig"], "signatures_verified_per_pass": 2 * w.units}
+    w.profile_key = ("tx", log_rows)
+    return w
+
+
+def build_super(ctx, log_rows, strong):
+    from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
+
+    w = Workload()
+    # ONE consistent witness: the State rows are the EVM trace's RW table (synth_block.py), Copy / Exp circuits included
+    if strong:
+        parts = synth_super_block(log_rows, seed=5) if ctx.rank == 0 else None
+        if ctx.rank == 0:
+            w.env = {"parts": parts}
+        parts = ctx.replicate_tree(parts, big=1 << 20)
+        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, shard=(ctx.rank, ctx.world))
+        w.total_units = sum(w.sess.global_rows.values())
+    else:
+        parts = synth_super_block(log_rows, seed=5 + ctx.rank)
+        w.env = {"parts": parts}
+        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev)
+    sess = w.sess
+    w.units = sum(sess.rows.values())
+    if not strong:
+        w.row_offset, w.total_units = ctx.rank * w.units, w.units * ctx.world
+    frac = {k: sess.rows[k] / max(sess.global_rows[k], 1) for k in sess.rows}
+    w.super_bytes = {"evm": parts["meta"]["algorithmic_bytes"] * frac["evm"], "state": sess.rows["state"] * 57 * 32,
+                     "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * TX_UNIT_BYTES,
+                     "copy": sess.rows.get("copy", 0) * (20 + 14) * 32, "exp": sess.rows.get("exp", 0) * 21 * 32}
+    w.workload = (f"Super circuit, ~2^{log_rows} rows {'in total' if strong else 'per GPU'} over ONE consistent witness (BASELINE configs[4]; State rows = "
+                  "the EVM trace's RW table re-keyed and re-sorted; Copy / Exp rows from the trace's own SHA3 / CODECOPY / EXP steps where "
+                  "the generator emits them): " + ", ".join(f"{k} {v}" for k, v in (sess.global_rows if strong else sess.rows).items()) + " rows")
+    w.extra_cfg = {"rows_per_gpu": dict(sess.rows), "state_assign_ms": sess.assign_ms}
+    if strong:
+        w.extra_cfg["rows_total"] = dict(sess.global_rows)
+    w.profile_key = ("super", log_rows)
+    return w
+
+
+BUILDERS = {"evm": build_evm, "state": build_state, "tx": build_tx, "super": build_super}
+
+
+def timed_passes(ctx, sess, steps, warmup):
+    """W untimed passes, then exactly K passes bracketed by barrier + synchronize on both sides; returns (seconds, last result)"""
+    for _ in range(warmup):
+        sess.launch()
+    sess.collect()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sess.launch()
+    res = sess.collect()
+    ctx.barrier()
+    return time.perf_counter() - t0, res
+
+
+def resolve_super(w, res):
+    """the super circuit's collect() -> (tally-like object, per-circuit block); picks the dominant kernel"""
+    sess = w.sess
+    results, total_fail_local, first_local = res
+    per_circuit = {k: {"rows": sess.rows[k], "kernel_ms": r.kernel_ms,
+                       "algorithmic_GBps": w.super_bytes[k] / (r.kernel_ms / 1e3) / 1e9} for k, r in results.items()}
+    dom = max(results, key=lambda k: results[k].kernel_ms)
+    w.kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_kernel", "bytecode": "bytecode_rows_kernel",
+                     "tx": "sign_units_kernel", "copy": "copy_rows_kernel", "exp": "exp_rows_kernel"}[dom]
+    w.kernel_needle = (w.kernel_name,) + (("-1",) if dom == "evm" else ())
+    w.algo_bytes = w.super_bytes[dom]
+
+    class _Tally:
+        fail_count = total_fail_local
+        # a failing row of circuit c is reported as its row in the GLOBAL block of that circuit (SuperCircuit.collect)
+        first_fail_row = None if first_local is None else first_local[1]
+        first_fail_code = 0 if first_local is None else first_local[2]
+        kernel_ms = results[dom].kernel_ms
+
+    return _Tally, per_circuit
+
+
+def roofline_block(w, res, world, strong, cold_ms=None):
+    kernel_s = res.kernel_ms / 1e3
+    algo_gbps = w.algo_bytes / kernel_s / 1e9
+    # HBM traffic and SQ counters come from separate rocprofv3 --pmc passes over this same command
+    # (tools/profile_bench.sh); the committed per-dispatch summary is attached when there is one for this size
+    profile, profile_src = load_profile(*w.profile_key)
+    kc = kernel_counters(profile, w.kernel_needle) if world == 1 or not strong else None
+    traffic = valu = None
+    wait_frac = None
+    if kc and "pmc" in kc:
+        pmc = kc["pmc"]
+        corr = FETCH_GATHER_CORRECTION if w.kernel_name == "evm_steps_kernel" else FETCH_STREAM_CORRECTION
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = pmc["FETCH_SIZE"]["avg_per_dispatch"] * 1024.0 * corr + pmc["WRITE_SIZE"]["avg_per_dispatch"] * 1024.0
+        if "SQ_ACTIVE_INST_VALU" in pmc:
+            # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles summed over waves (guide, PMC table): VALU-active shader
+            # cycles = 4 x counter; the chip offers N_SIMD x kernel cycles of VALU issue
+            act = pmc["SQ_ACTIVE_INST_VALU"]["avg_per_dispatch"] * 4.0
+            wave_cycles = pmc.get("SQ_WAVE_CYCLES", {}).get("avg_per_dispatch", 0) * 4.0
+            if wave_cycles and "SQ_WAIT_ANY" in pmc:
+                wait_frac = pmc["SQ_WAIT_ANY"]["avg_per_dispatch"] * 4.0 / wave_cycles
+            valu = {"insts_valu_per_launch": pmc.get("SQ_INSTS_VALU", {}).get("avg_per_dispatch"),
+                    "active_valu_cycles_per_launch": act, "wave_cycles_per_launch": wave_cycles,
+                    "wait_any_frac_of_wave_cycles": wait_frac,
+                    "frac_of_issue_peak": act / (kernel_s * SHADER_CLOCK_HZ * N_SIMD),
+                    "note": f"VALU-active cycles / ({N_SIMD} SIMDs x kernel time x {SHADER_CLOCK_HZ / 1e9:.1f} GHz nominal); counters from {profile_src}"}
+    physical = traffic / kernel_s / 1e9 if traffic else None
+    streaming = w.kernel_name in ("state_rows_kernel", "bytecode_rows_kernel", "exp_rows_kernel")
+    return {
+        # what binds the dominant kernel; the HBM figures below are the roofline north_star names, reported either way
+        "bound": "hbm" if streaming else "latency+valu-issue (not hbm: see binding_resource)",
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        # physical HBM-side bytes moved per launch (PMC) over the live kernel time; falls back to the algorithmic figure,
+        # labelled, when no counter pass is committed for this configuration
+        "achieved": physical if physical is not None else algo_gbps,
+        "frac": (physical if physical is not None else algo_gbps) / HBM_PEAK_GBPS,
+        "frac_source": "pmc traffic / live kernel time" if physical is not None else "ALGORITHMIC bytes (no counter pass committed for this configuration)",
+        "traffic": traffic, "traffic_source": profile_src if traffic else None,
+        "algorithmic": {"bytes_per_launch": w.algo_bytes, "GBps": algo_gbps, "frac": algo_gbps / HBM_PEAK_GBPS,
+                        "note": "SURVEY.md §8d bytes (every looked-up row at its wire size) / kernel time: work per byte budget, "
+                                "not HBM utilisation — lookups read packed key records, so it may exceed what the memory system moves"},
+        "binding_resource": ("HBM streaming (one coalesced pass over the witness columns)" if streaming else
+                             "VALU issue + dependent-lookup latency (integer-modular path); see `valu`"),
+        "valu": valu,
+        "kernel": w.kernel_name, "kernel_ms": res.kernel_ms,
+        "rocprof_avg_kernel_ms": None if not kc or "trace" not in kc else kc["trace"]["avg_ns"] / 1e6,
+        "cold_cache": None if cold_ms is None else {
+            "kernel_ms": cold_ms, "algorithmic_GBps": w.algo_bytes / (cold_ms / 1e3) / 1e9,
+            "traffic_GBps": None if not traffic else traffic / (cold_ms / 1e3) / 1e9,
+            "note": "same kernel, each pass preceded (same stream) by a 2 GiB read-only sweep: cold L2 / Infinity Cache / page-table lines"},
+    }, profile, profile_src
+
+
+def fresh_leg(ctx, w, flush):
+    """A verifier sees each witness once.  (a) open (device-resident inputs: packed key records, density check, bytecode
+    directory, small-table indices — device kernels, no host synchronisation inside) + one pass over cold caches, wall clock
+    around both with ONE synchronisation at the end (the collect); (b) the same split into open / pass with a flush and a
+    synchronisation between them (round-2 definition, comparable); (c) the one-shot C entry (open + launch + collect + close).
+    Best of 5 each."""
+    np, torch = ctx.np, ctx.torch
+    both, opens, passes, open_dev, shots = [], [], [], [], []
+    for _ in range(5):
+        flush.sum()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        s2 = w.fresh()
+        r2 = s2.run()
+        both.append(time.perf_counter() - t)
+        assert r2.ok
+        s2.close()
+    for _ in range(5):
+        flush.sum()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = time.perf_counter()
+        e0.record()
+        s2 = w.fresh()
+        e1.record()
+        torch.cuda.synchronize()
+        t_open = time.perf_counter() - t
+        flush.sum()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r2 = s2.run()
+        t_pass = time.perf_counter() - t
+        assert r2.ok
+        s2.close()
+        opens.append(t_open)
+        passes.append(t_pass)
+        open_dev.append(e0.elapsed_time(e1))
+    if w.oneshot is not None:
+        for _ in range(5):
+            flush.sum()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r3 = w.oneshot()
+            shots.append(time.perf_counter() - t)
+            assert r3.ok
+    k = int(np.argmin([a + b for a, b in zip(opens, passes)]))
+    best = min(both)
+    return {"open_plus_pass_ms": best * 1e3, "rows_per_s": w.units / best,
+            "split": {"open_ms": opens[k] * 1e3, "open_device_span_ms": open_dev[k], "cold_pass_ms": passes[k] * 1e3,
+                      "rows_per_s": w.units / (opens[k] + passes[k])},
+            "one_shot_c_entry_ms": min(shots) * 1e3 if shots else None,
+            "one_shot_rows_per_s": w.units / min(shots) if shots else None,
+            "note": "inputs resident in HBM; caches flushed (2 GiB sweep) before every repetition; `open_plus_pass_ms` = session open (device-side "
+                    "index / packed-key / directory builds from a per-device buffer arena, no host synchronisation) + launch + collect, one wall-clock "
+                    "interval; `split` re-flushes and synchronises between open and pass (the round-2 definition); best of 5"}
 
 
 def main():
@@ -63,230 +538,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the fresh-witness (open + one cold pass) timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[1], [3], [4] after the headline (default: run them at N = 1, evm workload)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)
 
-    import numpy as np
-    import torch
+    ctx = Ctx(args)
+    np, torch, dist, rank, world = ctx.np, ctx.torch, ctx.dist, ctx.rank, ctx.world
+    from zkevm_specs_amd import _lib, distributed
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    # test hooks (single-GPU dry run of the N > 1 path): ZK_BENCH_DEVICE pins every rank to one GPU, ZK_BENCH_BACKEND=gloo
-    # replaces RCCL, which refuses two ranks on one device
-    if os.environ.get("ZK_BENCH_DEVICE") is not None:
-        local_rank = int(os.environ["ZK_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from zkevm_specs_amd import _lib, distributed, engine
-
-    log_rows = args.log_rows if args.log_rows is not None else {"evm": 18, "state": 16, "super": 20, "tx": 14}[args.workload]
-    n = 1 << log_rows
+    log_rows = args.log_rows if args.log_rows is not None else DEFAULT_LOG_ROWS[args.workload]
     strong = args.scaling == "strong" and world > 1
-    assert not (args.scaling == "strong" and args.workload not in ("evm", "state")), "--scaling strong: evm / state workloads"
-    _lib.init(local_rank)
+    _lib.init(ctx.local_rank)
     # one real (non-default) stream shared by torch and the engine: uploads, the passes and the cold leg's flush kernel are
     # ordered on it (torch's default stream is handle 0, which the engine reads as "use your own stream")
     bench_stream = torch.cuda.Stream()
     torch.cuda.set_stream(bench_stream)
     _lib.check(_lib.load().zk_set_stream(bench_stream.cuda_stream), "zk_set_stream")
 
-    def to_dev(x):
-        if x.dtype == np.uint8:
-            return torch.from_numpy(x).cuda()
-        if x.dtype.itemsize == 2:
-            return torch.from_numpy(x.view(np.int16)).cuda()
-        return torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
-
-    h2d = {"bytes": 0, "seconds": 0.0}
-
-    def upload(arrays):
-        """numpy dict -> device tensors, timed (pageable host memory, the path a ctypes caller takes)"""
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        out = {k: to_dev(v) for k, v in arrays.items()}
-        torch.cuda.synchronize()
-        h2d["seconds"] += time.perf_counter() - t
-        h2d["bytes"] += sum(int(v.nbytes) for v in arrays.values())
-        return out
-
-    def replicate(arrays, src=0):
-        """strong scaling: rank `src`'s arrays on every rank (shapes first, then one broadcast per array: RCCL over xGMI)"""
-        names = sorted(arrays) if rank == src else None
-        meta = [[(k, tuple(arrays[k].shape), str(arrays[k].dtype)) for k in names]] if rank == src else [None]
-        dist.broadcast_object_list(meta, src=src)
-        out = {}
-        for k, shape, dt in meta[0]:
-            if rank == src:
-                t = to_dev(arrays[k])
-            else:
-                tdt = torch.uint8 if dt == "uint8" else (torch.int64 if dt == "uint64" else torch.int32)
-                t = torch.empty(shape, dtype=tdt, device="cuda")
-            if t.numel():
-                dist.broadcast(t, src=src)
-            out[k] = t
-        return out
-
-    fresh = None  # (open_fn, close_fn) of the fresh-witness leg
-    row_offset = 0
-    wire_h = None
-    if args.workload == "evm":
-        from zkevm_specs_amd.synth_evm import synth_evm_trace
-
-        if strong:
-            wire_h = synth_evm_trace(n, seed=3) if rank == 0 else None
-            meta_box = [wire_h.pop("meta") if rank == 0 else None]
-            dist.broadcast_object_list(meta_box, src=0)
-            meta = meta_box[0]
-            full = replicate(wire_h if rank == 0 else {})
-            lo, hi = distributed.shard_bounds(n - 1, rank, world)
-            wire_d = dict(full, steps=full["steps"][lo: hi + 1].contiguous())
-            units, row_offset = hi - lo, lo
-            total_units = n - 1
-            algo_bytes = meta["algorithmic_bytes"] * units / (n - 1)
-        else:
-            wire_h = synth_evm_trace(n, seed=3 + rank)
-            meta = wire_h.pop("meta")
-            wire_d = upload(wire_h)
-            units, row_offset = n - 1, rank * (n - 1)
-            total_units = units * world
-            algo_bytes = meta["algorithmic_bytes"]
-        open_fn = lambda: engine.open_evm(wire_d, device=local_rank)  # noqa: E731
-        sess = open_fn()
-        fresh = open_fn
-        kernel_name, kernel_needle = "evm_steps_kernel", ("evm_steps_kernel", "-1")
-        workload = (f"EVM circuit, 2^{log_rows} execution steps {'in total' if strong else 'per GPU'}, mixed-opcode synthetic trace "
-                    f"(BASELINE configs[2]); RW table {meta['n_rw']} rows, bytecode table {meta['n_bytecode']} rows")
-        extra_cfg = {"steps_per_gpu": units + 1, "rw_rows": meta["n_rw"], "bytecode_rows": meta["n_bytecode"]}
-    elif args.workload == "tx":
-        # BASELINE configs[3]: Tx circuit over 2^log_rows signed synthetic txs per GPU; a pass = secp256k1 ECDSA verification of
-        # every signature (fills the units' ecdsa_status column in HBM) + the SignVerify / copy-constraint kernel.  The public-key
-        # hashes are keccak-256 digests built by the device table builder once per witness.
-        from zkevm_specs_amd.synth import device_keccak_digests, synth_tx_witness
-
-        r_tx = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221 + rank
-        w_tx = synth_tx_witness(n, r_tx, seed=4 + rank, signed=True, digests_of=device_keccak_digests(r_tx))
-        d_tx = upload(w_tx)
-
-        class _TxPass:
-            def __init__(self):
-                self.ecdsa = engine.open_ecdsa(d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4,
-                                               device=local_rank)
-                self.sign = engine.open_sign(d_tx, r_tx, False, device=local_rank)
-
-            def launch(self):
-                self.ecdsa.launch()
-                self.sign.launch()
-
-            def collect(self):
-                re_, rs_ = self.ecdsa.collect(), self.sign.collect()
-                rs_.ecdsa_ms = re_.kernel_ms  # a signature that does not verify fails its unit in the Tx kernel already
-                return rs_
-
-            def close(self):
-                self.ecdsa.close()
-                self.sign.close()
-
-        sess = _TxPass()
-        units, row_offset = n, rank * n
-        total_units = units * world
-        algo_bytes = n * (8 * 32 + 288 + 2 * 5 * 32)
-        kernel_name, kernel_needle = "sign_units_kernel", ("sign_units_kernel",)
-        workload = f"Tx circuit, 2^{log_rows} signed synthetic txs per GPU (BASELINE configs[3]): ECDSA verification + SignVerify kernel per pass"
-        extra_cfg = {"txs_per_gpu": n}
-    elif args.workload == "super":
-        # BASELINE configs[4]: EVM + State + Bytecode + Tx kernels over one witness set of 2^log_rows rows per GPU
-        from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
-
-        # ONE consistent witness: the State rows are the EVM trace's RW table (synth_block.py), Copy / Exp circuits included
-        parts = synth_super_block(log_rows, seed=5 + rank)
-        super_meta = parts["meta"]
-        sess = SuperCircuit(parts, device=local_rank, to_device=to_dev)
-        units, row_offset = sum(sess.rows.values()), rank * sum(sess.rows.values())
-        total_units = units * world
-        tx_bytes = 8 * 32 + 288 + 2 * 5 * 32
-        super_bytes = {"evm": super_meta["algorithmic_bytes"], "state": sess.rows["state"] * 57 * 32,
-                       "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * tx_bytes,
-                       "copy": sess.rows.get("copy", 0) * (20 + 14) * 32, "exp": sess.rows.get("exp", 0) * 21 * 32}
-        algo_bytes = None  # per-circuit, resolved after the run (dominant kernel)
-        kernel_name, kernel_needle = None, None
-        workload = (f"Super circuit, ~2^{log_rows} rows per GPU over ONE consistent witness (BASELINE configs[4]; State rows = the EVM trace's RW "
-                    "table re-keyed and re-sorted): " + ", ".join(f"{k} {v}" for k, v in sess.rows.items()) + " rows")
-        extra_cfg = {"rows_per_gpu": dict(sess.rows), "state_assign_ms": sess.assign_ms}
-    else:
-        from zkevm_specs_amd.synth import synth_state_witness
-
-        if strong:
-            host = None
-            if rank == 0:
-                cols, flags, mpt = synth_state_witness(n, seed=2)
-                host = {"cols": cols, "flags": flags, "mpt": mpt}
-            full = replicate(host if rank == 0 else {})
-            lo, hi = distributed.shard_bounds(n, rank, world)
-            idx = torch.arange(lo - 1, hi + 1, device="cuda") % n  # the rank's rows + one halo row on each side
-            d_cols, d_flags, d_mpt = full["cols"][:, idx].contiguous(), full["flags"][idx].contiguous(), full["mpt"]
-            units, row_offset, total_units = hi - lo, lo, n
-
-            def open_fn():
-                s = engine.open_state(d_cols, d_flags, d_mpt, device=local_rank)
-                s.set_range(1, 1 + units)
-                return s
-        else:
-            cols, flags, mpt = synth_state_witness(n, seed=2 + rank)
-            d = upload({"cols": cols, "flags": flags, "mpt": mpt})
-            d_cols, d_flags, d_mpt = d["cols"], d["flags"], d["mpt"]
-            units, row_offset = n, rank * n
-            total_units = units * world
-            open_fn = lambda: engine.open_state(d_cols, d_flags, d_mpt, device=local_rank)  # noqa: E731
-        sess = open_fn()
-        fresh = open_fn
-        algo_bytes = units * 57 * 32  # SURVEY.md §8(d): every witness cell counted once
-        kernel_name, kernel_needle = "state_rows_kernel", ("state_rows_kernel",)
-        workload = f"State circuit, 2^{log_rows} RW rows {'in total' if strong else 'per GPU'} (BASELINE configs[1])"
-        extra_cfg = {"rows_per_gpu": units, "mpt_rows": int(d_mpt.shape[0])}
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        sess.launch()
-    sess.collect()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sess.launch()
-    res = sess.collect()
-    barrier()
-    dt = time.perf_counter() - t0
+    w = BUILDERS[args.workload](ctx, log_rows, strong)
+    sess = w.sess
+    dt, res = timed_passes(ctx, sess, args.steps, args.warmup)
     per_circuit = None
     if args.workload == "super":
-        results, total_fail_local, first_local = res
-        per_circuit = {k: {"rows": sess.rows[k], "kernel_ms": r.kernel_ms,
-                           "algorithmic_GBps": super_bytes[k] / (r.kernel_ms / 1e3) / 1e9} for k, r in results.items()}
-        dom = max(results, key=lambda k: results[k].kernel_ms)
-        kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_kernel", "bytecode": "bytecode_rows_kernel",
-                       "tx": "sign_units_kernel", "copy": "copy_rows_kernel", "exp": "exp_rows_kernel"}[dom]
-        kernel_needle = (kernel_name,) + (("-1",) if dom == "evm" else ())
-        algo_bytes = super_bytes[dom]
-
-        class _Tally:
-            fail_count = total_fail_local
-            first_fail_row = None if first_local is None else first_local[1]
-            first_fail_code = 0 if first_local is None else first_local[2]
-            kernel_ms = results[dom].kernel_ms
-
-        res = _Tally
+        res, per_circuit = resolve_super(w, res)
 
     # Cold-cache leg (outside the timed region): the timed passes re-read the same witness, so page-table lines and part of
     # the rows are still in L2 / Infinity Cache from the previous pass.  Here every pass is preceded by a read-only sweep over
@@ -300,41 +575,13 @@ def main():
             flush.sum()
             sess.launch()
         cold_ms = sess.collect().kernel_ms
-
-    # Fresh-witness leg: a verifier sees each witness once.  open (device-resident inputs: index builds, packed key records,
-    # density check, bytecode directory) + one pass over cold caches, wall clock, 3 repetitions.
     fresh_block = None
-    if not args.no_fresh_leg and fresh is not None and flush is not None:
-        opens, passes, open_dev = [], [], []
-        for _ in range(3):
-            flush.sum()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t = time.perf_counter()
-            e0.record()
-            s2 = fresh()
-            e1.record()
-            torch.cuda.synchronize()
-            t_open = time.perf_counter() - t
-            flush.sum()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r2 = s2.run()
-            t_pass = time.perf_counter() - t
-            assert r2.ok
-            s2.close()
-            opens.append(t_open)
-            passes.append(t_pass)
-            open_dev.append(e0.elapsed_time(e1))
-        k = int(np.argmin([a + b for a, b in zip(opens, passes)]))
-        fresh_block = {"open_ms": opens[k] * 1e3, "open_device_span_ms": open_dev[k], "cold_pass_ms": passes[k] * 1e3,
-                       "rows_per_s": units / (opens[k] + passes[k]),
-                       "note": "inputs resident in HBM; open = hipMalloc + index / packed-key / directory builds (device kernels, two "
-                               "host syncs); cold pass = launch + collect after a 2 GiB flush; best of 3 (wall clock)"}
+    if not args.no_fresh_leg and w.fresh is not None and flush is not None:
+        fresh_block = fresh_leg(ctx, w, flush)
     del flush
 
     total_fail, first_row, first_code = distributed.reduce_tally(res.fail_count, res.first_fail_row, res.first_fail_code,
-                                                                 row_offset, device="cuda")
+                                                                 0 if args.workload == "super" else w.row_offset, device="cuda")
     t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -342,49 +589,8 @@ def main():
     assert total_fail == 0 and first_row is None, "synthetic witness must satisfy every constraint"
 
     if rank == 0:
-        rows_total = total_units * args.steps
-        kernel_s = res.kernel_ms / 1e3
-        algo_gbps = algo_bytes / kernel_s / 1e9
-        # HBM traffic and SQ counters come from separate rocprofv3 --pmc passes over this same command
-        # (tools/profile_bench.sh); the committed per-dispatch summary is attached when there is one for this size
-        profile, profile_src = load_profile(args.workload, log_rows)
-        kc = kernel_counters(profile, kernel_needle) if world == 1 or not strong else None
-        traffic = valu = None
-        if kc and "pmc" in kc:
-            pmc = kc["pmc"]
-            corr = FETCH_GATHER_CORRECTION if kernel_name == "evm_steps_kernel" else FETCH_STREAM_CORRECTION
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                traffic = pmc["FETCH_SIZE"]["avg_per_dispatch"] * 1024.0 * corr + pmc["WRITE_SIZE"]["avg_per_dispatch"] * 1024.0
-            if "SQ_ACTIVE_INST_VALU" in pmc:
-                # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles summed over waves (guide, PMC table): VALU-active shader
-                # cycles = 4 x counter; the chip offers N_SIMD x kernel cycles of VALU issue
-                act = pmc["SQ_ACTIVE_INST_VALU"]["avg_per_dispatch"] * 4.0
-                valu = {"insts_valu_per_launch": pmc.get("SQ_INSTS_VALU", {}).get("avg_per_dispatch"),
-                        "active_valu_cycles_per_launch": act,
-                        "wave_cycles_per_launch": pmc.get("SQ_WAVE_CYCLES", {}).get("avg_per_dispatch", 0) * 4.0,
-                        "frac_of_issue_peak": act / (kernel_s * SHADER_CLOCK_HZ * N_SIMD),
-                        "note": f"VALU-active cycles / ({N_SIMD} SIMDs x kernel time x {SHADER_CLOCK_HZ / 1e9:.1f} GHz nominal); counters from {profile_src}"}
-        physical = traffic / kernel_s / 1e9 if traffic else None
-        roofline = {
-            "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            # physical HBM-side bytes moved per launch (PMC) over the live kernel time; falls back to the algorithmic figure,
-            # labelled, when no counter pass is committed for this configuration
-            "achieved": physical if physical is not None else algo_gbps,
-            "frac": (physical if physical is not None else algo_gbps) / HBM_PEAK_GBPS,
-            "frac_source": "pmc traffic / live kernel time" if physical is not None else "ALGORITHMIC bytes (no counter pass committed for this configuration)",
-            "traffic": traffic, "traffic_source": profile_src if traffic else None,
-            "algorithmic": {"bytes_per_launch": algo_bytes, "GBps": algo_gbps, "frac": algo_gbps / HBM_PEAK_GBPS,
-                            "note": "SURVEY.md §8d bytes (every looked-up row at its wire size) / kernel time: work per byte budget, "
-                                    "not HBM utilisation — lookups read packed key records, so it may exceed what the memory system moves"},
-            "binding_resource": "VALU issue + dependent-lookup latency (integer-modular path); see `valu`",
-            "valu": valu,
-            "kernel": kernel_name, "kernel_ms": res.kernel_ms,
-            "rocprof_avg_kernel_ms": None if not kc or "trace" not in kc else kc["trace"]["avg_ns"] / 1e6,
-            "cold_cache": None if cold_ms is None else {
-                "kernel_ms": cold_ms, "algorithmic_GBps": algo_bytes / (cold_ms / 1e3) / 1e9,
-                "traffic_GBps": None if not traffic else traffic / (cold_ms / 1e3) / 1e9,
-                "note": "same kernel, each pass preceded (same stream) by a 2 GiB read-only sweep: cold L2 / Infinity Cache / page-table lines"},
-        }
+        rows_total = w.total_units * args.steps
+        roofline, profile, profile_src = roofline_block(w, res, world, strong, cold_ms)
         out = {
             "metric": "BN254 constraint-rows/sec",
             "value": rows_total / dt,
@@ -398,18 +604,19 @@ def main():
             "vs_baseline": None,
             "dtype": "u256 (BN254 Fr, 4xu64 canonical cells; u32-limb Montgomery multiply)",
             "data": "synthetic",
-            "config": dict({"workload": workload, "sharding": f"rows x{world} ({'one global witness, tables broadcast' if strong else 'independent witnesses'}), tally all-gather"},
-                           **extra_cfg),
+            "config": dict({"workload": w.workload, "sharding": f"rows x{world} ({'one global witness, tables broadcast' if strong else 'independent witnesses'}), tally all-gather"},
+                           **w.extra_cfg),
             "roofline": roofline,
         }
         if fresh_block is not None:
             out["fresh_witness"] = fresh_block
+        h2d = ctx.h2d
         if h2d["bytes"]:
             out["host_path"] = {"h2d_bytes": h2d["bytes"], "h2d_seconds": h2d["seconds"], "h2d_GBps": h2d["bytes"] / h2d["seconds"] / 1e9,
-                                "rows_per_s_including_h2d": units / (h2d["seconds"] + dt / args.steps),
+                                "rows_per_s_including_h2d": w.units / (h2d["seconds"] + dt / args.steps),
                                 "note": "pageable host arrays -> HBM (torch .cuda()); never part of `value`"}
-        if args.workload == "evm" and wire_h is not None and "host_path" in out and not args.no_cpu_baseline:
-            out["host_path"]["marshalling"] = marshalling_sample(wire_h)
+        if args.workload == "evm" and w.wire_h is not None and "host_path" in out and not args.no_cpu_baseline:
+            out["host_path"]["marshalling"] = marshalling_sample(w.wire_h)
         if per_circuit is not None:
             # per-circuit HBM-side traffic from the committed counter passes of this workload (when there are any)
             names = {"evm": ("evm_steps_kernel", "-1"), "state": ("state_rows",), "bytecode": ("bytecode_rows_kernel",), "tx": ("sign_units_kernel",),
@@ -422,24 +629,64 @@ def main():
                     v["traffic_GBps"] = v["traffic_bytes"] / (v["kernel_ms"] / 1e3) / 1e9
             out["roofline"]["per_circuit"] = per_circuit
         if args.workload == "tx":
-            out["roofline"]["ecdsa_verify_kernel_ms"] = res.ecdsa_ms
-            ke = kernel_counters(profile, ("ecdsa_verify_kernel",))
-            if ke and "pmc" in ke and "SQ_ACTIVE_INST_VALU" in ke["pmc"]:
-                act = ke["pmc"]["SQ_ACTIVE_INST_VALU"]["avg_per_dispatch"] * 4.0
-                out["roofline"]["ecdsa_valu"] = {
-                    "insts_valu_per_launch": ke["pmc"]["SQ_INSTS_VALU"]["avg_per_dispatch"], "active_valu_cycles_per_launch": act,
-                    "wavefronts": ke["pmc"].get("SQ_WAVES", {}).get("avg_per_dispatch"),
-                    "frac_of_issue_peak": act / ((res.ecdsa_ms / 1e3) * SHADER_CLOCK_HZ * N_SIMD),
-                    "note": "the pass is VALU-issue bound: one wavefront per SIMD issues one VALU instruction per ~4 cycles (half the "
-                            f"2-cycle SIMD rate, profiles/r02_valu_issue_rates.txt); counters from {profile_src}"}
-            out["roofline"]["note"] = ("the pass is dominated by ecdsa_verify_kernel (integer-ALU bound, no HBM roofline); the roofline block "
-                                       "describes the SignVerify kernel")
-        if not args.no_cpu_baseline and args.workload != "tx":
-            out["cpu_baseline"] = cpu_baseline(args.workload, units, wire_h, locals())
-        print(json.dumps(out))
+            tx_extras(out["roofline"], res, profile, profile_src)
+        if not args.no_cpu_baseline and (w.env is not None or w.wire_h is not None):
+            out["cpu_baseline"] = cpu_baseline(args.workload, w)
     sess.close()
+    del w, sess
+    if rank == 0 and world == 1 and args.workload == "evm" and args.log_rows is None and not args.no_other_configs:
+        out["other_configs"] = other_configs(ctx, args)
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def tx_extras(roof, res, profile, profile_src):
+    roof["ecdsa_verify_kernel_ms"] = res.ecdsa_ms
+    roof["sig_circuit"] = {"row_kernel_ms": res.sig_ms, "ecdsa_verify_kernel_ms": res.sig_ecdsa_ms}
+    ke = kernel_counters(profile, ("ecdsa_verify_kernel",))
+    if ke and "pmc" in ke and "SQ_ACTIVE_INST_VALU" in ke["pmc"]:
+        act = ke["pmc"]["SQ_ACTIVE_INST_VALU"]["avg_per_dispatch"] * 4.0
+        roof["ecdsa_valu"] = {
+            "insts_valu_per_launch": ke["pmc"]["SQ_INSTS_VALU"]["avg_per_dispatch"], "active_valu_cycles_per_launch": act,
+            "wavefronts": ke["pmc"].get("SQ_WAVES", {}).get("avg_per_dispatch"),
+            "frac_of_issue_peak": act / ((res.ecdsa_ms / 1e3) * SHADER_CLOCK_HZ * N_SIMD),
+            "note": "the pass is VALU-issue bound: one wavefront per SIMD issues one VALU instruction per ~4 cycles (half the "
+                    f"2-cycle SIMD rate, profiles/r02_valu_issue_rates.txt); counters from {profile_src}"}
+    roof["note"] = ("the pass is dominated by ecdsa_verify_kernel (integer-ALU bound, no HBM roofline; two launches per pass, one per "
+                    "circuit, on two streams); the roofline block describes the Tx circuit's SignVerify kernel")
+
+
+def other_configs(ctx, args):
+    """BASELINE configs[1], [3], [4] on the driver's clock, after the headline: each one timed like the headline (barrier +
+    synchronize around K passes), a reduced K so that the three add well under a minute of GPU time (witness synthesis is
+    host work outside the timed regions)."""
+    out = {}
+    for name, steps, warmup in (("state", 50, 5), ("tx", 10, 2), ("super", 20, 3)):
+        t_build = time.perf_counter()
+        w = BUILDERS[name](ctx, DEFAULT_LOG_ROWS[name], False)
+        t_build = time.perf_counter() - t_build
+        dt, res = timed_passes(ctx, w.sess, steps, warmup)
+        per_circuit = None
+        if name == "super":
+            res, per_circuit = resolve_super(w, res)
+        assert res.fail_count == 0, f"{name}: synthetic witness must satisfy every constraint"
+        roof, profile, profile_src = roofline_block(w, res, 1, False)
+        if name == "tx":
+            tx_extras(roof, res, profile, profile_src)
+        if per_circuit is not None:
+            roof["per_circuit"] = per_circuit
+        blk = {"workload": w.workload, "value": w.total_units * steps / dt, "unit": "rows/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": dt / steps * 1e3, "units_per_pass": w.total_units, "witness_build_s": t_build,
+               "roofline": roof, "config": w.extra_cfg}
+        if not args.no_cpu_baseline:
+            blk["cpu_baseline"] = cpu_baseline(name, w)
+        w.sess.close()
+        out[f"{name}_2p{DEFAULT_LOG_ROWS[name]}"] = blk
+        del w
+        ctx.torch.cuda.empty_cache()
+    return out
 
 
 def marshalling_sample(wire_h, n_steps=1 << 10):
@@ -465,7 +712,7 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
                     "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
 
 
-def cpu_baseline(workload, units, wire_h, env):
+def cpu_baseline(workload, w):
     """CPU legs on rank 0's host cores, bounded samples.  `value` is the reference's own figure when the committed
     build-container measurement exists (kind "reference"), else the oracle port's."""
     import ctypes
@@ -480,12 +727,13 @@ def cpu_baseline(workload, units, wire_h, env):
     if not os.path.exists(so):
         subprocess.check_call([os.path.join(ROOT, "tests", "hostsim", "build.sh")])
     sim = ctypes.CDLL(so)
+    vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
     legs = {}
     if workload in ("evm", "super"):
         from oracle import evm_oracle, wire
         from tests.evm_cases import hostsim_status
 
-        ev = wire_h if workload == "evm" else env["parts"]["evm"]
+        ev = w.wire_h if workload == "evm" else w.env["parts"]["evm"]
         sample = min(int(ev["steps"].shape[0]) - 1, 1 << 15)
         W = evm_oracle.EvmWitness(wire.rowmajor_to_rows(ev["steps"][: sample + 1]), wire.rowmajor_to_rows(ev["rw"]),
                                   ev["rw_flags"], wire.rowmajor_to_rows(ev["bytecode"]))
@@ -513,11 +761,57 @@ def cpu_baseline(workload, units, wire_h, env):
                                  "fit": e["fit"], "extrapolated": True,
                                  "sample": "verify_steps of the unmodified reference on 2^4 / 2^6 / 2^8-pair prefixes of this trace, build container "
                                            f"({os.path.basename(ref_file[0])}); the 2^18 figure is EXTRAPOLATED from the fit (linear-scan lookups, table.py:864-884)"}
+    elif workload == "tx":
+        from oracle import sign_oracle
+
+        tx, sg = w.env["tx"], w.env["sig"]
+        n = int(tx["bytes"].shape[0])
+        sample = min(n, 1 << 9)
+        r4 = np.frombuffer(int(0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221).to_bytes(32, "little"), dtype="<u8").copy()
+        tc = time.perf_counter()
+        for wire_, layout, is_sig in ((tx, 1, 0), (sg, 2, 1)):
+            b = np.ascontiguousarray(wire_["bytes"][:sample])
+            meta = np.ascontiguousarray(wire_["meta"][:sample]).copy()
+            est = np.zeros(sample, dtype=np.uint32)
+            v = np.ascontiguousarray(meta[:, 3])
+            sim.sim_ecdsa_verify(vp(b), ctypes.c_uint32(layout), vp(v), ctypes.c_uint32(1), ctypes.c_uint64(sample), vp(est))
+            meta[:, 0] = est
+            cells = np.ascontiguousarray(wire_["cells"][:, :sample])
+            txr = np.ascontiguousarray(wire_["tx_rows"][: 12 * sample]) if not is_sig else np.zeros((0, 5, 4), dtype=np.uint64)
+            txf = np.ascontiguousarray(wire_["tx_flags"][: 12 * sample]) if not is_sig else np.zeros(0, dtype=np.uint32)
+            st = np.zeros(sample, dtype=np.uint32)
+            kk = np.ascontiguousarray(wire_["keccak"])
+            sim.sim_sign_verify(vp(b), vp(cells), vp(meta), ctypes.c_uint64(sample), vp(kk), ctypes.c_uint64(kk.shape[0]), vp(txr), vp(txf),
+                                ctypes.c_uint64(txr.shape[0]), vp(r4), ctypes.c_uint32(is_sig), vp(st))
+            assert not st.any(), (is_sig, st[:8])
+        tc = time.perf_counter() - tc
+        legs["hostsim"] = {"value": sample / tc, "unit": "txs/s", "cores": 1,
+                           "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications, the kernels' own device functions compiled "
+                                     "for the host (tests/hostsim, g++ -O2)"}
+        from oracle import ecdsa_oracle, wire
+
+        sample_p = min(n, 1 << 5)
+        tc = time.perf_counter()
+        b = tx["bytes"][:sample_p]
+        packed = np.stack([b[:, 0], b[:, 1], b[:, 4, ::-1], b[:, 7], b[:, 8]], axis=1)  # Tx units carry msg_hash little-endian
+        meta = tx["meta"][:sample_p].copy()
+        meta[:, 0] = ecdsa_oracle.verify_packed(packed)
+        st = sign_oracle.verify_units(b, tx["cells"][:, :sample_p], meta, wire.rowmajor_to_rows(tx["keccak"]), int.from_bytes(r4.tobytes(), "little"), False,
+                                      wire.rowmajor_to_rows(tx["tx_rows"][: 12 * sample_p]), tx["tx_flags"][: 12 * sample_p])
+        tc = time.perf_counter() - tc
+        assert not any(st)
+        legs["port"] = {"value": sample_p / tc, "unit": "txs/s", "cores": 1,
+                        "sample": f"first {sample_p} txs, Tx circuit with ECDSA verification, pure-Python oracle (oracle/sign_oracle.py + oracle/ecdsa_oracle.py)"}
+        if ref and "tx" in ref:
+            t = ref["tx"]
+            legs["reference"] = {"value": t["txs_per_s"], "unit": "txs/s", "cores": 1, "extrapolated": False, "measured": t.get("measured"),
+                                 "sample": f"tx_circuit.verify_circuit + sig_circuit.verify_circuit of the unmodified reference over {t['txs']} of these txs "
+                                           f"(eth-keys stand-in: oracle/refshim), build container ({os.path.basename(ref_file[0])})"}
     else:
         from oracle import state_oracle, wire
 
-        cols, flags, mpt = env["cols"], env["flags"], env["mpt"]
-        sample = min(units, 1 << 16)
+        cols, flags, mpt = w.env["cols"], w.env["flags"], w.env["mpt"]
+        sample = min(int(cols.shape[1]), 1 << 16)
         rows_i = wire.colmajor_to_rows(cols[:, :sample])
         mpt_i = wire.rowmajor_to_rows(mpt)
         tc = time.perf_counter()
@@ -525,7 +819,6 @@ def cpu_baseline(workload, units, wire_h, env):
         tc = time.perf_counter() - tc
         legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
                         "sample": f"first {sample} rows of the same witness, pure-Python oracle (oracle/state_oracle.py)"}
-        vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
         c, f, m = np.ascontiguousarray(cols), np.ascontiguousarray(flags), np.ascontiguousarray(mpt)
         st = np.zeros(c.shape[1], dtype=np.uint32)
         tc = time.perf_counter()
@@ -538,11 +831,14 @@ def cpu_baseline(workload, units, wire_h, env):
             legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
                                  "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
                                            f"({os.path.basename(ref_file[0])})"}
-    head = legs.get("reference") or legs["port"]
-    return {"value": head["value"], "unit": "rows/s", "cores": 1, "cores_total": cores_total,
+    head = legs.get("reference") or legs.get("port") or legs["hostsim"]
+    return {"value": head["value"], "unit": head["unit"], "cores": 1,
             "kind": "reference" if "reference" in legs else "port",
             "sample": head["sample"], "legs": legs,
-            "reference_host": None if not ref else ref.get("host")}
+            "this_box_cores_total": cores_total,
+            "reference_measured_on": None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: /root/reference does not exist "
+                                                               "here, so the `reference` leg is a cross-box figure; `port` and `hostsim` are timed on this box"),
+            }
 
 
 if __name__ == "__main__":

@@ -86,6 +86,12 @@ int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n,
  * outside the range are a read-only halo (prev/next of the boundary rows).  Default: all rows,
  * neighbours wrapping modulo n as in the reference's driver. */
 int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi);
+/* The same for every row-circuit session (State, Bytecode, Copy, Exp, Tx / Sig units, PI): a rank of a row-sharded
+ * run opens its session over rows [lo, hi + halo) of the global witness (halo = the rows after the range that the
+ * range's last rows read: State 1 before + 1 after, Bytecode / Exp / PI 1 after, Copy 2 after, Tx / Sig none;
+ * SURVEY.md §8e) and evaluates [0, hi - lo) (State: [1, 1 + hi - lo)).  zk_result.rows_evaluated reports the range.
+ * EVM sessions shard by the step rows they are opened over (pairs [lo, hi) need steps [lo, hi]). */
+int zk_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi);
 /* One-shot convenience: open + launch + collect (+ copy per-row status to host) + close. */
 int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n,
                     const uint64_t* mpt, uint64_t n_mpt, uint32_t opts,

@@ -31,6 +31,34 @@ def test_strong_scaling_two_ranks_one_gpu(workload, log_rows):
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - total) < 1e-6 * total  # value = units all ranks processed / time
 
 
+def _run_plain(extra):
+    """the way the driver may start it: plain `python bench.py --gpus 2 ...`, no torchrun environment — bench.py spawns its ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZK_BENCH_DEVICE="0", ZK_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-cold-leg",
+           "--no-fresh-leg"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(line) == 1, p.stdout.decode()[-2000:]
+    return json.loads(line[0])
+
+
+@pytest.mark.parametrize("workload,log_rows,scaling", [("evm", 14, "strong"), ("state", 13, "strong"), ("tx", 8, "strong"), ("super", 14, "strong"),
+                                                      ("tx", 7, "weak")])
+def test_self_spawned_ranks(workload, log_rows, scaling):
+    d = _run_plain(["--workload", workload, "--log-rows", str(log_rows), "--scaling", scaling])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    units = d["value"] * d["ms_per_step"] / 1e3  # units all ranks processed per pass
+    if workload == "super":
+        total = sum(d["config"]["rows_total"].values())
+        # every circuit's rows are cut in two: the ranks' shares add up to the block
+        assert sum(d["config"]["rows_per_gpu"].values()) in (total // 2, (total + 1) // 2, total // 2 + 2, total // 2 + 3)
+    else:
+        total = ((1 << log_rows) - (1 if workload == "evm" else 0)) * (2 if scaling == "weak" else 1)
+    assert abs(units - total) < 1e-6 * total
+
+
 def test_weak_scaling_two_ranks_one_gpu():
     d = _run(["--workload", "evm", "--log-rows", "14"], 29761)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"

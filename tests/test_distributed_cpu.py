@@ -1,5 +1,6 @@
 """World-size-2 gloo test of the multi-GPU path's host logic: row sharding with halos, replicated
-tables, and the tally all-reduce.  Each rank evaluates its shard with the CPU logic harness
+tables, and the tally all-reduce — State (±1 halo), EVM (+1 step), Tx units (no halo, their tx-table rows travel with
+them) and Copy rows (+2 halo).  Each rank evaluates its shard with the CPU logic harness
 (hostsim) in place of the GPU; the reduced tally must equal the single-process one."""
 import ctypes
 import os
@@ -56,6 +57,62 @@ full = np.array(hostsim_status(lib, w), dtype=np.uint32)
 ff = np.nonzero(full)[0]
 assert len(ff) >= 2
 assert res == (len(ff), int(ff[0]), int(full[ff[0]])), (rank, res)
+assert np.array_equal(local, full[off:off + len(local)])
+# ---- Tx units: one global witness, no halo; the twelve fixed tx-table rows travel with their unit -------------
+from zkevm_specs_amd.synth import synth_tx_witness, synth_copy_events
+R = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
+r4 = np.frombuffer(R.to_bytes(32, "little"), dtype="<u8").copy()
+tx = synth_tx_witness(101, R, seed=21)
+tx["cells"][0, 70, 0] ^= 1            # address cell of unit 70 (rank 1)
+tx["tx_rows"][12 * 13 + 11, 3, 0] ^= 1  # TxSignHash row of unit 13 (rank 0)
+def sign_status(w):
+    n = w["bytes"].shape[0]
+    st = np.zeros(n, dtype=np.uint32)
+    a = {k: np.ascontiguousarray(v) for k, v in w.items()}
+    lib.sim_sign_verify(vp(a["bytes"]), vp(a["cells"]), vp(a["meta"]), ctypes.c_uint64(n), vp(a["keccak"]), ctypes.c_uint64(a["keccak"].shape[0]),
+                        vp(a["tx_rows"]), vp(a["tx_flags"]), ctypes.c_uint64(a["tx_rows"].shape[0]), vp(r4), ctypes.c_uint32(0), vp(st))
+    return st
+lw, off = distributed.shard_units(tx, rank, world)
+local = sign_status(lw)
+fails = np.nonzero(local)[0]
+res = distributed.reduce_tally(len(fails), int(fails[0]) if len(fails) else None, int(local[fails[0]]) if len(fails) else 0, off)
+full = sign_status(tx)
+ff = np.nonzero(full)[0]
+assert ff.tolist() == [13, 70], ff
+assert res == (2, 13, int(full[13])), (rank, res)
+assert np.array_equal(local, full[off:off + len(local)])
+
+# ---- Copy circuit: rows sharded with a 2-row halo (copy_circuit.py:92-130 reads rows i + 1 and i + 2) ------
+ce = synth_copy_events(600, seed=22)
+n_rows = int(ce["n_rows"])
+evl = [[int(c[0]) for c in e] for e in ce["events"]]  # every event cell of the generator fits 64 bits
+n_real = lambda e: max(0, min(e[9], e[7] - e[6]))
+n_rw = sum((n_real(e) if e[2] == 2 else 0) + (e[9] if e[5] in (2, 4) else 0) for e in evl)
+rows = np.zeros((20, n_rows, 4), dtype=np.uint64); rf = np.zeros(n_rows, dtype=np.uint32)
+table = np.zeros((len(evl), 14, 4), dtype=np.uint64)
+rw = np.zeros((max(n_rw, 1), 14, 4), dtype=np.uint64); rwf = np.zeros(max(n_rw, 1), dtype=np.uint32)
+rc4 = np.frombuffer(int(ce["r"]).to_bytes(32, "little"), dtype="<u8").copy()
+ev, fl, da, of = (np.ascontiguousarray(ce[k]) for k in ("events", "flags", "data", "offsets"))
+assert lib.sim_copy_assign(vp(ev), vp(fl), ctypes.c_uint64(ev.shape[0]), vp(da), vp(of), vp(rc4), vp(rows), vp(rf), vp(table), vp(rw), vp(rwf),
+                           ctypes.c_uint64(n_rows)) == 0
+half = n_rows // 2
+rows[9, half - 1, 0] ^= 1   # a cell of the last row of rank 0's range
+rows[9, half + 1, 0] ^= 1   # ... and of a halo row of rank 0 = row 1 of rank 1's range
+def copy_status(c, f):
+    st = np.zeros(c.shape[1], dtype=np.uint32)
+    bc, txr, txf = (np.ascontiguousarray(ce[k]) for k in ("bytecode", "tx", "tx_flags"))
+    lib.sim_copy_verify(vp(c), vp(f), ctypes.c_uint64(c.shape[1]), vp(rc4), vp(rw), vp(rwf), ctypes.c_uint64(n_rw), vp(bc), ctypes.c_uint64(bc.shape[0]),
+                        vp(txr), vp(txf), ctypes.c_uint64(txr.shape[0]), ctypes.c_uint32(0), vp(st))
+    return st
+lc, lf, elo, ehi, off = distributed.shard_rows(rows, rf, rank, world, "copy")
+assert lc.shape[1] == (ehi - elo) + 2 and elo == 0
+local = copy_status(lc, lf)[elo:ehi]
+fails = np.nonzero(local)[0]
+res = distributed.reduce_tally(len(fails), int(fails[0]) if len(fails) else None, int(local[fails[0]]) if len(fails) else 0, off)
+full = copy_status(rows, rf)
+ff = np.nonzero(full)[0]
+assert len(ff) >= 2 and ff[0] < half <= ff[-1], ff
+assert res == (len(ff), int(ff[0]), int(full[ff[0]])), (rank, res, ff)
 assert np.array_equal(local, full[off:off + len(local)])
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -15,6 +15,8 @@ What is timed, single process, one core (the r
   * State circuit: `check_state_row` over all 2^16 rows of bench.py's config-2 witness (state_circuit.py:492).
   * Bytecode circuit: `check_bytecode_row` over config 1 (256-byte contract, k = 9).
   * Exp circuit: `verify_exp_circuit` over 2^12 rows.
+  * Tx + Sig circuits (round 3): `tx_circuit.verify_circuit` + `sig_circuit.verify_circuit` over 2^6 / 2^8 / 2^10 signed legacy txs.
+ZK_TIME_ONLY=tx,bytecode,... selects sections; ZK_TIME_MERGE=<earlier json> carries the other sections over (marked).
 """
 import json
 import os
@@ -151,16 +153,79 @@ def time_exp():
     return {"rows": len(rows), "seconds": dt, "rows_per_s": len(rows) / dt}
 
 
+def time_tx_sig():
+    """BASELINE configs[3] at the sizes the pure-Python reference finishes: N signed legacy transactions built like the reference's
+    own tests (tests/test_tx_circuit.py:103-114 gen_tx / sign_tx; keys sk_i = SHA-256(i) mod n), then
+    `tx_circuit.verify_circuit` (tx_circuit.py:253-291) and `sig_circuit.verify_circuit` (sig_circuit.py:113-122) over them.
+    secp256k1 / keccak / rlp are the oracle/refshim stand-ins (eth-keys 0.4.0's native backend restated), so the ECDSA share
+    is pure Python exactly as with the real eth-keys native backend."""
+    import hashlib
+
+    import rlp
+    from eth_keys import KeyAPI, keys
+    from eth_utils import keccak
+    from zkevm_specs import sig_circuit, tx_circuit
+    from zkevm_specs.tx_circuit import Transaction, txs2witness
+    from zkevm_specs.util import FQ, KeccakTable, Word
+    from zkevm_specs.util.ec import ECDSAVerifyChip
+
+    SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    chain_id = 1337
+    r = FQ(0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221)
+    pts = []
+    for log_n in (6, 8, 10):
+        n = 1 << log_n
+        sks = [keys.PrivateKey((int.from_bytes(hashlib.sha256(i.to_bytes(4, "big")).digest(), "big") % (SECP_N - 1) + 1).to_bytes(32, "big"))
+               for i in range(n)]
+        txs, signed = [], []
+        for i, sk in enumerate(sks):
+            to = int.from_bytes(sks[(i + 1) % n].public_key.to_canonical_address(), "big")
+            data = bytes([i % 256]) * (i % 64)
+            tx = Transaction(300 + i, 1000 + 2 * i, 20000 + 3 * i, to, 0x30000 + 4 * i, data, 0, 0, 0)
+            sign_data = rlp.encode([tx.nonce, tx.gas_price, tx.gas, tx.encode_to(), tx.value, tx.data, chain_id, 0, 0])
+            h = keccak(sign_data)
+            sig = sk.sign_msg_hash(h)
+            txs.append(Transaction(tx.nonce, tx.gas_price, tx.gas, tx.to, tx.value, tx.data, sig.v + chain_id * 2 + 35, sig.r, sig.s))
+            signed.append((h, sig, sk.public_key))
+        max_calldata = sum(len(t.data) for t in txs) + 16
+        witness = txs2witness(txs, chain_id, n, max_calldata, r)
+        t0 = time.perf_counter()
+        tx_circuit.verify_circuit(witness, n, max_calldata, r)
+        t_tx = time.perf_counter() - t0
+        rows, kt = [], KeccakTable()
+        for h, sig, pk in signed:
+            chip = ECDSAVerifyChip.assign(KeyAPI.Signature(vrs=(sig.v, sig.r, sig.s)), pk, h)
+            kt.add(pk.to_bytes(), r)
+            ph = keccak(pk.to_bytes())
+            rows.append(sig_circuit.Row(ph, FQ(int.from_bytes(ph[-20:], "big")), Word(h), chip))
+        t0 = time.perf_counter()
+        sig_circuit.verify_circuit(sig_circuit.Witness(rows, kt), r)
+        t_sig = time.perf_counter() - t0
+        pts.append({"txs": n, "tx_circuit_seconds": t_tx, "sig_circuit_seconds": t_sig, "txs_per_s": n / (t_tx + t_sig),
+                    "tx_rows": len(witness.rows), "calldata_bytes": max_calldata})
+        print(f"tx+sig 2^{log_n}: {t_tx:.2f} + {t_sig:.2f} s", file=sys.stderr, flush=True)
+    last = pts[-1]
+    return {"txs": last["txs"], "txs_per_s": last["txs_per_s"], "measured": pts,
+            "note": "Tx circuit + Sig circuit over the same signed txs; per-tx cost is flat in N (no table scans), so the largest measured size "
+                    "is the figure (not extrapolated)"}
+
+
 def main():
     import platform
 
     out = {"what": "the unmodified reference (/root/reference, tag 2024_08_07) on oracle/refshim dependency stand-ins, pure Python, 1 process / 1 core",
            "host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
                     "cores_total": os.cpu_count(), "cores_used": 1, "python": platform.python_version()}}
-    out["bytecode"] = time_bytecode()
-    out["exp"] = time_exp()
-    out["state"] = time_state()
-    out["evm"] = time_evm()
+    only = set(os.environ.get("ZK_TIME_ONLY", "bytecode,exp,tx,state,evm").split(","))
+    prev = os.environ.get("ZK_TIME_MERGE")  # an earlier result file: sections not re-timed are carried over, marked with their origin
+    if prev:
+        old = json.load(open(prev))
+        for k in ("bytecode", "exp", "state", "evm", "tx"):
+            if k in old and k not in only:
+                out[k] = dict(old[k], carried_over_from=os.path.basename(prev))
+    for k, fn in (("bytecode", time_bytecode), ("exp", time_exp), ("tx", time_tx_sig), ("state", time_state), ("evm", time_evm)):
+        if k in only:
+            out[k] = fn()
     print(json.dumps(out, indent=1))
 
 

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("ZK_HIP_LIB") or os.path.join(_HERE, "libzkevm_hip.so"
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
+    "zk_state_open", "zk_state_set_range", "zk_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
     "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close",
 ]
 
@@ -112,6 +112,7 @@ def load():
     lib.zk_fr_op.argtypes = [ctypes.c_int, vp, vp, vp, u64, u32]
     lib.zk_state_open.argtypes = [vp, vp, u64, vp, u64, u32, ctypes.POINTER(vp)]
     lib.zk_state_set_range.argtypes = [vp, u64, u64]
+    lib.zk_set_range.argtypes = [vp, u64, u64]
     lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_evm_open.argtypes = [ctypes.POINTER(ZkEvmTables), u32, ctypes.POINTER(vp)]
     lib.zk_evm_verify.argtypes = [ctypes.POINTER(ZkEvmTables), u32, vp, ctypes.POINTER(ZkResult)]

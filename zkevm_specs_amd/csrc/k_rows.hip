@@ -11,21 +11,21 @@ __global__ void fr_to_mont_kernel(Fr x, u64* out) {  // one cell to Montgomery f
         for (int j = 0; j < 4; j++) out[j] = (u64)m.v[2 * j] | ((u64)m.v[2 * j + 1] << 32);
     }
 }
-__global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.rows.n) {
+    if (i < hi) {
         code = bytecode_check_row(a, i);
         if (status) status[i] = code;
     }
     tally_commit(tally, i, code);
 }
-__global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.rows.n) {
+    if (i < hi) {
         code = copy_check_row(a, i);
         if (status) status[i] = code;
     }
@@ -35,52 +35,52 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u32* status,
 __global__ void sign_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) sign_fill_rpow(r, out);
 }
-__global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.cells.n) {
+    if (i < hi) {
         code = sign_check_unit(a, i);
         if (status) status[i] = code;
     }
     tally_commit(tally, i, code);
 }
-__global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256) void exp_rows_kernel(ExpArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.rows.n) {
+    if (i < hi) {
         code = exp_check_row(a, i);
         if (status) status[i] = code;
     }
     tally_commit(tally, i, code);
 }
 
-__global__ __launch_bounds__(256) void pi_rows_kernel(PiArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256) void pi_rows_kernel(PiArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
-    if (i < a.rows.n) {
+    if (i < hi) {
         code = pi_check_row(a, i);
         if (status) status[i] = code;
     }
     tally_commit(tally, i, code);
 }
 static inline u32 grid256(u64 n) { return (u32)((n + 255) / 256); }
-void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
+void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
-void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
+void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
-void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(sign_units_kernel, dim3(grid256(a.cells.n)), dim3(256), 0, st, a, status, tally);
+void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(sign_units_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
-void zk_launch_exp_rows(hipStream_t st, const ExpArgs& a, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(exp_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
+void zk_launch_exp_rows(hipStream_t st, const ExpArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(exp_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
-void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(pi_rows_kernel, dim3(grid256(a.rows.n)), dim3(256), 0, st, a, status, tally);
+void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(pi_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
 void zk_launch_fr_to_mont(hipStream_t st, const Fr& x, u64* out) { hipLaunchKernelGGL(fr_to_mont_kernel, dim3(1), dim3(64), 0, st, x, out); }
 void zk_launch_sign_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(sign_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }

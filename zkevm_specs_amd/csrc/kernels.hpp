@@ -46,10 +46,10 @@ void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTal
 // hot: e0 rides on the dispatch as its start event; cold: e1 as its stop event (either may be null)
 void zk_launch_evm_hot(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e0);
 void zk_launch_evm_cold(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1);
-void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u32* status, ZkTally* tally);
-void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u32* status, ZkTally* tally);
-void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u32* status, ZkTally* tally);
-void zk_launch_exp_rows(hipStream_t st, const ExpArgs& a, u32* status, ZkTally* tally);
+void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
+void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
+void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
+void zk_launch_exp_rows(hipStream_t st, const ExpArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
 void zk_launch_fr_to_mont(hipStream_t st, const Fr& x, u64* out);
 void zk_launch_sign_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out);
@@ -57,7 +57,7 @@ void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status,
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally);
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally);
-void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u32* status, ZkTally* tally);
+void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
 void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally);

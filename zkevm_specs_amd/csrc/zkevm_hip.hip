@@ -227,6 +227,7 @@ struct zk_session {
     int device = t_device;            // captured at open: the session is its own context from here on
     hipStream_t stream = t_stream;
     u64 n = 0;                      // rows per pass
+    u64 eval_lo = 0, eval_hi = 0;   // row sessions: rows [eval_lo, eval_hi) are evaluated (zk_set_range); 0, 0 = all n
     std::vector<void*> owned;       // device allocations to free at close
     ZkTally* d_tally = nullptr;
     u32* d_status = nullptr;        // internal per-row status (zeroed at open; what zk_read_status copies)
@@ -1331,13 +1332,26 @@ extern "C" int zk_exp_verify(const uint64_t* rows, uint64_t n, uint32_t opts, ui
     return one_shot(s, opts & ZK_OPT_DEVICE_PTRS, status_out, result);
 }
 
-extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
-    ARG_TRY(s && s->kind == SESSION_STATE, "zk_state_set_range: not a State session");
-    ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_state_set_range: bad range");
-    s->state.eval_lo = row_lo;
-    s->state.eval_hi = row_hi;
+static inline u64 range_lo(const zk_session* s) { return s->eval_hi ? s->eval_lo : 0; }
+static inline u64 range_hi(const zk_session* s) { return s->eval_hi ? s->eval_hi : s->n; }
+extern "C" int zk_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
+    ARG_TRY(s && (s->kind == SESSION_STATE || s->kind == SESSION_BYTECODE || s->kind == SESSION_COPY || s->kind == SESSION_EXP ||
+                  s->kind == SESSION_SIGN || s->kind == SESSION_PI),
+            "zk_set_range: not a row-circuit session (EVM sessions shard by the steps they are opened over)");
+    ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_set_range: bad range");
+    HIP_TRY(hipSetDevice(s->device));
+    s->eval_lo = row_lo;
+    s->eval_hi = row_hi;
+    if (s->kind == SESSION_STATE) {
+        s->state.eval_lo = row_lo;
+        s->state.eval_hi = row_hi;
+    }
     HIP_TRY(hipMemsetAsync(s->d_status, 0, (size_t)s->n * sizeof(u32), s->stream));
     return 0;
+}
+extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
+    ARG_TRY(s && s->kind == SESSION_STATE, "zk_state_set_range: not a State session");
+    return zk_set_range(s, row_lo, row_hi);
 }
 
 // tuning aid (not part of the public ABI): copy the phase timestamps of the last pass
@@ -1415,15 +1429,15 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, s->stream));
     switch (s->kind) {
     case SESSION_STATE: zk_launch_state_rows(s->stream, s->state, status, tally); break;
-    case SESSION_BYTECODE: zk_launch_bytecode_rows(s->stream, s->bytecode, status, tally); break;
-    case SESSION_COPY: zk_launch_copy_rows(s->stream, s->copy, status, tally); break;
-    case SESSION_SIGN: zk_launch_sign_units(s->stream, s->sign, status, tally); break;
-    case SESSION_EXP: zk_launch_exp_rows(s->stream, s->exp, status, tally); break;
+    case SESSION_BYTECODE: zk_launch_bytecode_rows(s->stream, s->bytecode, range_lo(s), range_hi(s), status, tally); break;
+    case SESSION_COPY: zk_launch_copy_rows(s->stream, s->copy, range_lo(s), range_hi(s), status, tally); break;
+    case SESSION_SIGN: zk_launch_sign_units(s->stream, s->sign, range_lo(s), range_hi(s), status, tally); break;
+    case SESSION_EXP: zk_launch_exp_rows(s->stream, s->exp, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_KECCAK: zk_launch_keccak_table(s->stream, s->keccak_gen, status, s->d_tally); break;
     case SESSION_ASSIGN: zk_launch_state_assign(s->stream, s->assign, status, s->d_tally); break;
     case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
     case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
-    case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, status, tally); break;
+    case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
@@ -1463,7 +1477,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     r->first_fail_row = t.first_fail == ~0ull ? UINT64_MAX : (t.first_fail >> 32);
     r->first_fail_code = t.first_fail == ~0ull ? 0u : (u32)(t.first_fail & 0xffffffffull);
     r->launches = s->launches;
-    r->rows_evaluated = s->kind == SESSION_STATE ? s->state.eval_hi - s->state.eval_lo : s->n;
+    r->rows_evaluated = range_hi(s) - range_lo(s);
     r->kernel_ms = timed ? ms / timed : 0.0;
     s->launches = 0;
     return 0;

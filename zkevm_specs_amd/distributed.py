@@ -19,10 +19,51 @@ def shard_bounds(n, rank, world):
 def shard_state(cols, flags, rank, world):
     """State witness shard: rows [lo-1, hi] (mod n) of the column-major table, i.e. the rank's rows
     plus one halo row on each side.  Returns (cols_local, flags_local, eval_lo, eval_hi, lo)."""
-    n = cols.shape[1]
+    return shard_rows(cols, flags, rank, world, "state")
+
+
+HALO = {"state": (1, 1), "bytecode": (0, 1), "exp": (0, 1), "pi": (0, 1), "copy": (0, 2), "tx": (0, 0), "sig": (0, 0)}
+"""rows before / after a rank's range that its boundary rows read (SURVEY.md §8e; the neighbours wrap modulo n:
+state_circuit.py:492 prev / next, bytecode_circuit.py:37 next, exp_circuit.py:88-97 next, copy_circuit.py:92-130
+rows i + 1 and i + 2, tx_circuit.py:253-291 none)"""
+
+
+def _take(a, idx, axis):
+    """rows `idx` along `axis` of a numpy array or a torch tensor (device tensors are gathered on the device)"""
+    if hasattr(a, "is_cuda"):
+        import torch
+
+        return a.index_select(axis, torch.as_tensor(idx, device=a.device)).contiguous()
+    return np.ascontiguousarray(np.take(a, idx, axis=axis))
+
+
+def shard_rows(cols, flags, rank, world, circuit):
+    """Row shard of a column-major circuit witness cols[c, n, 4] (+ optional flags[n]): the rank's rows [lo, hi) with the
+    circuit's halo (HALO) on either side, modulo n.  Returns (cols_local, flags_local, eval_lo, eval_hi, lo): the
+    session over the local rows evaluates [eval_lo, eval_hi) (Session.set_range) and its row i is global row
+    lo + i - eval_lo."""
+    n = int(cols.shape[1])
+    before, after = HALO[circuit]
     lo, hi = shard_bounds(n, rank, world)
-    idx = np.arange(lo - 1, hi + 1) % n
-    return np.ascontiguousarray(cols[:, idx]), np.ascontiguousarray(flags[idx]), 1, 1 + (hi - lo), lo
+    idx = np.arange(lo - before, hi + after) % n
+    return _take(cols, idx, 1), (None if flags is None else _take(flags, idx, 0)), before, before + (hi - lo), lo
+
+
+def shard_units(wire, rank, world):
+    """Tx / Sig units shard (no halo: units are independent, tx_circuit.py:253-291): bytes[n, 9, 32], cells[8, n, 4],
+    meta[n, 4] and the units' twelve fixed tx-table rows are cut to the rank's units, the keccak table stays whole (replicated).  Returns (wire_local, lo)."""
+    n = int(wire["bytes"].shape[0])
+    lo, hi = shard_bounds(n, rank, world)
+    idx = np.arange(lo, hi)
+    local = dict(wire)
+    local["bytes"], local["cells"], local["meta"] = _take(wire["bytes"], idx, 0), _take(wire["cells"], idx, 1), _take(wire["meta"], idx, 0)
+    # the Tx circuit reads unit i's CallerAddress / TxSignHash rows at tx_rows[12 i + 3], [12 i + 11] (tx_circuit.py:270-289): the
+    # twelve fixed rows of a tx belong to its unit and travel with it
+    if wire.get("tx_rows") is not None and int(wire["tx_rows"].shape[0]) > 0:
+        assert int(wire["tx_rows"].shape[0]) >= 12 * n, "tx_rows: twelve fixed rows per unit expected"
+        ridx = np.arange(12 * lo, 12 * hi)
+        local["tx_rows"], local["tx_flags"] = _take(wire["tx_rows"], ridx, 0), _take(wire["tx_flags"], ridx, 0)
+    return local, lo
 
 
 def shard_evm(wire, rank, world, begin_with_first_step=False, end_with_last_step=False):
@@ -31,10 +72,10 @@ def shard_evm(wire, rank, world, begin_with_first_step=False, end_with_last_step
     n_pairs = wire["steps"].shape[0] - 1
     lo, hi = shard_bounds(n_pairs, rank, world)
     local = dict(wire)
-    local["steps"] = np.ascontiguousarray(wire["steps"][lo : hi + 1])
+    local["steps"] = _take(wire["steps"], np.arange(lo, hi + 1), 0)
     for k in ("aux", "aux_kind"):  # per-step side data travels with the step rows
         if wire.get(k) is not None:
-            local[k] = np.ascontiguousarray(wire[k][lo : hi + 1])
+            local[k] = _take(wire[k], np.arange(lo, hi + 1), 0)
     return local, bool(begin_with_first_step and rank == 0), bool(end_with_last_step and rank == world - 1), lo
 
 

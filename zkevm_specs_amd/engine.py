@@ -65,8 +65,8 @@ class Session:
         check(_lib.load().zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream")
 
     def set_range(self, row_lo, row_hi):
-        """State sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
-        check(_lib.load().zk_state_set_range(self._h, int(row_lo), int(row_hi)), "zk_state_set_range")
+        """Row-circuit sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
+        check(_lib.load().zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range")
 
     def read_status(self):
         out = np.empty(self.n, dtype=np.uint32)
@@ -161,13 +161,8 @@ def open_state(rows, flags, mpt, device=None):
     return Session(h, n, (rows, flags, mpt))
 
 
-def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
-             generic_index=False):
-    """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
-    and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4], sig uint64[m, 9, 4], ecc uint64[m, 13, 4],
-    aux uint64[n, 2 or 12, 4] + aux_kind, withdrawals uint64[m, 4, 4]
-    (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
-    lib = _lib.init(device)
+def _evm_tables(wire, begin_with_first_step, end_with_last_step):
+    """wire dict -> (ZkEvmTables, opts, kept arrays); host arrays are made contiguous, device tensors are used in place"""
     names = ["steps", "rw", "rw_flags", "bytecode", "tx", "tx_flags", "block", "block_flags", "copy", "keccak", "exp", "aux",
              "aux_kind", "withdrawals", "sig", "ecc"]
     cells = {"steps": 13, "rw": 14, "bytecode": 6, "tx": 5, "block": 4, "copy": 14, "keccak": 5, "exp": 11, "withdrawals": 4,
@@ -202,13 +197,36 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         p(a["sig"]) if rows(a["sig"]) else None, rows(a["sig"]),
         p(a["ecc"]) if rows(a["ecc"]) else None, rows(a["ecc"]),
         int(a["aux"].shape[1]) if rows(a["aux"]) else 0, 0)
+    return t, opts, arrs, int(a["steps"].shape[0]) - 1
+
+
+def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
+             generic_index=False):
+    """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
+    and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4], sig uint64[m, 9, 4], ecc uint64[m, 13, 4],
+    aux uint64[n, 2 or 12, 4] + aux_kind, withdrawals uint64[m, 4, 4]
+    (numpy arrays or torch CUDA tensors) -> Session over the n-1 step pairs."""
+    lib = _lib.init(device)
+    t, opts, arrs, n_pairs = _evm_tables(wire, begin_with_first_step, end_with_last_step)
     if not state_sort:
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:
         opts |= _lib.OPT_GENERIC_INDEX
     h = ctypes.c_void_p()
     check(lib.zk_evm_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_evm_open")
-    return Session(h, int(a["steps"].shape[0]) - 1, arrs)
+    return Session(h, n_pairs, arrs)
+
+
+def evm_verify(wire, begin_with_first_step=False, end_with_last_step=False, status_dev=None, device=None):
+    """The one-shot C entry zk_evm_verify (open + one pass + collect + close) over a wire dict of host arrays or of torch
+    CUDA tensors (then status_dev, an optional CUDA uint32[n - 1] tensor, receives the per-pair status) -> Result."""
+    lib = _lib.init(device)
+    t, opts, arrs, n_pairs = _evm_tables(wire, begin_with_first_step, end_with_last_step)
+    if status_dev is not None:
+        _expect(status_dev, "status_dev", 4, (n_pairs,))
+    r = ZkResult()
+    check(lib.zk_evm_verify(ctypes.byref(t), opts, _lib.ptr(status_dev), ctypes.byref(r)), "zk_evm_verify")
+    return Result(r)
 
 
 def open_bytecode(rows, keccak, randomness, device=None):

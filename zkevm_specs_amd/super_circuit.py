@@ -19,6 +19,7 @@ The Copy and Exp circuits have no rows here: BASELINE config 3's opcode mix cont
 import numpy as np
 
 from . import engine
+from .errors import exception_for_code
 from .synth import synth_bytecode_witness, synth_state_ops, synth_tx_witness
 from .synth_evm import synth_evm_codes, synth_evm_trace
 
@@ -122,12 +123,26 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True)}
 
 
+def _on_device(x):
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
 class SuperCircuit:
     """Sessions of the four circuits over one witness set; launch() enqueues one pass of each, collect() returns
     ({circuit: Result}, total fail_count, first failing (circuit, row, code))."""
 
-    def __init__(self, parts, device=None, to_device=None):
-        dev = to_device if to_device is not None else (lambda x: x)
+    def __init__(self, parts, device=None, to_device=None, shard=None):
+        """shard = (rank, world): ONE global block, every circuit's rows cut into `world` contiguous ranges with that
+        circuit's halo (distributed.HALO), all tables whole on every rank (BASELINE configs[4]).  The
+        witness assignment (State / Bytecode / Copy rows from ops / unrolled codes / copy events) runs over the whole
+        block on every rank — it is open-time work, tables and op lists being replicated anyway — and the rank keeps its
+        slice.  self.rows then holds the rank's evaluated rows, self.global_rows the block's, self.row_lo each circuit's
+        first global row."""
+        from . import distributed
+
+        to_dev_fn = to_device if to_device is not None else (lambda x: x)
+        dev = lambda x: x if (_on_device(x) or x is None) else to_dev_fn(x)  # noqa: E731  (replicated tensors arrive on the device)
+        rank, world = shard if shard is not None else (0, 1)
         self._keep = []
         ops, op_flags = (dev(a) for a in parts["state_ops"])
         # State rows: assigned on the device from the op list, then evaluated from the same HBM buffers
@@ -146,7 +161,8 @@ class SuperCircuit:
             with engine.open_state_assign(ops, op_flags, device=device) as a:
                 res = a.run()
                 rows, flags, mpt = a.read()
-        assert res.ok, f"state witness assignment failed: {res}"
+        if not res.ok:
+            raise exception_for_code(res.first_fail_code, f"state witness assignment: op {res.first_fail_row}")
         self.assign_ms = res.kernel_ms
         _, bc_keccak, r = parts["bytecode"]
         # Bytecode circuit rows: assigned on the device from the EVM circuit's own bytecode table
@@ -162,14 +178,28 @@ class SuperCircuit:
             with engine.open_bytecode_assign(d_ub, ub_off, ub_len, k, r, device=device) as a:
                 res = a.run()
                 bc_rows = a.rows()
-        assert res.ok
+        if not res.ok:
+            raise exception_for_code(res.first_fail_code, f"bytecode witness assignment: row {res.first_fail_row}")
         dev_rows = bc_rows
         tx, r_tx = parts["tx"]
+        evm_w = {k: dev(v) for k, v in parts["evm"].items()}
+        tx_w = {k: dev(v) for k, v in tx.items()}
+        self.global_rows = {"evm": int(evm_w["steps"].shape[0]) - 1, "state": int(rows.shape[1]), "bytecode": int(dev_rows.shape[1]),
+                            "tx": int(tx_w["bytes"].shape[0])}
+        self.row_lo = {k: 0 for k in self.global_rows}
+        ranges = {}
+        if world > 1:
+            evm_w, _, _, self.row_lo["evm"] = distributed.shard_evm(evm_w, rank, world)
+            rows, flags, lo_, hi_, self.row_lo["state"] = distributed.shard_rows(rows, flags, rank, world, "state")
+            ranges["state"] = (lo_, hi_)
+            dev_rows, _, lo_, hi_, self.row_lo["bytecode"] = distributed.shard_rows(dev_rows, None, rank, world, "bytecode")
+            ranges["bytecode"] = (lo_, hi_)
+            tx_w, self.row_lo["tx"] = distributed.shard_units(tx_w, rank, world)
         self.sessions = {
-            "evm": engine.open_evm({k: dev(v) for k, v in parts["evm"].items()}, device=device),
+            "evm": engine.open_evm(evm_w, device=device),
             "state": engine.open_state(rows, flags, mpt, device=device),
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
-            "tx": engine.open_sign({k: dev(v) for k, v in tx.items()}, r_tx, False, device=device),
+            "tx": engine.open_sign(tx_w, r_tx, False, device=device),
         }
         # Copy circuit: events expanded on the device (rows + their RW rows), then evaluated from the same HBM buffers
         if "copy_events" in parts:
@@ -184,16 +214,32 @@ class SuperCircuit:
                 c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=ops.device)
                 c_rwf = torch.empty(n_rw, dtype=torch.int32, device=ops.device)
                 with engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, None, c_rw, c_rwf, device=device) as a:
-                    assert a.run().ok
+                    res = a.run()
+                if not res.ok:
+                    raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
             else:
                 with engine.open_copy_assign(ce["events"], ce["flags"], ce["data"], ce["offsets"], ce["r"], device=device) as a:
-                    assert a.run().ok
+                    res = a.run()
+                    if not res.ok:
+                        raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
                     c_rows, c_rf, _, c_rw, c_rwf = a.read()
+            self.global_rows["copy"], self.row_lo["copy"] = int(c_rows.shape[1]), 0
+            if world > 1:
+                c_rows, c_rf, lo_, hi_, self.row_lo["copy"] = distributed.shard_rows(c_rows, c_rf, rank, world, "copy")
+                ranges["copy"] = (lo_, hi_)
             self.sessions["copy"] = engine.open_copy(c_rows, c_rf, ce["r"], c_rw, c_rwf, dev(ce["bytecode"]), dev(ce["tx"]), dev(ce["tx_flags"]),
                                                      device=device)
         if "exp_rows" in parts:
-            self.sessions["exp"] = engine.open_exp(dev(parts["exp_rows"]), device=device)
-        self.rows = {k: s.n for k, s in self.sessions.items()}
+            e_rows = dev(parts["exp_rows"])
+            self.global_rows["exp"], self.row_lo["exp"] = int(e_rows.shape[1]), 0
+            if world > 1:
+                e_rows, _, lo_, hi_, self.row_lo["exp"] = distributed.shard_rows(e_rows, None, rank, world, "exp")
+                ranges["exp"] = (lo_, hi_)
+            self.sessions["exp"] = engine.open_exp(e_rows, device=device)
+        for k, (lo_, hi_) in ranges.items():
+            self.sessions[k].set_range(lo_, hi_)
+        self.rows = {k: (ranges[k][1] - ranges[k][0] if k in ranges else s.n) for k, s in self.sessions.items()}
+        self.eval_lo = {k: ranges.get(k, (0, 0))[0] for k in self.sessions}
         # one HIP stream per circuit: the kernels are independent and bound by different things (the State kernel streams
         # HBM, the EVM kernel is latency / issue bound), so their passes overlap on the device
         self._streams = None
@@ -212,7 +258,8 @@ class SuperCircuit:
     def collect(self):
         results = {k: s.collect() for k, s in self.sessions.items()}
         total = sum(r.fail_count for r in results.values())
-        first = next(((k, r.first_fail_row, r.first_fail_code) for k, r in results.items() if not r.ok), None)
+        # first failure: (circuit, row of the GLOBAL block, code) — a sharded session reports rows of its local slice
+        first = next(((k, r.first_fail_row - self.eval_lo[k] + self.row_lo[k], r.first_fail_code) for k, r in results.items() if not r.ok), None)
         return results, total, first
 
     def close(self):

@@ -520,6 +520,42 @@ def synth_tx_witness(n_txs, r, seed=4, padding=0, signed=False, digests_of=None)
     }
 
 
+def synth_sig_witness(n, r, seed=4, digests_of=None):
+    """The Sig circuit's rows (sig_circuit.py:7-62) for the SAME n signatures synth_tx_witness(signed=True, seed) signs: the
+    chip's byte strings (public key little-endian, msg_hash_bytes = to_be_bytes() of the hash, util/ec.py:86-88; (r, s)
+    little-endian), the table cells (recovered_addr = low 20 bytes of keccak(pk), msg_hash = Word(msg_hash_bytes), sig_v,
+    sig_r / sig_s as lo / hi) and meta = (ecdsa_status PENDING for the device ECDSA pass, is_valid = 1, 0, the chip's v).
+    v = 0 throughout: ECDSAVerifyChip.verify (util/ec.py:109-117) hands it to KeyAPI.Signature, which only checks v in {0, 1}.
+    digests_of: as in synth_tx_witness (default: a synthetic digest — the circuit checks keccak-table membership)."""
+    import hashlib
+
+    from .wire import rows_to_colmajor, rows_to_rowmajor
+
+    sigs = synth_signatures(n + 1, seed)[:n]
+    real = digests_of([q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big") for q in sigs]) if digests_of is not None else None
+    bts, cells, meta = [], [], []
+    keccak = {(0, 0, 0, 0, 0)}
+    m128 = (1 << 128) - 1
+    for i, (qx, qy, z, sr, ss) in enumerate(sigs):
+        pk_x, pk_y = qx.to_bytes(32, "little"), qy.to_bytes(32, "little")
+        msg = z.to_bytes(32, "big")
+        h = real[i] if real is not None else hashlib.blake2b(pk_x + pk_y, digest_size=32).digest()
+        acc = 0
+        for b in reversed(pk_y + pk_x):
+            acc = (acc * r + b) % _FR_P
+        keccak.add((1, acc, 64, int.from_bytes(h[:16], "little"), int.from_bytes(h[16:], "little")))
+        bts.append([list(pk_x), list(pk_y), list(pk_x), list(pk_y), list(msg), list(msg), list(h), list(sr.to_bytes(32, "little")),
+                    list(ss.to_bytes(32, "little"))])
+        cells.append([int.from_bytes(h[-20:], "big"), int.from_bytes(msg[:16], "little"), int.from_bytes(msg[16:], "little"), 0,
+                      sr & m128, sr >> 128, ss & m128, ss >> 128])
+        meta.append([ECDSA_STATUS_PENDING, 1, 0, 0])
+    return {
+        "bytes": np.array(bts, dtype=np.uint8), "cells": rows_to_colmajor(cells, 8), "meta": np.array(meta, dtype=np.uint32),
+        "keccak": rows_to_rowmajor([list(k) for k in sorted(keccak)], 5),
+        "tx_rows": np.zeros((0, 5, 4), dtype=np.uint64), "tx_flags": np.zeros(0, dtype=np.uint32),
+    }
+
+
 # ---- Copy circuit: synthetic copy events (the inputs of zk_copy_assign) ------------------------------------------------
 def synth_copy_events(target_rows, seed=6, max_len=192):
     """Random copy events of every source / destination kind the reference's gadgets produce — CODECOPY / EXTCODECOPY
