@@ -88,6 +88,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
                               const u64* wds, u64 n_wds, const u64* sig, u64 n_sig, const u64* ecc, u64 n_ecc, u32 aux_cells,
                               u32 opts, u32* status) {
     EvmArgs a;
+    a.dyn = nullptr;
     a.steps = steps;
     a.n_steps = n_steps;
     HostTable trw, tbc, ttx, tblk, tcopy, tkeccak, texp;

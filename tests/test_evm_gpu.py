@@ -150,11 +150,11 @@ def test_full_size_trace_properties():
             assert eo.verify_step(W, j) == st1[j]
 
 
-def test_full_size_all_pairs_vs_logic_harness(hostsim):
-    """BASELINE config 3 size (2^18 steps), ~1,200 tampered cells: the status of EVERY pair against the C++ logic harness (the
-    kernels' own gadget sources in a plain host loop, tests/hostsim; the CPU suite pins it to the oracle case by case, and the
-    2^16 test above pins the GPU to the oracle directly) — what this adds at full size is the device machinery around the
-    gadgets: the by-state sort with its padded bins, the quad-staged step pairs, the LDS directory, the batched row requests."""
+def test_full_size_all_pairs_vs_oracle(hostsim):
+    """BASELINE config 3 size (2^18 steps), ~1,200 tampered cells: the status of EVERY one of the 2^18 - 1 pairs against the
+    independent oracle (oracle/evm_oracle.py, pinned to the unmodified reference by the golden fixtures) — kind and site — and,
+    as a second opinion on the device machinery, against the C++ logic harness (the kernels' own gadget sources in a plain
+    host loop, tests/hostsim).  Round 2 compared with the harness only at this size (partly the kernel with itself)."""
     from tests.evm_cases import hostsim_status
 
     n = 1 << 18
@@ -163,9 +163,20 @@ def test_full_size_all_pairs_vs_logic_harness(hostsim):
     rng = random.Random(41)
     for _ in range(600):
         w = fuzz_wire(w, rng, copy=False)
-    exp = hostsim_status(hostsim, w)
+    exp = oracle_status(w)
     assert len(exp) == n - 1 and sum(1 for c in exp if c) >= 400
     res, status = _run(w)
     assert status == exp
     _check_tally(res, exp)
+    assert hostsim_status(hostsim, w) == exp
+    # the one-shot C entry over device-resident tables (zk_evm_verify: open + pass + collect + close, no host copy of the tables)
+    import torch
 
+    def dev(x):
+        return torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).cuda()
+
+    wd = {k: dev(v) for k, v in w.items() if v is not None and v.size}
+    st_dev = torch.zeros(n - 1, dtype=torch.int32, device="cuda")
+    res1 = engine.evm_verify(wd, status_dev=st_dev)
+    assert st_dev.cpu().numpy().view(np.uint32).tolist() == exp
+    assert (res1.fail_count, res1.first_fail_row, res1.first_fail_code) == (res.fail_count, res.first_fail_row, res.first_fail_code)

@@ -8,8 +8,18 @@
 // (evm_circuit/typing.py:390-405).  Regular codes are addressed directly (header_row / byte_base + index); anything else
 // goes through the generic open-addressing index.  The order of the directory entries is whatever the atomics produce;
 // lookups only ever reach an entry through the slot table, by hash.
+//
+// Round 3: nothing is read back by the host.  The number of codes is not known when the buffers are taken, so the
+// directory has a fixed capacity (DIRB_MAX_ENTRIES codes; a table with more distinct hashes gets no directory and every
+// bytecode lookup goes through the generic index — correct, only slower); the entry count and the slot mask go to the
+// session's EvmDyn block, which the evaluation kernels read at entry.  Only the first row of every run of equal hashes
+// inserts into the row hash table (43,913 rows of 16 contracts used to be 43,913 CAS / atomicMin operations on 16 words:
+// 65 us; now 16).
 #pragma once
 #include "common.hpp"
+
+#define DIRB_MAX_ENTRIES 4096u
+#define DIRB_SMALL_SLOTS 16384u  // capacity of the directory's own slot table (>= 2 * DIRB_MAX_ENTRIES + 2, power of two)
 
 struct DirBuild {
     const u64* rows;   // [n][6][4]: hash lo, hi, field_tag, index, is_code, value
@@ -17,14 +27,13 @@ struct DirBuild {
     u32* big_slots;    // open addressing over the ROWS keyed by the hash cells: smallest row index of each group
     u32* slot_entry;   // directory entry of the group that owns a big slot
     u32 big_mask;
-    ZkCodeEntry* entries;
-    u32* n_entries;    // device counter
+    ZkCodeEntry* entries;  // [DIRB_MAX_ENTRIES]
+    EvmDyn* dyn;       // dir_entries (counter), codes_n / codes_mask (result)
     u32* e_headers;    // per entry: number of Header rows
     u32* e_first;      // per entry: smallest Byte row
     u32* e_last;       // per entry: largest Byte row
     u32* e_bad;        // per entry: a row that rules out "regular"
-    u32* small_slots;  // the directory's own slot table (ZkCodeDir::slots)
-    u32 small_mask;
+    u32* small_slots;  // the directory's own slot table (ZkCodeDir::slots), DIRB_SMALL_SLOTS entries, pre-filled with ZK_EMPTY_SLOT
     uint16_t* packed;  // ZkCodeDir::packed
 };
 
@@ -53,9 +62,17 @@ __device__ __forceinline__ u32 dirb_find(const DirBuild& d, u32 r) {
         s = (s + 1) & d.big_mask;
     }
 }
+__device__ __forceinline__ u32 dirb_mask_for(u32 n_entries) {
+    u32 cap = 16;
+    while (cap < 2 * n_entries + 2) cap <<= 1;
+    return cap - 1;
+}
+// Run leaders (rows whose hash differs from the previous row's) insert their group; the slot keeps the smallest row
+// index of the group whatever the launch order and however many runs a hash has.
 __global__ void dirb_insert_kernel(DirBuild d) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= d.n) return;
+    if (r != 0 && dirb_same_hash(d.rows, r - 1, r)) return;
     u32 s = dirb_hash_of_row(d.rows, r) & d.big_mask;
     while (true) {
         u32 cur = d.big_slots[s];
@@ -70,20 +87,16 @@ __global__ void dirb_insert_kernel(DirBuild d) {
         s = (s + 1) & d.big_mask;
     }
 }
+// The group's smallest row numbers its entry and initialises it (entries past the capacity are counted, not stored).
 __global__ void dirb_leaders_kernel(DirBuild d) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= d.n) return;
+    if (r != 0 && dirb_same_hash(d.rows, r - 1, r)) return;  // not even a run leader
     const u32 s = dirb_find(d, r);
     if (d.big_slots[s] != r) return;
-    d.slot_entry[s] = atomicAdd(d.n_entries, 1u);
-}
-// the entries array is sized from the group count the leaders pass produced
-__global__ void dirb_init_kernel(DirBuild d) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= d.n) return;
-    const u32 s = dirb_find(d, r);
-    if (d.big_slots[s] != r) return;
-    const u32 k = d.slot_entry[s];
+    const u32 k = atomicAdd(&d.dyn->dir_entries, 1u);
+    d.slot_entry[s] = k;
+    if (k >= DIRB_MAX_ENTRIES) return;
     ZkCodeEntry e;
 #pragma unroll
     for (int q = 0; q < 8; q++) e.hash[q] = d.rows[(u64)r * 24 + q];
@@ -102,10 +115,10 @@ __global__ void dirb_init_kernel(DirBuild d) {
 __global__ void dirb_accumulate_kernel(DirBuild d) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = r < d.n;
+    const bool overflow = d.dyn->dir_entries > DIRB_MAX_ENTRIES;  // uniform: no directory will be published
     u32 k = 0xffffffffu;
     u32 cat = 3;  // 0 rules out "regular", 1 Header row, 2 Byte row, 3 lane past the table
     if (in) {
-        k = d.slot_entry[dirb_find(d, r)];
         u64 tag, index, is_code, value;
         const bool small = dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index);
         cat = (!small || (tag != 1 && tag != 2) || (tag == 1 && index != 0)) ? 0u : (u32)tag;
@@ -113,7 +126,9 @@ __global__ void dirb_accumulate_kernel(DirBuild d) {
         if (dirb_small(d.rows, r, 4, is_code) && dirb_small(d.rows, r, 5, value) && is_code < 2 && value < 256)
             p = (uint16_t)(0x8000u | (u32)(is_code << 8) | (u32)value);
         d.packed[r] = p;
+        if (!overflow) k = d.slot_entry[dirb_find(d, r)];
     }
+    if (overflow) return;
     const unsigned long long active = __ballot(in);
     if (active == 0ull) return;
     const u32 lane = threadIdx.x & 63u;
@@ -150,15 +165,23 @@ __global__ void dirb_accumulate_kernel(DirBuild d) {
 // Byte rows must sit at first_byte + index
 __global__ void dirb_check_kernel(DirBuild d) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= d.n) return;
+    if (r >= d.n || d.dyn->dir_entries > DIRB_MAX_ENTRIES) return;
     u64 tag, index;
     if (!(dirb_small(d.rows, r, 2, tag) & dirb_small(d.rows, r, 3, index)) || tag != 2) return;
     const u32 k = d.slot_entry[dirb_find(d, r)];
     if (index != (u64)(r - d.e_first[k])) d.e_bad[k] = 1;
 }
+// One lane per possible entry; publishes the directory (entry count, slot mask) in the session's EvmDyn block.
 __global__ void dirb_finalize_kernel(DirBuild d) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *d.n_entries) return;
+    const u32 n_entries = d.dyn->dir_entries;
+    if (n_entries > DIRB_MAX_ENTRIES) return;  // too many codes: codes_n stays 0 (generic index only)
+    const u32 mask = dirb_mask_for(n_entries);
+    if (k == 0) {
+        d.dyn->codes_n = n_entries;
+        d.dyn->codes_mask = mask;
+    }
+    if (k >= n_entries) return;
     ZkCodeEntry& e = d.entries[k];
     const u32 nb = e.n_bytes;
     const bool regular = !d.e_bad[k] && d.e_headers[k] == 1u && (nb == 0 || d.e_last[k] - d.e_first[k] + 1u == nb);
@@ -170,6 +193,6 @@ __global__ void dirb_finalize_kernel(DirBuild d) {
     } else {
         e.header_row = e.byte_base = e.n_bytes = 0;
     }
-    u32 s = (u32)zk_code_hash_key(fr_load(e.hash), fr_load(e.hash + 4)) & d.small_mask;
-    while (atomicCAS(&d.small_slots[s], ZK_EMPTY_SLOT, k) != ZK_EMPTY_SLOT) s = (s + 1) & d.small_mask;
+    u32 s = (u32)zk_code_hash_key(fr_load(e.hash), fr_load(e.hash + 4)) & mask;
+    while (atomicCAS(&d.small_slots[s], ZK_EMPTY_SLOT, k) != ZK_EMPTY_SLOT) s = (s + 1) & mask;
 }

@@ -40,7 +40,21 @@ enum { SIG_T_NCELLS = 9, ECC_T_NCELLS = 13 };
 enum { AUX_PAIR = 3, AUX_ECRECOVER = 5, AUX_ECADD = 6, AUX_ECMUL = 7, AUX_ECPAIRING = 8 };  // flatten_step_aux kinds
 enum { CDT_Bytecode = 1, CDT_Memory, CDT_TxCalldata, CDT_TxLog, CDT_RlcAcc };  // CopyDataTypeTag (table.py:336-353)
 
+// Session-open verdicts that stay in HBM: zk_evm_open enqueues the kernels that compute them and returns without reading
+// anything back (no host synchronisation at open); the evaluation kernels patch their copy of EvmArgs from this block at
+// entry (evm_args_resolve).  Zero-initialised, so every field is phrased such that 0 is the "nothing built" state.
+struct EvmDyn {
+    u32 rw_sparse;      // set by rw_prepare_kernel when the RW rows are NOT consecutive rw_counters from rw_base
+    u32 codes_n;        // directory entries (0: no directory, generic bytecode index only)
+    u64 rw_base;
+    u32 codes_mask;
+    u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
+    u32 dir_entries;    // directory build: groups counted so far (may exceed the capacity; then codes_n stays 0)
+    u32 pad;
+};
+
 struct EvmArgs {
+    const EvmDyn* dyn;  // optional (device sessions): see EvmDyn; nullptr = the fields below are final (CPU logic harness)
     const u64* steps;  // [n_steps][13][4]
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
@@ -61,6 +75,18 @@ struct EvmArgs {
     u32 n_pairs;      // n_steps - 1
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
 };
+
+ZK_HD void evm_args_resolve(EvmArgs& a) {
+    if (a.dyn) {
+        const EvmDyn d = *a.dyn;  // uniform address: scalar loads
+        a.rw_dense = (a.rw.n != 0u && d.rw_sparse == 0u) ? 1u : 0u;
+        a.rw_base = d.rw_base;
+        a.codes.n = d.codes_n;
+        a.codes.mask = d.codes_mask;
+        a.agg_max_txs = d.agg_max_txs; a.agg_total_txs = d.agg_total_txs; a.agg_invalid_txs = d.agg_invalid_txs;
+        a.agg_bad_invalid_rows = d.agg_bad_invalid_rows; a.agg_total_wds = d.agg_total_wds;
+    }
+}
 
 // LDS staging of the step pair (hot kernel), one u32 entry per lane, lane-major (conflict-free ds_read_b32 / ds_write_b32).
 // Per step s (0 curr, 1 next) 12 entries at s * 12: the ten cells that are small integers in every well-formed witness

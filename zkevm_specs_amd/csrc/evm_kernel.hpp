@@ -14,6 +14,7 @@
 #endif
 template <int G, int OCC, int BLOCK>
 __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
+    evm_args_resolve(a);  // open-time verdicts (dense RW index, directory size, EndBlock aggregates) live in HBM
     // lane range: with the state-sorted mapping the hot instantiation owns [0, group_start[COLD]) and the
     // cold one [group_start[COLD], n); without it both walk all pairs and skip the other's states
     u32 lo = 0, hi = a.n_pairs;

@@ -47,6 +47,7 @@ static thread_local std::string g_err;
     } while (0)
 
 extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
+static void arena_release_all();
 
 extern "C" int zk_init(int device) {
     int count = 0;
@@ -66,7 +67,8 @@ extern "C" int zk_init(int device) {
     return 0;
 }
 extern "C" void zk_shutdown(void) {
-    // sessions own their buffers (zk_close); the per-device streams are released here.  Callers close sessions first.
+    // sessions own their buffers (zk_close); the per-device streams and the buffer arena are released here.  Callers close sessions first.
+    arena_release_all();
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     for (int d = 0; d < ZK_MAX_DEVICES; d++)
         if (g_own_stream[d]) {
@@ -121,14 +123,94 @@ __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
     if (!ok) atomicAnd(&meta->dense, 0u);
 }
 
-// Packed key records of the RW rows (RwKey, evm_circuit.hpp): one lane per row, 32 B out per row.
-__global__ void rw_pack_kernel(ZkTable t, u64* keys) {
+// EVM session open, RW table: ONE read of the key cells of every row gives (a) the density verdict of the dense index
+// (ZkRwMeta / EvmDyn: rw_counter of row r == rw_counter of row 0 + r) and (b) the packed key record (RwKey).  The verdict
+// stays on the device (EvmDyn::rw_sparse); the packed records are only consulted when it is "dense".
+__global__ __launch_bounds__(256) void rw_prepare_kernel(ZkTable t, u64* keys, EvmDyn* dyn) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= t.n) return;
+    const u64* p = t.cells + (u64)r * RW_NCELLS * 4;
+    const u64* p0 = t.cells;
+    const u64 base = p0[0];
+    const bool ok = (p0[1] | p0[2] | p0[3]) == 0 && (p[1] | p[2] | p[3]) == 0 && p[0] == base + r && base + r >= base;
+    if (r == 0) dyn->rw_base = base;
+    if (__ballot(!ok) != 0ull && !ok) atomicOr(&dyn->rw_sparse, 1u);
     const RwKey k = rw_pack_row(t, r);
     uint4* out = reinterpret_cast<uint4*>(keys + (u64)r * 4);
     out[0] = make_uint4((u32)k.w[0], (u32)(k.w[0] >> 32), (u32)k.w[1], (u32)(k.w[1] >> 32));
     out[1] = make_uint4((u32)k.w[2], (u32)(k.w[2] >> 32), (u32)k.w[3], (u32)(k.w[3] >> 32));
+}
+// The generic RW index is only needed when the rows are not dense: the launch is unconditional (the host does not know the
+// verdict), the work is not.
+__global__ void rw_generic_index_kernel(ZkTable t, u32* slots, const EvmDyn* dyn, u32 force) {
+    if (!force && dyn->rw_sparse == 0u) return;
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.n) return;
+    u32 s = (u32)rw_key_hash(t, r) & t.mask;
+    while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
+}
+// All the small tables of an EVM session in one launch: open-addressing inserts of the tx / block / bytecode / copy / keccak /
+// exp / sig / ecc rows (block ranges per table) + EndBlock's whole-table aggregates over the tx and withdrawal rows
+// (end_block.py:55-91; host_index.hpp's evm_aggregates_host is the CPU statement of the same counts) + the tally reset.
+#define EVM_OPEN_TABLES 8
+struct EvmOpenTables {
+    ZkTable t[EVM_OPEN_TABLES];      // tx, block, bytecode, copy, keccak, exp, sig, ecc (slots writable: they are this session's)
+    u32 block_start[EVM_OPEN_TABLES + 2];  // first block of each table's range; [8] = withdrawals, [9] = end
+    const u64* wds;
+    u32 n_wds;
+    EvmDyn* dyn;
+    ZkTally* tally;
+};
+__global__ __launch_bounds__(256) void evm_open_tables_kernel(EvmOpenTables o) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        o.tally[threadIdx.x].fail_count = 0ull;
+        o.tally[threadIdx.x].first_fail = ~0ull;
+    }
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j <= EVM_OPEN_TABLES; j++) k += blockIdx.x >= o.block_start[j] ? 1 : 0;
+    const u32 r = (blockIdx.x - o.block_start[k]) * blockDim.x + threadIdx.x;
+    if (k == EVM_OPEN_TABLES) {  // withdrawals: rows with a non-zero amount
+        const bool nz = r < o.n_wds && !fr_is_zero(fr_load(o.wds + ((u64)r * 4 + 3) * 4));
+        const unsigned long long b = __ballot(nz);
+        if (b && (threadIdx.x & 63u) == 0) atomicAdd(&o.dyn->agg_total_wds, (u32)__popcll(b));
+        return;
+    }
+    const ZkTable& t = o.t[k];
+    const bool in = r < t.n;
+    if (k == 0) {  // tx rows: CallerAddress rows count MAX_TXS / the txs present, TxInvalid rows the invalid ones
+        bool caller = false, present = false, invalid = false, bad = false;
+        if (in) {
+            const Fr tag = zk_table_cell(t, r, 1), lo = zk_table_cell(t, r, 3), hi = zk_table_cell(t, r, 4);
+            caller = fr_eq_u64(tag, 4);
+            present = caller && !(fr_is_zero(lo) && fr_is_zero(hi));
+            const bool inv_row = fr_eq_u64(tag, 10);
+            bad = inv_row && t.flags && (t.flags[r] & 1u);
+            invalid = inv_row && fr_eq_u64(lo, 1);
+        }
+        const unsigned long long bc = __ballot(caller), bp = __ballot(present), bi = __ballot(invalid), bb = __ballot(bad);
+        if ((threadIdx.x & 63u) == 0) {
+            if (bc) atomicAdd(&o.dyn->agg_max_txs, (u32)__popcll(bc));
+            if (bp) atomicAdd(&o.dyn->agg_total_txs, (u32)__popcll(bp));
+            if (bi) atomicAdd(&o.dyn->agg_invalid_txs, (u32)__popcll(bi));
+            if (bb) atomicOr(&o.dyn->agg_bad_invalid_rows, 1u);
+        }
+    }
+    if (!in) return;
+    u64 h;
+    switch (k) {
+    case 0: h = tx_key_hash(t, r); break;
+    case 1: h = blk_key_hash(t, r); break;
+    case 2: h = bc_key_hash(t, r); break;
+    case 3: h = copy_key_hash(t, r); break;
+    case 4: h = keccak_key_hash(t, r); break;
+    case 5: h = expt_key_hash(t, r); break;
+    case 6: h = sig_key_hash(t, r); break;
+    default: h = ecc_key_hash(t, r); break;
+    }
+    u32* slots = const_cast<u32*>(t.slots);
+    u32 s = (u32)h & t.mask;
+    while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
 }
 
 // Counting sort of the step pairs by (group, state): histogram, scan, scatter.
@@ -228,7 +310,8 @@ struct zk_session {
     hipStream_t stream = t_stream;
     u64 n = 0;                      // rows per pass
     u64 eval_lo = 0, eval_hi = 0;   // row sessions: rows [eval_lo, eval_hi) are evaluated (zk_set_range); 0, 0 = all n
-    std::vector<void*> owned;       // device allocations to free at close
+    std::vector<void*> owned;       // device buffers (arena) returned at close
+    std::vector<int> owned_class;   // their arena size classes
     ZkTally* d_tally = nullptr;
     u32* d_status = nullptr;        // internal per-row status (zeroed at open; what zk_read_status copies)
     bool status_external = false;   // the last pass wrote to the caller's status_dev instead
@@ -271,9 +354,99 @@ static int session_rebind_stream(zk_session* s, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// per-device buffer arena
+// ---------------------------------------------------------------------------------------
+// hipMalloc / hipFree cost tens of microseconds each and hipFree synchronises the device; a verifier opens a session per
+// witness.  Session buffers therefore come from per-device free lists of power-of-two size classes: a closed session
+// returns its buffers (after its stream has drained), the next open re-uses them.  The cache is bounded
+// (ZK_ARENA_MAX_BYTES, default 16 GiB per device: beyond that buffers go back to the runtime); zk_shutdown releases it.
+// ZK_NO_ARENA=1 turns it off (every buffer a hipMalloc / hipFree pair, as before round 3).
+#define ZK_ARENA_CLASSES 48
+struct DevArena {
+    std::mutex m;
+    std::vector<void*> free_[ZK_ARENA_CLASSES];
+    std::vector<hipEvent_t> events;
+    size_t cached_bytes = 0;
+};
+static DevArena g_arena[ZK_MAX_DEVICES];
+static size_t arena_limit() {
+    static const size_t lim = [] { const char* e = getenv("ZK_ARENA_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30); }();
+    return lim;
+}
+static bool arena_off() {
+    static const bool off = [] { const char* e = getenv("ZK_NO_ARENA"); return e && e[0] == '1'; }();
+    return off;
+}
+static int arena_class(size_t bytes) {
+    int c = 8;  // 256 B: hipMalloc's own granularity
+    while (((size_t)1 << c) < bytes) c++;
+    return c;
+}
+static int arena_take(int device, size_t bytes, void** p, int* cls) {
+    const int c = arena_class(bytes ? bytes : 16);
+    *cls = c;
+    if (!arena_off() && c < ZK_ARENA_CLASSES) {
+        DevArena& A = g_arena[device];
+        std::lock_guard<std::mutex> lock(A.m);
+        if (!A.free_[c].empty()) {
+            *p = A.free_[c].back();
+            A.free_[c].pop_back();
+            A.cached_bytes -= (size_t)1 << c;
+            return 0;
+        }
+    }
+    HIP_TRY(hipMalloc(p, arena_off() ? (bytes ? bytes : 16) : ((size_t)1 << c)));
+    return 0;
+}
+static void arena_give(int device, void* p, int cls) {
+    if (!arena_off() && cls < ZK_ARENA_CLASSES) {
+        DevArena& A = g_arena[device];
+        std::lock_guard<std::mutex> lock(A.m);
+        if (A.cached_bytes + ((size_t)1 << cls) <= arena_limit()) {
+            A.free_[cls].push_back(p);
+            A.cached_bytes += (size_t)1 << cls;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+static int arena_event(int device, hipEvent_t* e) {
+    {
+        DevArena& A = g_arena[device];
+        std::lock_guard<std::mutex> lock(A.m);
+        if (!A.events.empty()) {
+            *e = A.events.back();
+            A.events.pop_back();
+            return 0;
+        }
+    }
+    HIP_TRY(hipEventCreate(e));
+    return 0;
+}
+static void arena_release_all() {
+    for (int d = 0; d < ZK_MAX_DEVICES; d++) {
+        DevArena& A = g_arena[d];
+        std::lock_guard<std::mutex> lock(A.m);
+        bool any = !A.events.empty();
+        for (int c = 0; c < ZK_ARENA_CLASSES; c++) any = any || !A.free_[c].empty();
+        if (!any || hipSetDevice(d) != hipSuccess) continue;
+        for (int c = 0; c < ZK_ARENA_CLASSES; c++) {
+            for (void* p : A.free_[c]) (void)hipFree(p);
+            A.free_[c].clear();
+        }
+        for (hipEvent_t e : A.events) (void)hipEventDestroy(e);
+        A.events.clear();
+        A.cached_bytes = 0;
+    }
+}
+
 static int dev_alloc(zk_session* s, void** p, size_t bytes) {
-    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    int cls = 0;
+    int rc = arena_take(s->device, bytes, p, &cls);
+    if (rc) return rc;
     s->owned.push_back(*p);
+    s->owned_class.push_back(cls);
     return 0;
 }
 // Bring a buffer to the device unless the caller already handed a device pointer.
@@ -328,9 +501,13 @@ static int session_common_init(zk_session* s) {
 extern "C" int zk_close(zk_session* s) {
     if (!s) return 0;
     (void)hipSetDevice(s->device);
-    (void)hipStreamSynchronize(s->stream);
-    for (void* p : s->owned) (void)hipFree(p);
-    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    (void)hipStreamSynchronize(s->stream);  // nothing enqueued may still read the buffers that go back to the arena
+    for (size_t k = 0; k < s->owned.size(); k++) arena_give(s->device, s->owned[k], s->owned_class[k]);
+    {
+        DevArena& A = g_arena[s->device];
+        std::lock_guard<std::mutex> lock(A.m);
+        for (hipEvent_t e : s->ev) A.events.push_back(e);
+    }
     delete s;
     return 0;
 }
@@ -398,6 +575,21 @@ static int evm_build_perm(zk_session* s) {
     return 0;
 }
 
+// slots of an open-addressing index over n rows
+static inline u32 index_cap(u64 n) {
+    u32 cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    return cap;
+}
+
+// Open an EVM session.  With device-resident inputs (ZK_OPT_DEVICE_PTRS) nothing is read back and the host never waits:
+// buffers come from the arena, every index / verdict is built by kernels enqueued on the session's stream —
+//   memset 0xFF (all slot tables, one region)  ·  memset 0 (EvmDyn, histograms, per-pair status: one region)
+//   evm_open_tables_kernel   small-table indices + EndBlock aggregates + tally reset
+//   rw_prepare_kernel        density verdict + packed key records, one read of the RW key cells
+//   rw_generic_index_kernel  (does nothing when the rows are dense)
+//   dirb_* x 5               bytecode directory
+// and the evaluation kernels pick the verdicts up from EvmDyn (evm_args_resolve).
 extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out) {
     ARG_TRY(t_device >= 0, "zk_evm_open: call zk_init first");
     HIP_TRY(hipSetDevice(t_device));
@@ -408,155 +600,150 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             "zk_evm_open: table too large");
     ARG_TRY(t->aux_cells == 0 || (t->aux_cells >= 2 && t->aux_cells <= 64), "zk_evm_open: aux_cells must be 0 (= 2) or 2..64");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    const bool generic = opts & ZK_OPT_GENERIC_INDEX;
     zk_session* s = new zk_session();
     s->kind = SESSION_EVM;
     s->n = t->n_steps - 1;
     int rc = 0;
     const void* p = nullptr;
+    EvmArgs& E = s->evm;
     if ((rc = stage(s, t->steps, (size_t)t->n_steps * STEP_NCELLS * 32, dev, &p))) goto fail;
-    s->evm.steps = (const u64*)p;
-    s->evm.n_steps = t->n_steps;
-    if ((rc = table_stage(s, s->evm.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.block, t->block, t->block_flags, t->n_block, BLOCK_NCELLS, dev))) goto fail;
-    if ((rc = build_index<rw_key_hash>(s, s->evm.rw))) goto fail;
-    if ((rc = build_index<bc_key_hash>(s, s->evm.bytecode))) goto fail;
-    if ((rc = build_index<tx_key_hash>(s, s->evm.tx))) goto fail;
-    if ((rc = build_index<blk_key_hash>(s, s->evm.block))) goto fail;
-    if ((rc = table_stage(s, s->evm.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.sig, t->sig, nullptr, t->n_sig, SIG_T_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.ecc, t->ecc, nullptr, t->n_ecc, ECC_T_NCELLS, dev))) goto fail;
-    if ((rc = table_stage(s, s->evm.withdrawals, t->withdrawals, nullptr, t->n_withdrawals, 4, dev))) goto fail;
-    s->evm.withdrawals.slots = nullptr;
-    s->evm.withdrawals.mask = 0;
-    {   // whole-table aggregates for EndBlock's last step: the tx and withdrawal tables are small, count on the host
-        std::vector<u64> h_tx, h_wd;
-        std::vector<u32> h_txf;
-        const u64* tx = t->tx;
-        const u32* txf = t->tx_flags;
-        const u64* wd = t->withdrawals;
-        if (dev) {
-            h_tx.resize((size_t)t->n_tx * TX_NCELLS * 4);
-            h_txf.resize((size_t)t->n_tx);
-            h_wd.resize((size_t)t->n_withdrawals * 16);
-            if ((t->n_tx && (hipMemcpy(h_tx.data(), t->tx, h_tx.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                             (t->tx_flags && hipMemcpy(h_txf.data(), t->tx_flags, h_txf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess))) ||
-                (t->n_withdrawals && hipMemcpy(h_wd.data(), t->withdrawals, h_wd.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) {
-                rc = -2; g_err = "table download failed"; goto fail;
-            }
-            tx = h_tx.data();
-            txf = t->tx_flags ? h_txf.data() : nullptr;
-            wd = h_wd.data();
-        }
-        const HostEvmAgg g = evm_aggregates_host(tx, txf, t->n_tx, wd, t->n_withdrawals);
-        s->evm.agg_max_txs = g.max_txs; s->evm.agg_total_txs = g.total_txs; s->evm.agg_invalid_txs = g.invalid_txs;
-        s->evm.agg_bad_invalid_rows = g.bad_invalid_rows; s->evm.agg_total_wds = g.total_wds;
-    }
-    s->evm.aux = nullptr;
-    s->evm.aux_kind = nullptr;
-    s->evm.aux_cells = t->aux_cells ? t->aux_cells : 2u;
+    E.steps = (const u64*)p;
+    E.n_steps = t->n_steps;
+    E.n_pairs = (u32)(t->n_steps - 1);
+    if ((rc = table_stage(s, E.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.block, t->block, t->block_flags, t->n_block, BLOCK_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.copy, t->copy, nullptr, t->n_copy, COPY_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.keccak, t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.exp, t->exp, nullptr, t->n_exp, EXP_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.sig, t->sig, nullptr, t->n_sig, SIG_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.ecc, t->ecc, nullptr, t->n_ecc, ECC_T_NCELLS, dev))) goto fail;
+    if ((rc = table_stage(s, E.withdrawals, t->withdrawals, nullptr, t->n_withdrawals, 4, dev))) goto fail;
+    E.withdrawals.slots = nullptr;
+    E.withdrawals.mask = 0;
+    E.aux = nullptr;
+    E.aux_kind = nullptr;
+    E.aux_cells = t->aux_cells ? t->aux_cells : 2u;
     if (t->aux && t->aux_kind) {
-        if ((rc = stage(s, t->aux, (size_t)t->n_steps * s->evm.aux_cells * 32, dev, &p))) goto fail;
-        s->evm.aux = (const u64*)p;
+        if ((rc = stage(s, t->aux, (size_t)t->n_steps * E.aux_cells * 32, dev, &p))) goto fail;
+        E.aux = (const u64*)p;
         if ((rc = stage(s, t->aux_kind, (size_t)t->n_steps * 4, dev, &p))) goto fail;
-        s->evm.aux_kind = (const u32*)p;
+        E.aux_kind = (const u32*)p;
     }
-    if ((rc = build_index<copy_key_hash>(s, s->evm.copy))) goto fail;
-    if ((rc = build_index<keccak_key_hash>(s, s->evm.keccak))) goto fail;
-    if ((rc = build_index<expt_key_hash>(s, s->evm.exp))) goto fail;
-    if ((rc = build_index<sig_key_hash>(s, s->evm.sig))) goto fail;
-    if ((rc = build_index<ecc_key_hash>(s, s->evm.ecc))) goto fail;
-    s->evm.rw_dense = 0;
-    s->evm.rw_base = 0;
-    s->evm.rw_keys = nullptr;
-    s->evm.codes.n = 0;
-    s->evm.codes.packed = nullptr;
-    if (!(opts & ZK_OPT_GENERIC_INDEX)) {
-        // dense RW index: verified on the device (the table can be hundreds of MB)
-        ZkRwMeta* d_meta = nullptr;
-        if ((rc = dev_alloc(s, (void**)&d_meta, sizeof(ZkRwMeta)))) goto fail;
-        ZkRwMeta init;
-        init.dense = t->n_rw ? 1u : 0u;
-        init.pad = 0;
-        init.base = 0;
-        if (hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
-        if (t->n_rw)
-            hipLaunchKernelGGL(rw_dense_check_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, s->stream, s->evm.rw, d_meta);
-        {   // the verdict travels as kernel arguments: no per-lookup metadata loads
-            ZkRwMeta h_meta;
-            if (hipMemcpyAsync(&h_meta, d_meta, sizeof h_meta, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-                hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "meta download failed"; goto fail; }
-            s->evm.rw_dense = h_meta.dense;
-            s->evm.rw_base = h_meta.base;
+    {
+        // ---- one 0xFF region: every slot table of the session --------------------------------------------------------
+        ZkTable* const small[EVM_OPEN_TABLES] = {&E.tx, &E.block, &E.bytecode, &E.copy, &E.keccak, &E.exp, &E.sig, &E.ecc};
+        const bool want_dir = !generic && t->n_bytecode != 0;
+        size_t n_slots = 0;
+        u32 caps[EVM_OPEN_TABLES];
+        for (int k = 0; k < EVM_OPEN_TABLES; k++) { caps[k] = index_cap(small[k]->n); n_slots += caps[k]; }
+        const u32 cap_rw = index_cap(E.rw.n), cap_big = want_dir ? index_cap(t->n_bytecode) : 0u;
+        n_slots += (size_t)cap_rw + cap_big + (want_dir ? DIRB_SMALL_SLOTS : 0u);
+        u32* slots = nullptr;
+        if ((rc = dev_alloc(s, (void**)&slots, n_slots * sizeof(u32)))) goto fail;
+        if (hipMemsetAsync(slots, 0xff, n_slots * sizeof(u32), s->stream) != hipSuccess) { rc = -2; g_err = "slot reset failed"; goto fail; }
+        u32* cur = slots;
+        for (int k = 0; k < EVM_OPEN_TABLES; k++) { small[k]->slots = cur; small[k]->mask = caps[k] - 1; cur += caps[k]; }
+        u32* rw_slots = cur;
+        E.rw.slots = rw_slots; E.rw.mask = cap_rw - 1; cur += cap_rw;
+        u32* big_slots = cur; cur += cap_big;
+        u32* small_slots = cur;
+        // ---- one zero region: EvmDyn, the two histograms, the per-pair status ------------------------------------
+        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (size_t)s->n * sizeof(u32);
+        char* zero = nullptr;
+        if ((rc = dev_alloc(s, (void**)&zero, dyn_bytes + 2 * hist_bytes + status_bytes))) goto fail;
+        if (hipMemsetAsync(zero, 0, dyn_bytes + 2 * hist_bytes + status_bytes, s->stream) != hipSuccess) { rc = -2; g_err = "open-state reset failed"; goto fail; }
+        EvmDyn* dyn = (EvmDyn*)zero;
+        static_assert(sizeof(EvmDyn) <= 256, "EvmDyn outgrew its slot");
+        s->d_hist = (u32*)(zero + dyn_bytes);
+        s->d_hist2 = (u32*)(zero + dyn_bytes + hist_bytes);
+        s->d_status = (u32*)(zero + dyn_bytes + 2 * hist_bytes);
+        E.dyn = dyn;
+        if ((rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally)))) goto fail;
+        s->tally_last = s->d_tally;
+        // ---- small tables, aggregates, tally ---------------------------------------------------------------------------
+        {
+            EvmOpenTables o;
+            u32 blk = 0;
+            for (int k = 0; k < EVM_OPEN_TABLES; k++) { o.t[k] = *small[k]; o.block_start[k] = blk; blk += (small[k]->n + 255u) / 256u; }
+            o.block_start[EVM_OPEN_TABLES] = blk;
+            blk += (u32)((t->n_withdrawals + 255) / 256);
+            o.block_start[EVM_OPEN_TABLES + 1] = blk;
+            o.wds = E.withdrawals.cells;
+            o.n_wds = (u32)t->n_withdrawals;
+            o.dyn = dyn;
+            o.tally = s->d_tally;
+            hipLaunchKernelGGL(evm_open_tables_kernel, dim3(blk ? blk : 1u), dim3(256), 0, s->stream, o);
         }
-        if (s->evm.rw_dense && t->n_rw) {
-            u64* d_keys = nullptr;
-            if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
-            hipLaunchKernelGGL(rw_pack_kernel, dim3((u32)((t->n_rw + 255) / 256)), dim3(256), 0, s->stream, s->evm.rw, d_keys);
-            s->evm.rw_keys = d_keys;
+        // ---- RW table: density verdict + packed key records; generic index only if needed -----------------------------
+        E.rw_dense = 0;
+        E.rw_base = 0;
+        E.rw_keys = nullptr;
+        E.codes.n = 0;
+        E.codes.mask = 0;
+        E.codes.packed = nullptr;
+        E.codes.entries = nullptr;
+        E.codes.slots = nullptr;
+        E.agg_max_txs = E.agg_total_txs = E.agg_invalid_txs = E.agg_bad_invalid_rows = E.agg_total_wds = 0;
+        if (t->n_rw) {
+            const dim3 grid((u32)((t->n_rw + 255) / 256)), blk256(256);
+            if (!generic) {
+                u64* d_keys = nullptr;
+                if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
+                hipLaunchKernelGGL(rw_prepare_kernel, grid, blk256, 0, s->stream, E.rw, d_keys, dyn);
+                E.rw_keys = d_keys;
+            } else {
+                // generic indices only (parity tests of the fallback path): mark the table sparse so that evm_args_resolve keeps rw_dense = 0
+                static const u32 one = 1;
+                if (hipMemcpyAsync(&dyn->rw_sparse, &one, 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
+            }
+            hipLaunchKernelGGL(rw_generic_index_kernel, grid, blk256, 0, s->stream, E.rw, rw_slots, dyn, generic ? 1u : 0u);
         }
-        // bytecode directory: built on the device from the table where it lies (code_dir_build.hpp)
-        if (t->n_bytecode) {
+        // ---- bytecode directory (code_dir_build.hpp) -----------------------------------------------------------------
+        if (want_dir) {
             DirBuild d;
             memset(&d, 0, sizeof d);
-            d.rows = s->evm.bytecode.cells;
+            d.rows = E.bytecode.cells;
             d.n = (u32)t->n_bytecode;
-            u32 cap = 16;
-            while (cap < 2 * d.n + 2) cap <<= 1;
-            d.big_mask = cap - 1;
-            if ((rc = dev_alloc(s, (void**)&d.big_slots, (size_t)cap * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.slot_entry, (size_t)cap * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.n_entries, 4))) goto fail;
+            d.big_slots = big_slots;
+            d.big_mask = cap_big - 1;
+            d.small_slots = small_slots;
+            d.dyn = dyn;
+            u32* per_entry = nullptr;
+            if ((rc = dev_alloc(s, (void**)&d.slot_entry, (size_t)cap_big * 4))) goto fail;
             if ((rc = dev_alloc(s, (void**)&d.packed, (size_t)d.n * sizeof(uint16_t)))) goto fail;
-            if (hipMemsetAsync(d.n_entries, 0, 4, s->stream) != hipSuccess) { rc = -2; g_err = "directory counter reset failed"; goto fail; }
-            const dim3 rows_grid((d.n + 255) / 256), blk(256);
-            hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), blk, 0, s->stream, d.big_slots, cap);
-            hipLaunchKernelGGL(dirb_insert_kernel, rows_grid, blk, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_leaders_kernel, rows_grid, blk, 0, s->stream, d);
-            u32 n_entries = 0;
-            if (hipMemcpyAsync(&n_entries, d.n_entries, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-                hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "directory size download failed"; goto fail; }
-            u32 scap = 16;
-            while (scap < 2 * n_entries + 2) scap <<= 1;
-            d.small_mask = scap - 1;
-            if ((rc = dev_alloc(s, (void**)&d.entries, (size_t)n_entries * sizeof(ZkCodeEntry)))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.small_slots, (size_t)scap * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.e_headers, (size_t)n_entries * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.e_first, (size_t)n_entries * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.e_last, (size_t)n_entries * 4))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&d.e_bad, (size_t)n_entries * 4))) goto fail;
-            hipLaunchKernelGGL(slots_fill_kernel, dim3((scap + 255) / 256), blk, 0, s->stream, d.small_slots, scap);
-            hipLaunchKernelGGL(dirb_init_kernel, rows_grid, blk, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_accumulate_kernel, rows_grid, blk, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_check_kernel, rows_grid, blk, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_finalize_kernel, dim3((n_entries + 255) / 256), blk, 0, s->stream, d);
-            s->evm.codes.entries = d.entries;
-            s->evm.codes.slots = d.small_slots;
-            s->evm.codes.mask = d.small_mask;
-            s->evm.codes.n = n_entries;
-            s->evm.codes.packed = d.packed;
+            if ((rc = dev_alloc(s, (void**)&d.entries, (size_t)DIRB_MAX_ENTRIES * sizeof(ZkCodeEntry)))) goto fail;
+            if ((rc = dev_alloc(s, (void**)&per_entry, (size_t)4 * DIRB_MAX_ENTRIES * 4))) goto fail;
+            d.e_headers = per_entry;
+            d.e_first = per_entry + DIRB_MAX_ENTRIES;
+            d.e_last = per_entry + 2 * DIRB_MAX_ENTRIES;
+            d.e_bad = per_entry + 3 * DIRB_MAX_ENTRIES;
+            const dim3 rows_grid((d.n + 255) / 256), blk256(256);
+            hipLaunchKernelGGL(dirb_insert_kernel, rows_grid, blk256, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_leaders_kernel, rows_grid, blk256, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_accumulate_kernel, rows_grid, blk256, 0, s->stream, d);
+            hipLaunchKernelGGL(dirb_check_kernel, rows_grid, blk256, 0, s->stream, d);
+            const u32 fin = d.n < DIRB_MAX_ENTRIES ? d.n : DIRB_MAX_ENTRIES;
+            hipLaunchKernelGGL(dirb_finalize_kernel, dim3((fin + 255) / 256), blk256, 0, s->stream, d);
+            E.codes.entries = d.entries;
+            E.codes.slots = d.small_slots;
+            E.codes.packed = d.packed;
         }
+        if (hipGetLastError() != hipSuccess) { rc = -2; g_err = "zk_evm_open: a build kernel failed to launch"; goto fail; }
     }
-    s->evm.n_pairs = (u32)(t->n_steps - 1);
-    s->evm.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
-    if ((rc = dev_alloc(s, (void**)&s->d_hist, EVM_N_BINS * sizeof(u32)))) goto fail;
+    E.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
     if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_hist2, EVM_N_BINS * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)s->evm.n_pairs * sizeof(uint16_t)))) goto fail;
-    if (hipMemsetAsync(s->d_hist, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess ||
-        hipMemsetAsync(s->d_hist2, 0, EVM_N_BINS * sizeof(u32), s->stream) != hipSuccess) { rc = -2; goto fail; }
+    if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)E.n_pairs * sizeof(uint16_t)))) goto fail;
     if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)s->evm.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
-    s->evm.prof = nullptr;
+    if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
+    E.prof = nullptr;
     if (getenv("ZK_EVM_PROF")) {
-        if ((rc = dev_alloc(s, (void**)&s->evm.prof, 1024 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
-        if (hipMemset(s->evm.prof, 0, 1024 * 4 * 8 * sizeof(unsigned long long)) != hipSuccess) { rc = -2; goto fail; }
+        if ((rc = dev_alloc(s, (void**)&E.prof, 1024 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
+        if (hipMemsetAsync(E.prof, 0, 1024 * 4 * 8 * sizeof(unsigned long long), s->stream) != hipSuccess) { rc = -2; goto fail; }
     }
-    s->evm.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
-    if ((rc = session_common_init(s))) goto fail;
+    E.perm = (opts & ZK_OPT_NO_STATE_SORT) ? nullptr : s->d_perm;
     *out = s;
     return 0;
 fail:
@@ -642,12 +829,8 @@ static int build_rw_meta(zk_session* s, const ZkTable& rw, const ZkRwMeta** out)
     ZkRwMeta* d_meta = nullptr;
     int rc = dev_alloc(s, (void**)&d_meta, sizeof(ZkRwMeta));
     if (rc) return rc;
-    ZkRwMeta init;
-    init.dense = rw.n ? 1u : 0u;
-    init.pad = 0;
-    init.base = 0;
-    HIP_TRY(hipMemcpyAsync(d_meta, &init, sizeof init, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));  // `init` lives on this stack frame
+    static const ZkRwMeta init_dense = {1u, 0u, 0ull}, init_empty = {0u, 0u, 0ull};  // static storage: no wait for the copy
+    HIP_TRY(hipMemcpyAsync(d_meta, rw.n ? &init_dense : &init_empty, sizeof(ZkRwMeta), hipMemcpyHostToDevice, s->stream));
     if (rw.n) hipLaunchKernelGGL(rw_dense_check_kernel, dim3((rw.n + 255) / 256), dim3(256), 0, s->stream, rw, d_meta);
     *out = d_meta;
     return 0;
@@ -1016,7 +1199,8 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
         a.chunks = (const BcaChunk*)p;
         if ((rc = stage(s, code_chunk0.data(), code_chunk0.size() * 4, false, &p))) goto fail;
         a.code_chunk0 = (const u32*)p;
-        HIP_TRY(hipStreamSynchronize(s->stream));  // the host vectors above go out of scope with this call
+        // the host vectors above go out of scope with this call
+        if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_bytecode_assign_open: upload failed"; goto fail; }
         if ((rc = dev_alloc(s, &d, (size_t)n_rows * 2))) goto fail;
         a.track = (uint8_t*)d;
         if ((rc = dev_alloc(s, &d, chunks.size() * 32))) goto fail;
@@ -1185,7 +1369,8 @@ extern "C" int zk_copy_assign_open(const zk_copy_events* t, uint64_t* rows_dev, 
     if ((rc = dev_alloc(s, &d, CPA_RPOW_ROWS * 32))) goto fail;
     a.rpow = (const u64*)d;
     zk_launch_cpa_rpow(s->stream, r, (u64*)d);
-    HIP_TRY(hipStreamSynchronize(s->stream));  // the plan vectors go out of scope with this call
+    // the plan vectors go out of scope with this call
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_copy_assign_open: upload failed"; goto fail; }
     if ((rc = dev_alloc(s, &d, pl.chunks.size() * 32))) goto fail;
     a.chunk_acc = (u64*)d;
     if ((rc = dev_alloc(s, &d, pl.chunks.size() * 32))) goto fail;
@@ -1408,9 +1593,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     const bool timed = s->launches < (u32)MAX_EVENT_PAIRS;
     if (timed) {
         if (s->ev.size() < 2 * (size_t)(s->launches + 1)) {
-            HIP_TRY(hipEventCreate(&e0));
+            int erc = arena_event(s->device, &e0);
+            if (erc) return erc;
             s->ev.push_back(e0);
-            HIP_TRY(hipEventCreate(&e1));
+            if ((erc = arena_event(s->device, &e1))) return erc;
             s->ev.push_back(e1);
         }
         e0 = s->ev[2 * s->launches];
