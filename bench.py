@@ -276,8 +276,9 @@ class TxSigPass:
         self.n = int(d_tx["bytes"].shape[0])
         self.ecdsa_tx = engine.open_ecdsa(d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4, device=dev)
         self.tx = engine.open_sign(d_tx, r, False, device=dev)
-        self.ecdsa_sig = engine.open_ecdsa(d_sig["bytes"], v=d_sig["meta"][:, 3], layout=engine.ECDSA_LAYOUT_SIG_UNITS, out_dev=d_sig["meta"],
-                                           out_stride=4, v_stride=4, device=dev) if d_sig is not None else None
+        # the chips' v: column 3 of the units' meta (a compact copy: the engine reads v[i * v_stride])
+        self.ecdsa_sig = engine.open_ecdsa(d_sig["bytes"], v=d_sig["meta"][:, 3].contiguous(), layout=engine.ECDSA_LAYOUT_SIG_UNITS, out_dev=d_sig["meta"],
+                                           out_stride=4, v_stride=1, device=dev) if d_sig is not None else None
         self.sig = engine.open_sign(d_sig, r, True, device=dev) if d_sig is not None else None
         torch.cuda.synchronize()
         self._side = torch.cuda.Stream() if d_sig is not None else None

@@ -38,7 +38,8 @@ def _run_plain(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-cold-leg",
            "--no-fresh-leg"] + extra
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    err = p.stderr.decode()
+    assert p.returncode == 0, "\n".join(ln for ln in err.splitlines() if "[rank" in ln or "Error" in ln)[-6000:] + err[-1500:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(line) == 1, p.stdout.decode()[-2000:]
     return json.loads(line[0])

@@ -156,11 +156,12 @@ def check(rc, what):
 
 
 def init(device=None):
-    """Initialise the engine on a HIP device (default: LOCAL_RANK or 0)."""
+    """Initialise the engine on a HIP device (default: the device an earlier init() of this process selected, else
+    LOCAL_RANK, else 0)."""
     global _inited_device
     lib = load()
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
+        device = _inited_device if _inited_device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     # zk_init is idempotent and its selection is per thread: always forward it (a cached "already initialised" flag would
     # be wrong for a second thread or after another device was selected in between)
     check(lib.zk_init(int(device)), "zk_init")

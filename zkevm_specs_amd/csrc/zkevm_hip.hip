@@ -23,6 +23,7 @@
 #define ZK_MAX_DEVICES 64
 static std::mutex g_dev_mutex;
 static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
+static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per device: "row 0" of every empty table
 static thread_local int t_device = -1;              // device selected by this thread's last zk_init
 static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
 static thread_local std::string g_err;
@@ -59,6 +60,10 @@ extern "C" int zk_init(int device) {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
         if (!g_own_stream[device]) HIP_TRY(hipStreamCreateWithFlags(&g_own_stream[device], hipStreamNonBlocking));
         own = g_own_stream[device];
+        if (!g_zero_row[device]) {
+            HIP_TRY(hipMalloc(&g_zero_row[device], 512));
+            HIP_TRY(hipMemset(g_zero_row[device], 0, 512));
+        }
     }
     // a stream set by zk_set_stream belongs to the device it was set on: re-selecting the same device keeps it, selecting
     // another device falls back to that device's own stream (never a handle of the previous device)
@@ -72,8 +77,12 @@ extern "C" void zk_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     for (int d = 0; d < ZK_MAX_DEVICES; d++)
         if (g_own_stream[d]) {
-            if (hipSetDevice(d) == hipSuccess) (void)hipStreamDestroy(g_own_stream[d]);
+            if (hipSetDevice(d) == hipSuccess) {
+                (void)hipStreamDestroy(g_own_stream[d]);
+                if (g_zero_row[d]) (void)hipFree(g_zero_row[d]);
+            }
             g_own_stream[d] = nullptr;
+            g_zero_row[d] = nullptr;
         }
     t_stream = nullptr;
     t_device = -1;
@@ -123,53 +132,202 @@ __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
     if (!ok) atomicAnd(&meta->dense, 0u);
 }
 
-// EVM session open, RW table: ONE read of the key cells of every row gives (a) the density verdict of the dense index
-// (ZkRwMeta / EvmDyn: rw_counter of row r == rw_counter of row 0 + r) and (b) the packed key record (RwKey).  The verdict
-// stays on the device (EvmDyn::rw_sparse); the packed records are only consulted when it is "dense".
-__global__ __launch_bounds__(256) void rw_prepare_kernel(ZkTable t, u64* keys, EvmDyn* dyn) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= t.n) return;
-    const u64* p = t.cells + (u64)r * RW_NCELLS * 4;
-    const u64* p0 = t.cells;
-    const u64 base = p0[0];
-    const bool ok = (p0[1] | p0[2] | p0[3]) == 0 && (p[1] | p[2] | p[3]) == 0 && p[0] == base + r && base + r >= base;
-    if (r == 0) dyn->rw_base = base;
-    if (__ballot(!ok) != 0ull && !ok) atomicOr(&dyn->rw_sparse, 1u);
-    const RwKey k = rw_pack_row(t, r);
-    uint4* out = reinterpret_cast<uint4*>(keys + (u64)r * 4);
-    out[0] = make_uint4((u32)k.w[0], (u32)(k.w[0] >> 32), (u32)k.w[1], (u32)(k.w[1] >> 32));
-    out[1] = make_uint4((u32)k.w[2], (u32)(k.w[2] >> 32), (u32)k.w[3], (u32)(k.w[3] >> 32));
+// Counting sort of the step pairs by (group, state): histogram, scan, scatter.
+struct EvmSortArgs {  // one pass of the counting sort (evm_build_perm); also rides on the session-open launches for the first pass
+    const u64* steps;
+    u32 n_pairs;
+    u32* hist;       // this pass's histogram (zero on entry)
+    u32* hist_next;  // the other buffer: cleared for the pass after this one
+    u32* taken;      // per-bin scatter cursors
+    uint16_t* bin16;
+    u32* group_start;
+    u32* perm;
+    ZkTally* tally;
+};
+__device__ __forceinline__ void evm_state_hist_body(u32 vblock, const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
+    __shared__ u32 local[EVM_N_BINS];
+    if (vblock == 0) {
+        if (threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
+            tally->fail_count = 0ull;
+            tally->first_fail = ~0ull;
+        }
+        for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) taken[k] = 0;  // the scatter's per-bin cursors
+    }
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
+    __syncthreads();
+    u32 i = vblock * blockDim.x + threadIdx.x;
+    if (i < n_pairs) {
+        const u32 bin = evm_state_bin((u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4]);
+        bin16[i] = (uint16_t)bin;  // the scatter reads this compact copy instead of the 416-byte-strided state cells
+        atomicAdd(&local[bin], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
+        if (local[k]) atomicAdd(&hist[k], local[k]);
 }
-// The generic RW index is only needed when the rows are not dense: the launch is unconditional (the host does not know the
-// verdict), the work is not.
-__global__ void rw_generic_index_kernel(ZkTable t, u32* slots, const EvmDyn* dyn, u32 force) {
-    if (!force && dyn->rw_sparse == 0u) return;
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= t.n) return;
-    u32 s = (u32)rw_key_hash(t, r) & t.mask;
-    while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
+__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
+    evm_state_hist_body(blockIdx.x, steps, n_pairs, hist, taken, bin16, tally);
 }
-// All the small tables of an EVM session in one launch: open-addressing inserts of the tx / block / bytecode / copy / keccak /
-// exp / sig / ecc rows (block ranges per table) + EndBlock's whole-table aggregates over the tx and withdrawal rows
-// (end_block.py:55-91; host_index.hpp's evm_aggregates_host is the CPU statement of the same counts) + the tally reset.
+// Scatter with block-level aggregation.  Every block scans the (complete) histogram itself — 512 bins, Hillis-Steele in
+// LDS — instead of waiting for a separate one-block scan launch; block 0 publishes the group boundaries and clears the
+// OTHER histogram buffer for the next pass (the two alternate).  Ranks inside a block come from LDS atomics, one global
+// atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
+// Every hot bin's lane range is padded to a multiple of 64 (pad lanes = EVM_NO_PAIR): a wavefront never holds two execution
+// states.  A mixed wavefront runs both gadget bodies one after the other, and with the longest states sorted first those
+// boundary wavefronts (STOP + ADDMOD, MEMORY + SSTORE: 190k cycles against a 118k median) were the last to leave the kernel.
+// (block size: at least EVM_N_BINS threads)
+__device__ __forceinline__ void evm_state_scatter_body(u32 vblock, const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
+                                                       u32* taken, u32* group_start, u32* perm) {
+    __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
+    __shared__ u32 local[EVM_N_BINS];
+    __shared__ u32 base[EVM_N_BINS];
+    const u32 k = threadIdx.x;
+    u32 c = 0, c_real = 0;
+    if (k < EVM_N_BINS) {
+        c_real = hist[k];
+        c = k < (u32)EVM_GROUP_COLD * 128u ? ((c_real + 63u) & ~63u) : c_real;
+        sa[k] = c;
+        local[k] = 0;
+        if (vblock == 0) hist_next[k] = 0;
+    }
+    __syncthreads();
+    u32* src = sa;
+    u32* dst = sb;
+    for (u32 off = 1; off < EVM_N_BINS; off <<= 1) {
+        if (k < EVM_N_BINS) dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
+        __syncthreads();
+        u32* t = src; src = dst; dst = t;
+    }
+    u32 excl = 0;
+    if (k < EVM_N_BINS) {
+        excl = src[k] - c;
+        if (vblock == 0) {
+            if ((k & 127u) == 0) group_start[k >> 7] = excl;
+            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
+            for (u32 j = c_real; j < c; j++) perm[excl + j] = EVM_NO_PAIR;
+        }
+    }
+    const u32 i = vblock * blockDim.x + threadIdx.x;
+    u32 bin = 0, rank = 0;
+    if (i < n_pairs) {
+        bin = bin16[i];
+        rank = atomicAdd(&local[bin], 1u);
+    }
+    __syncthreads();
+    if (k < EVM_N_BINS && local[k]) base[k] = excl + atomicAdd(&taken[k], local[k]);
+    __syncthreads();
+    if (i < n_pairs) perm[base[bin] + rank] = i;
+}
+__global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
+                                                                 u32* taken, u32* group_start, u32* perm) {
+    evm_state_scatter_body(blockIdx.x, bin16, n_pairs, hist, hist_next, taken, group_start, perm);
+}
+// ---------------------------------------------------------------------------------------
+// EVM session open: three launches, whatever the tables (the host enqueues them and returns; nothing is read back).
+//   evm_open_fill_kernel    every slot table / "min" array of the session to 0xFF.., every counter / status array to 0
+//   evm_open_phase1_kernel  block ranges: small-table index inserts + EndBlock aggregates + tally reset | RW table:
+//                           density verdict + packed key records (one read of the key cells) | bytecode directory events
+//   evm_open_phase2_kernel  block ranges: directory entries | generic RW index (does nothing when the rows are dense)
+// A launch costs the host ~10 us on this stack and the device ~3 us of gap: round 2's open was 20 launches, 15 hipMallocs and
+// two host synchronisations (0.49 ms for 2^18 steps); the independent builds now share launches and overlap on the device
+// (the RW pass streams HBM, the others are latency-bound).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void evm_open_fill_kernel(uint4* ff, u64 n_ff, uint4* zero, u64 n_zero) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const uint4 F = make_uint4(~0u, ~0u, ~0u, ~0u), Z = make_uint4(0u, 0u, 0u, 0u);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_ff; i += stride) ff[i] = F;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += stride) zero[i] = Z;
+}
+// RW table: ONE read of the key cells of every row gives (a) the density verdict of the dense index (ZkRwMeta / EvmDyn:
+// rw_counter of row r == rw_counter of row 0 + r) and (b) the packed key record (RwKey).  The verdict stays on the device
+// (EvmDyn::rw_sparse); the packed records are only consulted when it is "dense".
+// Four lanes share a row: the 192 bytes of its six key cells are 12 chunks of 16 bytes, lane q of the quad loads chunks q,
+// q + 4, q + 8 — every load instruction of the wavefront is 16 rows x 64 contiguous bytes instead of 64 rows x 16 bytes
+// 448 bytes apart — and the quad ORs its partial key words together (rw_pack_row's record, bit for bit).
+//   lane 0: rw_counter[0..128)   tag[0..128)   address[0..128)        lane 2: rw[0..128)   id[0..128)   field_tag[0..128)
+//   lane 1: rw_counter[128..256) tag[128..256) address[128..256)      lane 3: rw[128..)    id[128..)    field_tag[128..)
+__device__ __forceinline__ void rw_prepare_quad(const ZkTable& t, u64* keys, EvmDyn* dyn, u32 vthread) {
+    const u32 r = vthread >> 2, q = vthread & 3u;
+    const bool in = r < t.n;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0;
+    u64 base = 0;
+    u32 flags = 3u;
+    if (in) {
+        const uint4* p = reinterpret_cast<const uint4*>(t.cells + (u64)r * RW_NCELLS * 4) + q;
+        c0 = p[0];
+        c1 = p[4];
+        c2 = p[8];
+        if (q == 0) {
+            base = t.cells[0];
+            if (t.flags) flags = t.flags[r];
+        }
+    }
+    // per-lane verdicts and partial key words
+    bool fit, dense_ok;
+    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    const bool z0hi = (c0.y | c0.z | c0.w) == 0u, z1hi = (c1.y | c1.z | c1.w) == 0u, z2hi = (c2.y | c2.z | c2.w) == 0u;
+    const bool z0 = z0hi && c0.x == 0u, z1 = z1hi && c1.x == 0u, z2 = z2hi && c2.x == 0u;
+    if (q == 0) {        // rw_counter low half, tag low half, address low half
+        const u64 rwc = (u64)c0.x | ((u64)c0.y << 32);
+        dense_ok = (c0.z | c0.w) == 0u && rwc == base + r && base + r >= base;
+        fit = z1hi && c1.x <= 255u;
+        w0 = (u64)(c1.x & 0xffu) << 8 | ((u64)(flags & 3u) << 56) | (1ull << 63);
+        w2 = (u64)c2.x | ((u64)c2.y << 32);
+        w3 = (u64)c2.z | ((u64)c2.w << 32);
+    } else if (q == 1) { // the high halves: rw_counter and tag must be zero there, the address may reach bit 160
+        dense_ok = z0;
+        fit = z1 && z2hi;
+        w0 = (u64)c2.x << 24;
+    } else if (q == 2) { // rw, id, field_tag low halves
+        dense_ok = true;
+        fit = z0hi && c0.x <= 255u && (c1.z | c1.w) == 0u && z2hi && c2.x <= 255u;
+        w0 = (u64)(c0.x & 0xffu) | ((u64)(c2.x & 0xffu) << 16);
+        w1 = (u64)c1.x | ((u64)c1.y << 32);
+    } else {             // rw, id, field_tag high halves: all zero in a record that fits
+        dense_ok = true;
+        fit = z0 && z1 && z2;
+    }
+    // quad reductions: the two verdicts by ballot, the key words by two xor-shuffle steps
+    const u32 qshift = threadIdx.x & 60u;
+    const bool fits = ((__ballot(fit) >> qshift) & 0xfull) == 0xfull;
+    const unsigned long long nd = __ballot(in && !dense_ok);
+    if (nd != 0ull && (threadIdx.x & 63u) == 0) atomicOr(&dyn->rw_sparse, 1u);
+    if (r == 0 && q == 0 && in) dyn->rw_base = base;
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        w0 |= __shfl_xor(w0, m);
+        w1 |= __shfl_xor(w1, m);
+        w2 |= __shfl_xor(w2, m);
+        w3 |= __shfl_xor(w3, m);
+    }
+    if (!fits) w0 = w1 = w2 = w3 = 0;
+    if (in && q < 2) {  // lanes 0 and 1 store the record's two halves: 32 contiguous bytes per quad
+        const u64 a = q == 0 ? w0 : w2, b2 = q == 0 ? w1 : w3;
+        reinterpret_cast<uint4*>(keys + (u64)r * 4)[q] = make_uint4((u32)a, (u32)(a >> 32), (u32)b2, (u32)(b2 >> 32));
+    }
+}
 #define EVM_OPEN_TABLES 8
 struct EvmOpenTables {
     ZkTable t[EVM_OPEN_TABLES];      // tx, block, bytecode, copy, keccak, exp, sig, ecc (slots writable: they are this session's)
-    u32 block_start[EVM_OPEN_TABLES + 2];  // first block of each table's range; [8] = withdrawals, [9] = end
+    u32 block_start[EVM_OPEN_TABLES + 2];  // first block of each table's range; [8] = withdrawals, [9] = end of the small tables
     const u64* wds;
     u32 n_wds;
     EvmDyn* dyn;
     ZkTally* tally;
+    ZkTable rw;          // phase 1: rw_prepare over [rw_block0, dir_block0)
+    u64* rw_keys;        // nullptr: generic indices only
+    u32 dir_block0, rw_block0;  // phase-1 block ranges: [0, dir_block0) small tables, [dir_block0, hist_block0) directory rows, [hist_block0, rw_block0) histogram, then RW rows
+    DirBuild dir;        // dir.n == 0: no directory
+    EvmSortArgs sort;    // sort.perm != nullptr: the first pass's counting sort rides on the two launches (histogram in phase 1, scatter in phase 2)
+    u32 hist_block0;
 };
-__global__ __launch_bounds__(256) void evm_open_tables_kernel(EvmOpenTables o) {
-    if (blockIdx.x == 0 && threadIdx.x < 2) {
-        o.tally[threadIdx.x].fail_count = 0ull;
-        o.tally[threadIdx.x].first_fail = ~0ull;
-    }
+// small-table index inserts + EndBlock's whole-table aggregates over the tx and withdrawal rows (end_block.py:55-91;
+// host_index.hpp's evm_aggregates_host is the CPU statement of the same counts)
+__device__ __forceinline__ void evm_open_small_tables(const EvmOpenTables& o, u32 block) {
     int k = 0;
 #pragma unroll
-    for (int j = 1; j <= EVM_OPEN_TABLES; j++) k += blockIdx.x >= o.block_start[j] ? 1 : 0;
-    const u32 r = (blockIdx.x - o.block_start[k]) * blockDim.x + threadIdx.x;
+    for (int j = 1; j <= EVM_OPEN_TABLES; j++) k += block >= o.block_start[j] ? 1 : 0;
+    const u32 r = (block - o.block_start[k]) * blockDim.x + threadIdx.x;
     if (k == EVM_OPEN_TABLES) {  // withdrawals: rows with a non-zero amount
         const bool nz = r < o.n_wds && !fr_is_zero(fr_load(o.wds + ((u64)r * 4 + 3) * 4));
         const unsigned long long b = __ballot(nz);
@@ -212,78 +370,42 @@ __global__ __launch_bounds__(256) void evm_open_tables_kernel(EvmOpenTables o) {
     u32 s = (u32)h & t.mask;
     while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
 }
+__global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        o.tally[threadIdx.x].fail_count = 0ull;
+        o.tally[threadIdx.x].first_fail = ~0ull;
+    }
+    // the latency-bound ranges come first (dependent loads, atomics: they start at once and finish under the stream); the RW
+    // range streams HBM for the rest of the launch
+    if (blockIdx.x < o.dir_block0) evm_open_small_tables(o, blockIdx.x);
+    else if (blockIdx.x < o.hist_block0) dirb_events_row(o.dir, (blockIdx.x - o.dir_block0) * blockDim.x + threadIdx.x);
+    else if (blockIdx.x < o.rw_block0) evm_state_hist_body(blockIdx.x - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally);
+    else rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (blockIdx.x - o.rw_block0) * blockDim.x + threadIdx.x);
+}
+// Phase 2.  The generic RW index is only needed when the rows are not dense: the blocks are always launched (the host does
+// not know the verdict), the work is conditional; grid-stride so that the idle case is 256 blocks that exit at once.
+#define EVM_OPEN_RW_GENERIC_BLOCKS 64u
+#define EVM_OPEN_P2_BLOCK 1024u  // the scatter scans EVM_N_BINS bins with one thread each
+__global__ __launch_bounds__(1024) void evm_open_phase2_kernel(EvmOpenTables o, u32 scatter_blocks, u32 dir_blocks, u32 force_generic) {
+    if (blockIdx.x < scatter_blocks) {  // the first pass's state-sorted permutation
+        evm_state_scatter_body(blockIdx.x, o.sort.bin16, o.sort.n_pairs, o.sort.hist, o.sort.hist_next, o.sort.taken, o.sort.group_start, o.sort.perm);
+        return;
+    }
+    const u32 b = blockIdx.x - scatter_blocks;
+    if (b < dir_blocks) {
+        dirb_finalize_entry(o.dir, b * blockDim.x + threadIdx.x);
+        return;
+    }
+    if (!force_generic && o.dyn->rw_sparse == 0u) return;
+    if (force_generic && b == dir_blocks && threadIdx.x == 0) o.dyn->rw_sparse = 1u;  // generic-index sessions never use the dense path
+    u32* slots = const_cast<u32*>(o.rw.slots);
+    const u32 stride = (gridDim.x - scatter_blocks - dir_blocks) * blockDim.x;
+    for (u32 r = (b - dir_blocks) * blockDim.x + threadIdx.x; r < o.rw.n; r += stride) {
+        u32 s = (u32)rw_key_hash(o.rw, r) & o.rw.mask;
+        while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & o.rw.mask;
+    }
+}
 
-// Counting sort of the step pairs by (group, state): histogram, scan, scatter.
-__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
-    __shared__ u32 local[EVM_N_BINS];
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
-            tally->fail_count = 0ull;
-            tally->first_fail = ~0ull;
-        }
-        for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) taken[k] = 0;  // the scatter's per-bin cursors
-    }
-    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x) local[k] = 0;
-    __syncthreads();
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pairs) {
-        const u32 bin = evm_state_bin((u32)steps[((u64)i * STEP_NCELLS + S_STATE) * 4]);
-        bin16[i] = (uint16_t)bin;  // the scatter reads this compact copy instead of the 416-byte-strided state cells
-        atomicAdd(&local[bin], 1u);
-    }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
-        if (local[k]) atomicAdd(&hist[k], local[k]);
-}
-// Scatter with block-level aggregation.  Every block scans the (complete) histogram itself — 512 bins, Hillis-Steele in
-// LDS — instead of waiting for a separate one-block scan launch; block 0 publishes the group boundaries and clears the
-// OTHER histogram buffer for the next pass (the two alternate).  Ranks inside a block come from LDS atomics, one global
-// atomic per (block, bin present).  Order inside a bin is irrelevant for correctness.
-// Every hot bin's lane range is padded to a multiple of 64 (pad lanes = EVM_NO_PAIR): a wavefront never holds two execution
-// states.  A mixed wavefront runs both gadget bodies one after the other, and with the longest states sorted first those
-// boundary wavefronts (STOP + ADDMOD, MEMORY + SSTORE: 190k cycles against a 118k median) were the last to leave the kernel.
-__global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
-                                                                 u32* taken, u32* group_start, u32* perm) {
-    __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
-    __shared__ u32 local[EVM_N_BINS];
-    __shared__ u32 base[EVM_N_BINS];
-    const u32 k = threadIdx.x;
-    u32 c = 0, c_real = 0;
-    if (k < EVM_N_BINS) {
-        c_real = hist[k];
-        c = k < (u32)EVM_GROUP_COLD * 128u ? ((c_real + 63u) & ~63u) : c_real;
-        sa[k] = c;
-        local[k] = 0;
-        if (blockIdx.x == 0) hist_next[k] = 0;
-    }
-    __syncthreads();
-    u32* src = sa;
-    u32* dst = sb;
-    for (u32 off = 1; off < EVM_N_BINS; off <<= 1) {
-        if (k < EVM_N_BINS) dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
-        __syncthreads();
-        u32* t = src; src = dst; dst = t;
-    }
-    u32 excl = 0;
-    if (k < EVM_N_BINS) {
-        excl = src[k] - c;
-        if (blockIdx.x == 0) {
-            if ((k & 127u) == 0) group_start[k >> 7] = excl;
-            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
-            for (u32 j = c_real; j < c; j++) perm[excl + j] = EVM_NO_PAIR;
-        }
-    }
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 bin = 0, rank = 0;
-    if (i < n_pairs) {
-        bin = bin16[i];
-        rank = atomicAdd(&local[bin], 1u);
-    }
-    __syncthreads();
-    if (k < EVM_N_BINS && local[k]) base[k] = excl + atomicAdd(&taken[k], local[k]);
-    __syncthreads();
-    if (i < n_pairs) perm[base[bin] + rank] = i;
-}
 __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -337,6 +459,7 @@ struct zk_session {
     u32* d_hist2 = nullptr;  // EVM: the other histogram buffer (the two alternate between passes)
     uint16_t* d_bin16 = nullptr;  // EVM: sort bin of every pair, written by the histogram pass
     u32 evm_pass = 0;
+    bool perm_ready = false; // EVM: zk_evm_open already enqueued the counting sort of the first pass
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
 };
@@ -452,12 +575,8 @@ static int dev_alloc(zk_session* s, void** p, size_t bytes) {
 // Bring a buffer to the device unless the caller already handed a device pointer.
 static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs, const void** out) {
     if (bytes == 0 || !src) {
-        // empty table: keep one zeroed row so that "row 0" is always readable on the device
-        void* z = nullptr;
-        int rc0 = dev_alloc(s, &z, 512);
-        if (rc0) return rc0;
-        HIP_TRY(hipMemsetAsync(z, 0, 512, s->stream));
-        *out = z;
+        // empty table: "row 0" is always readable on the device — the device's shared block of zeros (read-only)
+        *out = g_zero_row[s->device];
         return 0;
     }
     if (device_ptrs) {
@@ -633,51 +752,43 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         E.aux_kind = (const u32*)p;
     }
     {
-        // ---- one 0xFF region: every slot table of the session --------------------------------------------------------
         ZkTable* const small[EVM_OPEN_TABLES] = {&E.tx, &E.block, &E.bytecode, &E.copy, &E.keccak, &E.exp, &E.sig, &E.ecc};
         const bool want_dir = !generic && t->n_bytecode != 0;
-        size_t n_slots = 0;
+        // ---- one 0xFF region (u32 units, every piece a multiple of 4 words): all slot tables + the directory's `first` -------
+        size_t n_ff = 0;
         u32 caps[EVM_OPEN_TABLES];
-        for (int k = 0; k < EVM_OPEN_TABLES; k++) { caps[k] = index_cap(small[k]->n); n_slots += caps[k]; }
+        for (int k = 0; k < EVM_OPEN_TABLES; k++) { caps[k] = index_cap(small[k]->n); n_ff += caps[k]; }
         const u32 cap_rw = index_cap(E.rw.n), cap_big = want_dir ? index_cap(t->n_bytecode) : 0u;
-        n_slots += (size_t)cap_rw + cap_big + (want_dir ? DIRB_SMALL_SLOTS : 0u);
-        u32* slots = nullptr;
-        if ((rc = dev_alloc(s, (void**)&slots, n_slots * sizeof(u32)))) goto fail;
-        if (hipMemsetAsync(slots, 0xff, n_slots * sizeof(u32), s->stream) != hipSuccess) { rc = -2; g_err = "slot reset failed"; goto fail; }
-        u32* cur = slots;
+        n_ff += (size_t)cap_rw + 2 * (size_t)cap_big + (want_dir ? DIRB_SMALL_SLOTS : 0u);
+        u32* ff = nullptr;
+        if ((rc = dev_alloc(s, (void**)&ff, n_ff * sizeof(u32)))) goto fail;
+        u32* cur = ff;
         for (int k = 0; k < EVM_OPEN_TABLES; k++) { small[k]->slots = cur; small[k]->mask = caps[k] - 1; cur += caps[k]; }
-        u32* rw_slots = cur;
-        E.rw.slots = rw_slots; E.rw.mask = cap_rw - 1; cur += cap_rw;
-        u32* big_slots = cur; cur += cap_big;
-        u32* small_slots = cur;
-        // ---- one zero region: EvmDyn, the two histograms, the per-pair status ------------------------------------
-        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (size_t)s->n * sizeof(u32);
+        E.rw.slots = cur; E.rw.mask = cap_rw - 1; cur += cap_rw;
+        u32* const dir_rep = cur; cur += cap_big;
+        u32* const dir_first = cur; cur += cap_big;
+        u32* const small_slots = cur;
+        // ---- one zero region: EvmDyn, the two histograms, the per-pair status, the directory's last / runs / bad -------------
+        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (((size_t)s->n * sizeof(u32)) + 15) & ~(size_t)15;
+        const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
         char* zero = nullptr;
-        if ((rc = dev_alloc(s, (void**)&zero, dyn_bytes + 2 * hist_bytes + status_bytes))) goto fail;
-        if (hipMemsetAsync(zero, 0, dyn_bytes + 2 * hist_bytes + status_bytes, s->stream) != hipSuccess) { rc = -2; g_err = "open-state reset failed"; goto fail; }
+        if ((rc = dev_alloc(s, (void**)&zero, zero_bytes))) goto fail;
         EvmDyn* dyn = (EvmDyn*)zero;
         static_assert(sizeof(EvmDyn) <= 256, "EvmDyn outgrew its slot");
+        static_assert((EVM_N_BINS * sizeof(u32)) % 16 == 0, "zero region pieces are 16-byte multiples");
         s->d_hist = (u32*)(zero + dyn_bytes);
         s->d_hist2 = (u32*)(zero + dyn_bytes + hist_bytes);
         s->d_status = (u32*)(zero + dyn_bytes + 2 * hist_bytes);
+        u32* const dir_last = (u32*)(zero + dyn_bytes + 2 * hist_bytes + status_bytes);
         E.dyn = dyn;
         if ((rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally)))) goto fail;
         s->tally_last = s->d_tally;
-        // ---- small tables, aggregates, tally ---------------------------------------------------------------------------
         {
-            EvmOpenTables o;
-            u32 blk = 0;
-            for (int k = 0; k < EVM_OPEN_TABLES; k++) { o.t[k] = *small[k]; o.block_start[k] = blk; blk += (small[k]->n + 255u) / 256u; }
-            o.block_start[EVM_OPEN_TABLES] = blk;
-            blk += (u32)((t->n_withdrawals + 255) / 256);
-            o.block_start[EVM_OPEN_TABLES + 1] = blk;
-            o.wds = E.withdrawals.cells;
-            o.n_wds = (u32)t->n_withdrawals;
-            o.dyn = dyn;
-            o.tally = s->d_tally;
-            hipLaunchKernelGGL(evm_open_tables_kernel, dim3(blk ? blk : 1u), dim3(256), 0, s->stream, o);
+            const u64 n16 = n_ff / 4 + zero_bytes / 16;
+            const u32 fill_grid = (u32)(n16 / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, (uint4*)ff, (u64)(n_ff / 4),
+                               (uint4*)zero, (u64)(zero_bytes / 16));
         }
-        // ---- RW table: density verdict + packed key records; generic index only if needed -----------------------------
         E.rw_dense = 0;
         E.rw_base = 0;
         E.rw_keys = nullptr;
@@ -687,57 +798,78 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         E.codes.entries = nullptr;
         E.codes.slots = nullptr;
         E.agg_max_txs = E.agg_total_txs = E.agg_invalid_txs = E.agg_bad_invalid_rows = E.agg_total_wds = 0;
-        if (t->n_rw) {
-            const dim3 grid((u32)((t->n_rw + 255) / 256)), blk256(256);
-            if (!generic) {
-                u64* d_keys = nullptr;
-                if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
-                hipLaunchKernelGGL(rw_prepare_kernel, grid, blk256, 0, s->stream, E.rw, d_keys, dyn);
-                E.rw_keys = d_keys;
-            } else {
-                // generic indices only (parity tests of the fallback path): mark the table sparse so that evm_args_resolve keeps rw_dense = 0
-                static const u32 one = 1;
-                if (hipMemcpyAsync(&dyn->rw_sparse, &one, 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = -2; g_err = "meta upload failed"; goto fail; }
-            }
-            hipLaunchKernelGGL(rw_generic_index_kernel, grid, blk256, 0, s->stream, E.rw, rw_slots, dyn, generic ? 1u : 0u);
+        EvmOpenTables o;
+        memset(&o, 0, sizeof o);
+        u32 blk = 0;
+        for (int k = 0; k < EVM_OPEN_TABLES; k++) { o.t[k] = *small[k]; o.block_start[k] = blk; blk += (small[k]->n + 255u) / 256u; }
+        o.block_start[EVM_OPEN_TABLES] = blk;
+        blk += (u32)((t->n_withdrawals + 255) / 256);
+        o.block_start[EVM_OPEN_TABLES + 1] = blk;
+        o.wds = E.withdrawals.cells;
+        o.n_wds = (u32)t->n_withdrawals;
+        o.dyn = dyn;
+        o.tally = s->d_tally;
+        o.rw = E.rw;
+        if (t->n_rw && !generic) {
+            u64* d_keys = nullptr;
+            if ((rc = dev_alloc(s, (void**)&d_keys, (size_t)t->n_rw * 32))) goto fail;
+            E.rw_keys = d_keys;
+            o.rw_keys = d_keys;
         }
-        // ---- bytecode directory (code_dir_build.hpp) -----------------------------------------------------------------
-        if (want_dir) {
-            DirBuild d;
-            memset(&d, 0, sizeof d);
+        const u32 rw_row_blocks = o.rw_keys ? (u32)((t->n_rw + 63) / 64) : 0u;  // four lanes per row
+        o.dir_block0 = blk;
+        u32 dir_row_blocks = 0;
+        if (want_dir) {  // bytecode directory (code_dir_build.hpp)
+            DirBuild& d = o.dir;
             d.rows = E.bytecode.cells;
             d.n = (u32)t->n_bytecode;
-            d.big_slots = big_slots;
+            d.rep = dir_rep;
+            d.first = dir_first;
+            d.last = dir_last;
+            d.runs = dir_last + cap_big;
+            d.bad = dir_last + 2 * (size_t)cap_big;
             d.big_mask = cap_big - 1;
             d.small_slots = small_slots;
             d.dyn = dyn;
-            u32* per_entry = nullptr;
-            if ((rc = dev_alloc(s, (void**)&d.slot_entry, (size_t)cap_big * 4))) goto fail;
             if ((rc = dev_alloc(s, (void**)&d.packed, (size_t)d.n * sizeof(uint16_t)))) goto fail;
             if ((rc = dev_alloc(s, (void**)&d.entries, (size_t)DIRB_MAX_ENTRIES * sizeof(ZkCodeEntry)))) goto fail;
-            if ((rc = dev_alloc(s, (void**)&per_entry, (size_t)4 * DIRB_MAX_ENTRIES * 4))) goto fail;
-            d.e_headers = per_entry;
-            d.e_first = per_entry + DIRB_MAX_ENTRIES;
-            d.e_last = per_entry + 2 * DIRB_MAX_ENTRIES;
-            d.e_bad = per_entry + 3 * DIRB_MAX_ENTRIES;
-            const dim3 rows_grid((d.n + 255) / 256), blk256(256);
-            hipLaunchKernelGGL(dirb_insert_kernel, rows_grid, blk256, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_leaders_kernel, rows_grid, blk256, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_accumulate_kernel, rows_grid, blk256, 0, s->stream, d);
-            hipLaunchKernelGGL(dirb_check_kernel, rows_grid, blk256, 0, s->stream, d);
-            const u32 fin = d.n < DIRB_MAX_ENTRIES ? d.n : DIRB_MAX_ENTRIES;
-            hipLaunchKernelGGL(dirb_finalize_kernel, dim3((fin + 255) / 256), blk256, 0, s->stream, d);
+            if ((rc = dev_alloc(s, (void**)&d.list, (size_t)DIRB_MAX_ENTRIES * 4))) goto fail;
+            dir_row_blocks = (d.n + 255u) / 256u;
             E.codes.entries = d.entries;
             E.codes.slots = d.small_slots;
             E.codes.packed = d.packed;
         }
+        // the first pass's counting sort rides on the same two launches (it only needs the step rows): zk_launch then goes
+        // straight to the evaluation kernels
+        if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)E.n_pairs * sizeof(uint16_t)))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
+        const bool sorted = !(opts & ZK_OPT_NO_STATE_SORT);
+        o.hist_block0 = o.dir_block0 + dir_row_blocks;
+        u32 hist_blocks = 0, scatter_blocks = 0;
+        if (sorted) {
+            o.sort.steps = E.steps; o.sort.n_pairs = E.n_pairs; o.sort.hist = s->d_hist; o.sort.hist_next = s->d_hist2;
+            o.sort.taken = s->d_cursor; o.sort.bin16 = s->d_bin16; o.sort.group_start = s->d_group_start; o.sort.perm = s->d_perm;
+            o.sort.tally = s->d_tally;
+            hist_blocks = (E.n_pairs + 255u) / 256u;
+            scatter_blocks = (E.n_pairs + EVM_OPEN_P2_BLOCK - 1u) / EVM_OPEN_P2_BLOCK;
+            s->evm_pass = 1;        // the next pass's histogram is d_hist2 (cleared by this scatter)
+            s->perm_ready = true;
+        }
+        o.rw_block0 = o.hist_block0 + hist_blocks;
+        const u32 grid1 = o.rw_block0 + rw_row_blocks;
+        hipLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, o);
+        {
+            const u32 dir_blocks = want_dir ? DIRB_MAX_ENTRIES / EVM_OPEN_P2_BLOCK : 0u;
+            const u32 rw_blocks = t->n_rw ? EVM_OPEN_RW_GENERIC_BLOCKS : 0u;
+            if (scatter_blocks + dir_blocks + rw_blocks)
+                hipLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, o,
+                                   scatter_blocks, dir_blocks, generic ? 1u : 0u);
+        }
         if (hipGetLastError() != hipSuccess) { rc = -2; g_err = "zk_evm_open: a build kernel failed to launch"; goto fail; }
     }
     E.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
-    if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)E.n_pairs * sizeof(uint16_t)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
     E.prof = nullptr;
     if (getenv("ZK_EVM_PROF")) {
         if ((rc = dev_alloc(s, (void**)&E.prof, 1024 * 4 * 8 * sizeof(unsigned long long)))) goto fail;
@@ -1627,7 +1759,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
-        if (s->evm.perm) { int prc = evm_build_perm(s); if (prc) return prc; }
+        if (s->evm.perm) {
+            if (s->perm_ready) s->perm_ready = false;  // the open's launches carried this pass's sort
+            else { int prc = evm_build_perm(s); if (prc) return prc; }
+        }
         // with the sorted mapping the hot lane range is padded per state (EVM_PERM_PAD bounds the padding); blocks past its end exit
         const u32 grid = (u32)((s->n + (s->evm.perm ? EVM_PERM_PAD : 0) + EVM_HOT_BLOCK - 1) / EVM_HOT_BLOCK);
         const u32 all_grid = (u32)((s->n + 255) / 256);
