@@ -144,6 +144,9 @@ typedef struct zk_evm_tables {
 } zk_evm_tables;
 #define ZK_OPT_NO_STATE_SORT 2u /* evaluate step pairs in trace order (no state-sorted lane mapping) */
 #define ZK_OPT_GENERIC_INDEX 4u /* skip the dense RW index / bytecode directory; open-addressing indices only */
+#define ZK_OPT_SINGLE_PASS 8u   /* EVM sessions: the session will evaluate ONE pass (what zk_evm_verify does): skip the packed step
+                                 * records, a one-off streaming pass over the step table that only pays for itself from the second
+                                 * evaluation pass on; results are identical either way */
 int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
 int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
                   uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);

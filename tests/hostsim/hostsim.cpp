@@ -89,6 +89,9 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
                               u32 opts, u32* status) {
     EvmArgs a;
     a.dyn = nullptr;
+    a.step_recs = nullptr;
+    a.defer_list = nullptr;
+    a.defer_count = nullptr;
     a.steps = steps;
     a.n_steps = n_steps;
     HostTable trw, tbc, ttx, tblk, tcopy, tkeccak, texp;

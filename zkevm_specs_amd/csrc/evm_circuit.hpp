@@ -50,12 +50,13 @@ struct EvmDyn {
     u32 codes_mask;
     u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
     u32 dir_entries;    // directory build: groups counted so far (may exceed the capacity; then codes_n stays 0)
-    u32 pad;
+    u32 n_deferred;     // pairs the fast (hot) kernel handed to the general build this pass (reset at the start of every pass)
 };
 
 struct EvmArgs {
     const EvmDyn* dyn;  // optional (device sessions): see EvmDyn; nullptr = the fields below are final (CPU logic harness)
     const u64* steps;  // [n_steps][13][4]
+    const u32* step_recs;  // device sessions: [n_steps][EVM_REC_WORDS] packed step records (see "step records"); nullptr on the CPU
     u64 n_steps;
     ZkTable rw, bytecode, tx, block;
     ZkTable copy, keccak, exp;  // optional (n == 0 when the trace has no copy / SHA3 / EXP steps)
@@ -71,6 +72,8 @@ struct EvmArgs {
     const u64* rw_keys;  // optional [n_rw][4]: packed (rw, tag, field_tag, id, address) of every row, see rw_pack_row
     ZkCodeDir codes;          // n == 0 = generic index only
     unsigned long long* prof;  // optional phase timestamps (tuning aid): [block][8]
+    u32* defer_list;   // device sessions: [n_pairs] pairs the EVM_FAST build could not decide (see EVM_FAST) ...
+    u32* defer_count;  // ... and their count (= &dyn->n_deferred)
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
     u32 n_pairs;      // n_steps - 1
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
@@ -132,8 +135,19 @@ struct WordOrValue {
     bool is_word;
 };
 
+// EVM_FAST (k_evm_hot.hip): the hot kernel is compiled with the common case only — dense RW index with packed key records,
+// step pairs staged from narrow cells, regular bytecode, word cells below 2^128.  Wherever the general code would take a
+// fallback (generic open-addressing probe with the query cells in a stack array, cell-by-cell key compare, step rows read from
+// HBM, tx / block table lookups) the fast build sets Ins::defer instead; the kernel appends the pair to the session's deferred
+// list and the cold launch — the same gadget sources compiled WITHOUT this macro — evaluates it.  Verdicts are identical by
+// construction (a deferred pair is evaluated by exactly the code that evaluated it before round 3); what the hot kernel sheds
+// is the fallbacks' register pressure (the 14-cell query structs alone are 112 VGPRs) and their stack frames.
+#ifndef EVM_FAST
+#define EVM_FAST 0
+#endif
 struct Ins {
     const EvmArgs* a;
+    u32 defer;  // EVM_FAST: this pair needs a fallback path -> the general build evaluates it (status / tally untouched here)
     u64 idx;   // pair index: curr = idx, next = idx + 1
     u32 err;   // first failure's status code (0 = none yet)
     u32 seq;   // checkpoint counter
@@ -190,8 +204,13 @@ ZK_HD Fr ev_staged_cell(const Ins& I, int s, int c) {
     for (int w = 0; w < n; w++) r.v[w] = I.stage[(e + w) * EVM_STAGE_STRIDE];
     return r;
 }
+#if EVM_FAST
+ZK_HD Fr ev_curr(const Ins& I, int c) { return ev_staged_cell(I, 0, c); }  // unstaged (wide) pairs are deferred before any gadget runs
+ZK_HD Fr ev_next(const Ins& I, int c) { return ev_staged_cell(I, 1, c); }
+#else
 ZK_HD Fr ev_curr(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 0, c) : ev_step_cell(*I.a, I.idx, c); }
 ZK_HD Fr ev_next(const Ins& I, int c) { return I.stage ? ev_staged_cell(I, 1, c) : ev_step_cell(*I.a, I.idx + 1, c); }
+#endif
 ZK_HD Fr fr_u(u64 x) { return fr_from_u64(x); }
 ZK_HD Word word_of(const Fr& lo, const Fr& hi) {
     Word w;
@@ -222,7 +241,11 @@ ZK_HD U256 to_u256(Ins& I, const Word& w) {
 // ints (`Word.int_value`, util/arithmetic.py:127-129).  Cells >= 2^128 would need unbounded
 // integers here; such malformed word cells are reported as ZK_UNSUPPORTED (no checkpoint).
 ZK_HD U256 int_value(Ins& I, const Word& w) {
+#if EVM_FAST
+    if (!word_cells_fit(w)) I.defer = 1u;
+#else
     if (!word_cells_fit(w) && I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+#endif
     return u256_from_lo_hi(w.lo, w.hi);
 }
 ZK_HD Word word_from_u256(const U256& v) { return word_of(u256_lo(v), u256_hi(v)); }
@@ -348,6 +371,11 @@ ZK_NOINLINE u64 table_probe_generic(ZkTable t, u64 h, const Fr* q, u32 mask) {
 }
 template <int NCELLS>
 ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32 mask) {
+#if EVM_FAST
+    I.defer = 2u;  // the generic probe lives in the general build
+    I.seq++;
+    return 0u;
+#endif
     I.seq++;
     Fr tmp[NCELLS];  // private copy: only this cold path's array escapes to the out-of-line probe
     for (int c = 0; c < NCELLS; c++) tmp[c] = ((mask >> c) & 1u) ? q[c] : fr_zero();
@@ -443,6 +471,9 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr, const RwRow*
         // branch-free compare: the row loads do not depend on earlier lookups' outcomes, so the
         // loads of consecutive lookups (MLOAD: 32 rows, PUSH32: 33 rows) overlap in flight
         bool key_cells = true;  // compare cells 1..5 one by one (no packed record, or the row does not fit it)
+#if EVM_FAST
+        if (!I.a->rw_keys) I.defer = 3u;
+#endif
         if (I.a->rw_keys) {
             uint4 k01, k23;
             if (pre) {
@@ -469,11 +500,15 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr, const RwRow*
                 key_cells = false;
             }
         }
+#if EVM_FAST
+        if (key_cells) I.defer = 4u;  // a row whose key cells exceed the packed widths: cell-by-cell compare in the general build
+#else
         if (key_cells) {
 #pragma unroll
             for (int c = 1; c <= R_FT; c++)
                 if ((Q.mask >> c) & 1u) ok = ok & fr_eq(zk_table_cell(I.a->rw, r, c), Q.q[c]);
         }
+#endif
 #pragma unroll
         for (int c = R_FT + 1; c < RW_NCELLS; c++)
             if ((Q.mask >> c) & 1u) ok = ok & fr_eq(zk_table_cell(I.a->rw, r, c), Q.q[c]);
@@ -1184,11 +1219,18 @@ ZK_HD void same_context_staged(Ins& I, const Tail& T, u64 dyn_gas) {
 #endif
 ZK_HD void same_context(Ins& I, const Tail& T) {
 #if !defined(ZK_HOSTSIM)
-    if (I.stage && fr_fits64(T.dyn_gas) && fr_lo64(T.dyn_gas) < (1ull << 62) && (T.pc_kind != 1u || fr_fits64(T.pc_val)) &&
+    // (EVM_FAST: every pair that gets here is staged — and `I.stage` must not be tested there: the stage column of the block's
+    // lane 0 starts at LDS address 0, which reads as a null pointer; in the general build that lane silently took the
+    // field-arithmetic form below)
+    if ((EVM_FAST || I.stage) && fr_fits64(T.dyn_gas) && fr_lo64(T.dyn_gas) < (1ull << 62) && (T.pc_kind != 1u || fr_fits64(T.pc_val)) &&
         (T.mws_kind != 1u || fr_fits64(T.mws_val))) {
         same_context_staged(I, T, fr_lo64(T.dyn_gas));
         return;
     }
+#endif
+#if EVM_FAST
+    I.defer = 5u;  // transition operands beyond 64 bits: the field-arithmetic form below, in the general build
+    return;
 #endif
     const Fr& opcode = T.opcode;
     // responsible-opcode membership (success states: (state, opcode, 0) rows, table.py:71-79), opcode
@@ -4083,14 +4125,14 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 #define GROUP_OF_ES_ADDRESS 2
 #define GROUP_OF_ES_BITWISE 2
 #define GROUP_OF_ES_BYTE 2
-#define GROUP_OF_ES_BlockCtx 2
+#define GROUP_OF_ES_BlockCtx 3
 #define GROUP_OF_ES_CALLDATASIZE 2
 #define GROUP_OF_ES_CALLER 2
 #define GROUP_OF_ES_CALLVALUE 2
 #define GROUP_OF_ES_CMP 2
 #define GROUP_OF_ES_CODESIZE 2
 #define GROUP_OF_ES_GAS 2
-#define GROUP_OF_ES_GASPRICE 2
+#define GROUP_OF_ES_GASPRICE 3
 #define GROUP_OF_ES_ISZERO 2
 #define GROUP_OF_ES_JUMP 2
 #define GROUP_OF_ES_JUMPI 2
@@ -4099,7 +4141,7 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 #define GROUP_OF_ES_MUL 1
 #define GROUP_OF_ES_MULMOD 1
 #define GROUP_OF_ES_NOT 2
-#define GROUP_OF_ES_ORIGIN 2
+#define GROUP_OF_ES_ORIGIN 3
 #define GROUP_OF_ES_POP 2
 #define GROUP_OF_ES_PUSH 2
 #define GROUP_OF_ES_RETURNDATASIZE 2
@@ -4121,6 +4163,9 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 // their code and register pressure stay out of the hot kernel (EVM_GROUP_ALL = the three hot groups).
 enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_GROUP_COLD = 3, EVM_N_GROUPS = 4, EVM_GROUP_ALL = -1 };
 #define ZK_NOT_MINE 0xffffffffu  // evm_check_step<G>: the state belongs to the other instantiation
+#define ZK_DEFERRED_BASE 0xfffffff0u  // evm_check_step (EVM_FAST build) returns BASE + reason (1 wide word cell, 2 generic probe, 3 no packed
+                                     // keys, 4 key cells beyond the packed widths, 5 wide transition operands; 8 = unstaged pair): the pair needs a
+                                     // fallback path of the general build
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
     case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
@@ -4135,6 +4180,8 @@ ZK_HD int evm_state_group(u32 state) {
     case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: case ES_DATACOPY:
     case ES_ErrorOutOfGasPrecompile: case ES_ErrorOutOfGasCREATE: case ES_ErrorGasUintOverflow: case ES_ECRECOVER: case ES_BN254_ADD:
     case ES_BN254_SCALAR_MUL: case ES_BN254_PAIRING: return EVM_GROUP_COLD;
+    // readers of the tx / block tables (generic open-addressing lookups: not in the fast build)
+    case ES_ORIGIN: case ES_GASPRICE: case ES_BlockCtx: return EVM_GROUP_COLD;
     default: return EVM_GROUP_LIGHT;
     }
 }
@@ -4187,26 +4234,120 @@ ZK_HD void evm_prefetch(Ins& I) {
 
 // verify_step (main.py:47-63) for pair `idx`; G selects which gadget bodies are compiled in
 #if !defined(ZK_HOSTSIM)
-// Fill the wavefront's LDS stage (layout: EVM_STAGE_ENTRIES) with its 64 lanes' step pairs, by lane quads.  A pair is 832
-// contiguous bytes of the step table = 52 16-byte chunks.  The four lanes of a quad fetch one pair together: lane r takes
-// chunks r, r + 4, … r + 48, so each load of the quad is 64 contiguous bytes = one request to the vector memory path (a lane
-// fetching its own pair makes every 16-byte load its own request: 3,328 per wavefront instead of 832); a wavefront serves its
-// 64 pairs in four rounds of sixteen, the per-load address is the round's base plus an immediate, and all 52 loads are in
-// flight together.  Lane r then holds the low (r even) or high (r odd) halves of cells r/2, r/2 + 2, …: the even lanes write
-// the low words into the pair's column of the stage, the odd ones only have to see zeros.  Returns whether this lane's own
-// pair has a cell wider than its entry (malformed witnesses only): that lane then reads its step rows from HBM.
-// Measured (2^18 steps): kernel 78.8 -> 76.9 us against the lane-by-lane fill.  What it does not change is the kernel's
-// first round: all 2,048 resident wavefronts ask for their 53 KB at t = 0 — 109 MB, half the step table — and that takes
-// ~37k cycles = 16 us whichever way it is requested: HBM rate.  Later wavefronts stage in ~13k.
-// (Also tried in round 2: the wavefront walking its 64 x 832 B in address order, lane l taking chunk (64 i + l) % 52 of pair
-// (64 i + l) / 52 — ~110 instructions of address / scatter arithmetic per chunk, 40-55k cycles in two half batches, 140k
-// with all 52 loads in one batch (spills).)
+// (Round 2 staged a pair from its 832 bytes of step-table rows, 52 chunks by lane quads: kernel 78.8 -> 76.9 us against a
+// lane-by-lane fill; the wavefront walking its 64 x 832 B in address order was also tried — ~110 instructions of address /
+// scatter arithmetic per chunk, 40-55k cycles.  Neither changes what the first round costs: 2,048 resident wavefronts asking
+// for 53 KB each at t = 0 is 109 MB at HBM rate, ~37k cycles.  Round 3 stages from packed step records instead.)
+// ---- step records (round 3) ----------------------------------------------------------------------------------------------
+// A well-formed step's 13 cells (416 B on the wire) hold 40 + 8 + 32 = 80 bytes of information: ten 32-bit integers, the
+// 64-bit gas_left and the two 128-bit code-hash cells.  zk_evm_open packs every step into a 96-byte record (one streaming
+// read of the step table, riding on the open launch); the hot kernel then stages a pair (curr, next) from 192 contiguous
+// bytes instead of 832: the staging phase was 14k-36k of a wavefront's 33k-130k cycles and its first round (2,048 wavefronts
+// asking for 53 KB each at t = 0) ran at HBM rate.  A step with a cell wider than its record field (malformed witnesses only)
+// sets the record's wide flag: a pair touching it is not staged, its lane reads the step rows from HBM as before.
+// Record layout (u32 words; chosen so that the two lanes that hold the low cell halves in the builder each store whole
+// 16-byte chunks):   0 state  1 call_id  2 is_create  3 sp | 4 memory_word_size  5 log_id  6 WIDE  7 - | 8-11 code_hash.hi |
+//                   12 rw_counter  13 is_root  14 pc  15 reversible_write_counter | 16-17 gas_left  18-19 - | 20-23 code_hash.lo
+#define EVM_REC_WORDS 24
+#define EVM_REC_WIDE_WORD 6
+// stage entry of word i of record chunk cj for step s (0xff = not staged): see evm_stage_entry
+ZK_HD u32 evm_rec_stage_entry(u32 s, u32 cj, u32 i) {
+    const u32 step12 = s * 12u, ch = 24u + s * 8u;
+    switch (cj) {
+    case 0: return step12 + (i == 0 ? 0u : i == 1 ? 2u : i == 2 ? 4u : 6u);              // state, call_id, is_create, sp
+    case 1: return i == 0 ? step12 + 7u : i == 1 ? step12 + 9u : 0xffu;                  // memory_word_size, log_id
+    case 2: return ch + 4u + i;                                                          // code_hash.hi
+    case 3: return step12 + (i == 0 ? 1u : i == 1 ? 3u : i == 2 ? 5u : 8u);              // rw_counter, is_root, pc, reversible_write_counter
+    case 4: return i < 2 ? step12 + (u32)EVM_STAGE_GAS + i : 0xffu;                      // gas_left
+    default: return ch + i;                                                              // code_hash.lo
+    }
+}
+// Builder: four lanes share a step row (26 chunks of 16 bytes, lane q loads chunks q, q + 4, ...): lane 0 ends up with the low
+// halves of cells 0, 2, ..., 12, lane 2 with those of cells 1, 3, ..., 11, lanes 1 and 3 with the high halves (all zero in a
+// well-formed step).
 ZK_HD u32 evm_quad_or(u32 v) {
     v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]
     v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]
     return v;
 }
+ZK_HD void evm_step_record_quad(const u64* steps, u32 n_steps, u32* recs, u32 vthread) {
+    const u32 st = vthread >> 2, q = vthread & 3u;
+    const bool in = st < n_steps;
+    const uint4 Z = make_uint4(0u, 0u, 0u, 0u);
+    uint4 c[7];
+    const uint4* src = reinterpret_cast<const uint4*>(steps + (u64)(in ? st : 0u) * (STEP_NCELLS * 4)) + q;
+#pragma unroll
+    for (int k = 0; k < 7; k++) c[k] = (k < 6 || q < 2) ? src[4 * k] : Z;  // chunks 24, 25 exist for lanes 0, 1 only
+    u32 bad = 0;
+    if (q & 1u) {  // high halves
+#pragma unroll
+        for (int k = 0; k < 7; k++) bad |= c[k].x | c[k].y | c[k].z | c[k].w;
+    } else if (q == 0) {  // cells 0 state, 2 call_id, 4 is_create, 6 code_hash.hi, 8 sp, 10 memory_word_size, 12 log_id
+#pragma unroll
+        for (int k = 0; k < 7; k++) if (k != 3) bad |= c[k].y | c[k].z | c[k].w;
+    } else {              // cells 1 rw_counter, 3 is_root, 5 code_hash.lo, 7 pc, 9 gas_left, 11 reversible_write_counter
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k != 2) bad |= (k == 4 ? 0u : c[k].y) | c[k].z | c[k].w;
+    }
+    const u32 wide = evm_quad_or(bad) != 0u ? 1u : 0u;
+    if (!in) return;
+    uint4* out = reinterpret_cast<uint4*>(recs + (u64)st * EVM_REC_WORDS);
+    if (q == 0) {
+        out[0] = make_uint4(c[0].x, c[1].x, c[2].x, c[4].x);
+        out[1] = make_uint4(c[5].x, c[6].x, wide, 0u);
+        out[2] = c[3];
+    } else if (q == 2) {
+        out[3] = make_uint4(c[0].x, c[1].x, c[3].x, c[5].x);
+        out[4] = make_uint4(c[4].x, c[4].y, 0u, 0u);
+        out[5] = c[2];
+    }
+}
+// Fill the wavefront's LDS stage (layout: EVM_STAGE_ENTRIES) with its 64 lanes' step pairs from the step records, by lane quads:
+// a pair is records idx and idx + 1 = 192 contiguous bytes = 12 chunks; lane r of the quad takes chunks r, r + 4, r + 8 (round
+// it: the quad's pair is 16 it + q) — twelve 16-byte loads per lane for the whole wavefront instead of fifty-two — and scatters
+// their words into the pair's column of the stage.  Returns whether this lane's own pair touches a wide step (malformed
+// witnesses only): that lane then reads its step rows from HBM.
 ZK_HD bool evm_stage_steps_quad(const EvmArgs& a, u32 idx, bool mine, __attribute__((address_space(3))) u32* wave_stage) {
+    const u32 lane = threadIdx.x & 63u, q = lane >> 2, r = lane & 3u;
+    u32 wide_rounds = 0;  // bit it: the pair this quad fetched in round it is wide
+    uint4 v[4][3];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const u32 p = 16u * (u32)it + q;
+        const u32 idx_p = (u32)__shfl((int)idx, (int)p);
+        const bool on = __shfl(mine ? 1 : 0, (int)p) != 0;  // a lane without a pair: fetch pair 0, nobody reads that column
+        const uint4* src = reinterpret_cast<const uint4*>(a.step_recs + (u64)(on ? idx_p : 0u) * EVM_REC_WORDS) + r;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[it][k] = src[4 * k];
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const u32 p = 16u * (u32)it + q;  // the pair (stage column) of this quad in this round
+        u32 bad = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const u32 j = r + 4u * (u32)k, s = j >= 6u ? 1u : 0u, cj = j - 6u * s;  // chunk j of the pair = chunk cj of record s
+            const uint4 x = v[it][k];
+            const u32 w[4] = {x.x, x.y, x.z, x.w};
+            if (cj == 1u) bad |= x.z;  // EVM_REC_WIDE_WORD = word 2 of chunk 1
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 e = evm_rec_stage_entry(s, cj, (u32)i);
+                if (e != 0xffu) wave_stage[e * EVM_STAGE_STRIDE + p] = w[i];
+            }
+        }
+        if (evm_quad_or(bad) != 0u) wide_rounds |= 1u << it;
+    }
+    const u32 theirs = (u32)__shfl((int)wide_rounds, (int)(4u * (lane & 15u)));  // the quad that fetched this lane's pair
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ((theirs >> (lane >> 4)) & 1u) != 0u;
+}
+// The same from the step table's own rows (a pair = 832 contiguous bytes = 52 chunks, lane r of the quad takes chunks r, r + 4,
+// ... r + 48; the even lanes write the low words into the pair's column, the odd ones only have to see zeros): used by sessions
+// without step records — the one-shot entry zk_evm_verify, where one streaming pass over the step table to build the records
+// (+34 us in the HBM-bound open launch at 2^18 steps) costs more than the single evaluation pass gains from them (7 us).
+ZK_HD bool evm_stage_steps_rows_quad(const EvmArgs& a, u32 idx, bool mine, __attribute__((address_space(3))) u32* wave_stage) {
     const u32 lane = threadIdx.x & 63u, q = lane >> 2, r = lane & 3u, r2 = r >> 1;
     const bool hi_half = (r & 1u) != 0u;
     u32 wide_rounds = 0;  // bit it: the pair this quad fetched in round it is wide
@@ -4276,14 +4417,21 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     I.op_info_byte = 0x100u;
     EV_PROF(I, 0);
     Fr statef, next_statef;
+    I.defer = 0;
+#if EVM_FAST
+    {   // (unstaged pairs never get here: the kernel defers them)
+#else
     if (I.stage) {  // one branch and one batch of LDS reads for the cells every step needs (not one of each per cell)
+#endif
         I.rwc = ev_staged_cell(I, 0, S_RWC);
         I.call_id = ev_staged_cell(I, 0, S_CALL_ID);
         I.sp = ev_staged_cell(I, 0, S_SP);
         I.pc = ev_staged_cell(I, 0, S_PC);
         statef = ev_staged_cell(I, 0, S_STATE);
         next_statef = ev_staged_cell(I, 1, S_STATE);
-    } else {
+    }
+#if !EVM_FAST
+    else {
         I.rwc = ev_step_cell(a, idx, S_RWC);
         I.call_id = ev_step_cell(a, idx, S_CALL_ID);
         I.sp = ev_step_cell(a, idx, S_SP);
@@ -4291,6 +4439,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
         statef = ev_step_cell(a, idx, S_STATE);
         next_statef = ev_step_cell(a, idx + 1, S_STATE);
     }
+#endif
     const bool is_first = (a.opts & 1u) && idx == 0;
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
     const u32 state = statef.v[0];
@@ -4340,10 +4489,10 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     case ES_ADDRESS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADDRESS) { g_ctx_word(I, T, OP_ADDRESS, CC_CalleeAddress); } break;
     case ES_CALLDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CALLDATASIZE) { g_ctx_value(I, T, OP_CALLDATASIZE, CC_CallDataLength); } break;
     case ES_RETURNDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_RETURNDATASIZE) { g_ctx_value(I, T, OP_RETURNDATASIZE, CC_LastCalleeReturnDataLength); } break;
-    case ES_ORIGIN: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ORIGIN) { g_tx_word(I, T, OP_ORIGIN, TXC_CallerAddress); } break;
-    case ES_GASPRICE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_GASPRICE) { g_tx_word(I, T, OP_GASPRICE, TXC_GasPrice); } break;
+    case ES_ORIGIN: if (G == EVM_GROUP_COLD) { g_tx_word(I, T, OP_ORIGIN, TXC_CallerAddress); } break;
+    case ES_GASPRICE: if (G == EVM_GROUP_COLD) { g_tx_word(I, T, OP_GASPRICE, TXC_GasPrice); } break;
     case ES_SELFBALANCE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SELFBALANCE) { g_selfbalance(I, T); } break;
-    case ES_BlockCtx: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_BlockCtx) { g_blockctx(I, T); } break;
+    case ES_BlockCtx: if (G == EVM_GROUP_COLD) { g_blockctx(I, T); } break;
     case ES_GAS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_GAS) { g_gas(I, T); } break;
     case ES_MSIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MSIZE) { g_msize(I, T); } break;
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
@@ -4403,5 +4552,8 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     if (I.err == 0u && T.enabled) same_context(I, T);
     if (I.err == 0u && T.err_tail) error_tail(I, T);
     EV_PROF(I, 3);
+#if EVM_FAST
+    if (I.defer) return ZK_DEFERRED_BASE + (I.defer & 7u);  // whatever the fast path concluded after a skipped fallback does not count
+#endif
     return I.err;
 }

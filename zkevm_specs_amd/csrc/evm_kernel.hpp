@@ -14,6 +14,18 @@
 #endif
 template <int G, int OCC, int BLOCK>
 __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const u32* group_start, u32* status, ZkTally* tally) {
+    // Entry: three independent loads in flight together — the open-time verdicts (EvmDyn), the lane range of the sorted mapping
+    // (group_start) and this lane's pair (perm; read before the range is known: the buffer is padded past every grid) — instead
+    // of three dependent round trips of 2-3 us each under load.
+    u32 perm_t = 0;
+    if (G != EVM_GROUP_COLD && a.perm) perm_t = a.perm[(u64)blockIdx.x * blockDim.x + threadIdx.x];
+    __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
+    const bool have_dir = G == EVM_GROUP_ALL && a.dyn != nullptr && a.codes.slots != nullptr && a.codes.entries != nullptr;
+    if (have_dir) {
+        for (u32 k = threadIdx.x; k < EVM_DIR_SLOT_U64; k += blockDim.x) s_dir[k] = (u64)a.codes.slots[2 * k] | ((u64)a.codes.slots[2 * k + 1] << 32);
+        const u64* e = (const u64*)a.codes.entries;
+        for (u32 k = threadIdx.x; k < EVM_DIR_MAX_ENTRIES * 12u; k += blockDim.x) s_dir[EVM_DIR_SLOT_U64 + k] = e[k];
+    }
     evm_args_resolve(a);  // open-time verdicts (dense RW index, directory size, EndBlock aggregates) live in HBM
     // lane range: with the state-sorted mapping the hot instantiation owns [0, group_start[COLD]) and the
     // cold one [group_start[COLD], n); without it both walk all pairs and skip the other's states
@@ -24,7 +36,6 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
     }
     u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ u32 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_ENTRIES * EVM_STAGE_STRIDE : 1];
-    __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
     if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
         if ((u64)blockIdx.x * blockDim.x >= (u64)hi) return;  // the grid is sized for the largest possible padding
         if (EV_PROF_ON(a)) {  // tuning aid: entry stamps (core clock, 100 MHz wall clock)
@@ -32,28 +43,37 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
             a.prof[EV_PROF_WAVE * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         }
         // small bytecode directories (the usual case: a handful of contracts) are mirrored in LDS by the whole block, so that
-        // resolving curr.code_hash costs no dependent HBM round trips
-        const bool dir_in_lds = a.codes.n != 0 && a.codes.n <= EVM_DIR_MAX_ENTRIES && a.codes.mask < EVM_DIR_MAX_SLOTS;
-        if (dir_in_lds) {
-            const u32 n_slots = a.codes.mask + 1u;
-            for (u32 k = threadIdx.x; k < EVM_DIR_SLOT_U64; k += blockDim.x) {
-                const u32 s0 = 2 * k < n_slots ? a.codes.slots[2 * k] : ZK_EMPTY_SLOT, s1 = 2 * k + 1 < n_slots ? a.codes.slots[2 * k + 1] : ZK_EMPTY_SLOT;
-                s_dir[k] = (u64)s0 | ((u64)s1 << 32);
-            }
-            const u64* e = (const u64*)a.codes.entries;
-            for (u32 k = threadIdx.x; k < a.codes.n * 12u; k += blockDim.x) s_dir[EVM_DIR_SLOT_U64 + k] = e[k];
-        }
+        // resolving curr.code_hash costs no dependent HBM round trips.  The copy does not wait for the directory's size (EvmDyn):
+        // it always takes the first EVM_DIR_MAX_SLOTS slots and EVM_DIR_MAX_ENTRIES entries of the session's (larger, pre-filled)
+        // buffers; whether the mirror is complete — and used — is decided from the size afterwards.
+        const bool dir_in_lds = have_dir && a.codes.n != 0 && a.codes.n <= EVM_DIR_MAX_ENTRIES && a.codes.mask < EVM_DIR_MAX_SLOTS;
         u32 code = 0;
         u64 idx = t;
-        if (t < (u64)hi && a.perm) idx = a.perm[t];
+        if (t < (u64)hi && a.perm) idx = perm_t;  // lo == 0 for the hot instantiation: t is the lane's global index
         const bool mine = t < (u64)hi && idx != (u64)EVM_NO_PAIR;
         // both steps of every pair of the wavefront go to LDS first (lane quads fetch them); the gadgets read them from there
         __attribute__((address_space(3))) u32* my = (__attribute__((address_space(3))) u32*)s_stage + threadIdx.x;
-        const bool wide = evm_stage_steps_quad(a, (u32)idx, mine, my - (threadIdx.x & 63u));
+        // from the packed step records when the session has them (zk_evm_open), else from the step rows (zk_evm_verify: one pass only)
+        const bool wide = a.step_recs ? evm_stage_steps_quad(a, (u32)idx, mine, my - (threadIdx.x & 63u))
+                                      : evm_stage_steps_rows_quad(a, (u32)idx, mine, my - (threadIdx.x & 63u));
         if (dir_in_lds) __syncthreads();
         if (mine) {
+#if EVM_FAST
+            // an unstaged pair (a step cell wider than its record field) or a pair that ran into a fallback path goes to the
+            // deferred list: the cold launch evaluates it with the general build of the same gadgets
+            code = wide ? (u32)ZK_DEFERRED_BASE + 8u
+                        : evm_check_step<G>(a, idx, (EVM_LDS32_PTR)my, dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
+            if (code >= ZK_DEFERRED_BASE && code != ZK_NOT_MINE) {
+#ifdef ZK_DEFER_DEBUG  // tuning aid: per-reason counters in the last slots of the profiling buffer (ZK_EVM_PROF=1)
+                if (a.prof) atomicAdd(&a.prof[4095 * 8 - 16 + (code & 15u)], 1ull);
+#endif
+                a.defer_list[atomicAdd(a.defer_count, 1u)] = (u32)idx;
+                code = 0;
+            } else
+#else
             code = evm_check_step<G>(a, idx, wide ? (EVM_LDS32_PTR) nullptr : (EVM_LDS32_PTR)my,
                                      dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
+#endif
             if (code == ZK_NOT_MINE) code = 0;
             else if (status) status[idx] = code;
         }
@@ -68,5 +88,19 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
             else if (status) status[idx] = code;
             tally_commit(tally, idx, code);  // ballot over the lanes still in the loop
         }
+#if !EVM_FAST
+        // the pairs the fast (hot) kernel deferred: every gadget in its general form (generic indices, cell-by-cell compares,
+        // step rows from HBM)
+        if (G == EVM_GROUP_COLD && a.defer_count) {
+            const u32 n_def = *a.defer_count;
+            for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < (u64)n_def; k += stride) {
+                const u64 idx = a.defer_list[k];
+                u32 code = evm_check_step<EVM_GROUP_ALL>(a, idx);
+                if (code == ZK_NOT_MINE) code = 0;
+                else if (status) status[idx] = code;
+                tally_commit(tally, idx, code);
+            }
+        }
+#endif
     }
 }

@@ -1,4 +1,5 @@
-// EVM circuit: the hot instantiation (BASELINE config 3's opcode mix)
+// EVM circuit: the hot instantiation (BASELINE config 3's opcode mix), fast build: fallback paths are deferred to the cold launch
+#define EVM_FAST 1
 #include "evm_kernel.hpp"
 
 void zk_launch_evm_hot(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e0) {

@@ -102,9 +102,10 @@ extern "C" int zk_session_set_stream(zk_session* s, void* st) {
 // ---------------------------------------------------------------------------------------
 // tally + index kernels
 // ---------------------------------------------------------------------------------------
-__global__ void tally_reset_kernel(ZkTally* t) {
+__global__ void tally_reset_kernel(ZkTally* t, u32* counter = nullptr) {
     t[threadIdx.x].fail_count = 0ull;
     t[threadIdx.x].first_fail = ~0ull;
+    if (counter && threadIdx.x == 0) *counter = 0u;  // EVM sessions in trace order: the deferred-pair count of the pass
 }
 
 
@@ -143,10 +144,13 @@ struct EvmSortArgs {  // one pass of the counting sort (evm_build_perm); also ri
     u32* group_start;
     u32* perm;
     ZkTally* tally;
+    u32* defer_count;  // reset with the tally
 };
-__device__ __forceinline__ void evm_state_hist_body(u32 vblock, const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
+__device__ __forceinline__ void evm_state_hist_body(u32 vblock, const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally,
+                                                    u32* defer_count) {
     __shared__ u32 local[EVM_N_BINS];
     if (vblock == 0) {
+        if (threadIdx.x == 0 && defer_count) *defer_count = 0u;
         if (threadIdx.x == 0) {  // fused tally reset (saves a launch per pass)
             tally->fail_count = 0ull;
             tally->first_fail = ~0ull;
@@ -165,8 +169,8 @@ __device__ __forceinline__ void evm_state_hist_body(u32 vblock, const u64* steps
     for (u32 k = threadIdx.x; k < EVM_N_BINS; k += blockDim.x)
         if (local[k]) atomicAdd(&hist[k], local[k]);
 }
-__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally) {
-    evm_state_hist_body(blockIdx.x, steps, n_pairs, hist, taken, bin16, tally);
+__global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally, u32* defer_count) {
+    evm_state_hist_body(blockIdx.x, steps, n_pairs, hist, taken, bin16, tally, defer_count);
 }
 // Scatter with block-level aggregation.  Every block scans the (complete) histogram itself — 512 bins, Hillis-Steele in
 // LDS — instead of waiting for a separate one-block scan launch; block 0 publishes the group boundaries and clears the
@@ -318,6 +322,10 @@ struct EvmOpenTables {
     u64* rw_keys;        // nullptr: generic indices only
     u32 dir_block0, rw_block0;  // phase-1 block ranges: [0, dir_block0) small tables, [dir_block0, hist_block0) directory rows, [hist_block0, rw_block0) histogram, then RW rows
     DirBuild dir;        // dir.n == 0: no directory
+    const u64* steps;    // phase 1: step records (evm_step_record_quad) over [rec_block0, end)
+    u32 n_steps;
+    u32* step_recs;
+    u32 rec_block0;
     EvmSortArgs sort;    // sort.perm != nullptr: the first pass's counting sort rides on the two launches (histogram in phase 1, scatter in phase 2)
     u32 hist_block0;
 };
@@ -379,8 +387,9 @@ __global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
     // range streams HBM for the rest of the launch
     if (blockIdx.x < o.dir_block0) evm_open_small_tables(o, blockIdx.x);
     else if (blockIdx.x < o.hist_block0) dirb_events_row(o.dir, (blockIdx.x - o.dir_block0) * blockDim.x + threadIdx.x);
-    else if (blockIdx.x < o.rw_block0) evm_state_hist_body(blockIdx.x - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally);
-    else rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (blockIdx.x - o.rw_block0) * blockDim.x + threadIdx.x);
+    else if (blockIdx.x < o.rw_block0) evm_state_hist_body(blockIdx.x - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally, o.sort.defer_count);
+    else if (blockIdx.x < o.rec_block0) rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (blockIdx.x - o.rw_block0) * blockDim.x + threadIdx.x);
+    else evm_step_record_quad(o.steps, o.n_steps, o.step_recs, (blockIdx.x - o.rec_block0) * blockDim.x + threadIdx.x);
 }
 // Phase 2.  The generic RW index is only needed when the rows are not dense: the blocks are always launched (the host does
 // not know the verdict), the work is conditional; grid-stride so that the idle case is 256 blocks that exit at once.
@@ -609,7 +618,7 @@ static int build_index(zk_session* s, ZkTable& t) {
 static int session_common_init(zk_session* s) {
     int rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally));
     if (rc) return rc;
-    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(2), 0, s->stream, s->d_tally);
+    hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(2), 0, s->stream, s->d_tally, (u32*)nullptr);
     s->tally_last = s->d_tally;
     rc = dev_alloc(s, (void**)&s->d_status, (size_t)s->n * sizeof(u32));
     if (rc) return rc;
@@ -687,7 +696,7 @@ static int evm_build_perm(zk_session* s) {
     u32* h_cur = (s->evm_pass & 1u) ? s->d_hist2 : s->d_hist;
     u32* h_next = (s->evm_pass & 1u) ? s->d_hist : s->d_hist2;
     s->evm_pass++;
-    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + ZK_HIST_BLOCK - 1) / ZK_HIST_BLOCK), dim3(ZK_HIST_BLOCK), 0, s->stream, s->evm.steps, n, h_cur, s->d_cursor, s->d_bin16, s->d_tally);
+    hipLaunchKernelGGL(evm_state_hist_kernel, dim3((n + ZK_HIST_BLOCK - 1) / ZK_HIST_BLOCK), dim3(ZK_HIST_BLOCK), 0, s->stream, s->evm.steps, n, h_cur, s->d_cursor, s->d_bin16, s->d_tally, s->evm.defer_count);
     hipLaunchKernelGGL(evm_state_scatter_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, s->stream, s->d_bin16, n, h_cur, h_next, s->d_cursor,
                        s->d_group_start, s->d_perm);
     HIP_TRY(hipGetLastError());
@@ -781,6 +790,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         s->d_status = (u32*)(zero + dyn_bytes + 2 * hist_bytes);
         u32* const dir_last = (u32*)(zero + dyn_bytes + 2 * hist_bytes + status_bytes);
         E.dyn = dyn;
+        E.defer_count = &dyn->n_deferred;
+        if ((rc = dev_alloc(s, (void**)&E.defer_list, (size_t)E.n_pairs * sizeof(u32)))) goto fail;
         if ((rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally)))) goto fail;
         s->tally_last = s->d_tally;
         {
@@ -844,7 +855,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
         if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)E.n_pairs * sizeof(uint16_t)))) goto fail;
         if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD) * sizeof(u32)))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD + 2 * EVM_HOT_BLOCK) * sizeof(u32)))) goto fail;  // + slack: the hot kernel reads perm[t] for every lane of its grid
         const bool sorted = !(opts & ZK_OPT_NO_STATE_SORT);
         o.hist_block0 = o.dir_block0 + dir_row_blocks;
         u32 hist_blocks = 0, scatter_blocks = 0;
@@ -852,13 +863,25 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             o.sort.steps = E.steps; o.sort.n_pairs = E.n_pairs; o.sort.hist = s->d_hist; o.sort.hist_next = s->d_hist2;
             o.sort.taken = s->d_cursor; o.sort.bin16 = s->d_bin16; o.sort.group_start = s->d_group_start; o.sort.perm = s->d_perm;
             o.sort.tally = s->d_tally;
+            o.sort.defer_count = E.defer_count;
             hist_blocks = (E.n_pairs + 255u) / 256u;
             scatter_blocks = (E.n_pairs + EVM_OPEN_P2_BLOCK - 1u) / EVM_OPEN_P2_BLOCK;
             s->evm_pass = 1;        // the next pass's histogram is d_hist2 (cleared by this scatter)
             s->perm_ready = true;
         }
         o.rw_block0 = o.hist_block0 + hist_blocks;
-        const u32 grid1 = o.rw_block0 + rw_row_blocks;
+        // packed step records (evm_circuit.hpp "step records"): the other streaming range of the launch
+        o.rec_block0 = o.rw_block0 + rw_row_blocks;
+        u32 rec_blocks = 0;
+        E.step_recs = nullptr;
+        if (!(opts & ZK_OPT_SINGLE_PASS)) {
+            u32* recs = nullptr;
+            if ((rc = dev_alloc(s, (void**)&recs, (size_t)t->n_steps * EVM_REC_WORDS * sizeof(u32)))) goto fail;
+            o.steps = E.steps; o.n_steps = (u32)t->n_steps; o.step_recs = recs;
+            E.step_recs = recs;
+            rec_blocks = (u32)((t->n_steps + 63) / 64);  // four lanes per step
+        }
+        const u32 grid1 = o.rec_block0 + rec_blocks;
         hipLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, o);
         {
             const u32 dir_blocks = want_dir ? DIRB_MAX_ENTRIES / EVM_OPEN_P2_BLOCK : 0u;
@@ -886,7 +909,7 @@ fail:
 extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_evm_verify: result is null");
     zk_session* s = nullptr;
-    int rc = zk_evm_open(t, opts, &s);
+    int rc = zk_evm_open(t, opts | ZK_OPT_SINGLE_PASS, &s);  // one pass: the step records would not pay for themselves
     if (rc) return rc;
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
@@ -1671,6 +1694,15 @@ extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_h
     return zk_set_range(s, row_lo, row_hi);
 }
 
+// tuning aid (not part of the public ABI): the pairs the fast EVM kernel deferred to the general build in the last pass
+extern "C" int zk_debug_read_deferred(zk_session* s, uint32_t* count, uint32_t* list, uint32_t max) {
+    if (!s || s->kind != SESSION_EVM || !s->evm.defer_count) return -1;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(count, s->evm.defer_count, 4, hipMemcpyDeviceToHost));
+    const uint32_t n = *count < max ? *count : max;
+    if (n && list) HIP_TRY(hipMemcpy(list, s->evm.defer_list, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 // tuning aid (not part of the public ABI): copy the phase timestamps of the last pass
 extern "C" int zk_debug_read_prof(zk_session* s, unsigned long long* out) {
     if (!s || !s->evm.prof) return -1;
@@ -1739,7 +1771,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
-        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, s->stream, s->d_tally);
+        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, s->stream, s->d_tally, s->kind == SESSION_EVM ? s->evm.defer_count : (u32*)nullptr);
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
     // no separate event packets between the sort passes and the evaluation kernels
