@@ -7,8 +7,8 @@ is one device pass (`zk_evm_verify`); arguments, the dummy EndBlock step and the
 the first failing pair decides — an AssertionError there is swallowed and re-raised iff `success`
 (main.py:36-44), any other exception class propagates as is.
 """
-from . import oneshot
-from .errors import KIND_ASSERT, exception_for_code
+from . import oneshot, replay
+from .errors import KIND_UNSUPPORTED, exception_for_code
 from .evm_tables import ExecutionState
 from .flatten import flatten_evm
 from .objects import Word  # noqa: F401  (re-exported: callers build code hashes with it)
@@ -45,13 +45,30 @@ def verify_steps(tables, steps, begin_with_first_step=False, end_with_last_step=
     if len(steps) < 2:
         assert success  # no pair, no exception (main.py:40-44)
         return None
-    res, _ = oneshot.evm_verify(flatten_evm(tables, steps), begin_with_first_step, end_with_last_step)
+    res, status = oneshot.evm_verify(flatten_evm(tables, steps), begin_with_first_step, end_with_last_step)
     exception = None
     if not res.ok:
-        exc = exception_for_code(res.first_fail_code, f"EVM circuit step {res.first_fail_row}")
-        if res.first_fail_kind != KIND_ASSERT:
-            raise exc
-        exception = exc
+        # The first failing pair decides (the reference's loop stops there).  Failure replay (replay.py): where the device has
+        # no verdict (word cells outside the wire domain: kind UnsupportedOnDevice) — or for every failure, on request — the
+        # pair is evaluated by the reference's own verify_step on the caller's own objects; a pair the reference accepts does
+        # not decide, the next failing pair does.
+        mode = replay.replay_mode()
+        can_replay = mode != "never" and replay.is_reference_tables(tables) and replay.reference_available()
+        for row in (int(j) for j in status.nonzero()[0]):
+            code = int(status[row])
+            exc = exception_for_code(code, f"EVM circuit step {row}")
+            if can_replay and (mode == "always" or (code >> 24) == KIND_UNSUPPORTED):
+                try:
+                    replay.replay_step(tables, steps, row, begin_with_first_step, end_with_last_step)
+                except AssertionError as e:  # main.py:36-38: swallowed, decides through `success`
+                    exc = e
+                else:
+                    if (code >> 24) == KIND_UNSUPPORTED:
+                        continue  # the reference accepts this pair
+            if not isinstance(exc, AssertionError):
+                raise exc
+            exception = exc
+            break
     if success:
         if exception:
             raise exception
