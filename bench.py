@@ -17,8 +17,9 @@ The JSON line carries, next to the contract's fields:
                   VALU-issue roofline of the same kernel (SQ counters).  `bound` names what binds the kernel.
   fresh_witness   what a verifier pays for a witness it sees once: session open (index / packed-key / directory builds on
                   the device, inputs resident) + one pass over cold caches, and the one-shot C entry (zk_evm_verify).
-  cpu_baseline    `port` (oracle/, pure Python, dict-indexed lookups), `hostsim` (the kernels' own sources built for the CPU,
-                  tests/hostsim: the "optimised CPU" line) — both timed here on a bounded sample — and `reference`: the
+  cpu_baseline    `port` (oracle/, pure Python, dict-indexed lookups), `cpu_backend_1core` / `cpu_backend_allcores` (libzkevm_cpu.so:
+                  the kernels' own sources built for the host behind the same C ABI, OpenMP: the "optimised CPU" line) — timed
+                  here on a bounded sample — and `reference`: the
                   unmodified reference timed in the build container (tools/time_reference.py -> profiles/r*_cpu_reference.json;
                   /root/reference does not exist on the GPU box, so this leg is a CROSS-BOX figure and says so).
   host_path       marshalling (Python objects -> wire arrays, flatten.py) and H2D staging, reported separately.
@@ -716,44 +717,50 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
 def cpu_baseline(workload, w):
     """CPU legs on rank 0's host cores, bounded samples.  `value` is the reference's own figure when the committed
     build-container measurement exists (kind "reference"), else the oracle port's."""
-    import ctypes
-    import subprocess
-
     import numpy as np
 
     cores_total = os.cpu_count()
     ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")), reverse=True)
     ref = json.load(open(ref_file[0])) if ref_file else None
-    so = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
-    if not os.path.exists(so):
-        subprocess.check_call([os.path.join(ROOT, "tests", "hostsim", "build.sh")])
-    sim = ctypes.CDLL(so)
-    vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
     legs = {}
     if workload in ("evm", "super"):
         from oracle import evm_oracle, wire
-        from tests.evm_cases import hostsim_status
 
-        ev = w.wire_h if workload == "evm" else w.env["parts"]["evm"]
+        from tests.evm_cases import to_witness
+
+        ev = w.wire_h if workload == "evm" else dict(w.env["parts"]["evm"])
+        if workload == "super" and "copy_events" in w.env["parts"]:
+            # the block's copy table on the host (on the device it is zk_copy_assign's output): the oracle's restatement of the same
+            # assignment — test infrastructure, used here only to hand the CPU legs the witness the device evaluates
+            from oracle import copy_assign_oracle
+            from zkevm_specs_amd.wire import rows_to_rowmajor
+
+            ce = w.env["parts"]["copy_events"]
+            ev["copy"] = rows_to_rowmajor(copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"],
+                                                                     ce["offsets"], ce["r"])[2], 14)
         sample = min(int(ev["steps"].shape[0]) - 1, 1 << 15)
-        W = evm_oracle.EvmWitness(wire.rowmajor_to_rows(ev["steps"][: sample + 1]), wire.rowmajor_to_rows(ev["rw"]),
-                                  ev["rw_flags"], wire.rowmajor_to_rows(ev["bytecode"]))
+        W = to_witness(dict({k: v for k, v in ev.items() if k != "meta"}, steps=ev["steps"][: sample + 1]))
         tc = time.perf_counter()
         st = evm_oracle.verify_steps(W)
         tc = time.perf_counter() - tc
         assert not any(st)
         legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
                         "sample": f"first {sample} step pairs of the same trace, pure-Python oracle with dict-indexed lookups (oracle/evm_oracle.py)"}
+        from zkevm_specs_amd import _lib as zlib, engine as zengine
+
         hs = min(int(ev["steps"].shape[0]) - 1, 1 << 18)
         sub = {k: v for k, v in ev.items() if k != "meta"}
         sub["steps"] = ev["steps"][: hs + 1]
-        tc = time.perf_counter()
-        st = hostsim_status(sim, sub)
-        tc = time.perf_counter() - tc
-        assert not any(st)
-        legs["hostsim"] = {"value": hs / tc, "unit": "rows/s", "cores": 1,
-                           "sample": f"{hs} step pairs, the kernels' own device functions compiled for the host (tests/hostsim, g++ -O2), "
-                                     "index build included: the optimised-CPU line"}
+        for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
+            zlib.set_cpu_threads(threads)
+            tc = time.perf_counter()
+            with zengine.open_evm(sub, device="cpu") as cs:
+                t_open = time.perf_counter() - tc
+                r_cpu = cs.run()
+            assert r_cpu.ok
+            legs[key] = {"value": hs / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms, "open_s": t_open,
+                         "sample": f"{hs} step pairs through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernels' own per-step functions compiled for the "
+                                   "host, OpenMP over the pairs; csrc/cpu_backend.cpp), one pass with tables and indices resident — the optimised-CPU line"}
         if ref and "evm" in ref:
             e = ref["evm"]
             legs["reference"] = {"value": e["extrapolated_2p18"]["pairs_per_s"], "unit": "rows/s", "cores": 1,
@@ -766,29 +773,28 @@ def cpu_baseline(workload, w):
         from oracle import sign_oracle
 
         tx, sg = w.env["tx"], w.env["sig"]
+        from zkevm_specs_amd import _lib as zlib, oneshot as zoneshot
+
         n = int(tx["bytes"].shape[0])
-        sample = min(n, 1 << 9)
-        r4 = np.frombuffer(int(0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221).to_bytes(32, "little"), dtype="<u8").copy()
-        tc = time.perf_counter()
-        for wire_, layout, is_sig in ((tx, 1, 0), (sg, 2, 1)):
-            b = np.ascontiguousarray(wire_["bytes"][:sample])
-            meta = np.ascontiguousarray(wire_["meta"][:sample]).copy()
-            est = np.zeros(sample, dtype=np.uint32)
-            v = np.ascontiguousarray(meta[:, 3])
-            sim.sim_ecdsa_verify(vp(b), ctypes.c_uint32(layout), vp(v), ctypes.c_uint32(1), ctypes.c_uint64(sample), vp(est))
-            meta[:, 0] = est
-            cells = np.ascontiguousarray(wire_["cells"][:, :sample])
-            txr = np.ascontiguousarray(wire_["tx_rows"][: 12 * sample]) if not is_sig else np.zeros((0, 5, 4), dtype=np.uint64)
-            txf = np.ascontiguousarray(wire_["tx_flags"][: 12 * sample]) if not is_sig else np.zeros(0, dtype=np.uint32)
-            st = np.zeros(sample, dtype=np.uint32)
-            kk = np.ascontiguousarray(wire_["keccak"])
-            sim.sim_sign_verify(vp(b), vp(cells), vp(meta), ctypes.c_uint64(sample), vp(kk), ctypes.c_uint64(kk.shape[0]), vp(txr), vp(txf),
-                                ctypes.c_uint64(txr.shape[0]), vp(r4), ctypes.c_uint32(is_sig), vp(st))
-            assert not st.any(), (is_sig, st[:8])
-        tc = time.perf_counter() - tc
-        legs["hostsim"] = {"value": sample / tc, "unit": "txs/s", "cores": 1,
-                           "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications, the kernels' own device functions compiled "
-                                     "for the host (tests/hostsim, g++ -O2)"}
+        R_TX = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
+        r4 = np.frombuffer(int(R_TX).to_bytes(32, "little"), dtype="<u8").copy()
+        for threads, key, sample in ((1, "cpu_backend_1core", min(n, 1 << 9)), (cores_total, "cpu_backend_allcores", min(n, 1 << 12))):
+            zlib.set_cpu_threads(threads)
+            tc = time.perf_counter()
+            for wire_, layout, is_sig in ((tx, 1, False), (sg, 2, True)):
+                wslice = {k: (np.ascontiguousarray(v[:sample]) if k in ("bytes", "meta") else (np.ascontiguousarray(v[:, :sample]) if k == "cells" else v))
+                          for k, v in wire_.items()}
+                if not is_sig:
+                    wslice["tx_rows"], wslice["tx_flags"] = wire_["tx_rows"][: 12 * sample], wire_["tx_flags"][: 12 * sample]
+                _, est = zoneshot.ecdsa_verify(wslice["bytes"], np.ascontiguousarray(wslice["meta"][:, 3]) if is_sig else None, layout=layout, device="cpu")
+                wslice["meta"] = wslice["meta"].copy()
+                wslice["meta"][:, 0] = est
+                r_cpu, _ = zoneshot.sign_verify(wslice, R_TX, is_sig, device="cpu")
+                assert r_cpu.ok, (is_sig, r_cpu)
+            tc = time.perf_counter() - tc
+            legs[key] = {"value": sample / tc, "unit": "txs/s", "cores": threads,
+                         "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications through libzkevm_cpu.so (ZK_BACKEND=cpu: "
+                                   "the kernels' own per-unit functions compiled for the host, OpenMP; csrc/cpu_backend.cpp), wall clock of the one-shot entries"}
         from oracle import ecdsa_oracle, wire
 
         sample_p = min(n, 1 << 5)
@@ -820,25 +826,27 @@ def cpu_baseline(workload, w):
         tc = time.perf_counter() - tc
         legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
                         "sample": f"first {sample} rows of the same witness, pure-Python oracle (oracle/state_oracle.py)"}
-        c, f, m = np.ascontiguousarray(cols), np.ascontiguousarray(flags), np.ascontiguousarray(mpt)
-        st = np.zeros(c.shape[1], dtype=np.uint32)
-        tc = time.perf_counter()
-        sim.sim_state_verify(vp(c), vp(f), ctypes.c_uint64(c.shape[1]), vp(m), ctypes.c_uint64(m.shape[0]), vp(st))
-        tc = time.perf_counter() - tc
-        assert not st.any()
-        legs["hostsim"] = {"value": c.shape[1] / tc, "unit": "rows/s", "cores": 1,
-                           "sample": f"all {c.shape[1]} rows, the kernel's own device functions compiled for the host (tests/hostsim, g++ -O2)"}
+        from zkevm_specs_amd import _lib as zlib, engine as zengine
+
+        for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
+            zlib.set_cpu_threads(threads)
+            with zengine.open_state(cols, flags, mpt, device="cpu") as cs:
+                r_cpu = cs.run()
+            assert r_cpu.ok
+            legs[key] = {"value": int(cols.shape[1]) / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms,
+                         "sample": f"all {int(cols.shape[1])} rows through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernel's own per-row function compiled for "
+                                   "the host, OpenMP over the rows; csrc/cpu_backend.cpp), one pass with the witness and the MPT index resident"}
         if ref and "state" in ref:
             legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
                                  "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
                                            f"({os.path.basename(ref_file[0])})"}
-    head = legs.get("reference") or legs.get("port") or legs["hostsim"]
+    head = legs.get("reference") or legs.get("port") or legs["cpu_backend_1core"]
     return {"value": head["value"], "unit": head["unit"], "cores": 1,
             "kind": "reference" if "reference" in legs else "port",
             "sample": head["sample"], "legs": legs,
             "this_box_cores_total": cores_total,
             "reference_measured_on": None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: /root/reference does not exist "
-                                                               "here, so the `reference` leg is a cross-box figure; `port` and `hostsim` are timed on this box"),
+                                                               "here, so the `reference` leg is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box"),
             }
 
 

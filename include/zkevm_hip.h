@@ -71,8 +71,9 @@ void zk_shutdown(void);
  * here, i.e. "engine's own": to order the engine with work of another library, hand over a real (non-default) stream. */
 int zk_set_stream(void* hip_stream);
 const char* zk_last_error(void);
-/* BN254-Fr vector ops on the device for tests: op 0 add, 1 sub, 2 mul, 3 montmul, 4 neg.
- * (reference: FQ.__add__/__sub__/__mul__/__neg__ via py_ecc, util/arithmetic.py:41) */
+/* BN254-Fr vector ops on the device: op 0 add, 1 sub, 2 mul, 3 montmul, 4 neg, 5 inv (of a; inv(0) = 0 as py_ecc's
+ * prime_field_inv), 6 div (a * inv(b)).
+ * (reference: FQ.__add__/__sub__/__mul__/__neg__/__truediv__ via py_ecc and FQ.inv, util/arithmetic.py:41-60) */
 int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts);
 
 /* ---- State circuit: replaces the `for row: check_state_row(row, prev, next, tables)` loop
@@ -257,12 +258,16 @@ int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, u
  *             util/ec.py:93).
  *      v: optional recovery ids, v[i * v_stride] (the Sig circuit's chip builds Signature(vrs=[v, r, s]) — for Sig
  *      units pass meta + 3 with stride 4; NULL = the Tx circuit's fixed 0).  Status per signature: 0 verified, 1 not verified, (ZK_KIND_UNSUPPORTED << 24) | 1 = eth_keys
- *      BadSignature (v outside {0, 1}, r or s outside (0, N)), (ZK_KIND_UNSUPPORTED << 24) | 2 = a public-key coordinate >= P
- *      (outside the engine's domain).  Public keys that are not on the curve are evaluated with eth-keys' Jacobian case
- *      analysis (a Y == 0 point is the point at infinity, inv(0) == 0), so their verdicts are reproducible too.
+ *      BadSignature (v outside {0, 1}, r or s outside (0, N)), (ZK_KIND_UNSUPPORTED << 24) | 2 = a public key with y == P exactly
+ *      (the one value outside the engine's domain: eth-keys' `if not p[1]` sees it as non-zero; any other coordinate >= P is
+ *      reduced mod P, as eth-keys' formulas do implicitly).  Public keys that are not on the curve are evaluated with eth-keys'
+ *      Jacobian case analysis (a Y == 0 point is the point at infinity, inv(0) == 0), so their verdicts are reproducible too.
  *      out_dev (DEVICE pointer, optional): out_dev[i * out_stride] = status, e.g. meta + 0 with stride 4 to fill the
  *      units' meta column in place.  zk_launch / zk_collect / zk_read_status as for the circuits (the tally counts
- *      the signatures that did not verify). */
+ *      the signatures that did not verify).
+ *      Device memory: the kernel keeps a 1,440-byte table of the key's multiples per lane (one lane per signature above 2^16
+ *      signatures, a lane pair below): at most 2^17 lanes' worth (189 MB) is allocated per session; larger batches run as
+ *      consecutive launches over the same tables. */
 int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                   uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out);
 int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,

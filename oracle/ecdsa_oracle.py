@@ -90,8 +90,11 @@ def verify(pk_x, pk_y, z, r, s, v=None):
         return BAD_SIGNATURE
     if not (0 < r < N and 0 < s < N):
         return BAD_SIGNATURE
-    if pk_x >= P or pk_y >= P:
+    # coordinates >= P: eth-keys' formulas reduce mod P as they go, so the verdict is that of (x mod P, y mod P) — except
+    # for y == P, which its `if not p[1]` infinity test sees as non-zero (csrc/secp256k1.hpp ecdsa_prepare): out of domain
+    if pk_y == P:
         return KEY_RANGE
+    pk_x, pk_y = pk_x % P, pk_y % P
     w = pow(s, -1, N)
     u1, u2 = z * w % N, r * w % N
     a = from_jac(jac_mul((G[0], G[1], 1), u1))

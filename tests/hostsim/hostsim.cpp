@@ -55,6 +55,8 @@ extern "C" void sim_fr_op(int op, const u64* a, const u64* b, u64* out, u64 n) {
         case 2: r = fr_mul(x, y); break;
         case 3: r = fr_mont(x, y); break;
         case 4: r = fr_neg(x); break;
+        case 5: r = fr_inv(x); break;
+        case 6: r = fr_div(x, y); break;
         default: r = fr_zero();
         }
         for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
@@ -155,6 +157,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
     }
     for (u64 i = 0; i + 1 < n_steps; i++) {  // as on the device: the hot and the cold instantiation split the states
         u32 c = evm_check_step<EVM_GROUP_ALL>(a, i);
+        if (c == ZK_NOT_MINE) c = evm_check_step<EVM_GROUP_WARM>(a, i);
         if (c == ZK_NOT_MINE) c = evm_check_step<EVM_GROUP_COLD>(a, i);
         status[i] = c;
     }
@@ -316,7 +319,7 @@ extern "C" int sim_state_assign(const u64* ops, const u32* op_flags, u64 n, u64*
 extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
     EcdsaArgs a;
-    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.out = nullptr; a.out_stride = 0;
+    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
     a.msg_be = layout != 1u;
     for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
     std::vector<u32> tab(15 * 24 * 2);
@@ -328,7 +331,7 @@ extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, 
 extern "C" int sim_ecdsa_verify_pairs(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
     EcdsaArgs a;
-    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.out = nullptr; a.out_stride = 0;
+    a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
     a.msg_be = layout != 1u;
     for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
     std::vector<u32> tab(15 * 24 * 2);

@@ -1,0 +1,122 @@
+"""The CPU backend behind the same C ABI (libzkevm_cpu.so, ZK_BACKEND=cpu; csrc/cpu_backend.cpp): BASELINE configs[0] — the
+Bytecode circuit over a 256-byte contract, "pure CPU path (plumbing, no GPU)" — and a slice of every other circuit, through
+the real boundary (ctypes -> C ABI -> the kernels' own per-row functions on the host cores), against the oracle.  Runs in a
+child process because the backend is chosen when zkevm_specs_amd._lib is first imported."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["ZK_ROOT"])
+from zkevm_specs_amd import _lib, engine, oneshot
+assert _lib.BACKEND == "cpu" and _lib.LIB_PATH.endswith("libzkevm_cpu.so")
+from oracle import row_oracles as ro, state_oracle, wire, sign_oracle as so, ecdsa_oracle
+from tests.evm_cases import golden_files, load_cases, oracle_status
+from zkevm_specs_amd.synth import synth_bytecode_witness, synth_state_witness, synth_tx_witness, synth_exp_witness
+out = {}
+
+# BASELINE configs[0]: 256-byte contract, k = 9 -> 512 rows (257 real), random keccak randomness; valid and tampered
+code = bytes(np.random.default_rng(1).integers(0, 256, 256, dtype=np.uint8))
+r = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % (1 << 253)
+cols, keccak = synth_bytecode_witness([code], 9, r)
+res, st = oneshot.bytecode_verify(cols, keccak, r)
+assert res.ok and res.rows_evaluated == 512 and not st.any()
+cols[6, 17, 0] ^= 1
+cols[9, 300, 0] ^= 1
+res, st = oneshot.bytecode_verify(cols, keccak, r)
+exp = ro.bytecode_verify_rows(wire.colmajor_to_rows(cols), wire.rowmajor_to_rows(keccak), r)
+assert st.tolist() == exp and res.fail_count == sum(1 for c in exp if c) >= 1 and res.first_fail_row == next(i for i, c in enumerate(exp) if c)
+out["bytecode_rows"] = 512
+
+# State circuit, sessions + ranges
+c, f, m = synth_state_witness(4096, seed=5)
+c[1, 1000, 0] = 2
+with engine.open_state(c, f, m) as s:
+    res = s.run()
+    st = s.read_status()
+    exp = state_oracle.verify_rows(wire.colmajor_to_rows(c), f, wire.rowmajor_to_rows(m))
+    assert st.tolist() == exp and res.fail_count == sum(1 for x in exp if x) >= 1
+    s.set_range(2000, 3000)
+    assert s.run().ok and s.collect().rows_evaluated == 1000
+out["state_rows"] = 4096
+
+# EVM circuit: a slice of the golden cases (kind and site) through zk_evm_verify
+n = 0
+for fn in golden_files(os.path.join(os.environ["ZK_ROOT"], "tests", "golden"))[::5]:
+    for name, w, opts, ref_kind in list(load_cases(fn))[::7]:
+        res, st = oneshot.evm_verify(w, bool(opts[0]), bool(opts[1]))
+        assert st.tolist() == oracle_status(w, opts), (fn, name)
+        n += 1
+out["evm_cases"] = n
+
+# Exp circuit
+e = synth_exp_witness(256, seed=3)
+res, st = oneshot.exp_verify(e)
+assert st.tolist() == ro.exp_verify_rows(wire.colmajor_to_rows(e))
+
+# Tx circuit with the ECDSA column computed by the same library
+R = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
+tx = synth_tx_witness(24, R, seed=4, signed=True)
+res_e, st_e = oneshot.ecdsa_verify(tx["bytes"], None, layout=1)
+assert not st_e.any()
+tx["meta"][:, 0] = st_e
+tx["cells"][1, 5, 0] ^= 1
+res, st = oneshot.sign_verify(tx, R, False)
+exp = so.verify_units(tx["bytes"], tx["cells"], tx["meta"], wire.rowmajor_to_rows(tx["keccak"]), R, 0, wire.rowmajor_to_rows(tx["tx_rows"]), tx["tx_flags"])
+assert st.tolist() == exp and res.fail_count == 1
+
+# Fr ops incl. inv / div
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+A = [0, 1, 8, P - 1, 2**200 + 12345]; B = [5, 7, P - 2, 3, 2**128]
+a, b = wire.ints_to_cells(A), wire.ints_to_cells(B)
+inv = lambda x: pow(x, -1, P) if x else 0
+assert wire.cells_to_ints(engine.fr_op(5, a, b)) == [inv(x) for x in A]
+assert wire.cells_to_ints(engine.fr_op(6, a, b)) == [x * inv(y) % P for x, y in zip(A, B)]
+assert wire.cells_to_ints(engine.fr_op(2, a, b)) == [x * y % P for x, y in zip(A, B)]
+
+# what the CPU backend does not do says so
+try:
+    oneshot.state_assign(np.zeros((12, 4, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint32))
+except _lib.EngineError as ex:
+    assert "not implemented by the CPU backend" in str(ex)
+else:
+    raise AssertionError("zk_state_assign should be refused")
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_cpu_backend_through_the_c_abi(tmp_path):
+    so = os.path.join(ROOT, "zkevm_specs_amd", "libzkevm_cpu.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    script = tmp_path / "child.py"
+    script.write_text(CHILD)
+    env = dict(os.environ, ZK_BACKEND="cpu", ZK_ROOT=ROOT, OMP_NUM_THREADS="4")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("RESULT ")]
+    out = json.loads(line[0][7:])
+    assert out["bytecode_rows"] == 512 and out["evm_cases"] >= 20
+
+
+def test_cpu_library_exports_the_declared_abi():
+    import ctypes
+    import re
+
+    so = os.path.join(ROOT, "zkevm_specs_amd", "libzkevm_cpu.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    lib = ctypes.CDLL(so)
+    text = open(os.path.join(ROOT, "include", "zkevm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for sym in sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text))):
+        assert hasattr(lib, sym), f"{sym} declared in include/zkevm_hip.h but not exported by libzkevm_cpu.so"

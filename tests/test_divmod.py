@@ -50,3 +50,26 @@ def test_u256_and_u512_long_division(hostsim):
         got = _run(hostsim, wide, pairs)
         for (n, d), (q, r) in zip(pairs, got):
             assert (q, r) == (n // d, n % d), (wide, hex(n), hex(d), hex(q), hex(r))
+
+
+def test_fr_inv_and_div_match_python(hostsim):
+    """FQ.inv / FQ division (util/arithmetic.py:59-60; py_ecc's prime_field_inv(0) == 0): the field inverse used by `zk_fr_op`
+    ops 5 / 6, through the CPU build of the same source, against Python's pow(x, -1, p)."""
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(7)
+    edge = [0, 1, 2, P - 1, P - 2, 8, 4, 2**128, 2**253, pow(8, -1, P)]
+    A = edge + [rng.randrange(P) for _ in range(300)]
+    B = list(reversed(edge)) + [rng.randrange(P) for _ in range(300)]
+    a = np.array([_pack(x, 4) for x in A], dtype=np.uint64)
+    b = np.array([_pack(x, 4) for x in B], dtype=np.uint64)
+    vp = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+    unpack = lambda row: sum(int(v) << (64 * k) for k, v in enumerate(row))  # noqa: E731
+    inv = lambda x: pow(x, -1, P) if x else 0  # noqa: E731
+    for op, f in ((5, lambda x, y: inv(x)), (6, lambda x, y: x * inv(y) % P)):
+        out = np.zeros_like(a)
+        hostsim.sim_fr_op(ctypes.c_int(op), vp(a), vp(b), vp(out), ctypes.c_uint64(len(A)))
+        assert [unpack(r) for r in out] == [f(x, y) for x, y in zip(A, B)], op
+    # the reference's own use: is_mul / is_div / is_mod come out as exactly 0 / 1 after FQ(8).inv() (execution/mul_div_mod.py:14-16)
+    for opcode, want in ((2, (1, 0, 0)), (4, (0, 1, 0)), (6, (0, 0, 1))):
+        got = ((4 - opcode) * (6 - opcode) * inv(8) % P, (opcode - 2) * (6 - opcode) * inv(4) % P, (opcode - 2) * (opcode - 4) * inv(8) % P)
+        assert got == want

@@ -64,6 +64,8 @@ def _hostile_cases(seed, n):
             x, y = rng.randrange(E.P), rng.randrange(E.P)
         elif c == 8:
             x = rng.choice([E.P, E.P + 1, (1 << 256) - 1])
+        elif c == 9:
+            y = rng.choice([E.P, E.P + 1, (1 << 256) - 1, E.P + 7])
         cases.append((x, y, z, r, s))
         vs.append(v)
     return E.pack(cases), np.array(vs, dtype=np.uint32)
@@ -126,6 +128,35 @@ def test_kernel_logic_group_law_edge_cases(hostsim):
     exp = E.verify_packed(sigs, None)
     assert _hostsim(hostsim, sigs, None, 0) == exp
     assert sum(1 for e in exp if e == 0) >= 25 and sum(1 for e in exp if e == 1) >= 25
+
+
+def test_out_of_range_key_coordinates_match_the_eth_keys_standin():
+    """Public-key coordinates >= P (the native backend of eth-keys 0.4.0 does not range-check them; oracle/refshim/eth_keys
+    restates it): the verdict is that of the coordinates mod P, except for y == P exactly, which stays out of domain
+    (csrc/secp256k1.hpp ecdsa_prepare).  Needs the refshim on the path (build container)."""
+    import random
+    import sys
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "refshim")
+    sys.path.insert(0, shim)
+    try:
+        from eth_keys import KeyAPI
+    finally:
+        sys.path.remove(shim)
+    rng = random.Random(5)
+    n_checked = 0
+    for (x, y, z, r, s, v) in E.sign_batch(24, 77):
+        for x2, y2 in ((E.P + rng.randrange(1 << 32), y), (x, E.P + 1 + rng.randrange(1 << 32)), ((1 << 256) - 1, (1 << 256) - 1),
+                       (x % (1 << 32) + E.P, y), (x, E.P)):
+            got = E.verify(x2, y2, z, r, s, v)
+            if y2 == E.P:
+                assert got == E.KEY_RANGE
+                continue
+            sig = KeyAPI.Signature(vrs=(v, r, s))
+            want = KeyAPI().ecdsa_verify(z.to_bytes(32, "big"), sig, KeyAPI.PublicKey(x2.to_bytes(32, "big") + y2.to_bytes(32, "big")))
+            assert got == (0 if want else 1), (hex(x2), hex(y2))
+            n_checked += 1
+    assert n_checked >= 90
 
 
 def test_oracle_matches_reference_chips(golden_dir):

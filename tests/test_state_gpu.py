@@ -19,7 +19,7 @@ def _run(cols, flags, mpt):
 
 
 def test_fr_ops_known_answers():
-    """Device Fr add/sub/mul/montmul/neg vs Python big-int (bit-exact)."""
+    """Device Fr add/sub/mul/montmul/neg/inv/div vs Python big-int (bit-exact)."""
     import random
 
     rng = random.Random(1)
@@ -28,8 +28,9 @@ def test_fr_ops_known_answers():
     B = [rng.choice(edge) if rng.random() < 0.3 else rng.randrange(P) for _ in range(20000)]
     a, b = wire.ints_to_cells(A), wire.ints_to_cells(B)
     rinv = pow(1 << 256, -1, P)
+    inv = lambda x: pow(x, -1, P) if x else 0  # noqa: E731  (py_ecc's prime_field_inv(0) == 0)
     fns = [lambda x, y: (x + y) % P, lambda x, y: (x - y) % P, lambda x, y: x * y % P,
-           lambda x, y: x * y * rinv % P, lambda x, y: (-x) % P]
+           lambda x, y: x * y * rinv % P, lambda x, y: (-x) % P, lambda x, y: inv(x), lambda x, y: x * inv(y) % P]
     for op, f in enumerate(fns):
         got = wire.cells_to_ints(engine.fr_op(op, a, b))
         assert got == [f(x, y) for x, y in zip(A, B)], f"op {op}"

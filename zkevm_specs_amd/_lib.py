@@ -1,13 +1,23 @@
 """ctypes binding of libzkevm_hip.so (C ABI: include/zkevm_hip.h).
 
 There is deliberately NO fallback: if the HIP library is missing or no GPU is usable the
-engine raises — the product path never routes through a CPU implementation.
+engine raises — the product path never routes through a CPU implementation on its own.
+
+ZK_BACKEND=cpu (an explicit choice, read once when the library is first loaded) binds the same C ABI to libzkevm_cpu.so
+instead: the kernels' own per-row device functions compiled for the host and run with OpenMP (csrc/cpu_backend.cpp) —
+BASELINE configs[0]'s "pure CPU path" through the real boundary and the optimised-CPU line of bench.py.  It implements the
+verify / open / launch / collect entries of every circuit, the keccak-table and ECDSA entries; not the device-side witness
+assignments, and ZK_OPT_DEVICE_PTRS has no meaning there (inputs are host arrays).
 """
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ZK_HIP_LIB") or os.path.join(_HERE, "libzkevm_hip.so")  # ZK_HIP_LIB: tuning builds (tools/)
+BACKEND = os.environ.get("ZK_BACKEND", "hip")
+if BACKEND not in ("hip", "cpu"):
+    raise ImportError(f"ZK_BACKEND={BACKEND!r}: expected 'hip' (default) or 'cpu'")
+CPU_LIB_PATH = os.path.join(_HERE, "libzkevm_cpu.so")
+LIB_PATH = CPU_LIB_PATH if BACKEND == "cpu" else (os.environ.get("ZK_HIP_LIB") or os.path.join(_HERE, "libzkevm_hip.so"))  # ZK_HIP_LIB: tuning builds (tools/)
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
@@ -102,9 +112,33 @@ def load():
     # torch ships its own libamdhip64.so.7; importing it first makes the dynamic loader bind
     # this library to the SAME HIP runtime instance (one runtime per process: device pointers,
     # streams and events are then interchangeable with torch's).
-    import torch  # noqa: F401
+    if BACKEND == "hip":
+        import torch  # noqa: F401
 
-    lib = ctypes.CDLL(LIB_PATH)
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+_cpu_lib = None
+
+
+def load_cpu():
+    """The CPU backend's library next to the default one (same C ABI; bench.py's optimised-CPU legs call it with
+    `device="cpu"` on the one-shot entries).  Never a fallback: only explicit callers get it."""
+    global _cpu_lib
+    if _cpu_lib is None:
+        if not os.path.exists(CPU_LIB_PATH):
+            raise EngineError(f"{CPU_LIB_PATH} is missing: build it with zkevm_specs_amd/csrc/build.sh")
+        _cpu_lib = _bind(ctypes.CDLL(CPU_LIB_PATH))
+    return _cpu_lib
+
+
+def set_cpu_threads(n):
+    """OpenMP threads of the CPU backend's passes (libgomp's omp_set_num_threads)"""
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+
+
+def _bind(lib):
     vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
     lib.zk_init.argtypes = [ctypes.c_int]
     lib.zk_set_stream.argtypes = [vp]
@@ -146,13 +180,14 @@ def load():
     lib.zk_collect.argtypes = [vp, ctypes.POINTER(ZkResult)]
     lib.zk_read_status.argtypes = [vp, vp]
     lib.zk_close.argtypes = [vp]
-    _lib = lib
     return lib
 
 
 def check(rc, what):
     if rc != 0:
         msg = load().zk_last_error().decode(errors="replace")
+        if not msg and _cpu_lib is not None:
+            msg = _cpu_lib.zk_last_error().decode(errors="replace")
         raise EngineError(f"{what} failed (rc={rc}): {msg}")
 
 
@@ -160,6 +195,8 @@ def init(device=None):
     """Initialise the engine on a HIP device (default: the device an earlier init() of this process selected, else
     LOCAL_RANK, else 0)."""
     global _inited_device
+    if device == "cpu":  # the CPU backend's library, explicitly (see load_cpu)
+        return load_cpu()
     lib = load()
     if device is None:
         device = _inited_device if _inited_device is not None else int(os.environ.get("LOCAL_RANK", "0"))

@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${ZK_BUILD_DIR:-build}
 mkdir -p "$OUT"
-UNITS="zkevm_hip k_state k_evm_hot k_evm_cold k_rows k_assign k_ecdsa"
+UNITS="zkevm_hip k_state k_evm_hot k_evm_cold k_evm_warm k_evm_slow k_rows k_assign k_ecdsa"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage $ZK_EXTRA_FLAGS"
 pids=()
 for u in $UNITS; do
@@ -23,5 +23,9 @@ if [ -n "$ZK_EXTRA_FLAGS" ]; then touch "$OUT/.extra_flags"; else rm -f "$OUT/.e
 OBJS=""
 for u in $UNITS; do OBJS="$OBJS $OUT/$u.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libzkevm_hip.so $OBJS
+# the CPU backend behind the same C ABI (cpu_backend.cpp: the same headers compiled for the host, OpenMP over the rows)
+if [ ! -f ../libzkevm_cpu.so ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name cpu_backend.cpp -o -name build.sh \) -newer ../libzkevm_cpu.so | head -1)" ]; then
+    g++ -O2 -std=c++17 -fopenmp -DZK_HOSTSIM -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-array-bounds -o ../libzkevm_cpu.so cpu_backend.cpp
+fi
 cat $OUT/*.log | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | paste - - - - - - | sed 's/remark: [^ ]* //g; s/\[-Rpass-analysis=kernel-resource-usage\]//g' > "$OUT/resource_usage.txt" || true
 echo "built $(ls -la ../libzkevm_hip.so)"

@@ -1,0 +1,555 @@
+// libzkevm_cpu.so — the C ABI of include/zkevm_hip.h evaluated on the host cores (SURVEY.md §2 native piece vi, §8b
+// `backend` selector, §8d "C++ CPU backend on 1 and all cores").
+//
+// The per-row / per-step device functions of csrc/*.hpp are plain C++ when compiled without hipcc (the ZK_HOSTSIM switch of
+// fr.hpp selects the host flavour of the ZK_HD / ZK_NOINLINE macros); this file puts the same session protocol around them
+// that zkevm_hip.hip puts around the kernels: open = copy the caller's arrays and build the indices, launch = one pass over the
+// rows with an OpenMP parallel-for, collect = the tally, read_status = the per-row codes.  What it is for:
+//   * BASELINE configs[0] ("Bytecode circuit ... pure CPU path (plumbing, no GPU)") through the real boundary;
+//   * the fair optimised-CPU line next to the GPU numbers (bench.py cpu_baseline legs `cpu_backend_1core` / `_allcores`).
+// It is selected explicitly (ZK_BACKEND=cpu -> zkevm_specs_amd/_lib.py loads this library instead of libzkevm_hip.so); nothing
+// falls back to it, and it shares no code with oracle/ (the Python restatement used as the test oracle).
+// Not implemented here (they return an error that says so): the device-side witness assignments (zk_state_assign*,
+// zk_bytecode_assign*, zk_copy_assign*), ZK_OPT_DEVICE_PTRS, zk_session_set_stream.
+#include <stdio.h>
+#include <string.h>
+#include <chrono>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/zkevm_hip.h"
+#include "state_circuit.hpp"
+#include "evm_circuit.hpp"
+#include "host_index.hpp"
+#include "row_circuits.hpp"
+#include "copy_circuit.hpp"
+#include "sign_circuit.hpp"
+#include "keccak_table.hpp"
+#include "secp256k1.hpp"
+#include "pi_circuit.hpp"
+
+static thread_local std::string g_err;
+#define ARG_TRY(cond, msg) do { if (!(cond)) { g_err = msg; return -1; } } while (0)
+static int unsupported(const char* what) {
+    g_err = std::string(what) + ": not implemented by the CPU backend (libzkevm_cpu.so)";
+    return -3;
+}
+
+extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
+extern "C" int zk_init(int) { return 0; }
+extern "C" void zk_shutdown(void) {}
+extern "C" int zk_set_stream(void*) { return 0; }
+
+// ---------------------------------------------------------------------------------------
+// tables: a private copy of the caller's rows + the open-addressing index
+// ---------------------------------------------------------------------------------------
+struct CpuTable {
+    ZkTable t;
+    std::vector<u64> cells;
+    std::vector<u32> flags, slots;
+};
+static void cpu_table(CpuTable& h, const u64* cells, const u32* flags, u64 n, u32 ncells, u64 (*hash_of)(const ZkTable&, u32)) {
+    static const u64 zero_row[64] = {0};
+    static const u32 zero_flag[1] = {0};
+    if (n) h.cells.assign(cells, cells + n * ncells * 4);
+    if (n && flags) h.flags.assign(flags, flags + n);
+    h.t.cells = n ? h.cells.data() : zero_row;  // empty table: one readable zero row (as in the HIP library)
+    h.t.flags = n ? (flags ? h.flags.data() : nullptr) : zero_flag;
+    h.t.n = (u32)n;
+    h.t.ncells = ncells;
+    u32 cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    h.slots.assign(cap, ZK_EMPTY_SLOT);
+    h.t.slots = h.slots.data();
+    h.t.mask = cap - 1;
+    if (hash_of)
+        for (u32 r = 0; r < (u32)n; r++) {
+            u32 s = (u32)hash_of(h.t, r) & h.t.mask;
+            while (h.slots[s] != ZK_EMPTY_SLOT) s = (s + 1) & h.t.mask;
+            h.slots[s] = r;
+        }
+}
+static Fr cell_of(const u64* p) { return fr_load(p); }
+
+// ---------------------------------------------------------------------------------------
+// sessions
+// ---------------------------------------------------------------------------------------
+struct zk_session {
+    u64 n = 0, lo = 0, hi = 0;            // rows; evaluated range
+    std::function<u32(u64)> row;          // status code of row i
+    std::vector<u32> status;
+    u32 launches = 0;
+    double ms = 0;
+    u64 fail_count = 0, first_row = ~0ull;
+    u32 first_code = 0;
+    bool range_ok = false;                // zk_set_range applies (row circuits)
+    // owned inputs (kept alive for `row`)
+    std::vector<u64> a64[4];
+    std::vector<u32> a32[4];
+    std::vector<uint8_t> a8;
+    CpuTable tab[12];
+    std::vector<u64> keccak_rows;         // keccak sessions: the table
+    // per-circuit argument blocks (one is used)
+    StateArgs state;
+    EvmArgs evm;
+    BytecodeArgs bytecode;
+    ExpArgs exp;
+    CopyArgs copy;
+    SignArgs sign;
+    PiArgs pi;
+    EcdsaArgs ecdsa;
+    KeccakGenArgs kgen;
+    ZkRwMeta rw_meta;
+    HostCodeDir dir;
+    std::vector<u64> aux64;
+};
+
+static void run_pass(zk_session* s, u32* status_out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    u32* st = status_out ? status_out : s->status.data();
+    const long long lo = (long long)s->lo, hi = (long long)s->hi;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long long i = lo; i < hi; i++) st[i] = s->row((u64)i);
+    u64 fails = 0, first = ~0ull;
+    for (long long i = lo; i < hi; i++)
+        if (st[i]) {
+            if (!fails) first = (u64)i;
+            fails++;
+        }
+    s->fail_count = fails;
+    s->first_row = first;
+    s->first_code = fails ? st[first] : 0u;
+    s->ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->launches++;
+}
+extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
+    ARG_TRY(s, "zk_launch: null session");
+    run_pass(s, status_dev);
+    return 0;
+}
+extern "C" int zk_collect(zk_session* s, zk_result* r) {
+    ARG_TRY(s && r, "zk_collect: bad arguments");
+    r->fail_count = s->fail_count;
+    r->first_fail_row = s->first_row == ~0ull ? UINT64_MAX : s->first_row;
+    r->first_fail_code = s->first_code;
+    r->launches = s->launches;
+    r->rows_evaluated = s->hi - s->lo;
+    r->kernel_ms = s->launches ? s->ms / s->launches : 0.0;
+    s->launches = 0;
+    s->ms = 0;
+    return 0;
+}
+extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
+    ARG_TRY(s && status_host, "zk_read_status: bad arguments");
+    memcpy(status_host, s->status.data(), s->n * sizeof(u32));
+    return 0;
+}
+extern "C" int zk_close(zk_session* s) {
+    delete s;
+    return 0;
+}
+extern "C" int zk_session_set_stream(zk_session*, void*) { return 0; }
+extern "C" int zk_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
+    ARG_TRY(s && s->range_ok, "zk_set_range: not a row-circuit session");
+    ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_set_range: bad range");
+    s->lo = row_lo;
+    s->hi = row_hi;
+    std::fill(s->status.begin(), s->status.end(), 0u);
+    return 0;
+}
+extern "C" int zk_state_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) { return zk_set_range(s, row_lo, row_hi); }
+
+static zk_session* new_session(u64 n, bool range_ok) {
+    zk_session* s = new zk_session();
+    s->n = n;
+    s->lo = 0;
+    s->hi = n;
+    s->status.assign(n ? n : 1, 0u);
+    s->range_ok = range_ok;
+    return s;
+}
+static int one_shot(zk_session* s, uint32_t* status_out, zk_result* result) {
+    int rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+#define NO_DEVICE_PTRS(opts, name) ARG_TRY(!((opts) & ZK_OPT_DEVICE_PTRS), name ": ZK_OPT_DEVICE_PTRS has no meaning on the CPU backend")
+
+// ---- Fr vector ops ------------------------------------------------------------------------------------------------------
+extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts) {
+    NO_DEVICE_PTRS(opts, "zk_fr_op");
+    ARG_TRY(a && b && out, "zk_fr_op: null pointer");
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) {
+        const Fr x = fr_load(a + 4 * i), y = fr_load(b + 4 * i);
+        Fr r;
+        switch (op) {
+        case 0: r = fr_add(x, y); break;
+        case 1: r = fr_sub(x, y); break;
+        case 2: r = fr_mul(x, y); break;
+        case 3: r = fr_mont(x, y); break;
+        case 4: r = fr_neg(x); break;
+        case 5: r = fr_inv(x); break;
+        case 6: r = fr_div(x, y); break;
+        default: r = fr_zero();
+        }
+        for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
+    }
+    return 0;
+}
+
+// ---- State circuit ------------------------------------------------------------------------------------------------------
+extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64_t n, const uint64_t* mpt, uint64_t n_mpt,
+                             uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_state_open");
+    ARG_TRY(out && rows && n > 0 && n < (1ull << 32) && n_mpt < (1ull << 31), "zk_state_open: bad arguments");
+    zk_session* s = new_session(n, true);
+    s->a64[0].assign(rows, rows + n * ST_NCELLS * 4);
+    if (flags) s->a32[0].assign(flags, flags + n);
+    else s->a32[0].assign(n, 0u);
+    cpu_table(s->tab[0], mpt, nullptr, n_mpt, MPT_NCELLS, state_mpt_key_hash);
+    s->state.rows.cells = s->a64[0].data();
+    s->state.rows.flags = s->a32[0].data();
+    s->state.rows.n = n;
+    s->state.mpt = s->tab[0].t;
+    s->state.eval_lo = 0;
+    s->state.eval_hi = n;
+    s->row = [s](u64 i) { return state_check_row(s->state, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_state_verify(const uint64_t* rows, const uint32_t* flags, uint64_t n, const uint64_t* mpt, uint64_t n_mpt,
+                               uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_state_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_state_open(rows, flags, n, mpt, n_mpt, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- EVM circuit --------------------------------------------------------------------------------------------------------
+extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_evm_open");
+    ARG_TRY(t && out && t->steps && t->n_steps >= 2 && t->n_steps < (1ull << 32), "zk_evm_open: bad arguments");
+    ARG_TRY(t->aux_cells == 0 || (t->aux_cells >= 2 && t->aux_cells <= 64), "zk_evm_open: aux_cells must be 0 (= 2) or 2..64");
+    zk_session* s = new_session(t->n_steps - 1, false);
+    EvmArgs& a = s->evm;
+    s->a64[0].assign(t->steps, t->steps + t->n_steps * STEP_NCELLS * 4);
+    a.dyn = nullptr;
+    a.step_recs = nullptr;
+    a.defer_list = nullptr;
+    a.defer_count = nullptr;
+    a.steps = s->a64[0].data();
+    a.n_steps = t->n_steps;
+    cpu_table(s->tab[0], t->rw, t->rw_flags, t->n_rw, RW_NCELLS, rw_key_hash);
+    cpu_table(s->tab[1], t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, bc_key_hash);
+    cpu_table(s->tab[2], t->tx, t->tx_flags, t->n_tx, TX_NCELLS, tx_key_hash);
+    cpu_table(s->tab[3], t->block, t->block_flags, t->n_block, BLOCK_NCELLS, blk_key_hash);
+    cpu_table(s->tab[4], t->copy, nullptr, t->n_copy, COPY_T_NCELLS, copy_key_hash);
+    cpu_table(s->tab[5], t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    cpu_table(s->tab[6], t->exp, nullptr, t->n_exp, EXP_T_NCELLS, expt_key_hash);
+    cpu_table(s->tab[7], t->sig, nullptr, t->n_sig, SIG_T_NCELLS, sig_key_hash);
+    cpu_table(s->tab[8], t->ecc, nullptr, t->n_ecc, ECC_T_NCELLS, ecc_key_hash);
+    cpu_table(s->tab[9], t->withdrawals, nullptr, t->n_withdrawals, 4, nullptr);  // walked in order: no index
+    a.rw = s->tab[0].t; a.bytecode = s->tab[1].t; a.tx = s->tab[2].t; a.block = s->tab[3].t; a.copy = s->tab[4].t;
+    a.keccak = s->tab[5].t; a.exp = s->tab[6].t; a.sig = s->tab[7].t; a.ecc = s->tab[8].t; a.withdrawals = s->tab[9].t;
+    {
+        const HostEvmAgg g = evm_aggregates_host(t->tx, t->tx_flags, t->n_tx, t->withdrawals, t->n_withdrawals);
+        a.agg_max_txs = g.max_txs; a.agg_total_txs = g.total_txs; a.agg_invalid_txs = g.invalid_txs;
+        a.agg_bad_invalid_rows = g.bad_invalid_rows; a.agg_total_wds = g.total_wds;
+    }
+    a.aux = nullptr;
+    a.aux_kind = nullptr;
+    a.aux_cells = t->aux_cells ? t->aux_cells : 2u;
+    if (t->aux && t->aux_kind) {
+        s->aux64.assign(t->aux, t->aux + t->n_steps * a.aux_cells * 4);
+        s->a32[1].assign(t->aux_kind, t->aux_kind + t->n_steps);
+        a.aux = s->aux64.data();
+        a.aux_kind = s->a32[1].data();
+    }
+    a.perm = nullptr;
+    a.prof = nullptr;
+    a.n_pairs = (u32)(t->n_steps - 1);
+    a.opts = (t->begin_with_first_step ? 1u : 0u) | (t->end_with_last_step ? 2u : 0u);
+    a.rw_dense = 0;
+    a.rw_base = 0;
+    a.rw_keys = nullptr;
+    a.codes.n = 0;
+    a.codes.mask = 0;
+    a.codes.packed = nullptr;
+    a.codes.entries = nullptr;
+    a.codes.slots = nullptr;
+    if (!(opts & ZK_OPT_GENERIC_INDEX)) {
+        s->rw_meta = rw_dense_meta_host(s->tab[0].t.n ? s->tab[0].cells.data() : nullptr, t->n_rw);
+        a.rw_dense = s->rw_meta.dense;
+        a.rw_base = s->rw_meta.base;
+        if (s->rw_meta.dense) {  // packed key records, as the device open builds them
+            s->a64[1].resize((size_t)t->n_rw * 4);
+            for (u64 r = 0; r < t->n_rw; r++) {
+                const RwKey k = rw_pack_row(a.rw, (u32)r);
+                for (int j = 0; j < 4; j++) s->a64[1][4 * r + j] = k.w[j];
+            }
+            a.rw_keys = s->a64[1].data();
+        }
+        if (t->n_bytecode) {
+            build_code_dir(s->tab[1].cells.data(), t->n_bytecode, s->dir);
+            a.codes.entries = s->dir.entries.data();
+            a.codes.slots = s->dir.slots.data();
+            a.codes.mask = s->dir.mask;
+            a.codes.n = (u32)s->dir.entries.size();
+            a.codes.packed = s->dir.packed.data();
+        }
+    }
+    s->row = [s](u64 i) {  // as on the device: the hot and the cold instantiation split the states
+        u32 c = evm_check_step<EVM_GROUP_ALL>(s->evm, i);
+        if (c == ZK_NOT_MINE) c = evm_check_step<EVM_GROUP_WARM>(s->evm, i);
+        if (c == ZK_NOT_MINE) c = evm_check_step<EVM_GROUP_COLD>(s->evm, i);
+        return c;
+    };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_evm_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_evm_open(t, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- Bytecode / Exp circuits --------------------------------------------------------------------------------------------
+extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* randomness,
+                                uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_bytecode_open");
+    ARG_TRY(out && rows && randomness && n > 0 && n < (1ull << 32) && n_keccak < (1ull << 31), "zk_bytecode_open: bad arguments");
+    zk_session* s = new_session(n, true);
+    s->a64[0].assign(rows, rows + n * BC_NCELLS * 4);
+    cpu_table(s->tab[0], keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    s->bytecode.rows.cells = s->a64[0].data();
+    s->bytecode.rows.flags = nullptr;
+    s->bytecode.rows.n = n;
+    s->bytecode.keccak = s->tab[0].t;
+    s->bytecode.r = cell_of(randomness);
+    s->bytecode.r_mont = nullptr;
+    s->row = [s](u64 i) { return bytecode_check_row(s->bytecode, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_bytecode_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* randomness,
+                                  uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_bytecode_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_bytecode_open(rows, n, keccak, n_keccak, randomness, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+extern "C" int zk_exp_open(const uint64_t* rows, uint64_t n, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_exp_open");
+    ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_exp_open: bad arguments");
+    zk_session* s = new_session(n, true);
+    s->a64[0].assign(rows, rows + n * EX_NCELLS * 4);
+    s->exp.rows.cells = s->a64[0].data();
+    s->exp.rows.flags = nullptr;
+    s->exp.rows.n = n;
+    s->row = [s](u64 i) { return exp_check_row(s->exp, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_exp_verify(const uint64_t* rows, uint64_t n, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_exp_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_exp_open(rows, n, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- Copy circuit -------------------------------------------------------------------------------------------------------
+extern "C" int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_copy_open");
+    ARG_TRY(t && out && t->rows && t->randomness && t->n_rows > 0 && t->n_rows < (1ull << 32), "zk_copy_open: bad arguments");
+    zk_session* s = new_session(t->n_rows, true);
+    s->a64[0].assign(t->rows, t->rows + t->n_rows * CP_NCELLS * 4);
+    if (t->row_flags) s->a32[0].assign(t->row_flags, t->row_flags + t->n_rows);
+    cpu_table(s->tab[0], t->rw, t->rw_flags, t->n_rw, RW_NCELLS, rw_key_hash);
+    cpu_table(s->tab[1], t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, bc_key_hash);
+    cpu_table(s->tab[2], t->tx, t->tx_flags, t->n_tx, TX_NCELLS, tx_key_hash);
+    s->copy.rows.cells = s->a64[0].data();
+    s->copy.rows.flags = t->row_flags ? s->a32[0].data() : nullptr;
+    s->copy.rows.n = t->n_rows;
+    s->copy.rw = s->tab[0].t;
+    s->copy.bytecode = s->tab[1].t;
+    s->copy.tx = s->tab[2].t;
+    s->rw_meta = rw_dense_meta_host(t->n_rw ? s->tab[0].cells.data() : nullptr, t->n_rw);
+    s->copy.rw_meta = (opts & ZK_OPT_GENERIC_INDEX) ? nullptr : &s->rw_meta;
+    s->copy.r = cell_of(t->randomness);
+    s->row = [s](u64 i) { return copy_check_row(s->copy, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_copy_verify(const zk_copy_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_copy_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_copy_open(t, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- Tx / Sig circuits --------------------------------------------------------------------------------------------------
+extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_sign_open");
+    ARG_TRY(t && out && t->bytes && t->cells && t->meta && t->randomness && t->n_units > 0 && t->n_units < (1ull << 32), "zk_sign_open: bad arguments");
+    const u64 n = t->n_units;
+    zk_session* s = new_session(n, true);
+    s->a8.assign(t->bytes, t->bytes + n * SG_NBYTES_ROWS * 32);
+    s->a64[0].assign(t->cells, t->cells + n * SG_NCELLS * 4);
+    s->a32[0].assign(t->meta, t->meta + n * 4);
+    cpu_table(s->tab[0], t->keccak, nullptr, t->n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    cpu_table(s->tab[1], t->tx_rows, t->tx_flags, t->n_tx_rows, TX_NCELLS, nullptr);
+    SignArgs& a = s->sign;
+    a.bytes = s->a8.data();
+    a.cells.cells = s->a64[0].data();
+    a.cells.flags = nullptr;
+    a.cells.n = n;
+    a.meta = s->a32[0].data();
+    a.keccak = s->tab[0].t;
+    a.tx_rows = s->tab[1].t;
+    a.tx_rows.n = (u32)t->n_tx_rows;
+    a.r = cell_of(t->randomness);
+    s->a64[1].resize(64 * 4);
+    sign_fill_rpow(a.r, s->a64[1].data());
+    a.rpow = s->a64[1].data();
+    a.is_sig = t->is_sig ? 1u : 0u;
+    s->row = [s](u64 i) { return sign_check_unit(s->sign, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_sign_verify(const zk_sign_units* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_sign_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_sign_open(t, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- PI circuit ---------------------------------------------------------------------------------------------------------
+extern "C" int zk_pi_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+                          uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_pi_open");
+    ARG_TRY(out && rows && keccak_rand && byte_pow_base && n > 0 && n < (1ull << 32), "zk_pi_open: bad arguments");
+    zk_session* s = new_session(n, true);
+    s->a64[0].assign(rows, rows + n * 24 * 4);
+    cpu_table(s->tab[0], keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
+    cpu_table(s->tab[1], gas, nullptr, n_gas, PI_GAS_NCELLS, pi_gas_key_hash);
+    PiArgs& a = s->pi;
+    a.rows.cells = s->a64[0].data();
+    a.rows.flags = nullptr;
+    a.rows.n = n;
+    a.keccak = s->tab[0].t;
+    a.gas = s->tab[1].t;
+    a.keccak_rand_m = fr_to_mont(cell_of(keccak_rand));
+    a.byte_pow_base_m = fr_to_mont(cell_of(byte_pow_base));
+    a.circuit_len = fr_from_u64(circuit_len);
+    s->row = [s](u64 i) { return pi_check_row(s->pi, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
+                            uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts,
+                            uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_pi_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_pi_open(rows, n, keccak, n_keccak, gas, n_gas, circuit_len, keccak_rand, byte_pow_base, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- Keccak table generation --------------------------------------------------------------------------------------------
+extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs, const uint64_t* randomness,
+                              uint32_t mode, uint64_t* rows_dev, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_keccak_open");
+    ARG_TRY(out && offsets && randomness && n_msgs > 0 && n_msgs < (1ull << 32) && (data || n_bytes == 0) && mode <= 1u && !rows_dev,
+            "zk_keccak_open: bad arguments");
+    for (u64 k = 0; k < n_msgs; k++) ARG_TRY(offsets[k] <= offsets[k + 1], "zk_keccak_open: offsets must be non-decreasing");
+    ARG_TRY(offsets[n_msgs] <= n_bytes, "zk_keccak_open: offsets exceed the data buffer");
+    zk_session* s = new_session(n_msgs, false);
+    s->a8.assign(data, data + n_bytes);
+    s->a64[0].assign(offsets, offsets + n_msgs + 1);
+    s->a64[1].resize(KT_RPOW_ROWS * 4);
+    kt_fill_rpow(cell_of(randomness), s->a64[1].data());
+    s->keccak_rows.assign(n_msgs * KT_NCELLS * 4, 0);
+    KeccakGenArgs& g = s->kgen;
+    g.data = s->a8.data();
+    g.offsets = s->a64[0].data();
+    g.n = n_msgs;
+    g.rpow = s->a64[1].data();
+    g.rows = s->keccak_rows.data();
+    g.mode = mode;
+    s->row = [s](u64 i) { return keccak_table_row(s->kgen, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_keccak_read_rows(zk_session* s, uint64_t* rows_host) {
+    ARG_TRY(s && rows_host && !s->keccak_rows.empty(), "zk_keccak_read_rows: bad arguments");
+    memcpy(rows_host, s->keccak_rows.data(), s->keccak_rows.size() * 8);
+    return 0;
+}
+extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint64_t* offsets, uint64_t n_msgs, const uint64_t* randomness,
+                               uint32_t mode, uint64_t* rows_out, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && rows_out, "zk_keccak_table: null output");
+    zk_session* s = nullptr;
+    int rc = zk_keccak_open(data, n_bytes, offsets, n_msgs, randomness, mode, nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = zk_keccak_read_rows(s, rows_out);
+    if (!rc && status_out) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
+// ---- secp256k1 ECDSA verification ---------------------------------------------------------------------------------------
+extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n, uint32_t* out_dev,
+                             uint32_t out_stride, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_ecdsa_open");
+    ARG_TRY(out && bytes && n > 0 && n < (1ull << 32) && layout <= 2u && (!v || v_stride >= 1) && !out_dev, "zk_ecdsa_open: bad arguments");
+    (void)out_stride;
+    static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
+    zk_session* s = new_session(n, false);
+    EcdsaArgs& a = s->ecdsa;
+    a.stride = layout ? 288 : 160;
+    s->a8.assign(bytes, bytes + n * a.stride);
+    if (v) s->a32[0].assign(v, v + n * v_stride);
+    a.bytes = s->a8.data();
+    a.v = v ? s->a32[0].data() : nullptr;
+    a.v_stride = v_stride;
+    a.n = n;
+    a.first = 0;
+    a.out = nullptr;
+    a.out_stride = 0;
+    a.msg_be = layout != 1u;
+    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
+    a.qtab = nullptr;
+    a.qtab_lanes = 1;
+    a.lanes_per_sig = 1;
+    s->row = [s](u64 i) {
+        u32 tab[15 * 24];  // the key's multiples: per call on the CPU
+        return ecdsa_verify_one(s->ecdsa, i, tab, 1);
+    };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n, uint32_t opts,
+                               uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result, "zk_ecdsa_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_ecdsa_open(bytes, layout, v, v_stride, n, nullptr, 0, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+// ---- device-side witness assignment: not on the CPU backend -------------------------------------------------------------
+extern "C" int zk_state_assign_open(const uint64_t*, const uint32_t*, uint64_t, uint64_t*, uint32_t*, uint64_t*, uint32_t, zk_session**) { return unsupported("zk_state_assign_open"); }
+extern "C" int zk_state_assign_read(zk_session*, uint64_t*, uint32_t*, uint64_t*, uint64_t, uint64_t*) { return unsupported("zk_state_assign_read"); }
+extern "C" int zk_state_assign(const uint64_t*, const uint32_t*, uint64_t, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t, uint32_t*, zk_result*) { return unsupported("zk_state_assign"); }
+extern "C" int zk_bytecode_assign_open(const uint64_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t, uint32_t, const uint64_t*, uint64_t*, uint32_t, zk_session**) { return unsupported("zk_bytecode_assign_open"); }
+extern "C" int zk_bytecode_assign_read(zk_session*, uint64_t*) { return unsupported("zk_bytecode_assign_read"); }
+extern "C" int zk_bytecode_assign(const uint64_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t, uint32_t, const uint64_t*, uint64_t*, uint32_t, zk_result*) { return unsupported("zk_bytecode_assign"); }
+extern "C" int zk_copy_assign_sizes(const zk_copy_events*, uint32_t, uint64_t*, uint64_t*, uint64_t*) { return unsupported("zk_copy_assign_sizes"); }
+extern "C" int zk_copy_assign_open(const zk_copy_events*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*, uint32_t, zk_session**) { return unsupported("zk_copy_assign_open"); }
+extern "C" int zk_copy_assign_read(zk_session*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*) { return unsupported("zk_copy_assign_read"); }
+extern "C" int zk_copy_assign(const zk_copy_events*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*, uint32_t, zk_result*) { return unsupported("zk_copy_assign"); }

@@ -80,6 +80,9 @@ struct EvmArgs {
 };
 
 ZK_HD void evm_args_resolve(EvmArgs& a) {
+#ifdef EVM_RESOLVE_OFF
+    return;
+#endif
     if (a.dyn) {
         const EvmDyn d = *a.dyn;  // uniform address: scalar loads
         a.rw_dense = (a.rw.n != 0u && d.rw_sparse == 0u) ? 1u : 0u;
@@ -448,6 +451,7 @@ ZK_HD u32 rw_dense_row(const EvmArgs& a, const Fr& rwc, bool& ok) {
 struct RwRow {
     uint4 k01, k23;
     Fr v_lo, v_hi;
+    u32 r;  // the dense-table row these were fetched from: a lookup only uses them when it addresses that very row
 };
 template <int N>
 struct RwRows {
@@ -477,6 +481,9 @@ ZK_HD u32 rw_lookup(Ins& I, RwQ& Q, const Fr* rw_counter = nullptr, const RwRow*
         if (I.a->rw_keys) {
             uint4 k01, k23;
             if (pre) {
+                // the row requested ahead must be the row this lookup addresses: a gadget whose batch offsets drifted from its lookup
+                // order gets no verdict (never a silently compared wrong row)
+                if (pre->r != r && I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
                 k01 = pre->k01;
                 k23 = pre->k23;
             } else {
@@ -530,6 +537,7 @@ ZK_HD void rw_rows_fetch_at(const Ins& I, RwRows<N>& R, u64 off) {  // rows of t
         const uint4* kp = reinterpret_cast<const uint4*>(a.rw_keys + (u64)r * 4);
         R.row[k].k01 = kp[0];
         R.row[k].k23 = kp[1];
+        R.row[k].r = r;
         R.row[k].v_lo = zk_table_cell(a.rw, r, R_VAL_LO);
         R.row[k].v_hi = zk_table_cell(a.rw, r, R_VAL_LO + 1);
     }
@@ -856,7 +864,7 @@ ZK_HD Word stack_lookup_row(Ins& I, u32 rw, int off, const RwRow& row) {
     rwq_set(Q, R_ID, I.call_id);
     const Fr& sp = I.sp;
     rwq_set(Q, R_ADDR, off >= 0 ? fr_add_u64(sp, (u64)off) : fr_sub_u64(sp, (u64)(-off)));
-    rw_lookup(I, Q, nullptr, &row);
+    rw_lookup(I, Q, nullptr, &row);  // (checks that `row` is the row it addresses)
     return word_of(row.v_lo, row.v_hi);
 }
 template <int N>
@@ -4161,21 +4169,25 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 // EVM_GROUP_COLD: states outside BASELINE config 3's opcode mix (error states, copy / account-access
 // gadgets, EXP, SDIV/SMOD, RETURN, LOG, EndBlock).  They get their own kernel instantiation so that
 // their code and register pressure stay out of the hot kernel (EVM_GROUP_ALL = the three hot groups).
-enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_GROUP_COLD = 3, EVM_N_GROUPS = 4, EVM_GROUP_ALL = -1 };
+// EVM_GROUP_WARM (round 3): the copy- / keccak- / exp-table gadgets (SHA3, the *COPY family, LOG, EXP).  A block has a few thousand of
+// these steps (BASELINE configs[4]); inside the cold instantiation — every error state, the CALL family, CREATE, Begin / EndTx in one
+// function: 512 registers + 2 KB of scratch — a wavefront of them took ~350 us.  Their own, much smaller instantiation keeps the
+// block's pass bound by the State kernel.
+enum { EVM_GROUP_MEM = 0, EVM_GROUP_MUL = 1, EVM_GROUP_LIGHT = 2, EVM_GROUP_WARM = 3, EVM_GROUP_COLD = 4, EVM_N_GROUPS = 5, EVM_GROUP_ALL = -1 };
 #define ZK_NOT_MINE 0xffffffffu  // evm_check_step<G>: the state belongs to the other instantiation
 #define ZK_DEFERRED_BASE 0xfffffff0u  // evm_check_step (EVM_FAST build) returns BASE + reason (1 wide word cell, 2 generic probe, 3 no packed
                                      // keys, 4 key cells beyond the packed widths, 5 wide transition operands; 8 = unstaged pair): the pair needs a
                                      // fallback path of the general build
 ZK_HD int evm_state_group(u32 state) {
     switch (state) {
+    case ES_EXP: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY: case ES_RETURNDATACOPY: case ES_EXTCODECOPY: case ES_LOG: return EVM_GROUP_WARM;
     case ES_MUL: case ES_SHL_SHR: case ES_ADDMOD: case ES_MULMOD: return EVM_GROUP_MUL;
     case ES_MEMORY: case ES_SLOAD: case ES_SSTORE: case ES_STOP: return EVM_GROUP_MEM;
-    case ES_SDIV_SMOD: case ES_EXP: case ES_BALANCE: case ES_EXTCODESIZE: case ES_EXTCODEHASH: case ES_BLOCKHASH:
+    case ES_SDIV_SMOD: case ES_BALANCE: case ES_EXTCODESIZE: case ES_EXTCODEHASH: case ES_BLOCKHASH:
     case ES_CALLDATALOAD: case ES_ErrorInvalidOpcode: case ES_ErrorStack: case ES_ErrorOutOfGasConstant:
-    case ES_ErrorInvalidJump: case ES_SHA3: case ES_CODECOPY: case ES_CALLDATACOPY: case ES_RETURNDATACOPY:
-    case ES_EXTCODECOPY: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
+    case ES_ErrorInvalidJump: case ES_ErrorOutOfGasStaticMemoryExpansion: case ES_ErrorOutOfGasDynamicMemoryExpansion:
     case ES_ErrorOutOfGasMemoryCopy: case ES_ErrorOutOfGasAccountAccess: case ES_ErrorOutOfGasLOG: case ES_ErrorOutOfGasEXP:
-    case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_LOG: case ES_RETURN:
+    case ES_ErrorOutOfGasSHA3: case ES_ErrorReturnDataOutOfBound: case ES_ErrorWriteProtection: case ES_RETURN:
     case ES_ErrorInvalidCreationCode: case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: case ES_EndBlock: case ES_EndTx: case ES_BeginTx: case ES_CALL_OP:
     case ES_ErrorOutOfGasCall: case ES_ErrorOutOfGasSloadSstore: case ES_CREATE: case ES_CREATE2: case ES_DATACOPY:
     case ES_ErrorOutOfGasPrecompile: case ES_ErrorOutOfGasCREATE: case ES_ErrorGasUintOverflow: case ES_ECRECOVER: case ES_BN254_ADD:
@@ -4190,7 +4202,8 @@ ZK_HD int evm_state_group(u32 state) {
 // measured wavefront time, longest first (tools/evm_wave_timeline.py): a longest-processing-time-first schedule over the
 // 2 x 1024 wavefront slots, with the short POP / STOP wavefronts making the kernel's tail.
 ZK_HD u32 evm_state_bin(u32 state) {
-    if (evm_state_group(state) == EVM_GROUP_COLD) return (u32)EVM_GROUP_COLD * 128u + (state & 127u);
+    const int grp = evm_state_group(state);
+    if (grp >= EVM_GROUP_WARM) return (u32)grp * 128u + (state & 127u);  // warm / cold: their own bin ranges (not padded)
     u32 key = (state & 127u) + 32u;  // everything not listed below, in state order (arbitrary cell values stay below 384)
     switch (state) {
     case ES_STOP: key = 0; break;  // non-root STOP restores the caller's context: a dozen lookups, the longest wavefronts
@@ -4217,7 +4230,7 @@ ZK_HD u32 evm_state_bin(u32 state) {
 }
 #define EVM_N_BINS (EVM_N_GROUPS * 128)
 #define EVM_NO_PAIR 0xffffffffu                   // a pad lane of the sorted mapping (hot bins are padded to whole wavefronts)
-#define EVM_PERM_PAD (64u * EVM_GROUP_COLD * 128u)  // upper bound of the padding
+#define EVM_PERM_PAD (64u * EVM_GROUP_WARM * 128u)  // upper bound of the padding (the hot bins)
 
 // Request the packed bytecode record at curr.program_counter (every hot gadget's opcode_lookup) before the common checks
 // and the gadget prologue run, so that its HBM round trip overlaps them.  (Requesting the leading RW rows the same way was
@@ -4444,7 +4457,10 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     const bool is_last = (a.opts & 2u) && idx == (u64)a.n_pairs - 1;
     const u32 state = statef.v[0];
     const u32 next_state = next_statef.v[0];  // used unless is_last
-    if ((G == EVM_GROUP_COLD) != (evm_state_group(state) == EVM_GROUP_COLD)) return ZK_NOT_MINE;
+    {   // the hot instantiation (ALL) owns the three hot groups, the warm and the cold one their own
+        const int grp = evm_state_group(state);
+        if (G == EVM_GROUP_ALL ? grp >= EVM_GROUP_WARM : grp != G) return ZK_NOT_MINE;
+    }
 #if !defined(ZK_HOSTSIM)
     if (EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 4] = state;
 #endif
@@ -4460,7 +4476,7 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
         ev_fail(I, ZK_NOT_IMPLEMENTED);
         return I.err;
     }
-    if (G != EVM_GROUP_COLD) evm_prefetch(I);
+    if (G == EVM_GROUP_ALL) evm_prefetch(I);
     EV_PROF(I, 1);
     Tail T;
     T.enabled = false;
@@ -4529,13 +4545,13 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     case ES_ErrorStack: if (G == EVM_GROUP_COLD) { g_error_stack(I, T); } break;
     case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_COLD) { g_error_oog_constant(I, T); } break;
     case ES_ErrorInvalidJump: if (G == EVM_GROUP_COLD) { g_error_invalid_jump(I, T); } break;
-    case ES_LOG: if (G == EVM_GROUP_COLD) { g_log(I, T); } break;
-    case ES_SHA3: if (G == EVM_GROUP_COLD) { g_sha3(I, T); } break;
-    case ES_CODECOPY: if (G == EVM_GROUP_COLD) { g_codecopy(I, T); } break;
-    case ES_CALLDATACOPY: if (G == EVM_GROUP_COLD) { g_calldatacopy(I, T); } break;
-    case ES_RETURNDATACOPY: if (G == EVM_GROUP_COLD) { g_returndatacopy(I, T); } break;
-    case ES_EXTCODECOPY: if (G == EVM_GROUP_COLD) { g_extcodecopy(I, T); } break;
-    case ES_EXP: if (G == EVM_GROUP_COLD) { g_exp(I, T); } break;
+    case ES_LOG: if (G == EVM_GROUP_WARM) { g_log(I, T); } break;
+    case ES_SHA3: if (G == EVM_GROUP_WARM) { g_sha3(I, T); } break;
+    case ES_CODECOPY: if (G == EVM_GROUP_WARM) { g_codecopy(I, T); } break;
+    case ES_CALLDATACOPY: if (G == EVM_GROUP_WARM) { g_calldatacopy(I, T); } break;
+    case ES_RETURNDATACOPY: if (G == EVM_GROUP_WARM) { g_returndatacopy(I, T); } break;
+    case ES_EXTCODECOPY: if (G == EVM_GROUP_WARM) { g_extcodecopy(I, T); } break;
+    case ES_EXP: if (G == EVM_GROUP_WARM) { g_exp(I, T); } break;
     case ES_BALANCE: if (G == EVM_GROUP_COLD) { g_balance(I, T); } break;
     case ES_EXTCODESIZE: if (G == EVM_GROUP_COLD) { g_extcodesize(I, T); } break;
     case ES_EXTCODEHASH: if (G == EVM_GROUP_COLD) { g_extcodehash(I, T); } break;

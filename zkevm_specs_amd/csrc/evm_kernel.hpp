@@ -18,7 +18,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
     // (group_start) and this lane's pair (perm; read before the range is known: the buffer is padded past every grid) — instead
     // of three dependent round trips of 2-3 us each under load.
     u32 perm_t = 0;
-    if (G != EVM_GROUP_COLD && a.perm) perm_t = a.perm[(u64)blockIdx.x * blockDim.x + threadIdx.x];
+    if (G == EVM_GROUP_ALL && a.perm) perm_t = a.perm[(u64)blockIdx.x * blockDim.x + threadIdx.x];
     __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
     const bool have_dir = G == EVM_GROUP_ALL && a.dyn != nullptr && a.codes.slots != nullptr && a.codes.entries != nullptr;
     if (have_dir) {
@@ -31,8 +31,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
     // cold one [group_start[COLD], n); without it both walk all pairs and skip the other's states
     u32 lo = 0, hi = a.n_pairs;
     if (a.perm) {  // lane ranges of the sorted mapping (hot bins padded to whole wavefronts with EVM_NO_PAIR lanes)
-        if (G == EVM_GROUP_COLD) { lo = group_start[EVM_GROUP_COLD]; hi = group_start[EVM_N_GROUPS]; }
-        else hi = group_start[EVM_GROUP_COLD];
+        if (G == EVM_GROUP_ALL) hi = group_start[EVM_GROUP_WARM];
+        else { lo = group_start[G]; hi = group_start[G + 1]; }
     }
     u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ u32 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_ENTRIES * EVM_STAGE_STRIDE : 1];
@@ -88,19 +88,23 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
             else if (status) status[idx] = code;
             tally_commit(tally, idx, code);  // ballot over the lanes still in the loop
         }
-#if !EVM_FAST
-        // the pairs the fast (hot) kernel deferred: every gadget in its general form (generic indices, cell-by-cell compares,
-        // step rows from HBM)
-        if (G == EVM_GROUP_COLD && a.defer_count) {
-            const u32 n_def = *a.defer_count;
-            for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < (u64)n_def; k += stride) {
-                const u64 idx = a.defer_list[k];
-                u32 code = evm_check_step<EVM_GROUP_ALL>(a, idx);
-                if (code == ZK_NOT_MINE) code = 0;
-                else if (status) status[idx] = code;
-                tally_commit(tally, idx, code);
-            }
-        }
-#endif
     }
 }
+
+#if defined(EVM_DEFERRED_KERNEL)
+// The pairs the fast (hot) kernel deferred (EVM_FAST, evm_circuit.hpp): every hot gadget in its general form — generic indices,
+// cell-by-cell key compares, step rows from HBM, field-arithmetic transitions.  Launched by the host only when a pass left
+// such pairs behind (zk_collect / zk_read_status read the count): well-formed witnesses never pay for it.
+__global__ __launch_bounds__(256, 1) void evm_deferred_kernel(EvmArgs a, u32* status, ZkTally* tally) {
+    evm_args_resolve(a);
+    const u32 n_def = *a.defer_count;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < (u64)n_def; k += stride) {
+        const u64 idx = a.defer_list[k];
+        u32 code = evm_check_step<EVM_GROUP_ALL>(a, idx);
+        if (code == ZK_NOT_MINE) code = 0;
+        else if (status) status[idx] = code;
+        tally_commit(tally, idx, code);
+    }
+}
+#endif

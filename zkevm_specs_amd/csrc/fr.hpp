@@ -210,6 +210,24 @@ ZK_NOINLINE Fr fr_mont(Fr a, Fr b) {
 ZK_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_mont(fr_mont(a, b), frm_r2()); }
 ZK_HD Fr fr_mulc(const Fr& a, const Fr& cM) { return fr_mont(a, cM); }
 ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont(a, frm_r2()); }
+// FQ.inv (util/arithmetic.py:59-60: py_ecc's prime_field_inv, which returns 0 for 0): Fermat, a^(p-2), a square-and-multiply
+// walk over the bits of p - 2 in Montgomery form (254 squarings + the products of its 109 one-bits below the top; a vector
+// op for callers and tests — the circuits' own inverses are all of constants, folded at build time)
+ZK_HD Fr fr_inv(const Fr& a) {
+    const Fr p = fr_modulus();
+    Fr e = p;
+    e.v[0] -= 2u;  // p - 2 (p ends in ...0001: no borrow past the low limb)
+    const Fr aM = fr_to_mont(a);
+    Fr acc = aM;   // bit 253 of p - 2 is its top bit
+    for (int bit = 252; bit >= 0; bit--) {
+        acc = fr_mont(acc, acc);
+        if ((e.v[bit >> 5] >> (bit & 31)) & 1u) acc = fr_mont(acc, aM);
+    }
+    Fr one = fr_zero();
+    one.v[0] = 1u;
+    return fr_mont(acc, one);  // out of Montgomery form; a == 0 stays 0
+}
+ZK_HD Fr fr_div(const Fr& a, const Fr& b) { return fr_mul(a, fr_inv(b)); }  // FQ.__truediv__: a * b.inv()
 // small-constant multiply by repeated doubling is avoided: use integer path when it fits.
 ZK_HD Fr fr_mul_u64(const Fr& a, u64 k) { return fr_mulc(a, fr_to_mont(fr_from_u64(k))); }
 

@@ -6,7 +6,7 @@
 template <int L>
 __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* status, ZkTally* tally) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 i = gid / L;
+    const u64 i = a.first + gid / L;
     const int role = (int)(gid % L);
     const bool valid = i < a.n;
 #if ZK_ECDSA_TAB_INTERLEAVED
@@ -45,9 +45,16 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     tally_commit(tally, i, code);
 }
 
-void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally) {
-    // 64-lane blocks: 2^14 signatures are only 256 (512 as lane pairs) wavefronts
-    const u32 grid = (u32)((a.n * a.lanes_per_sig + 63) / 64);
-    if (a.lanes_per_sig == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<2>), dim3(grid), dim3(64), 0, st, a, status, tally);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<1>), dim3(grid), dim3(64), 0, st, a, status, tally);
+void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a0, u32* status, ZkTally* tally) {
+    // 64-lane blocks: 2^14 signatures are only 256 (512 as lane pairs) wavefronts.  The per-lane key tables cost 1,440 bytes
+    // per lane (ZK_ECDSA_CHUNK_LANES of them are allocated, 189 MB): a larger batch runs as consecutive launches over the same
+    // tables (in order on the stream, so a chunk's tables are free when the next one starts).
+    EcdsaArgs a = a0;
+    const u64 per_chunk = a.qtab_lanes / a.lanes_per_sig;  // signatures per launch
+    for (a.first = 0; a.first < a.n; a.first += per_chunk) {
+        const u64 m = a.n - a.first < per_chunk ? a.n - a.first : per_chunk;
+        const u32 grid = (u32)((m * a.lanes_per_sig + 63) / 64);
+        if (a.lanes_per_sig == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<2>), dim3(grid), dim3(64), 0, st, a, status, tally);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(ecdsa_verify_kernel<1>), dim3(grid), dim3(64), 0, st, a, status, tally);
+    }
 }

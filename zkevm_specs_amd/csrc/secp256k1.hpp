@@ -356,7 +356,7 @@ ZK_HD Fr sp_load_be(const uint8_t* p) {
 
 enum { ECDSA_OK = 0, ECDSA_NOT_VERIFIED = 1 };
 #define ECDSA_BAD_SIGNATURE ZK_CODE(ZK_UNSUPPORTED, 1)   // eth_keys BadSignature: no class of its own on the wire
-#define ECDSA_KEY_RANGE ZK_CODE(ZK_UNSUPPORTED, 2)       // public-key coordinate >= P: outside the engine's domain
+#define ECDSA_KEY_RANGE ZK_CODE(ZK_UNSUPPORTED, 2)       // public key with y == P exactly: outside the engine's domain (see ecdsa_prepare)
 #define ECDSA_PENDING 0xfffffffeu                        // internal: the verdict comes out of the joint multiplication
 
 struct EcdsaArgs {
@@ -367,6 +367,7 @@ struct EcdsaArgs {
     const u32* v;          // optional recovery ids, v[i * v_stride] (Sig circuit): outside {0, 1} -> BadSignature
     u32 v_stride;
     u64 n;
+    u64 first;             // first signature of this launch (large batches run in chunks that share one key table, zk_launch_ecdsa)
     u32* out;              // optional: out[i * out_stride] = status (e.g. the sign units' meta column)
     u32 out_stride;
     u32* qtab;             // per-lane tables of the key's multiples, word w of entry e of lane l at qtab[(e * 24 + w) * qtab_lanes + l]
@@ -499,14 +500,20 @@ ZK_HD u32 sp_digit4(const Fr& k, int w) { return (k.v[w >> 3] >> ((w & 7) * 4)) 
 // the final status (the case-exact path ran here).
 ZK_HD u32 ecdsa_prepare(const EcdsaArgs& a, u64 i, EcdsaPrep& pr, bool run_exact_path) {
     const uint8_t* base = a.bytes + i * a.stride;
-    const Fr pkx = sp_load_le(base + a.off[0]), pky = sp_load_le(base + a.off[1]);
+    Fr pkx = sp_load_le(base + a.off[0]), pky = sp_load_le(base + a.off[1]);
     const Fr z = a.msg_be ? sp_load_be(base + a.off[2]) : sp_load_le(base + a.off[2]);
     const Fr r = sp_load_le(base + a.off[3]), s = sp_load_le(base + a.off[4]);
     const Fr n = SecpN::mod(), p = SecpP::mod();
     if (a.v && a.v[i * a.v_stride] > 1u) return ECDSA_BAD_SIGNATURE;
     // validate_signature_r_or_s: 0 < value < N
     if (!fr_lt(r, n) || !fr_lt(s, n) || fr_is_zero(r) || fr_is_zero(s)) return ECDSA_BAD_SIGNATURE;
-    if (!fr_lt(pkx, p) || !fr_lt(pky, p)) return ECDSA_KEY_RANGE;
+    // A coordinate >= P (the native backend does not range-check public-key bytes): every formula of eth-keys' Jacobian chain
+    // reduces mod P as it goes, so the verdict is that of the coordinates mod P — with ONE exception, `if not p[1]` (the
+    // point-at-infinity test of jacobian_double / jacobian_add), which sees y == P as non-zero: that single value stays outside
+    // the domain.  (2^256 < 2 P: one conditional subtraction reduces.)
+    if (fr_eq(pky, p)) return ECDSA_KEY_RANGE;
+    pkx = sp_reduce_once<SecpP>(pkx);
+    pky = sp_reduce_once<SecpP>(pky);
     const Fr wM = sp_inv_n(sp_to_mont<SecpN>(s));
     const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
     const Fr u2 = sp_mont<SecpN>(r, wM);

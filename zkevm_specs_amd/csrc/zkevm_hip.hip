@@ -21,6 +21,7 @@
 // per thread (the "current" device / stream that zk_*_open captures, the error text) or per session (device, stream,
 // buffers, events): sessions are independent contexts, calls on different sessions may come from different threads.
 #define ZK_MAX_DEVICES 64
+#define ZK_ECDSA_CHUNK_LANES (1ull << 17)  // lanes per ECDSA launch (x 1,440 B of key tables = 189 MB); a multiple of 64
 static std::mutex g_dev_mutex;
 static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
 static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per device: "row 0" of every empty table
@@ -189,7 +190,7 @@ __device__ __forceinline__ void evm_state_scatter_body(u32 vblock, const uint16_
     u32 c = 0, c_real = 0;
     if (k < EVM_N_BINS) {
         c_real = hist[k];
-        c = k < (u32)EVM_GROUP_COLD * 128u ? ((c_real + 63u) & ~63u) : c_real;
+        c = k < (u32)EVM_GROUP_WARM * 128u ? ((c_real + 63u) & ~63u) : c_real;  // hot bins: whole wavefronts
         sa[k] = c;
         local[k] = 0;
         if (vblock == 0) hist_next[k] = 0;
@@ -425,6 +426,8 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
     case 2: r = fr_mul(x, y); break;
     case 3: r = fr_mont(x, y); break;
     case 4: r = fr_neg(x); break;
+    case 5: r = fr_inv(x); break;
+    case 6: r = fr_div(x, y); break;
     default: r = fr_zero();
     }
     for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
@@ -469,6 +472,10 @@ struct zk_session {
     uint16_t* d_bin16 = nullptr;  // EVM: sort bin of every pair, written by the histogram pass
     u32 evm_pass = 0;
     bool perm_ready = false; // EVM: zk_evm_open already enqueued the counting sort of the first pass
+    int evm_ranges_known = 0;       // EVM: 1 once a collect has read the warm / cold lane ranges of this session's (fixed) step table ...
+    bool evm_warm_empty = false, evm_cold_empty = false;  // ... empty ranges are not launched again
+    bool deferred_pending = false;  // EVM: the last pass may have left deferred pairs (evm_finish_deferred has not looked yet)
+    u32* last_status = nullptr;     // EVM: where the last pass wrote its statuses
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
 };
@@ -1271,7 +1278,9 @@ extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32
     // one lane per signature beyond that (less total work).  ZK_ECDSA_LANES=1|2 overrides (tuning / tests).
     a.lanes_per_sig = n <= (1ull << 16) ? 2u : 1u;
     if (const char* e = getenv("ZK_ECDSA_LANES")) a.lanes_per_sig = atoi(e) == 2 ? 2u : 1u;
+    a.first = 0;
     a.qtab_lanes = ((n * a.lanes_per_sig + 63) / 64) * 64;
+    if (a.qtab_lanes > ZK_ECDSA_CHUNK_LANES) a.qtab_lanes = ZK_ECDSA_CHUNK_LANES;  // larger batches: chunked launches over one set of tables
     if ((rc = dev_alloc(s, (void**)&a.qtab, (size_t)a.qtab_lanes * 15 * 24 * sizeof(u32)))) goto fail;
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
@@ -1802,8 +1811,18 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         // one kernel with every gadget; with `perm` the lanes are state-sorted (heavy gadget families first); then the
         // rarely-taken states (evm_state_group == COLD): a small grid-stride launch, empty for most traces.  With the sorted
         // mapping the two timing events ride on the dispatches themselves (no event packets between the kernels).
-        zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr);
-        zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
+        s->deferred_pending = true;
+        s->last_status = status;
+        // The warm (copy- / keccak- / exp-table gadgets) and cold (everything rare) instantiations walk their own lane ranges of
+        // the sorted mapping.  Which states a session's step table contains does not change between passes: once a collect has
+        // seen a range empty (the usual case for the cold one, and for both on BASELINE config 3's mix) it is not launched again.
+        const bool sorted = s->evm.perm != nullptr;
+        const bool run_warm = !(sorted && s->evm_ranges_known && s->evm_warm_empty);
+        const bool run_cold = !(sorted && s->evm_ranges_known && s->evm_cold_empty);
+        hipEvent_t e_hot1 = (evm_ext_events && !run_warm && !run_cold) ? e1 : nullptr;  // the hot dispatch carries both events then
+        zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr, e_hot1);
+        if (run_warm) zk_launch_evm_warm(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, (evm_ext_events && !run_cold) ? e1 : nullptr);
+        if (run_cold) zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
         break;
     }
     }
@@ -1813,12 +1832,49 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     return 0;
 }
 
+// EVM sessions: the hot kernel is the fast build (EVM_FAST); a pair that needs one of the general build's fallback paths — only
+// malformed or oddly shaped witnesses produce any — is put on the session's deferred list.  Whoever asks for the pass's results
+// first (zk_collect, zk_read_status) looks at the count and, if there are such pairs, runs the general build over them before
+// answering.  A well-formed witness costs one extra 4-byte read, in the same synchronisation as the tally.
+static int evm_finish_deferred(zk_session* s) {
+    if (s->kind != SESSION_EVM || !s->deferred_pending || !s->evm.defer_count) return 0;
+    u32 n_def = 0;
+    HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->deferred_pending = false;
+    if (n_def) {
+        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ARG_TRY(s && r, "zk_collect: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     ZkTally t;
+    u32 n_def = 0;
+    const bool check_deferred = s->kind == SESSION_EVM && s->deferred_pending && s->evm.defer_count;
+    if (check_deferred) HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));  // rides on the tally's synchronisation
+    u32 gs[EVM_N_GROUPS + 1] = {0};
+    const bool read_ranges = s->kind == SESSION_EVM && s->evm.perm && !s->evm_ranges_known && s->launches > 0;
+    if (read_ranges) HIP_TRY(hipMemcpyAsync(gs, s->d_group_start, sizeof gs, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (read_ranges) {
+        s->evm_ranges_known = 1;
+        s->evm_warm_empty = gs[EVM_GROUP_WARM] == gs[EVM_GROUP_WARM + 1];
+        s->evm_cold_empty = gs[EVM_GROUP_COLD] == gs[EVM_GROUP_COLD + 1];
+    }
+    if (check_deferred) {
+        s->deferred_pending = false;
+        if (n_def) {  // the general build decides the pairs the fast kernel left (see evm_finish_deferred), then the tally is final
+            zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+        }
+    }
     double ms = 0;
     u32 timed = s->launches < (u32)MAX_EVENT_PAIRS ? s->launches : (u32)MAX_EVENT_PAIRS;
     for (u32 k = 0; k < timed; k++) {
@@ -1840,6 +1896,7 @@ extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
     ARG_TRY(s && status_host, "zk_read_status: bad arguments");
     ARG_TRY(!s->status_external, "zk_read_status: the last pass wrote its statuses to the caller's status_dev buffer, not the session's");
     HIP_TRY(hipSetDevice(s->device));
+    { int drc = evm_finish_deferred(s); if (drc) return drc; }
     HIP_TRY(hipMemcpyAsync(status_host, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;

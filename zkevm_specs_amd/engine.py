@@ -37,21 +37,22 @@ class Session:
     """RAII wrapper of zk_session*.  Inputs may be numpy arrays (staged to HBM by the library)
     or torch CUDA tensors (used in place; the caller keeps them alive)."""
 
-    def __init__(self, handle, n, keepalive):
+    def __init__(self, handle, n, keepalive, lib=None):
         self._h = handle
         self.n = n
         self._keep = keepalive
+        self._lib = lib if lib is not None else _lib.load()  # the library that opened the session (HIP, or the CPU backend's)
 
     def launch(self, status_dev=None):
         if status_dev is not None:
             _expect(status_dev, "status_dev", 4, (self.n,))
             if not _is_contiguous(status_dev):
                 raise ValueError("status_dev must be contiguous")
-        check(_lib.load().zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch")
+        check(self._lib.zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch")
 
     def collect(self):
         r = ZkResult()
-        check(_lib.load().zk_collect(self._h, ctypes.byref(r)), "zk_collect")
+        check(self._lib.zk_collect(self._h, ctypes.byref(r)), "zk_collect")
         return Result(r)
 
     def run(self):
@@ -62,20 +63,20 @@ class Session:
         """Bind the session to another HIP stream of its device (a torch.cuda.Stream, a raw handle, or None = the
         engine's own stream); passes already enqueued are waited for first."""
         h = getattr(stream, "cuda_stream", stream)
-        check(_lib.load().zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream")
+        check(self._lib.zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream")
 
     def set_range(self, row_lo, row_hi):
         """Row-circuit sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
-        check(_lib.load().zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range")
+        check(self._lib.zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range")
 
     def read_status(self):
         out = np.empty(self.n, dtype=np.uint32)
-        check(_lib.load().zk_read_status(self._h, _lib.ptr(out)), "zk_read_status")
+        check(self._lib.zk_read_status(self._h, _lib.ptr(out)), "zk_read_status")
         return out
 
     def close(self):
         if self._h:
-            _lib.load().zk_close(self._h)
+            self._lib.zk_close(self._h)
             self._h = None
 
     def __enter__(self):
@@ -158,7 +159,7 @@ def open_state(rows, flags, mpt, device=None):
     h = ctypes.c_void_p()
     check(lib.zk_state_open(_lib.ptr(rows), _lib.ptr(flags), n, _lib.ptr(mpt) if m else None, m, opts,
                             ctypes.byref(h)), "zk_state_open")
-    return Session(h, n, (rows, flags, mpt))
+    return Session(h, n, (rows, flags, mpt), lib=lib)
 
 
 def _evm_tables(wire, begin_with_first_step, end_with_last_step):
@@ -214,7 +215,7 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         opts |= _lib.OPT_GENERIC_INDEX
     h = ctypes.c_void_p()
     check(lib.zk_evm_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_evm_open")
-    return Session(h, n_pairs, arrs)
+    return Session(h, n_pairs, arrs, lib=lib)
 
 
 def evm_verify(wire, begin_with_first_step=False, end_with_last_step=False, status_dev=None, device=None):
@@ -242,7 +243,7 @@ def open_bytecode(rows, keccak, randomness, device=None):
     h = ctypes.c_void_p()
     check(lib.zk_bytecode_open(_lib.ptr(rows), n, _lib.ptr(keccak) if m else None, m, _lib.ptr(randomness), opts,
                                ctypes.byref(h)), "zk_bytecode_open")
-    return Session(h, n, (rows, keccak, randomness))
+    return Session(h, n, (rows, keccak, randomness), lib=lib)
 
 
 def open_exp(rows, device=None):
@@ -252,7 +253,7 @@ def open_exp(rows, device=None):
     (rows,), opts = _prep([rows])
     h = ctypes.c_void_p()
     check(lib.zk_exp_open(_lib.ptr(rows), rows.shape[1], opts, ctypes.byref(h)), "zk_exp_open")
-    return Session(h, rows.shape[1], (rows,))
+    return Session(h, rows.shape[1], (rows,), lib=lib)
 
 
 def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags, device=None, generic_index=False):
@@ -281,7 +282,7 @@ def open_copy(rows, row_flags, randomness, rw, rw_flags, bytecode, tx, tx_flags,
         opts |= _lib.OPT_GENERIC_INDEX
     h = ctypes.c_void_p()
     check(lib.zk_copy_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_copy_open")
-    return Session(h, int(rows.shape[1]), arrs)
+    return Session(h, int(rows.shape[1]), arrs, lib=lib)
 
 
 def open_sign(wire, randomness, is_sig, device=None):
@@ -310,7 +311,7 @@ def open_sign(wire, randomness, is_sig, device=None):
                          nrows(a["tx_rows"]), int(bool(is_sig)))
     h = ctypes.c_void_p()
     check(lib.zk_sign_open(ctypes.byref(t), opts, ctypes.byref(h)), "zk_sign_open")
-    return Session(h, n, arrs)
+    return Session(h, n, arrs, lib=lib)
 
 
 KECCAK_MODE_CIRCUIT = 0  # KeccakCircuit.add rows (EVM / bytecode circuits)
@@ -322,7 +323,7 @@ class KeccakSession(Session):
 
     def rows(self):
         out = np.empty((self.n, 5, 4), dtype=np.uint64)
-        check(_lib.load().zk_keccak_read_rows(self._h, _lib.ptr(out)), "zk_keccak_read_rows")
+        check(self._lib.zk_keccak_read_rows(self._h, _lib.ptr(out)), "zk_keccak_read_rows")
         return out
 
 
@@ -354,7 +355,7 @@ def open_keccak(data, offsets, randomness, mode=KECCAK_MODE_CIRCUIT, rows_dev=No
     h = ctypes.c_void_p()
     check(lib.zk_keccak_open(_lib.ptr(data) if n_bytes else None, n_bytes, _lib.ptr(offsets), n, _lib.ptr(randomness),
                              int(mode), _lib.ptr(rows_dev), opts, ctypes.byref(h)), "zk_keccak_open")
-    return KeccakSession(h, n, (data, offsets, randomness, rows_dev))
+    return KeccakSession(h, n, (data, offsets, randomness, rows_dev), lib=lib)
 
 
 def keccak_table(messages, randomness, mode=KECCAK_MODE_CIRCUIT, device=None):
@@ -377,7 +378,7 @@ class AssignSession(Session):
 
     def n_mpt(self):
         m = ctypes.c_uint64()
-        check(_lib.load().zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read")
+        check(self._lib.zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read")
         return int(m.value)
 
     def read(self):
@@ -387,7 +388,7 @@ class AssignSession(Session):
         flags = np.empty(self.n, dtype=np.uint32)
         mpt = np.empty((m, 12, 4), dtype=np.uint64)
         got = ctypes.c_uint64()
-        check(_lib.load().zk_state_assign_read(self._h, _lib.ptr(rows), _lib.ptr(flags), _lib.ptr(mpt) if m else None, m,
+        check(self._lib.zk_state_assign_read(self._h, _lib.ptr(rows), _lib.ptr(flags), _lib.ptr(mpt) if m else None, m,
                                                ctypes.byref(got)), "zk_state_assign_read")
         return rows, flags, mpt
 
@@ -409,7 +410,7 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     h = ctypes.c_void_p()
     check(lib.zk_state_assign_open(_lib.ptr(ops), _lib.ptr(op_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev),
                                    _lib.ptr(mpt_dev), opts, ctypes.byref(h)), "zk_state_assign_open")
-    return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev))
+    return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
 
 
 class BytecodeAssignSession(Session):
@@ -417,7 +418,7 @@ class BytecodeAssignSession(Session):
 
     def rows(self):
         out = np.empty((12, self.n, 4), dtype=np.uint64)
-        check(_lib.load().zk_bytecode_assign_read(self._h, _lib.ptr(out)), "zk_bytecode_assign_read")
+        check(self._lib.zk_bytecode_assign_read(self._h, _lib.ptr(out)), "zk_bytecode_assign_read")
         return out
 
 
@@ -438,7 +439,7 @@ def open_bytecode_assign(in_rows, offsets, lengths, k, randomness, rows_dev=None
     check(lib.zk_bytecode_assign_open(_lib.ptr(in_rows) if n_rows else None, n_rows, _lib.ptr(offsets), _lib.ptr(lengths) if n_codes else None,
                                       n_codes, int(k), _lib.ptr(randomness), _lib.ptr(rows_dev), opts, ctypes.byref(h)),
           "zk_bytecode_assign_open")
-    return BytecodeAssignSession(h, 1 << int(k), (in_rows, offsets, lengths, randomness, rows_dev))
+    return BytecodeAssignSession(h, 1 << int(k), (in_rows, offsets, lengths, randomness, rows_dev), lib=lib)
 
 
 def open_pi(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255, device=None):
@@ -453,7 +454,7 @@ def open_pi(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255, 
     h = ctypes.c_void_p()
     check(lib.zk_pi_open(_lib.ptr(rows), n, _lib.ptr(keccak) if m else None, m, _lib.ptr(gas) if k else None, k, int(circuit_len), _lib.ptr(kr),
                          _lib.ptr(bp), opts, ctypes.byref(h)), "zk_pi_open")
-    return Session(h, n, (rows, keccak, gas, kr, bp))
+    return Session(h, n, (rows, keccak, gas, kr, bp), lib=lib)
 
 
 def _copy_events_struct(events, flags, data, offsets, randomness):
@@ -484,7 +485,7 @@ class CopyAssignSession(Session):
         rows, rf = np.empty((20, self.n, 4), dtype=np.uint64), np.empty(self.n, dtype=np.uint32)
         table = np.empty((self.n_table, 14, 4), dtype=np.uint64)
         rw, rwf = np.empty((self.n_rw, 14, 4), dtype=np.uint64), np.empty(self.n_rw, dtype=np.uint32)
-        check(_lib.load().zk_copy_assign_read(self._h, _lib.ptr(rows), _lib.ptr(rf), _lib.ptr(table) if self.n_table else None,
+        check(self._lib.zk_copy_assign_read(self._h, _lib.ptr(rows), _lib.ptr(rf), _lib.ptr(table) if self.n_table else None,
                                               _lib.ptr(rw) if self.n_rw else None, _lib.ptr(rwf) if self.n_rw else None), "zk_copy_assign_read")
         return rows, rf, table, rw, rwf
 
@@ -514,7 +515,7 @@ def open_copy_assign(events, flags, data, offsets, randomness, rows_dev=None, ro
     h = ctypes.c_void_p()
     check(lib.zk_copy_assign_open(ctypes.byref(t), _lib.ptr(rows_dev), _lib.ptr(row_flags_dev), _lib.ptr(table_dev), _lib.ptr(rw_dev),
                                   _lib.ptr(rw_flags_dev), opts, ctypes.byref(h)), "zk_copy_assign_open")
-    s = CopyAssignSession(h, n_rows, arrs)
+    s = CopyAssignSession(h, n_rows, arrs, lib=lib)
     s.n_table, s.n_rw = n_table, n_rw
     return s
 
@@ -535,7 +536,7 @@ def open_ecdsa(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, out_dev=None, out_
     h = ctypes.c_void_p()
     check(lib.zk_ecdsa_open(_lib.ptr(sig_bytes), int(layout), _lib.ptr(v), int(v_stride), n, _lib.ptr(out_dev),
                             int(out_stride), opts, ctypes.byref(h)), "zk_ecdsa_open")
-    return Session(h, n, (sig_bytes, v, out_dev))
+    return Session(h, n, (sig_bytes, v, out_dev), lib=lib)
 
 
 def ecdsa_status(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, device=None, v_stride=1):

@@ -85,7 +85,6 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
     table), plus a Copy circuit (copy events expanded on the device, zk_copy_assign) and an Exp circuit — about 2^log_total
     rows in total: the EVM share is sized so that its RW table (about 2.9 rows per step) fits.  Returns the dict
     SuperCircuit takes; `rows` has the six circuits."""
-    from .synth import synth_copy_events, synth_exp_witness
     from .synth_block import rw_to_state_ops, synth_block_codes, synth_block_trace
 
     assert log_total >= 12
@@ -93,19 +92,35 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
     r = (0x1234567 * (seed + 1) ** 7 + 0x9E3779B97F4A7C15) % P
     n_contracts = min(16, 1 << (log_total - 16)) if log_total >= 16 else 2
     seg_len = 640 if log_total >= 16 else 96
-    codes = synth_block_codes(seed, seg_len=seg_len, n_contracts=n_contracts)
+    from .synth_block import synth_block_sha3_inputs
+
+    bw = 1 if log_total >= 18 else (4 if log_total >= 16 else 12)  # weight of the SHA3 / CODECOPY / EXP kinds (synth_block._BLOCK_MIX)
+    codes = synth_block_codes(seed, seg_len=seg_len, n_contracts=n_contracts, block_ops=bw)
     if keccak_rows_of is None:
         keccak_rows_of = lambda c, rr: engine.keccak_table(c, rr, engine.KECCAK_MODE_CIRCUIT)  # noqa: E731
-    keccak = keccak_rows_of(codes, r)
+    # ONE keccak pass over everything the block hashes: the contracts (their code hashes) and the SHA3 steps' inputs
+    sha3_inputs = synth_block_sha3_inputs(seed, seg_len=seg_len, n_contracts=n_contracts, block_ops=bw)
+    sha3_unique = sorted(set(sha3_inputs))
+    all_rows = keccak_rows_of(list(codes) + sha3_unique, r)
+    keccak = np.ascontiguousarray(all_rows[: len(codes)])
+    sha3_rows = np.ascontiguousarray(all_rows[len(codes):])
     hashes = [_digest_of_row(keccak[i]) for i in range(len(codes))]
+    sha3_digest = {m: _digest_of_row(sha3_rows[i]).to_bytes(32, "big") for i, m in enumerate(sha3_unique)}
     n_code_rows = sum(len(c) + 1 for c in codes)
     k = max(6, int(np.ceil(np.log2(n_code_rows + 1))))
     n_tx = 1 << max(log_total - 8, 2)
-    n_copy_target = 1 << max(log_total - 5, 6)
-    n_exp = 1 << max(log_total - 8, 4)
-    n_steps = int((total - (1 << k) - n_tx - n_copy_target - n_exp) / 3.95)
-    evm = synth_block_trace(n_steps, seed=seed, seg_len=seg_len, n_contracts=n_contracts, code_hashes=hashes)
+    # EVM share: BASELINE configs[4] has the 2^18-step trace inside a ~2^20-row block; smaller blocks scale it (a step brings
+    # ~2.9 State rows and, through its SHA3 / CODECOPY / EXP steps, ~0.2 Copy / Exp rows)
+    n_steps = (1 << (log_total - 2)) if log_total >= 16 else int((total - (1 << k) - n_tx) / 4.3)
+    evm = synth_block_trace(n_steps, seed=seed, seg_len=seg_len, n_contracts=n_contracts, code_hashes=hashes, block_ops=bw,
+                            digest_of=lambda msgs: [sha3_digest[m] for m in msgs], randomness=r)
     meta = evm.pop("meta")
+    copy_ev = evm.pop("copy_events")
+    exp_rows = evm.pop("exp_rows")
+    evm.pop("sha3_inputs")
+    evm["keccak"] = sha3_rows  # the EVM circuit's keccak table: the SHA3 steps' rows (execution/sha3.py:31)
+    # evm["exp"] (the exp table of the EXP steps) came with the trace; evm["copy"] is produced by the copy assignment (SuperCircuit)
+    copy_ev["from_trace"] = True  # the Copy circuit looks up the BLOCK's RW / bytecode tables, not tables of its own
     ops, op_flags = rw_to_state_ops(evm["rw"], evm["rw_flags"])
     digest = dict(zip(codes, hashes))
     bc_rows, bc_keccak = synth_bytecode_witness(codes, k, r, digest=lambda c: digest[c])
@@ -115,12 +130,11 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
     starts = [0] + [i for i in range(1, n_bt) if not np.array_equal(bt[i, 0:2], bt[i - 1, 0:2])] + [n_bt]
     offsets = np.array(starts, dtype=np.uint64)
     lengths = (offsets[1:] - offsets[:-1] - np.uint64(1)).astype(np.uint64)
-    copy_ev = synth_copy_events(n_copy_target, seed=seed + 3)
-    exp_rows = synth_exp_witness(n_exp, seed=seed + 4)
+    n_exp = int(exp_rows.shape[1])
     rows = {"evm": n_steps - 1, "state": int(ops.shape[1]), "bytecode": 1 << k, "tx": n_tx, "copy": int(copy_ev["n_rows"]), "exp": n_exp}
     return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "bytecode_unrolled": (bt, offsets, lengths, k),
             "tx": (tx, r), "copy_events": copy_ev, "exp_rows": exp_rows, "rows": rows,
-            "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True)}
+            "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True, copy_exp_rows_from_trace=True)}
 
 
 def _on_device(x):
@@ -181,8 +195,38 @@ class SuperCircuit:
         if not res.ok:
             raise exception_for_code(res.first_fail_code, f"bytecode witness assignment: row {res.first_fail_row}")
         dev_rows = bc_rows
+        # Copy circuit: the block's copy events expanded on the device (zk_copy_assign): the Copy circuit's rows, the EVM circuit's
+        # copy table and (for events that do not come from the trace) the RW rows they imply
+        copy_open = None
+        if "copy_events" in parts and int(parts["copy_events"]["events"].shape[0]) > 0:  # (a block without copy events has no Copy circuit rows)
+            ce = parts["copy_events"]
+            ev, fl, da, of = dev(ce["events"]), dev(ce["flags"]), (dev(ce["data"].view(np.int16)) if hasattr(ops, "is_cuda") else ce["data"]), dev(ce["offsets"])
+            if hasattr(ops, "is_cuda"):
+                import torch
+
+                h_ev, h_fl, h_da, h_of = (x.cpu().numpy() if hasattr(x, "is_cuda") else x for x in (ce["events"], ce["flags"], ce["data"], ce["offsets"]))
+                n_rows, n_table, n_rw = engine.copy_assign_sizes(h_ev.view(np.uint64), h_fl.view(np.uint32), h_da.view(np.uint16), h_of.view(np.uint64), device)
+                c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device=ops.device)
+                c_rf = torch.empty(n_rows, dtype=torch.int32, device=ops.device)
+                c_table = torch.empty((n_table, 14, 4), dtype=torch.int64, device=ops.device)
+                c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=ops.device)
+                c_rwf = torch.empty(n_rw, dtype=torch.int32, device=ops.device)
+                with engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, c_table, c_rw, c_rwf, device=device) as a:
+                    res = a.run()
+                if not res.ok:
+                    raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
+            else:
+                with engine.open_copy_assign(ce["events"], ce["flags"], ce["data"], ce["offsets"], ce["r"], device=device) as a:
+                    res = a.run()
+                    if not res.ok:
+                        raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
+                    c_rows, c_rf, c_table, c_rw, c_rwf = a.read()
+            copy_open = (c_rows, c_rf, c_table, c_rw, c_rwf, ce)
         tx, r_tx = parts["tx"]
         evm_w = {k: dev(v) for k, v in parts["evm"].items()}
+        if copy_open is not None and copy_open[5].get("from_trace"):
+            evm_w["copy"] = copy_open[2]  # the copy table the SHA3 / CODECOPY steps look up = the table of the very events the Copy circuit checks
+
         tx_w = {k: dev(v) for k, v in tx.items()}
         self.global_rows = {"evm": int(evm_w["steps"].shape[0]) - 1, "state": int(rows.shape[1]), "bytecode": int(dev_rows.shape[1]),
                             "tx": int(tx_w["bytes"].shape[0])}
@@ -201,35 +245,19 @@ class SuperCircuit:
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign(tx_w, r_tx, False, device=device),
         }
-        # Copy circuit: events expanded on the device (rows + their RW rows), then evaluated from the same HBM buffers
-        if "copy_events" in parts:
-            ce = parts["copy_events"]
-            ev, fl, da, of = dev(ce["events"]), dev(ce["flags"]), (dev(ce["data"].view(np.int16)) if hasattr(ops, "is_cuda") else ce["data"]), dev(ce["offsets"])
-            if hasattr(ops, "is_cuda"):
-                import torch
-
-                n_rows, n_table, n_rw = engine.copy_assign_sizes(ce["events"], ce["flags"], ce["data"], ce["offsets"], device)
-                c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device=ops.device)
-                c_rf = torch.empty(n_rows, dtype=torch.int32, device=ops.device)
-                c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=ops.device)
-                c_rwf = torch.empty(n_rw, dtype=torch.int32, device=ops.device)
-                with engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, None, c_rw, c_rwf, device=device) as a:
-                    res = a.run()
-                if not res.ok:
-                    raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
-            else:
-                with engine.open_copy_assign(ce["events"], ce["flags"], ce["data"], ce["offsets"], ce["r"], device=device) as a:
-                    res = a.run()
-                    if not res.ok:
-                        raise exception_for_code(res.first_fail_code, f"copy witness assignment: event {res.first_fail_row}")
-                    c_rows, c_rf, _, c_rw, c_rwf = a.read()
+        if copy_open is not None:
+            c_rows, c_rf, c_table, c_rw, c_rwf, ce = copy_open
             self.global_rows["copy"], self.row_lo["copy"] = int(c_rows.shape[1]), 0
             if world > 1:
                 c_rows, c_rf, lo_, hi_, self.row_lo["copy"] = distributed.shard_rows(c_rows, c_rf, rank, world, "copy")
                 ranges["copy"] = (lo_, hi_)
-            self.sessions["copy"] = engine.open_copy(c_rows, c_rf, ce["r"], c_rw, c_rwf, dev(ce["bytecode"]), dev(ce["tx"]), dev(ce["tx_flags"]),
-                                                     device=device)
-        if "exp_rows" in parts:
+            if ce.get("from_trace"):  # the events are the trace's: the Copy circuit looks up the block's own RW / bytecode / tx tables
+                self.sessions["copy"] = engine.open_copy(c_rows, c_rf, ce["r"], evm_w["rw"], evm_w["rw_flags"], evm_w["bytecode"], evm_w["tx"],
+                                                         evm_w["tx_flags"], device=device)
+            else:
+                self.sessions["copy"] = engine.open_copy(c_rows, c_rf, ce["r"], c_rw, c_rwf, dev(ce["bytecode"]), dev(ce["tx"]), dev(ce["tx_flags"]),
+                                                         device=device)
+        if "exp_rows" in parts and int(parts["exp_rows"].shape[1]) > 0:
             e_rows = dev(parts["exp_rows"])
             self.global_rows["exp"], self.row_lo["exp"] = int(e_rows.shape[1]), 0
             if world > 1:

@@ -32,6 +32,10 @@ ES, OP, TG, CC = T.ExecutionState, T.Opcode, T.Target, T.CallContextFieldTag
 _MIX = [(12, "ADDSUB"), (10, "MULDIVMOD"), (5, "CMP"), (3, "SCMP"), (4, "BITWISE"), (2, "NOT"), (5, "ISZERO"), (3, "BYTE"),
         (2, "SIGNEXTEND"), (5, "SHIFT"), (1.5, "ADDMOD"), (1.5, "MULMOD"), (6, "POP"), (4, "MEMORY"), (1, "SLOAD"), (1, "SSTORE"),
         (2, "READER"), (14, "PUSH")]
+# config 5's copy / keccak / exp traffic comes from the trace itself (block_ops=True): SHA3 over a word the program has just stored
+# (execution/sha3.py:20-34: copy lookup Memory -> RlcAcc + keccak lookup), CODECOPY of a piece of the running contract
+# (codecopy.py:26: copy lookup Bytecode -> Memory) and EXP with a small exponent (exp.py:31-33: two exp-table lookups)
+_BLOCK_MIX = [(0.16, "SHA3"), (0.14, "CODECOPY"), (0.12, "EXP")]
 _POPS = {"ADDSUB": 2, "MULDIVMOD": 2, "CMP": 2, "SCMP": 2, "BITWISE": 2, "NOT": 1, "ISZERO": 1, "BYTE": 2, "SHIFT": 2, "MULMOD": 3, "POP": 1,
          "SLOAD": 1, "SSTORE": 2, "READER": 0, "PUSH": 0}
 _READERS = ["ADDRESS", "CALLER", "CALLVALUE", "CALLDATASIZE", "CODESIZE"]
@@ -44,9 +48,13 @@ STATE_TAG_OF_TARGET = {int(TG.Start): 1, int(TG.Memory): 2, int(TG.Stack): 3, in
 class _Program:
     """straight-line contract generated against a stack-depth counter: no instruction ever finds too few operands"""
 
-    def __init__(self, rng, n_ops, seed_tag=0):
+    def __init__(self, rng, n_ops, seed_tag=0, block_ops=False):
         self.ops, code, depth = [], bytearray(), 0
-        kinds, weights = [k for _, k in _MIX], [w for w, _ in _MIX]
+        # block_ops: False, or the weight multiplier of the SHA3 / CODECOPY / EXP kinds (True = 1: BASELINE configs[4]'s shares at 2^18 steps;
+        # small test blocks raise it so that a few of each appear)
+        mix = _MIX + ([(w * float(block_ops), k) for w, k in _BLOCK_MIX] if block_ops else [])
+        kinds, weights = [k for _, k in mix], [w for w, _ in mix]
+        self.sha3_inputs = []
 
         def emit(name, data=b""):
             self.ops.append((name, len(code), data))
@@ -71,6 +79,33 @@ class _Program:
                 emit(name)
                 depth -= 1 if name == "MLOAD" else 2
                 depth += 1 if name == "MLOAD" else 0
+                continue
+            if kind == "SHA3":  # store a constant word, then hash exactly those 32 bytes: the input is known when the program is written
+                c = rng.getrandbits(256)
+                off = rng.randrange(0, 4096)
+                push(32, c)
+                push(2, off)
+                emit("MSTORE")
+                depth -= 2
+                push(1, 32)
+                push(2, off)
+                emit("SHA3")
+                depth -= 1
+                self.sha3_inputs.append(c.to_bytes(32, "big"))
+                continue
+            if kind == "CODECOPY":  # size, code offset, memory offset from pushes right in front (reads past the code's end pad with zeros)
+                push(1, rng.randrange(1, 64))
+                push(2, rng.randrange(0, 700))
+                push(2, rng.randrange(0, 4096))
+                emit("CODECOPY")
+                depth -= 3
+                continue
+            if kind == "EXP":  # exponent >= 2 from a PUSH1 / PUSH2 (the exp circuit's trace is ~1.5 rows per exponent bit), any base
+                e_ = rng.randrange(2, 1 << rng.choice([3, 8, 12]))
+                push(1 if e_ < 256 else 2, e_)
+                push(rng.choice([1, 8, 32]))
+                emit("EXP")
+                depth -= 1
                 continue
             if kind == "ADDMOD":  # the modulus must be below the field modulus (addmod.py:61): a 31-byte push, then a, b
                 push(31)
@@ -111,6 +146,10 @@ class _Program:
             assert depth >= 0
         emit("STOP")
         self.code = bytes(code)
+        self.is_code = bytearray(b"\x01" * len(self.code))  # 0 on push data (bytecode table's is_code column)
+        for _, pc_, data_ in self.ops:
+            for k in range(len(data_)):
+                self.is_code[pc_ + 1 + k] = 0
         h = rng.getrandbits(256)
         self.hash = (h & M128, h >> 128)
 
@@ -125,15 +164,69 @@ class _Program:
         return rows
 
 
-def synth_block_codes(seed=5, seg_len=640, n_contracts=16):
+def synth_block_codes(seed=5, seg_len=640, n_contracts=16, block_ops=False):
     rng = random.Random(seed)
-    return [_Program(rng, seg_len - 1, k).code for k in range(n_contracts)]
+    return [_Program(rng, seg_len - 1, k, block_ops).code for k in range(n_contracts)]
 
 
-def synth_block_trace(n_steps, seed=5, seg_len=640, n_contracts=16, code_hashes=None):
-    """-> EVM wire dict (steps, rw, rw_flags, bytecode, tx, tx_flags, block, block_flags, meta) of a consistent n_steps-step trace"""
+def synth_block_sha3_inputs(seed=5, seg_len=640, n_contracts=16, block_ops=True):
+    """the byte strings the SHA3 steps of synth_block_trace(seed, ..., block_ops) hash (known from the programs alone)"""
     rng = random.Random(seed)
-    contracts = [_Program(rng, seg_len - 1, k) for k in range(n_contracts)]
+    return [m for k in range(n_contracts) for m in _Program(rng, seg_len - 1, k, block_ops).sha3_inputs]
+
+
+def exp_event_rows(base, exponent, identifier):
+    """ExpCircuit.add_event(base, exponent, identifier) (evm_circuit/typing.py:880-939): the square-and-multiply steps, most
+    significant first -> (circuit rows of 21 cells, table rows of 11 cells: ExpTableRow, table.py:654-671)"""
+    M = M256
+    lo_hi = lambda v: [v & M128, v >> 128]  # noqa: E731
+    steps = []
+
+    def rec(e):
+        if e == 0:
+            return 1
+        if e == 1:
+            return base
+        e1 = rec(e // 2)
+        e2 = (e1 * e1) & M
+        steps.append((e1, e1, e2))
+        if e % 2 == 0:
+            return e2
+        ex = (base * e2) & M
+        steps.append((e2, base, ex))
+        return ex
+
+    rec(exponent)
+    steps.reverse()
+    rows, table, e = [], [], exponent
+    limbs = [(base >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
+    for i, (a, b, d) in enumerate(steps):
+        q, odd = divmod(e, 2)
+        last = int(i == len(steps) - 1)
+        rows.append([1, 1, identifier, last] + lo_hi(base) + lo_hi(e) + lo_hi(d) + lo_hi(a) + lo_hi(b) + [0, 0] + lo_hi(d) + lo_hi(q) + [odd])
+        table.append([1, identifier, last] + limbs + lo_hi(e) + lo_hi(d))
+        e = e // 2 if odd == 0 else e - 1
+    return rows, table
+
+
+def synth_block_trace(n_steps, seed=5, seg_len=640, n_contracts=16, code_hashes=None, block_ops=False, digest_of=None, randomness=None):
+    """-> EVM wire dict (steps, rw, rw_flags, bytecode, tx, tx_flags, block, block_flags, meta) of a consistent n_steps-step trace.
+    block_ops=True: the programs also hash, copy code and exponentiate (SHA3 / CODECOPY / EXP); the dict then carries what the
+    other circuits and tables of the block are derived from — `copy_events` (the events of those steps in zk_copy_events form,
+    rw_counters absolute: zk_copy_assign expands them to the Copy circuit's rows and the EVM circuit's copy table; their Memory
+    rows are ALREADY in `rw`), `exp_rows` / `exp` (Exp circuit rows, column-major, and the EVM circuit's exp table), `sha3_inputs`
+    (the keccak table's messages).  digest_of(list of bytes) -> list of 32-byte keccak-256 digests (the pushed hashes must be the
+    real ones: the keccak table is built from the inputs); randomness: the block's keccak randomness (copy-table RLCs)."""
+    rng = random.Random(seed)
+    contracts = [_Program(rng, seg_len - 1, k, block_ops) for k in range(n_contracts)]
+    digest = {}
+    if block_ops:
+        assert digest_of is not None and randomness is not None, "block_ops needs keccak digests and the keccak randomness"
+        msgs = [m for c in contracts for m in c.sha3_inputs]
+        digest = dict(zip(msgs, digest_of(msgs)))
+    copy_events, copy_flags, copy_data, copy_offsets = [], [], [], [0]
+    exp_rows, exp_table = [], []
+    fixups = []  # (list, index, column): rw_counter-valued cells recorded relative to the prelude, shifted with the rows at the end
     if code_hashes is not None:
         for c, h in zip(contracts, code_hashes):
             c.hash = (h & M128, h >> 128)
@@ -302,6 +395,50 @@ def synth_block_trace(n_steps, seed=5, seg_len=640, n_contracts=16, code_hashes=
                 push(len(C.code), -1)
                 sp -= 1
                 n_bc += 1
+            elif name == "SHA3":
+                off, size = pop(0), pop(1)
+                data = bytes(memory.get(off + k, 0) for k in range(size))
+                push(int.from_bytes(digest[data], "big"), 1)
+                sp += 1
+                copy_events.append([call_id, 0, 2, call_id, 0, 5, off, off + size, 0, size, 0, rwc])  # Memory -> RlcAcc
+                fixups.append((copy_events, len(copy_events) - 1, 11))
+                copy_flags.append(0)
+                copy_data.extend(data)
+                copy_offsets.append(len(copy_data))
+                for k in range(size):
+                    add_rw(0, TG.Memory, call_id, off + k, value=data[k], vw=False)
+                nxt = max(mws, (off + size + 31) // 32)
+                gas += 6 * ((size + 31) // 32) + (nxt * nxt // 512 + 3 * nxt) - (mws * mws // 512 + 3 * mws)
+                mws = nxt
+            elif name == "CODECOPY":
+                moff, coff, size = pop(0), pop(1), pop(2)
+                sp += 3
+                n_real = max(0, min(size, len(C.code) - coff))
+                copy_events.append([C.hash[0], C.hash[1], 1, call_id, 0, 2, coff, len(C.code), moff, size, 0, rwc])  # Bytecode -> Memory
+                fixups.append((copy_events, len(copy_events) - 1, 11))
+                copy_flags.append(1)  # the source id is a Word (the code hash)
+                copy_data.extend(C.code[coff + k] | (C.is_code[coff + k] << 8) for k in range(n_real))
+                copy_offsets.append(len(copy_data))
+                for k in range(size):
+                    b = C.code[coff + k] if k < n_real else 0
+                    memory[moff + k] = b
+                    add_rw(1, TG.Memory, call_id, moff + k, value=b, vw=False)
+                n_bc += n_real
+                nxt = max(mws, (moff + size + 31) // 32)
+                gas += 3 * ((size + 31) // 32) + (nxt * nxt // 512 + 3 * nxt) - (mws * mws // 512 + 3 * mws)
+                mws = nxt
+            elif name == "EXP":
+                base, exponent = pop(0), pop(1)
+                push(pow(base, exponent, 1 << 256), 1)
+                sp += 1
+                rows_, table_ = exp_event_rows(base, exponent, rwc)  # identifier = the rw_counter after the three stack rows (exp.py:31)
+                for r_ in rows_:
+                    fixups.append((exp_rows, len(exp_rows), 2))
+                    exp_rows.append(r_)
+                for t_ in table_:
+                    fixups.append((exp_table, len(exp_table), 1))
+                    exp_table.append(t_)
+                gas += 50 * ((exponent.bit_length() + 7) // 8)
             elif name == "STOP":
                 n_bc += 1
                 nxt_seg = seg + 1
@@ -333,13 +470,24 @@ def synth_block_trace(n_steps, seed=5, seg_len=640, n_contracts=16, code_hashes=
         row[0] += K + 1
     for s in steps:
         s[1] += K + 1
+    for lst, j, col in fixups:
+        lst[j][col] += K + 1
     rw, rw_flags = pre + rw, pre_flags + rw_flags
     bytecode_rows = [r for c in contracts for r in c.table_rows()]
     meta = {"n_steps": n_steps, "n_pairs": n_steps - 1, "n_rw": len(rw), "n_bytecode": len(bytecode_rows), "segments": seg,
             "prelude_rows": K, "looked_up_cells": looked_up_cells, "algorithmic_bytes": 32 * (13 * (n_steps - 1) + looked_up_cells)}
-    return {"steps": rows_to_rowmajor(steps, 13), "rw": rows_to_rowmajor(rw, 14), "rw_flags": np.array(rw_flags, dtype=np.uint32),
-            "bytecode": rows_to_rowmajor(bytecode_rows, 6), "tx": np.zeros((0, 5, 4), dtype=np.uint64), "tx_flags": np.zeros(0, dtype=np.uint32),
-            "block": np.zeros((0, 4, 4), dtype=np.uint64), "block_flags": np.zeros(0, dtype=np.uint32), "meta": meta}
+    out = {"steps": rows_to_rowmajor(steps, 13), "rw": rows_to_rowmajor(rw, 14), "rw_flags": np.array(rw_flags, dtype=np.uint32),
+           "bytecode": rows_to_rowmajor(bytecode_rows, 6), "tx": np.zeros((0, 5, 4), dtype=np.uint64), "tx_flags": np.zeros(0, dtype=np.uint32),
+           "block": np.zeros((0, 4, 4), dtype=np.uint64), "block_flags": np.zeros(0, dtype=np.uint32), "meta": meta}
+    if block_ops:
+        meta.update(copy_events=len(copy_events), copy_rows=2 * sum(e[9] for e in copy_events), exp_rows=len(exp_rows), sha3_steps=len(digest))
+        out["copy_events"] = {"events": rows_to_rowmajor(copy_events, 12), "flags": np.array(copy_flags, dtype=np.uint32),
+                              "data": np.array(copy_data, dtype=np.uint16), "offsets": np.array(copy_offsets, dtype=np.uint64), "r": int(randomness),
+                              "n_rows": 2 * sum(e[9] for e in copy_events)}
+        out["exp_rows"] = rows_to_colmajor(exp_rows, 21)
+        out["exp"] = rows_to_rowmajor(exp_table, 11)
+        out["sha3_inputs"] = [m for c in contracts for m in c.sha3_inputs]
+    return out
 
 
 MAX_STATE_FIELD_TAG = 24  # state_circuit.py:34
