@@ -36,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import zkevm_specs_amd  # noqa: E402,F401  (before torch touches the GPU: the package sets the HIP runtime's hardware-queue default)
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈ 6.3 TB/s achievable)
 N_SIMD = 1024                # 256 CUs x 4 SIMDs

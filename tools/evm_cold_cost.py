@@ -11,7 +11,7 @@ dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x
 full = list(synth_block._BLOCK_MIX)
 for mix in ([[], [full[0]], [full[1]], [full[2]], full] if not os.environ.get('ONLY') else [[full[int(k)] for k in os.environ['ONLY'].split(',') if k != '']]):
     synth_block._BLOCK_MIX[:] = mix if mix else [(1e-9, "EXP")]
-    p = synth_super_block(18, seed=5)
+    p = synth_super_block(int(os.environ.get("LOGT", "18")), seed=5)
     with SuperCircuit(p, to_device=dev) as sc:
         ev = sc.sessions["evm"]
         ev.run()

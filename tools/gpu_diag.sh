@@ -1,9 +1,20 @@
 #!/bin/bash
 out=gpurun_out/diag; mkdir -p $out
-for only in "" "0" "1" "2"; do
-cd /tmp && export TMPDIR=/tmp
-ONLY="$only," timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/trace -- python $GRAFT_REPO_ROOT/tools/evm_cold_cost.py > $GRAFT_REPO_ROOT/$out/trace.log 2>&1
-cd $GRAFT_REPO_ROOT
-grep "steps" $out/trace.log
-f=$(find $out/trace -name '*kernel_stats.csv' | head -1); grep "evm_steps_kernel\|evm_deferred" "$f" | cut -d, -f1-4,6,7 ; rm -rf $out/trace
+for q in 4 8 12; do
+echo "== GPU_MAX_HW_QUEUES=$q"
+GPU_MAX_HW_QUEUES=$q python bench.py --workload super --no-cpu-baseline --steps 20 --warmup 3 2>&1 | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d = json.loads(ln); print(d['value'], d['ms_per_step'], d['config'].get('per_circuit_kernel_ms'))
+"
+done
+echo "== tx"
+for q in 4 8; do
+GPU_MAX_HW_QUEUES=$q python bench.py --workload tx --no-cpu-baseline --steps 10 --warmup 2 2>&1 | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d = json.loads(ln); print(d['value'], d['ms_per_step'])
+"
 done

@@ -331,7 +331,10 @@ ZK_HD u64 blk_key_hash(const ZkTable& t, u32 r) { return blk_key_hash_cells(zk_t
 
 ZK_HD u64 copy_key_hash_cells(const Fr& rwc, const Fr& src_addr) { return zk_hash_cell(zk_hash_cell(0xc09fu, rwc), src_addr); }
 ZK_HD u64 copy_key_hash(const ZkTable& t, u32 r) { return copy_key_hash_cells(zk_table_cell(t, r, CT_RWC), zk_table_cell(t, r, CT_SRC_ADDR)); }
-ZK_HD u64 expt_key_hash_cells(const Fr& id, const Fr& is_last) { return zk_hash_cell(zk_hash_cell(0xe4b7u, id), is_last); }
+// exp table: keyed on (identifier, is_last, exponent.lo) — every exp lookup gives the exponent, and the rows of one exponentiation share
+// (identifier, is_last = 0): keyed on those two alone, a lookup walked the whole trace of its exponentiation, two dependent HBM round
+// trips per row (a wavefront of EXP steps took ~400 us)
+ZK_HD u64 expt_key_hash_cells(const Fr& id, const Fr& is_last, const Fr& exp_lo) { return zk_hash_cell(zk_hash_cell(zk_hash_cell(0xe4b7u, id), is_last), exp_lo); }
 ZK_HD u64 sig_key_hash_cells(const Fr& msg_lo, const Fr& r_lo, const Fr& s_lo) { return zk_hash_cell(zk_hash_cell(zk_hash_cell(0x516u, msg_lo), r_lo), s_lo); }
 ZK_HD u64 sig_key_hash(const ZkTable& t, u32 r) { return sig_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 3), zk_table_cell(t, r, 5)); }
 ZK_HD u64 ecc_key_hash_cells(const Fr& op, const Fr& px_lo, const Fr& qx_lo, const Fr& input_rlc) {
@@ -340,7 +343,7 @@ ZK_HD u64 ecc_key_hash_cells(const Fr& op, const Fr& px_lo, const Fr& qx_lo, con
 ZK_HD u64 ecc_key_hash(const ZkTable& t, u32 r) {
     return ecc_key_hash_cells(zk_table_cell(t, r, 0), zk_table_cell(t, r, 1), zk_table_cell(t, r, 5), zk_table_cell(t, r, 9));
 }
-ZK_HD u64 expt_key_hash(const ZkTable& t, u32 r) { return expt_key_hash_cells(zk_table_cell(t, r, XT_ID), zk_table_cell(t, r, XT_IS_LAST)); }
+ZK_HD u64 expt_key_hash(const ZkTable& t, u32 r) { return expt_key_hash_cells(zk_table_cell(t, r, XT_ID), zk_table_cell(t, r, XT_IS_LAST), zk_table_cell(t, r, XT_EXP_LO)); }
 
 ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
     bool same = true;
@@ -751,7 +754,7 @@ ZK_HD Word exp_lookup(Ins& I, const Fr& identifier, const Fr& is_last, const u64
     q[XT_IS_STEP] = fr_u(1); q[XT_ID] = identifier; q[XT_IS_LAST] = is_last;
     for (int k = 0; k < 4; k++) q[XT_BASE0 + k] = fr_u(base_limbs[k]);
     q[XT_EXP_LO] = exponent.lo; q[XT_EXP_HI] = exponent.hi; q[XT_RES_LO] = fr_zero(); q[XT_RES_HI] = fr_zero();
-    u32 r = table_lookup<EXP_T_NCELLS>(I, I.a->exp, expt_key_hash_cells(identifier, is_last), q, 0x1ffu);
+    u32 r = table_lookup<EXP_T_NCELLS>(I, I.a->exp, expt_key_hash_cells(identifier, is_last, exponent.lo), q, 0x1ffu);
     return word_of(zk_table_cell(I.a->exp, r, XT_RES_LO), zk_table_cell(I.a->exp, r, XT_RES_HI));
 }
 

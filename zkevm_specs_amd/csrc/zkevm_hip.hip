@@ -49,6 +49,13 @@ static thread_local std::string g_err;
     } while (0)
 
 extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
+
+// The circuits of a block run as concurrent sessions, one HIP stream each (SuperCircuit: six).  The HIP runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run back to back: with 4 queues the
+// EVM and State sessions of the 2^20-row block landed on one queue and the pass took their SUM (0.49 ms vs 0.37 ms with 8).  The
+// runtime reads the variable at its first API call, so a default set when this library is loaded is early enough for any host that
+// has not used HIP yet; a host that has, or that sets the variable itself, keeps its own choice.
+__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 static void arena_release_all();
 
 extern "C" int zk_init(int device) {
