@@ -39,6 +39,8 @@ extern "C" int sim_state_verify_range(const u64* cells, const u32* flags, u64 n,
     std::vector<u32> slots;
     u32 mask = 0;
     build_index(slots, mask, (u32)n_mpt, state_mpt_key_hash, a.mpt);
+    for (u32& sv : slots)  // MPT slots carry a hash fingerprint (state_mpt_slot_value)
+        if (sv != ZK_EMPTY_SLOT) sv = state_mpt_slot_value(a.mpt, sv, state_mpt_key_hash(a.mpt, sv));
     a.eval_lo = lo;
     a.eval_hi = hi;
     for (u64 i = lo; i < hi; i++) status[i] = state_check_row(a, i);

@@ -210,7 +210,16 @@ extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64
     s->a64[0].assign(rows, rows + n * ST_NCELLS * 4);
     if (flags) s->a32[0].assign(flags, flags + n);
     else s->a32[0].assign(n, 0u);
-    cpu_table(s->tab[0], mpt, nullptr, n_mpt, MPT_NCELLS, state_mpt_key_hash);
+    cpu_table(s->tab[0], mpt, nullptr, n_mpt, MPT_NCELLS, nullptr);
+    {  // the MPT index carries a hash fingerprint in each slot (state_mpt_slot_value)
+        CpuTable& h = s->tab[0];
+        for (u32 r = 0; r < (u32)n_mpt; r++) {
+            const u64 hv = state_mpt_key_hash(h.t, r);
+            u32 k = (u32)hv & h.t.mask;
+            while (h.slots[k] != ZK_EMPTY_SLOT) k = (k + 1) & h.t.mask;
+            h.slots[k] = state_mpt_slot_value(h.t, r, hv);
+        }
+    }
     s->state.rows.cells = s->a64[0].data();
     s->state.rows.flags = s->a32[0].data();
     s->state.rows.n = n;

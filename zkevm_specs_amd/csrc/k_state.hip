@@ -1,33 +1,68 @@
 // State-circuit kernel (state_circuit.hpp)
 #include "kernels.hpp"
 #include <stdlib.h>
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------
-// State circuit kernel.  Column-major cells make every cell load a fully coalesced 32 B/lane
-// access (2 x dwordx4).  A lane loads ONLY its own row; what the checks need from the previous
-// row arrives from lane - 1 through DPP moves, so every wavefront evaluates 63 rows and its
-// lane 0 holds the (read-only) row in front of them.  The next row (Storage / Account last-
-// access test) is re-read through L1/L2 by the few rows that need it.
+// State circuit kernels.  Column-major cells; one lane per row; what the checks need from the previous row arrives from lane - 1
+// through DPP moves, so a wavefront evaluates 63 rows and its lane 0 holds the (read-only) row in front of them.
+//   state_rows_dma_kernel   (default) the 14 wide cells are ordinary loads, the 42 limb / byte cells stream through a per-wavefront
+//                           LDS ring with global_load_lds (state_load_row_dma)
+//   state_rows_group_kernel<4>  ZK_STATE_DMA=0: a lane quad per row, everything through registers (round 2's small-batch form,
+//                           kept as the comparison point; round 2's one-lane all-register kernel is gone: with the batched MPT
+//                           compare it no longer fits 256 registers)
 // ---------------------------------------------------------------------------------------
-#ifndef ZK_STATE_OCC
-#define ZK_STATE_OCC 2  // waves per SIMD the State kernel is compiled for (3 was measured: 168 VGPRs + 32 B scratch, 2^20 rows 0.423 vs 0.404 ms)
+// The same evaluation with the 42 limb / byte cells streamed through a per-wavefront LDS ring (state_load_row_dma).
+#ifndef ZK_STATE_DMA_OCC
+#define ZK_STATE_DMA_OCC 2
 #endif
-__global__ __launch_bounds__(256, ZK_STATE_OCC) void state_rows_kernel(StateArgs a, u32* status, ZkTally* tally) {
+__global__ __launch_bounds__(256, ZK_STATE_DMA_OCC) void state_rows_dma_kernel(StateArgs a, u32* status, ZkTally* tally) {
+    extern __shared__ uint4 st_lds[];
     tally_clear_twin(tally);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;  // first row this wavefront evaluates
+    const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;
     const u64 n = a.rows.n;
-    // lane l holds row first + l - 1 (lane 0: the predecessor of `first`, wrapping to n - 1)
-    u64 i = lane == 0 ? (first == 0 ? n - 1 : first - 1) : first + lane - 1;
-    const bool evaluate = lane != 0 && i < a.eval_hi;
-    if (i >= n) i = n - 1;  // lanes past the range still take part in the DPP moves: keep their loads in bounds
+    // lane j holds row rowof(j): the predecessor of `first` (wrapping to n - 1) in lane 0, then first, first + 1, ...; rows past
+    // the witness are clamped to n - 1 so that every load stays in bounds (those lanes do not report)
+    auto rowof = [&](u32 j) -> u64 {
+        u64 r = j == 0 ? (first == 0 ? n - 1 : first - 1) : first + j - 1;
+        return r >= n ? n - 1 : r;
+    };
+    const u64 i_raw = lane == 0 ? (first == 0 ? n - 1 : first - 1) : first + lane - 1;
+    const bool evaluate = lane != 0 && i_raw < a.eval_hi;
+    const u64 i = rowof(lane);
+    const u64 off[2] = {rowof(lane >> 1) * 32u + (lane & 1u) * 16u, rowof(32u + (lane >> 1)) * 32u + (lane & 1u) * 16u};
+    uint4* ring = st_lds + (threadIdx.x >> 6) * (ST_DMA_WAVE_BYTES / 16);
     StRow C;
     u32 code = 0;
-    state_load_row(a.rows, i, C, code);
+#ifdef ZK_STATE_PROF  // tuning build (tools/state_wave_timeline.py): per-wavefront clocks + placement instead of the row status
+    const u64 t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+#endif
+    state_load_row_dma(a.rows, i, off, ring, lane, C, code);
+#ifdef ZK_STATE_PROF
+    const u64 c1 = __builtin_amdgcn_s_memtime();
+#endif
     code = state_check_loaded<1>(a, i, C, C, code);
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2  // per-row clocks of the Storage / Account branch instead of the status
+    if (status && evaluate) status[i] = code;
+    code = 0;
+#elif defined(ZK_STATE_PROF)
+    if (!evaluate) code = 0;
+    if (status && lane == 0 && first + 17 < n) {
+        const u64 t1 = __builtin_amdgcn_s_memrealtime(), c2 = __builtin_amdgcn_s_memtime();
+        u32* o = status + first;
+        o[0] = (u32)t0; o[1] = (u32)(t0 >> 32); o[2] = (u32)t1; o[3] = (u32)(t1 >> 32);
+        o[4] = (u32)(c1 - c0); o[5] = (u32)(c2 - c0);
+        o[9] = (u32)(st_prof_stamp[threadIdx.x >> 6][0] - c0); o[10] = (u32)(st_prof_stamp[threadIdx.x >> 6][1] - c0);
+        o[11] = (u32)(st_prof_stamp[threadIdx.x >> 6][2] - c0);
+        for (int k = 3; k < 7; k++) o[9 + k] = (u32)(st_prof_stamp[threadIdx.x >> 6][k] - c0);
+        o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); o[8] = 0xabcd1234u;
+    }
+#else
     if (!evaluate) code = 0;
     else if (status) status[i] = code;
+#endif
     tally_commit(tally, i, code);
 }
 
@@ -60,20 +95,14 @@ __global__ __launch_bounds__(ZK_STATE_QUAD_BLOCK, ZK_STATE_QUAD_OCC) void state_
     tally_commit(tally, i, code);
 }
 
-#ifndef ZK_STATE_SMALL_LANES
-#define ZK_STATE_SMALL_LANES 4  // lanes per row below 2^18 rows
-#endif
-// Measured (profiles/r02_state_lanes.txt): 2^16 rows 67.6 us (quad) vs 81.6 us (one lane per row); 2^20 rows 555 us vs 415 us —
-// the quad form wins while one wavefront per SIMD is all a launch has, the one-lane form once the chip is full (a quarter of
-// the cross-lane traffic and of the redundant per-quad checks).  ZK_STATE_LANES=1|4 overrides (tuning / tests).
-static int state_lanes_per_row(u64 rows) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("ZK_STATE_LANES");
-        forced = e ? (atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 4) : 0;
+// ZK_STATE_DMA=0|1: the LDS-ring kernel (default on)
+static int state_use_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ZK_STATE_DMA");
+        v = e ? (atoi(e) != 0) : 1;
     }
-    if (forced) return forced;
-    return rows < (1ull << 18) ? ZK_STATE_SMALL_LANES : 1;
+    return v;
 }
 template <int L>
 static void launch_group(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
@@ -83,10 +112,23 @@ static void launch_group(hipStream_t st, const StateArgs& a, u32* status, ZkTall
 }
 void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
     const int block = 256;
-    const int lanes = state_lanes_per_row(a.eval_hi - a.eval_lo);
-    if (lanes == 4) { launch_group<4>(st, a, status, tally); return; }
-    if (lanes == 2) { launch_group<2>(st, a, status, tally); return; }
+    if (!state_use_dma()) {
+        launch_group<4>(st, a, status, tally);
+        return;
+    }
+    const int lds = (block / 64) * ST_DMA_WAVE_BYTES;
+    {  // > 64 KiB of dynamic LDS has to be asked for, once per device
+        static std::mutex m;
+        static bool asked[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(m);
+        if (dev >= 0 && dev < 64 && !asked[dev]) {
+            (void)hipFuncSetAttribute((const void*)state_rows_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            asked[dev] = true;
+        }
+    }
     const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
     const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(state_rows_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);
+    hipLaunchKernelGGL(state_rows_dma_kernel, dim3(grid), dim3(block), lds, st, a, status, tally);
 }

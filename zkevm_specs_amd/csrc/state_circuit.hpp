@@ -17,6 +17,14 @@
 #pragma once
 #include "common.hpp"
 
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 1
+__shared__ u64 st_prof_stamp[4][8];
+#define ST_STAMP_ANY(k) do { st_prof_stamp[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ST_STAMP(k) do { if ((threadIdx.x & 63u) == 0) st_prof_stamp[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ST_STAMP(k) do { } while (0)
+#define ST_STAMP_ANY(k) do { } while (0)
+#endif
 enum {
     ST_RWC = 0, ST_IS_WRITE = 1, ST_TAG = 2, ST_ID = 3, ST_ADDR = 4, ST_FIELD_TAG = 5,
     ST_KEY_LO = 6, ST_KEY_HI = 7, ST_LIMB0 = 8, ST_BYTE0 = 18, ST_VAL_LO = 50, ST_VAL_HI = 51,
@@ -96,31 +104,132 @@ ZK_HD bool state_pair_zero(const ZkCols& w, int c, u64 i) {
     return fr_is_zero(zk_col(w, c, i)) && fr_is_zero(zk_col(w, c + 1, i));
 }
 
-// MPT lookup with every field given (state_circuit.py:165-184 -> table.py:864-884): since
-// the query covers all 12 cells and the table is a set, 0 or 1 distinct rows can match.
+// MPT lookup with every field given (state_circuit.py:165-184 -> table.py:864-884): since the query covers all 12 cells and the
+// table is a set, 0 or 1 distinct rows can match.  The index is keyed on the WHOLE row, so a probe chain holds only genuine hash
+// neighbours (expected length ~1 at load factor <= 1/2), and a candidate row is compared with all of its 24 loads in flight at
+// once (no short-circuit): a lookup is two dependent memory latencies, not one per cell.
+ZK_HD u64 state_mpt_hash_cells(const Fr q[MPT_NCELLS]) {
+    // address, proof type, storage key and the new root's low half: the trie leaf and which of its updates (the other seven cells
+    // follow from these in any consistent table; the hash only has to spread the rows, the compare below is on all twelve)
+    u64 h = 0x5bd1e995u;
+#pragma unroll
+    for (int c = 0; c < 5; c++) h = zk_hash_cell(h, q[c]);
+    return h;
+}
+// Index slot of an MPT row: the row number with eight more bits of its hash on top (tables below 2^24 - 1 rows), so that a probe
+// chain's other residents are told apart without reading their 384 bytes.
+ZK_HD u32 state_mpt_fp_bits(const ZkTable& t) { return t.n < 0xffffffu ? 8u : 0u; }
+ZK_HD u32 state_mpt_slot_value(const ZkTable& t, u32 r, u64 h) { return state_mpt_fp_bits(t) ? (r | ((u32)(h >> 56) << 24)) : r; }
+#ifndef ZK_HOSTSIM
+typedef u32 st_ld_u32x4 __attribute__((ext_vector_type(4)));
+// The 24 16-byte loads of one table row issued together and waited for together.  Written as asm because under this kernel's
+// register pressure the compiler emits such a compare as load, wait, compare, 24 times over (one register tuple re-used: a
+// candidate row cost 24 dependent memory latencies, ~50k clocks per Storage / Account wavefront); here a row is one.
+__device__ __forceinline__ void st_load_mpt_row(const u64* p, st_ld_u32x4 (&x)[24]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %24, off\n\tglobal_load_dwordx4 %1, %24, off offset:16\n\t"
+        "global_load_dwordx4 %2, %24, off offset:32\n\tglobal_load_dwordx4 %3, %24, off offset:48\n\t"
+        "global_load_dwordx4 %4, %24, off offset:64\n\tglobal_load_dwordx4 %5, %24, off offset:80\n\t"
+        "global_load_dwordx4 %6, %24, off offset:96\n\tglobal_load_dwordx4 %7, %24, off offset:112\n\t"
+        "global_load_dwordx4 %8, %24, off offset:128\n\tglobal_load_dwordx4 %9, %24, off offset:144\n\t"
+        "global_load_dwordx4 %10, %24, off offset:160\n\tglobal_load_dwordx4 %11, %24, off offset:176\n\t"
+        "global_load_dwordx4 %12, %24, off offset:192\n\tglobal_load_dwordx4 %13, %24, off offset:208\n\t"
+        "global_load_dwordx4 %14, %24, off offset:224\n\tglobal_load_dwordx4 %15, %24, off offset:240\n\t"
+        "global_load_dwordx4 %16, %24, off offset:256\n\tglobal_load_dwordx4 %17, %24, off offset:272\n\t"
+        "global_load_dwordx4 %18, %24, off offset:288\n\tglobal_load_dwordx4 %19, %24, off offset:304\n\t"
+        "global_load_dwordx4 %20, %24, off offset:320\n\tglobal_load_dwordx4 %21, %24, off offset:336\n\t"
+        "global_load_dwordx4 %22, %24, off offset:352\n\tglobal_load_dwordx4 %23, %24, off offset:368\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+          "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17]), "=&v"(x[18]),
+          "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21]), "=&v"(x[22]), "=&v"(x[23])
+        : "v"(p)
+        : "memory");
+}
+// key cells (tag .. storage_key hi: columns 2 .. 7) of row j against `mine`: twelve loads in flight, one wait
+__device__ __forceinline__ u32 st_next_keys_diff(const ZkCols& w, u64 j, const Fr* const mine[6]) {
+    st_ld_u32x4 x[12];
+    const u64* p0 = w.cells + ((u64)ST_TAG * w.n + j) * 4;
+    const u64 *p1 = p0 + w.n * 4, *p2 = p1 + w.n * 4, *p3 = p2 + w.n * 4, *p4 = p3 + w.n * 4, *p5 = p4 + w.n * 4;
+    asm volatile(
+        "global_load_dwordx4 %0, %12, off\n\tglobal_load_dwordx4 %1, %12, off offset:16\n\t"
+        "global_load_dwordx4 %2, %13, off\n\tglobal_load_dwordx4 %3, %13, off offset:16\n\t"
+        "global_load_dwordx4 %4, %14, off\n\tglobal_load_dwordx4 %5, %14, off offset:16\n\t"
+        "global_load_dwordx4 %6, %15, off\n\tglobal_load_dwordx4 %7, %15, off offset:16\n\t"
+        "global_load_dwordx4 %8, %16, off\n\tglobal_load_dwordx4 %9, %16, off offset:16\n\t"
+        "global_load_dwordx4 %10, %17, off\n\tglobal_load_dwordx4 %11, %17, off offset:16\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+          "=&v"(x[10]), "=&v"(x[11])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+        : "memory");
+    u32 d = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const Fr& c = *mine[k >> 1];
+        const int o = (k & 1) * 4;
+        d |= (x[k].x ^ c.v[o]) | (x[k].y ^ c.v[o + 1]) | (x[k].z ^ c.v[o + 2]) | (x[k].w ^ c.v[o + 3]);
+    }
+    return d;
+}
+#endif
+ZK_HD bool state_mpt_row_equals(const ZkTable& t, u32 r, const Fr q[MPT_NCELLS]) {
+    u32 diff = 0;
+#ifndef ZK_HOSTSIM
+    st_ld_u32x4 x[24];
+    st_load_mpt_row(t.cells + (u64)r * (MPT_NCELLS * 4), x);
+#pragma unroll
+    for (int k = 0; k < 24; k++) {
+        const Fr& c = q[k >> 1];
+        const int o = (k & 1) * 4;
+        diff |= (x[k].x ^ c.v[o]) | (x[k].y ^ c.v[o + 1]) | (x[k].z ^ c.v[o + 2]) | (x[k].w ^ c.v[o + 3]);
+    }
+#else
+    for (int c = 0; c < MPT_NCELLS; c++) {
+        const Fr x = zk_table_cell(t, r, c);
+        for (int k = 0; k < 8; k++) diff |= x.v[k] ^ q[c].v[k];
+    }
+#endif
+    return diff == 0;
+}
 ZK_HD bool state_mpt_lookup(const ZkTable& t, const Fr q[MPT_NCELLS]) {
     if (t.n == 0) return false;
-    u64 h = 0x5bd1e995u;
-    h = zk_hash_cell(h, q[0]);
-    h = zk_hash_cell(h, q[2]);
-    h = zk_hash_cell(h, q[3]);
+    const u64 h = state_mpt_hash_cells(q);
+    const u32 fp_bits = state_mpt_fp_bits(t), want = fp_bits ? (u32)(h >> 56) : 0u, row_mask = fp_bits ? 0xffffffu : 0xffffffffu;
     u32 slot = (u32)h & t.mask;
-    for (u32 probes = 0; probes <= t.mask; probes++) {
-        u32 r = t.slots[slot];
-        if (r == ZK_EMPTY_SLOT) return false;
-        bool m = true;
-        for (int c = 0; c < MPT_NCELLS; c++) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
-        if (m) return true;
-        slot = (slot + 1) & t.mask;
+    ST_STAMP_ANY(6);
+    // Four slots of the probe chain per round trip (the index has at least 16 slots and always an empty one).  Each lane scans its
+    // window in registers for the next slot whose fingerprint matches; the row compare sits after the scan, so all lanes of a
+    // wavefront that have a candidate compare it in the SAME round trip wherever in their windows it was found.
+    bool found = false, done = false;
+    u32 k = 4, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    while (!done) {
+        if (k == 4) {
+            w0 = t.slots[slot], w1 = t.slots[(slot + 1u) & t.mask], w2 = t.slots[(slot + 2u) & t.mask], w3 = t.slots[(slot + 3u) & t.mask];
+            slot = (slot + 4) & t.mask;
+            k = 0;
+        }
+        u32 cand = ZK_EMPTY_SLOT;
+        while (k < 4) {
+            const u32 sv = w0;
+            w0 = w1, w1 = w2, w2 = w3;
+            k++;
+            if (sv == ZK_EMPTY_SLOT) {
+                done = true;
+                break;
+            }
+            if (!fp_bits || (sv >> 24) == want) {
+                cand = sv;
+                break;
+            }
+        }
+        if (!done && cand != ZK_EMPTY_SLOT && state_mpt_row_equals(t, cand & row_mask, q)) found = done = true;
     }
-    return false;
+    return found;
 }
 ZK_HD u64 state_mpt_key_hash(const ZkTable& t, u32 r) {
-    u64 h = 0x5bd1e995u;
-    h = zk_hash_cell(h, zk_table_cell(t, r, 0));
-    h = zk_hash_cell(h, zk_table_cell(t, r, 2));
-    h = zk_hash_cell(h, zk_table_cell(t, r, 3));
-    return h;
+    Fr q[MPT_NCELLS];
+#pragma unroll
+    for (int c = 0; c < MPT_NCELLS; c++) q[c] = zk_table_cell(t, r, c);
+    return state_mpt_hash_cells(q);
 }
 
 // Checks are accumulated branch-free ("first failure wins") instead of returning early, so the
@@ -238,9 +347,12 @@ ZK_HD Fr st_shr_fr(const Fr& x) {
 template <int SHIFT = 1>
 ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const StRow& P, u32 code) {
     (void)P;
+    ST_STAMP(0);
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
+    u32 prof_lane = 0;  // tuning build: the return value is (clocks / 16) of the next-row compare | of the MPT lookup << 16
+#endif
     const ZkCols& w = a.rows;
     const u64 n = w.n;
-    const u64 ip = i == 0 ? n - 1 : i - 1;
     const u64 in = i + 1 == n ? 0 : i + 1;
     const bool val_is_word = C.flags & 1u, init_is_word = C.flags & 2u;
     const u32 tagv = C.tag.v[0];
@@ -267,6 +379,9 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
     const Fr p_root_lo = ST_PREV_FR(root_lo), p_root_hi = ST_PREV_FR(root_hi);
     const bool keys_eq_prev = fr_eq(tag, p_tag) & fr_eq(id, p_id) & fr_eq(addr, p_addr) & fr_eq(ftag, p_ftag) &
                               fr_eq(C.key_lo, p_key_lo) & fr_eq(C.key_hi, p_key_hi);
+#ifndef ZK_HOSTSIM
+    const u64 eq_prev_mask = __ballot(keys_eq_prev);  // every lane is active here
+#endif
     const bool val_same = fr_eq(C.val_lo, p_val_lo) & fr_eq(C.val_hi, p_val_hi);
     const bool init_same = fr_eq(C.init_lo, p_init_lo) & fr_eq(C.init_hi, p_init_hi);
     const bool root_same = fr_eq(C.root_lo, p_root_lo) & fr_eq(C.root_hi, p_root_hi);
@@ -284,6 +399,7 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
     const bool init_zero = fr_is_zero(init_lo) && fr_is_zero(init_hi);
     const bool is_write_one = C.is_write01 == 1u;
 
+    ST_STAMP(1);
     switch (tagv) {
     case 1:  // Start (:216-236)
         ST_ASSERT(fr_is_zero(ftag), 20);
@@ -349,7 +465,33 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
             bool non_exist = val_zero && init_zero && fr_eq_u64(ftag, 3);
             proof_type = non_exist ? 4 : fr_lo64(ftag);  // from_account_field_tag: tag k -> proof k
         }
-        if (!state_keys_eq(w, i, in)) {
+        // last access to this key = the next row's keys differ (six loads in flight; this row's own keys are in registers)
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
+        const u64 pt0 = __builtin_amdgcn_s_memtime();
+#endif
+        u32 next_diff;
+        {
+            const Fr* const mine[6] = {&tag, &id, &addr, &ftag, &C.key_lo, &C.key_hi};
+#ifndef ZK_HOSTSIM
+            // row i + 1 sits SHIFT lanes up and has compared its keys with this row's already (its keys_eq_prev): one ballot.
+            // The last rows of the wavefront, and the row in front of the wrap-around, read the next row instead.
+            const u32 lane = threadIdx.x & 63u;
+            if (lane + SHIFT < 64u && i + 1 < n) next_diff = ((eq_prev_mask >> (lane + SHIFT)) & 1ull) ? 0u : 1u;
+            else next_diff = st_next_keys_diff(w, in, mine);
+#else
+            next_diff = 0;
+            for (int c = 0; c < 6; c++) {
+                const Fr x = zk_col(w, ST_TAG + c, in);
+                for (int k = 0; k < 8; k++) next_diff |= x.v[k] ^ mine[c]->v[k];
+            }
+#endif
+        }
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
+        const u64 pt1 = __builtin_amdgcn_s_memtime();
+        prof_lane = (u32)((pt1 - pt0) >> 4) & 0xffffu;
+#endif
+        ST_STAMP_ANY(3);
+        if (next_diff != 0) {
             Fr q[MPT_NCELLS];
             q[0] = addr;
             q[1] = fr_from_u64(proof_type);
@@ -357,13 +499,18 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
             q[3] = C.key_hi;
             q[4] = C.root_lo;
             q[5] = C.root_hi;
-            q[6] = zk_col(w, ST_ROOT_LO, ip);
-            q[7] = zk_col(w, ST_ROOT_HI, ip);
+            q[6] = p_root_lo;  // root of row i - 1: already here from the neighbour exchange
+            q[7] = p_root_hi;
             q[8] = val_lo;
             q[9] = val_hi;
             q[10] = init_lo;
             q[11] = init_hi;
+            ST_STAMP_ANY(4);
             if (code == 0u && !state_mpt_lookup(a.mpt, q)) ST_FAIL(ZK_LOOKUP_UNSAT, tagv == 4 ? 71 : 95);
+            ST_STAMP_ANY(5);
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
+            prof_lane |= ((u32)((__builtin_amdgcn_s_memtime() - pt1) >> 4) & 0xffffu) << 16;
+#endif
         } else {
             ST_ASSERT(root_same, tagv == 4 ? 73 : 97);
         }
@@ -443,7 +590,12 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
     default:  // tag 12: passes 0.0 but is no Tag variant -> ValueError("Unreachable") (:613)
         ST_FAIL(ZK_VALUE_ERROR, 160);
     }
+    ST_STAMP(2);
+#if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
+    return prof_lane;
+#else
     return code;
+#endif
 }
 
 #ifndef ZK_HOSTSIM
@@ -522,6 +674,180 @@ ZK_HD void state_load_row_group(const ZkCols& w, u64 i, u32 q, StRow& R, u32& co
     R.root_lo = ST_GROUP_CELL(54);
     R.root_hi = ST_GROUP_CELL(55);
     // sites 1..8 exactly as state_load_row
+    ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
+    ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
+    ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
+    ST_ASSERT(!bad_limb, 4);
+    ST_ASSERT(fr_eq(R.addr, lcv), 5);
+    R.pack_ok = bad_byte ? 0u : 1u;
+    ST_ASSERT(!bad_byte, 6);
+    ST_ASSERT(fr_eq(R.key_lo, u256_lo(keyv)) && fr_eq(R.key_hi, u256_hi(keyv)), 7);
+    ST_ASSERT(fr_le_u64(is_write, 1), 8);
+    R.is_write01 = fr_is_zero(is_write) ? 0u : (fr_eq_u64(is_write, 1) ? 1u : 2u);
+    {
+        Big18 out;
+        for (int k = 0; k < 18; k++) out.v[k] = 0;
+        big_shl_add(out, 0, 0, R.tag);
+        big_shl_add(out, 0, 28, R.id);
+        big_shl_add(out, 5, 0, R.addr);
+        big_shl_add(out, 0, 16, R.ftag);
+        big_shl_add(out, 1, 0, keyv);
+        big_shl_add(out, 1, 0, R.rwc);
+        out.v[15] &= 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 16; k++) R.pack[k] = out.v[k];
+    }
+}
+#endif
+
+#ifndef ZK_HOSTSIM
+// ---- The 42 range-check cells through LDS (round 3).  Three quarters of a row are cells whose whole content is "a 16-bit
+// limb" or "a byte": 10 address limbs + 32 storage-key bytes, 32 B each on the wire.  Held in registers they are what caps the
+// one-lane-per-row kernel at the loads a lane can keep in flight (174 VGPRs, 4.7 TB/s at 2^20 rows, one dependent batch per
+// wavefront at 2^16).  Here a wavefront streams them through a private LDS ring with global_load_lds_dwordx4 (1 KiB per wave
+// instruction = 32 rows of one column, no registers, asynchronous): ST_DMA_COLS columns x 64 rows per chunk, ST_DMA_RING chunks
+// in flight, each lane then reads ITS row's cell back (two ds_read_b128), range-checks it and ORs its bits into the packed
+// address / key words.  The 14 wide cells are ordinary loads issued first, in flight the whole time; the cross-row part is the
+// unchanged wave_shr exchange of state_check_loaded<1>.  vmcnt retires in issue order, so "chunk k has landed" is
+// vmcnt(pieces issued after chunk k); the compiler's own loads only make that wait more conservative.
+#ifndef ST_DMA_COLS
+#define ST_DMA_COLS 3
+#endif
+#ifndef ST_DMA_RING
+#define ST_DMA_RING 3
+#endif
+#define ST_DMA_SMALL 42  // cells 8 .. 49
+#define ST_DMA_CHUNKS (ST_DMA_SMALL / ST_DMA_COLS)
+#define ST_DMA_CHUNK_U4 (ST_DMA_COLS * 64 * 2)               // uint4s per chunk (64 rows x 32 B per column)
+#define ST_DMA_WAVE_BYTES (ST_DMA_RING * ST_DMA_CHUNK_U4 * 16)
+static_assert(ST_DMA_SMALL % ST_DMA_COLS == 0, "chunks cover the 42 small cells exactly");
+static_assert(2 * ST_DMA_COLS * (ST_DMA_RING - 1) < 64, "vmcnt is a 6-bit counter");
+
+template <int N>
+__device__ __forceinline__ void st_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// chunk -> its ring slot: ST_DMA_COLS columns, two 1 KiB pieces each (rows 0..31, 32..63 of the wavefront)
+__device__ __forceinline__ void st_dma_issue(const ZkCols& w, int chunk, uint4* ring, const u64 off[2]) {
+    uint4* slot = ring + (chunk % ST_DMA_RING) * ST_DMA_CHUNK_U4;
+    const char* base = (const char*)w.cells;
+#pragma unroll
+    for (int k = 0; k < ST_DMA_COLS; k++) {
+        const u64 col = (u64)(ST_LIMB0 + chunk * ST_DMA_COLS + k) * w.n * 32u;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + col + off[h]),
+                                             (__attribute__((address_space(3))) void*)(slot + (k * 64 + h * 32) * 2), 16, 0, 0);
+    }
+}
+typedef u32 st_u32x4 __attribute__((ext_vector_type(4)));
+// One column's cell of this lane out of a landed chunk.  Written as asm because the compiler orders every LDS read it emits itself
+// behind vmcnt(0) once an LDS-DMA is in flight (it cannot tell the ring slots apart), which would serialise the ring.
+template <int OFF>
+__device__ __forceinline__ void st_lds_cell(u32 addr, st_u32x4& lo, st_u32x4& hi) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF), "n"(OFF + 16) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void st_dma_steps(const ZkCols& w, uint4* ring, u32 lds_lane, const u64 off[2], u32 lc[5], u32 key[8], u32& bad_limb,
+                                             u32& bad_byte) {
+    if constexpr (K < ST_DMA_CHUNKS) {
+        // chunks K+1 .. K+RING-1 were issued after chunk K (those that exist)
+        constexpr int later = (ST_DMA_CHUNKS - 1 - K) < (ST_DMA_RING - 1) ? (ST_DMA_CHUNKS - 1 - K) : (ST_DMA_RING - 1);
+#ifdef ST_DMA_WAIT_ALL
+        st_wait_vmcnt<0>();
+#else
+        st_wait_vmcnt<later * ST_DMA_COLS * 2>();
+#endif
+        constexpr int slot_off = (K % ST_DMA_RING) * ST_DMA_CHUNK_U4 * 16;
+        st_u32x4 lo[ST_DMA_COLS], hi[ST_DMA_COLS];
+        if constexpr (ST_DMA_COLS > 0) st_lds_cell<slot_off + 0 * 2048>(lds_lane, lo[0], hi[0]);
+        if constexpr (ST_DMA_COLS > 1) st_lds_cell<slot_off + 1 * 2048>(lds_lane, lo[1], hi[1]);
+        if constexpr (ST_DMA_COLS > 2) st_lds_cell<slot_off + 2 * 2048>(lds_lane, lo[2], hi[2]);
+        if constexpr (ST_DMA_COLS > 3) st_lds_cell<slot_off + 3 * 2048>(lds_lane, lo[3], hi[3]);
+        if constexpr (ST_DMA_COLS > 4) st_lds_cell<slot_off + 4 * 2048>(lds_lane, lo[4], hi[4]);
+        if constexpr (ST_DMA_COLS > 5) st_lds_cell<slot_off + 5 * 2048>(lds_lane, lo[5], hi[5]);
+        static_assert(ST_DMA_COLS <= 6, "add st_lds_cell lines");
+        // the cells are in registers after this (the wait names them: their consumers must not be scheduled in front of it); the
+        // slot may then be refilled
+        if constexpr (ST_DMA_COLS == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1])::"memory");
+        else if constexpr (ST_DMA_COLS == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2])::"memory");
+        else {
+            static_assert(ST_DMA_COLS == 6, "add a wait for this chunk width");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4]),
+                           "+v"(lo[5]), "+v"(hi[5])::"memory");
+        }
+        if constexpr (K + ST_DMA_RING < ST_DMA_CHUNKS) st_dma_issue(w, K + ST_DMA_RING, ring, off);
+#pragma unroll
+        for (int k = 0; k < ST_DMA_COLS; k++) {
+            const u32 upper = lo[k].y | lo[k].z | lo[k].w | hi[k].x | hi[k].y | hi[k].z | hi[k].w;
+            const int c = ST_LIMB0 + K * ST_DMA_COLS + k;
+            if (c < ST_BYTE0) {
+                const int l = c - ST_LIMB0;
+                bad_limb |= upper | (lo[k].x >> 16);
+                lc[l >> 1] |= (lo[k].x & 0xffffu) << (16 * (l & 1));
+            } else {
+                const int b = c - ST_BYTE0;
+                bad_byte |= upper | (lo[k].x >> 8);
+                key[b >> 2] |= (lo[k].x & 0xffu) << (8 * (b & 3));
+            }
+        }
+        // pin the chunk's arithmetic in front of the next chunk's reads: asm statements keep their order, plain VALU work does not,
+        // and the scheduler otherwise parks all 42 cells in registers (then scratch) and reduces them at the end
+        asm volatile("" : "+v"(bad_limb), "+v"(bad_byte), "+v"(lc[0]), "+v"(lc[1]), "+v"(lc[2]), "+v"(lc[3]), "+v"(lc[4]), "+v"(key[0]), "+v"(key[1]),
+                     "+v"(key[2]), "+v"(key[3]), "+v"(key[4]), "+v"(key[5]), "+v"(key[6]), "+v"(key[7]));
+        st_dma_steps<K + 1>(w, ring, lds_lane, off, lc, key, bad_limb, bad_byte);
+    }
+}
+// state_load_row for lane `lane` of a wavefront whose lane j holds row rowof(j); off[h] = byte offset inside a column of what
+// this lane fetches for piece h (row rowof(32 h + lane / 2), half lane & 1).  Sites 1..8 in state_load_row's order.
+__device__ __forceinline__ void state_load_row_dma(const ZkCols& w, u64 i, const u64 off[2], uint4* ring, u32 lane, StRow& R, u32& code) {
+    R.flags = w.flags ? w.flags[i] : 0u;
+#ifndef ST_DMA_BIG_LATE
+    R.rwc = zk_col(w, ST_RWC, i);
+    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
+    R.tag = zk_col(w, ST_TAG, i);
+    R.id = zk_col(w, ST_ID, i);
+    R.addr = zk_col(w, ST_ADDR, i);
+    R.ftag = zk_col(w, ST_FIELD_TAG, i);
+    R.key_lo = zk_col(w, ST_KEY_LO, i);
+    R.key_hi = zk_col(w, ST_KEY_HI, i);
+    R.val_lo = zk_col(w, ST_VAL_LO, i);
+    R.val_hi = zk_col(w, ST_VAL_HI, i);
+    R.init_lo = zk_col(w, ST_INIT_LO, i);
+    R.init_hi = zk_col(w, ST_INIT_HI, i);
+    R.root_lo = zk_col(w, ST_ROOT_LO, i);
+    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+#endif
+#pragma unroll
+    for (int k = 0; k < ST_DMA_RING; k++) st_dma_issue(w, k, ring, off);
+    u32 lc[5] = {0, 0, 0, 0, 0}, key[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bad_limb = 0, bad_byte = 0;
+    // LDS byte address of this lane's cell in column 0 of slot 0 (64 rows x 32 B per column)
+    const u32 lds_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)ring + lane * 32u;
+    st_dma_steps<0>(w, ring, lds_lane, off, lc, key, bad_limb, bad_byte);
+#ifdef ST_DMA_BIG_LATE
+    R.rwc = zk_col(w, ST_RWC, i);
+    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
+    R.tag = zk_col(w, ST_TAG, i);
+    R.id = zk_col(w, ST_ID, i);
+    R.addr = zk_col(w, ST_ADDR, i);
+    R.ftag = zk_col(w, ST_FIELD_TAG, i);
+    R.key_lo = zk_col(w, ST_KEY_LO, i);
+    R.key_hi = zk_col(w, ST_KEY_HI, i);
+    R.val_lo = zk_col(w, ST_VAL_LO, i);
+    R.val_hi = zk_col(w, ST_VAL_HI, i);
+    R.init_lo = zk_col(w, ST_INIT_LO, i);
+    R.init_hi = zk_col(w, ST_INIT_HI, i);
+    R.root_lo = zk_col(w, ST_ROOT_LO, i);
+    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+#endif
+    U256 lcv = fr_zero(), keyv;
+#pragma unroll
+    for (int k = 0; k < 5; k++) lcv.v[k] = lc[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) keyv.v[k] = key[k];
     ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
     ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
     ST_ASSERT(fr_le_u64(R.ftag, 24), 3);

@@ -129,6 +129,15 @@ __global__ void index_build_kernel(ZkTable t, u32* slots) {
     u32 s = (u32)HASH(t, r) & t.mask;
     while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
 }
+// MPT index: slot value = row | hash fingerprint (state_mpt_slot_value)
+__global__ void mpt_index_build_kernel(ZkTable t, u32* slots) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.n) return;
+    const u64 h = state_mpt_key_hash(t, r);
+    u32 s = (u32)h & t.mask;
+    const u32 v = state_mpt_slot_value(t, r, h);
+    while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, v) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
+}
 // RW-table density check (see ZkRwMeta): meta->dense must be pre-set to 1.
 __global__ void rw_dense_check_kernel(ZkTable t, ZkRwMeta* meta) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,7 +624,7 @@ static int stage(zk_session* s, const void* src, size_t bytes, bool device_ptrs,
 }
 
 template <u64 (*HASH)(const ZkTable&, u32)>
-static int build_index(zk_session* s, ZkTable& t) {
+static int build_index(zk_session* s, ZkTable& t, bool mpt_fingerprints = false) {
     u32 cap = 16;
     while (cap < 2 * t.n + 2) cap <<= 1;
     u32* slots = nullptr;
@@ -624,7 +633,8 @@ static int build_index(zk_session* s, ZkTable& t) {
     t.mask = cap - 1;
     t.slots = slots;
     hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, s->stream, slots, cap);
-    if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
+    if (t.n && mpt_fingerprints) hipLaunchKernelGGL(mpt_index_build_kernel, dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
+    else if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -678,7 +688,7 @@ extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64
     s->state.mpt.flags = nullptr;
     s->state.mpt.n = (u32)n_mpt;
     s->state.mpt.ncells = MPT_NCELLS;
-    if ((rc = build_index<state_mpt_key_hash>(s, s->state.mpt))) goto fail;
+    if ((rc = build_index<state_mpt_key_hash>(s, s->state.mpt, /*mpt_fingerprints=*/true))) goto fail;
     if ((rc = session_common_init(s))) goto fail;
     *out = s;
     return 0;
