@@ -69,6 +69,107 @@ ZK_HD Fr zk_table_cell(const ZkTable& t, u32 row, u32 c) {
     return fr_load(t.cells + ((u64)row * t.ncells + c) * 4);
 }
 
+// Does row r equal the query on the cells `mask` selects?  The compiler turns a cell-by-cell compare into one load + wait per
+// 16 bytes when registers are short (every probed row then costs two dependent memory latencies PER CELL); here up to eight
+// cells = sixteen 16-byte loads share one round trip (then four, two, one: a 14-cell row is three trips, a mismatch in the
+// first eight cells — where every table's hashed key cells sit — is one), and a group the mask does not touch is not read.
+#ifndef ZK_HOSTSIM
+typedef u32 zk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void zk_load2x16(const u64* p, zk_u32x4 (&x)[2]) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)" : "=&v"(x[0]), "=&v"(x[1]) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void zk_load4x16(const u64* p, zk_u32x4 (&x)[4]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+        "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void zk_load8x16(const u64* p, zk_u32x4 (&x)[8]) {  // 128 contiguous bytes, one wait
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\t"
+        "global_load_dwordx4 %2, %8, off offset:32\n\tglobal_load_dwordx4 %3, %8, off offset:48\n\t"
+        "global_load_dwordx4 %4, %8, off offset:64\n\tglobal_load_dwordx4 %5, %8, off offset:80\n\t"
+        "global_load_dwordx4 %6, %8, off offset:96\n\tglobal_load_dwordx4 %7, %8, off offset:112\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void zk_load16x16(const u64* p, zk_u32x4 (&x)[16]) {  // 256 contiguous bytes, one wait
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:16\n\t"
+        "global_load_dwordx4 %2, %16, off offset:32\n\tglobal_load_dwordx4 %3, %16, off offset:48\n\t"
+        "global_load_dwordx4 %4, %16, off offset:64\n\tglobal_load_dwordx4 %5, %16, off offset:80\n\t"
+        "global_load_dwordx4 %6, %16, off offset:96\n\tglobal_load_dwordx4 %7, %16, off offset:112\n\t"
+        "global_load_dwordx4 %8, %16, off offset:128\n\tglobal_load_dwordx4 %9, %16, off offset:144\n\t"
+        "global_load_dwordx4 %10, %16, off offset:160\n\tglobal_load_dwordx4 %11, %16, off offset:176\n\t"
+        "global_load_dwordx4 %12, %16, off offset:192\n\tglobal_load_dwordx4 %13, %16, off offset:208\n\t"
+        "global_load_dwordx4 %14, %16, off offset:224\n\tglobal_load_dwordx4 %15, %16, off offset:240\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+          "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
+        : "v"(p)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ u32 zk_cells_diff(const zk_u32x4 (&x)[N], u32 c, const Fr* q, u32 mask) {  // N / 2 cells from cell c on
+    u32 diff = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const u32 cell = c + (u32)(k >> 1);
+        if ((mask >> cell) & 1u) {
+            const u32* qq = q[cell].v + (k & 1) * 4;
+            diff |= (x[k].x ^ qq[0]) | (x[k].y ^ qq[1]) | (x[k].z ^ qq[2]) | (x[k].w ^ qq[3]);
+        }
+    }
+    return diff;
+}
+#endif
+ZK_HD bool zk_row_matches(const ZkTable& t, u32 r, const Fr* q, u32 mask) {
+    u32 diff = 0, c = 0;
+#ifndef ZK_HOSTSIM
+    const u64* p = t.cells + (u64)r * t.ncells * 4;
+    for (; c + 8 <= t.ncells && diff == 0; c += 8)
+        if ((mask >> c) & 0xffu) {
+            zk_u32x4 x[16];
+            zk_load16x16(p + (u64)c * 4, x);
+            diff = zk_cells_diff<16>(x, c, q, mask);
+        }
+    if (c + 4 <= t.ncells && diff == 0) {
+        if ((mask >> c) & 0xfu) {
+            zk_u32x4 x[8];
+            zk_load8x16(p + (u64)c * 4, x);
+            diff = zk_cells_diff<8>(x, c, q, mask);
+        }
+        c += 4;
+    }
+    if (c + 2 <= t.ncells && diff == 0) {
+        if ((mask >> c) & 0x3u) {
+            zk_u32x4 x[4];
+            zk_load4x16(p + (u64)c * 4, x);
+            diff = zk_cells_diff<4>(x, c, q, mask);
+        }
+        c += 2;
+    }
+    if (c < t.ncells && diff == 0) {
+        if ((mask >> c) & 1u) {
+            zk_u32x4 x[2];
+            zk_load2x16(p + (u64)c * 4, x);
+            diff = zk_cells_diff<2>(x, c, q, mask);
+        }
+        c++;
+    }
+    return diff == 0;
+#else
+    for (; c < t.ncells && diff == 0; c++)
+        if ((mask >> c) & 1u) {
+            const Fr x = zk_table_cell(t, r, c);
+            for (int k = 0; k < 8; k++) diff |= x.v[k] ^ q[c].v[k];
+        }
+    return diff == 0;
+#endif
+}
+
 // Direct-index metadata built when a session is opened (the analogue of the reference building
 // its `Tables` sets, evm_circuit/table.py:592-625, before verify_steps runs):
 //  * RW table: when the rows are sorted with consecutive rw_counters (rw[i].rw_counter == base + i,

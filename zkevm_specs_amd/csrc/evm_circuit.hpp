@@ -358,18 +358,26 @@ ZK_NOINLINE u64 table_probe_generic(ZkTable t, u64 h, const Fr* q, u32 mask) {
     u32 found = ZK_EMPTY_SLOT;
     bool ambiguous = false;
     if (t.n != 0) {
+        // the chain is walked to its first empty slot (a second, distinct matching row makes the lookup ambiguous), four slots per
+        // round trip (an index has at least 16 slots and always an empty one)
         u32 slot = (u32)h & t.mask;
-        for (u32 probes = 0; probes <= t.mask; probes++) {
-            const u32 r = t.slots[slot];
-            if (r == ZK_EMPTY_SLOT) break;
-            bool m = true;
-            for (u32 c = 0; c < t.ncells; c++)
-                if ((mask >> c) & 1u) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
-            if (m) {
-                if (found == ZK_EMPTY_SLOT) found = r;
-                else if (!rows_identical(t, found, r)) ambiguous = true;
+        bool done = false;
+        for (u32 probes = 0; probes <= t.mask && !done; probes += 4) {
+            u32 w0 = t.slots[slot], w1 = t.slots[(slot + 1u) & t.mask], w2 = t.slots[(slot + 2u) & t.mask], w3 = t.slots[(slot + 3u) & t.mask];
+            slot = (slot + 4u) & t.mask;
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {  // one copy of the row compare: the window shifts through w0
+                const u32 r = w0;
+                w0 = w1, w1 = w2, w2 = w3;
+                if (r == ZK_EMPTY_SLOT) {
+                    done = true;
+                    break;
+                }
+                if (zk_row_matches(t, r, q, mask)) {
+                    if (found == ZK_EMPTY_SLOT) found = r;
+                    else if (!rows_identical(t, found, r)) ambiguous = true;
+                }
             }
-            slot = (slot + 1) & t.mask;
         }
     }
     if (found == ZK_EMPTY_SLOT) return (u64)ZK_LOOKUP_UNSAT << 32;
@@ -2189,20 +2197,33 @@ ZK_HD void copy_tail(Ins& I, Tail& T, const Fr& opcode, const Fr& rwc_inc, int s
     set_tail(T, opcode, 0, t_delta_i(1), sp_delta, t_to(next_size), 0, gas);
     set_tail_rwc_delta(I, T, fr_add_u64(rwc_inc, I.rw_off));
 }
+#if defined(ZK_WARM_STAMPS) && !defined(ZK_HOSTSIM)  // tuning build: where a SHA3 step's clocks go (tools/evm_warm_timeline.py)
+#define EV_STAMP2(I, k) do { if ((I).a->prof && (threadIdx.x & 63) == 0 && EV_PROF_WAVE < 1024u) (I).a->prof[(2048u + EV_PROF_WAVE) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EV_STAMP2(I, k) do { } while (0)
+#endif
 ZK_HD void g_sha3(Ins& I, Tail& T) {  // sha3.py
+    EV_STAMP2(I, 0);
     Fr opcode; opcode = opcode_lookup(I, true);
+    EV_STAMP2(I, 1);
     Word offset, size, sha3_value;
     offset = stack_pop(I); size = stack_pop(I); sha3_value = stack_push(I);
+    EV_STAMP2(I, 2);
     Fr mem_off, length; EV_TRY(memory_offset_and_length(I, offset, size, mem_off, length));
     const Word cid = word_value(I.call_id);
     CopyRes cr; cr.rwc_inc = fr_zero(); cr.rlc_acc = fr_zero();
+    EV_STAMP2(I, 3);
     if (!fr_is_zero(length))
         EV_TRY(cr = copy_lookup(I, cid, CDT_Memory, cid, CDT_RlcAcc, mem_off, fr_add(mem_off, length), fr_zero(), length,
                                 fr_add_u64(I.rwc, I.rw_off)));
+    EV_STAMP2(I, 4);
     Word out; EV_TRY(out = keccak_lookup(I, length, cr.rlc_acc));
+    EV_STAMP2(I, 5);
     constrain_equal_word(I, out, sha3_value);
     Fr next_size, gas; EV_TRY(copy_memory_gas(I, mem_off, length, 6, next_size, gas));
+    EV_STAMP2(I, 6);
     copy_tail(I, T, opcode, cr.rwc_inc, 1, next_size, gas);
+    EV_STAMP2(I, 7);
 }
 ZK_HD void g_codecopy(Ins& I, Tail& T) {  // codecopy.py
     Fr opcode; opcode = opcode_lookup(I, true);

@@ -35,10 +35,15 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
         else { lo = group_start[G]; hi = group_start[G + 1]; }
     }
     u64 t = (u64)lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ u32 s_stage[G == EVM_GROUP_ALL ? EVM_STAGE_ENTRIES * EVM_STAGE_STRIDE : 1];
-    if (G == EVM_GROUP_ALL) {  // the grid covers every pair: one step per lane
-        if ((u64)blockIdx.x * blockDim.x >= (u64)hi) return;  // the grid is sized for the largest possible padding
-        if (EV_PROF_ON(a)) {  // tuning aid: entry stamps (core clock, 100 MHz wall clock)
+    // One step per lane, both steps of the pair staged in LDS: the hot instantiation, and the warm one when it is launched with
+    // EVM_HOT_BLOCK-lane blocks over the sorted mapping (its gadgets read ~40 step cells each: from HBM, one dependent round trip
+    // per cell, a wavefront of SHA3 / EXP steps took 150k-220k clocks).
+    const bool staged_launch = G == EVM_GROUP_ALL || (G == EVM_GROUP_WARM && BLOCK == EVM_HOT_BLOCK && a.perm != nullptr);
+    __shared__ u32 s_stage[(G == EVM_GROUP_ALL || (G == EVM_GROUP_WARM && BLOCK == EVM_HOT_BLOCK)) ? EVM_STAGE_ENTRIES * EVM_STAGE_STRIDE : 1];
+    if (staged_launch) {  // the grid covers every pair of the range: one step per lane
+        if ((u64)lo + (u64)blockIdx.x * blockDim.x >= (u64)hi) return;  // the grid is sized for the largest possible range / padding
+        if (G != EVM_GROUP_ALL) perm_t = t < (u64)hi ? a.perm[t] : 0u;
+        if (G == EVM_GROUP_ALL && EV_PROF_ON(a)) {  // tuning aid: entry stamps (core clock, 100 MHz wall clock)
             a.prof[EV_PROF_WAVE * 8 + 5] = __builtin_readcyclecounter();
             a.prof[EV_PROF_WAVE * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         }
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
             else if (status) status[idx] = code;
         }
         tally_commit(tally, idx, code);
-        if (EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        if (G == EVM_GROUP_ALL && EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     } else {  // small grid, grid-stride loop
         const u64 stride = (u64)gridDim.x * blockDim.x;
         for (; t < (u64)hi; t += stride) {

@@ -45,7 +45,7 @@ __device__ __forceinline__ void tally_commit(ZkTally* tally, u64 row, u32 code) 
 void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally);
 // hot: e0 rides on the dispatch as its start event; cold: e1 as its stop event (either may be null)
 void zk_launch_evm_hot(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e0, hipEvent_t e1 = nullptr);
-void zk_launch_evm_warm(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1);
+void zk_launch_evm_warm(hipStream_t st, u32 grid, u32 warm_lanes, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1);
 void zk_launch_evm_cold(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1);
 // the pairs the hot (fast) kernel deferred, evaluated by the general build (k_evm_slow.hip); launched only when there are any
 void zk_launch_evm_deferred(hipStream_t st, const EvmArgs& a, u32* status, ZkTally* tally);

@@ -36,9 +36,7 @@ ZK_HD bool keccak_contains(const ZkTable& t, const Fr q[KECCAK_NCELLS]) {
     for (u32 probes = 0; probes <= t.mask; probes++) {
         const u32 r = t.slots[slot];
         if (r == ZK_EMPTY_SLOT) return false;
-        bool m = true;
-        for (int c = 0; c < KECCAK_NCELLS; c++) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
-        if (m) return true;
+        if (zk_row_matches(t, r, q, 0x1fu)) return true;
         slot = (slot + 1) & t.mask;
     }
     return false;

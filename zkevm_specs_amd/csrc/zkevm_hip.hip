@@ -490,6 +490,7 @@ struct zk_session {
     bool perm_ready = false; // EVM: zk_evm_open already enqueued the counting sort of the first pass
     int evm_ranges_known = 0;       // EVM: 1 once a collect has read the warm / cold lane ranges of this session's (fixed) step table ...
     bool evm_warm_empty = false, evm_cold_empty = false;  // ... empty ranges are not launched again
+    u32 evm_warm_lanes = 0;         // ... and the warm launch is sized to its range (0 = not known yet: sized for every pair)
     bool deferred_pending = false;  // EVM: the last pass may have left deferred pairs (evm_finish_deferred has not looked yet)
     u32* last_status = nullptr;     // EVM: where the last pass wrote its statuses
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
@@ -1838,7 +1839,9 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const bool run_cold = !(sorted && s->evm_ranges_known && s->evm_cold_empty);
         hipEvent_t e_hot1 = (evm_ext_events && !run_warm && !run_cold) ? e1 : nullptr;  // the hot dispatch carries both events then
         zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr, e_hot1);
-        if (run_warm) zk_launch_evm_warm(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, (evm_ext_events && !run_cold) ? e1 : nullptr);
+        if (run_warm)
+            zk_launch_evm_warm(s->stream, cold_grid, (sorted && s->evm_ranges_known) ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->d_tally,
+                               (evm_ext_events && !run_cold) ? e1 : nullptr);
         if (run_cold) zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
         break;
     }
@@ -1881,6 +1884,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     if (read_ranges) {
         s->evm_ranges_known = 1;
         s->evm_warm_empty = gs[EVM_GROUP_WARM] == gs[EVM_GROUP_WARM + 1];
+        s->evm_warm_lanes = gs[EVM_GROUP_WARM + 1] - gs[EVM_GROUP_WARM];
         s->evm_cold_empty = gs[EVM_GROUP_COLD] == gs[EVM_GROUP_COLD + 1];
     }
     if (check_deferred) {
