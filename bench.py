@@ -258,7 +258,7 @@ def build_state(ctx, log_rows, strong):
     w.sess = open_fn()
     w.fresh = open_fn
     w.algo_bytes = w.units * 57 * 32  # every witness cell counted once
-    w.kernel_name, w.kernel_needle = "state_rows_kernel", ("state_rows",)
+    w.kernel_name, w.kernel_needle = "state_rows_dma_kernel", ("state_rows",)
     w.workload = f"State circuit, 2^{log_rows} RW rows {'in total' if strong else 'per GPU'} (BASELINE configs[1])"
     w.extra_cfg = {"rows_per_gpu": w.units, "mpt_rows": int(d_mpt.shape[0])}
     w.profile_key = ("state", log_rows)
@@ -405,7 +405,7 @@ def resolve_super(w, res):
     per_circuit = {k: {"rows": sess.rows[k], "kernel_ms": r.kernel_ms,
                        "algorithmic_GBps": w.super_bytes[k] / (r.kernel_ms / 1e3) / 1e9} for k, r in results.items()}
     dom = max(results, key=lambda k: results[k].kernel_ms)
-    w.kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_kernel", "bytecode": "bytecode_rows_kernel",
+    w.kernel_name = {"evm": "evm_steps_kernel", "state": "state_rows_dma_kernel", "bytecode": "bytecode_rows_kernel",
                      "tx": "sign_units_kernel", "copy": "copy_rows_kernel", "exp": "exp_rows_kernel"}[dom]
     w.kernel_needle = (w.kernel_name,) + (("-1",) if dom == "evm" else ())
     w.algo_bytes = w.super_bytes[dom]
@@ -447,7 +447,7 @@ def roofline_block(w, res, world, strong, cold_ms=None):
                     "frac_of_issue_peak": act / (kernel_s * SHADER_CLOCK_HZ * N_SIMD),
                     "note": f"VALU-active cycles / ({N_SIMD} SIMDs x kernel time x {SHADER_CLOCK_HZ / 1e9:.1f} GHz nominal); counters from {profile_src}"}
     physical = traffic / kernel_s / 1e9 if traffic else None
-    streaming = w.kernel_name in ("state_rows_kernel", "bytecode_rows_kernel", "exp_rows_kernel")
+    streaming = w.kernel_name in ("state_rows_dma_kernel", "bytecode_rows_kernel", "exp_rows_kernel")
     return {
         # what binds the dominant kernel; the HBM figures below are the roofline north_star names, reported either way
         "bound": "hbm" if streaming else "latency+valu-issue (not hbm: see binding_resource)",

@@ -17,7 +17,7 @@ import csv, glob, json, shutil, sys
 out = sys.argv[1]
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, out + "/kernel_stats.csv")
-names = ("evm_steps_kernel", "evm_state_hist_kernel", "evm_state_scatter_kernel", "state_rows_kernel", "bytecode_rows_kernel", "sign_units_kernel")
+names = ("evm_steps_kernel", "evm_state_hist_kernel", "evm_state_scatter_kernel", "state_rows_dma_kernel", "bytecode_rows_kernel", "sign_units_kernel")
 iv = []
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
