@@ -76,6 +76,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
                 code = 0;
             } else
 #else
+#ifdef ZK_WARM_TWICE  // tuning build: the same step a second time — its stamps are those of warm instruction / data caches
+            if (G == EVM_GROUP_WARM)
+                code = evm_check_step<G>(a, idx, wide ? (EVM_LDS32_PTR) nullptr : (EVM_LDS32_PTR)my, (EVM_LDS_PTR) nullptr);
+#endif
             code = evm_check_step<G>(a, idx, wide ? (EVM_LDS32_PTR) nullptr : (EVM_LDS32_PTR)my,
                                      dir_in_lds ? (EVM_LDS_PTR)(__attribute__((address_space(3))) u64*)s_dir : (EVM_LDS_PTR) nullptr);
 #endif
