@@ -1,3 +1,4 @@
 #!/bin/bash
 export PYTHONPATH=$PWD
-ZK_HIP_LIB=$PWD/zkevm_specs_amd/libzkevm_hip_st.so python tools/evm_warm_timeline.py 2>&1 | tail -6
+echo "== current"; python tools/bench_row_kernels.py 2>&1 | grep "^copy_rows\|^bytecode \|^tx_sign"
+echo "== original probe"; ZK_HIP_LIB=$PWD/zkevm_specs_amd/libzkevm_hip_orig.so python tools/bench_row_kernels.py 2>&1 | grep "^copy_rows\|^bytecode \|^tx_sign"

@@ -354,30 +354,25 @@ ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
 // Generic "exactly one distinct matching row" lookup (table.py:864-884) over the open-addressing
 // index: `q` holds the query cells, bit c of `mask` says cell c is part of the query.  Out of
 // line; returns row | (kind << 32) with kind 0 / ZK_LOOKUP_UNSAT / ZK_LOOKUP_AMBIGUOUS.
+// (Round 3 measured a form with four slots per round trip and batched row compares (zk_row_matches): the Copy kernel got slower,
+// 42 -> 47 us at 2^15 rows and 0.179 -> 0.202 ms at 2^19 — the masked cell-by-cell compare reads fewer bytes — and the warm EVM
+// gadgets did not get faster; the batched compare stays where all cells are compared: keccak_contains, the State MPT lookup.)
 ZK_NOINLINE u64 table_probe_generic(ZkTable t, u64 h, const Fr* q, u32 mask) {
     u32 found = ZK_EMPTY_SLOT;
     bool ambiguous = false;
     if (t.n != 0) {
-        // the chain is walked to its first empty slot (a second, distinct matching row makes the lookup ambiguous), four slots per
-        // round trip (an index has at least 16 slots and always an empty one)
         u32 slot = (u32)h & t.mask;
-        bool done = false;
-        for (u32 probes = 0; probes <= t.mask && !done; probes += 4) {
-            u32 w0 = t.slots[slot], w1 = t.slots[(slot + 1u) & t.mask], w2 = t.slots[(slot + 2u) & t.mask], w3 = t.slots[(slot + 3u) & t.mask];
-            slot = (slot + 4u) & t.mask;
-#pragma unroll 1
-            for (int k = 0; k < 4; k++) {  // one copy of the row compare: the window shifts through w0
-                const u32 r = w0;
-                w0 = w1, w1 = w2, w2 = w3;
-                if (r == ZK_EMPTY_SLOT) {
-                    done = true;
-                    break;
-                }
-                if (zk_row_matches(t, r, q, mask)) {
-                    if (found == ZK_EMPTY_SLOT) found = r;
-                    else if (!rows_identical(t, found, r)) ambiguous = true;
-                }
+        for (u32 probes = 0; probes <= t.mask; probes++) {
+            const u32 r = t.slots[slot];
+            if (r == ZK_EMPTY_SLOT) break;
+            bool m = true;
+            for (u32 c = 0; c < t.ncells; c++)
+                if ((mask >> c) & 1u) m = m && fr_eq(zk_table_cell(t, r, c), q[c]);
+            if (m) {
+                if (found == ZK_EMPTY_SLOT) found = r;
+                else if (!rows_identical(t, found, r)) ambiguous = true;
             }
+            slot = (slot + 1) & t.mask;
         }
     }
     if (found == ZK_EMPTY_SLOT) return (u64)ZK_LOOKUP_UNSAT << 32;
