@@ -1,4 +1,5 @@
 #!/bin/bash
 export PYTHONPATH=$PWD
-echo "== current"; python tools/bench_row_kernels.py 2>&1 | grep "^copy_rows\|^bytecode \|^tx_sign"
-echo "== original probe"; ZK_HIP_LIB=$PWD/zkevm_specs_amd/libzkevm_hip_orig.so python tools/bench_row_kernels.py 2>&1 | grep "^copy_rows\|^bytecode \|^tx_sign"
+timeout 1500 python -m pytest tests/test_row_circuits.py tests/test_bytecode_assign.py tests/test_super_circuit.py tests/test_dropin_gpu.py tests/test_cpu_backend.py -m gpu -x -q 2>&1 | tail -3
+python tools/bench_row_kernels.py 2>&1 | grep "^bytecode \|^exp \|^tx_sign"
+timeout 900 python -m pytest tests/test_bench_multi_gpu_dryrun.py -m gpu -x -q -k "super" 2>&1 | tail -2

@@ -11,14 +11,22 @@ __global__ void fr_to_mont_kernel(Fr x, u64* out) {  // one cell to Montgomery f
         for (int j = 0; j < 4; j++) out[j] = (u64)m.v[2 * j] | ((u64)m.v[2 * j + 1] << 32);
     }
 }
+// Bytecode: a wavefront holds 64 consecutive rows, evaluates the first 63 and takes each row's successor from lane + 1; its last
+// lane is the (read-only) successor of the 63rd.  The successor of the witness's last row is row 0.
+#define BC_ROWS_PER_WAVE 63
 __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < hi) {
-        code = bytecode_check_row(a, i);
-        if (status) status[i] = code;
-    }
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 n = a.rows.n;
+    u64 i = lo + wave * BC_ROWS_PER_WAVE + lane;
+    const bool evaluate = lane != 63u && i < hi;
+    if (i >= n) i = i == n ? 0 : n - 1;  // row n is the wrap-around successor; lanes further out only keep their loads in bounds
+    BcRow C;
+    bytecode_load_row(a.rows, i, C);
+    u32 code = bytecode_check_loaded(a, C, C);
+    if (!evaluate) code = 0;
+    else if (status) status[i] = code;
     tally_commit(tally, i, code);
 }
 __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
@@ -68,7 +76,8 @@ __global__ __launch_bounds__(256) void pi_rows_kernel(PiArgs a, u64 lo, u64 hi, 
 }
 static inline u32 grid256(u64 n) { return (u32)((n + 255) / 256); }
 void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(bytecode_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
+    const u64 rows_per_block = 4 * BC_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
+    hipLaunchKernelGGL(bytecode_rows_kernel, dim3((u32)((hi - lo + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
 void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);

@@ -44,15 +44,40 @@ ZK_HD bool keccak_contains(const ZkTable& t, const Fr q[KECCAK_NCELLS]) {
 
 #define RC_ASSERT(cond, site) code = (code == 0u && !(cond)) ? ZK_CODE(ZK_ASSERT, site) : code
 
-ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
-    const ZkCols& w = a.rows;
-    const u64 in = i + 1 == w.n ? 0 : i + 1;
+// One row's twelve cells.  A lane loads only its own row; the nine cells the transition checks need from row i + 1 come from the
+// lane that holds it (wave_shl:1 DPP moves on the device — the State kernel's neighbour exchange, mirrored; round 2 re-read them
+// through L2: 1.44 x the algorithmic traffic), or from a second load on the host.
+struct BcRow {
+    Fr c[BC_NCELLS];
+};
+ZK_HD void bytecode_load_row(const ZkCols& w, u64 i, BcRow& R) {
+#pragma unroll
+    for (int k = 0; k < BC_NCELLS; k++) R.c[k] = zk_col(w, k, i);
+}
+#ifndef ZK_HOSTSIM
+ZK_HD Fr bc_next_lane(const Fr& x) {  // the same cell in lane + 1 (every lane of the wavefront takes part)
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)x.v[k], 0x130, 0xf, 0xf, false);  // wave_shl:1
+    return r;
+}
+#define BC_NEXT(cell) bc_next_lane(C.c[cell])
+#else
+#define BC_NEXT(cell) (N.c[cell])
+#endif
+// Row C against its successor N (host: loaded; device: the neighbour lane's registers, so every lane must call this).
+ZK_HD u32 bytecode_check_loaded(const BytecodeArgs& a, const BcRow& C, const BcRow& N) {
+    (void)N;
     u32 code = 0;
-    const Fr q_first = zk_col(w, BC_Q_FIRST, i), q_last = zk_col(w, BC_Q_LAST, i);
-    const Fr tag = zk_col(w, BC_TAG, i), ntag = zk_col(w, BC_TAG, in);
-    const Fr hash_lo = zk_col(w, BC_HASH_LO, i), hash_hi = zk_col(w, BC_HASH_HI, i);
-    const Fr index = zk_col(w, BC_INDEX, i), value = zk_col(w, BC_VALUE, i), length = zk_col(w, BC_LENGTH, i);
-    const Fr value_rlc = zk_col(w, BC_VALUE_RLC, i);
+    const Fr& q_first = C.c[BC_Q_FIRST]; const Fr& q_last = C.c[BC_Q_LAST];
+    const Fr& tag = C.c[BC_TAG];
+    const Fr& hash_lo = C.c[BC_HASH_LO]; const Fr& hash_hi = C.c[BC_HASH_HI];
+    const Fr& index = C.c[BC_INDEX]; const Fr& value = C.c[BC_VALUE]; const Fr& length = C.c[BC_LENGTH];
+    const Fr& value_rlc = C.c[BC_VALUE_RLC];
+    // the successor's cells, moved unconditionally with all lanes active
+    const Fr ntag = BC_NEXT(BC_TAG), n_length = BC_NEXT(BC_LENGTH), n_index = BC_NEXT(BC_INDEX), n_is_code = BC_NEXT(BC_IS_CODE);
+    const Fr n_hash_lo = BC_NEXT(BC_HASH_LO), n_hash_hi = BC_NEXT(BC_HASH_HI), n_value_rlc = BC_NEXT(BC_VALUE_RLC);
+    const Fr n_value = BC_NEXT(BC_VALUE), n_left = BC_NEXT(BC_PUSH_LEFT);
     const bool is_header = fr_eq_u64(tag, 1), is_byte = fr_eq_u64(tag, 2);
     const bool next_header = fr_eq_u64(ntag, 1), next_byte = fr_eq_u64(ntag, 2);
     // EMPTY_HASH = keccak256("") as a Word (util/hash.py:13)
@@ -67,11 +92,11 @@ ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
             RC_ASSERT(fr_eq(value, length), 2);
             RC_ASSERT(fr_is_zero(index), 3);
             if (next_byte) {  // check_bytecode_row_header_to_byte :71-76
-                RC_ASSERT(fr_eq(zk_col(w, BC_LENGTH, in), length), 4);
-                RC_ASSERT(fr_is_zero(zk_col(w, BC_INDEX, in)), 5);
-                RC_ASSERT(fr_eq_u64(zk_col(w, BC_IS_CODE, in), 1), 6);
-                RC_ASSERT(fr_eq(zk_col(w, BC_HASH_LO, in), hash_lo) && fr_eq(zk_col(w, BC_HASH_HI, in), hash_hi), 7);
-                RC_ASSERT(fr_eq(zk_col(w, BC_VALUE_RLC, in), zk_col(w, BC_VALUE, in)), 8);
+                RC_ASSERT(fr_eq(n_length, length), 4);
+                RC_ASSERT(fr_is_zero(n_index), 5);
+                RC_ASSERT(fr_eq_u64(n_is_code, 1), 6);
+                RC_ASSERT(fr_eq(n_hash_lo, hash_lo) && fr_eq(n_hash_hi, hash_hi), 7);
+                RC_ASSERT(fr_eq(n_value_rlc, n_value), 8);
             }
             if (next_header) {  // check_bytecode_row_header_to_header :80-82
                 RC_ASSERT(hdr_to_hdr_ok_len, 9);
@@ -79,22 +104,21 @@ ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
             }
         }
         if (is_byte) {
-            const Fr push_size = zk_col(w, BC_PUSH_SIZE, i), push_left = zk_col(w, BC_PUSH_LEFT, i);
-            const Fr is_code = zk_col(w, BC_IS_CODE, i);
+            const Fr& push_size = C.c[BC_PUSH_SIZE]; const Fr& push_left = C.c[BC_PUSH_LEFT];
+            const Fr& is_code = C.c[BC_IS_CODE];
             // (value, push_data_size) in push_table: value a byte, size = get_push_size(value) (opcode.py:432)
             const u32 v = value.v[0] & 0xffu;
             const u32 want = (v >= 0x60u && v <= 0x7fu) ? v - 0x5fu : 0u;
             RC_ASSERT(fr_le_u64(value, 255) && fr_eq_u64(push_size, want), 11);
             RC_ASSERT(fr_eq_u64(is_code, fr_is_zero(push_left) ? 1 : 0), 12);
             if (next_byte) {  // check_bytecode_row_byte_to_byte :86-94
-                RC_ASSERT(fr_eq(zk_col(w, BC_LENGTH, in), length), 13);
-                RC_ASSERT(fr_eq(zk_col(w, BC_INDEX, in), fr_add_u64(index, 1)), 14);
-                RC_ASSERT(fr_eq(zk_col(w, BC_HASH_LO, in), hash_lo) && fr_eq(zk_col(w, BC_HASH_HI, in), hash_hi), 15);
-                const Fr want_rlc = fr_add(a.r_mont ? fr_mulc(value_rlc, fr_load(a.r_mont)) : fr_mul(value_rlc, a.r), zk_col(w, BC_VALUE, in));
-                RC_ASSERT(fr_eq(zk_col(w, BC_VALUE_RLC, in), want_rlc), 16);
-                const Fr nleft = zk_col(w, BC_PUSH_LEFT, in);
-                if (fr_eq_u64(is_code, 1)) RC_ASSERT(fr_eq(nleft, push_size), 17);
-                else RC_ASSERT(fr_eq(nleft, fr_sub_u64(push_left, 1)), 18);
+                RC_ASSERT(fr_eq(n_length, length), 13);
+                RC_ASSERT(fr_eq(n_index, fr_add_u64(index, 1)), 14);
+                RC_ASSERT(fr_eq(n_hash_lo, hash_lo) && fr_eq(n_hash_hi, hash_hi), 15);
+                const Fr want_rlc = fr_add(a.r_mont ? fr_mulc(value_rlc, fr_load(a.r_mont)) : fr_mul(value_rlc, a.r), n_value);
+                RC_ASSERT(fr_eq(n_value_rlc, want_rlc), 16);
+                if (fr_eq_u64(is_code, 1)) RC_ASSERT(fr_eq(n_left, push_size), 17);
+                else RC_ASSERT(fr_eq(n_left, fr_sub_u64(push_left, 1)), 18);
             }
             if (next_header) {  // check_bytecode_row_byte_to_header :98-100
                 RC_ASSERT(fr_eq(fr_add_u64(index, 1), length), 19);
@@ -115,6 +139,14 @@ ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {
     }
     return code;
 }
+#ifdef ZK_HOSTSIM
+ZK_HD u32 bytecode_check_row(const BytecodeArgs& a, u64 i) {  // host build: both rows loaded
+    BcRow C, N;
+    bytecode_load_row(a.rows, i, C);
+    bytecode_load_row(a.rows, i + 1 == a.rows.n ? 0 : i + 1, N);
+    return bytecode_check_loaded(a, C, N);
+}
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // Exp circuit
