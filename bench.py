@@ -777,11 +777,11 @@ def cpu_baseline(workload, w):
             tc = time.perf_counter()
             with zengine.open_evm(sub, device="cpu") as cs:
                 t_open = time.perf_counter() - tc
-                r_cpu = cs.run()
+                r_cpu = min((cs.run() for _ in range(3)), key=lambda r: r.kernel_ms)  # the first pass pays for the OpenMP thread pool
             assert r_cpu.ok
             legs[key] = {"value": hs / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms, "open_s": t_open,
                          "sample": f"{hs} step pairs through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernels' own per-step functions compiled for the "
-                                   "host, OpenMP over the pairs; csrc/cpu_backend.cpp), one pass with tables and indices resident — the optimised-CPU line"}
+                                   "host, OpenMP over the pairs; csrc/cpu_backend.cpp), best of three passes with tables and indices resident — the optimised-CPU line"}
         if ref and "evm" in ref:
             e = ref["evm"]
             legs["reference"] = {"value": e["extrapolated_2p18"]["pairs_per_s"], "unit": "rows/s", "cores": 1,
@@ -799,8 +799,8 @@ def cpu_baseline(workload, w):
         n = int(tx["bytes"].shape[0])
         R_TX = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
         r4 = np.frombuffer(int(R_TX).to_bytes(32, "little"), dtype="<u8").copy()
-        for threads, key, sample in ((1, "cpu_backend_1core", min(n, 1 << 9)), (cores_total, "cpu_backend_allcores", min(n, 1 << 12))):
-            zlib.set_cpu_threads(threads)
+        def both_circuits(sample):
+            """Tx circuit + Sig circuit over the first `sample` txs through the one-shot entries of the CPU backend; wall clock"""
             tc = time.perf_counter()
             for wire_, layout, is_sig in ((tx, 1, False), (sg, 2, True)):
                 wslice = {k: (np.ascontiguousarray(v[:sample]) if k in ("bytes", "meta") else (np.ascontiguousarray(v[:, :sample]) if k == "cells" else v))
@@ -812,10 +812,15 @@ def cpu_baseline(workload, w):
                 wslice["meta"][:, 0] = est
                 r_cpu, _ = zoneshot.sign_verify(wslice, R_TX, is_sig, device="cpu")
                 assert r_cpu.ok, (is_sig, r_cpu)
-            tc = time.perf_counter() - tc
+            return time.perf_counter() - tc
+
+        for threads, key, sample, reps in ((1, "cpu_backend_1core", min(n, 1 << 9), 1), (cores_total, "cpu_backend_allcores", n, 2)):
+            zlib.set_cpu_threads(threads)
+            tc = min(both_circuits(sample) for _ in range(reps))  # all cores: the first repetition pays for the OpenMP thread pool
             legs[key] = {"value": sample / tc, "unit": "txs/s", "cores": threads,
                          "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications through libzkevm_cpu.so (ZK_BACKEND=cpu: "
-                                   "the kernels' own per-unit functions compiled for the host, OpenMP; csrc/cpu_backend.cpp), wall clock of the one-shot entries"}
+                                   "the kernels' own per-unit functions compiled for the host, OpenMP; csrc/cpu_backend.cpp), wall clock of the one-shot "
+                                   f"entries, best of {reps}"}
         from oracle import ecdsa_oracle, wire
 
         sample_p = min(n, 1 << 5)
@@ -852,11 +857,11 @@ def cpu_baseline(workload, w):
         for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
             zlib.set_cpu_threads(threads)
             with zengine.open_state(cols, flags, mpt, device="cpu") as cs:
-                r_cpu = cs.run()
+                r_cpu = min((cs.run() for _ in range(3)), key=lambda r: r.kernel_ms)  # the first pass pays for the OpenMP thread pool
             assert r_cpu.ok
             legs[key] = {"value": int(cols.shape[1]) / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms,
                          "sample": f"all {int(cols.shape[1])} rows through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernel's own per-row function compiled for "
-                                   "the host, OpenMP over the rows; csrc/cpu_backend.cpp), one pass with the witness and the MPT index resident"}
+                                   "the host, OpenMP over the rows; csrc/cpu_backend.cpp), best of three passes with the witness and the MPT index resident"}
         if ref and "state" in ref:
             legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
                                  "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
