@@ -116,3 +116,53 @@ def test_sharded_ranges_with_halo_match_full_pass():
         got[off:off + hi - lo] = st[lo:hi]
         total += res.fail_count
     assert np.array_equal(got, full) and total == int((full != 0).sum()) >= 2
+
+
+def _tamper_mpt_and_rows(n, seed):
+    """a valid witness with the MPT table and the rows that look it up damaged in every way the lookup has to notice"""
+    rng = np.random.default_rng(seed)
+    cols, flags, mpt = synth_state_witness(n, seed=seed)
+    m = mpt.shape[0]
+    for c in range(12):  # every MPT column, hashed (0..4) or only compared (5..11), both halves of the cell
+        r = int(rng.integers(0, m))
+        mpt[r, c, int(rng.integers(0, 4))] ^= np.uint64(1 << int(rng.integers(0, 60)))
+    tags = cols[2, :, 0]
+    for t in (4, 6):  # Storage / Account rows: value, initial value, root, storage key, address
+        rows = np.nonzero(tags == t)[0]
+        for c in (50, 52, 54, 55, 6, 4):
+            if len(rows):
+                cols[c, int(rng.choice(rows)), 0] ^= np.uint64(1 << int(rng.integers(0, 30)))
+    return cols, flags, mpt
+
+
+@pytest.mark.parametrize("n", [64, 65, 126, 127, 1000, 4097])
+def test_mpt_lookup_and_ragged_sizes_match_oracle(n):
+    """Row counts around the 63-rows-per-wavefront tiling; damaged MPT rows / Storage / Account rows: statuses bit-identical to the oracle's."""
+    cols, flags, mpt = _tamper_mpt_and_rows(n, seed=40 + n)
+    res, status = _run(cols, flags, mpt)
+    exp = state_oracle.verify_rows(wire.colmajor_to_rows(cols), flags, wire.rowmajor_to_rows(mpt))
+    assert status.tolist() == exp
+    assert res.fail_count == sum(1 for c in exp if c)
+
+
+def test_lane_quad_form_matches_oracle():
+    """ZK_STATE_DMA=0 selects the all-register lane-quad kernel (the comparison point of the LDS-ring kernel): same statuses."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import state_oracle, wire\n"
+        "from zkevm_specs_amd import engine\n"
+        "from tests.test_state_gpu import _tamper_mpt_and_rows\n"
+        "for n in (65, 4097):\n"
+        "    cols, flags, mpt = _tamper_mpt_and_rows(n, seed=7 + n)\n"
+        "    with engine.open_state(cols, flags, mpt) as s:\n"
+        "        s.run(); st = s.read_status()\n"
+        "    exp = state_oracle.verify_rows(wire.colmajor_to_rows(cols), flags, wire.rowmajor_to_rows(mpt))\n"
+        "    assert st.tolist() == exp and any(exp), n\n"
+        "print('quad ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZK_STATE_DMA="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"quad ok" in p.stdout, p.stderr.decode()[-2000:]

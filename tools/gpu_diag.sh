@@ -1,3 +1,3 @@
 #!/bin/bash
-PROFILE_CMD="python $PWD/tools/bench_row_kernels.py" tools/profile_bench.sh row_kernels > gpurun_out/prof_rows.log 2>&1
-tail -5 gpurun_out/prof_rows.log | cut -c1-200
+export PYTHONPATH=$PWD
+timeout 1500 python -m pytest tests/test_state_gpu.py -m gpu -x -q 2>&1 | tail -4
