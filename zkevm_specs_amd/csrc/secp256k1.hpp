@@ -243,7 +243,7 @@ __device__ __forceinline__ void sp_mul_wide(const Fr& a, const Fr& b, u32* t) {
 #endif
 // a * b mod P for P = 2^256 - 2^32 - 977 (plain residues, a, b < P, result < P): 8 x 8 schoolbook product, then the high
 // half is folded twice with 2^256 = 2^32 + 977 (mod P) — 72 multiply-adds instead of the 128 of a Montgomery product
-ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
+ZK_HD Fr sp_mul_p(Fr a, Fr b) {  // inlined (round 3): the call's argument / result moves were ~6 % of a product; the kernel grows to 240 KB, measured +3 %
     u32 t[16];
 #ifndef ZK_HOSTSIM
     sp_mul_wide(a, b, t);
@@ -266,7 +266,7 @@ ZK_NOINLINE Fr sp_mul_p(Fr a, Fr b) {
     return sp_fold_p(t);
 }
 // a^2 mod P: the 28 cross products once, doubled, plus the 8 squares (36 multiply-adds instead of 64), then the same fold
-ZK_NOINLINE Fr sp_sqr_p(Fr a) {
+ZK_HD Fr sp_sqr_p(Fr a) {
     u32 t[16];
 #ifndef ZK_HOSTSIM
     // (on the device the product-scanning multiplier is shorter than this specialised form: 164 instructions for the product
