@@ -96,6 +96,23 @@ def test_field_products_known_answers(hostsim):
             assert wire.cells_to_ints(out) == [x * x % m for x, _ in pairs]
 
 
+def test_scalar_field_inversion_known_answers(hostsim):
+    """sp_inv_n_binary (the right-shift binary inversion the verification uses for s^-1 mod N) against pow(x, -1, N)"""
+    import random
+
+    from oracle import wire
+
+    rng = random.Random(5)
+    xs = [1, 2, 3, E.N - 1, E.N - 2, (E.N + 1) // 2, 1 << 255, (1 << 255) - 1, 1 << 128, (1 << 128) - 1, 0xFFFFFFFF, 1 << 32, E.N >> 1]
+    xs += [1 << k for k in range(1, 256, 7)] + [(E.N - (1 << k)) for k in range(0, 250, 11)]
+    xs += [rng.randrange(1, E.N) for _ in range(4000)]
+    xs = [x % E.N or 1 for x in xs]
+    a = wire.ints_to_cells(xs)
+    out = np.zeros_like(a)
+    hostsim.sim_secp_mul(ctypes.c_int(3), vp(a), vp(a), vp(out), ctypes.c_uint64(len(xs)))
+    assert wire.cells_to_ints(out) == [pow(x, -1, E.N) for x in xs]
+
+
 def _group_law_edge_cases():
     """curve keys that drive the joint multiplication through its special cases: Q = +-G, Q = lambda G, u1 or u2 with zero
     windows, R = infinity (u1 G = -u2 Q), acc == table entry (doubling inside an addition)"""

@@ -629,30 +629,53 @@ ZK_HD bool sp_glv_split(const Fr& k, Fr& k1, u32& neg1, Fr& k2, u32& neg2) {
     return (k1.v[4] | k1.v[5] | k1.v[6] | k1.v[7] | k2.v[4] | k2.v[5] | k2.v[6] | k2.v[7]) == 0u;
 }
 
-// s^-1 mod N in Montgomery form (s != 0): Fermat with the exponent N - 2 = (2^127 - 1) 2^129 + low, where the run of 127
-// ones costs 126 squarings + 10 products (x^(2^k - 1) ladder) and the low 129 bits go in 2-bit windows over {x, x^2, x^3}
-ZK_NOINLINE Fr sp_inv_n(Fr xM) {
-    typedef SecpN M;
-    auto sqn = [](Fr a, int n) { for (int i = 0; i < n; i++) a = sp_mont<M>(a, a); return a; };
-    const Fr x2 = sp_mont<M>(sqn(xM, 1), xM);          // 2 ones
-    const Fr x3 = sp_mont<M>(sqn(x2, 1), xM);          // 3
-    const Fr x6 = sp_mont<M>(sqn(x3, 3), x3);
-    const Fr x12 = sp_mont<M>(sqn(x6, 6), x6);
-    const Fr x24 = sp_mont<M>(sqn(x12, 12), x12);
-    const Fr x48 = sp_mont<M>(sqn(x24, 24), x24);
-    const Fr x96 = sp_mont<M>(sqn(x48, 48), x48);
-    const Fr x120 = sp_mont<M>(sqn(x96, 24), x24);
-    const Fr x126 = sp_mont<M>(sqn(x120, 6), x6);
-    Fr acc = sp_mont<M>(sqn(x126, 1), xM);             // 127 ones
-    const Fr xx = sp_mont<M>(xM, xM), xxx = sp_mont<M>(xx, xM);
-    const Fr e = M::m2();
-    acc = sp_mont<M>(acc, acc);                          // bit 128 of N - 2 is 0
-    for (int w = 63; w >= 0; w--) {                      // bits 127..0
-        acc = sqn(acc, 2);
-        const u32 d = (e.v[w >> 4] >> ((w & 15) * 2)) & 3u;
-        if (d) acc = sp_mont<M>(acc, d == 1u ? xM : (d == 2u ? xx : xxx));
+// a^-1 mod N for 0 < a < N, canonical in and out: the right-shift binary algorithm with v kept odd.  Invariants x1 a = u and
+// x2 a = v (mod N); every round makes u even (if it is odd: swap so that u >= v, subtract) and halves it, so bitlen(u) +
+// bitlen(v) drops by at least one per round: at most 512 rounds of ~150 instructions where the Fermat ladder of rounds 1-2 was ~390
+// Montgomery products of ~600 instructions (a quarter of the whole verification).  Branch-free inside a round; the lanes of a wavefront leave
+// the loop together (the slowest one's round count).
+ZK_HD Fr sp_inv_n_binary(const Fr& a) {
+    const Fr n = SecpN::mod();
+    Fr u = a, v = n, x1 = fr_zero(), x2 = fr_zero();
+    x1.v[0] = 1u;
+    for (int round = 0; round < 512 && !fr_is_zero(u); round++) {
+        const u32 odd = u.v[0] & 1u;
+        const bool sw = odd && fr_lt(u, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {  // conditional swap (u, x1) <-> (v, x2)
+            const u32 tu = u.v[k], tv = v.v[k], t1 = x1.v[k], t2 = x2.v[k];
+            u.v[k] = sw ? tv : tu; v.v[k] = sw ? tu : tv;
+            x1.v[k] = sw ? t2 : t1; x2.v[k] = sw ? t1 : t2;
+        }
+        // u odd: u -= v (>= 0, even), x1 -= x2 (mod N)
+        Fr vm, xm;
+        const u32 m = 0u - odd;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { vm.v[k] = v.v[k] & m; xm.v[k] = x2.v[k] & m; }
+        Fr d;
+        u256_sub(d, u, vm);
+        u = d;
+        if (u256_sub(d, x1, xm)) {  // went below zero: + N
+            Fr e;
+            u256_add(e, d, n);
+            d = e;
+        }
+        x1 = d;
+        // halve u; halve x1 mod N (x1 odd: (x1 + N) / 2, a 257-bit sum)
+#pragma unroll
+        for (int k = 0; k < 7; k++) u.v[k] = (u.v[k] >> 1) | (u.v[k + 1] << 31);
+        u.v[7] >>= 1;
+        Fr nm;
+        const u32 mx = 0u - (x1.v[0] & 1u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) nm.v[k] = n.v[k] & mx;
+        Fr h;
+        const u32 carry = u256_add(h, x1, nm);
+#pragma unroll
+        for (int k = 0; k < 7; k++) x1.v[k] = (h.v[k] >> 1) | (h.v[k + 1] << 31);
+        x1.v[7] = (h.v[7] >> 1) | (carry << 31);
     }
-    return acc;
+    return x2;  // u == 0: v == gcd == 1 (N is prime), x2 a == 1
 }
 
 struct EcdsaPrep {
@@ -682,7 +705,7 @@ ZK_HD u32 ecdsa_prepare(const EcdsaArgs& a, u64 i, EcdsaPrep& pr, bool run_exact
     if (fr_eq(pky, p)) return ECDSA_KEY_RANGE;
     pkx = sp_reduce_once<SecpP>(pkx);
     pky = sp_reduce_once<SecpP>(pky);
-    const Fr wM = sp_inv_n(sp_to_mont<SecpN>(s));
+    const Fr wM = sp_to_mont<SecpN>(sp_inv_n_binary(s));
     const Fr u1 = sp_mont<SecpN>(sp_reduce_once<SecpN>(z), wM);  // z * w mod N (canonical: one operand in Montgomery form)
     const Fr u2 = sp_mont<SecpN>(r, wM);
     // y^2 == x^3 + 7 ?
