@@ -201,7 +201,7 @@ ZK_HD bool state_mpt_lookup(const ZkTable& t, const Fr q[MPT_NCELLS]) {
     // wavefront that have a candidate compare it in the SAME round trip wherever in their windows it was found.
     bool found = false, done = false;
     u32 k = 4, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    while (!done) {
+    for (u32 scanned = 0; !done && scanned <= t.mask; ) {  // (bounded by the slot count: a damaged index cannot spin the wavefront)
         if (k == 4) {
             w0 = t.slots[slot], w1 = t.slots[(slot + 1u) & t.mask], w2 = t.slots[(slot + 2u) & t.mask], w3 = t.slots[(slot + 3u) & t.mask];
             slot = (slot + 4) & t.mask;
@@ -212,6 +212,7 @@ ZK_HD bool state_mpt_lookup(const ZkTable& t, const Fr q[MPT_NCELLS]) {
             const u32 sv = w0;
             w0 = w1, w1 = w2, w2 = w3;
             k++;
+            scanned++;
             if (sv == ZK_EMPTY_SLOT) {
                 done = true;
                 break;
