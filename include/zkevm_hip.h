@@ -12,6 +12,12 @@
  *
  * Ownership: the caller owns every buffer for the duration of the call (or of the session
  * for zk_*_open); nothing is retained after zk_*_close / after a one-shot call returns.
+ * Immutability: the tables a session was opened over are IMMUTABLE for the session's lifetime, also with
+ * ZK_OPT_DEVICE_PTRS (where the session reads the caller's buffers in place).  zk_*_open derives state from them that
+ * later passes rely on — lookup indices, packed key / step / bytecode records, the dense-RW verdict, EndBlock's whole-table
+ * aggregates, and (EVM) which of the warm / cold lane ranges are empty, after which those kernels are no longer launched.
+ * A witness that changed is a new witness: close the session and open another one (an EVM open at 2^18 steps is ~0.1 ms
+ * of device time).  Editing a table between passes is undefined: stale records would be evaluated, silently.
  * Errors: every function returns 0 on success and a negative code on infrastructure errors
  * (bad arguments, HIP failures — text via zk_last_error()); constraint failures are NOT
  * errors, they are reported in zk_result.  Nothing throws across this boundary.
@@ -338,8 +344,13 @@ int zk_copy_assign(const zk_copy_events* ev, uint64_t* rows_out, uint32_t* row_f
                    uint64_t* rw_out, uint32_t* rw_flags_out, uint32_t opts, zk_result* result);
 
 /* ---- Session protocol shared by every circuit.
- * launch: enqueue one evaluation pass (asynchronous).  status_dev: optional DEVICE buffer of
- *         n uint32 receiving the per-row status codes.
+ * launch: enqueue one evaluation pass (asynchronous) on the session's stream.  status_dev: optional DEVICE buffer of
+ *         n uint32 receiving the per-row status codes.  A caller-provided status_dev is final in stream order: once the
+ *         work enqueued by zk_launch has completed (the caller's own event / stream synchronisation on the session's stream,
+ *         no zk_collect needed) every row's code is there — for EVM sessions this includes the pairs the fast kernel hands
+ *         to the general build (malformed word cells, generic-index fallbacks): that kernel is enqueued behind the pass
+ *         whenever status_dev is given.  Without status_dev the codes go to the session's own buffer and are final once
+ *         zk_collect or zk_read_status has returned (they run the general build only if the pass left such pairs).
  * collect: wait for all enqueued passes, return the tally of the LAST pass and the mean kernel
  *         time over the passes since the previous collect. */
 int zk_launch(zk_session* s, uint32_t* status_dev);

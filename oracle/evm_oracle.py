@@ -12,7 +12,7 @@ Pinned against the reference itself by oracle/gen_golden_evm.py (tests/golden/ev
 """
 from .codes import (ASSERT, CONSTRAINT, LOOKUP_AMBIGUOUS, LOOKUP_UNSAT, NAME_ERROR, NOT_IMPLEMENTED, OK, OVERFLOW_ERROR,
                     UNSUPPORTED, VALUE_ERROR, ZERO_DIVISION, Fail)
-from .codes import ATTRIBUTE_ERROR, TYPE_ERROR
+from .codes import ATTRIBUTE_ERROR, TYPE_ERROR, code
 from .wire import P
 from . import keccak as _keccak
 
@@ -181,12 +181,17 @@ class Ins:
         return (lo % P, hi % P)
 
     def int_value(self, word):
-        """Word.int_value() for the big-int witness computations.  The HIP engine refuses
-        malformed word cells (>= 2^128) at this point (ZK_UNSUPPORTED, no checkpoint); the oracle
-        mirrors that rule so the two stay comparable — such rows are outside the parity claim."""
-        if word[0] > M128 or word[1] > M128:
-            raise Fail(UNSUPPORTED, self.seq)
+        """Word.int_value() (util/arithmetic.py:127-129): lo.n + (hi.n << 128) on unbounded Python ints — cells >= 2^128
+        (malformed words) simply add into each other, as in the reference."""
         return word[0] + (word[1] << 128)
+
+    def int_bytes32(self, word):
+        """Word.int_value().to_bytes(32, "little") (instruction.py:1349-1350, precompiles/ecrecover.py:49-52): OverflowError,
+        outside every checkpoint, when the sum of malformed cells needs more than 32 bytes."""
+        v = self.int_value(word)
+        if v >= 1 << 256:
+            raise Fail(OVERFLOW_ERROR, self.seq)
+        return v
 
     def compare(self, lhs, rhs, n_bytes):  # instruction.py:447-451
         self.require(lhs < 256**n_bytes and rhs < 256**n_bytes)
@@ -2224,7 +2229,7 @@ def g_create(i):  # create.py (CREATE and CREATE2)
         if is_create == 1:
             contract = _keccak.create_address(caller, nonce % P)
         else:
-            contract = _keccak.create2_address(caller, i.int_value(salt_w), i.int_value(code_hash))
+            contract = _keccak.create2_address(caller, i.int_bytes32(salt_w), i.int_bytes32(code_hash))
         i.cp()  # address_to_word: a 20-byte digest always fits
         contract_w = (contract & M128, contract >> 128)
         rowf = i.state_write(TG.TxAccessListAccount, tx_id, contract, value=(1, 0))
@@ -2347,7 +2352,7 @@ def g_ecrecover(i):  # precompiles/ecrecover.py:26-94
     msg_hash, sig_v, sig_r, sig_s = (a[0], a[1]), (a[2], a[3]), (a[4], a[5]), (a[6], a[7])
     recovered_addr, aux_input_rlc, aux_output_rlc, rand = a[8], a[9], a[10], a[11]
     is_recovered = int(recovered_addr % P != 0)
-    input_bytes = b"".join(i.int_value(w).to_bytes(32, "little") for w in (msg_hash, sig_v, sig_r, sig_s))
+    input_bytes = b"".join(i.int_bytes32(w).to_bytes(32, "little") for w in (msg_hash, sig_v, sig_r, sig_s))
     i.constrain_equal(aux_input_rlc, _horner(input_bytes, rand))
     i.constrain_equal(aux_output_rlc, _horner(recovered_addr.to_bytes(32, "little"), rand))
     i.constrain_equal(is_success, 1)
@@ -2636,6 +2641,8 @@ def verify_step(w, idx, is_first=False, is_last=False):
         g(i)
     except Fail as f:
         return f.code
+    except ZeroDivisionError:  # SMOD: `a1 // a2` with get_int_abs(pop2) == 0 for pop2 == 2^256 (hi cell 2^128), sdiv_smod.py:100-102
+        return code(ZERO_DIVISION, i.seq)
     return OK
 
 

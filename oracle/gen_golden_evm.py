@@ -31,9 +31,9 @@ calldataload error_invalid_opcode error_stack error_oog_constant error_invalid_j
 returndatacopy extcodecopy exp error_oog_static_memory_expansion error_oog_dynamic_memory_expansion
 error_oog_memory_copy error_oog_account_access error_oog_log error_oog_exp error_oog_sha3
 error_return_data_out_of_bound error_write_protection logs return_revert
-error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom error_oog_create error_gas_uint_overflow ecRecover ecAdd ecMul ecPairing""".split()
+error_invalild_creation_code error_code_store end_block_padding end_tx begin_tx callop error_oog_call error_oog_sload_store create end_block dataCopy error_oog_precompile_custom error_oog_create error_gas_uint_overflow ecRecover ecAdd ecMul ecPairing wide_cells""".split()
 PRECOMPILE_TESTS = ("ecRecover", "ecAdd", "ecMul", "ecPairing")  # tests/evm/precompiles/
-MAX_CASES_PER_FILE = 48
+MAX_CASES_PER_FILE = 48  # (wide_cells: 80 harvested cases, each with six wide-cell variants)
 
 
 def ref_step_outcomes(tables, steps, begin, end):
@@ -221,6 +221,61 @@ def fuzz_wire(wire, rng):
     return w
 
 
+WIDE_SOURCES = ("mul_div_mod", "shl_shr", "sar", "sdiv_smod", "addmod", "mulmod", "create", "ecRecover")
+
+
+def wide_fuzz_wire(wire, rng):
+    """Malformed *word cells*: one to three lo / hi cells of the stack operands (or of ecRecover's aux words) set to values
+    >= 2^128, where the reference's witness code computes with unbounded Python ints (`Word.int_value()`:
+    mul_div_mod.py:23-41, shl_shr.py:103-127, sar.py:158, sdiv_smod.py:85-99, addmod.py:32-41, mulmod.py:41-50,
+    instruction.py:1349-1350, precompiles/ecrecover.py:49-52)."""
+    from zkevm_specs_amd.evm_tables import Target
+
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    w = {k: v.copy() for k, v in wire.items()}
+
+    def put(arr, idx, val):
+        arr[idx] = np.frombuffer(int(val % P).to_bytes(32, "little"), dtype="<u8")
+
+    def cur(arr, idx):
+        return int.from_bytes(arr[idx].tobytes(), "little")
+
+    def wide_value(old):
+        return rng.choice([1 << 128, (1 << 128) + rng.randrange(1, 1 << 20), P - 1, rng.randrange(1 << 128, P), 1 << 253,
+                           (1 << 128) + old, (1 << 128) - 1 + (1 << 128), rng.randrange(1 << 128, 1 << 130), (1 << 127) << 1,
+                           ((1 << 127) + rng.randrange(1 << 64)) << 1])
+
+    stack_rows = [i for i in range(w["rw"].shape[0]) if cur(w["rw"], (i, 2)) == int(Target.Stack)]
+    aux_words = "aux" in w and w["aux"].shape[1] > 2 and any(int(k) == 5 for k in w["aux_kind"])
+    for _ in range(rng.choice([1, 1, 2, 3])):
+        if aux_words and rng.random() < 0.6:
+            i = rng.choice([j for j in range(w["aux"].shape[0]) if int(w["aux_kind"][j]) == 5])
+            c = rng.randrange(8)
+            put(w["aux"], (i, c), wide_value(cur(w["aux"], (i, c))))
+        elif stack_rows:
+            i, c = rng.choice(stack_rows), rng.choice([8, 9])
+            put(w["rw"], (i, c), wide_value(cur(w["rw"], (i, c))))
+            if rng.random() < 0.3:  # keep the other cell small so that the witness arithmetic goes deep
+                put(w["rw"], (i, 17 - c), rng.choice([0, 1, rng.randrange(1 << 64)]))
+    return w
+
+
+def wide_cell_cases():
+    """The reference's own tests of the big-int gadgets, re-harvested, each with wide-cell variants (labelled by the unmodified
+    reference like every other golden case)."""
+    cases = []
+    for name in WIDE_SOURCES:
+        path = os.path.join(REF_TESTS, "precompiles" if name in PRECOMPILE_TESTS else "", f"test_{name}.py")
+        h = Harvest()
+        reseed(name)
+        rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null", path], plugins=[h])
+        assert rc == 0, (name, rc)
+        rng = random.Random(sum(map(ord, name)) + 777)
+        got = h.cases if len(h.cases) <= 10 else rng.sample(h.cases, 10)
+        cases += [(f"{name}::{c[0]}",) + c[1:] for c in got]
+    return cases
+
+
 def check_tables_against_reference():
     """zkevm_specs_amd/evm_tables.py restates the reference's enum numberings and opcode metadata as
     data; assert every entry against the imported reference so a drift fails golden generation."""
@@ -311,6 +366,8 @@ def main():
             cases = end_block_padding_cases()
         elif name == "error_oog_precompile_custom":
             cases = error_oog_precompile_cases()
+        elif name == "wide_cells":
+            cases = wide_cell_cases()
         else:
             path = os.path.join(REF_TESTS, "precompiles" if name in PRECOMPILE_TESTS else "", f"test_{name}.py")
             h = Harvest()
@@ -318,7 +375,7 @@ def main():
             rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", "--rootdir=/tmp", "-c", "/dev/null", path], plugins=[h])
             assert rc == 0, (name, rc)
             cases = h.cases
-        if len(cases) > MAX_CASES_PER_FILE:
+        if len(cases) > MAX_CASES_PER_FILE and name != "wide_cells":
             cases = rng.sample(cases, MAX_CASES_PER_FILE)
         out, names = {}, []
         n_fuzz_fail = 0
@@ -332,8 +389,8 @@ def main():
             driver = ref_driver_outcomes(t2, s2, begin, end)
             assert driver == ref_driver_outcomes(tables, steps, begin, end), tid
             variants = [("", wire, kinds, driver)]
-            for k in range(3):
-                fw = fuzz_wire(wire, rng)
+            for k in range(6 if name == "wide_cells" else 3):
+                fw = wide_fuzz_wire(wire, rng) if name == "wide_cells" else fuzz_wire(wire, rng)
                 t3, s3 = unflatten(fw)
                 fk = ref_step_outcomes(t3, s3, begin, end)
                 n_fuzz_fail += any(fk)

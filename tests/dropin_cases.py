@@ -37,9 +37,11 @@ def expect_outcome(kind, call):
     if kind == 0:
         call()
     else:
-        with pytest.raises(exc_class(kind)) as ei:
+        with pytest.raises(Exception) as ei:  # noqa: B017, PT011
             call()
-        assert type(ei.value) is exc_class(kind)
+        # by class NAME: with the reference loaded in the process the mirror raises the reference's own class objects, of which
+        # ConstraintUnsatFailure exists twice (errors._boundary_exception)
+        assert type(ei.value).__name__ == exc_class(kind).__name__, (type(ei.value), kind)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -463,3 +463,18 @@ extern "C" int sim_pi_verify(const u64* rows, u64 n, const u64* keccak, u64 n_ke
     for (u64 i = 0; i < n; i++) status[i] = pi_check_row(a, i);
     return 0;
 }
+
+// wide_witness (csrc/bigz.hpp): the unbounded-integer witness stages, one call per operand tuple.  x: 8 cells (x0.lo, x0.hi, ...,
+// x3.hi) per tuple; out: 4 x 4 u64 values, 4 flags, b0, b1 per tuple.
+extern "C" void sim_wide_witness(u32 op, const u64* x, u64* out, u32* flags, u64 count) {
+    for (u64 i = 0; i < count; i++) {
+        Fr c[8];
+        for (int k = 0; k < 8; k++) c[k] = fr_load(x + (8 * i + k) * 4);
+        const WideRes R = wide_witness(op, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+        for (int o = 0; o < 4; o++)
+            for (int k = 0; k < 4; k++) out[(4 * i + o) * 4 + k] = (u64)R.o[o].v[2 * k] | ((u64)R.o[o].v[2 * k + 1] << 32);
+        for (int o = 0; o < 4; o++) flags[6 * i + o] = R.fl[o];
+        flags[6 * i + 4] = R.b0;
+        flags[6 * i + 5] = R.b1;
+    }
+}

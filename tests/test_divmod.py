@@ -73,3 +73,94 @@ def test_fr_inv_and_div_match_python(hostsim):
     for opcode, want in ((2, (1, 0, 0)), (4, (0, 1, 0)), (6, (0, 0, 1))):
         got = ((4 - opcode) * (6 - opcode) * inv(8) % P, (opcode - 2) * (6 - opcode) * inv(4) % P, (opcode - 2) * (opcode - 4) * inv(8) % P)
         assert got == want
+
+
+def test_wide_witness_matches_python_ints(hostsim):
+    """csrc/bigz.hpp `wide_witness`: the witness values the reference computes on unbounded Python ints when word cells are
+    >= 2^128 (mul_div_mod.py:23-41, shl_shr.py:121, instruction.py:545, sdiv_smod.py:85-104, addmod.py:32-41,61,
+    mulmod.py:10,41-50), restated here with Python ints: low 256 bits, the two ways `Word(int)` raises, the side booleans."""
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(11)
+
+    def cell():
+        return rng.choice([0, 1, rng.getrandbits(64), rng.getrandbits(128), 1 << 128, (1 << 128) + rng.getrandbits(20), P - 1,
+                           rng.randrange(P), 1 << 253, 1 << 127, (1 << 128) - 1, rng.getrandbits(130) % P, 1 << 255 - 128])
+
+    def word_flags(v):
+        return 1 if v < 0 else (2 if v >= 1 << 256 else 0)
+
+    def int_neg(x):
+        return 0 if x == 0 else (1 << 256) - x
+
+    def int_abs(x):
+        return int_neg(x) if x >> 255 else x
+
+    def expect(op, c):
+        x = [c[2 * k] + (c[2 * k + 1] << 128) for k in range(4)]
+        outs, b0, b1 = [None] * 4, 0, 0
+        if op == 0:
+            outs[0] = x[0] - x[1] * x[2]
+        elif op == 1:
+            if x[1] == 0:
+                return None
+            outs[0] = (x[0] - x[2]) // x[1]
+        elif op == 2:
+            outs[0] = (1 << 256) - x[0]
+        elif op == 3:
+            a1, a2, ap = int_abs(x[0]), int_abs(x[1]), int_abs(x[2])
+            rem = a1 - ap * a2
+            outs[0] = rem if x[0] >> 255 == 0 else int_neg(rem)
+        elif op == 4:
+            b0 = int(x[1] == 0)
+            if not b0:
+                a1, a2 = int_abs(x[0]), int_abs(x[1])
+                if a2 == 0:
+                    b1 = 1
+                else:
+                    outs[0] = a1 // a2 if x[0] >> 255 == x[1] >> 255 else int_neg(a1 // a2)
+        elif op == 5:
+            a, b, n, pr = x
+            b0 = int(n == 0)
+            if b0:
+                ared, k, d, r = a, 0, 0, (a + b) % (1 << 256)
+            else:
+                ared, k, d, r = a % n, a // n, (a % n + b) // n, pr
+            outs = [k, ared, d, r]
+            n_is_zero = int((c[4] + c[5]) % P == 0)
+            r_int = (r & ((1 << 256) - 1)) if b0 else pr
+            b1 = int(pr == r_int * (1 - n_is_zero) % P)
+        elif op == 6:
+            a, b, n, r = x
+            b0 = int(n == 0)
+            ared, k = (0, 0) if b0 else (a % n, (a % n * b) // n)
+            prod = ared * b
+            outs = [ared, k, prod % (1 << 256), prod >> 256]
+            b1 = int(prod == k * n + r)
+        elif op == 7:
+            outs[0] = x[0] // x[1] if x[1] else 0
+        elif op == 8:
+            outs[0] = x[0]
+        return outs, b0, b1
+
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    n_checked = 0
+    for op in range(9):
+        tuples = [[cell() for _ in range(8)] for _ in range(1500)]
+        exp = [expect(op, c) for c in tuples]
+        keep = [i for i, e in enumerate(exp) if e is not None]
+        x = np.array([[_pack(v, 4) for v in tuples[i]] for i in keep], dtype=np.uint64)
+        out = np.zeros((len(keep), 4, 4), dtype=np.uint64)
+        fl = np.zeros((len(keep), 6), dtype=np.uint32)
+        hostsim.sim_wide_witness(ctypes.c_uint32(op), vp(x), vp(out), vp(fl), ctypes.c_uint64(len(keep)))
+        for row, i in enumerate(keep):
+            outs, b0, b1 = exp[i]
+            assert (int(fl[row, 4]), int(fl[row, 5])) == (b0, b1), (op, tuples[i])
+            for o, v in enumerate(outs):
+                if v is None:
+                    continue
+                assert int(fl[row, o]) == word_flags(v), (op, o, tuples[i])
+                if word_flags(v) == 0:
+                    got = sum(int(w) << (64 * k) for k, w in enumerate(out[row, o]))
+                    assert got == v, (op, o, tuples[i])
+                n_checked += 1
+    assert n_checked > 15000

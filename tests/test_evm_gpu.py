@@ -40,9 +40,8 @@ def test_golden_cases_match_reference_and_oracle(golden_dir):
             _check_tally(res, exp)
             if n % 7 == 0:  # the generic open-addressing index must give the same answers
                 assert _run(w, opts, generic_index=True)[1] == exp, (os.path.basename(fn), name)
-            for c, rk in zip(status, ref_kind.tolist()):
-                if codes.kind_of(c) != codes.UNSUPPORTED:
-                    assert codes.kind_of(c) == rk, (os.path.basename(fn), name)
+            for c, rk in zip(status, ref_kind.tolist()):  # no exceptions: wide word cells have device verdicts too (csrc/bigz.hpp)
+                assert codes.kind_of(c) == rk, (os.path.basename(fn), name)
             n += 1
     assert n > 2000
 

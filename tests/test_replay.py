@@ -1,7 +1,6 @@
-"""Failure replay (zkevm_specs_amd/replay.py) in the build container: the golden step pairs for which the device
-has no verdict (word cells >= 2^128 in MUL/DIV/MOD, SHL/SHR, SAR, SDIV/SMOD, the ecRecover aux data: kind UnsupportedOnDevice)
-must come out of the mirror's `verify_steps` with the exception class the unmodified reference raises, once the caller hands
-over the reference's own objects.  The device is stood in for by the oracle (as in tests/test_dropin_cpu.py); the replay
+"""Failure replay (zkevm_specs_amd/replay.py) in the build container.  Since round 4 replay is an opt-in
+diagnostic (ZK_REPLAY=always: the reference's own message): every golden pair — word cells >= 2^128 included — has a verdict of
+its own, and the mirror's `verify_steps` must raise the class the unmodified reference raises without executing the reference.  The device is stood in for by the oracle (as in tests/test_dropin_cpu.py); the replay
 itself runs the reference (needs /root/reference + oracle/refshim: skipped elsewhere, e.g. on the GPU box)."""
 import os
 import sys
@@ -23,13 +22,17 @@ def reference_on_path(monkeypatch):
     yield
 
 
-def test_unsupported_pairs_report_the_references_class(reference_on_path, monkeypatch, golden_dir):
+def test_wide_cell_pairs_need_no_replay(reference_on_path, monkeypatch, golden_dir):
+    """Round 4: word cells >= 2^128 (where the reference computes with unbounded Python ints) have verdicts of their own
+    (csrc/bigz.hpp), so with the default ZK_REPLAY=never the mirror's `verify_steps` must raise the class the unmodified
+    reference's driver raised on the reference-labelled wide-cell goldens — and, the reference being loaded in this process,
+    the reference's OWN exception class objects (errors._boundary_exception)."""
     from oracle import codes
     from oracle.gen_golden_evm import unflatten
     from tests import dropin_cases as D
-    from tests.evm_cases import golden_files, load_cases, oracle_status
+    from tests.evm_cases import load_cases, oracle_status
     from tests.test_dropin_cpu import _result
-    from zkevm_specs_amd import errors, oneshot, replay
+    from zkevm_specs_amd import oneshot, replay
     from zkevm_specs_amd.evm_circuit import verify_steps
 
     def evm_verify(w, begin=False, end=False, opts=0, device=None):
@@ -37,29 +40,43 @@ def test_unsupported_pairs_report_the_references_class(reference_on_path, monkey
         return _result(st), np.array(st, dtype=np.uint32)
 
     monkeypatch.setattr(oneshot, "evm_verify", evm_verify)
-    assert replay.reference_available()
+    monkeypatch.delenv("ZK_REPLAY", raising=False)
+    assert replay.replay_mode() == "never"
+    called = []
+    monkeypatch.setattr(replay, "replay_step", lambda *a, **k: called.append(a))
+    fn = os.path.join(golden_dir, "evm_wide_cells.npz")
+    g = np.load(fn)
     n = 0
-    for fn in golden_files(golden_dir):
-        g = np.load(fn)
-        for ci, (name, w, opts, ref_kind) in enumerate(load_cases(fn)):
-            first = next((c for c in oracle_status(w, opts) if c), 0)
-            if codes.kind_of(first) != codes.UNSUPPORTED:
-                continue
-            driver = g[f"c{ci:04d}_ref_driver"].tolist()
-            begin, end = bool(opts[0]), bool(opts[1])
-            for success, kind in zip((True, False), driver):
-                tables, steps = unflatten(w)
-                assert replay.is_reference_tables(tables)
-                st = list(steps[:-1] if end else steps)
-                D.expect_outcome(kind, lambda: verify_steps(tables, st, begin, end, success))  # noqa: B023
-            # without the replay the mirror says where the device stopped
-            monkeypatch.setenv("ZK_REPLAY", "never")
+    for ci, (name, w, opts, ref_kind) in enumerate(load_cases(fn)):
+        if ci % 5 or "#fuzz" not in name:
+            continue
+        assert not any(codes.kind_of(c) == codes.UNSUPPORTED for c in oracle_status(w, opts))
+        driver = g[f"c{ci:04d}_ref_driver"].tolist()
+        begin, end = bool(opts[0]), bool(opts[1])
+        for success, kind in zip((True, False), driver):
             tables, steps = unflatten(w)
-            with pytest.raises(errors.UnsupportedOnDevice):
-                verify_steps(tables, list(steps[:-1] if end else steps), begin, end, True)
-            monkeypatch.delenv("ZK_REPLAY")
-            n += 1
-    assert n == 8
+            st = list(steps[:-1] if end else steps)
+            D.expect_outcome(kind, lambda: verify_steps(tables, st, begin, end, success))  # noqa: B023
+        n += 1
+    assert n >= 70 and not called
+
+
+def test_mirror_raises_the_references_own_classes(reference_on_path):
+    """errors.exception_for_code with the reference loaded: the reference's class objects, constructed with its signatures
+    (evm_circuit/table.py:363-378, instruction.py:53, util/constraint_system.py:7)."""
+    import zkevm_specs.evm_circuit.instruction as ins
+    import zkevm_specs.evm_circuit.table as tab
+    import zkevm_specs.util.constraint_system as cs
+    from zkevm_specs_amd import errors
+
+    assert type(errors.exception_for_code((2 << 24) | 5, "EVM circuit step 3")) is ins.ConstraintUnsatFailure
+    assert type(errors.exception_for_code((2 << 24) | 5, "Exp circuit row 3")) is cs.ConstraintUnsatFailure
+    assert type(errors.exception_for_code((3 << 24) | 1, "EVM circuit step 0")) is tab.LookupUnsatFailure
+    assert type(errors.exception_for_code((4 << 24) | 1, "EVM circuit step 0")) is tab.LookupAmbiguousFailure
+    assert type(errors.exception_for_code((5 << 24) | 1, "EVM circuit step 0")) is tab.WrongQueryKey
+    e = errors.exception_for_code((1 << 24) | 9, "EVM circuit step 1")
+    assert type(e) is AssertionError and type(e.args[0]) is ins.ConstraintUnsatFailure
+    assert "site 9" in errors.exception_for_code((3 << 24) | 9, "x").message
 
 
 def test_replay_always_gives_the_references_own_exception(reference_on_path, monkeypatch, golden_dir):

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Run the reference's OWN pytest suite through this engine's boundary (BASELINE north_star: "the existing
+verify_circuit()/Expression surface and pytest suite stay intact").
+
+A pytest plugin rebinds, inside every reference test module that imported them, the names the reference's tests call —
+
+    verify_steps                    zkevm_specs/evm_circuit/main.py:14      -> zkevm_specs_amd.evm_circuit.verify_steps
+    check_state_row                 zkevm_specs/state_circuit.py:492        -> zkevm_specs_amd.state_circuit.check_state_row
+    check_bytecode_row              zkevm_specs/bytecode_circuit.py:37      -> zkevm_specs_amd.bytecode_circuit.check_bytecode_row
+    verify_copy_table               zkevm_specs/copy_circuit.py:92          -> zkevm_specs_amd.copy_circuit.verify_copy_table
+    verify_exp_circuit              zkevm_specs/exp_circuit.py:88           -> zkevm_specs_amd.exp_circuit.verify_exp_circuit
+    verify_circuit (tx / sig / pi)  tx_circuit.py:253, sig_circuit.py:113, pi_circuit.py:338 -> the three mirrors
+
+— to the host mirrors, which flatten the reference's own witness objects to the wire and evaluate them behind the C ABI
+(`--backend cpu`: libzkevm_cpu.so, runs in the GPU-less build container; `--backend hip`: libzkevm_hip.so on an MI355X).
+Everything else of the tests — witness construction with the reference's own classes, the expected outcomes — is untouched.
+
+The reference itself cannot travel to the GPU box (`/root/reference` only exists in the build container): `--stage` copies
+its `src/` and `tests/` under oracle/_ref/reference/ (git-ignored, shipped by gpurun like other built artefacts; never part
+of the repository's history) and `--ref-root oracle/_ref/reference` runs against that copy.
+
+Writes a JSON summary (`--out`): totals, per-file counts, every non-passing test with the reason, and how many calls went
+through each rebound entry.
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REBIND = {  # name in the test module -> (module the test imported it from, mirror module, mirror attribute)
+    "verify_steps": ("zkevm_specs.evm_circuit.main", "zkevm_specs_amd.evm_circuit", "verify_steps"),
+    "check_state_row": ("zkevm_specs.state_circuit", "zkevm_specs_amd.state_circuit", "check_state_row"),
+    "check_bytecode_row": ("zkevm_specs.bytecode_circuit", "zkevm_specs_amd.bytecode_circuit", "check_bytecode_row"),
+    "verify_copy_table": ("zkevm_specs.copy_circuit", "zkevm_specs_amd.copy_circuit", "verify_copy_table"),
+    "verify_exp_circuit": ("zkevm_specs.exp_circuit", "zkevm_specs_amd.exp_circuit", "verify_exp_circuit"),
+}
+VERIFY_CIRCUIT = {  # `verify_circuit` exists three times: told apart by the module that defined the imported function
+    "zkevm_specs.tx_circuit": ("zkevm_specs_amd.tx_circuit", "verify_circuit"),
+    "zkevm_specs.sig_circuit": ("zkevm_specs_amd.sig_circuit", "verify_circuit"),
+    "zkevm_specs.pi_circuit": ("zkevm_specs_amd.pi_circuit", "verify_circuit"),
+}
+
+
+class Rebind:
+    """pytest plugin: swap the reference's drivers for the mirrors in each collected test module; count the calls."""
+
+    def __init__(self):
+        self.calls = {}
+        self.outcomes = {}
+        self.durations = {}
+        self.rebound_modules = {}
+
+    def _counted(self, label, fn):
+        def call(*a, **k):
+            self.calls[label] = self.calls.get(label, 0) + 1
+            return fn(*a, **k)
+
+        call.__name__ = getattr(fn, "__name__", label)
+        call.__zk_mirror__ = True
+        return call
+
+    def pytest_collection_modifyitems(self, session, config, items):
+        import importlib
+
+        seen = set()
+        for item in items:
+            mod = item.module
+            if mod in seen:
+                continue
+            seen.add(mod)
+            done = []
+            # identity with the reference's own function object decides (some of them are wrapped by `is_circuit_code`,
+            # util/typing.py:10, without functools.wraps: `__module__` does not tell)
+            for name, (src, mirror_mod, attr) in REBIND.items():
+                cur = getattr(mod, name, None)
+                if cur is not None and cur is getattr(importlib.import_module(src), name, None):
+                    setattr(mod, name, self._counted(f"{mirror_mod}.{attr}", getattr(importlib.import_module(mirror_mod), attr)))
+                    done.append(name)
+            cur = getattr(mod, "verify_circuit", None)
+            for src, (mirror_mod, attr) in VERIFY_CIRCUIT.items():
+                if cur is not None and src in sys.modules and cur is getattr(sys.modules[src], "verify_circuit", None):
+                    setattr(mod, "verify_circuit", self._counted(f"{mirror_mod}.{attr}", getattr(importlib.import_module(mirror_mod), attr)))
+                    done.append("verify_circuit")
+            self.rebound_modules[os.path.relpath(str(mod.__file__), str(config.rootpath))] = done
+
+    def pytest_runtest_logreport(self, report):
+        if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+            self.outcomes[report.nodeid] = (report.outcome, "" if report.outcome == "passed" else str(report.longrepr)[-1500:])
+            self.durations[report.nodeid] = report.duration
+
+
+def stage_reference(dst):
+    src_root = "/root/reference"
+    if os.path.isdir(dst):
+        shutil.rmtree(dst)
+    os.makedirs(dst)
+    for sub in ("src", "tests"):
+        shutil.copytree(os.path.join(src_root, sub), os.path.join(dst, sub), ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+    print(f"staged {src_root}/{{src,tests}} -> {dst} (git-ignored; travels with gpurun)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=("cpu", "hip"), default="cpu")
+    ap.add_argument("--ref-root", default="/root/reference", help="directory holding the reference's src/ and tests/")
+    ap.add_argument("--stage", action="store_true", help="copy the reference under oracle/_ref/reference and exit")
+    ap.add_argument("--out", default=None, help="JSON summary path")
+    ap.add_argument("--select", nargs="*", default=None, help="test files / node ids relative to <ref-root>/tests (default: all)")
+    ap.add_argument("-k", dest="keyword", default=None)
+    ap.add_argument("-x", dest="exitfirst", action="store_true")
+    args = ap.parse_args()
+    if args.stage:
+        stage_reference(os.path.join(ROOT, "oracle", "_ref", "reference"))
+        return 0
+    ref_root = os.path.abspath(args.ref_root)
+    tests_dir = os.path.join(ref_root, "tests")
+    if not os.path.isdir(tests_dir):
+        print(f"{tests_dir} not found (build container: /root/reference; GPU box: --stage first, then --ref-root oracle/_ref/reference)")
+        return 2
+    os.environ["ZK_BACKEND"] = args.backend  # read when zkevm_specs_amd._lib is first imported
+    os.environ.setdefault("ZKEVM_SHIM_SEED", "20240807")
+    os.environ.pop("ZK_REPLAY", None)        # default: never — the product path must not execute the reference's verify_step
+    for p in (ROOT, os.path.join(ROOT, "oracle", "refshim"), os.path.join(ref_root, "src"), tests_dir):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import pytest
+
+    from zkevm_specs_amd import _lib
+
+    assert _lib.BACKEND == args.backend
+    if args.backend == "hip":
+        _lib.init()
+    plugin = Rebind()
+    targets = [os.path.join(tests_dir, t) for t in args.select] if args.select else [tests_dir]
+    pa = ["-q", "-p", "no:cacheprovider", "--rootdir", tests_dir, "-c", "/dev/null", "--tb=short", "-o", "python_files=test_*.py"] + targets
+    if args.keyword:
+        pa += ["-k", args.keyword]
+    if args.exitfirst:
+        pa.append("-x")
+    t0 = time.time()
+    rc = pytest.main(pa, plugins=[plugin])
+    wall = time.time() - t0
+    by_file = {}
+    for nodeid, (outcome, _) in plugin.outcomes.items():
+        f = nodeid.split("::")[0]
+        d = by_file.setdefault(f, {"passed": 0, "failed": 0, "skipped": 0})
+        d[outcome] = d.get(outcome, 0) + 1
+    n_pass = sum(1 for o, _ in plugin.outcomes.values() if o == "passed")
+    not_passed = {k: {"outcome": o, "why": why} for k, (o, why) in plugin.outcomes.items() if o != "passed"}
+    summary = {
+        "what": "the reference's own pytest suite with its drivers rebound to the zkevm_specs_amd mirrors (tools/run_reference_suite.py)",
+        "backend": args.backend, "library": _lib.LIB_PATH, "ref_root": ref_root, "pytest_rc": int(rc), "wall_s": round(wall, 1),
+        "tests_run": len(plugin.outcomes), "passed": n_pass, "not_passed": len(not_passed),
+        "calls_through_the_boundary": plugin.calls,
+        "modules_without_a_rebound_driver": sorted(m for m, d in plugin.rebound_modules.items() if not d),
+        "rebound": {m: d for m, d in sorted(plugin.rebound_modules.items()) if d},
+        "by_file": dict(sorted(by_file.items())),
+        "not_passed_detail": not_passed,
+        "notes": "Modules without a rebound driver test circuits outside SURVEY.md section 8 (ECC, Withdrawal): they run on the reference's own "
+                 "Python path, unchanged.  In the build container the reference's third-party dependencies are the stand-ins of oracle/refshim; "
+                 "its py_ecc stand-in has no FQ2 / pairing arithmetic, which is what test_ecc_circuit.py::test_ecc_pairing needs (the same seven "
+                 "tests fail on the unmodified reference under the shim, with no engine code involved).",
+    }
+    print(json.dumps({k: summary[k] for k in ("backend", "tests_run", "passed", "not_passed", "wall_s", "calls_through_the_boundary")}))
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(summary, f, indent=1)
+    return 0 if rc in (0, 1) else int(rc)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

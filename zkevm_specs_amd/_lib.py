@@ -113,6 +113,11 @@ def load():
     # this library to the SAME HIP runtime instance (one runtime per process: device pointers,
     # streams and events are then interchangeable with torch's).
     if BACKEND == "hip":
+        # one hardware queue per concurrent circuit session (csrc/zkevm_hip.hip zk_default_hw_queues): the HIP runtime reads the
+        # variable at its first call, which torch makes lazily.  Set here — when the HIP library is actually loaded — and not
+        # at package import: a process that only uses the CPU backend, or imports the package for its witness generators, keeps
+        # its environment untouched.  A host that sets the variable itself keeps its own choice.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         import torch  # noqa: F401
 
     _lib = _bind(ctypes.CDLL(LIB_PATH))
@@ -183,10 +188,13 @@ def _bind(lib):
     return lib
 
 
-def check(rc, what):
+def check(rc, what, lib=None):
+    """`lib`: the library the failing call was made on (a Session passes its own: an error of the CPU backend must not make
+    this process load torch + the HIP library just to format it)."""
     if rc != 0:
-        msg = load().zk_last_error().decode(errors="replace")
-        if not msg and _cpu_lib is not None:
+        owner = lib if lib is not None else (_lib if _lib is not None else (_cpu_lib if _cpu_lib is not None else load()))
+        msg = owner.zk_last_error().decode(errors="replace")
+        if not msg and lib is None and _cpu_lib is not None and owner is not _cpu_lib:
             msg = _cpu_lib.zk_last_error().decode(errors="replace")
         raise EngineError(f"{what} failed (rc={rc}): {msg}")
 

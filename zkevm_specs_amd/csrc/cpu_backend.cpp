@@ -103,6 +103,7 @@ struct zk_session {
     ZkRwMeta rw_meta;
     HostCodeDir dir;
     std::vector<u64> aux64;
+    bool status_external = false;  // the last pass wrote to the caller's buffer (zk_read_status refuses then, like the HIP library)
 };
 
 static void run_pass(zk_session* s, u32* status_out) {
@@ -125,6 +126,7 @@ static void run_pass(zk_session* s, u32* status_out) {
 }
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
+    s->status_external = status_dev != nullptr;
     run_pass(s, status_dev);
     return 0;
 }
@@ -142,6 +144,8 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
 }
 extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
     ARG_TRY(s && status_host, "zk_read_status: bad arguments");
+    // same contract as the HIP library: the last pass's codes are the caller's when it handed over its own buffer
+    ARG_TRY(!s->status_external, "zk_read_status: the last pass wrote its statuses to the caller's status_dev buffer, not the session's");
     memcpy(status_host, s->status.data(), s->n * sizeof(u32));
     return 0;
 }

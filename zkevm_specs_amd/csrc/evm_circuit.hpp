@@ -25,6 +25,7 @@
 #include "evm_tables.h"
 #include "keccak.hpp"
 #include "secp_constants.h"
+#include "bigz.hpp"
 
 enum { S_STATE = 0, S_RWC, S_CALL_ID, S_IS_ROOT, S_IS_CREATE, S_CH_LO, S_CH_HI, S_PC, S_SP, S_GAS, S_MWS, S_REV, S_LOG, STEP_NCELLS };
 enum { R_RWC = 0, R_RW, R_TAG, R_ID, R_ADDR, R_FT, R_KEY_LO, R_KEY_HI, R_VAL_LO, R_VAL_HI, R_PREV_LO, R_PREV_HI, R_AUX_LO, R_AUX_HI, RW_NCELLS };
@@ -241,16 +242,30 @@ ZK_HD U256 to_u256(Ins& I, const Word& w) {
     return u256_from_lo_hi(w.lo, w.hi);
 }
 // Integer value of a word for the witness computations the reference does with Python big
-// ints (`Word.int_value`, util/arithmetic.py:127-129).  Cells >= 2^128 would need unbounded
-// integers here; such malformed word cells are reported as ZK_UNSUPPORTED (no checkpoint).
+// ints (`Word.int_value`, util/arithmetic.py:127-129), for cells known to fit 128 bits.  Gadgets test
+// `words_wide` first: cells >= 2^128 (malformed words) make the reference compute with unbounded
+// integers, which is `wide_witness` (bigz.hpp) in the general build; the fast build defers the pair.
 ZK_HD U256 int_value(Ins& I, const Word& w) {
 #if EVM_FAST
     if (!word_cells_fit(w)) I.defer = 1u;
 #else
-    if (!word_cells_fit(w) && I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);
+    if (!word_cells_fit(w) && I.err == 0u) I.err = ZK_CODE(ZK_UNSUPPORTED, I.seq);  // a call site that did not test words_wide
 #endif
     return u256_from_lo_hi(w.lo, w.hi);
 }
+ZK_HD bool words_wide(Ins& I, const Word& a, const Word& b, const Word& c, const Word& d) {
+    const bool wide = !(word_cells_fit(a) && word_cells_fit(b) && word_cells_fit(c) && word_cells_fit(d));
+#if EVM_FAST
+    if (wide) I.defer = 1u;
+    return false;
+#else
+    return wide;
+#endif
+}
+ZK_HD bool words_wide(Ins& I, const Word& a, const Word& b, const Word& c) { return words_wide(I, a, b, c, c); }
+ZK_HD bool words_wide(Ins& I, const Word& a, const Word& b) { return words_wide(I, a, b, b, b); }
+ZK_HD bool words_wide(Ins& I, const Word& a) { return words_wide(I, a, a, a, a); }
+ZK_HD bool word_is_zero_int(const Word& w) { return fr_is_zero(w.lo) && fr_is_zero(w.hi); }  // int_value() == 0: both cells (they are >= 0)
 ZK_HD Word word_from_u256(const U256& v) { return word_of(u256_lo(v), u256_hi(v)); }
 // Word(int) (util/arithmetic.py:115-122): `neg` -> OverflowError, `too_big` (>= 2^256) -> AssertionError
 ZK_HD Word word_from_int(Ins& I, const U256& v, bool neg = false, bool too_big = false) {
@@ -258,6 +273,26 @@ ZK_HD Word word_from_int(Ins& I, const U256& v, bool neg = false, bool too_big =
     if (too_big) ev_fail(I, ZK_ASSERT);
     else if (neg) ev_fail(I, ZK_OVERFLOW_ERROR);
     return word_from_u256(v);
+}
+#if !EVM_FAST
+ZK_HD WideRes wide_words(u32 op, const Word& x0, const Word& x1, const Word& x2, const Word& x3) {
+    return wide_witness(op, x0.lo, x0.hi, x1.lo, x1.hi, x2.lo, x2.hi, x3.lo, x3.hi);
+}
+// Word(int) of a wide_witness output: flag bit 0 = negative (OverflowError), bit 1 = not below 2^256 (AssertionError)
+ZK_HD Word word_from_wide(Ins& I, const WideRes& W, int k) { return word_from_int(I, W.o[k], (W.fl[k] & 1u) != 0u, (W.fl[k] & 2u) != 0u); }
+#endif
+// Word.int_value().to_bytes(32, "little") (instruction.py:1349-1350, precompiles/ecrecover.py:49-52): cells >= 2^128 add into
+// each other, and a sum that needs more than 32 bytes raises OverflowError outside every checkpoint
+ZK_HD U256 int_bytes32(Ins& I, const Word& w) {
+    if (word_cells_fit(w)) return u256_from_lo_hi(w.lo, w.hi);
+#if EVM_FAST
+    I.defer = 1u;
+    return fr_zero();
+#else
+    const WideRes W = wide_words(WIDE_INT256, w, w, w, w);
+    if ((W.fl[0] & 2u) && I.err == 0u) I.err = ZK_CODE(ZK_OVERFLOW_ERROR, I.seq);
+    return W.o[0];
+#endif
 }
 // Word((lo, hi)) with check=True (util/arithmetic.py:110-114)
 ZK_HD Word word_checked(Ins& I, const Fr& lo, const Fr& hi) {
@@ -1355,21 +1390,33 @@ ZK_HD void g_mul_div_mod(Ins& I, Tail& T) {  // mul_div_mod.py
         a = pop1; b = pop2; c = word_from_int(I, fr_zero()); d = push;
     } else if (fr_eq_u64(is_div, 1)) {
         d = pop1; b = pop2; a = push;
-        U256 dv, bv, av;
-        EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b)); EV_TRY(av = int_value(I, a));
-        U512 prod = u256_mul_full(bv, av);
-        U256 plo = u512_lo(prod), rem;
-        bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, plo);
-        EV_TRY(c = word_from_int(I, rem, neg));
+        if (words_wide(I, d, b, a)) {
+#if !EVM_FAST
+            const WideRes W = wide_words(WIDE_SUB_MUL, d, b, a, a);
+            EV_TRY(c = word_from_wide(I, W, 0));
+#endif
+        } else {
+            U256 dv, bv, av;
+            EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b)); EV_TRY(av = int_value(I, a));
+            U512 prod = u256_mul_full(bv, av);
+            U256 plo = u512_lo(prod), rem;
+            bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, plo);
+            EV_TRY(c = word_from_int(I, rem, neg));
+        }
     } else {
         d = pop1; b = pop2;
-        U256 dv, bv;
-        EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b));
-        if (fr_is_zero(bv)) {
+        if (word_is_zero_int(b)) {
             c = d; a = word_from_int(I, fr_zero());
+        } else if (words_wide(I, d, b, push)) {
+            c = push;
+#if !EVM_FAST
+            const WideRes W = wide_words(WIDE_MOD_QUOT, d, b, c, c);
+            EV_TRY(a = word_from_wide(I, W, 0));
+#endif
         } else {
             c = push;
-            U256 cv; EV_TRY(cv = int_value(I, c));
+            U256 dv, bv, cv;
+            EV_TRY(dv = int_value(I, d)); EV_TRY(bv = int_value(I, b)); EV_TRY(cv = int_value(I, c));
             U256 diff, q, r;
             bool neg = u256_sub(diff, dv, cv);
             u256_divmod(diff, bv, q, r);
@@ -1704,12 +1751,19 @@ ZK_HD void g_shl_shr(Ins& I, Tail& T) {  // shl_shr.py
         dividend = push; quotient = pop2; remainder = word_from_int(I, fr_zero());
     } else {
         dividend = pop2; quotient = push;
-        U256 dv, qv;
-        EV_TRY(dv = int_value(I, dividend)); EV_TRY(qv = int_value(I, quotient));
-        U512 prod = u256_mul_full(qv, dvs);
-        U256 rem;
-        bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, u512_lo(prod));
-        EV_TRY(remainder = word_from_int(I, rem, neg));
+        if (words_wide(I, dividend, quotient)) {
+#if !EVM_FAST
+            const WideRes W = wide_words(WIDE_SUB_MUL, dividend, quotient, divisor, divisor);
+            EV_TRY(remainder = word_from_wide(I, W, 0));
+#endif
+        } else {
+            U256 dv, qv;
+            EV_TRY(dv = int_value(I, dividend)); EV_TRY(qv = int_value(I, quotient));
+            U512 prod = u256_mul_full(qv, dvs);
+            U256 rem;
+            bool neg = !fr_is_zero(u512_hi(prod)) || u256_sub(rem, dv, u512_lo(prod));
+            EV_TRY(remainder = word_from_int(I, rem, neg));
+        }
     }
     // check_witness (:35-100)
     Fr is_shr = fr_sub(fr_u(1), is_shl);
@@ -1757,9 +1811,12 @@ ZK_HD void g_sar(Ins& I, Tail& T) {
     Fr opcode; opcode = opcode_lookup(I, true);
     Word shift, a, b;
     shift = stack_pop(I, R, 0); a = stack_pop(I, R, 1); b = stack_push(I, R, 2);
-    U256 av; EV_TRY(av = int_value(I, a));
+    // is_neg = a.int_value() >> 255 (:158) only feeds witness values computed after a.to_64s() (:166), which raises for cells
+    // >= 2^128: with such cells its value is never used
+    (void)words_wide(I, a);
+    const U256 av = u256_from_lo_hi(a.lo, a.hi);
     U256 sb; EV_TRY(sb = to_u256(I, shift));
-    I.seq++;  // a.to_64s(): the cells fit (int_value passed)
+    EV_TRY(to_u256(I, a));  // a.to_64s()
     const u32 is_neg = av.v[7] >> 31;
     const u32 shf0 = fr_byte(sb, 0), dv = shf0 >> 6, md = shf0 & 63u;
     bool rest_zero = true;
@@ -1809,9 +1866,17 @@ ZK_HD Word abs_word(Ins& I, const Word& x, u32& is_neg) {
     if (I.err) return x;
     Word x_abs = x;
     if (is_neg) {
-        U256 v = int_value(I, x);
-        if (I.err) return x;
-        x_abs = word_from_int(I, u256_neg(v));
+        if (words_wide(I, x)) {  // x.hi fits (the compare above), x.lo does not: 2^256 - (lo + (hi << 128)) in full
+#if !EVM_FAST
+            const WideRes W = wide_words(WIDE_NEG256, x, x, x, x);
+            x_abs = word_from_wide(I, W, 0);
+            if (I.err) return x;
+#endif
+        } else {
+            U256 v = int_value(I, x);
+            if (I.err) return x;
+            x_abs = word_from_int(I, u256_neg(v));
+        }
     }
     I.seq += 6;
     return x_abs;
@@ -1822,27 +1887,45 @@ ZK_HD void g_sdiv_smod(Ins& I, Tail& T) {  // sdiv_smod.py
     pop1 = stack_pop(I); pop2 = stack_pop(I); push = stack_push(I);
     // gen_witness (:79-119); is_sdiv = (SMOD - opcode) / 2 equals 1 exactly for SDIV
     const bool is_sdiv = fr_eq_u64(opcode, OP_SDIV);
-    U256 v1, v2, vp;
-    EV_TRY(v1 = int_value(I, pop1)); EV_TRY(v2 = int_value(I, pop2)); EV_TRY(vp = int_value(I, push));
-    const u32 n1 = v1.v[7] >> 31, n2 = v2.v[7] >> 31, np = vp.v[7] >> 31;
-    const U256 a1 = n1 ? u256_neg(v1) : v1, a2 = n2 ? u256_neg(v2) : v2, ap = np ? u256_neg(vp) : vp;
     Word quotient, divisor = pop2, remainder, dividend = pop1;
-    if (is_sdiv) {
-        quotient = push;
-        U512 prod = u256_mul_full(ap, a2);
-        U256 rem;
-        const bool neg = u256_sub(rem, a1, u512_lo(prod)) || !fr_is_zero(u512_hi(prod));
-        if (n1 == 0) EV_TRY(remainder = word_from_int(I, rem, neg));
-        else EV_TRY(remainder = word_from_int(I, u256_neg(rem), false, neg));  // 2^256 - rem >= 2^256 when rem < 0
-    } else {
-        if (fr_is_zero(v2)) {
-            quotient = word_from_int(I, fr_zero());
+    if (words_wide(I, pop1, pop2, push)) {
+#if !EVM_FAST
+        // unbounded-integer forms (get_int_abs of a value >= 2^256 is negative, `//` floors, a divisor of exactly 2^256 has
+        // get_int_abs == 0: ZeroDivisionError, raised outside every checkpoint)
+        if (is_sdiv) {
+            quotient = push;
+            const WideRes W = wide_words(WIDE_SDIV, pop1, pop2, push, push);
+            EV_TRY(remainder = word_from_wide(I, W, 0));
         } else {
-            U256 q, r;
-            u256_divmod(a1, a2, q, r);
-            quotient = word_from_int(I, n1 == n2 ? q : u256_neg(q));
+            const WideRes W = wide_words(WIDE_SMOD, pop1, pop2, pop2, pop2);
+            if (W.b1) { if (I.err == 0u) I.err = ZK_CODE(ZK_ZERO_DIVISION, I.seq); return; }
+            if (W.b0) quotient = word_from_int(I, fr_zero());
+            else EV_TRY(quotient = word_from_wide(I, W, 0));
+            remainder = W.b0 ? pop1 : push;
         }
-        remainder = fr_is_zero(v2) ? pop1 : push;
+#endif
+    } else {
+        U256 v1, v2, vp;
+        EV_TRY(v1 = int_value(I, pop1)); EV_TRY(v2 = int_value(I, pop2)); EV_TRY(vp = int_value(I, push));
+        const u32 n1 = v1.v[7] >> 31, n2 = v2.v[7] >> 31, np = vp.v[7] >> 31;
+        const U256 a1 = n1 ? u256_neg(v1) : v1, a2 = n2 ? u256_neg(v2) : v2, ap = np ? u256_neg(vp) : vp;
+        if (is_sdiv) {
+            quotient = push;
+            U512 prod = u256_mul_full(ap, a2);
+            U256 rem;
+            const bool neg = u256_sub(rem, a1, u512_lo(prod)) || !fr_is_zero(u512_hi(prod));
+            if (n1 == 0) EV_TRY(remainder = word_from_int(I, rem, neg));
+            else EV_TRY(remainder = word_from_int(I, u256_neg(rem), false, neg));  // 2^256 - rem >= 2^256 when rem < 0
+        } else {
+            if (fr_is_zero(v2)) {
+                quotient = word_from_int(I, fr_zero());
+            } else {
+                U256 q, r;
+                u256_divmod(a1, a2, q, r);
+                quotient = word_from_int(I, n1 == n2 ? q : u256_neg(q));
+            }
+            remainder = fr_is_zero(v2) ? pop1 : push;
+        }
     }
     // check_witness (:34-76)
     u32 q_neg, d_neg, r_neg, n_neg;
@@ -1871,39 +1954,72 @@ ZK_HD void g_addmod(Ins& I, Tail& T) {  // addmod.py
     constrain_equal(I, opcode, fr_u(OP_ADDMOD));
     Word a, b, n, pushed_r;
     a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); n = stack_pop(I, R, 2); pushed_r = stack_push(I, R, 3);
-    U256 av, bv, nv;
-    EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n));
-    const bool n_zero = fr_is_zero(nv);
-    U256 a_red, k = fr_zero(), d = fr_zero();
-    Word r;
-    if (n_zero) {
-        a_red = av;
-        U256 s; u256_add(s, a_red, bv);  // (a_red + b) % 2^256
-        r = word_from_int(I, s);
-    } else {
-        u256_divmod(av, nv, k, a_red);
-        U256 s; u32 carry = u256_add(s, a_red, bv);
-        U512 num = u512_from(s, fr_u(carry)), q; U256 rem;
-        divmod_512(num, nv, q, rem);
-        d = u512_lo(q);
-        r = pushed_r;
+    const bool wide = words_wide(I, a, b, n, pushed_r);
+    bool n_zero = word_is_zero_int(n);
+    U256 a_red = fr_zero(), k = fr_zero(), d = fr_zero();
+    Word r, kw, arw;
+#if !EVM_FAST
+    WideRes W;
+    if (wide) {  // a % n, a // n, (a % n + b) // n on unbounded integers; every Word(int) below can raise
+        W = wide_words(WIDE_ADDMOD, a, b, n, pushed_r);
+        if (n_zero) EV_TRY(r = word_from_wide(I, W, 3));
+        else r = pushed_r;
+        EV_TRY(kw = word_from_wide(I, W, 0));
+        EV_TRY(arw = word_from_wide(I, W, 1));
+    } else
+#endif
+    {
+        U256 av, bv, nv;
+        EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n));
+        if (n_zero) {
+            a_red = av;
+            U256 s; u256_add(s, a_red, bv);  // (a_red + b) % 2^256
+            r = word_from_int(I, s);
+        } else {
+            u256_divmod(av, nv, k, a_red);
+            U256 s; u32 carry = u256_add(s, a_red, bv);
+            U512 num = u512_from(s, fr_u(carry)), q; U256 rem;
+            divmod_512(num, nv, q, rem);
+            d = u512_lo(q);
+            r = pushed_r;
+        }
+        kw = word_from_int(I, k);
+        arw = word_from_int(I, a_red);
     }
-    Word kw = word_from_int(I, k);
-    Word arw = word_from_int(I, a_red);
     Fr overflow; EV_TRY(overflow = mul_add_words(I, kw, n, arw, a));
     constrain_zero(I, overflow);
-    Word arw2 = word_from_int(I, a_red);
+    Word arw2, dw;
     Fr carry_hi;
-    Word a_red_plus_b = add_words2(I, arw2, b, carry_hi);
-    Word dw = word_from_int(I, d);
+    Word a_red_plus_b;
+#if !EVM_FAST
+    if (wide) {
+        EV_TRY(arw2 = word_from_wide(I, W, 1));
+        a_red_plus_b = add_words2(I, arw2, b, carry_hi);
+        EV_TRY(dw = word_from_wide(I, W, 2));
+    } else
+#endif
+    {
+        arw2 = word_from_int(I, a_red);
+        a_red_plus_b = add_words2(I, arw2, b, carry_hi);
+        dw = word_from_int(I, d);
+    }
     Word ow = n_zero ? word_from_int(I, fr_zero()) : word_checked(I, carry_hi, fr_zero());
     EV_TRY(mul_add_words_512(I, dw, n, r, ow, a_red_plus_b));
     const u32 nz = is_zero_word(n);
     u32 r_lt_n; EV_TRY(r_lt_n = lt_u256_sel(I, r, n));
-    Word arw3 = word_from_int(I, a_red);
+    Word arw3;
+#if !EVM_FAST
+    if (wide) EV_TRY(arw3 = word_from_wide(I, W, 1));
+    else
+#endif
+        arw3 = word_from_int(I, a_red);
     u32 a_lt_n; EV_TRY(a_lt_n = lt_u256_sel(I, arw3, n));
     ev_require(I, 2 == a_lt_n + r_lt_n + 2 * nz);
     // pushed_r.int_value() == FQ(r.int_value() * (1 - n_is_zero)).n  (reduction mod p, addmod.py:61)
+#if !EVM_FAST
+    if (wide) ev_require(I, W.b1 != 0u);
+    else
+#endif
     {
         U256 pv; EV_TRY(pv = int_value(I, pushed_r));
         U256 rv; EV_TRY(rv = int_value(I, r));
@@ -1918,17 +2034,19 @@ ZK_HD void g_addmod(Ins& I, Tail& T) {  // addmod.py
     set_tail3(T, opcode, 4, 1, 2);
 }
 
-ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r, const U256& a_div_n) {  // mulmod.py:6-29
-    U256 nv = u256_from_lo_hi(n.lo, n.hi);
+// kw = Word(a.int_value() // n.int_value()) (0 when n == 0), made by the caller (it has a // n from the same division as a % n)
+ZK_HD void mulmod_mod(Ins& I, const Word& a, const Word& n, const Word& r, const U256& a_div_n, u32 k_flags) {  // mulmod.py:6-29
     Word a_or_zero;
     U256 k = fr_zero();
-    if (fr_is_zero(nv)) {
+    u32 kf = 0;
+    if (word_is_zero_int(n)) {
         a_or_zero = word_from_int(I, fr_zero());
     } else {
         a_or_zero = a;
         k = a_div_n;  // a // n, computed once by the caller together with a % n
+        kf = k_flags;
     }
-    Word kw = word_from_int(I, k);
+    Word kw; EV_TRY(kw = word_from_int(I, k, (kf & 1u) != 0u, (kf & 2u) != 0u));
     EV_TRY(mul_add_words(I, kw, n, r, a_or_zero));
     const u32 eq = is_equal_word(a, a_or_zero);
     u32 lt, e2; compare_word(I, r, n, lt, e2);
@@ -1943,30 +2061,56 @@ ZK_HD void g_mulmod(Ins& I, Tail& T) {  // mulmod.py
     constrain_equal(I, opcode, fr_u(OP_MULMOD));
     Word a, b, n, r;
     a = stack_pop(I, R, 0); b = stack_pop(I, R, 1); n = stack_pop(I, R, 2); r = stack_push(I, R, 3);
-    U256 av, bv, nv, rv;
-    EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
+    const bool wide = words_wide(I, a, b, n, r);
     U256 a_red = fr_zero(), k = fr_zero(), q0 = fr_zero();
-    U512 prod;
-    bool safety;
-    if (fr_is_zero(nv)) {
-        prod = u256_mul_full(a_red, bv);  // 0
-        safety = fr_is_zero(rv);          // 0 == 0*0 + r
-    } else {
-        u256_divmod(av, nv, q0, a_red);
-        prod = u256_mul_full(a_red, bv);
-        U512 q; U256 rem; divmod_512(prod, nv, q, rem);
-        k = u512_lo(q);      // k < b < 2^256
-        safety = fr_eq(rem, rv);  // prod == k*n + r  <=>  r == prod mod n
+    u32 q0_flags = 0;
+    Word e, d, arw, arw2, kw;
+#if !EVM_FAST
+    WideRes W;
+    if (wide) {  // a % n, (a % n * b) // n, the product's halves and a // n on unbounded integers; every Word(int) can raise
+        W = wide_words(WIDE_MULMOD, a, b, n, r);
+        EV_TRY(e = word_from_wide(I, W, 2));
+        EV_TRY(d = word_from_wide(I, W, 3));
+        ev_require(I, W.b1 != 0u);
+        EV_TRY(arw = word_from_wide(I, W, 0));
+        const WideRes Q = wide_words(WIDE_DIV, a, n, n, n);
+        q0 = Q.o[0];
+        q0_flags = Q.fl[0];
+    } else
+#endif
+    {
+        U256 av, bv, nv, rv;
+        EV_TRY(av = int_value(I, a)); EV_TRY(bv = int_value(I, b)); EV_TRY(nv = int_value(I, n)); EV_TRY(rv = int_value(I, r));
+        U512 prod;
+        bool safety;
+        if (fr_is_zero(nv)) {
+            prod = u256_mul_full(a_red, bv);  // 0
+            safety = fr_is_zero(rv);          // 0 == 0*0 + r
+        } else {
+            u256_divmod(av, nv, q0, a_red);
+            prod = u256_mul_full(a_red, bv);
+            U512 q; U256 rem; divmod_512(prod, nv, q, rem);
+            k = u512_lo(q);      // k < b < 2^256
+            safety = fr_eq(rem, rv);  // prod == k*n + r  <=>  r == prod mod n
+        }
+        e = word_from_int(I, u512_lo(prod));
+        d = word_from_int(I, u512_hi(prod));
+        ev_require(I, safety);
+        arw = word_from_int(I, a_red);
     }
-    Word e = word_from_int(I, u512_lo(prod));
-    Word d = word_from_int(I, u512_hi(prod));
-    ev_require(I, safety);
-    Word arw = word_from_int(I, a_red);
-    EV_TRY(mulmod_mod(I, a, n, arw, q0));
-    Word arw2 = word_from_int(I, a_red);
+    EV_TRY(mulmod_mod(I, a, n, arw, q0, q0_flags));
+#if !EVM_FAST
+    if (wide) EV_TRY(arw2 = word_from_wide(I, W, 0));
+    else
+#endif
+        arw2 = word_from_int(I, a_red);
     Word zero = word_from_int(I, fr_zero());
     EV_TRY(mul_add_words_512(I, arw2, b, zero, d, e));
-    Word kw = word_from_int(I, k);
+#if !EVM_FAST
+    if (wide) EV_TRY(kw = word_from_wide(I, W, 1));
+    else
+#endif
+        kw = word_from_int(I, k);
     EV_TRY(mul_add_words_512(I, kw, n, r, d, e));
     const u32 nz = is_zero_word(n);
     u32 lt, eq; compare_word(I, r, n, lt, eq);
@@ -3718,8 +3862,8 @@ ZK_HD void g_create(Ins& I, Tail& T) {
             contract = keccak_create_address(caller, nonce);
         } else {
             U256 salt_v, hash_v;
-            EV_TRY(salt_v = int_value(I, salt_w));
-            EV_TRY(hash_v = int_value(I, code_hash));
+            EV_TRY(salt_v = int_bytes32(I, salt_w));
+            EV_TRY(hash_v = int_bytes32(I, code_hash));
             contract = keccak_create2_address(caller, salt_v, hash_v);
         }
         I.seq++;  // address_to_word
@@ -3907,7 +4051,7 @@ ZK_HD void g_ecrecover(Ins& I, Tail& T) {  // precompiles/ecrecover.py:26-94
     {
         const Word* ws[4] = {&msg_hash, &sig_v, &sig_r, &sig_s};
         U256 vals[4];
-        for (int k = 0; k < 4; k++) { vals[k] = int_value(I, *ws[k]); if (I.err) return; }  // int_value().to_bytes(32, "little")
+        for (int k = 0; k < 4; k++) { vals[k] = int_bytes32(I, *ws[k]); if (I.err) return; }  // int_value().to_bytes(32, "little")
         for (int k = 0; k < 4; k++) rlc_le_bytes32(in, vals[k]);
     }
     constrain_equal(I, aux_cell(I, 9), in.acc); if (I.err) return;
@@ -4152,14 +4296,14 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 #define GROUP_OF_ES_ADDRESS 2
 #define GROUP_OF_ES_BITWISE 2
 #define GROUP_OF_ES_BYTE 2
-#define GROUP_OF_ES_BlockCtx 3
+#define GROUP_OF_ES_BlockCtx 4
 #define GROUP_OF_ES_CALLDATASIZE 2
 #define GROUP_OF_ES_CALLER 2
 #define GROUP_OF_ES_CALLVALUE 2
 #define GROUP_OF_ES_CMP 2
 #define GROUP_OF_ES_CODESIZE 2
 #define GROUP_OF_ES_GAS 2
-#define GROUP_OF_ES_GASPRICE 3
+#define GROUP_OF_ES_GASPRICE 4
 #define GROUP_OF_ES_ISZERO 2
 #define GROUP_OF_ES_JUMP 2
 #define GROUP_OF_ES_JUMPI 2
@@ -4168,7 +4312,7 @@ ZK_HD bool state_transition_ok(u32 curr, u32 next) {
 #define GROUP_OF_ES_MUL 1
 #define GROUP_OF_ES_MULMOD 1
 #define GROUP_OF_ES_NOT 2
-#define GROUP_OF_ES_ORIGIN 3
+#define GROUP_OF_ES_ORIGIN 4
 #define GROUP_OF_ES_POP 2
 #define GROUP_OF_ES_PUSH 2
 #define GROUP_OF_ES_RETURNDATASIZE 2

@@ -1843,6 +1843,14 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
             zk_launch_evm_warm(s->stream, cold_grid, (sorted && s->evm_ranges_known) ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->d_tally,
                                (evm_ext_events && !run_cold) ? e1 : nullptr);
         if (run_cold) zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
+        // A caller who hands over its own status buffer may read it after its own stream synchronisation, without zk_collect:
+        // the general build is enqueued right behind the pass (it reads the deferred count on the device and returns at once
+        // when it is zero), so that buffer — and the tally — are final in stream order.  Passes into the session's own buffer
+        // keep the lazy form (zk_collect / zk_read_status look at the count in the synchronisation they need anyway).
+        if (status_dev && s->evm.defer_count) {
+            zk_launch_evm_deferred(s->stream, s->evm, status, s->d_tally);
+            s->deferred_pending = false;
+        }
         break;
     }
     }

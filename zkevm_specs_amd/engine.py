@@ -48,11 +48,11 @@ class Session:
             _expect(status_dev, "status_dev", 4, (self.n,))
             if not _is_contiguous(status_dev):
                 raise ValueError("status_dev must be contiguous")
-        check(self._lib.zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch")
+        check(self._lib.zk_launch(self._h, _lib.ptr(status_dev)), "zk_launch", self._lib)
 
     def collect(self):
         r = ZkResult()
-        check(self._lib.zk_collect(self._h, ctypes.byref(r)), "zk_collect")
+        check(self._lib.zk_collect(self._h, ctypes.byref(r)), "zk_collect", self._lib)
         return Result(r)
 
     def run(self):
@@ -63,15 +63,15 @@ class Session:
         """Bind the session to another HIP stream of its device (a torch.cuda.Stream, a raw handle, or None = the
         engine's own stream); passes already enqueued are waited for first."""
         h = getattr(stream, "cuda_stream", stream)
-        check(self._lib.zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream")
+        check(self._lib.zk_session_set_stream(self._h, ctypes.c_void_p(h) if h else None), "zk_session_set_stream", self._lib)
 
     def set_range(self, row_lo, row_hi):
         """Row-circuit sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
-        check(self._lib.zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range")
+        check(self._lib.zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range", self._lib)
 
     def read_status(self):
         out = np.empty(self.n, dtype=np.uint32)
-        check(self._lib.zk_read_status(self._h, _lib.ptr(out)), "zk_read_status")
+        check(self._lib.zk_read_status(self._h, _lib.ptr(out)), "zk_read_status", self._lib)
         return out
 
     def close(self):
@@ -323,7 +323,7 @@ class KeccakSession(Session):
 
     def rows(self):
         out = np.empty((self.n, 5, 4), dtype=np.uint64)
-        check(self._lib.zk_keccak_read_rows(self._h, _lib.ptr(out)), "zk_keccak_read_rows")
+        check(self._lib.zk_keccak_read_rows(self._h, _lib.ptr(out)), "zk_keccak_read_rows", self._lib)
         return out
 
 
@@ -378,7 +378,7 @@ class AssignSession(Session):
 
     def n_mpt(self):
         m = ctypes.c_uint64()
-        check(self._lib.zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read")
+        check(self._lib.zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read", self._lib)
         return int(m.value)
 
     def read(self):
@@ -418,7 +418,7 @@ class BytecodeAssignSession(Session):
 
     def rows(self):
         out = np.empty((12, self.n, 4), dtype=np.uint64)
-        check(self._lib.zk_bytecode_assign_read(self._h, _lib.ptr(out)), "zk_bytecode_assign_read")
+        check(self._lib.zk_bytecode_assign_read(self._h, _lib.ptr(out)), "zk_bytecode_assign_read", self._lib)
         return out
 
 

@@ -40,19 +40,44 @@ KIND_NAMES = {
 }
 
 
+def _boundary_exception(name, msg, where):
+    """One of the four exception classes of the reference's boundary.  When the caller has the reference loaded in this
+    process (a drop-in user has: its tests build `Tables` / `StepState` with it) the mirror raises the reference's OWN class
+    objects, so `except LookupUnsatFailure` written against `zkevm_specs` keeps catching; this module never imports the
+    reference itself.  ConstraintUnsatFailure exists twice there: evm_circuit/instruction.py:53 (EVM circuit) and
+    util/constraint_system.py:7 (the ConstraintSystem circuits: Exp, Copy)."""
+    import sys
+
+    tab = sys.modules.get("zkevm_specs.evm_circuit.table")
+    if name == "ConstraintUnsatFailure":
+        mod = sys.modules.get("zkevm_specs.evm_circuit.instruction" if where.startswith("EVM circuit") else "zkevm_specs.util.constraint_system")
+        return getattr(mod, name, ConstraintUnsatFailure)(msg)
+    cls = getattr(tab, name, None)
+    if cls is None:
+        return globals()[name](msg)
+    if name == "WrongQueryKey":  # table.py:363-378: the reference's constructors take the table name and the query
+        e = cls("device", set())
+    elif name == "LookupUnsatFailure":
+        e = cls("device", msg)
+    else:
+        e = cls("device", msg, [])
+    e.message = msg
+    return e
+
+
 def exception_for_code(code, where=""):
     kind, site = code >> 24, code & 0xFFFFFF
     msg = f"{where}: constraint site {site} unsatisfied" if where else f"constraint site {site} unsatisfied"
     if kind == KIND_ASSERT:
-        return AssertionError(ConstraintUnsatFailure(msg))
+        return AssertionError(_boundary_exception("ConstraintUnsatFailure", msg, where))
     if kind == KIND_CONSTRAINT:
-        return ConstraintUnsatFailure(msg)
+        return _boundary_exception("ConstraintUnsatFailure", msg, where)
     if kind == KIND_LOOKUP_UNSAT:
-        return LookupUnsatFailure(msg)
+        return _boundary_exception("LookupUnsatFailure", msg, where)
     if kind == KIND_LOOKUP_AMBIGUOUS:
-        return LookupAmbiguousFailure(msg)
+        return _boundary_exception("LookupAmbiguousFailure", msg, where)
     if kind == KIND_WRONG_QUERY_KEY:
-        return WrongQueryKey(msg)
+        return _boundary_exception("WrongQueryKey", msg, where)
     if kind == KIND_NOT_IMPLEMENTED:
         return NotImplementedError(msg)
     if kind == KIND_TYPE_ERROR:

@@ -48,10 +48,11 @@ def verify_steps(tables, steps, begin_with_first_step=False, end_with_last_step=
     res, status = oneshot.evm_verify(flatten_evm(tables, steps), begin_with_first_step, end_with_last_step)
     exception = None
     if not res.ok:
-        # The first failing pair decides (the reference's loop stops there).  Failure replay (replay.py): where the device has
-        # no verdict (word cells outside the wire domain: kind UnsupportedOnDevice) — or for every failure, on request — the
-        # pair is evaluated by the reference's own verify_step on the caller's own objects; a pair the reference accepts does
-        # not decide, the next failing pair does.
+        # The first failing pair decides (the reference's loop stops there).  Failure replay (replay.py) is an opt-in
+        # diagnostic (ZK_REPLAY, default never): on request the failing pair is evaluated by the reference's own verify_step on
+        # the caller's own objects, for its message; with ZK_REPLAY=unsupported only a pair without a device verdict
+        # (UnsupportedOnDevice: an aux_data shape the wire does not carry) is, and a pair the reference accepts does not
+        # decide, the next failing pair does.
         mode = replay.replay_mode()
         can_replay = mode != "never" and replay.is_reference_tables(tables) and replay.reference_available()
         for row in (int(j) for j in status.nonzero()[0]):

@@ -1,16 +1,15 @@
-"""Failure replay: re-run ONE step pair on the reference's own Python path.
+"""Failure replay, an opt-in diagnostic: re-run ONE step pair on the reference's own Python path.
 
-The device decides every pair of a trace; for the first failing pair it reports the class of the exception the reference
-raises and the checkpoint.  Two things it cannot give are (a) the reference's exception *message* and (b) a verdict for the
-few witness shapes outside the wire domain — word cells >= 2^128 where the reference computes with unbounded Python
-integers (execution/mul_div_mod.py:23-41, shl_shr.py:103-127, sar.py, sdiv_smod.py:85-99, addmod.py, mulmod.py), reported
-as `UnsupportedOnDevice`.  A caller that switches over from the reference has the reference installed and hands this mirror
-the reference's own `Tables` / `StepState` objects, so the mirror can do what §8b recommends: evaluate exactly that pair with
-`zkevm_specs.evm_circuit.main.verify_step` and let it raise.  One pair costs the reference a few linear scans of the tables
-(seconds on a large block) — only ever on a failing witness.
+The device decides every pair of a trace — since round 4 also the pairs whose word cells are >= 2^128, where the reference
+computes with unbounded Python integers (csrc/bigz.hpp) — and for the first failing pair it reports the class of the
+exception the reference raises and the checkpoint.  What it cannot give is the reference's exception *message*.  A caller who
+has the reference installed and hands this mirror the reference's own `Tables` / `StepState` objects can ask for it
+(`ZK_REPLAY=always`): the mirror then evaluates exactly that pair with `zkevm_specs.evm_circuit.main.verify_step` and lets it
+raise; the device's kind is the cross-check.  `ZK_REPLAY=unsupported` replays only pairs the device reports as
+`UnsupportedOnDevice` (a `StepState.aux_data` of a Python type the wire does not carry).  The default is `never`: the product
+path does not execute the reference.
 
-Nothing here is imported unless a failure has to be replayed; without the reference the mirror keeps raising the mapped
-exception (or `UnsupportedOnDevice`).
+Nothing here is imported unless a failure has to be replayed.
 """
 import os
 
@@ -29,9 +28,9 @@ def is_reference_tables(tables):
 
 
 def replay_mode():
-    """ZK_REPLAY = unsupported (default: only where the device has no verdict) | always (every failure: the reference's own
-    message) | never"""
-    return os.environ.get("ZK_REPLAY", "unsupported")
+    """ZK_REPLAY = never (default) | unsupported (only where the device has no verdict) | always (every failure: the reference's
+    own message)"""
+    return os.environ.get("ZK_REPLAY", "never")
 
 
 def replay_step(tables, steps, idx, begin_with_first_step=False, end_with_last_step=False):
