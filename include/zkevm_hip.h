@@ -358,6 +358,12 @@ int zk_collect(zk_session* s, zk_result* result);
 /* Copy the per-row status of the last pass into a HOST buffer (n entries).  Fails when that pass wrote its statuses
  * to a caller-provided status_dev (they are the caller's then); all zero before the first pass. */
 int zk_read_status(zk_session* s, uint32_t* status_host);
+/* Device-side time spans, measured by HIP events that ride on the kernel dispatches themselves (measurement aid of bench.py;
+ * EVM sessions, -1 where not measured).  zk_session_timing, after a zk_collect: open_ms = first to last kernel of zk_evm_open
+ * (index, packed-record and first-pass sort builds), span_ms = first open kernel to the end of the session's FIRST pass.
+ * zk_last_timing: the same for the calling thread's last one-shot zk_evm_verify, plus its pass span (== zk_result.kernel_ms). */
+int zk_session_timing(zk_session* s, double* open_ms, double* span_ms);
+int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms);
 /* Re-bind a session to another stream of its device (NULL = the engine's own); waits for its enqueued passes first. */
 int zk_session_set_stream(zk_session* s, void* hip_stream);
 int zk_close(zk_session* s);

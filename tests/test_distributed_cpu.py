@@ -26,11 +26,20 @@ rank, world = dist.get_rank(), dist.get_world_size()
 lib = ctypes.CDLL(os.path.join(os.environ["ZK_ROOT"], "tests", "hostsim", "libhostsim.so"))
 vp = lambda x: ctypes.c_void_p(x.ctypes.data)
 
-# ---- State circuit: one global 4096-row witness, tampered in both halves ------------------
-cols, flags, mpt = synth_state_witness(4096, seed=9)
+# ZK_ODD=1 (the world-size-8 run): row counts not divisible by the world size, a tampered cell on both sides of EVERY shard boundary,
+# and the EVM driver's begin_with_first_step / end_with_last_step flags (only rank 0 / the last rank may apply them)
+odd = os.environ.get("ZK_ODD") == "1"
+N_STATE = 4099 if odd else 4096
+# ---- State circuit: one global witness, tampered around the shard boundaries ------------------
+cols, flags, mpt = synth_state_witness(N_STATE, seed=9)
 cols[1, 3000, 0] = 2      # is_write not boolean (rank 1's range)
 cols[50, 2047, 0] ^= 1    # value of the last row of rank 0's range
 cols[0, 2048, 0] = 0      # rw_counter of the first row of rank 1's range (halo of rank 0)
+if odd:
+    for r in range(1, world):
+        b = distributed.shard_bounds(N_STATE, r, world)[0]
+        cols[50, b - 1, 0] ^= 1   # last row of rank r - 1 (read as `prev` by rank r's first row)
+        cols[0, b, 0] ^= 4        # first row of rank r (read as `next` by rank r - 1's last row)
 lc, lf, elo, ehi, off = distributed.shard_state(cols, flags, rank, world)
 st = np.zeros(lc.shape[1], dtype=np.uint32)
 lib.sim_state_verify_range(vp(lc), vp(lf), ctypes.c_uint64(lc.shape[1]), vp(mpt), ctypes.c_uint64(mpt.shape[0]),
@@ -38,8 +47,8 @@ lib.sim_state_verify_range(vp(lc), vp(lf), ctypes.c_uint64(lc.shape[1]), vp(mpt)
 local = st[elo:ehi]
 fails = np.nonzero(local)[0]
 res = distributed.reduce_tally(len(fails), int(fails[0]) if len(fails) else None, int(local[fails[0]]) if len(fails) else 0, off)
-full = np.zeros(4096, dtype=np.uint32)
-lib.sim_state_verify(vp(cols), vp(flags), ctypes.c_uint64(4096), vp(mpt), ctypes.c_uint64(mpt.shape[0]), vp(full))
+full = np.zeros(N_STATE, dtype=np.uint32)
+lib.sim_state_verify(vp(cols), vp(flags), ctypes.c_uint64(N_STATE), vp(mpt), ctypes.c_uint64(mpt.shape[0]), vp(full))
 ff = np.nonzero(full)[0]
 assert res == (len(ff), int(ff[0]), int(full[ff[0]])), (rank, res, len(ff), ff[:4])
 assert np.array_equal(local, full[off:off + len(local)])
@@ -49,11 +58,20 @@ w = synth_evm_trace(1501, seed=12)
 w.pop("meta")
 w["steps"][750, 7, 0] += 1     # program counter of the boundary step
 w["rw"][40, 8, 0] ^= 1
-lw, b, e, off = distributed.shard_evm(w, rank, world)
+if odd:
+    n_pairs = w["steps"].shape[0] - 1
+    for r in range(1, world):
+        b_ = distributed.shard_bounds(n_pairs, r, world)[0]
+        w["steps"][b_, 8, 0] += 1   # stack pointer of the step both neighbouring shards read (last pair of r - 1, first pair of r)
+lw, b, e, off = distributed.shard_evm(w, rank, world, begin_with_first_step=odd, end_with_last_step=odd)
+assert (b, e) == (odd and rank == 0, odd and rank == world - 1)
 local = np.array(hostsim_status(lib, lw, (b, e)), dtype=np.uint32)
 fails = np.nonzero(local)[0]
 res = distributed.reduce_tally(len(fails), int(fails[0]) if len(fails) else None, int(local[fails[0]]) if len(fails) else 0, off)
-full = np.array(hostsim_status(lib, w), dtype=np.uint32)
+full = np.array(hostsim_status(lib, w, (odd, odd)), dtype=np.uint32)
+if odd:  # the trace neither begins with BeginTx nor ends in EndBlock: exactly the first and the last pair notice the flags
+    plain = hostsim_status(lib, w)
+    assert full[0] != plain[0] and full[-1] != plain[-1] and full[1:-1].tolist() == plain[1:-1]
 ff = np.nonzero(full)[0]
 assert len(ff) >= 2
 assert res == (len(ff), int(ff[0]), int(full[ff[0]])), (rank, res)
@@ -98,6 +116,10 @@ assert lib.sim_copy_assign(vp(ev), vp(fl), ctypes.c_uint64(ev.shape[0]), vp(da),
 half = n_rows // 2
 rows[9, half - 1, 0] ^= 1   # a cell of the last row of rank 0's range
 rows[9, half + 1, 0] ^= 1   # ... and of a halo row of rank 0 = row 1 of rank 1's range
+if odd:
+    for r in range(1, world):
+        b_ = distributed.shard_bounds(n_rows, r, world)[0]
+        rows[9, b_ + 1, 0] ^= 2   # second halo row of rank r - 1
 def copy_status(c, f):
     st = np.zeros(c.shape[1], dtype=np.uint32)
     bc, txr, txf = (np.ascontiguousarray(ce[k]) for k in ("bytecode", "tx", "tx_flags"))
@@ -119,15 +141,28 @@ print("rank", rank, "ok")
 '''
 
 
-def test_two_rank_sharding_and_tally_allreduce(hostsim, tmp_path):
+def _run_world(tmp_path, world, port, odd):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, ZK_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    env = dict(os.environ, ZK_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), ZK_ODD="1" if odd else "0",
+               OMP_NUM_THREADS="1")
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{o}"
         assert f"rank {rank} ok" in o
+
+
+def test_two_rank_sharding_and_tally_allreduce(hostsim, tmp_path):
+    _run_world(tmp_path, 2, 29613, odd=False)
+
+
+def test_eight_rank_uneven_shards_and_driver_flags(hostsim, tmp_path):
+    """The shape the driver's 8-GPU run has: world size 8, row counts not divisible by 8 (State 4,099 rows, 1,500
+    step pairs, 101 Tx units, the Copy rows of 600 events), tampered cells on both sides of every shard boundary, and
+    begin_with_first_step / end_with_last_step applied by rank 0 / rank 7 only — the reduced tally (SUM of the counts, MIN of the
+    first failing global row) equals the single-process one for all four workloads."""
+    _run_world(tmp_path, 8, 29641, odd=True)

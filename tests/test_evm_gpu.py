@@ -179,3 +179,79 @@ def test_full_size_all_pairs_vs_oracle(hostsim):
     res1 = engine.evm_verify(wd, status_dev=st_dev)
     assert st_dev.cpu().numpy().view(np.uint32).tolist() == exp
     assert (res1.fail_count, res1.first_fail_row, res1.first_fail_code) == (res.fail_count, res.first_fail_row, res.first_fail_code)
+
+
+def test_warm_gadget_trace_all_pairs_vs_oracle():
+    """VERDICT r3 #2c: a 2^14-step trace in which the copy- / keccak- / exp-table gadgets dominate as far as straight-line programs
+    allow (≈ 3,000 SHA3 / CODECOPY / EXP steps, execution/sha3.py:20-34, codecopy.py:26, exp.py:31-33, each fed by its PUSHes and
+    MSTOREs) through the warm instantiation's staged launch over the sorted mapping: every pair's status vs oracle/evm_oracle.py,
+    valid and with tampered cells in the steps, the RW rows and the copy / keccak / exp tables those gadgets look up."""
+    import torch
+
+    from oracle import copy_assign_oracle, wire
+    from zkevm_specs_amd import evm_tables as T
+    from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
+    from zkevm_specs_amd.wire import rows_to_rowmajor
+
+    p = synth_super_block(17, seed=9, block_ops=400, n_steps=1 << 14)
+    states = [int(x) for x in p["evm"]["steps"][:, 0, 0]]
+    n_warm = sum(states.count(int(s)) for s in (T.ExecutionState.SHA3, T.ExecutionState.CODECOPY, T.ExecutionState.EXP))
+    assert n_warm >= 2500
+    ce = p["copy_events"]
+    table = copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"], ce["offsets"], ce["r"])[2]
+    w = dict(p["evm"], copy=rows_to_rowmajor(table, 14))
+    # the copy table the device assigns from the same events is the oracle's (so the EVM session below sees what SuperCircuit hands it)
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    with SuperCircuit(p, to_device=dev) as sc:
+        sc.launch()
+        results, total, first = sc.collect()
+        assert total == 0, {k: (r.fail_count, r.first_fail_row, r.first_fail_code) for k, r in results.items()}
+    for sort in (True, False):
+        res, status = _run(w, state_sort=sort)
+        assert res.ok and not any(status)
+    rng = random.Random(31)
+    warm_steps = [i for i, s in enumerate(states[:-1]) if s in (int(T.ExecutionState.SHA3), int(T.ExecutionState.CODECOPY), int(T.ExecutionState.EXP))]
+
+    def flip(arr, idx, bit=0):
+        arr[idx] ^= np.uint64(1 << bit)
+
+    for i in rng.sample(warm_steps, 60):  # cells of the warm steps themselves and of their successors
+        flip(w["steps"], (i + rng.randrange(2), rng.choice([1, 7, 8, 9, 10, 11]), 0))
+    for t, n_cells in (("copy", 14), ("keccak", 5), ("exp", 11)):
+        for _ in range(40):
+            flip(w[t], (rng.randrange(w[t].shape[0]), rng.randrange(n_cells), 0), rng.randrange(8))
+    rwc = w["steps"][:, 1, 0].astype(np.int64)
+    base = int(w["rw"][0, 0, 0])
+    for i in rng.sample(warm_steps, 60):  # RW rows the warm steps look up (stack operands, memory / call-context rows)
+        j = int(rwc[i]) - base + rng.randrange(4)
+        if 0 <= j < w["rw"].shape[0]:
+            flip(w["rw"], (j, rng.choice([1, 3, 4, 8, 9]), 0))
+    exp = oracle_status(w)
+    assert sum(1 for e in exp if e) >= 150
+    for sort in (True, False):
+        res, status = _run(w, state_sort=sort)
+        assert status == exp, sort
+        _check_tally(res, exp)
+
+
+def test_caller_status_buffer_is_final_after_a_stream_sync():
+    """a pair the fast kernel defers (here: wide word cells, >= 2^128) must have its verdict in a caller-provided
+    status_dev once the stream has drained — no zk_collect in between (include/zkevm_hip.h, zk_launch)."""
+    import torch
+
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "evm_wide_cells.npz")
+    cases = [c for c in load_cases(fn) if "#fuzz" in c[0]]
+    n = 0
+    for name, w, opts, _ in cases[::9]:
+        exp = oracle_status(w, opts)
+        if not any(exp):
+            continue
+        with engine.open_evm({k: v for k, v in w.items()}, bool(opts[0]), bool(opts[1])) as s:
+            buf = torch.full((len(exp),), 0x7fffffff, dtype=torch.int32, device="cuda")
+            s.launch(status_dev=buf)
+            torch.cuda.synchronize()  # the caller's own synchronisation; zk_collect has not run
+            assert buf.cpu().numpy().view(np.uint32).tolist() == exp, name
+            res = s.collect()
+            _check_tally(res, exp)
+        n += 1
+    assert n >= 20

@@ -174,3 +174,88 @@ def test_block_super_circuit_on_device():
     assert not res["evm"].ok and res["exp"].ok and res["state"].ok and res["copy"].ok
     p["evm"]["exp"][0, 9, 0] ^= np.uint64(1)
     assert all(r.ok for r in run(p).values())
+
+
+@pytest.mark.gpu
+def test_full_size_block_every_row_of_every_circuit_vs_oracles():
+    """VERDICT r3 #2b: BASELINE config 5 at its full size (the 2^18-step trace inside a ~1.17 M-row block), per-row / per-pair
+    statuses of ALL SIX circuits read back from the device and compared with their oracles — the valid block (every status 0,
+    tally 0) and the block with 600 tampered cells of SHARED data (RW rows: EVM + State + Copy; bytecode table: EVM + Bytecode +
+    Copy; copy events' bytes: Copy + EVM's copy table; step cells, exp rows / table, keccak rows, Tx cells)."""
+    import random
+
+    import torch
+
+    from oracle import copy_assign_oracle, copy_oracle
+    from zkevm_specs_amd import evm_tables as ET
+    from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, SuperCircuit, synth_super_block
+    from zkevm_specs_amd.synth_block import rw_to_state_ops
+    from zkevm_specs_amd.wire import rows_to_rowmajor
+
+    p = synth_super_block(20, seed=5)
+    assert sum(p["rows"].values()) > 1_100_000 and p["rows"]["evm"] == (1 << 18) - 1
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    with SuperCircuit(p, to_device=dev) as sc:
+        assert set(sc.rows) == set(BLOCK_CIRCUITS)
+        sc.launch()
+        results, total, first = sc.collect()
+        assert total == 0 and first is None
+        for k, s in sc.sessions.items():
+            assert not s.read_status().any(), k
+    # ---- tamper shared data ------------------------------------------------------------------------------------------
+    rng = random.Random(2024)
+    evm = p["evm"]
+    rw, bt = evm["rw"], evm["bytecode"]
+    tag = rw[:, 2, 0].astype(np.int64)
+    plain = np.nonzero((tag == int(ET.Target.Stack)) | (tag == int(ET.Target.Memory)))[0]
+    for j in rng.sample(plain.tolist(), 260):          # a Stack / Memory row's value: the step that looks it up, the State circuit, the Copy circuit
+        rw[j, 8, 0] ^= np.uint64(1 << rng.randrange(8))
+    ub = p["bytecode_unrolled"][0]
+    assert np.array_equal(ub, bt)
+    for j in rng.sample(range(bt.shape[0]), 120):      # a byte of a contract: opcode / push-data lookups, the Bytecode circuit, CODECOPY's source
+        if int(bt[j, 2, 0]) == 2:
+            bt[j, 5, 0] ^= np.uint64(1 << rng.randrange(8))
+            ub[j, 5, 0] = bt[j, 5, 0]
+    for _ in range(120):                               # step cells: the EVM circuit alone
+        evm["steps"][rng.randrange(evm["steps"].shape[0]), rng.choice([1, 7, 8, 9, 10, 11]), 0] ^= np.uint64(1)
+    ce = p["copy_events"]
+    for j in rng.sample(range(ce["data"].shape[0]), 40):  # a copied byte: the Copy circuit's rows AND the copy table the SHA3 / CODECOPY steps look up
+        ce["data"][j] ^= np.uint16(1)
+    for _ in range(20):
+        evm["exp"][rng.randrange(evm["exp"].shape[0]), rng.randrange(11), 0] ^= np.uint64(1)
+        p["exp_rows"][rng.randrange(21), rng.randrange(p["exp_rows"].shape[1]), 0] ^= np.uint64(1)
+    for _ in range(10):
+        evm["keccak"][rng.randrange(evm["keccak"].shape[0]), rng.randrange(5), 0] ^= np.uint64(1)
+    tx, r_tx = p["tx"]
+    for _ in range(30):
+        tx["cells"][rng.randrange(tx["cells"].shape[0]), rng.randrange(tx["cells"].shape[1]), 0] ^= np.uint64(1)
+    p["state_ops"] = rw_to_state_ops(rw, evm["rw_flags"])
+    with SuperCircuit(p) as sc:
+        sc.launch()
+        results, total, first = sc.collect()
+        got = {k: s.read_status().tolist() for k, s in sc.sessions.items()}
+    # ---- the oracles over the same block -----------------------------------------------------------------------------
+    c_rows, c_rf, c_table, c_rw, c_rwf = copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"], ce["offsets"], ce["r"])
+    exp = {"evm": oracle_status(dict(evm, copy=rows_to_rowmajor(c_table, 14)))}
+    ops, flags = p["state_ops"]
+    rows, rflags, mpt, a_status = assign_oracle.assign(wire.colmajor_to_rows(ops), flags.tolist())
+    assert not any(a_status)
+    exp["state"] = state_oracle.verify_rows(rows, rflags, mpt)
+    ub_rows, ub_off, ub_len, k = p["bytecode_unrolled"]
+    _, keccak, r = p["bytecode"]
+    exp["bytecode"] = row_oracles.bytecode_verify_rows(bytecode_assign_oracle.assign(k, wire.rowmajor_to_rows(ub_rows), ub_off, ub_len, r),
+                                                       wire.rowmajor_to_rows(keccak), r)
+    T_ = copy_oracle.CopyTables(wire.rowmajor_to_rows(rw), evm["rw_flags"], wire.rowmajor_to_rows(bt), wire.rowmajor_to_rows(evm["tx"]), evm["tx_flags"])
+    exp["copy"] = copy_oracle.verify_rows(c_rows, c_rf, T_, ce["r"])
+    exp["tx"] = sign_oracle.verify_units(tx["bytes"], tx["cells"], tx["meta"], wire.rowmajor_to_rows(tx["keccak"]), r_tx, 0,
+                                         wire.rowmajor_to_rows(tx["tx_rows"]), tx["tx_flags"])
+    exp["exp"] = row_oracles.exp_verify_rows(wire.colmajor_to_rows(p["exp_rows"]))
+    n_fail = {}
+    for k in BLOCK_CIRCUITS:
+        assert len(got[k]) == len(exp[k]), k
+        bad = [i for i, (a, b) in enumerate(zip(got[k], exp[k])) if a != b]
+        assert not bad, (k, len(bad), bad[:5], [(got[k][i], exp[k][i]) for i in bad[:5]])
+        n_fail[k] = sum(1 for e in exp[k] if e)
+        assert results[k].fail_count == n_fail[k], k
+    assert all(n_fail[k] >= 5 for k in BLOCK_CIRCUITS), n_fail
+    assert total == sum(n_fail.values())

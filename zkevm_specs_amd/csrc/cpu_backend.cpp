@@ -154,6 +154,18 @@ extern "C" int zk_close(zk_session* s) {
     return 0;
 }
 extern "C" int zk_session_set_stream(zk_session*, void*) { return 0; }
+// device-side event spans: nothing to measure on the host (callers read -1 = not measured)
+extern "C" int zk_session_timing(zk_session*, double* open_ms, double* span_ms) {
+    if (open_ms) *open_ms = -1.0;
+    if (span_ms) *span_ms = -1.0;
+    return 0;
+}
+extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {
+    if (open_ms) *open_ms = -1.0;
+    if (pass_ms) *pass_ms = -1.0;
+    if (span_ms) *span_ms = -1.0;
+    return 0;
+}
 extern "C" int zk_set_range(zk_session* s, uint64_t row_lo, uint64_t row_hi) {
     ARG_TRY(s && s->range_ok, "zk_set_range: not a row-circuit session");
     ARG_TRY(row_lo < row_hi && row_hi <= s->n, "zk_set_range: bad range");

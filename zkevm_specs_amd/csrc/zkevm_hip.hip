@@ -28,6 +28,7 @@ static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per devi
 static thread_local int t_device = -1;              // device selected by this thread's last zk_init
 static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
 static thread_local std::string g_err;
+static thread_local double t_timing[3] = {0, 0, 0};  // zk_last_timing: open span, pass span, first open dispatch -> last pass dispatch (ms)
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -495,6 +496,7 @@ struct zk_session {
     u32* last_status = nullptr;     // EVM: where the last pass wrote its statuses
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
+    hipEvent_t ev_open0 = nullptr, ev_open1 = nullptr;  // EVM: ride on the first / last dispatch of zk_evm_open (zk_session_timing)
 };
 
 static const int MAX_EVENT_PAIRS = 256;
@@ -660,6 +662,8 @@ extern "C" int zk_close(zk_session* s) {
         DevArena& A = g_arena[s->device];
         std::lock_guard<std::mutex> lock(A.m);
         for (hipEvent_t e : s->ev) A.events.push_back(e);
+        if (s->ev_open0) A.events.push_back(s->ev_open0);
+        if (s->ev_open1) A.events.push_back(s->ev_open1);
     }
     delete s;
     return 0;
@@ -822,8 +826,11 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         {
             const u64 n16 = n_ff / 4 + zero_bytes / 16;
             const u32 fill_grid = (u32)(n16 / 256 < 2048 ? (n16 + 255) / 256 : 2048);
-            hipLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, (uint4*)ff, (u64)(n_ff / 4),
-                               (uint4*)zero, (u64)(zero_bytes / 16));
+            // the open's device span is measured by two events that ride on its first and last dispatch (no event packets of their
+            // own between the kernels): zk_session_timing / zk_last_timing
+            if (arena_event(s->device, &s->ev_open0) || arena_event(s->device, &s->ev_open1)) s->ev_open0 = s->ev_open1 = nullptr;
+            hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, s->ev_open0, nullptr, 0, (uint4*)ff,
+                                  (u64)(n_ff / 4), (uint4*)zero, (u64)(zero_bytes / 16));
         }
         E.rw_dense = 0;
         E.rw_base = 0;
@@ -907,13 +914,14 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             rec_blocks = (u32)((t->n_steps + 63) / 64);  // four lanes per step
         }
         const u32 grid1 = o.rec_block0 + rec_blocks;
-        hipLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, o);
         {
             const u32 dir_blocks = want_dir ? DIRB_MAX_ENTRIES / EVM_OPEN_P2_BLOCK : 0u;
             const u32 rw_blocks = t->n_rw ? EVM_OPEN_RW_GENERIC_BLOCKS : 0u;
-            if (scatter_blocks + dir_blocks + rw_blocks)
-                hipLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, o,
-                                   scatter_blocks, dir_blocks, generic ? 1u : 0u);
+            const bool phase2 = scatter_blocks + dir_blocks + rw_blocks != 0;
+            hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
+            if (phase2)
+                hipExtLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, nullptr,
+                                      s->ev_open1, 0, o, scatter_blocks, dir_blocks, generic ? 1u : 0u);
         }
         if (hipGetLastError() != hipSuccess) { rc = -2; g_err = "zk_evm_open: a build kernel failed to launch"; goto fail; }
     }
@@ -931,6 +939,7 @@ fail:
     return rc;
 }
 
+static void session_timing(zk_session* s, double pass_ms, double* open_ms, double* span_ms);
 extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_evm_verify: result is null");
     zk_session* s = nullptr;
@@ -939,6 +948,10 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
     if (!rc) rc = zk_collect(s, result);
+    if (!rc) {
+        t_timing[1] = result->kernel_ms;
+        session_timing(s, result->kernel_ms, &t_timing[0], &t_timing[2]);
+    }
     if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
     zk_close(s);
     return rc;
@@ -1928,6 +1941,30 @@ extern "C" int zk_read_status(zk_session* s, uint32_t* status_host) {
     { int drc = evm_finish_deferred(s); if (drc) return drc; }
     HIP_TRY(hipMemcpyAsync(status_host, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+// Device-side spans of an EVM session, by HIP events riding on the dispatches: `open_ms` = first to last kernel of zk_evm_open,
+// `pass_ms` = the mean evaluation-kernel span of the passes of the last zk_collect, `span_ms` = first open kernel to the end of the
+// FIRST pass's last evaluation kernel (what a witness seen once costs on the device).  Valid after a zk_collect; -1 = not measured.
+static void session_timing(zk_session* s, double pass_ms, double* open_ms, double* span_ms) {
+    *open_ms = *span_ms = -1.0;
+    if (s->kind != SESSION_EVM || !s->ev_open0 || !s->ev_open1) return;
+    float f = 0;
+    if (hipEventElapsedTime(&f, s->ev_open0, s->ev_open1) == hipSuccess) *open_ms = f;
+    if (pass_ms > 0 && s->ev.size() >= 2 && hipEventElapsedTime(&f, s->ev_open0, s->ev[1]) == hipSuccess) *span_ms = f;
+    (void)hipGetLastError();
+}
+extern "C" int zk_session_timing(zk_session* s, double* open_ms, double* span_ms) {
+    ARG_TRY(s && open_ms && span_ms, "zk_session_timing: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    session_timing(s, 1.0, open_ms, span_ms);
+    return 0;
+}
+extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {
+    if (open_ms) *open_ms = t_timing[0];
+    if (pass_ms) *pass_ms = t_timing[1];
+    if (span_ms) *span_ms = t_timing[2];
     return 0;
 }
 

@@ -69,6 +69,12 @@ class Session:
         """Row-circuit sessions: evaluate rows [row_lo, row_hi) only (the rest is a read-only halo)."""
         check(self._lib.zk_set_range(self._h, int(row_lo), int(row_hi)), "zk_set_range", self._lib)
 
+    def timing(self):
+        """EVM sessions, after a collect: (open_ms, span_ms) — device spans of the open's kernels and of open + first pass"""
+        a, b = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.zk_session_timing(self._h, ctypes.byref(a), ctypes.byref(b)), "zk_session_timing", self._lib)
+        return a.value, b.value
+
     def read_status(self):
         out = np.empty(self.n, dtype=np.uint32)
         check(self._lib.zk_read_status(self._h, _lib.ptr(out)), "zk_read_status", self._lib)
@@ -228,6 +234,38 @@ def evm_verify(wire, begin_with_first_step=False, end_with_last_step=False, stat
     r = ZkResult()
     check(lib.zk_evm_verify(ctypes.byref(t), opts, _lib.ptr(status_dev), ctypes.byref(r)), "zk_evm_verify")
     return Result(r)
+
+
+class EvmOneShot:
+    """A prepared call of the one-shot C entry `zk_evm_verify` over a resident wire dict: the argument block is marshalled
+    once, `__call__` is the C call alone (what a foreign caller of the ABI pays — bench.py's timed region)."""
+
+    def __init__(self, wire, begin_with_first_step=False, end_with_last_step=False, status_dev=None, device=None):
+        self._lib = _lib.init(device)
+        self._t, self._opts, self._keep, self.n_pairs = _evm_tables(wire, begin_with_first_step, end_with_last_step)
+        if status_dev is not None:
+            _expect(status_dev, "status_dev", 4, (self.n_pairs,))
+        self._status = status_dev
+        self._status_ptr = _lib.ptr(status_dev)
+        self._r = ZkResult()
+        self._tref, self._rref = ctypes.byref(self._t), ctypes.byref(self._r)
+
+    def __call__(self):
+        rc = self._lib.zk_evm_verify(self._tref, self._opts, self._status_ptr, self._rref)
+        if rc:
+            check(rc, "zk_evm_verify", self._lib)
+        return self._r
+
+    def result(self):
+        return Result(self._r)
+
+
+def last_timing(lib=None):
+    """(open_ms, pass_ms, span_ms) of the calling thread's last one-shot zk_evm_verify (device spans by HIP events; -1 = not measured)"""
+    lib = lib if lib is not None else _lib.load()
+    a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.zk_last_timing(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    return a.value, b.value, c.value
 
 
 def open_bytecode(rows, keccak, randomness, device=None):

@@ -78,7 +78,7 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows)}
 
 
-def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
+def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None, n_steps=None):
     """BASELINE config 5 over ONE consistent witness (synth_block.py): the State circuit's rows ARE the EVM trace's RW table
     (re-keyed with the explicit Target -> Tag / key-slot mapping of synth_block.rw_to_state_ops and re-sorted), the Bytecode
     circuit's rows are the contracts the trace executes (their code hashes the keccak digests of the device-built keccak
@@ -94,7 +94,9 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
     seg_len = 640 if log_total >= 16 else 96
     from .synth_block import synth_block_sha3_inputs
 
-    bw = 1 if log_total >= 18 else (4 if log_total >= 16 else 12)  # weight of the SHA3 / CODECOPY / EXP kinds (synth_block._BLOCK_MIX)
+    # weight of the SHA3 / CODECOPY / EXP kinds (synth_block._BLOCK_MIX); `block_ops` / `n_steps` override the block's shape (tests of the
+    # warm gadgets use a trace where those kinds dominate)
+    bw = block_ops if block_ops is not None else (1 if log_total >= 18 else (4 if log_total >= 16 else 12))
     codes = synth_block_codes(seed, seg_len=seg_len, n_contracts=n_contracts, block_ops=bw)
     if keccak_rows_of is None:
         keccak_rows_of = lambda c, rr: engine.keccak_table(c, rr, engine.KECCAK_MODE_CIRCUIT)  # noqa: E731
@@ -111,7 +113,8 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None):
     n_tx = 1 << max(log_total - 8, 2)
     # EVM share: BASELINE configs[4] has the 2^18-step trace inside a ~2^20-row block; smaller blocks scale it (a step brings
     # ~2.9 State rows and, through its SHA3 / CODECOPY / EXP steps, ~0.2 Copy / Exp rows)
-    n_steps = (1 << (log_total - 2)) if log_total >= 16 else int((total - (1 << k) - n_tx) / 4.3)
+    if n_steps is None:
+        n_steps = (1 << (log_total - 2)) if log_total >= 16 else int((total - (1 << k) - n_tx) / 4.3)
     evm = synth_block_trace(n_steps, seed=seed, seg_len=seg_len, n_contracts=n_contracts, code_hashes=hashes, block_ops=bw,
                             digest_of=lambda msgs: [sha3_digest[m] for m in msgs], randomness=r)
     meta = evm.pop("meta")
