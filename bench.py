@@ -42,6 +42,7 @@ below them: the driver's record keeps scalars of those two objects):
                   Tx + Sig 2^14, Super 2^20 — ms / pass, dominant kernel, physical and algorithmic fractions, CPU legs.
 """
 import argparse
+import ctypes
 import glob
 import json
 import os
@@ -237,6 +238,7 @@ def build_evm(ctx, log_rows, strong):
     # the witness resident N_COPIES times (device-side clones): the one-shot steps rotate over them
     copies = [wire_d] + [{k: v.clone() for k, v in wire_d.items()} for _ in range(ctx.args.witness_copies - 1)]
     w.shots = [engine.EvmOneShot(c, device=ctx.local_rank) for c in copies]
+    w.copies = copies
     w.witness_bytes = sum(int(v.numel()) * v.element_size() for v in wire_d.values())
     w.sess = None if ctx.args.no_session_leg and not ctx.args.session_pass else w.fresh()
     w.kernel_name, w.kernel_needle = "evm_steps_kernel", ("evm_steps_kernel", "-1")
@@ -439,7 +441,30 @@ def timed_oneshots(ctx, w, steps, warmup):
     dt = time.perf_counter() - t0
     res = shots[(warmup + steps - 1) % len(shots)].result()
     res.fail_count = fails
+    hp = (ctypes.c_double * 4)()
+    lib.zk_last_host_phases(hp)
+    w.host_phases_us = {"open": hp[0], "launch": hp[1], "collect": hp[2], "close": hp[3]}  # of the last timed step
     return dt, res, [x / steps for x in spans]
+
+
+def timed_batch(ctx, w, steps, warmup):
+    """the same K fresh-witness verifications through ONE call of the batch entry (zk_evm_verify_batch: two witnesses in flight on
+    two streams); wall clock of the call, bracketed like the headline"""
+    from zkevm_specs_amd import engine
+
+    n_copies = len(w.shots)
+    mk = lambda n, first: engine.EvmBatch(w.copies, [(first + i) % n_copies for i in range(n)], device=ctx.local_rank)  # noqa: E731
+    mk(max(warmup, 2), 0)()
+    b = mk(steps, warmup)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    b()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    rs = b.results()
+    assert all(r.ok for r in rs), "synthetic witness must satisfy every constraint"
+    return {"ms_per_witness": dt / steps * 1e3, "rows_per_s": w.units * steps / dt, "witnesses": steps,
+            "mean_pass_kernel_ms": sum(r.kernel_ms for r in rs) / len(rs)}
 
 
 def resolve_super(w, res):
@@ -614,6 +639,8 @@ def oneshot_roofline(w, spans, log_rows):
         "kernel": "zk_evm_verify = evm_open_fill + evm_open_phase1 + evm_open_phase2 + evm_steps_kernel<hot> (+ warm / cold)",
         "kernel_ms": span_ms, "open_ms": open_ms, "pass_kernel_ms": pass_ms,
         "rocprof_sum_kernel_ms_per_step": rocprof_ms,
+        "host_us_in_open": w.host_phases_us["open"], "host_us_in_launch": w.host_phases_us["launch"],
+        "host_us_in_collect": w.host_phases_us["collect"], "host_us_in_close": w.host_phases_us["close"],
     }, profile, profile_src
 
 
@@ -650,6 +677,7 @@ def main():
     ap.add_argument("--session-pass", action="store_true", help="EVM: a step = one pass of an OPEN session (the round-1..3 headline; not the SURVEY 8(d) metric)")
     ap.add_argument("--witness-copies", type=int, default=3, help="EVM one-shot steps rotate over this many resident copies of the witness")
     ap.add_argument("--no-session-leg", action="store_true", help="EVM: skip the open-session side measurement")
+    ap.add_argument("--no-batch-leg", action="store_true", help="EVM: skip the batch-entry (two witnesses in flight) side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
@@ -677,8 +705,11 @@ def main():
     per_circuit = None
     spans = None
     session_side = None
+    batch_side = None
     if oneshot_mode:
         dt, res, spans = timed_oneshots(ctx, w, args.steps, args.warmup)
+        if not args.no_batch_leg:
+            batch_side = timed_batch(ctx, w, args.steps, args.warmup)
         if sess is not None:
             dt_s, res_s = timed_passes(ctx, sess, args.steps, args.warmup)
             session_side = (dt_s, res_s)
@@ -738,6 +769,16 @@ def main():
         if oneshot_mode:
             out["config"]["step"] = "one-shot zk_evm_verify (open + pass + collect + close) of a witness not touched for the previous steps"
             out["config"]["witness_copies"] = len(w.shots)
+            if batch_side is not None:
+                traffic = roofline.get("traffic")
+                batch_side["note"] = ("zk_evm_verify_batch: the same fresh-witness verifications, two in flight on two streams (the HBM-bound open of one under "
+                                      "the latency-bound evaluation of the other); every witness is opened, evaluated and collected once")
+                batch_side["algorithmic_GBps"] = w.algo_bytes / (batch_side["ms_per_witness"] / 1e3) / 1e9
+                batch_side["traffic_GBps"] = None if not traffic else traffic / (batch_side["ms_per_witness"] / 1e3) / 1e9
+                out["batch"] = batch_side
+                roofline["batch_ms_per_witness"] = batch_side["ms_per_witness"]
+                roofline["batch_rows_per_s"] = batch_side["rows_per_s"]
+                roofline["batch_traffic_frac"] = None if not traffic else batch_side["traffic_GBps"] / HBM_PEAK_GBPS
             if session_side is not None:
                 dt_s, res_s = session_side
                 blk, _, _ = roofline_block(w, res_s, world, strong, cold_ms)

@@ -157,6 +157,11 @@ typedef struct zk_evm_tables {
 int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
 int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
                   uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);
+/* Batch form: n independent witnesses (e.g. the blocks of a queue), each verified exactly as zk_evm_verify does — its own open
+ * (indices, key records, sort), one evaluation pass, its own tally in results[i] — software-pipelined two deep on two streams of
+ * the device: the HBM-bound open of witness i + 1 runs under the latency-bound evaluation of witness i.  The caller's current
+ * stream is synchronised first (uploads it enqueued are complete).  Per-pair statuses are not returned. */
+int zk_evm_verify_batch(const zk_evm_tables* const* tables, uint64_t n, uint32_t opts, zk_result* results);
 
 /* ---- Bytecode circuit: replaces the `for row: check_bytecode_row(row, next, push_table, keccak_table, r)`
  *      loop (src/zkevm_specs/bytecode_circuit.py:37-100; loop tests/test_bytecode_circuit.py:26-47, next row
@@ -311,6 +316,15 @@ int zk_pi_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_
 int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
                  uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts,
                  uint32_t* status_out, zk_result* result);
+/* PI circuit copy constraints (pi_circuit.py:355-445): constraint i asserts cells[i] == bytes_to_fq(entry_i[::-1]), entry_i =
+ * bytes[i][0 .. lens[i]) (an element of `witness.copy_constrains` as popped, big-endian, left-aligned in its 32-byte slot;
+ * lens[i] > 31 fails bytes_to_fq's own assert, util/arithmetic.py:227-229); lens[i] == 0xFFFFFFFF: bytes[i] is a canonical cell
+ * (little-endian) compared as is (the word equality of pi_circuit.py:358).  The host side lists the constraints in the
+ * reference's statement order; the tally's first failing index is the reference's first failing assert.  Status per
+ * constraint: 0, or (ZK_KIND_ASSERTION_ERROR << 24) | site (1 = length assert, 2 = equality). */
+int zk_pi_copy_open(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts, zk_session** out);
+int zk_pi_copy_verify(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts,
+                      uint32_t* status_out, zk_result* result);
 
 /* ---- Copy-circuit witness assignment: replaces `CopyCircuit.copy(r, rw_dict, src_id, src_tag, dst_id,
  *      dst_tag, src_addr, src_addr_end, dst_addr, copy_length, src_data, log_id)` (src/zkevm_specs/evm_circuit/typing.py:
@@ -364,6 +378,9 @@ int zk_read_status(zk_session* s, uint32_t* status_host);
  * zk_last_timing: the same for the calling thread's last one-shot zk_evm_verify, plus its pass span (== zk_result.kernel_ms). */
 int zk_session_timing(zk_session* s, double* open_ms, double* span_ms);
 int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms);
+/* Host microseconds the calling thread's last one-shot zk_evm_verify spent inside its open / launch / collect / close calls
+ * (tuning aid: where the wall time beyond the device span goes). */
+int zk_last_host_phases(double* us4);
 /* Re-bind a session to another stream of its device (NULL = the engine's own); waits for its enqueued passes first. */
 int zk_session_set_stream(zk_session* s, void* hip_stream);
 int zk_close(zk_session* s);

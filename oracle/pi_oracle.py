@@ -95,3 +95,26 @@ def verify_rows(rows, gas_rows, keccak_rows, circuit_len, keccak_rand=255, byte_
     gas = set(tuple(g) for g in gas_rows)
     kt = set(tuple(k) for k in keccak_rows)
     return [check_row(rows, i, gas, kt, circuit_len % P, keccak_rand, byte_pow_base) for i in range(len(rows))]
+
+
+def copy_constraints_status(cells, data, lens):
+    """Per-constraint status of the PI circuit's copy constraints (pi_circuit.py:355-445), in the wire form the mirror lists them
+    (zkevm_specs_amd/pi_circuit.py): `assert cell == bytes_to_fq(entry[::-1])`, where bytes_to_fq asserts len(entry) <= 31 first
+    (util/arithmetic.py:227-229); lens == 0xFFFFFFFF: the 32 bytes are a canonical cell compared as is (the word equality, :358).
+    cells: list of ints, data: uint8[n][32], lens: ints.  Site 1 = the length assert, 2 = the equality."""
+    from .codes import ASSERT, code
+
+    out = []
+    for c, d, ln in zip(cells, data, lens):
+        ln = int(ln)
+        raw = bytes(bytearray(int(x) for x in d))
+        if ln == 0xFFFFFFFF:
+            out.append(0 if int(c) == int.from_bytes(raw, "little") else code(ASSERT, 2))
+            continue
+        if ln > 31:
+            out.append(code(ASSERT, 1))
+            continue
+        entry = raw[:ln]
+        out.append(0 if int(c) == int.from_bytes(entry[::-1], "little") % P else code(ASSERT, 2))
+    return out
+

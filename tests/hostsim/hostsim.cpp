@@ -478,3 +478,11 @@ extern "C" void sim_wide_witness(u32 op, const u64* x, u64* out, u32* flags, u64
         flags[6 * i + 5] = R.b1;
     }
 }
+
+// PI circuit copy constraints (csrc/pi_circuit.hpp pi_copy_check)
+extern "C" int sim_pi_copy_verify(const u64* cells, const uint8_t* bytes, const u32* lens, u64 n, u32* status) {
+    PiCopyArgs a;
+    a.cells = cells; a.bytes = bytes; a.lens = lens; a.n = n;
+    for (u64 i = 0; i < n; i++) status[i] = pi_copy_check(a, i);
+    return 0;
+}

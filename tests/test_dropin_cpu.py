@@ -77,6 +77,12 @@ def oracle_backend(monkeypatch):
                                    keccak_rand, byte_pow_base)
         return _result(st), np.array(st, dtype=np.uint32)
 
+    def pi_copy_verify(cells, data, lens, device=None):
+        from oracle import pi_oracle
+
+        st = pi_oracle.copy_constraints_status(wire.cells_to_ints(np.asarray(cells)), np.asarray(data), [int(x) for x in lens])
+        return _result(st), np.array(st, dtype=np.uint32)
+
     def copy_assign(events, flags, data, offsets, randomness, device=None):
         from oracle import copy_assign_oracle as CA
 
@@ -99,7 +105,7 @@ def test_every_oneshot_entry_has_a_stand_in(oracle_backend):
 
     real = [n for n, f in vars(oneshot).items() if inspect.isfunction(f) and f.__module__ == __name__]
     assert sorted(real) == sorted(["state_verify", "evm_verify", "bytecode_verify", "exp_verify", "copy_verify", "sign_verify",
-                                   "keccak_table", "state_assign", "bytecode_assign", "ecdsa_verify", "pi_verify", "copy_assign"])
+                                   "keccak_table", "state_assign", "bytecode_assign", "ecdsa_verify", "pi_verify", "copy_assign", "pi_copy_verify"])
 
 
 def test_mirror_verify_steps_host_logic(oracle_backend):

@@ -71,3 +71,82 @@ def test_gpu_goldens(golden_dir):
         if idx % 4 == 0:
             res1, st1 = oneshot.pi_verify(cols, keccak, gas, circuit_len)
             assert st1.tolist() == exp and res1.fail_count == len(fails)
+
+
+def _constraint_cases():
+    """the copy constraints (pi_circuit.py:355-445) of the reference's own PI test witness (tests/golden/pi_driver.npz), as the mirror
+    lists them, valid and under the reference's seven tampering tests; then cell / byte / length fuzz of the valid list"""
+    import copy
+    import random
+
+    from tests import dropin_cases as D
+    from zkevm_specs_amd import objects
+    from zkevm_specs_amd.pi_circuit import list_copy_constraints
+
+    w0, shape, names, kinds = D.pi_witness_from_driver_fixture()
+    word123 = objects.WordOrValue(123, 0, True)
+    tampers = {"valid": lambda w: None,
+               "bad_block_table": lambda w: w.block_table.table.__setitem__(5, word123),
+               "bad_tx_table_tx_id": lambda w: setattr(w.tx_table.table[5], "tx_id", objects.FQ(123)),
+               "bad_tx_table_index": lambda w: setattr(w.tx_table.table[5], "index", objects.FQ(123)),
+               "bad_tx_table_value": lambda w: setattr(w.tx_table.table[5], "value", word123),
+               "bad_keccak_digest": lambda w: setattr(w.public_inputs, "pi_keccak", objects.Word(123, 0)),
+               "bad_state_root": lambda w: setattr(w.public_inputs, "state_root", objects.Word(123, 0)),
+               "bad_state_root_prev": lambda w: setattr(w.public_inputs, "state_root_prev", objects.Word(123, 0))}
+    base = None
+    for name, kind in zip(names, kinds):
+        w = copy.deepcopy(w0)
+        tampers[name](w)
+        C, pending = list_copy_constraints(w, *shape)
+        cells, data, lens = C.wire()
+        if name == "valid":
+            base = (cells, data, lens)
+        yield name, cells, data, lens, (kind, pending)
+    rng = random.Random(6)
+    for k in range(40):
+        cells, data, lens = (a.copy() for a in base)
+        for _ in range(rng.choice([1, 2, 5])):
+            i = rng.randrange(len(lens))
+            what = rng.choice(["cell", "byte", "len", "len32"])
+            if what == "cell":
+                cells[i, rng.randrange(4)] ^= np.uint64(1 << rng.randrange(64))
+            elif what == "byte":
+                data[i, rng.randrange(32)] ^= np.uint8(1 << rng.randrange(8))
+            elif what == "len" and int(lens[i]) != 0xFFFFFFFF:
+                lens[i] = rng.randrange(0, 32)
+            elif int(lens[i]) != 0xFFFFFFFF:
+                lens[i] = 32
+        yield f"fuzz{k}", cells, data, lens, None
+
+
+def test_copy_constraints_oracle_and_kernel_logic(hostsim):
+    n = n_fail = 0
+    for name, cells, data, lens, ref in _constraint_cases():
+        exp = PO.copy_constraints_status(wire.cells_to_ints(cells), data, lens.tolist())
+        st = np.zeros(len(exp), dtype=np.uint32)
+        hostsim.sim_pi_copy_verify(vp(cells), vp(data), vp(lens), ctypes.c_uint64(len(exp)), vp(st))
+        assert st.tolist() == exp, name
+        if ref is not None:  # the reference driver's recorded outcome of this tampering: an AssertionError iff a constraint fails
+            kind, pending = ref
+            # (a table entry turned into a word makes the reference pop one entry more: the list runs out at the end, after the
+            # failing assert — `pending` is the IndexError the mirror raises only if every listed constraint passed)
+            if name == "valid":
+                assert pending is None and not any(exp)
+            elif kind == codes.ASSERT and name.startswith("bad_"):
+                assert any(exp), name
+        n += len(exp)
+        n_fail += sum(1 for e in exp if e)
+    assert n > 10000 and n_fail > 40
+
+
+@pytest.mark.gpu
+def test_gpu_copy_constraints():
+    from zkevm_specs_amd import oneshot
+
+    for name, cells, data, lens, _ in _constraint_cases():
+        exp = PO.copy_constraints_status(wire.cells_to_ints(cells), data, lens.tolist())
+        res, st = oneshot.pi_copy_verify(cells, data, lens)
+        assert st.tolist() == exp, name
+        fails = [j for j, e in enumerate(exp) if e]
+        assert res.fail_count == len(fails) and (not fails or (res.first_fail_row == fails[0] and res.first_fail_code == exp[fails[0]]))
+

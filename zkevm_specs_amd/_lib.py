@@ -21,8 +21,8 @@ LIB_PATH = CPU_LIB_PATH if BACKEND == "cpu" else (os.environ.get("ZK_HIP_LIB") o
 
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
-    "zk_state_open", "zk_state_set_range", "zk_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
-    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing",
+    "zk_state_open", "zk_state_set_range", "zk_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_evm_verify_batch", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
+    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_ecdsa_open", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_pi_copy_open", "zk_pi_copy_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing", "zk_last_host_phases",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -156,6 +156,7 @@ def _bind(lib):
     lib.zk_state_verify.argtypes = [vp, vp, u64, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_evm_open.argtypes = [ctypes.POINTER(ZkEvmTables), u32, ctypes.POINTER(vp)]
     lib.zk_evm_verify.argtypes = [ctypes.POINTER(ZkEvmTables), u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_evm_verify_batch.argtypes = [ctypes.POINTER(ctypes.POINTER(ZkEvmTables)), u64, u32, ctypes.POINTER(ZkResult)]
     lib.zk_bytecode_open.argtypes = [vp, u64, vp, u64, vp, u32, ctypes.POINTER(vp)]
     lib.zk_bytecode_verify.argtypes = [vp, u64, vp, u64, vp, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_exp_open.argtypes = [vp, u64, u32, ctypes.POINTER(vp)]
@@ -177,6 +178,8 @@ def _bind(lib):
     lib.zk_bytecode_assign.argtypes = [vp, u64, vp, vp, u64, u32, vp, vp, u32, ctypes.POINTER(ZkResult)]
     lib.zk_pi_open.argtypes = [vp, u64, vp, u64, vp, u64, u64, vp, vp, u32, ctypes.POINTER(vp)]
     lib.zk_pi_verify.argtypes = [vp, u64, vp, u64, vp, u64, u64, vp, vp, u32, vp, ctypes.POINTER(ZkResult)]
+    lib.zk_pi_copy_open.argtypes = [vp, vp, vp, u64, u32, ctypes.POINTER(vp)]
+    lib.zk_pi_copy_verify.argtypes = [vp, vp, vp, u64, u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_copy_assign_sizes.argtypes = [ctypes.POINTER(ZkCopyEvents), u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.zk_copy_assign_open.argtypes = [ctypes.POINTER(ZkCopyEvents), vp, vp, vp, vp, vp, u32, ctypes.POINTER(vp)]
     lib.zk_copy_assign_read.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -188,6 +191,7 @@ def _bind(lib):
     dp = ctypes.POINTER(ctypes.c_double)
     lib.zk_session_timing.argtypes = [vp, dp, dp]
     lib.zk_last_timing.argtypes = [dp, dp, dp]
+    lib.zk_last_host_phases.argtypes = [dp]
     return lib
 
 

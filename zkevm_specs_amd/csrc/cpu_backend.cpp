@@ -98,6 +98,7 @@ struct zk_session {
     CopyArgs copy;
     SignArgs sign;
     PiArgs pi;
+    PiCopyArgs picopy;
     EcdsaArgs ecdsa;
     KeccakGenArgs kgen;
     ZkRwMeta rw_meta;
@@ -158,6 +159,10 @@ extern "C" int zk_session_set_stream(zk_session*, void*) { return 0; }
 extern "C" int zk_session_timing(zk_session*, double* open_ms, double* span_ms) {
     if (open_ms) *open_ms = -1.0;
     if (span_ms) *span_ms = -1.0;
+    return 0;
+}
+extern "C" int zk_last_host_phases(double* us4) {
+    if (us4) for (int k = 0; k < 4; k++) us4[k] = -1.0;
     return 0;
 }
 extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {
@@ -343,6 +348,15 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     return rc ? rc : one_shot(s, status_out, result);
 }
 
+extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, uint32_t opts, zk_result* results) {
+    ARG_TRY((t && results) || n == 0, "zk_evm_verify_batch: bad arguments");
+    for (uint64_t i = 0; i < n; i++) {  // nothing to pipeline on the host: one witness after the other
+        const int rc = zk_evm_verify(t[i], opts, nullptr, &results[i]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // ---- Bytecode / Exp circuits --------------------------------------------------------------------------------------------
 extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* randomness,
                                 uint32_t opts, zk_session** out) {
@@ -481,6 +495,29 @@ extern "C" int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* ke
     ARG_TRY(result, "zk_pi_verify: result is null");
     zk_session* s = nullptr;
     const int rc = zk_pi_open(rows, n, keccak, n_keccak, gas, n_gas, circuit_len, keccak_rand, byte_pow_base, opts, &s);
+    return rc ? rc : one_shot(s, status_out, result);
+}
+
+extern "C" int zk_pi_copy_open(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_pi_copy_open");
+    ARG_TRY(out && cells && bytes && lens && n > 0 && n < (1ull << 32), "zk_pi_copy_open: bad arguments");
+    zk_session* s = new_session(n, false);
+    s->a64[0].assign(cells, cells + n * 4);
+    s->a8.assign(bytes, bytes + n * 32);
+    s->a32[0].assign(lens, lens + n);
+    s->picopy.cells = s->a64[0].data();
+    s->picopy.bytes = s->a8.data();
+    s->picopy.lens = s->a32[0].data();
+    s->picopy.n = n;
+    s->row = [s](u64 i) { return pi_copy_check(s->picopy, i); };
+    *out = s;
+    return 0;
+}
+extern "C" int zk_pi_copy_verify(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts, uint32_t* status_out,
+                                 zk_result* result) {
+    ARG_TRY(result, "zk_pi_copy_verify: result is null");
+    zk_session* s = nullptr;
+    const int rc = zk_pi_copy_open(cells, bytes, lens, n, opts, &s);
     return rc ? rc : one_shot(s, status_out, result);
 }
 

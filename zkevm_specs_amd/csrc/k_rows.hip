@@ -74,7 +74,20 @@ __global__ __launch_bounds__(256) void pi_rows_kernel(PiArgs a, u64 lo, u64 hi, 
     }
     tally_commit(tally, i, code);
 }
+__global__ __launch_bounds__(256) void pi_copy_kernel(PiCopyArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 code = 0;
+    if (i < a.n) {
+        code = pi_copy_check(a, i);
+        if (status) status[i] = code;
+    }
+    tally_commit(tally, i, code);
+}
 static inline u32 grid256(u64 n) { return (u32)((n + 255) / 256); }
+void zk_launch_pi_copy(hipStream_t st, const PiCopyArgs& a, u32* status, ZkTally* tally) {
+    hipLaunchKernelGGL(pi_copy_kernel, dim3(grid256(a.n)), dim3(256), 0, st, a, status, tally);
+}
 void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     const u64 rows_per_block = 4 * BC_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
     hipLaunchKernelGGL(bytecode_rows_kernel, dim3((u32)((hi - lo + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, a, lo, hi, status, tally);

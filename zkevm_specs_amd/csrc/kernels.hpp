@@ -61,6 +61,7 @@ void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, Zk
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);
+void zk_launch_pi_copy(hipStream_t st, const PiCopyArgs& a, u32* status, ZkTally* tally);
 void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally);

@@ -138,3 +138,37 @@ ZK_HD u32 pi_check_row(const PiArgs& a, u64 i) {
     }
     return code;
 }
+
+// ---- PI circuit copy constraints (pi_circuit.py:355-445) ----------------------------------------------------------------------------
+// The reference walks `witness.copy_constrains` (byte strings cut out of the raw public inputs, big-endian) in a fixed order
+// and asserts, per entry, `cell == bytes_to_fq(entry[::-1])` against a cell of the block / tx / withdrawal table or of the
+// public inputs (bytes_to_fq asserts len <= MAX_N_BYTES = 31 first, util/arithmetic.py:227-229); the very first statement
+// compares two words cell by cell (`rows[0].rpi_digest_word == public_inputs.pi_keccak`, :358).  One lane per constraint; the
+// tally's first failing index is the reference's first failing statement.  Sites: 1 = bytes_to_fq's length assert, 2 = the
+// equality.  Wire: cells[n][4], bytes[n][32] (the entry as popped, left-aligned), lens[n] (PI_COPY_CELL: the 32 bytes are a
+// canonical cell, little-endian, compared as is).
+#define PI_COPY_CELL 0xFFFFFFFFu
+struct PiCopyArgs {
+    const u64* cells;
+    const uint8_t* bytes;
+    const u32* lens;
+    u64 n;
+};
+ZK_HD u32 pi_copy_check(const PiCopyArgs& a, u64 i) {
+    const Fr cell = fr_load(a.cells + i * 4);
+    const u32 len = a.lens[i];
+    const uint8_t* b = a.bytes + i * 32;
+    Fr v = fr_zero();
+    if (len == PI_COPY_CELL) {
+        for (int k = 0; k < 32; k++) v.v[k >> 2] |= (u32)b[k] << (8 * (k & 3));
+    } else {
+        if (len > 31u) return ZK_CODE(ZK_ASSERT, 1);
+        // int.from_bytes(entry[::-1], "little") == the entry read big-endian; at most 31 bytes: below the modulus, no reduction
+        for (u32 k = 0; k < len; k++) {
+            const u32 pos = len - 1u - k;  // byte k of the entry has weight 256^(len - 1 - k)
+            v.v[pos >> 2] |= (u32)b[k] << (8 * (pos & 3u));
+        }
+    }
+    return fr_eq(cell, v) ? 0u : ZK_CODE(ZK_ASSERT, 2);
+}
+

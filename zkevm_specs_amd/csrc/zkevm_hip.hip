@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -24,10 +25,12 @@
 #define ZK_ECDSA_CHUNK_LANES (1ull << 17)  // lanes per ECDSA launch (x 1,440 B of key tables = 189 MB); a multiple of 64
 static std::mutex g_dev_mutex;
 static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
+static hipStream_t g_batch_stream[ZK_MAX_DEVICES][2] = {{nullptr}};  // zk_evm_verify_batch: the two pipeline slots of a device
 static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per device: "row 0" of every empty table
 static thread_local int t_device = -1;              // device selected by this thread's last zk_init
 static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
 static thread_local std::string g_err;
+static thread_local double t_host_phase[4] = {0, 0, 0, 0};  // zk_last_host_phases: host microseconds inside open / launch / collect / close of the last one-shot
 static thread_local double t_timing[3] = {0, 0, 0};  // zk_last_timing: open span, pass span, first open dispatch -> last pass dispatch (ms)
 
 #define HIP_TRY(expr)                                                                         \
@@ -89,6 +92,10 @@ extern "C" void zk_shutdown(void) {
             if (hipSetDevice(d) == hipSuccess) {
                 (void)hipStreamDestroy(g_own_stream[d]);
                 if (g_zero_row[d]) (void)hipFree(g_zero_row[d]);
+            }
+            for (int k = 0; k < 2; k++) {
+                if (g_batch_stream[d][k]) (void)hipStreamDestroy(g_batch_stream[d][k]);
+                g_batch_stream[d][k] = nullptr;
             }
             g_own_stream[d] = nullptr;
             g_zero_row[d] = nullptr;
@@ -453,7 +460,16 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // ---------------------------------------------------------------------------------------
 // sessions
 // ---------------------------------------------------------------------------------------
-enum SessionKind { SESSION_PI = 12, SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
+// What zk_collect reads back from an EVM session, contiguous at the start of the session's zero-filled region.
+struct EvmResultBlock {
+    EvmDyn dyn;                      // n_deferred
+    u32 pad0[(64 - sizeof(EvmDyn)) / 4];
+    ZkTally tally[2];                // offset 64
+    u32 group_start[EVM_N_GROUPS + 1];  // offset 96
+    u32 pad1[8 - (EVM_N_GROUPS + 1)];
+};
+static_assert(sizeof(EvmDyn) <= 64 && sizeof(EvmResultBlock) == 128, "EvmResultBlock layout");
+enum SessionKind { SESSION_PICOPY = 13, SESSION_PI = 12, SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
 
 struct zk_session {
     SessionKind kind;
@@ -482,6 +498,7 @@ struct zk_session {
     BcaArgs bca;
     CpaArgs cpa;
     PiArgs pi;
+    PiCopyArgs picopy;
     u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
@@ -497,6 +514,10 @@ struct zk_session {
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
     hipEvent_t ev_open0 = nullptr, ev_open1 = nullptr;  // EVM: ride on the first / last dispatch of zk_evm_open (zk_session_timing)
+    // EVM: EvmDyn, the two tallies and the lane ranges sit in ONE 128-byte device block (EvmResultBlock) that zk_collect reads
+    // back with ONE copy into page-locked host memory (three copies into pageable memory cost three blocking round trips)
+    void* d_result = nullptr;
+    void* h_result = nullptr;
 };
 
 static const int MAX_EVENT_PAIRS = 256;
@@ -525,6 +546,7 @@ struct DevArena {
     std::mutex m;
     std::vector<void*> free_[ZK_ARENA_CLASSES];
     std::vector<hipEvent_t> events;
+    std::vector<void*> pinned;  // ZK_PINNED_BYTES-byte blocks of page-locked host memory (result read-backs)
     size_t cached_bytes = 0;
 };
 static DevArena g_arena[ZK_MAX_DEVICES];
@@ -569,6 +591,20 @@ static void arena_give(int device, void* p, int cls) {
     }
     (void)hipFree(p);
 }
+#define ZK_PINNED_BYTES 256
+static int arena_pinned(int device, void** p) {
+    {
+        DevArena& A = g_arena[device];
+        std::lock_guard<std::mutex> lock(A.m);
+        if (!A.pinned.empty()) {
+            *p = A.pinned.back();
+            A.pinned.pop_back();
+            return 0;
+        }
+    }
+    HIP_TRY(hipHostMalloc(p, ZK_PINNED_BYTES, hipHostMallocDefault));
+    return 0;
+}
 static int arena_event(int device, hipEvent_t* e) {
     {
         DevArena& A = g_arena[device];
@@ -586,7 +622,7 @@ static void arena_release_all() {
     for (int d = 0; d < ZK_MAX_DEVICES; d++) {
         DevArena& A = g_arena[d];
         std::lock_guard<std::mutex> lock(A.m);
-        bool any = !A.events.empty();
+        bool any = !A.events.empty() || !A.pinned.empty();
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) any = any || !A.free_[c].empty();
         if (!any || hipSetDevice(d) != hipSuccess) continue;
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) {
@@ -595,6 +631,8 @@ static void arena_release_all() {
         }
         for (hipEvent_t e : A.events) (void)hipEventDestroy(e);
         A.events.clear();
+        for (void* h : A.pinned) (void)hipHostFree(h);
+        A.pinned.clear();
         A.cached_bytes = 0;
     }
 }
@@ -664,6 +702,7 @@ extern "C" int zk_close(zk_session* s) {
         for (hipEvent_t e : s->ev) A.events.push_back(e);
         if (s->ev_open0) A.events.push_back(s->ev_open0);
         if (s->ev_open1) A.events.push_back(s->ev_open1);
+        if (s->h_result) A.pinned.push_back(s->h_result);
     }
     delete s;
     return 0;
@@ -811,8 +850,11 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
         char* zero = nullptr;
         if ((rc = dev_alloc(s, (void**)&zero, zero_bytes))) goto fail;
-        EvmDyn* dyn = (EvmDyn*)zero;
-        static_assert(sizeof(EvmDyn) <= 256, "EvmDyn outgrew its slot");
+        EvmResultBlock* const rb = (EvmResultBlock*)zero;  // the first 128 of the region's 256 leading bytes
+        EvmDyn* dyn = &rb->dyn;
+        s->d_result = rb;
+        if ((rc = arena_pinned(s->device, &s->h_result))) goto fail;
+        static_assert(sizeof(EvmResultBlock) <= 256, "the result block outgrew its slot");
         static_assert((EVM_N_BINS * sizeof(u32)) % 16 == 0, "zero region pieces are 16-byte multiples");
         s->d_hist = (u32*)(zero + dyn_bytes);
         s->d_hist2 = (u32*)(zero + dyn_bytes + hist_bytes);
@@ -821,7 +863,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         E.dyn = dyn;
         E.defer_count = &dyn->n_deferred;
         if ((rc = dev_alloc(s, (void**)&E.defer_list, (size_t)E.n_pairs * sizeof(u32)))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&s->d_tally, 2 * sizeof(ZkTally)))) goto fail;
+        s->d_tally = rb->tally;
         s->tally_last = s->d_tally;
         {
             const u64 n16 = n_ff / 4 + zero_bytes / 16;
@@ -886,7 +928,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         // straight to the evaluation kernels
         if ((rc = dev_alloc(s, (void**)&s->d_cursor, EVM_N_BINS * sizeof(u32)))) goto fail;
         if ((rc = dev_alloc(s, (void**)&s->d_bin16, (size_t)E.n_pairs * sizeof(uint16_t)))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&s->d_group_start, (EVM_N_GROUPS + 1) * sizeof(u32)))) goto fail;
+        s->d_group_start = rb->group_start;
         if ((rc = dev_alloc(s, (void**)&s->d_perm, ((size_t)E.n_pairs + EVM_PERM_PAD + 2 * EVM_HOT_BLOCK) * sizeof(u32)))) goto fail;  // + slack: the hot kernel reads perm[t] for every lane of its grid
         const bool sorted = !(opts & ZK_OPT_NO_STATE_SORT);
         o.hist_block0 = o.dir_block0 + dir_row_blocks;
@@ -943,17 +985,65 @@ static void session_timing(zk_session* s, double pass_ms, double* open_ms, doubl
 extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_evm_verify: result is null");
     zk_session* s = nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
     int rc = zk_evm_open(t, opts | ZK_OPT_SINGLE_PASS, &s);  // one pass: the step records would not pay for themselves
     if (rc) return rc;
+    const auto h1 = std::chrono::steady_clock::now();
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    const auto h2 = std::chrono::steady_clock::now();
     if (!rc) rc = zk_collect(s, result);
+    const auto h3 = std::chrono::steady_clock::now();
     if (!rc) {
         t_timing[1] = result->kernel_ms;
         session_timing(s, result->kernel_ms, &t_timing[0], &t_timing[2]);
     }
     if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
     zk_close(s);
+    const auto h4 = std::chrono::steady_clock::now();
+    t_host_phase[0] = std::chrono::duration<double, std::micro>(h1 - h0).count();
+    t_host_phase[1] = std::chrono::duration<double, std::micro>(h2 - h1).count();
+    t_host_phase[2] = std::chrono::duration<double, std::micro>(h3 - h2).count();
+    t_host_phase[3] = std::chrono::duration<double, std::micro>(h4 - h3).count();
+    return rc;
+}
+
+// Batch verification: n independent witnesses, each opened, evaluated and collected exactly as zk_evm_verify does, two in flight —
+// witness i + 1 is opened and launched on the device's other pipeline stream before the host waits for witness i's tally, so the
+// HBM-bound open of one (key-record / index builds streaming the RW table) runs under the latency-bound evaluation kernel of the
+// other, and the host's launch and synchronisation latencies are hidden.  Results are written in input order; per-pair statuses
+// are not returned (zk_evm_verify on the failing witness gives them).
+extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, uint32_t opts, zk_result* results) {
+    ARG_TRY(t_device >= 0, "zk_evm_verify_batch: call zk_init first");
+    ARG_TRY((t && results) || n == 0, "zk_evm_verify_batch: bad arguments");
+    HIP_TRY(hipSetDevice(t_device));
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        for (int k = 0; k < 2; k++)
+            if (!g_batch_stream[t_device][k]) HIP_TRY(hipStreamCreateWithFlags(&g_batch_stream[t_device][k], hipStreamNonBlocking));
+    }
+    // the caller's stream orders its own uploads before this call: the pipeline streams start behind it
+    const hipStream_t caller = t_stream;
+    HIP_TRY(hipStreamSynchronize(caller));
+    zk_session* pend[2] = {nullptr, nullptr};
+    int rc = 0;
+    for (uint64_t i = 0; i < n + 2 && !rc; i++) {
+        const int slot = (int)(i & 1u);
+        if (pend[slot]) {  // witness i - 2
+            rc = zk_collect(pend[slot], &results[i - 2]);
+            zk_close(pend[slot]);
+            pend[slot] = nullptr;
+        }
+        if (!rc && i < n) {
+            ARG_TRY(t[i], "zk_evm_verify_batch: null witness");
+            t_stream = g_batch_stream[t_device][slot];
+            rc = zk_evm_open(t[i], opts | ZK_OPT_SINGLE_PASS, &pend[slot]);
+            t_stream = caller;
+            if (!rc) rc = zk_launch(pend[slot], nullptr);
+        }
+    }
+    for (int k = 0; k < 2; k++)
+        if (pend[k]) zk_close(pend[k]);
     return rc;
 }
 
@@ -1671,6 +1761,44 @@ fail:
     zk_close(s);
     return rc;
 }
+// PI circuit copy constraints (pi_circuit.py:355-445; csrc/pi_circuit.hpp pi_copy_check)
+extern "C" int zk_pi_copy_open(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts, zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_pi_copy_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(out && cells && bytes && lens && n > 0 && n < (1ull << 32), "zk_pi_copy_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_PICOPY;
+    s->n = n;
+    int rc = 0;
+    const void* p = nullptr;
+    if ((rc = stage(s, cells, (size_t)n * 32, dev, &p))) goto fail;
+    s->picopy.cells = (const u64*)p;
+    if ((rc = stage(s, bytes, (size_t)n * 32, dev, &p))) goto fail;
+    s->picopy.bytes = (const uint8_t*)p;
+    if ((rc = stage(s, lens, (size_t)n * 4, dev, &p))) goto fail;
+    s->picopy.lens = (const u32*)p;
+    s->picopy.n = n;
+    if ((rc = session_common_init(s))) goto fail;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_pi_copy_verify(const uint64_t* cells, const uint8_t* bytes, const uint32_t* lens, uint64_t n, uint32_t opts, uint32_t* status_out,
+                                 zk_result* result) {
+    ARG_TRY(result, "zk_pi_copy_verify: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_pi_copy_open(cells, bytes, lens, n, opts, &s);
+    if (rc) return rc;
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
 extern "C" int zk_pi_verify(const uint64_t* rows, uint64_t n, const uint64_t* keccak, uint64_t n_keccak, const uint64_t* gas, uint64_t n_gas,
                             uint64_t circuit_len, const uint64_t* keccak_rand, const uint64_t* byte_pow_base, uint32_t opts,
                             uint32_t* status_out, zk_result* result) {
@@ -1807,7 +1935,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         e1 = s->ev[2 * s->launches + 1];
     }
     const bool twin_tally = s->kind == SESSION_STATE || s->kind == SESSION_BYTECODE || s->kind == SESSION_COPY ||
-                            s->kind == SESSION_SIGN || s->kind == SESSION_EXP || s->kind == SESSION_PI;
+                            s->kind == SESSION_SIGN || s->kind == SESSION_EXP || s->kind == SESSION_PI || s->kind == SESSION_PICOPY;
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
@@ -1828,6 +1956,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
     case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
     case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, range_lo(s), range_hi(s), status, tally); break;
+    case SESSION_PICOPY: zk_launch_pi_copy(s->stream, s->picopy, status, tally); break;
     case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
@@ -1896,12 +2025,22 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ZkTally t;
     u32 n_def = 0;
     const bool check_deferred = s->kind == SESSION_EVM && s->deferred_pending && s->evm.defer_count;
-    if (check_deferred) HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));  // rides on the tally's synchronisation
     u32 gs[EVM_N_GROUPS + 1] = {0};
     const bool read_ranges = s->kind == SESSION_EVM && s->evm.perm && !s->evm_ranges_known && s->launches > 0;
-    if (read_ranges) HIP_TRY(hipMemcpyAsync(gs, s->d_group_start, sizeof gs, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->kind == SESSION_EVM && s->d_result && s->h_result) {
+        // one copy of the 128-byte result block (deferred count, both tallies, lane ranges) into page-locked memory, one wait
+        HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(EvmResultBlock), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const EvmResultBlock* h = (const EvmResultBlock*)s->h_result;
+        n_def = h->dyn.n_deferred;
+        for (int k = 0; k <= EVM_N_GROUPS; k++) gs[k] = h->group_start[k];
+        t = h->tally[s->tally_last - s->d_tally];
+    } else {
+        if (check_deferred) HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));  // rides on the tally's synchronisation
+        if (read_ranges) HIP_TRY(hipMemcpyAsync(gs, s->d_group_start, sizeof gs, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     if (read_ranges) {
         s->evm_ranges_known = 1;
         s->evm_warm_empty = gs[EVM_GROUP_WARM] == gs[EVM_GROUP_WARM + 1];
@@ -1959,6 +2098,10 @@ extern "C" int zk_session_timing(zk_session* s, double* open_ms, double* span_ms
     ARG_TRY(s && open_ms && span_ms, "zk_session_timing: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     session_timing(s, 1.0, open_ms, span_ms);
+    return 0;
+}
+extern "C" int zk_last_host_phases(double* us4) {
+    if (us4) for (int k = 0; k < 4; k++) us4[k] = t_host_phase[k];
     return 0;
 }
 extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {

@@ -260,6 +260,31 @@ class EvmOneShot:
         return Result(self._r)
 
 
+class EvmBatch:
+    """A prepared call of `zk_evm_verify_batch` over resident wire dicts (the witness list may name the same dict several times):
+    n independent verifications, software-pipelined two deep by the library."""
+
+    def __init__(self, wires, order, device=None):
+        self._lib = _lib.init(device)
+        prepared = [_evm_tables(w, False, False) for w in wires]
+        self._keep = prepared
+        self._opts = prepared[0][1]
+        self.n = len(order)
+        self.n_pairs = prepared[0][3]
+        arr_t = ctypes.POINTER(_lib.ZkEvmTables) * self.n
+        self._ptrs = arr_t(*[ctypes.pointer(prepared[k][0]) for k in order])
+        self._results = (ZkResult * self.n)()
+
+    def __call__(self):
+        rc = self._lib.zk_evm_verify_batch(self._ptrs, self.n, self._opts, self._results)
+        if rc:
+            check(rc, "zk_evm_verify_batch", self._lib)
+        return self._results
+
+    def results(self):
+        return [Result(r) for r in self._results]
+
+
 def last_timing(lib=None):
     """(open_ms, pass_ms, span_ms) of the calling thread's last one-shot zk_evm_verify (device spans by HIP events; -1 = not measured)"""
     lib = lib if lib is not None else _lib.load()

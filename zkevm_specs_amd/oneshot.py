@@ -221,3 +221,17 @@ def pi_verify(rows, keccak, gas, circuit_len, keccak_rand=255, byte_pow_base=255
     check(lib.zk_pi_verify(_p(rows), n, _p(keccak, m), m, _p(gas, k), k, int(circuit_len), _p(kr), _p(bp), 0, _p(status), ctypes.byref(r)),
           "zk_pi_verify")
     return Result(r), status
+
+
+def pi_copy_verify(cells, data, lens, device=None):
+    """zk_pi_copy_verify over cells uint64[n, 4], data uint8[n, 32], lens uint32[n] -> (Result, status uint32[n])"""
+    lib = _lib.init(device)
+    cells, data, lens = _c(cells), _c(data), _c(lens)
+    _expect(cells, "pi copy cells", 8, (None, 4))
+    _expect(data, "pi copy bytes", 1, (cells.shape[0], 32))
+    _expect(lens, "pi copy lens", 4, (cells.shape[0],))
+    n = int(cells.shape[0])
+    status, r = np.zeros(n, dtype=np.uint32), ZkResult()
+    check(lib.zk_pi_copy_verify(_p(cells), _p(data), _p(lens), n, 0, _p(status), ctypes.byref(r)), "zk_pi_copy_verify")
+    return Result(r), status
+
