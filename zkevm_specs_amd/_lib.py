@@ -5,9 +5,9 @@ engine raises — the product path never routes through a CPU implementation on 
 
 ZK_BACKEND=cpu (an explicit choice, read once when the library is first loaded) binds the same C ABI to libzkevm_cpu.so
 instead: the kernels' own per-row device functions compiled for the host and run with OpenMP (csrc/cpu_backend.cpp) —
-BASELINE configs[0]'s "pure CPU path" through the real boundary and the optimised-CPU line of bench.py.  It implements the
-verify / open / launch / collect entries of every circuit, the keccak-table and ECDSA entries; not the device-side witness
-assignments, and ZK_OPT_DEVICE_PTRS has no meaning there (inputs are host arrays).
+BASELINE configs[0]'s "pure CPU path" through the real boundary and the optimised-CPU line of bench.py.  It implements every
+entry of include/zkevm_hip.h — the verify / open / launch / collect entries of every circuit, the keccak-table and ECDSA entries
+and (round 4) the State / Bytecode / Copy witness assignments; ZK_OPT_DEVICE_PTRS has no meaning there (inputs are host arrays).
 """
 import ctypes
 import os

@@ -28,13 +28,12 @@
 #include "keccak_table.hpp"
 #include "secp256k1.hpp"
 #include "pi_circuit.hpp"
+#include "state_assign.hpp"
+#include "bytecode_assign.hpp"
 
 static thread_local std::string g_err;
 #define ARG_TRY(cond, msg) do { if (!(cond)) { g_err = msg; return -1; } } while (0)
-static int unsupported(const char* what) {
-    g_err = std::string(what) + ": not implemented by the CPU backend (libzkevm_cpu.so)";
-    return -3;
-}
+#include "copy_assign_plan.hpp"  // (uses ARG_TRY)
 
 extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
 extern "C" int zk_init(int) { return 0; }
@@ -88,6 +87,12 @@ struct zk_session {
     std::vector<u64> a64[4];
     std::vector<u32> a32[4];
     std::vector<uint8_t> a8;
+    std::vector<uint16_t> a16;
+    std::vector<u64> w64[4];              // assignment sessions: work / output buffers
+    std::vector<u32> out32;
+    void (*pass)(zk_session*) = nullptr;  // assignment sessions: one pass computes the outputs and fills `status`
+    int assign_kind = 0;                  // 1 state, 2 bytecode, 3 copy
+    u64 n_mpt = 0;
     CpuTable tab[12];
     std::vector<u64> keccak_rows;         // keccak sessions: the table
     // per-circuit argument blocks (one is used)
@@ -99,6 +104,11 @@ struct zk_session {
     SignArgs sign;
     PiArgs pi;
     PiCopyArgs picopy;
+    AssignArgs assign;
+    BcaArgs bca;
+    std::vector<BcaChunk> bca_chunks;
+    CpaArgs cpa;
+    CpaPlan cpa_plan;
     EcdsaArgs ecdsa;
     KeccakGenArgs kgen;
     ZkRwMeta rw_meta;
@@ -111,8 +121,13 @@ static void run_pass(zk_session* s, u32* status_out) {
     const auto t0 = std::chrono::steady_clock::now();
     u32* st = status_out ? status_out : s->status.data();
     const long long lo = (long long)s->lo, hi = (long long)s->hi;
+    if (s->pass) {  // witness assignment: sequential host loops over the device functions
+        s->pass(s);
+        if (status_out) memcpy(status_out, s->status.data(), s->n * sizeof(u32));
+    } else {
 #pragma omp parallel for schedule(dynamic, 256)
-    for (long long i = lo; i < hi; i++) st[i] = s->row((u64)i);
+        for (long long i = lo; i < hi; i++) st[i] = s->row((u64)i);
+    }
     u64 fails = 0, first = ~0ull;
     for (long long i = lo; i < hi; i++)
         if (st[i]) {
@@ -604,14 +619,226 @@ extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint
     return rc ? rc : one_shot(s, status_out, result);
 }
 
-// ---- device-side witness assignment: not on the CPU backend -------------------------------------------------------------
-extern "C" int zk_state_assign_open(const uint64_t*, const uint32_t*, uint64_t, uint64_t*, uint32_t*, uint64_t*, uint32_t, zk_session**) { return unsupported("zk_state_assign_open"); }
-extern "C" int zk_state_assign_read(zk_session*, uint64_t*, uint32_t*, uint64_t*, uint64_t, uint64_t*) { return unsupported("zk_state_assign_read"); }
-extern "C" int zk_state_assign(const uint64_t*, const uint32_t*, uint64_t, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t, uint32_t*, zk_result*) { return unsupported("zk_state_assign"); }
-extern "C" int zk_bytecode_assign_open(const uint64_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t, uint32_t, const uint64_t*, uint64_t*, uint32_t, zk_session**) { return unsupported("zk_bytecode_assign_open"); }
-extern "C" int zk_bytecode_assign_read(zk_session*, uint64_t*) { return unsupported("zk_bytecode_assign_read"); }
-extern "C" int zk_bytecode_assign(const uint64_t*, uint64_t, const uint64_t*, const uint64_t*, uint64_t, uint32_t, const uint64_t*, uint64_t*, uint32_t, zk_result*) { return unsupported("zk_bytecode_assign"); }
-extern "C" int zk_copy_assign_sizes(const zk_copy_events*, uint32_t, uint64_t*, uint64_t*, uint64_t*) { return unsupported("zk_copy_assign_sizes"); }
-extern "C" int zk_copy_assign_open(const zk_copy_events*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*, uint32_t, zk_session**) { return unsupported("zk_copy_assign_open"); }
-extern "C" int zk_copy_assign_read(zk_session*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*) { return unsupported("zk_copy_assign_read"); }
-extern "C" int zk_copy_assign(const zk_copy_events*, uint64_t*, uint32_t*, uint64_t*, uint64_t*, uint32_t*, uint32_t, zk_result*) { return unsupported("zk_copy_assign"); }
+// ---- witness assignment (state_circuit.py:827-934, bytecode_circuit.py:104-167, evm_circuit/typing.py CopyCircuit.copy): the device
+// functions of csrc/state_assign.hpp / bytecode_assign.hpp / copy_assign.hpp in plain host loops.  A pass (zk_launch) computes the
+// outputs into session-owned buffers; zk_*_assign_read copies them out.  Output pointers at open need ZK_OPT_DEVICE_PTRS, which
+// has no meaning here.
+static void state_assign_pass(zk_session* s) {
+    AssignArgs& a = s->assign;
+    const u64 n = a.n;
+    std::fill(s->a32[1].begin(), s->a32[1].end(), ZK_EMPTY_SLOT);  // slots
+    std::fill(s->a32[2].begin(), s->a32[2].end(), ASG_NONE);       // first
+    // ops are inserted in REVERSE order so that the "smallest index wins" rule is what makes the result right
+    for (u64 i = n; i-- > 0;)
+        if (asg_has_key(asg_slot(a, ASG_TAG, i))) asg_insert(a, (u32)i);
+    u32 r = 0;
+    u32* first = s->a32[2].data();
+    u32* rank = s->a32[3].data();
+    for (u64 i = 0; i < n; i++) {
+        if (!asg_has_key(asg_slot(a, ASG_TAG, i))) continue;
+        first[i] = asg_find_first(a, (u32)i);
+        if (first[i] == (u32)i) { rank[i] = r; asg_write_mpt(a, i, r); r++; }
+    }
+    s->n_mpt = r;
+    u32 nxt = ASG_NONE;
+    for (u64 i = n; i-- > 0;) {
+        const u64 root = 3ull + 5ull * (nxt == ASG_NONE ? r : rank[first[nxt]]);
+        s->status[i] = asg_write_row(a, i, root, first[i] == (u32)i);
+        if (first[i] != ASG_NONE) nxt = (u32)i;
+    }
+}
+extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_dev, uint32_t* row_flags_dev,
+                                    uint64_t* mpt_dev, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_state_assign_open");
+    ARG_TRY(out && ops && op_flags && n > 0 && n < (1ull << 31) && !rows_dev && !row_flags_dev && !mpt_dev, "zk_state_assign_open: bad arguments");
+    zk_session* s = new_session(n, false);
+    s->a64[0].assign(ops, ops + n * ASG_NSLOTS * 4);
+    s->a32[0].assign(op_flags, op_flags + n);
+    s->a64[1].assign(n * ASG_ROW_NCELLS * 4, 0);  // rows
+    s->a64[2].assign(n * ASG_MPT_NCELLS * 4, 0);  // mpt
+    s->out32.assign(n, 0);                        // row flags
+    u32 cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    s->a32[1].assign(cap, ZK_EMPTY_SLOT);
+    s->a32[2].assign(n, ASG_NONE);
+    s->a32[3].assign(n, 0);
+    AssignArgs& a = s->assign;
+    a.ops = s->a64[0].data(); a.op_flags = s->a32[0].data(); a.n = n;
+    a.rows = s->a64[1].data(); a.row_flags = s->out32.data(); a.mpt = s->a64[2].data();
+    a.slots = s->a32[1].data(); a.mask = cap - 1; a.first = s->a32[2].data(); a.rank = s->a32[3].data();
+    a.nb = 0; a.blk_cnt = nullptr; a.blk_next = nullptr;
+    s->pass = state_assign_pass;
+    s->assign_kind = 1;
+    *out = s;
+    return 0;
+}
+extern "C" int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* mpt_host, uint64_t mpt_capacity_rows,
+                                    uint64_t* n_mpt_out) {
+    ARG_TRY(s && s->assign_kind == 1, "zk_state_assign_read: bad arguments");
+    if (n_mpt_out) *n_mpt_out = s->n_mpt;
+    if (rows_host) memcpy(rows_host, s->a64[1].data(), s->a64[1].size() * 8);
+    if (row_flags_host) memcpy(row_flags_host, s->out32.data(), s->out32.size() * 4);
+    if (mpt_host) {
+        ARG_TRY(mpt_capacity_rows >= s->n_mpt, "zk_state_assign_read: mpt buffer too small");
+        memcpy(mpt_host, s->a64[2].data(), (size_t)s->n_mpt * ASG_MPT_NCELLS * 32);
+    }
+    return 0;
+}
+extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, uint64_t* rows_out, uint32_t* row_flags_out,
+                               uint64_t* mpt_out, uint64_t* n_mpt_out, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && n_mpt_out, "zk_state_assign: null output");
+    zk_session* s = nullptr;
+    int rc = zk_state_assign_open(ops, op_flags, n, nullptr, nullptr, nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = zk_state_assign_read(s, rows_out, row_flags_out, mpt_out, n, n_mpt_out);
+    if (!rc && status_out) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
+static void bytecode_assign_pass(zk_session* s) {
+    BcaArgs& a = s->bca;
+    for (u64 j = 0; j < a.n_codes; j++) bca_track_code(a, j);
+    for (u64 c = 0; c < a.n_chunks; c++) bca_chunk(a, c);
+    for (u64 j = 0; j < a.n_codes; j++) bca_prefix_code(a, j);
+    for (u64 c = 0; c < a.n_chunks; c++) bca_rlc_chunk(a, c);
+    for (u64 i = 0; i < a.n_out; i++) bca_write_row(a, i);
+}
+extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths, uint64_t n_codes,
+                                       uint32_t k, const uint64_t* randomness, uint64_t* rows_dev, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_bytecode_assign_open");
+    ARG_TRY(out && offsets && lengths && randomness && k >= 1 && k <= 30 && n_rows < (1ull << 31) && n_codes < (1ull << 31) && (in_rows || n_rows == 0) &&
+            !rows_dev, "zk_bytecode_assign_open: bad arguments");
+    ARG_TRY(offsets[0] == 0 && offsets[n_codes] == n_rows, "zk_bytecode_assign_open: offsets must span the rows");
+    for (u64 j = 0; j < n_codes; j++) ARG_TRY(offsets[j] <= offsets[j + 1], "zk_bytecode_assign_open: offsets must be non-decreasing");
+    zk_session* s = new_session(1ull << k, false);
+    s->a64[0].assign(in_rows, in_rows + n_rows * 6 * 4);
+    s->a64[1].assign(offsets, offsets + n_codes + 1);
+    s->a64[2].assign(lengths, lengths + n_codes);
+    std::vector<BcaChunk>& chunks = s->bca_chunks;
+    s->a32[0].assign(n_codes + 1, 0);  // code_chunk0
+    for (u64 j = 0; j < n_codes; j++) {
+        s->a32[0][j] = (u32)chunks.size();
+        for (u64 g = offsets[j]; g < offsets[j + 1]; g += BCA_CHUNK) {
+            BcaChunk c;
+            c.code = (u32)j; c.start = (u32)g;
+            c.count = (u32)((offsets[j + 1] - g < BCA_CHUNK) ? offsets[j + 1] - g : BCA_CHUNK);
+            c.first = g == offsets[j] ? 1u : 0u;
+            chunks.push_back(c);
+        }
+    }
+    s->a32[0][n_codes] = (u32)chunks.size();
+    s->a64[3].assign(BCA_RPOW_ROWS * 4, 0);
+    bca_fill_rpow(cell_of(randomness), s->a64[3].data());
+    s->w64[0].assign(chunks.size() * 4 + 4, 0);  // chunk_acc
+    s->w64[1].assign(chunks.size() * 4 + 4, 0);  // chunk_in
+    s->w64[2].assign(n_rows * 4 + 4, 0);         // rlc
+    s->w64[3].assign((size_t)(1ull << k) * 12 * 4, 0);  // output rows
+    s->a32[1].assign(chunks.size() + 1, 0);      // chunk_m
+    s->a32[2].assign(n_rows + 1, 0);             // row_code
+    s->a8.assign(2 * n_rows + 2, 0);             // track
+    BcaArgs& a = s->bca;
+    a.in_rows = s->a64[0].data(); a.offsets = s->a64[1].data(); a.lengths = s->a64[2].data(); a.n_in = n_rows; a.n_codes = n_codes; a.n_out = 1ull << k;
+    a.rpow = s->a64[3].data(); a.chunks = chunks.data(); a.code_chunk0 = s->a32[0].data(); a.n_chunks = chunks.size();
+    a.track = s->a8.data(); a.chunk_acc = s->w64[0].data(); a.chunk_m = s->a32[1].data(); a.chunk_in = s->w64[1].data(); a.rlc = s->w64[2].data();
+    a.row_code = s->a32[2].data(); a.rows = s->w64[3].data();
+    s->pass = bytecode_assign_pass;
+    s->assign_kind = 2;
+    *out = s;
+    return 0;
+}
+extern "C" int zk_bytecode_assign_read(zk_session* s, uint64_t* rows_host) {
+    ARG_TRY(s && rows_host && s->assign_kind == 2, "zk_bytecode_assign_read: bad arguments");
+    memcpy(rows_host, s->w64[3].data(), s->w64[3].size() * 8);
+    return 0;
+}
+extern "C" int zk_bytecode_assign(const uint64_t* in_rows, uint64_t n_rows, const uint64_t* offsets, const uint64_t* lengths, uint64_t n_codes, uint32_t k,
+                                  const uint64_t* randomness, uint64_t* rows_out, uint32_t opts, zk_result* result) {
+    ARG_TRY(result && rows_out, "zk_bytecode_assign: null output");
+    zk_session* s = nullptr;
+    int rc = zk_bytecode_assign_open(in_rows, n_rows, offsets, lengths, n_codes, k, randomness, nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = zk_bytecode_assign_read(s, rows_out);
+    zk_close(s);
+    return rc;
+}
+
+static void copy_assign_pass(zk_session* s) {
+    CpaArgs& a = s->cpa;
+    for (u64 c = 0; c < a.n_chunks; c++) cpa_chunk(a, c);
+    for (u64 e = 0; e < a.n_events; e++) cpa_prefix_event(a, e);
+    for (u64 c = 0; c < a.n_chunks; c++) cpa_rlc_chunk(a, c);
+    for (u64 j = 0; j < a.n_rows; j++) cpa_write_row(a, j);
+}
+extern "C" int zk_copy_assign_sizes(const zk_copy_events* t, uint32_t opts, uint64_t* n_rows, uint64_t* n_table, uint64_t* n_rw) {
+    NO_DEVICE_PTRS(opts, "zk_copy_assign_sizes");
+    ARG_TRY(t && t->n_events > 0 && t->events && t->data_offsets, "zk_copy_assign_sizes: bad arguments");
+    CpaPlan pl;
+    const int rc = cpa_plan(t->events, t->flags, t->data_offsets, t->n_events, pl);
+    if (rc) return rc;
+    if (n_rows) *n_rows = pl.n_rows;
+    if (n_table) *n_table = pl.n_table;
+    if (n_rw) *n_rw = pl.n_rw;
+    return 0;
+}
+extern "C" int zk_copy_assign_open(const zk_copy_events* t, uint64_t* rows_dev, uint32_t* row_flags_dev, uint64_t* table_dev, uint64_t* rw_dev,
+                                   uint32_t* rw_flags_dev, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_copy_assign_open");
+    ARG_TRY(t && out && t->n_events > 0 && t->n_events < (1ull << 31) && t->events && t->data_offsets && t->randomness, "zk_copy_assign_open: bad arguments");
+    ARG_TRY(!rows_dev && !row_flags_dev && !table_dev && !rw_dev && !rw_flags_dev, "zk_copy_assign_open: output buffers need ZK_OPT_DEVICE_PTRS");
+    zk_session* s = new_session(1, false);
+    CpaPlan& pl = s->cpa_plan;
+    const int rc = cpa_plan(t->events, t->flags, t->data_offsets, t->n_events, pl);
+    if (rc) { delete s; return rc; }
+    s->n = s->hi = pl.n_rows;
+    s->status.assign(pl.n_rows ? pl.n_rows : 1, 0u);
+    s->a64[0].assign(t->events, t->events + t->n_events * CPA_EV_NCELLS * 4);
+    s->a16.assign(t->data, t->data + pl.n_data);
+    s->a64[1].assign(CPA_RPOW_ROWS * 4, 0);
+    cpa_fill_rpow(cell_of(t->randomness), s->a64[1].data());
+    s->w64[0].assign(pl.chunks.size() * 4 + 4, 0);  // chunk_acc
+    s->w64[1].assign(pl.chunks.size() * 4 + 4, 0);  // chunk_in
+    s->w64[2].assign(t->n_events * 4 + 4, 0);       // ev_rlc
+    s->w64[3].assign(pl.n_rlc * 4 + 4, 0);          // rlc
+    s->a64[2].assign(pl.n_rows * CPA_ROW_NCELLS * 4 + 4, 0);   // rows
+    s->a64[3].assign(pl.n_table * CPA_TABLE_NCELLS * 4 + 4, 0);  // table
+    s->keccak_rows.assign(pl.n_rw * CPA_RW_NCELLS * 4 + 4, 0);  // rw rows
+    s->out32.assign(pl.n_rows + 1, 0);              // row flags
+    s->a32[0].assign(pl.n_rw + 1, 0);               // rw flags
+    CpaArgs& a = s->cpa;
+    a.events = s->a64[0].data(); a.ev = pl.ev.data(); a.row0 = pl.row0.data(); a.n_events = t->n_events; a.n_rows = pl.n_rows; a.data = s->a16.data();
+    a.rpow = s->a64[1].data(); a.chunks = pl.chunks.data(); a.n_chunks = pl.chunks.size(); a.chunk_acc = s->w64[0].data(); a.chunk_in = s->w64[1].data();
+    a.ev_rlc = s->w64[2].data(); a.rlc = s->w64[3].data(); a.rows = s->a64[2].data(); a.row_flags = s->out32.data(); a.table = s->a64[3].data();
+    a.rw = s->keccak_rows.data(); a.rw_flags = s->a32[0].data();
+    s->pass = copy_assign_pass;
+    s->assign_kind = 3;
+    *out = s;
+    return 0;
+}
+extern "C" int zk_copy_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_host, uint64_t* table_host, uint64_t* rw_host,
+                                   uint32_t* rw_flags_host) {
+    ARG_TRY(s && s->assign_kind == 3, "zk_copy_assign_read: bad arguments");
+    const CpaPlan& pl = s->cpa_plan;
+    if (rows_host) memcpy(rows_host, s->a64[2].data(), (size_t)pl.n_rows * CPA_ROW_NCELLS * 32);
+    if (row_flags_host) memcpy(row_flags_host, s->out32.data(), (size_t)pl.n_rows * 4);
+    if (table_host && pl.n_table) memcpy(table_host, s->a64[3].data(), (size_t)pl.n_table * CPA_TABLE_NCELLS * 32);
+    if (rw_host && pl.n_rw) memcpy(rw_host, s->keccak_rows.data(), (size_t)pl.n_rw * CPA_RW_NCELLS * 32);
+    if (rw_flags_host && pl.n_rw) memcpy(rw_flags_host, s->a32[0].data(), (size_t)pl.n_rw * 4);
+    return 0;
+}
+extern "C" int zk_copy_assign(const zk_copy_events* t, uint64_t* rows_out, uint32_t* row_flags_out, uint64_t* table_out, uint64_t* rw_out,
+                              uint32_t* rw_flags_out, uint32_t opts, zk_result* result) {
+    ARG_TRY(result && rows_out && row_flags_out, "zk_copy_assign: null output");
+    zk_session* s = nullptr;
+    int rc = zk_copy_assign_open(t, nullptr, nullptr, nullptr, nullptr, nullptr, opts, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = zk_copy_assign_read(s, rows_out, row_flags_out, table_out, rw_out, rw_flags_out);
+    zk_close(s);
+    return rc;
+}
