@@ -373,13 +373,12 @@ extern "C" int sim_bytecode_assign(const u64* in_rows, u64 n_rows, const u64* of
     Fr r;
     for (int q = 0; q < 4; q++) { r.v[2 * q] = (u32)r4[q]; r.v[2 * q + 1] = (u32)(r4[q] >> 32); }
     std::vector<u64> rpow(BCA_RPOW_ROWS * 4), acc(chunks.size() * 4 + 4), cin(chunks.size() * 4 + 4), rlc(n_rows * 4 + 4);
-    std::vector<u32> cm(chunks.size() + 1), rc(n_rows + 1);
-    std::vector<uint8_t> track(2 * n_rows + 2);
+    std::vector<u32> cm(chunks.size() + 1), rc(n_rows + 1), cstate(chunks.size() + 1);
+    std::vector<uint8_t> track(2 * n_rows + 2), cmap((chunks.size() + 1) * BCA_MAP_STRIDE);
     bca_fill_rpow(r, rpow.data());
     a.rpow = rpow.data(); a.chunks = chunks.data(); a.code_chunk0 = c0.data(); a.n_chunks = chunks.size();
     a.track = track.data(); a.chunk_acc = acc.data(); a.chunk_m = cm.data(); a.chunk_in = cin.data(); a.rlc = rlc.data();
-    a.row_code = rc.data(); a.rows = rows_out;
-    for (u64 j = 0; j < n_codes; j++) bca_track_code(a, j);
+    a.row_code = rc.data(); a.rows = rows_out; a.chunk_map = cmap.data(); a.chunk_state = cstate.data();
     for (u64 c = 0; c < chunks.size(); c++) bca_chunk(a, c);
     for (u64 j = 0; j < n_codes; j++) bca_prefix_code(a, j);
     for (u64 c = 0; c < chunks.size(); c++) bca_rlc_chunk(a, c);

@@ -8,17 +8,21 @@
 // is_code, value) + row offsets and byte lengths per bytecode; output: the 12-cell circuit rows column-major, exactly
 // what zk_bytecode_open takes.
 //
-// The two per-bytecode recurrences are sequential in the reference.  Here:
-//   bca_track_code   one lane per bytecode walks its rows with integers only (push_data_left <= 32): 2 bytes per row
-//   bca_chunk        one lane per 64-row chunk: Horner over the chunk from 0  -> (acc, number of byte rows m)
-//   bca_prefix_code  one lane per bytecode: incoming value_rlc of every chunk, running = running * r^m + acc
-//   bca_rlc_chunk    one lane per chunk: value_rlc of each of its rows from the incoming value
+// The two per-bytecode recurrences are sequential in the reference.  Here both are cut into 64-row chunks:
+//   bca_chunk        one lane per chunk: Horner over the chunk from 0 -> (acc, number of byte rows m), AND the chunk's push-data
+//                    transition map: push_data_left after the chunk as a function of push_data_left before it (33 states; once
+//                    the counter reaches 0 inside the chunk the rest does not depend on how it was entered, so the map is a
+//                    backward pass over "state after the chunk when position p is entered with 0")
+//   bca_prefix_code  one lane per bytecode: incoming value_rlc (running = running * r^m + acc) and incoming push_data_left (one
+//                    table lookup) of every chunk
+//   bca_rlc_chunk    one lane per chunk: value_rlc and (push_data_left, push_data_size) of each of its rows from the incoming values
 //   bca_write_row    one lane per OUTPUT row (coalesced 32 B/lane stores of the 12 cells), padding rows included
-// so a 24,576-byte contract costs ~2 x 64 + 384 dependent Montgomery products per lane instead of 24,576.
+// so a 24,576-byte contract costs ~2 x 64 + 384 dependent steps per lane instead of 24,576 (round 3 walked the push-data
+// counter with one lane per bytecode: 2.7 ms for the block's largest contract).
 #pragma once
 #include "common.hpp"
 
-enum { BCA_IN_NCELLS = 6, BCA_OUT_NCELLS = 12, BCA_CHUNK = 64, BCA_RPOW_ROWS = BCA_CHUNK + 1 };
+enum { BCA_IN_NCELLS = 6, BCA_OUT_NCELLS = 12, BCA_CHUNK = 64, BCA_RPOW_ROWS = BCA_CHUNK + 1, BCA_MAP_STRIDE = 36 /* 33 states, padded */ };
 
 struct BcaChunk {
     u32 code;   // bytecode index
@@ -37,6 +41,8 @@ struct BcaArgs {
     const u32* code_chunk0; // [n_codes + 1]: first chunk of every bytecode
     u64 n_chunks;
     uint8_t* track;         // [n_in][2]: push_data_left, push_data_size
+    uint8_t* chunk_map;     // [n_chunks][BCA_MAP_STRIDE]: push_data_left after the chunk for every push_data_left (0..32) before it
+    u32* chunk_state;       // [n_chunks] push_data_left entering the chunk
     u64* chunk_acc;         // [n_chunks][4] Horner of the chunk from 0
     u32* chunk_m;           // [n_chunks] byte rows in the chunk
     u64* chunk_in;          // [n_chunks][4] incoming value_rlc
@@ -60,49 +66,65 @@ ZK_HD void bca_fill_rpow(const Fr& r, u64* out) {  // single lane, once per sess
         acc = fr_mont(acc, rM);
     }
 }
-ZK_HD void bca_track_code(const BcaArgs& a, u64 j) {
-    u32 next = 0;
-    const u64 lo = a.offsets[j], hi = a.offsets[j + 1];
-    for (u64 g = lo; g < hi; g++) {
-        const u32 left = next;
-        u32 size = 0;
-        if (g > lo) {
-            size = bca_push_size(bca_in_cell(a, g, 5));
-            next = left == 0u ? size : left - 1u;
-        }
-        a.track[2 * g] = (uint8_t)left;
-        a.track[2 * g + 1] = (uint8_t)size;
-    }
-}
+// The push-data counter (bytecode_circuit.py:117-130): entering a byte row with `left`, the next row is entered with
+// (left == 0 ? get_push_size(value) : left - 1); the Header row (the bytecode's first row) leaves it alone.
 ZK_HD void bca_chunk(const BcaArgs& a, u64 c) {
     const BcaChunk ch = a.chunks[c];
     const Fr rM = fr_load(a.rpow + 4);
     Fr acc = fr_zero();
     u32 m = 0;
+    uint8_t size[BCA_CHUNK];
     for (u32 t = 0; t < ch.count; t++) {
+        size[t] = 0;
         if (ch.first && t == 0) continue;
-        acc = fr_add(fr_mont(acc, rM), bca_in_cell(a, (u64)ch.start + t, 5));
+        const Fr v = bca_in_cell(a, (u64)ch.start + t, 5);
+        size[t] = (uint8_t)bca_push_size(v);
+        acc = fr_add(fr_mont(acc, rM), v);
         m++;
     }
     bca_store(a.chunk_acc + 4 * c, acc);
     a.chunk_m[c] = m;
+    // zero_out[p]: the counter after the chunk when position p is entered with 0
+    uint8_t zero_out[BCA_CHUNK + 1];
+    zero_out[ch.count] = 0;
+    for (int p = (int)ch.count - 1; p >= 0; p--) {
+        const u32 sz = size[p];
+        if (sz == 0) zero_out[p] = zero_out[p + 1];
+        else if ((u32)p + sz + 1u <= ch.count) zero_out[p] = zero_out[p + sz + 1];
+        else zero_out[p] = (uint8_t)(sz - (ch.count - 1u - (u32)p));  // the push data runs past the chunk
+    }
+    uint8_t* map = a.chunk_map + c * BCA_MAP_STRIDE;
+    for (u32 left = 0; left <= 32u; left++) map[left] = left <= ch.count ? zero_out[left] : (uint8_t)(left - ch.count);
 }
 ZK_HD void bca_prefix_code(const BcaArgs& a, u64 j) {
     Fr running = fr_zero();
+    u32 left = 0;
     for (u32 c = a.code_chunk0[j]; c < a.code_chunk0[j + 1]; c++) {
         bca_store(a.chunk_in + 4 * (u64)c, running);
+        a.chunk_state[c] = left;
         running = fr_add(fr_mont(running, fr_load(a.rpow + 4 * a.chunk_m[c])), fr_load(a.chunk_acc + 4 * (u64)c));
+        left = a.chunk_map[(u64)c * BCA_MAP_STRIDE + left];
     }
 }
 ZK_HD void bca_rlc_chunk(const BcaArgs& a, u64 c) {
     const BcaChunk ch = a.chunks[c];
     const Fr rM = fr_load(a.rpow + 4);
     Fr rlc = fr_load(a.chunk_in + 4 * c);
+    u32 next = a.chunk_state[c];
     for (u32 t = 0; t < ch.count; t++) {
         const u64 g = (u64)ch.start + t;
-        if (!(ch.first && t == 0)) rlc = fr_add(fr_mont(rlc, rM), bca_in_cell(a, g, 5));
+        const u32 left = next;
+        u32 size = 0;
+        if (!(ch.first && t == 0)) {
+            const Fr v = bca_in_cell(a, g, 5);
+            rlc = fr_add(fr_mont(rlc, rM), v);
+            size = bca_push_size(v);
+            next = left == 0u ? size : left - 1u;
+        }
         bca_store(a.rlc + 4 * g, rlc);
         a.row_code[g] = ch.code;
+        a.track[2 * g] = (uint8_t)left;
+        a.track[2 * g + 1] = (uint8_t)size;
     }
 }
 // Output row i (bytecode_circuit.Row: q_first, q_last, hash lo, hi, tag, index, value, is_code, push_data_left, value_rlc,

@@ -107,6 +107,7 @@ struct zk_session {
     AssignArgs assign;
     BcaArgs bca;
     std::vector<BcaChunk> bca_chunks;
+    std::vector<uint8_t> bca_map;
     CpaArgs cpa;
     CpaPlan cpa_plan;
     EcdsaArgs ecdsa;
@@ -700,7 +701,6 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
 
 static void bytecode_assign_pass(zk_session* s) {
     BcaArgs& a = s->bca;
-    for (u64 j = 0; j < a.n_codes; j++) bca_track_code(a, j);
     for (u64 c = 0; c < a.n_chunks; c++) bca_chunk(a, c);
     for (u64 j = 0; j < a.n_codes; j++) bca_prefix_code(a, j);
     for (u64 c = 0; c < a.n_chunks; c++) bca_rlc_chunk(a, c);
@@ -738,12 +738,15 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
     s->w64[3].assign((size_t)(1ull << k) * 12 * 4, 0);  // output rows
     s->a32[1].assign(chunks.size() + 1, 0);      // chunk_m
     s->a32[2].assign(n_rows + 1, 0);             // row_code
+    s->a32[3].assign(chunks.size() + 1, 0);      // chunk_state
+    s->bca_map.assign((chunks.size() + 1) * BCA_MAP_STRIDE, 0);
     s->a8.assign(2 * n_rows + 2, 0);             // track
     BcaArgs& a = s->bca;
     a.in_rows = s->a64[0].data(); a.offsets = s->a64[1].data(); a.lengths = s->a64[2].data(); a.n_in = n_rows; a.n_codes = n_codes; a.n_out = 1ull << k;
     a.rpow = s->a64[3].data(); a.chunks = chunks.data(); a.code_chunk0 = s->a32[0].data(); a.n_chunks = chunks.size();
     a.track = s->a8.data(); a.chunk_acc = s->w64[0].data(); a.chunk_m = s->a32[1].data(); a.chunk_in = s->w64[1].data(); a.rlc = s->w64[2].data();
     a.row_code = s->a32[2].data(); a.rows = s->w64[3].data();
+    a.chunk_map = s->bca_map.data(); a.chunk_state = s->a32[3].data();
     s->pass = bytecode_assign_pass;
     s->assign_kind = 2;
     *out = s;

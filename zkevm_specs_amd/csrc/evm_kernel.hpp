@@ -40,8 +40,13 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
     // per cell, a wavefront of SHA3 / EXP steps took 150k-220k clocks).
     const bool staged_launch = G == EVM_GROUP_ALL || (G == EVM_GROUP_WARM && BLOCK == EVM_HOT_BLOCK && a.perm != nullptr);
     __shared__ u32 s_stage[(G == EVM_GROUP_ALL || (G == EVM_GROUP_WARM && BLOCK == EVM_HOT_BLOCK)) ? EVM_STAGE_ENTRIES * EVM_STAGE_STRIDE : 1];
-    if (staged_launch) {  // the grid covers every pair of the range: one step per lane
-        if ((u64)lo + (u64)blockIdx.x * blockDim.x >= (u64)hi) return;  // the grid is sized for the largest possible range / padding
+    if (staged_launch) {  // one step per lane.  Hot: the grid covers every pair of the range.  Warm: the launch may be smaller than the
+        // range (its size is not known to the host before the session's first collect: a capped grid instead of one block per
+        // 128 pairs of the whole trace, most of which would only find the range empty) and walks it block-stride
+      for (u32 vblock = blockIdx.x;; vblock += gridDim.x) {
+        t = (u64)lo + (u64)vblock * blockDim.x + threadIdx.x;
+        if ((u64)lo + (u64)vblock * blockDim.x >= (u64)hi) return;  // the grid is sized for the largest possible range / padding
+        if (G != EVM_GROUP_ALL && vblock != blockIdx.x) __syncthreads();  // the stage columns of the previous iteration are done with
         if (G != EVM_GROUP_ALL) perm_t = t < (u64)hi ? a.perm[t] : 0u;
         if (G == EVM_GROUP_ALL && EV_PROF_ON(a)) {  // tuning aid: entry stamps (core clock, 100 MHz wall clock)
             a.prof[EV_PROF_WAVE * 8 + 5] = __builtin_readcyclecounter();
@@ -88,6 +93,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
         }
         tally_commit(tally, idx, code);
         if (G == EVM_GROUP_ALL && EV_PROF_ON(a)) a.prof[EV_PROF_WAVE * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        if (G == EVM_GROUP_ALL) return;
+      }
     } else {  // small grid, grid-stride loop
         const u64 stride = (u64)gridDim.x * blockDim.x;
         for (; t < (u64)hi; t += stride) {

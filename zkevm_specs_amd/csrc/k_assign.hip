@@ -114,10 +114,6 @@ __global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u3
 __global__ void bca_rpow_kernel(Fr r, u64* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) bca_fill_rpow(r, out);
 }
-__global__ void bca_track_kernel(BcaArgs a) {
-    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < a.n_codes) bca_track_code(a, j);
-}
 __global__ void bca_chunk_kernel(BcaArgs a) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < a.n_chunks) bca_chunk(a, c);
@@ -164,7 +160,6 @@ void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernel
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally) {
     const u32 gc = (u32)((a.n_codes + 63) / 64), gk = (u32)((a.n_chunks + 63) / 64);
     if (a.n_codes) {
-        hipLaunchKernelGGL(bca_track_kernel, dim3(gc), dim3(64), 0, st, a);
         hipLaunchKernelGGL(bca_chunk_kernel, dim3(gk ? gk : 1), dim3(64), 0, st, a);
         hipLaunchKernelGGL(bca_prefix_kernel, dim3(gc), dim3(64), 0, st, a);
         hipLaunchKernelGGL(bca_rlc_kernel, dim3(gk ? gk : 1), dim3(64), 0, st, a);

@@ -7,7 +7,8 @@
 void zk_launch_evm_warm(hipStream_t st, u32 grid, u32 warm_lanes, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1) {
     if (a.perm) {
         const u32 lanes = warm_lanes ? warm_lanes : a.n_pairs;
-        const u32 g = (lanes + EVM_HOT_BLOCK - 1) / EVM_HOT_BLOCK;
+        u32 g = (lanes + EVM_HOT_BLOCK - 1) / EVM_HOT_BLOCK;
+        if (!warm_lanes && g > 512u) g = 512u;  // range not known yet: a capped grid that walks the range block-stride (evm_kernel.hpp)
         if (e1)
             hipExtLaunchKernelGGL(HIP_KERNEL_NAME(evm_steps_kernel<EVM_GROUP_WARM, 1, EVM_HOT_BLOCK>), dim3(g), dim3(EVM_HOT_BLOCK), 0, st, nullptr, e1, 0, a, group_start, status, tally);
         else

@@ -1492,6 +1492,10 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
         a.chunk_acc = (u64*)d;
         if ((rc = dev_alloc(s, &d, chunks.size() * 4))) goto fail;
         a.chunk_m = (u32*)d;
+        if ((rc = dev_alloc(s, &d, chunks.size() * (size_t)BCA_MAP_STRIDE))) goto fail;
+        a.chunk_map = (uint8_t*)d;
+        if ((rc = dev_alloc(s, &d, chunks.size() * 4))) goto fail;
+        a.chunk_state = (u32*)d;
         if ((rc = dev_alloc(s, &d, chunks.size() * 32))) goto fail;
         a.chunk_in = (u64*)d;
         if ((rc = dev_alloc(s, &d, (size_t)n_rows * 32))) goto fail;
