@@ -78,7 +78,8 @@ void zk_shutdown(void);
 int zk_set_stream(void* hip_stream);
 const char* zk_last_error(void);
 /* BN254-Fr vector ops on the device: op 0 add, 1 sub, 2 mul, 3 montmul, 4 neg, 5 inv (of a; inv(0) = 0 as py_ecc's
- * prime_field_inv), 6 div (a * inv(b)).
+ * prime_field_inv), 6 div (a * inv(b)); 16 / 17: the secp256k1 BASE-field product a * b / square a^2 mod 2^256 - 2^32 - 977
+ * (operands are residues below that prime; unit-test hooks of the ECDSA kernel's multiplier).
  * (reference: FQ.__add__/__sub__/__mul__/__neg__/__truediv__ via py_ecc and FQ.inv, util/arithmetic.py:41-60) */
 int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts);
 

@@ -331,3 +331,24 @@ def test_config4_signed_txs_end_to_end_on_device():
     idx = np.arange(0, n, 257)
     st = dev["meta"].cpu().numpy().view(np.uint32)[idx, 0].tolist()
     assert st == E.verify_packed(_packed_from_units(w["bytes"][idx], False))
+
+
+@pytest.mark.gpu
+def test_secp_base_field_product_on_device():
+    """csrc/secp256k1.hpp `sp_mul_p` / `sp_sqr_p` as the ECDSA kernel runs them (product scanning + the explicit carry-chain fold of
+    round 4) against Python integers: random residues and the operands that exercise every branch of the fold — products whose high
+    half is all ones, results in [P, 2^256), the double wrap past 2^256."""
+    import random
+
+    from oracle import wire
+    from zkevm_specs_amd import engine
+
+    P = 2**256 - 2**32 - 977
+    rng = random.Random(41)
+    edge = [0, 1, 2, P - 1, P - 2, 2**32 + 977, 2**32 + 976, 2**255, 2**256 - 2**33, P - 2**32, 977, 2**128, 2**128 - 1, (P - 1) // 2,
+            (P + 1) // 2, 2**224 - 1, 2**192 + 12345]
+    a = edge * len(edge) + [rng.randrange(P) for _ in range(20000)] + [P - 1 - rng.randrange(2**40) for _ in range(2000)]
+    b = [y for y in edge for _ in edge] + [rng.randrange(P) for _ in range(20000)] + [P - 1 - rng.randrange(2**40) for _ in range(2000)]
+    A, B = wire.ints_to_cells(a), wire.ints_to_cells(b)
+    assert wire.cells_to_ints(engine.fr_op(16, A, B)) == [x * y % P for x, y in zip(a, b)]
+    assert wire.cells_to_ints(engine.fr_op(17, A, B)) == [x * x % P for x in a]

@@ -111,6 +111,98 @@ __device__ __forceinline__ void zk_load16x16(const u64* p, zk_u32x4 (&x)[16]) { 
         : "v"(p)
         : "memory");
 }
+__device__ __forceinline__ void zk_load10x16(const u64* p, zk_u32x4 (&x)[10]) {  // 160 contiguous bytes, one wait
+    asm volatile(
+        "global_load_dwordx4 %0, %10, off\n\t"
+        "global_load_dwordx4 %1, %10, off offset:16\n\t"
+        "global_load_dwordx4 %2, %10, off offset:32\n\t"
+        "global_load_dwordx4 %3, %10, off offset:48\n\t"
+        "global_load_dwordx4 %4, %10, off offset:64\n\t"
+        "global_load_dwordx4 %5, %10, off offset:80\n\t"
+        "global_load_dwordx4 %6, %10, off offset:96\n\t"
+        "global_load_dwordx4 %7, %10, off offset:112\n\t"
+        "global_load_dwordx4 %8, %10, off offset:128\n\t"
+        "global_load_dwordx4 %9, %10, off offset:144\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void zk_load22x16(const u64* p, zk_u32x4 (&x)[22]) {  // 352 contiguous bytes, one wait
+    asm volatile(
+        "global_load_dwordx4 %0, %22, off\n\t"
+        "global_load_dwordx4 %1, %22, off offset:16\n\t"
+        "global_load_dwordx4 %2, %22, off offset:32\n\t"
+        "global_load_dwordx4 %3, %22, off offset:48\n\t"
+        "global_load_dwordx4 %4, %22, off offset:64\n\t"
+        "global_load_dwordx4 %5, %22, off offset:80\n\t"
+        "global_load_dwordx4 %6, %22, off offset:96\n\t"
+        "global_load_dwordx4 %7, %22, off offset:112\n\t"
+        "global_load_dwordx4 %8, %22, off offset:128\n\t"
+        "global_load_dwordx4 %9, %22, off offset:144\n\t"
+        "global_load_dwordx4 %10, %22, off offset:160\n\t"
+        "global_load_dwordx4 %11, %22, off offset:176\n\t"
+        "global_load_dwordx4 %12, %22, off offset:192\n\t"
+        "global_load_dwordx4 %13, %22, off offset:208\n\t"
+        "global_load_dwordx4 %14, %22, off offset:224\n\t"
+        "global_load_dwordx4 %15, %22, off offset:240\n\t"
+        "global_load_dwordx4 %16, %22, off offset:256\n\t"
+        "global_load_dwordx4 %17, %22, off offset:272\n\t"
+        "global_load_dwordx4 %18, %22, off offset:288\n\t"
+        "global_load_dwordx4 %19, %22, off offset:304\n\t"
+        "global_load_dwordx4 %20, %22, off offset:320\n\t"
+        "global_load_dwordx4 %21, %22, off offset:336\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17]), "=&v"(x[18]), "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void zk_load28x16(const u64* p, zk_u32x4 (&x)[28]) {  // 448 contiguous bytes, one wait
+    asm volatile(
+        "global_load_dwordx4 %0, %28, off\n\t"
+        "global_load_dwordx4 %1, %28, off offset:16\n\t"
+        "global_load_dwordx4 %2, %28, off offset:32\n\t"
+        "global_load_dwordx4 %3, %28, off offset:48\n\t"
+        "global_load_dwordx4 %4, %28, off offset:64\n\t"
+        "global_load_dwordx4 %5, %28, off offset:80\n\t"
+        "global_load_dwordx4 %6, %28, off offset:96\n\t"
+        "global_load_dwordx4 %7, %28, off offset:112\n\t"
+        "global_load_dwordx4 %8, %28, off offset:128\n\t"
+        "global_load_dwordx4 %9, %28, off offset:144\n\t"
+        "global_load_dwordx4 %10, %28, off offset:160\n\t"
+        "global_load_dwordx4 %11, %28, off offset:176\n\t"
+        "global_load_dwordx4 %12, %28, off offset:192\n\t"
+        "global_load_dwordx4 %13, %28, off offset:208\n\t"
+        "global_load_dwordx4 %14, %28, off offset:224\n\t"
+        "global_load_dwordx4 %15, %28, off offset:240\n\t"
+        "global_load_dwordx4 %16, %28, off offset:256\n\t"
+        "global_load_dwordx4 %17, %28, off offset:272\n\t"
+        "global_load_dwordx4 %18, %28, off offset:288\n\t"
+        "global_load_dwordx4 %19, %28, off offset:304\n\t"
+        "global_load_dwordx4 %20, %28, off offset:320\n\t"
+        "global_load_dwordx4 %21, %28, off offset:336\n\t"
+        "global_load_dwordx4 %22, %28, off offset:352\n\t"
+        "global_load_dwordx4 %23, %28, off offset:368\n\t"
+        "global_load_dwordx4 %24, %28, off offset:384\n\t"
+        "global_load_dwordx4 %25, %28, off offset:400\n\t"
+        "global_load_dwordx4 %26, %28, off offset:416\n\t"
+        "global_load_dwordx4 %27, %28, off offset:432\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15]), "=&v"(x[16]), "=&v"(x[17]), "=&v"(x[18]), "=&v"(x[19]), "=&v"(x[20]), "=&v"(x[21]), "=&v"(x[22]), "=&v"(x[23]), "=&v"(x[24]), "=&v"(x[25]), "=&v"(x[26]), "=&v"(x[27])
+        : "v"(p)
+        : "memory");
+}
+// whole row of an NCELLS-cell table in one round trip (the loaders above exist for the cell counts that need it)
+template <int NCHUNKS>
+__device__ __forceinline__ void zk_load_row(const u64* p, zk_u32x4 (&x)[NCHUNKS]) {
+    if constexpr (NCHUNKS == 10) zk_load10x16(p, x);
+    else if constexpr (NCHUNKS == 22) zk_load22x16(p, x);
+    else if constexpr (NCHUNKS == 28) zk_load28x16(p, x);
+    else {
+#pragma unroll
+        for (int k = 0; k < NCHUNKS; k++) x[k] = reinterpret_cast<const zk_u32x4*>(p)[k];
+    }
+}
 template <int N>
 __device__ __forceinline__ u32 zk_cells_diff(const zk_u32x4 (&x)[N], u32 c, const Fr* q, u32 mask) {  // N / 2 cells from cell c on
     u32 diff = 0;

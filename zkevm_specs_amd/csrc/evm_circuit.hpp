@@ -434,44 +434,72 @@ ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u
 // warm kernel's scratch) and the candidate row is compared in 4-cell groups — the loads of a group in flight together,
 // folded into one difference word — instead of one dependent round trip per cell.  Same verdicts as table_probe_generic.
 template <int NCELLS, u32 MASK>
-ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS]) {
+ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
+                              int out1_cell = 0) {
 #if EVM_FAST
     I.defer = 2u;
     I.seq++;
     return 0u;
 #endif
 #ifdef ZK_WARM_GENERIC_LOOKUP  // tuning build: the out-of-line generic probe, for A / B timelines
-    return table_lookup<NCELLS>(I, t, h, q, MASK);
+    {
+        const u32 rg = table_lookup<NCELLS>(I, t, h, q, MASK);
+        if (out0) *out0 = zk_table_cell(t, rg, out0_cell);
+        if (out1) *out1 = zk_table_cell(t, rg, out1_cell);
+        return rg;
+    }
 #endif
     I.seq++;
     u32 found = ZK_EMPTY_SLOT;
     bool ambiguous = false;
+    if (out0) *out0 = fr_zero();
+    if (out1) *out1 = fr_zero();
     if (t.n != 0) {
         u32 slot = (u32)h & t.mask;
+        // two dependent round trips per probe: the slot and its successor together (an empty successor ends the probe sequence
+        // without a trip of its own), then the candidate's whole row in one batch — compared in registers, and the cells the
+        // caller wants back (out0 / out1) taken from the same batch
+        u32 r = t.slots[slot], r_next = t.slots[(slot + 1) & t.mask];
         for (u32 probes = 0; probes <= t.mask; probes++) {
-            const u32 r = t.slots[slot];
             if (r == ZK_EMPTY_SLOT) break;
-            const uint4* p = reinterpret_cast<const uint4*>(t.cells + (u64)r * NCELLS * 4);
+            const u64* p = t.cells + (u64)r * NCELLS * 4;
             u32 diff = 0;
+#ifndef ZK_HOSTSIM
+            zk_u32x4 x[2 * NCELLS];
+            zk_load_row<2 * NCELLS>(p, x);
 #pragma unroll
-            for (int g = 0; g < NCELLS; g += 4) {
-                if (((MASK >> g) & 0xfu) == 0u || diff != 0u) continue;
-                uint4 x[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (g + (k >> 1) < NCELLS && ((MASK >> (g + (k >> 1))) & 1u)) x[k] = p[2 * g + k];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (g + (k >> 1) < NCELLS && ((MASK >> (g + (k >> 1))) & 1u)) {
-                        const u32* qq = q[g + (k >> 1)].v + (k & 1) * 4;
-                        diff |= (x[k].x ^ qq[0]) | (x[k].y ^ qq[1]) | (x[k].z ^ qq[2]) | (x[k].w ^ qq[3]);
-                    }
-            }
+            for (int k = 0; k < 2 * NCELLS; k++)
+                if ((MASK >> (k >> 1)) & 1u) {
+                    const u32* qq = q[k >> 1].v + (k & 1) * 4;
+                    diff |= (x[k].x ^ qq[0]) | (x[k].y ^ qq[1]) | (x[k].z ^ qq[2]) | (x[k].w ^ qq[3]);
+                }
+#else
+            for (int c = 0; c < NCELLS; c++)
+                if ((MASK >> c) & 1u) {
+                    const Fr cell = fr_load(p + 4 * c);
+                    for (int k = 0; k < 8; k++) diff |= cell.v[k] ^ q[c].v[k];
+                }
+#endif
             if (diff == 0u) {
-                if (found == ZK_EMPTY_SLOT) found = r;
-                else if (!rows_identical(t, found, r)) ambiguous = true;
+                if (found == ZK_EMPTY_SLOT) {
+                    found = r;
+#ifndef ZK_HOSTSIM
+#pragma unroll
+                    for (int c = 0; c < NCELLS; c++) {  // (out*_cell are compile-time constants at every call site)
+                        if (out0 && c == out0_cell) { for (int k = 0; k < 4; k++) { out0->v[k] = x[2 * c][k]; out0->v[4 + k] = x[2 * c + 1][k]; } }
+                        if (out1 && c == out1_cell) { for (int k = 0; k < 4; k++) { out1->v[k] = x[2 * c][k]; out1->v[4 + k] = x[2 * c + 1][k]; } }
+                    }
+#else
+                    if (out0) *out0 = fr_load(p + 4 * out0_cell);
+                    if (out1) *out1 = fr_load(p + 4 * out1_cell);
+#endif
+                } else if (!rows_identical(t, found, r)) {
+                    ambiguous = true;
+                }
             }
             slot = (slot + 1) & t.mask;
+            r = r_next;
+            if (r != ZK_EMPTY_SLOT) r_next = t.slots[(slot + 1) & t.mask];
         }
     }
     if (found == ZK_EMPTY_SLOT) { ev_fail(I, ZK_LOOKUP_UNSAT); return 0u; }
@@ -822,10 +850,8 @@ ZK_HD CopyRes copy_lookup(Ins& I, const Word& src_id, u32 src_tag, const Word& d
     q[CT_SRC_ADDR] = src_addr; q[CT_SRC_ADDR_END] = src_addr_end; q[CT_DST_ADDR] = dst_addr;
     q[CT_LENGTH] = length; q[CT_RLC_ACC] = fr_zero(); q[CT_RWC] = rw_counter; q[CT_RWC_INC] = fr_zero();
     constexpr u32 mask = ((1u << COPY_T_NCELLS) - 1u) & ~((1u << CT_IS_FIRST) | (1u << CT_RLC_ACC) | (1u << CT_RWC_INC));
-    u32 r = table_lookup_inline<COPY_T_NCELLS, mask>(I, I.a->copy, copy_key_hash_cells(rw_counter, src_addr), q);
     CopyRes R;
-    R.rwc_inc = zk_table_cell(I.a->copy, r, CT_RWC_INC);
-    R.rlc_acc = zk_table_cell(I.a->copy, r, CT_RLC_ACC);
+    table_lookup_inline<COPY_T_NCELLS, mask>(I, I.a->copy, copy_key_hash_cells(rw_counter, src_addr), q, &R.rwc_inc, CT_RWC_INC, &R.rlc_acc, CT_RLC_ACC);
     return R;
 }
 ZK_HD Word word_value(const Fr& v) { return word_of(v, fr_zero()); }  // WordOrValue(FQ): hi cell is 0
@@ -833,8 +859,9 @@ ZK_HD Word word_value(const Fr& v) { return word_of(v, fr_zero()); }  // WordOrV
 ZK_HD Word keccak_lookup(Ins& I, const Fr& length, const Fr& value_rlc) {
     Fr q[KECCAK_NCELLS];
     q[0] = fr_u(2); q[1] = value_rlc; q[2] = length; q[3] = fr_zero(); q[4] = fr_zero();
-    u32 r = table_lookup_inline<KECCAK_NCELLS, 0x7u>(I, I.a->keccak, keccak_key_hash_cells(value_rlc, length), q);
-    return word_of(zk_table_cell(I.a->keccak, r, 3), zk_table_cell(I.a->keccak, r, 4));
+    Word out;
+    table_lookup_inline<KECCAK_NCELLS, 0x7u>(I, I.a->keccak, keccak_key_hash_cells(value_rlc, length), q, &out.lo, 3, &out.hi, 4);
+    return out;
 }
 // Tables.exp_lookup (table.py:797-814): is_step = 1, identifier, is_last, base limbs, exponent -> exponentiation
 ZK_HD Word exp_lookup(Ins& I, const Fr& identifier, const Fr& is_last, const u64 base_limbs[4], const Word& exponent) {
@@ -842,8 +869,9 @@ ZK_HD Word exp_lookup(Ins& I, const Fr& identifier, const Fr& is_last, const u64
     q[XT_IS_STEP] = fr_u(1); q[XT_ID] = identifier; q[XT_IS_LAST] = is_last;
     for (int k = 0; k < 4; k++) q[XT_BASE0 + k] = fr_u(base_limbs[k]);
     q[XT_EXP_LO] = exponent.lo; q[XT_EXP_HI] = exponent.hi; q[XT_RES_LO] = fr_zero(); q[XT_RES_HI] = fr_zero();
-    u32 r = table_lookup_inline<EXP_T_NCELLS, 0x1ffu>(I, I.a->exp, expt_key_hash_cells(identifier, is_last, exponent.lo), q);
-    return word_of(zk_table_cell(I.a->exp, r, XT_RES_LO), zk_table_cell(I.a->exp, r, XT_RES_HI));
+    Word out;
+    table_lookup_inline<EXP_T_NCELLS, 0x1ffu>(I, I.a->exp, expt_key_hash_cells(identifier, is_last, exponent.lo), q, &out.lo, XT_RES_LO, &out.hi, XT_RES_HI);
+    return out;
 }
 
 // Tables.sig_lookup (table.py:816-833) and ecc_lookup (:835-858): the query names every field of the row

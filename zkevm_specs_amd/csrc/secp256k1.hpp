@@ -241,13 +241,123 @@ __device__ __forceinline__ void sp_mul_wide(const Fr& a, const Fr& b, u32* t) {
     t[15] = (u32)acc;
 }
 #endif
+#ifndef ZK_HOSTSIM
+// ---- the fold as explicit carry chains (round 4).  The C form above compiled to ~160 instructions per product (64-bit adds in
+// register pairs around every 977-multiply, a branch for the rare wrap, a compare + subtract + select at the end).  Here:
+//   m = hi * 977                      eight v_mad_u64_u32 chained through their high halves (m: nine limbs)
+//   r = lo + m + (hi << 32)           two add-with-carry chains over ten limbs
+//   s = r[0..7] + v * 977 + (v << 32) v = r[8..9] < 2^34: one 64-bit multiply, one carry chain
+//   a carry out of s (s is tiny then) and the final "s >= P" both add 2^32 + 977: s >= P  <=>  s + 2^32 + 977 carries out of 2^256
+// ~70 instructions.  Carries live in VCC; every chain is one asm statement.
+__device__ __forceinline__ Fr sp_fold_p_chain(const u32* t) {
+    u32 m[9];
+    {
+        u64 c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c = (u64)t[8 + k] * 977ull + (c >> 32);
+            m[k] = (u32)c;
+        }
+        m[8] = (u32)(c >> 32);
+    }
+    u32 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9;
+    // r = lo + m (nine limbs), then += hi << 32 (limbs 1..8, carry into limb 9).  (VOP2: src1 is a VGPR, constants go first)
+    asm("v_add_co_u32 %0, vcc, %10, %18\n\t"
+        "v_addc_co_u32 %1, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %15, %23, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %16, %24, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %17, %25, vcc\n\t"
+        "v_addc_co_u32 %8, vcc, 0, %26, vcc\n\t"
+        "v_add_co_u32 %1, vcc, %1, %27\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %28, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %29, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %30, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %5, %31, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %6, %32, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %7, %33, vcc\n\t"
+        "v_addc_co_u32 %8, vcc, %8, %34, vcc\n\t"
+        "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]),
+          "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]),
+          "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]), "v"(t[14]), "v"(t[15])
+        : "vcc");
+    // second fold: v = r8 + r9 * 2^32 (< 2^34): s = r[0..7] + v * 977 + (v << 32)
+    const u64 v977 = ((u64)r8 | ((u64)r9 << 32)) * 977ull;  // < 2^44
+    const u32 a0 = (u32)v977, a1 = (u32)(v977 >> 32);
+    u32 s0, s1, s2, s3, s4, s5, s6, s7, cy, cy2;
+    asm("v_add_co_u32 %0, vcc, %10, %18\n\t"
+        "v_addc_co_u32 %1, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %12, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %13, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %14, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %15, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, 0, %16, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, 0, %17, vcc\n\t"
+        "v_addc_co_u32_e64 %8, vcc, 0, 0, vcc\n\t"
+        "v_add_co_u32 %1, vcc, %1, %20\n\t"      // + (v << 32): limb 1 += r8, limb 2 += r9
+        "v_addc_co_u32 %2, vcc, %2, %21, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
+        "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(s4), "=&v"(s5), "=&v"(s6), "=&v"(s7), "=&v"(cy), "=&v"(cy2)
+        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(a0), "v"(a1), "v"(r8), "v"(r9)
+        : "vcc");
+    // wrapped past 2^256 (at most once over the two chains; s is tiny then): + (2^32 + 977), no further carry.  Then
+    // s >= P  <=>  s + 2^32 + 977 >= 2^256: the sum's low 256 bits are s - P
+    const u32 w = cy + cy2;  // 0 or 1
+    const u32 w977 = w * 977u;
+    u32 q0, q1, q2, q3, q4, q5, q6, q7;
+    Fr out;
+    asm("v_add_co_u32 %16, vcc, %16, %24\n\t"
+        "v_addc_co_u32 %17, vcc, %17, %25, vcc\n\t"
+        "v_addc_co_u32 %18, vcc, 0, %18, vcc\n\t"
+        "v_addc_co_u32 %19, vcc, 0, %19, vcc\n\t"
+        "v_addc_co_u32 %20, vcc, 0, %20, vcc\n\t"
+        "v_addc_co_u32 %21, vcc, 0, %21, vcc\n\t"
+        "v_addc_co_u32 %22, vcc, 0, %22, vcc\n\t"
+        "v_addc_co_u32 %23, vcc, 0, %23, vcc\n\t"
+        "v_add_co_u32 %0, vcc, 0x3d1, %16\n\t"
+        "v_addc_co_u32 %1, vcc, 1, %17, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, 0, %18, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %19, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %20, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %21, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, 0, %22, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, 0, %23, vcc\n\t"
+        "v_cndmask_b32 %8, %16, %0, vcc\n\t"
+        "v_cndmask_b32 %9, %17, %1, vcc\n\t"
+        "v_cndmask_b32 %10, %18, %2, vcc\n\t"
+        "v_cndmask_b32 %11, %19, %3, vcc\n\t"
+        "v_cndmask_b32 %12, %20, %4, vcc\n\t"
+        "v_cndmask_b32 %13, %21, %5, vcc\n\t"
+        "v_cndmask_b32 %14, %22, %6, vcc\n\t"
+        "v_cndmask_b32 %15, %23, %7, vcc"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7),
+          "=&v"(out.v[0]), "=&v"(out.v[1]), "=&v"(out.v[2]), "=&v"(out.v[3]), "=&v"(out.v[4]), "=&v"(out.v[5]), "=&v"(out.v[6]), "=&v"(out.v[7]),
+          "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)
+        : "v"(w977), "v"(w)
+        : "vcc");
+    return out;
+}
+#endif
 // a * b mod P for P = 2^256 - 2^32 - 977 (plain residues, a, b < P, result < P): 8 x 8 schoolbook product, then the high
 // half is folded twice with 2^256 = 2^32 + 977 (mod P) — 72 multiply-adds instead of the 128 of a Montgomery product
 ZK_HD Fr sp_mul_p(Fr a, Fr b) {  // inlined (round 3): the call's argument / result moves were ~6 % of a product; the kernel grows to 240 KB, measured +3 %
     u32 t[16];
 #ifndef ZK_HOSTSIM
     sp_mul_wide(a, b, t);
+#ifdef ZK_SECP_FOLD_C
     return sp_fold_p(t);
+#else
+    return sp_fold_p_chain(t);
+#endif
 #endif
 #pragma unroll
     for (int i = 0; i < 16; i++) t[i] = 0;
@@ -272,7 +382,11 @@ ZK_HD Fr sp_sqr_p(Fr a) {
     // (on the device the product-scanning multiplier is shorter than this specialised form: 164 instructions for the product
     // against ~190; a squaring that doubles the cross products pays more per column than it saves)
     sp_mul_wide(a, a, t);
+#ifdef ZK_SECP_FOLD_C
     return sp_fold_p(t);
+#else
+    return sp_fold_p_chain(t);
+#endif
 #endif
 #pragma unroll
     for (int i = 0; i < 16; i++) t[i] = 0;

@@ -452,6 +452,8 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
     case 4: r = fr_neg(x); break;
     case 5: r = fr_inv(x); break;
     case 6: r = fr_div(x, y); break;
+    case 16: r = sp_mul_p(x, y); break;   // secp256k1 base field (unit-test hooks of csrc/secp256k1.hpp): a * b mod P, residues in and out
+    case 17: r = sp_sqr_p(x); break;
     default: r = fr_zero();
     }
     for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
