@@ -295,48 +295,62 @@ def build_state(ctx, log_rows, strong):
 class TxSigPass:
     """BASELINE configs[3]: one pass = the Tx circuit (tx_circuit.py:253-291) AND the Sig circuit (sig_circuit.py:113-122) over
     the same 2^k signed transactions, each circuit verifying its own chips' signatures as the reference does: secp256k1 ECDSA
-    verification (fills the units' ecdsa_status column in HBM) + the SignVerify / Row.verify kernel.  The two circuits are
-    independent, so they run on two streams."""
+    verification (fills the units' ecdsa_status column in HBM) + the SignVerify / Row.verify kernel.  The signatures of both
+    circuits go through ONE ECDSA launch; the two row kernels then run on two streams."""
 
     def __init__(self, ctx, d_tx, d_sig, r):
         from zkevm_specs_amd import engine
 
         torch, dev = ctx.torch, ctx.local_rank
         self.n = int(d_tx["bytes"].shape[0])
-        self.ecdsa_tx = engine.open_ecdsa(d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4, device=dev)
+        # ONE ECDSA launch for the chips of both circuits (zk_ecdsa_open_batches: 2 x 2^14 signatures in one dispatch take 1.4 ms,
+        # two concurrent launches 1.9 ms each), each circuit's verdict column filled in its own units
+        tx_b = dict(sig_bytes=d_tx["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS, out_dev=d_tx["meta"], out_stride=4)
+        if d_sig is not None:
+            # the chips' v: column 3 of the units' meta (a compact copy: the engine reads v[i * v_stride])
+            sig_b = dict(sig_bytes=d_sig["bytes"], v=d_sig["meta"][:, 3].contiguous(), layout=engine.ECDSA_LAYOUT_SIG_UNITS, out_dev=d_sig["meta"],
+                         out_stride=4, v_stride=1)
+            self.ecdsa = engine.open_ecdsa_batches([tx_b, sig_b], device=dev)
+        else:
+            self.ecdsa = engine.open_ecdsa_batches([tx_b], device=dev)
         self.tx = engine.open_sign(d_tx, r, False, device=dev)
-        # the chips' v: column 3 of the units' meta (a compact copy: the engine reads v[i * v_stride])
-        self.ecdsa_sig = engine.open_ecdsa(d_sig["bytes"], v=d_sig["meta"][:, 3].contiguous(), layout=engine.ECDSA_LAYOUT_SIG_UNITS, out_dev=d_sig["meta"],
-                                           out_stride=4, v_stride=1, device=dev) if d_sig is not None else None
         self.sig = engine.open_sign(d_sig, r, True, device=dev) if d_sig is not None else None
         torch.cuda.synchronize()
+        # the two row kernels are independent: the Sig circuit's runs on a side stream that waits for the ECDSA launch
         self._side = torch.cuda.Stream() if d_sig is not None else None
+        self._main = torch.cuda.current_stream()
+        self._ev = torch.cuda.Event() if d_sig is not None else None
+        self._ev_side = None
+        self.torch = torch
         if self._side is not None:
-            self.ecdsa_sig.set_stream(self._side)
             self.sig.set_stream(self._side)
 
     def launch(self):
-        self.ecdsa_tx.launch()
-        if self.ecdsa_sig is not None:
-            self.ecdsa_sig.launch()
-        self.tx.launch()
+        if self.sig is not None and self._ev_side is not None:
+            self._main.wait_event(self._ev_side)  # the previous pass's Sig kernel has read its units' verdict column
+        self.ecdsa.launch()
         if self.sig is not None:
+            self._ev.record(self._main)
+            self._side.wait_event(self._ev)
             self.sig.launch()
+            self._ev_side = self._ev_side or self.torch.cuda.Event()
+            self._ev_side.record(self._side)
+        self.tx.launch()
 
     def collect(self):
-        re_, rs_ = self.ecdsa_tx.collect(), self.tx.collect()
-        rs_.ecdsa_ms = re_.kernel_ms  # a signature that does not verify fails its unit in the Tx kernel already
+        re_, rs_ = self.ecdsa.collect(), self.tx.collect()
+        rs_.ecdsa_ms = re_.kernel_ms  # a signature that does not verify fails its unit in the row kernel already
         rs_.sig_ms = rs_.sig_ecdsa_ms = None
         if self.sig is not None:
-            r2e, r2 = self.ecdsa_sig.collect(), self.sig.collect()
-            rs_.sig_ms, rs_.sig_ecdsa_ms = r2.kernel_ms, r2e.kernel_ms
+            r2 = self.sig.collect()
+            rs_.sig_ms, rs_.sig_ecdsa_ms = r2.kernel_ms, re_.kernel_ms
             if not r2.ok and rs_.ok:
                 rs_.first_fail_row, rs_.first_fail_code = r2.first_fail_row, r2.first_fail_code
             rs_.fail_count += r2.fail_count
         return rs_
 
     def close(self):
-        for s in (self.ecdsa_tx, self.tx, self.ecdsa_sig, self.sig):
+        for s in (self.ecdsa, self.tx, self.sig):
             if s is not None:
                 s.close()
 

@@ -322,6 +322,7 @@ extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, 
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
     EcdsaArgs a;
     a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
+    ecdsa_single_batch(a);
     a.msg_be = layout != 1u;
     for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
     std::vector<u32> tab(15 * 24 * 2);
@@ -334,6 +335,7 @@ extern "C" int sim_ecdsa_verify_pairs(const uint8_t* bytes, u32 layout, const u3
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
     EcdsaArgs a;
     a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
+    ecdsa_single_batch(a);
     a.msg_be = layout != 1u;
     for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
     std::vector<u32> tab(15 * 24 * 2);

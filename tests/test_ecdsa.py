@@ -352,3 +352,37 @@ def test_secp_base_field_product_on_device():
     A, B = wire.ints_to_cells(a), wire.ints_to_cells(b)
     assert wire.cells_to_ints(engine.fr_op(16, A, B)) == [x * y % P for x, y in zip(a, b)]
     assert wire.cells_to_ints(engine.fr_op(17, A, B)) == [x * x % P for x in a]
+
+
+@pytest.mark.gpu
+def test_two_batches_in_one_launch():
+    """zk_ecdsa_open_batches: two signature arrays with different layouts (packed big-endian hashes with recovery ids | Tx units with
+    little-endian hashes) verified by ONE launch: statuses = batch 0's then batch 1's, each batch's verdict column written where
+    that batch asked for it; the same answers as two single-batch sessions and as the oracle."""
+    import torch
+
+    from zkevm_specs_amd import engine
+
+    sigs, v = _hostile_cases(5, 300)
+    exp0 = E.verify_packed(sigs, v)
+    r = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
+    w = synth_tx_witness(257, r, seed=8, signed=True)
+    w["bytes"][7, 7, 0] ^= 1  # a forged r
+    exp1 = engine.ecdsa_status(w["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS).tolist()
+    assert exp1[7] != 0 and sum(1 for e in exp1 if e) == 1
+    # host arrays
+    with engine.open_ecdsa_batches([dict(sig_bytes=sigs, v=v), dict(sig_bytes=w["bytes"], layout=engine.ECDSA_LAYOUT_TX_UNITS)]) as s:
+        res = s.run()
+        got = s.read_status().tolist()
+    assert got == exp0 + exp1 and res.fail_count == sum(1 for e in exp0 + exp1 if e)
+    # device arrays, verdict columns in place
+    d_sigs, d_v = torch.from_numpy(sigs).cuda(), torch.from_numpy(v.view(np.int32)).cuda()
+    d_bytes = torch.from_numpy(w["bytes"]).cuda()
+    out0 = torch.full((len(exp0),), -1, dtype=torch.int32, device="cuda")
+    meta = torch.full((257, 4), -1, dtype=torch.int32, device="cuda")
+    with engine.open_ecdsa_batches([dict(sig_bytes=d_sigs, v=d_v, out_dev=out0), dict(sig_bytes=d_bytes, layout=engine.ECDSA_LAYOUT_TX_UNITS,
+                                                                                       out_dev=meta, out_stride=4)]) as s:
+        s.run()
+    assert out0.cpu().numpy().view(np.uint32).tolist() == exp0
+    m = meta.cpu().numpy().view(np.uint32)
+    assert m[:, 0].tolist() == exp1 and (m[:, 1:] == 0xFFFFFFFF).all()

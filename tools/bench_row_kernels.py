@@ -87,7 +87,7 @@ n_sig = 1 << 14
 sigs = synth_signatures(n_sig, 9)
 packed = np.frombuffer(b"".join(x.to_bytes(32, "little") + y.to_bytes(32, "little") + z.to_bytes(32, "big") + rr.to_bytes(32, "little") +
                                 ss.to_bytes(32, "little") for x, y, z, rr, ss in sigs), dtype=np.uint8).reshape(n_sig, 5, 32).copy()
-for reps in (1, 8):
+for reps in (1, 2, 4, 8):
     d = torch.from_numpy(np.tile(packed, (reps, 1, 1))).cuda()
     run(f"ecdsa_verify_{n_sig * reps}", engine.open_ecdsa(d), n_sig * reps, 160 + 4)
 print(json.dumps(out))

@@ -86,7 +86,7 @@ struct zk_session {
     // owned inputs (kept alive for `row`)
     std::vector<u64> a64[4];
     std::vector<u32> a32[4];
-    std::vector<uint8_t> a8;
+    std::vector<uint8_t> a8, a8b;
     std::vector<uint16_t> a16;
     std::vector<u64> w64[4];              // assignment sessions: work / output buffers
     std::vector<u32> out32;
@@ -582,26 +582,38 @@ extern "C" int zk_keccak_table(const uint8_t* data, uint64_t n_bytes, const uint
 }
 
 // ---- secp256k1 ECDSA verification ---------------------------------------------------------------------------------------
-extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n, uint32_t* out_dev,
-                             uint32_t out_stride, uint32_t opts, zk_session** out) {
-    NO_DEVICE_PTRS(opts, "zk_ecdsa_open");
-    ARG_TRY(out && bytes && n > 0 && n < (1ull << 32) && layout <= 2u && (!v || v_stride >= 1) && !out_dev, "zk_ecdsa_open: bad arguments");
-    (void)out_stride;
+extern "C" int zk_ecdsa_open_batches(const zk_ecdsa_batch* bt, uint32_t n_batches, uint32_t opts, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_ecdsa_open_batches");
+    ARG_TRY(out && bt && (n_batches == 1 || n_batches == 2), "zk_ecdsa_open_batches: one or two batches");
+    u64 n = 0;
+    for (u32 k = 0; k < n_batches; k++) {
+        ARG_TRY(bt[k].bytes && bt[k].n > 0 && bt[k].n < (1ull << 31) && bt[k].layout <= 2u && (!bt[k].v || bt[k].v_stride >= 1) && !bt[k].out_dev,
+                "zk_ecdsa_open: bad arguments");
+        n += bt[k].n;
+    }
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
     zk_session* s = new_session(n, false);
     EcdsaArgs& a = s->ecdsa;
-    a.stride = layout ? 288 : 160;
-    s->a8.assign(bytes, bytes + n * a.stride);
-    if (v) s->a32[0].assign(v, v + n * v_stride);
-    a.bytes = s->a8.data();
-    a.v = v ? s->a32[0].data() : nullptr;
-    a.v_stride = v_stride;
     a.n = n;
+    ecdsa_single_batch(a);
+    a.n0 = bt[0].n;
+    for (u32 k = 0; k < n_batches; k++) {
+        const u64 stride = bt[k].layout ? 288 : 160;
+        std::vector<uint8_t>& hb = k == 0 ? s->a8 : s->a8b;
+        std::vector<u32>& hv = s->a32[k];
+        hb.assign(bt[k].bytes, bt[k].bytes + bt[k].n * stride);
+        if (bt[k].v) hv.assign(bt[k].v, bt[k].v + bt[k].n * bt[k].v_stride);
+        if (k == 0) {
+            a.stride = stride; a.bytes = hb.data(); a.v = bt[k].v ? hv.data() : nullptr; a.v_stride = bt[k].v_stride; a.msg_be = bt[k].layout != 1u;
+            for (int c = 0; c < 5; c++) a.off[c] = OFF[bt[k].layout ? 1 : 0][c];
+        } else {
+            a.stride1 = stride; a.bytes1 = hb.data(); a.v1 = bt[k].v ? hv.data() : nullptr; a.v_stride1 = bt[k].v_stride; a.msg_be1 = bt[k].layout != 1u;
+            for (int c = 0; c < 5; c++) a.off1[c] = OFF[bt[k].layout ? 1 : 0][c];
+        }
+    }
     a.first = 0;
     a.out = nullptr;
     a.out_stride = 0;
-    a.msg_be = layout != 1u;
-    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
     a.qtab = nullptr;
     a.qtab_lanes = 1;
     a.lanes_per_sig = 1;
@@ -611,6 +623,12 @@ extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32
     };
     *out = s;
     return 0;
+}
+extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n, uint32_t* out_dev,
+                             uint32_t out_stride, uint32_t opts, zk_session** out) {
+    zk_ecdsa_batch b;
+    b.bytes = bytes; b.layout = layout; b.v = v; b.v_stride = v_stride; b.n = n; b.out_dev = out_dev; b.out_stride = out_stride;
+    return zk_ecdsa_open_batches(&b, 1, opts, out);
 }
 extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n, uint32_t opts,
                                uint32_t* status_out, zk_result* result) {

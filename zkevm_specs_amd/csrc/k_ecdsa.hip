@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     if (valid && role == 0) {
         code = st == ECDSA_PENDING ? ecdsa_verdict(pr, part) : st;
         if (status) status[i] = code;
-        if (a.out) a.out[i * a.out_stride] = code;
+        if (i < a.n0) { if (a.out) a.out[i * a.out_stride] = code; }
+        else if (a.out1) a.out1[(i - a.n0) * a.out_stride1] = code;
     }
     tally_commit(tally, i, code);
 }

@@ -655,7 +655,29 @@ struct EcdsaArgs {
     u32* qtab;             // per-lane tables of the key's multiples, word w of entry e of lane l at qtab[(e * 24 + w) * qtab_lanes + l]
     u64 qtab_lanes;
     u32 lanes_per_sig;     // 1: one lane runs both halves of the GLV split; 2: a lane pair, one half each
+    // A second batch in the same launch (zk_ecdsa_open_batches): signatures [n0, n) come from these arrays (the Tx circuit's and
+    // the Sig circuit's chips of one block: two launches of 2^14 signatures each ran 1.9 ms side by side where one launch of
+    // 2^15 takes 1.4 ms — 1,024 wavefronts placed one per SIMD by ONE dispatch).  n0 == n: a single batch.
+    u64 n0;
+    const uint8_t* bytes1;
+    u64 stride1;
+    u32 off1[5];
+    u32 msg_be1;
+    const u32* v1;
+    u32 v_stride1;
+    u32* out1;
+    u32 out_stride1;
 };
+#if defined(ZK_HOSTSIM)
+static inline
+#else
+__host__ __device__ inline
+#endif
+void ecdsa_single_batch(EcdsaArgs& a) {  // callers that fill the first batch only (host code)
+    a.n0 = a.n;
+    a.bytes1 = nullptr; a.stride1 = 0; a.msg_be1 = 0; a.v1 = nullptr; a.v_stride1 = 0; a.out1 = nullptr; a.out_stride1 = 0;
+    for (int k = 0; k < 5; k++) a.off1[k] = 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Joint multiplication u1 G + u2 Q for keys ON the curve (there every correct group law gives eth-keys' point).
@@ -804,12 +826,16 @@ ZK_HD u32 sp_digit4(const Fr& k, int w) { return (k.v[w >> 3] >> ((w & 7) * 4)) 
 // Validation + scalars.  ECDSA_PENDING: the key is on the curve and `pr` is filled for ecdsa_partial; any other value is
 // the final status (the case-exact path ran here).
 ZK_HD u32 ecdsa_prepare(const EcdsaArgs& a, u64 i, EcdsaPrep& pr, bool run_exact_path) {
-    const uint8_t* base = a.bytes + i * a.stride;
-    Fr pkx = sp_load_le(base + a.off[0]), pky = sp_load_le(base + a.off[1]);
-    const Fr z = a.msg_be ? sp_load_be(base + a.off[2]) : sp_load_le(base + a.off[2]);
-    const Fr r = sp_load_le(base + a.off[3]), s = sp_load_le(base + a.off[4]);
+    const bool second = i >= a.n0;
+    const u64 li = second ? i - a.n0 : i;
+    const uint8_t* base = second ? a.bytes1 + li * a.stride1 : a.bytes + li * a.stride;
+    const u32* off = second ? a.off1 : a.off;
+    Fr pkx = sp_load_le(base + off[0]), pky = sp_load_le(base + off[1]);
+    const Fr z = (second ? a.msg_be1 : a.msg_be) ? sp_load_be(base + off[2]) : sp_load_le(base + off[2]);
+    const Fr r = sp_load_le(base + off[3]), s = sp_load_le(base + off[4]);
     const Fr n = SecpN::mod(), p = SecpP::mod();
-    if (a.v && a.v[i * a.v_stride] > 1u) return ECDSA_BAD_SIGNATURE;
+    const u32* vv = second ? a.v1 : a.v;
+    if (vv && vv[li * (second ? a.v_stride1 : a.v_stride)] > 1u) return ECDSA_BAD_SIGNATURE;
     // validate_signature_r_or_s: 0 < value < N
     if (!fr_lt(r, n) || !fr_lt(s, n) || fr_is_zero(r) || fr_is_zero(s)) return ECDSA_BAD_SIGNATURE;
     // A coordinate >= P (the native backend does not range-check public-key bytes): every formula of eth-keys' Jacobian chain

@@ -1366,14 +1366,18 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
 }
 
 // ---- secp256k1 ECDSA verification
-extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
-                             uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out) {
+extern "C" int zk_ecdsa_open_batches(const zk_ecdsa_batch* bt, uint32_t n_batches, uint32_t opts, zk_session** out) {
     ARG_TRY(t_device >= 0, "zk_ecdsa_open: call zk_init first");
     HIP_TRY(hipSetDevice(t_device));
-    ARG_TRY(out && bytes && n > 0 && n < (1ull << 32) && layout <= 2u && (!v || v_stride >= 1), "zk_ecdsa_open: bad arguments");
+    ARG_TRY(out && bt && (n_batches == 1 || n_batches == 2), "zk_ecdsa_open_batches: one or two batches");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
-    ARG_TRY(dev || !out_dev, "zk_ecdsa_open: out_dev needs ZK_OPT_DEVICE_PTRS");
-    ARG_TRY(!out_dev || out_stride >= 1, "zk_ecdsa_open: out_stride must be >= 1");
+    u64 n = 0;
+    for (u32 k = 0; k < n_batches; k++) {
+        ARG_TRY(bt[k].bytes && bt[k].n > 0 && bt[k].n < (1ull << 31) && bt[k].layout <= 2u && (!bt[k].v || bt[k].v_stride >= 1), "zk_ecdsa_open: bad arguments");
+        ARG_TRY(dev || !bt[k].out_dev, "zk_ecdsa_open: out_dev needs ZK_OPT_DEVICE_PTRS");
+        ARG_TRY(!bt[k].out_dev || bt[k].out_stride >= 1, "zk_ecdsa_open: out_stride must be >= 1");
+        n += bt[k].n;
+    }
     zk_session* s = new zk_session();
     s->kind = SESSION_ECDSA;
     s->n = n;
@@ -1383,20 +1387,29 @@ extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32
     // layout 0: packed uint8[n][5][32] (msg_hash big-endian); 1 / 2: the Tx / Sig units' byte rows uint8[n][9][32]
     // (rows 2, 3, 5, 7, 8; the Tx chip keeps msg_hash little-endian, the Sig chip big-endian)
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
-    a.stride = layout ? 288 : 160;
-    a.msg_be = layout != 1u;
-    for (int k = 0; k < 5; k++) a.off[k] = OFF[layout ? 1 : 0][k];
-    if ((rc = stage(s, bytes, (size_t)n * a.stride, dev, &p))) goto fail;
-    a.bytes = (const uint8_t*)p;
-    a.v = nullptr;
-    a.v_stride = v_stride;
-    if (v) {
-        if ((rc = stage(s, v, (size_t)n * 4 * v_stride, dev, &p))) goto fail;
-        a.v = (const u32*)p;
-    }
     a.n = n;
-    a.out = out_dev;
-    a.out_stride = out_stride;
+    ecdsa_single_batch(a);
+    a.n0 = bt[0].n;
+    for (u32 k = 0; k < n_batches; k++) {
+        const u64 stride = bt[k].layout ? 288 : 160;
+        const uint8_t* d_bytes;
+        const u32* d_v = nullptr;
+        if ((rc = stage(s, bt[k].bytes, (size_t)bt[k].n * stride, dev, &p))) goto fail;
+        d_bytes = (const uint8_t*)p;
+        if (bt[k].v) {
+            if ((rc = stage(s, bt[k].v, (size_t)bt[k].n * 4 * bt[k].v_stride, dev, &p))) goto fail;
+            d_v = (const u32*)p;
+        }
+        if (k == 0) {
+            a.stride = stride; a.msg_be = bt[k].layout != 1u; a.bytes = d_bytes; a.v = d_v; a.v_stride = bt[k].v_stride;
+            a.out = bt[k].out_dev; a.out_stride = bt[k].out_stride;
+            for (int c = 0; c < 5; c++) a.off[c] = OFF[bt[k].layout ? 1 : 0][c];
+        } else {
+            a.stride1 = stride; a.msg_be1 = bt[k].layout != 1u; a.bytes1 = d_bytes; a.v1 = d_v; a.v_stride1 = bt[k].v_stride;
+            a.out1 = bt[k].out_dev; a.out_stride1 = bt[k].out_stride;
+            for (int c = 0; c < 5; c++) a.off1[c] = OFF[bt[k].layout ? 1 : 0][c];
+        }
+    }
     // lane pairs while the batch cannot fill the chip anyway (the pass is then bound by one lane's dependent chain: halve it);
     // one lane per signature beyond that (less total work).  ZK_ECDSA_LANES=1|2 overrides (tuning / tests).
     a.lanes_per_sig = n <= (1ull << 16) ? 2u : 1u;
@@ -1411,6 +1424,12 @@ extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32
 fail:
     zk_close(s);
     return rc;
+}
+extern "C" int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
+                             uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out) {
+    zk_ecdsa_batch b;
+    b.bytes = bytes; b.layout = layout; b.v = v; b.v_stride = v_stride; b.n = n; b.out_dev = out_dev; b.out_stride = out_stride;
+    return zk_ecdsa_open_batches(&b, 1, opts, out);
 }
 extern "C" int zk_ecdsa_verify(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                                uint32_t opts, uint32_t* status_out, zk_result* result) {

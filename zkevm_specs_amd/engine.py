@@ -602,6 +602,27 @@ def open_ecdsa(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, out_dev=None, out_
     return Session(h, n, (sig_bytes, v, out_dev), lib=lib)
 
 
+def open_ecdsa_batches(batches, device=None):
+    """One launch over one or two signature arrays (zk_ecdsa_open_batches): `batches` = list of dicts with the arguments of
+    open_ecdsa (sig_bytes, v, layout, out_dev, out_stride, v_stride).  Statuses: batch 0's signatures first."""
+    lib = _lib.init(device)
+    keep, arr, opts_all, n_total = [], (_lib.ZkEcdsaBatch * len(batches))(), None, 0
+    for k, b in enumerate(batches):
+        layout = b.get("layout", ECDSA_LAYOUT_PACKED)
+        _expect(b["sig_bytes"], "signature bytes", 1, (None, 5 if layout == ECDSA_LAYOUT_PACKED else 9, 32))
+        (sb, v, od), opts = _prep([b["sig_bytes"], b.get("v"), b.get("out_dev")], outputs=(2,))
+        assert opts_all is None or opts == opts_all, "mix of host and device batches"
+        opts_all = opts
+        keep += [sb, v, od]
+        n = int(sb.shape[0])
+        n_total += n
+        pv = lambda x: None if x is None else _lib.ptr(x).value  # noqa: E731
+        arr[k] = _lib.ZkEcdsaBatch(pv(sb), int(layout), pv(v), int(b.get("v_stride", 1)), n, pv(od), int(b.get("out_stride", 1)))
+    h = ctypes.c_void_p()
+    check(lib.zk_ecdsa_open_batches(arr, len(batches), opts_all, ctypes.byref(h)), "zk_ecdsa_open_batches")
+    return Session(h, n_total, tuple(keep), lib=lib)
+
+
 def ecdsa_status(sig_bytes, v=None, layout=ECDSA_LAYOUT_PACKED, device=None, v_stride=1):
     """-> uint32[n] ecdsa_status computed on the GPU"""
     with open_ecdsa(sig_bytes, v, layout, device=device, v_stride=v_stride) as s:
