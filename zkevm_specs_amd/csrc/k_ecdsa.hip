@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     SpPoint part = sp_infinity();
     if (valid) {
         st = ecdsa_prepare(a, i, pr, role == 0);
-        if (st == ECDSA_PENDING) part = ecdsa_partial(pr, L == 1 ? 0 : role, L == 1 ? 1 : role, tab, tab_stride);
+        if (st == ECDSA_PENDING) part = ecdsa_partial(pr, L == 1 ? 0 : role, L == 1 ? 1 : role, tab, tab_stride, a.gcomb);
     }
     if (L == 2) {  // every lane takes part in the exchange; lane 2i receives the partial sum of lane 2i + 1
         SpPoint other;
@@ -46,6 +46,13 @@ __global__ __launch_bounds__(64) void ecdsa_verify_kernel(EcdsaArgs a, u32* stat
     tally_commit(tally, i, code);
 }
 
+__global__ __launch_bounds__(64) void ecdsa_comb_build_kernel(u32* table) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < ECDSA_COMB_ENTRIES) ecdsa_comb_entry(e, table);
+}
+void zk_launch_ecdsa_comb_build(hipStream_t st, u32* table) {
+    hipLaunchKernelGGL(ecdsa_comb_build_kernel, dim3((ECDSA_COMB_ENTRIES + 63) / 64), dim3(64), 0, st, table);
+}
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a0, u32* status, ZkTally* tally) {
     // 64-lane blocks: 2^14 signatures are only 256 (512 as lane pairs) wavefronts.  The per-lane key tables cost 1,440 bytes
     // per lane (ZK_ECDSA_CHUNK_LANES of them are allocated, 189 MB): a larger batch runs as consecutive launches over the same

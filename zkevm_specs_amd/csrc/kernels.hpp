@@ -65,3 +65,4 @@ void zk_launch_pi_copy(hipStream_t st, const PiCopyArgs& a, u32* status, ZkTally
 void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_ecdsa(hipStream_t st, const EcdsaArgs& a, u32* status, ZkTally* tally);
+void zk_launch_ecdsa_comb_build(hipStream_t st, u32* table);  // the device's 8-bit fixed-base table of G (522 KB), built once

@@ -655,6 +655,7 @@ struct EcdsaArgs {
     u32* qtab;             // per-lane tables of the key's multiples, word w of entry e of lane l at qtab[(e * 24 + w) * qtab_lanes + l]
     u64 qtab_lanes;
     u32 lanes_per_sig;     // 1: one lane runs both halves of the GLV split; 2: a lane pair, one half each
+    const u32* gcomb;      // optional: the 8-bit fixed-base table of G built on the device (ecdsa_comb_entry), nullptr: 4-bit constant table
     // A second batch in the same launch (zk_ecdsa_open_batches): signatures [n0, n) come from these arrays (the Tx circuit's and
     // the Sig circuit's chips of one block: two launches of 2^14 signatures each ran 1.9 ms side by side where one launch of
     // 2^15 takes 1.4 ms — 1,024 wavefronts placed one per SIMD by ONE dispatch).  n0 == n: a single batch.
@@ -675,6 +676,7 @@ __host__ __device__ inline
 #endif
 void ecdsa_single_batch(EcdsaArgs& a) {  // callers that fill the first batch only (host code)
     a.n0 = a.n;
+    a.gcomb = nullptr;
     a.bytes1 = nullptr; a.stride1 = 0; a.msg_be1 = 0; a.v1 = nullptr; a.v_stride1 = 0; a.out1 = nullptr; a.out_stride1 = 0;
     for (int k = 0; k < 5; k++) a.off1[k] = 0;
 }
@@ -892,10 +894,51 @@ ZK_HD SpPoint sp_tab_load(const u32* tab, u64 stride, int e) {
     }
     return p;
 }
+// Fixed-base comb for the u1 G half (round 4).  u1 = sum over 32 byte windows W of d_W * 2^(8 W): with the table
+// T[W][d - 1] = d * 2^(8 W) * G (affine, 32 x 255 entries of 64 bytes = 522 KB, L2-resident) u1 G is 32 mixed additions and NO
+// doublings — it no longer rides in the key's doubling chain, and a role (16 windows) adds 16 points where the 4-bit interleaved
+// form added ~30.  The table is built once per device by ecdsa_comb_entry (one lane per entry: d * 2^(8 W) * G through the
+// 4-bit constant table, then to affine with one Fermat inversion); without it (CPU builds) the same comb runs over the 4-bit
+// constant table secp_g_table (64 windows).
+#define ECDSA_COMB_WINDOWS 32
+#define ECDSA_COMB_ENTRIES (ECDSA_COMB_WINDOWS * 255)
+ZK_HD void ecdsa_comb_entry(u32 e, u32* table) {  // e = W * 255 + (d - 1)
+    const u32 W = e / 255u, d = e % 255u + 1u;
+    Fr k = fr_zero();
+    k.v[W >> 2] = d << (8u * (W & 3u));  // d * 2^(8 W) < 2^256, below N for every W < 32 (255 * 2^248 < N)
+    const SpPoint pt = sp_scalar_mul_g(k);
+    const Fr zi = sp_inv<SecpP>(pt.Z), zi2 = spf_sqr(zi);
+    const Fr x = spf_mul(pt.X, zi2), y = spf_mul(pt.Y, spf_mul(zi2, zi));
+    u32* out = table + (u64)e * 16;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { out[q] = x.v[q]; out[8 + q] = y.v[q]; }
+}
+// acc += kg * base_h for the role h (kg < 2^128: windows 16 h .. 16 h + 15 of u1)
+ZK_HD void ecdsa_add_g_half(SpPoint& acc, const Fr& kg, int h, const u32* gcomb) {
+    if (gcomb) {
+        for (int w = 0; w < 16; w++) {
+            const u32 d = (kg.v[w >> 2] >> (8 * (w & 3))) & 0xffu;
+            if (d) {
+                Fr x, y;
+                sp_load_affine(gcomb + ((u64)(16 * h + w) * 255u + (d - 1u)) * 16u, x, y);
+                sp_add_affine_ip(acc, x, y);
+            }
+        }
+        return;
+    }
+    for (int j = 0; j < 32; j++) {
+        const u32 d = (kg.v[j >> 3] >> (4 * (j & 7))) & 15u;
+        if (d) {
+            Fr x, y;
+            sp_load_affine(secp_g_table[15 * (32 * h + j) + (int)d - 1], x, y);
+            sp_add_affine_ip(acc, x, y);
+        }
+    }
+}
 // Partial sum of the roles [h_lo, h_hi] (0-0, 1-1 or 0-1).  `tab`: this lane's table (15 entries x 24 words, stride apart).
 // The table holds the multiples of the FIRST role's base with that role's sign; the second role of a one-lane run derives
 // its entries from it (X times beta, Y negated when the two signs differ).
-ZK_HD SpPoint ecdsa_partial(const EcdsaPrep& pr, int h_lo, int h_hi, u32* tab, u64 stride) {
+ZK_HD SpPoint ecdsa_partial(const EcdsaPrep& pr, int h_lo, int h_hi, u32* tab, u64 stride, const u32* gcomb = nullptr) {
     const Fr beta = secp_beta();
     {   // entry e - 1 = e * base: 2k = double(k), 2k + 1 = 2k + base (mixed)
         Fr bx = h_lo == 1 ? spf_mul(pr.qx, beta) : pr.qx;
@@ -927,14 +970,9 @@ ZK_HD SpPoint ecdsa_partial(const EcdsaPrep& pr, int h_lo, int h_hi, u32* tab, u
                 }
                 sp_add_ip(acc, t);
             }
-            const u32 g = sp_digit4(pr.kg[h], w);
-            if (g) {
-                Fr x, y;
-                sp_load_affine(secp_g_small[h][g - 1], x, y);
-                sp_add_affine_ip(acc, x, y);
-            }
         }
     }
+    for (int h = h_lo; h <= h_hi; h++) ecdsa_add_g_half(acc, pr.kg[h], h, gcomb);
     return acc;
 }
 ZK_HD u32 ecdsa_verdict(const EcdsaPrep& pr, const SpPoint& C) {
@@ -947,5 +985,5 @@ ZK_HD u32 ecdsa_verify_one(const EcdsaArgs& a, u64 i, u32* tab, u64 stride) {
     EcdsaPrep pr;
     const u32 st = ecdsa_prepare(a, i, pr, true);
     if (st != ECDSA_PENDING) return st;
-    return ecdsa_verdict(pr, ecdsa_partial(pr, 0, 1, tab, stride));
+    return ecdsa_verdict(pr, ecdsa_partial(pr, 0, 1, tab, stride, a.gcomb));
 }

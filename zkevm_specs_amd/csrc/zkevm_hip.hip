@@ -25,7 +25,8 @@
 #define ZK_ECDSA_CHUNK_LANES (1ull << 17)  // lanes per ECDSA launch (x 1,440 B of key tables = 189 MB); a multiple of 64
 static std::mutex g_dev_mutex;
 static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
-static hipStream_t g_batch_stream[ZK_MAX_DEVICES][2] = {{nullptr}};  // zk_evm_verify_batch: the two pipeline slots of a device
+static hipStream_t g_batch_stream[ZK_MAX_DEVICES][2] = {{nullptr}};
+static u32* g_secp_comb[ZK_MAX_DEVICES] = {nullptr};  // per device: the ECDSA kernel's 8-bit fixed-base table of G (secp256k1.hpp), built at the first ECDSA open  // zk_evm_verify_batch: the two pipeline slots of a device
 static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per device: "row 0" of every empty table
 static thread_local int t_device = -1;              // device selected by this thread's last zk_init
 static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
@@ -92,6 +93,8 @@ extern "C" void zk_shutdown(void) {
             if (hipSetDevice(d) == hipSuccess) {
                 (void)hipStreamDestroy(g_own_stream[d]);
                 if (g_zero_row[d]) (void)hipFree(g_zero_row[d]);
+                if (g_secp_comb[d]) (void)hipFree(g_secp_comb[d]);
+                g_secp_comb[d] = nullptr;
             }
             for (int k = 0; k < 2; k++) {
                 if (g_batch_stream[d][k]) (void)hipStreamDestroy(g_batch_stream[d][k]);
@@ -1390,6 +1393,17 @@ extern "C" int zk_ecdsa_open_batches(const zk_ecdsa_batch* bt, uint32_t n_batche
     a.n = n;
     ecdsa_single_batch(a);
     a.n0 = bt[0].n;
+    {   // the fixed-base table of G: built once per device (ordered before this session's first pass: same stream + a synchronisation)
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (!g_secp_comb[s->device]) {
+            u32* tab = nullptr;
+            if (hipMalloc(&tab, (size_t)ECDSA_COMB_ENTRIES * 16 * sizeof(u32)) != hipSuccess) { rc = -2; g_err = "zk_ecdsa_open: table allocation failed"; goto fail; }
+            zk_launch_ecdsa_comb_build(s->stream, tab);
+            if (hipStreamSynchronize(s->stream) != hipSuccess) { (void)hipFree(tab); rc = -2; g_err = "zk_ecdsa_open: table build failed"; goto fail; }
+            g_secp_comb[s->device] = tab;
+        }
+        a.gcomb = g_secp_comb[s->device];
+    }
     for (u32 k = 0; k < n_batches; k++) {
         const u64 stride = bt[k].layout ? 288 : 160;
         const uint8_t* d_bytes;
