@@ -11,7 +11,7 @@ typedef uint32_t u32; typedef uint64_t u64;
 __device__ __forceinline__ uint4 orr(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
 
 // v0: one quarter-row per thread (the product's form): lane q of a quad loads chunks q, q+4, q+8
-__global__ __launch_bounds__(256) void v0(const uint4* rows, u32 n, uint4* keys) {
+__global__ __launch_bounds__(1024) void v0(const uint4* rows, u32 n, uint4* keys) {
     const u32 vt = blockIdx.x * blockDim.x + threadIdx.x, r = vt >> 2, q = vt & 3u;
     if (r >= n) return;
     const uint4* p = rows + (u64)r * ROW_U4 + q;
@@ -86,22 +86,25 @@ __global__ __launch_bounds__(256) void v5(const uint4* rows, u32 n, uint4* keys)
     }
     if ((c.x | c.y | c.z | c.w) == 0x12345u) keys[0] = c;
 }
-__global__ void flush_k(uint4* p, u64 n) {
+// read-only sweep over 2 GiB of unrelated data (a write sweep leaves dirty lines whose write-back then competes with the measured kernel)
+__global__ void flush_k(const uint4* p, u64 n, uint4* sink) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = make_uint4((u32)i, 0, 0, 0);
+    uint4 c = make_uint4(0, 0, 0, 0);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c = orr(c, p[i]);
+    if ((c.x | c.y | c.z | c.w) == 0x12345u) sink[0] = c;
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main() {
     const u32 n = 816377;
     const u64 bytes = (u64)n * 448;
     uint4 *rows, *keys, *fl;
-    CK(hipMalloc(&rows, bytes)); CK(hipMalloc(&keys, (u64)n * 64)); CK(hipMalloc(&fl, 1ull << 30));
+    CK(hipMalloc(&rows, bytes)); CK(hipMalloc(&keys, (u64)n * 64)); CK(hipMalloc(&fl, 2ull << 30)); CK(hipMemset(fl, 3, 2ull << 30));
     CK(hipMemset(rows, 1, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char* name, auto launch, double mb) {
         float best = 1e9, sum = 0;
         for (int it = 0; it < 6; it++) {
-            hipLaunchKernelGGL(flush_k, dim3(2048), dim3(256), 0, 0, fl, (u64)(1ull << 30) / 16);
+            hipLaunchKernelGGL(flush_k, dim3(4096), dim3(256), 0, 0, fl, (u64)(2ull << 30) / 16, keys);
             CK(hipEventRecord(e0, 0));
             launch();
             CK(hipEventRecord(e1, 0));
@@ -113,6 +116,8 @@ int main() {
     };
     const double key_lines = (double)n * 256, all = (double)bytes;
     run("v0 quarter-row/thread", [&] { hipLaunchKernelGGL(v0, dim3((n * 4 + 255) / 256), dim3(256), 0, 0, rows, n, keys); }, key_lines);
+    run("v0 (blocks of 1024)", [&] { hipLaunchKernelGGL(v0, dim3((n * 4 + 1023) / 1024), dim3(1024), 0, 0, rows, n, keys); }, key_lines);
+    run("v0 (blocks of 64)", [&] { hipLaunchKernelGGL(v0, dim3((n * 4 + 63) / 64), dim3(64), 0, 0, rows, n, keys); }, key_lines);
     for (int g : {1024, 2048, 4096}) {
         char nm[64];
         snprintf(nm, 64, "v1<2> grid %d", g); run(nm, [&] { hipLaunchKernelGGL(v1<2>, dim3(g), dim3(256), 0, 0, rows, n, keys); }, key_lines);
