@@ -631,6 +631,8 @@ def oneshot_profile_numbers(profile):
     n = profile["bench_line"]["steps"] + profile["bench_line"]["warmup"]
     traffic, kernel_ns, seen_pmc = 0.0, 0.0, False
     for name, k in profile["kernels"].items():
+        if name.startswith("__amd_rocclr"):
+            continue  # the runtime's copy kernels: the witness uploads of that run (outside the steps) and the 128-byte result read-back
         pmc = k.get("pmc", {})
         corr = FETCH_GATHER_CORRECTION if "evm_steps_kernel" in name or "evm_deferred" in name else FETCH_STREAM_CORRECTION
         if "FETCH_SIZE" in pmc:
