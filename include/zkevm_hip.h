@@ -155,6 +155,10 @@ typedef struct zk_evm_tables {
 #define ZK_OPT_SINGLE_PASS 8u   /* EVM sessions: the session will evaluate ONE pass (what zk_evm_verify does): skip the packed step
                                  * records, a one-off streaming pass over the step table that only pays for itself from the second
                                  * evaluation pass on; results are identical either way */
+#define ZK_OPT_SIDE_STREAM 16u  /* EVM sessions: every pass runs its warm / cold gadget launches on a second stream of the device
+                                 * beside the hot one (fork and join by events, results final in the session's stream order as
+                                 * always).  Costs two cross-queue barriers (~8 us) and saves the sum of the two launches: a gain
+                                 * when the device is shared with other sessions' passes (the Super circuit), a loss alone */
 int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** out);
 int zk_evm_verify(const zk_evm_tables* t, uint32_t opts,
                   uint32_t* status_out /* nullable, n_steps-1 entries */, zk_result* result);

@@ -232,6 +232,18 @@ def test_warm_gadget_trace_all_pairs_vs_oracle():
         res, status = _run(w, state_sort=sort)
         assert status == exp, sort
         _check_tally(res, exp)
+    # ZK_OPT_SIDE_STREAM (what SuperCircuit opens its EVM session with): warm / cold launches forked to the device's side stream,
+    # joined before anything later on the session's stream; three passes, the third into a caller buffer read after a plain sync
+    with engine.open_evm(dict(w), side_stream=True) as s:
+        for _ in range(2):
+            res = s.run()
+            _check_tally(res, exp)
+            assert s.read_status().tolist() == exp
+        buf = torch.full((len(exp),), 0x7fffffff, dtype=torch.int32, device="cuda")
+        s.launch(status_dev=buf)
+        torch.cuda.synchronize()
+        assert buf.cpu().numpy().view(np.uint32).tolist() == exp
+        _check_tally(s.collect(), exp)
 
 
 def test_caller_status_buffer_is_final_after_a_stream_sync():

@@ -94,6 +94,7 @@ class ZkCopyEvents(ctypes.Structure):
 OPT_NO_STATE_SORT = 2
 OPT_GENERIC_INDEX = 4
 OPT_SINGLE_PASS = 8
+OPT_SIDE_STREAM = 16
 
 
 class EngineError(RuntimeError):

@@ -26,6 +26,12 @@
 static std::mutex g_dev_mutex;
 static hipStream_t g_own_stream[ZK_MAX_DEVICES] = {nullptr};
 static hipStream_t g_batch_stream[ZK_MAX_DEVICES][2] = {{nullptr}};
+// EVM passes: the warm and cold builds walk their own lane ranges of the sorted mapping and are independent of the hot build's;
+// they run on this stream, forked from / joined to the session's stream by events, so a pass lasts max(hot, warm + cold) instead
+// of their sum.  Opt-in per session (ZK_OPT_SIDE_STREAM): the fork / join barriers cost more than the two launches when the
+// session has the device to itself.
+static hipStream_t g_side_stream[ZK_MAX_DEVICES] = {nullptr};
+
 static u32* g_secp_comb[ZK_MAX_DEVICES] = {nullptr};  // per device: the ECDSA kernel's 8-bit fixed-base table of G (secp256k1.hpp), built at the first ECDSA open  // zk_evm_verify_batch: the two pipeline slots of a device
 static void* g_zero_row[ZK_MAX_DEVICES] = {nullptr};  // 512 zero bytes per device: "row 0" of every empty table
 static thread_local int t_device = -1;              // device selected by this thread's last zk_init
@@ -100,6 +106,8 @@ extern "C" void zk_shutdown(void) {
                 if (g_batch_stream[d][k]) (void)hipStreamDestroy(g_batch_stream[d][k]);
                 g_batch_stream[d][k] = nullptr;
             }
+            if (g_side_stream[d]) (void)hipStreamDestroy(g_side_stream[d]);
+            g_side_stream[d] = nullptr;
             g_own_stream[d] = nullptr;
             g_zero_row[d] = nullptr;
         }
@@ -356,6 +364,10 @@ struct EvmOpenTables {
     u32 rec_block0;
     EvmSortArgs sort;    // sort.perm != nullptr: the first pass's counting sort rides on the two launches (histogram in phase 1, scatter in phase 2)
     u32 hist_block0;
+    u32 lat_period;      // phase 1: every lat_period-th block of the launch's first part is one of the latency-bound ranges' (0 / 1: they all come first)
+#ifdef ZK_DIAG_P1
+    u32 diag_skip;       // tuning builds only (tools/p1_ranges.py): ranges of phase 1 that return at once — results are INVALID
+#endif
 };
 // small-table index inserts + EndBlock's whole-table aggregates over the tx and withdrawal rows (end_block.py:55-91;
 // host_index.hpp's evm_aggregates_host is the CPU statement of the same counts)
@@ -411,13 +423,27 @@ __global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
         o.tally[threadIdx.x].fail_count = 0ull;
         o.tally[threadIdx.x].first_fail = ~0ull;
     }
-    // the latency-bound ranges come first (dependent loads, atomics: they start at once and finish under the stream); the RW
-    // range streams HBM for the rest of the launch
-    if (blockIdx.x < o.dir_block0) evm_open_small_tables(o, blockIdx.x);
-    else if (blockIdx.x < o.hist_block0) dirb_events_row(o.dir, (blockIdx.x - o.dir_block0) * blockDim.x + threadIdx.x);
-    else if (blockIdx.x < o.rw_block0) evm_state_hist_body(blockIdx.x - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally, o.sort.defer_count);
-    else if (blockIdx.x < o.rec_block0) rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (blockIdx.x - o.rw_block0) * blockDim.x + threadIdx.x);
-    else evm_step_record_quad(o.steps, o.n_steps, o.step_recs, (blockIdx.x - o.rec_block0) * blockDim.x + threadIdx.x);
+    // Virtual block order [0, rw_block0): the latency-bound ranges (dependent loads, atomics) | [rw_block0, rec_block0): the RW
+    // rows, streaming | step records, streaming.  The ~1,400 latency-bound blocks used to be dispatched first: for the first
+    // ~10 us they held two thirds of the chip's block slots and the stream ran at half rate (tools/p1_ranges.py: 14 us of the
+    // launch).  They are now dealt into the RW range, one every lat_period blocks, so the stream has most of the slots from
+    // the first cycle and the chains finish under it.
+    u32 b = blockIdx.x;
+    if (o.lat_period > 1u && b < o.rec_block0) {
+        const u32 q = b / o.lat_period;
+        b = (b == q * o.lat_period && q < o.rw_block0) ? q : o.rw_block0 + b - (q + 1u < o.rw_block0 ? q + 1u : o.rw_block0);
+    }
+#ifdef ZK_DIAG_P1
+    {
+        const u32 range = b < o.dir_block0 ? 1u : b < o.hist_block0 ? 2u : b < o.rw_block0 ? 4u : b < o.rec_block0 ? 8u : 16u;
+        if (o.diag_skip & range) return;
+    }
+#endif
+    if (b < o.dir_block0) evm_open_small_tables(o, b);
+    else if (b < o.hist_block0) dirb_events_row(o.dir, (b - o.dir_block0) * blockDim.x + threadIdx.x);
+    else if (b < o.rw_block0) evm_state_hist_body(b - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally, o.sort.defer_count);
+    else if (b < o.rec_block0) rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (b - o.rw_block0) * blockDim.x + threadIdx.x);
+    else evm_step_record_quad(o.steps, o.n_steps, o.step_recs, (b - o.rec_block0) * blockDim.x + threadIdx.x);
 }
 // Phase 2.  The generic RW index is only needed when the rows are not dense: the blocks are always launched (the host does
 // not know the verdict), the work is conditional; grid-stride so that the idle case is 256 blocks that exit at once.
@@ -519,6 +545,8 @@ struct zk_session {
     u32* d_group_start = nullptr;  // EVM: lane range of each kernel group inside d_perm
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
     hipEvent_t ev_open0 = nullptr, ev_open1 = nullptr;  // EVM: ride on the first / last dispatch of zk_evm_open (zk_session_timing)
+    bool side_stream = false;                           // EVM: ZK_OPT_SIDE_STREAM
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // EVM: fork to / join from the device's side stream (warm + cold builds)
     // EVM: EvmDyn, the two tallies and the lane ranges sit in ONE 128-byte device block (EvmResultBlock) that zk_collect reads
     // back with ONE copy into page-locked host memory (three copies into pageable memory cost three blocking round trips)
     void* d_result = nullptr;
@@ -707,6 +735,8 @@ extern "C" int zk_close(zk_session* s) {
         for (hipEvent_t e : s->ev) A.events.push_back(e);
         if (s->ev_open0) A.events.push_back(s->ev_open0);
         if (s->ev_open1) A.events.push_back(s->ev_open1);
+        if (s->ev_fork) A.events.push_back(s->ev_fork);
+        if (s->ev_join) A.events.push_back(s->ev_join);
         if (s->h_result) A.pinned.push_back(s->h_result);
     }
     delete s;
@@ -805,6 +835,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     zk_session* s = new zk_session();
     s->kind = SESSION_EVM;
     s->n = t->n_steps - 1;
+    s->side_stream = (opts & ZK_OPT_SIDE_STREAM) != 0;
     int rc = 0;
     const void* p = nullptr;
     EvmArgs& E = s->evm;
@@ -961,10 +992,20 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             rec_blocks = (u32)((t->n_steps + 63) / 64);  // four lanes per step
         }
         const u32 grid1 = o.rec_block0 + rec_blocks;
+        {   // latency-bound blocks dealt into the first 1 / ZK_P1_LAT_SPREAD of the RW range (evm_open_phase1_kernel)
+            static const u32 spread = [] { const char* e = getenv("ZK_P1_LAT_SPREAD"); const int v = e ? atoi(e) : 2; return (u32)(v < 0 ? 0 : v); }();
+            o.lat_period = (o.rw_block0 && spread) ? o.rec_block0 / (spread * o.rw_block0) : 0u;
+        }
+#ifdef ZK_DIAG_P1
+        if (const char* e = getenv("ZK_DIAG_P1_SKIP")) o.diag_skip = (u32)atoi(e);
+#endif
         {
             const u32 dir_blocks = want_dir ? DIRB_MAX_ENTRIES / EVM_OPEN_P2_BLOCK : 0u;
             const u32 rw_blocks = t->n_rw ? EVM_OPEN_RW_GENERIC_BLOCKS : 0u;
-            const bool phase2 = scatter_blocks + dir_blocks + rw_blocks != 0;
+            bool phase2 = scatter_blocks + dir_blocks + rw_blocks != 0;
+#ifdef ZK_DIAG_P1
+            if (o.diag_skip) phase2 = false;  // its inputs are missing
+#endif
             hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
             if (phase2)
                 hipExtLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, nullptr,
@@ -1934,8 +1975,21 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
     // no separate event packets between the sort passes and the evaluation kernels
-    const bool evm_ext_events = timed && s->kind == SESSION_EVM && s->evm.perm;
-    if (timed && !evm_ext_events) HIP_TRY(hipEventRecord(e0, s->stream));
+    bool evm_ext_events = timed && s->kind == SESSION_EVM && s->evm.perm;
+    hipStream_t side = nullptr;
+    if (s->kind == SESSION_EVM && s->evm.perm && s->side_stream &&
+        !(s->evm_ranges_known && s->evm_warm_empty && s->evm_cold_empty)) {
+        if (!g_side_stream[s->device]) HIP_TRY(hipStreamCreateWithFlags(&g_side_stream[s->device], hipStreamNonBlocking));
+        if (!s->ev_fork) {
+            int erc = arena_event(s->device, &s->ev_fork);
+            if (!erc) erc = arena_event(s->device, &s->ev_join);
+            if (erc) return erc;
+        }
+        side = g_side_stream[s->device];
+        if (side == s->stream) side = nullptr;
+    }
+    if (side) evm_ext_events = false;  // the pass's events are the fork / join records themselves
+    if (timed && !evm_ext_events && !side) HIP_TRY(hipEventRecord(e0, s->stream));
     switch (s->kind) {
     case SESSION_STATE: zk_launch_state_rows(s->stream, s->state, status, tally); break;
     case SESSION_BYTECODE: zk_launch_bytecode_rows(s->stream, s->bytecode, range_lo(s), range_hi(s), status, tally); break;
@@ -1970,6 +2024,23 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         const bool sorted = s->evm.perm != nullptr;
         const bool run_warm = !(sorted && s->evm_ranges_known && s->evm_warm_empty);
         const bool run_cold = !(sorted && s->evm_ranges_known && s->evm_cold_empty);
+        if (side) {
+            // fork after the sort: the small warm / cold launches go first and finish under the hot one
+            hipEvent_t fork = timed ? e0 : s->ev_fork;
+            HIP_TRY(hipEventRecord(fork, s->stream));
+            HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+            if (run_warm)
+                zk_launch_evm_warm(side, cold_grid, s->evm_ranges_known ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->d_tally, nullptr);
+            if (run_cold) zk_launch_evm_cold(side, cold_grid, s->evm, s->d_group_start, status, s->d_tally, nullptr);
+            HIP_TRY(hipEventRecord(s->ev_join, side));
+            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, nullptr, nullptr);
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+            if (status_dev && s->evm.defer_count) {
+                zk_launch_evm_deferred(s->stream, s->evm, status, s->d_tally);
+                s->deferred_pending = false;
+            }
+            break;
+        }
         hipEvent_t e_hot1 = (evm_ext_events && !run_warm && !run_cold) ? e1 : nullptr;  // the hot dispatch carries both events then
         zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr, e_hot1);
         if (run_warm)
@@ -2019,7 +2090,9 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     u32 gs[EVM_N_GROUPS + 1] = {0};
     const bool read_ranges = s->kind == SESSION_EVM && s->evm.perm && !s->evm_ranges_known && s->launches > 0;
     if (s->kind == SESSION_EVM && s->d_result && s->h_result) {
-        // one copy of the 128-byte result block (deferred count, both tallies, lane ranges) into page-locked memory, one wait
+        // one copy of the 128-byte result block (deferred count, both tallies, lane ranges) into page-locked memory, one wait.
+        // (Having the pass's last block write the block to the host itself — system-scope stores + fence from inside the cold
+        // launch — was measured: the launch waits for the PCIe writes, pass 76 -> 90 us, step 0.179 -> 0.187 ms.  Rejected.)
         HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(EvmResultBlock), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         const EvmResultBlock* h = (const EvmResultBlock*)s->h_result;

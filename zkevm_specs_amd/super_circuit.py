@@ -247,7 +247,7 @@ class SuperCircuit:
             ranges["bytecode"] = (lo_, hi_)
             tx_w, self.row_lo["tx"] = distributed.shard_units(tx_w, rank, world)
         self.sessions = {
-            "evm": engine.open_evm(evm_w, device=device),
+            "evm": engine.open_evm(evm_w, device=device, side_stream=True),
             "state": engine.open_state(rows, flags, mpt, device=device),
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign(tx_w, r_tx, False, device=device),
