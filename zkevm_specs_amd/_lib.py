@@ -123,7 +123,7 @@ def load():
         # variable at its first call, which torch makes lazily.  Set here — when the HIP library is actually loaded — and not
         # at package import: a process that only uses the CPU backend, or imports the package for its witness generators, keeps
         # its environment untouched.  A host that sets the variable itself keeps its own choice.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         import torch  # noqa: F401
 
     _lib = _bind(ctypes.CDLL(LIB_PATH))

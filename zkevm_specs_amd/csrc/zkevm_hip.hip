@@ -65,8 +65,10 @@ extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
 // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run back to back: with 4 queues the
 // EVM and State sessions of the 2^20-row block landed on one queue and the pass took their SUM (0.49 ms vs 0.37 ms with 8).  The
 // runtime reads the variable at its first API call, so a default set when this library is loaded is early enough for any host that
-// has not used HIP yet; a host that has, or that sets the variable itself, keeps its own choice.
-__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// has not used HIP yet; a host that has, or that sets the variable itself, keeps its own choice.  16 since round 4: a process
+// that also holds the batch entry's two pipeline streams, the side stream and a Tx / Sig pass's streams mapped two of the block's
+// sessions onto one of 8 queues again (0.44 ms per block pass inside the default bench line against 0.35 alone; 0.35 with 16).
+__attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 static void arena_release_all();
 
 extern "C" int zk_init(int device) {

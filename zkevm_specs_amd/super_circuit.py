@@ -17,7 +17,7 @@ mirrors use, each session bound to its own HIP stream (zk_session_set_stream), a
 The Copy and Exp circuits have no rows here: BASELINE config 3's opcode mix contains no copy / EXP steps.
 
 Concurrency note: the sessions overlap on the device only when their streams land on different hardware queues.  The HIP runtime
-reads GPU_MAX_HW_QUEUES (default 4) at its first call; `zkevm_specs_amd._lib.load()` defaults it to 8 — call it (or `init()`)
+reads GPU_MAX_HW_QUEUES (default 4) at its first call; `zkevm_specs_amd._lib.load()` defaults it to 16 — call it (or `init()`)
 before the process's first HIP call (e.g. before `torch.cuda.set_device`), or export the variable yourself.
 """
 import numpy as np
