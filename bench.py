@@ -699,6 +699,8 @@ def main():
     ap.add_argument("--witness-copies", type=int, default=3, help="EVM one-shot steps rotate over this many resident copies of the witness")
     ap.add_argument("--no-session-leg", action="store_true", help="EVM: skip the open-session side measurement")
     ap.add_argument("--no-batch-leg", action="store_true", help="EVM: skip the batch-entry (two witnesses in flight) side measurement")
+    ap.add_argument("--tally", default="torch", choices=["torch", "abi"],
+                    help="the tally exchange: torch.distributed all-gather (default) or the C ABI's own RCCL communicator (zk_dist_*; checked against the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
@@ -758,6 +760,11 @@ def main():
 
     total_fail, first_row, first_code = distributed.reduce_tally(res.fail_count, res.first_fail_row if res.fail_count else None, res.first_fail_code,
                                                                  0 if args.workload == "super" else w.row_offset, device="cuda")
+    if args.tally == "abi":  # the same exchange through zk_dist_* (the engine's own RCCL communicator): must agree
+        with distributed.RcclTally(rank, world, device=ctx.local_rank) as rt:
+            via_abi = rt.reduce(res if res.fail_count else type("Clean", (), {"fail_count": 0, "first_fail_row": None, "first_fail_code": 0}),
+                                0 if args.workload == "super" else w.row_offset)
+        assert via_abi == (total_fail, first_row, first_code), (via_abi, total_fail, first_row, first_code)
     t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)

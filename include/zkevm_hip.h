@@ -393,6 +393,27 @@ int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms);
 /* Host microseconds the calling thread's last one-shot zk_evm_verify spent inside its open / launch / collect / close calls
  * (tuning aid: where the wall time beyond the device span goes). */
 int zk_last_host_phases(double* us4);
+
+/* ---- Multi-GPU tally (§2 (vii) "RCCL all-reduce of {fail_count: SUM, first_fail_row: MIN}").  Rows shard across
+ *      the GPUs of a node with no data-path collective; the only exchange is the pass / fail tally.  These entries put it behind
+ *      the C ABI for hosts without torch.distributed: ONE RCCL collective per call — an all-gather of three 64-bit words per rank
+ *      (fail count, first failing GLOBAL row, its status code) on the communicator's own stream, read back once; SUM and the
+ *      lexicographic MIN are then taken on the host, identically on every rank (the same exchange the Python mirror makes through
+ *      torch.distributed, zkevm_specs_amd/distributed.py reduce_tally).  librccl.so.1 is loaded on first use (dlopen): processes
+ *      that never call these entries do not depend on it.
+ *        zk_dist_unique_id  rank 0: a fresh communicator id (ncclGetUniqueId); the host carries it to the other ranks
+ *        zk_dist_init       every rank, after zk_init(device): joins the communicator (collective: blocks until all ranks call)
+ *        zk_dist_tally      collective.  local: this rank's zk_collect result; row_offset: global index of its row 0.
+ *                           global->fail_count = SUM, first_fail_row / first_fail_code = those of the smallest failing global
+ *                           row (UINT64_MAX / 0 if none), rows_evaluated = SUM, launches = local's, kernel_ms = MAX over ranks
+ *        zk_dist_close      leaves the communicator
+ *      The CPU backend implements them for world == 1 (the identity with the offset applied). */
+#define ZK_DIST_ID_BYTES 128
+typedef struct zk_comm zk_comm;
+int zk_dist_unique_id(uint8_t* id /* ZK_DIST_ID_BYTES */);
+int zk_dist_init(const uint8_t* id /* ZK_DIST_ID_BYTES */, int rank, int world, zk_comm** out);
+int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_offset, zk_result* global);
+int zk_dist_close(zk_comm* c);
 /* Re-bind a session to another stream of its device (NULL = the engine's own); waits for its enqueued passes first. */
 int zk_session_set_stream(zk_session* s, void* hip_stream);
 int zk_close(zk_session* s);

@@ -117,6 +117,22 @@ for i in range(0, len(g["names"]), 6):
     assert wire.rowmajor_to_rows(c_table) == exp[2] and wire.rowmajor_to_rows(c_rw) == exp[3] and c_rwf.tolist() == list(exp[4]), g["names"][i]
     n_cp += 1
 out["assign_cases"] = [n_as, n_bc, n_cp]
+
+# zk_dist_* on the CPU backend: one process = world 1, the identity with the row offset applied; a larger world is refused
+from zkevm_specs_amd import distributed
+cols, flags, mpt = synth_state_witness(512, seed=4)
+cols[1, 77, 0] = np.uint64(2)
+with engine.open_state(cols, flags, mpt) as s:
+    res = s.run()
+with distributed.RcclTally(0, 1) as t:
+    assert t.reduce(res, row_offset=1000) == (res.fail_count, 1077, res.first_fail_code) and res.fail_count >= 1
+    class Clean: fail_count = 0; first_fail_row = None; first_fail_code = 0
+    assert t.reduce(Clean, row_offset=5) == (0, None, 0)
+import ctypes
+lib = _lib.load()
+h = ctypes.c_void_p()
+assert lib.zk_dist_init((ctypes.c_uint8 * 128)(), 1, 2, ctypes.byref(h)) != 0 and b"world must be 1" in lib.zk_last_error()
+out["dist"] = "ok"
 print("RESULT " + json.dumps(out))
 '''
 

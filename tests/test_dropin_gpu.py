@@ -96,3 +96,29 @@ def test_sessions_are_independent_contexts():
             s.read_status()
         s.set_stream(torch.cuda.Stream())
         assert s.run().ok and not s.read_status().any()
+
+
+def test_tally_exchange_through_the_c_abi():
+    """zk_dist_* (include/zkevm_hip.h): the engine's own RCCL communicator.  One GPU here, so world = 1 — communicator creation,
+    the all-gather on the communicator's stream and the host-side SUM / MIN are exercised; the result must be the local tally
+    with the shard's row offset applied, and equal to what the torch.distributed mirror (reduce_tally) returns."""
+    import numpy as np
+
+    from zkevm_specs_amd import distributed, engine
+    from zkevm_specs_amd.synth import synth_state_witness
+
+    cols, flags, mpt = synth_state_witness(4096, seed=6)
+    cols[1, 1234, 0] = np.uint64(2)
+    cols[50, 3000, 0] ^= np.uint64(1)
+    with engine.open_state(cols, flags, mpt) as s:
+        res = s.run()
+    assert res.fail_count >= 2 and res.first_fail_row == 1234
+    with distributed.RcclTally(0, 1, device=0) as t:
+        for off in (0, 1 << 20, (1 << 33) + 5):  # global rows beyond 32 bits
+            assert t.reduce(res, row_offset=off) == (res.fail_count, 1234 + off, res.first_fail_code)
+            assert t.reduce(res, row_offset=off) == distributed.reduce_tally(res.fail_count, res.first_fail_row, res.first_fail_code, off)
+
+        class Clean:
+            fail_count, first_fail_row, first_fail_code = 0, None, 0
+
+        assert t.reduce(Clean, row_offset=7) == (0, None, 0)

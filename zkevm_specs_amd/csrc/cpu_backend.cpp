@@ -177,6 +177,30 @@ extern "C" int zk_session_timing(zk_session*, double* open_ms, double* span_ms) 
     if (span_ms) *span_ms = -1.0;
     return 0;
 }
+// Multi-GPU tally: the CPU backend is one process (world == 1: the identity with the row offset applied); ranks of a CPU job
+// exchange their tallies on the host (zkevm_specs_amd.distributed.reduce_tally over gloo)
+struct zk_comm { int world; };
+extern "C" int zk_dist_unique_id(uint8_t* id) {
+    ARG_TRY(id, "zk_dist_unique_id: id is null");
+    memset(id, 0, ZK_DIST_ID_BYTES);
+    return 0;
+}
+extern "C" int zk_dist_init(const uint8_t* id, int rank, int world, zk_comm** out) {
+    ARG_TRY(id && out, "zk_dist_init: bad arguments");
+    ARG_TRY(world == 1 && rank == 0, "zk_dist_init: the CPU backend has no collective (world must be 1); reduce on the host");
+    *out = new zk_comm{1};
+    return 0;
+}
+extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_offset, zk_result* global) {
+    ARG_TRY(c && local && global, "zk_dist_tally: bad arguments");
+    *global = *local;
+    if (local->first_fail_row != UINT64_MAX) global->first_fail_row = local->first_fail_row + row_offset;
+    return 0;
+}
+extern "C" int zk_dist_close(zk_comm* c) {
+    delete c;
+    return 0;
+}
 extern "C" int zk_last_host_phases(double* us4) {
     if (us4) for (int k = 0; k < 4; k++) us4[k] = -1.0;
     return 0;

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include <mutex>
+#include <dlfcn.h>
 
 #include "../../include/zkevm_hip.h"
 #include "kernels.hpp"
@@ -2219,5 +2220,136 @@ extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* 
         (void)hipFree(tb);
         (void)hipFree(to);
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-GPU tally through RCCL (include/zkevm_hip.h "Multi-GPU tally").  librccl is bound at first use: nothing else in the
+// library needs it, and torch — when it is in the process — has usually loaded the same SONAME already.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[ZK_DIST_ID_BYTES]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+const int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h ncclDataType_t)
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return a;
+        a.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
+        a.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
+        a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+        a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+#define RCCL_TRY(expr, what)                                                                                        \
+    do {                                                                                                            \
+        const int r_ = (expr);                                                                                      \
+        if (r_ != 0) {                                                                                              \
+            char buf_[256];                                                                                         \
+            snprintf(buf_, sizeof buf_, "%s: RCCL error %d (%s)", what, r_, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); \
+            g_err = buf_;                                                                                           \
+            return -3;                                                                                              \
+        }                                                                                                           \
+    } while (0)
+
+struct zk_comm {
+    void* nccl = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    u64* d_buf = nullptr;  // ZK_TALLY_WORDS of this rank | ZK_TALLY_WORDS * world gathered
+    u64* h_buf = nullptr;  // page-locked, same layout, gathered part first
+};
+#define ZK_TALLY_WORDS 5  // per rank: fail count | first failing GLOBAL row (UINT64_MAX: none) | its code | rows evaluated | kernel_ms (the double's bits)
+
+extern "C" int zk_dist_unique_id(uint8_t* id) {
+    ARG_TRY(id, "zk_dist_unique_id: id is null");
+    ARG_TRY(rccl().ok, "zk_dist_unique_id: librccl.so.1 could not be loaded");
+    RcclId u;
+    RCCL_TRY(rccl().GetUniqueId(&u), "ncclGetUniqueId");
+    memcpy(id, u.internal, ZK_DIST_ID_BYTES);
+    return 0;
+}
+extern "C" int zk_dist_close(zk_comm* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+extern "C" int zk_dist_init(const uint8_t* id, int rank, int world, zk_comm** out) {
+    ARG_TRY(t_device >= 0, "zk_dist_init: call zk_init first");
+    ARG_TRY(id && out && world >= 1 && rank >= 0 && rank < world, "zk_dist_init: bad arguments");
+    ARG_TRY(rccl().ok, "zk_dist_init: librccl.so.1 could not be loaded");
+    HIP_TRY(hipSetDevice(t_device));
+    zk_comm* c = new zk_comm();
+    c->rank = rank; c->world = world; c->device = t_device;
+    RcclId u;
+    memcpy(u.internal, id, ZK_DIST_ID_BYTES);
+    int rc = 0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->d_buf, (size_t)(world + 1) * ZK_TALLY_WORDS * sizeof(u64)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_buf, (size_t)(world + 1) * ZK_TALLY_WORDS * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+        g_err = "zk_dist_init: buffer allocation failed";
+        rc = -2;
+    } else if (int r = rccl().CommInitRank(&c->nccl, world, u, rank)) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "ncclCommInitRank: RCCL error %d (%s)", r, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+        g_err = buf;
+        c->nccl = nullptr;
+        rc = -3;
+    }
+    if (rc) { zk_dist_close(c); return rc; }
+    *out = c;
+    return 0;
+}
+extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_offset, zk_result* global) {
+    ARG_TRY(c && local && global, "zk_dist_tally: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    u64* mine = c->h_buf + (size_t)c->world * ZK_TALLY_WORDS;
+    mine[0] = local->fail_count;
+    mine[1] = local->first_fail_row == UINT64_MAX ? UINT64_MAX : local->first_fail_row + row_offset;
+    mine[2] = local->first_fail_row == UINT64_MAX ? 0u : (u64)local->first_fail_code;
+    mine[3] = local->rows_evaluated;
+    memcpy(&mine[4], &local->kernel_ms, 8);
+    HIP_TRY(hipMemcpyAsync(c->d_buf, mine, ZK_TALLY_WORDS * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(rccl().AllGather(c->d_buf, c->d_buf + ZK_TALLY_WORDS, ZK_TALLY_WORDS, RCCL_UINT64, c->nccl, c->stream), "ncclAllGather");
+    HIP_TRY(hipMemcpyAsync(c->h_buf, c->d_buf + ZK_TALLY_WORDS, (size_t)c->world * ZK_TALLY_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *global = *local;
+    u64 total = 0, rows = 0, row = UINT64_MAX, code = 0;
+    double kmax = 0.0;
+    for (int r = 0; r < c->world; r++) {
+        const u64* w = c->h_buf + (size_t)r * ZK_TALLY_WORDS;
+        total += w[0];
+        rows += w[3];
+        if (w[1] < row) { row = w[1]; code = w[2]; }  // global rows of different ranks are distinct: no tie to break
+        double k;
+        memcpy(&k, &w[4], 8);
+        if (k > kmax) kmax = k;
+    }
+    global->rows_evaluated = rows;
+    global->fail_count = total;
+    global->first_fail_row = row;
+    global->first_fail_code = row == UINT64_MAX ? 0u : (u32)code;
+    global->kernel_ms = kmax;
     return 0;
 }

@@ -102,3 +102,58 @@ def reduce_tally(fail_count, first_fail_row, first_fail_code, row_offset, device
     if row == none:
         return total, None, 0
     return total, row, code
+
+
+class RcclTally:
+    """The same exchange through the C ABI (`zk_dist_*`, include/zkevm_hip.h): the engine's own RCCL communicator, for hosts without
+    torch.distributed.  Here the communicator id still travels over torch.distributed (any backend) when it is initialised; a
+    single process (world 1) needs nothing.  `reduce(result, row_offset)` is collective and returns what `reduce_tally` returns."""
+
+    def __init__(self, rank=0, world=1, device=None, group=None):
+        import ctypes
+
+        from . import _lib
+        from .engine import check
+
+        self._lib = _lib.init(device)
+        self._check = check
+        ident = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            check(self._lib.zk_dist_unique_id(ident), "zk_dist_unique_id", self._lib)
+        if world > 1:
+            import torch.distributed as dist
+
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        self._h = ctypes.c_void_p()
+        check(self._lib.zk_dist_init(ident, int(rank), int(world), ctypes.byref(self._h)), "zk_dist_init", self._lib)
+
+    def reduce(self, result, row_offset=0):
+        """result: an engine.Result (or anything with fail_count / first_fail_row / first_fail_code) of this rank's shard"""
+        import ctypes
+
+        from ._lib import ZkResult
+
+        raw = ZkResult()
+        raw.fail_count = int(result.fail_count)
+        raw.first_fail_row = 0xFFFFFFFFFFFFFFFF if result.first_fail_row is None else int(result.first_fail_row)
+        raw.first_fail_code = int(getattr(result, "first_fail_code", 0) or 0)
+        raw.rows_evaluated = int(getattr(result, "rows_evaluated", 0) or 0)
+        raw.kernel_ms = float(getattr(result, "kernel_ms", 0.0) or 0.0)
+        out = ZkResult()
+        self._check(self._lib.zk_dist_tally(self._h, ctypes.byref(raw), int(row_offset), ctypes.byref(out)), "zk_dist_tally", self._lib)
+        if out.first_fail_row == 0xFFFFFFFFFFFFFFFF:
+            return int(out.fail_count), None, 0
+        return int(out.fail_count), int(out.first_fail_row), int(out.first_fail_code)
+
+    def close(self):
+        if self._h:
+            self._lib.zk_dist_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
