@@ -395,7 +395,7 @@ extern "C" void sim_secp_mul(int which, const u64* a, const u64* b, u64* out, u6
             x.v[2 * q] = (u32)a[4 * i + q]; x.v[2 * q + 1] = (u32)(a[4 * i + q] >> 32);
             y.v[2 * q] = (u32)b[4 * i + q]; y.v[2 * q + 1] = (u32)(b[4 * i + q] >> 32);
         }
-        const Fr r = which == 0 ? sp_mont<SecpP>(x, y) : (which == 2 ? sp_sqr_p(x) : (which == 3 ? sp_inv_n_binary(x) : sp_mont<SecpN>(x, y)));  // 3: x^-1 mod N
+        const Fr r = which == 0 ? sp_mont<SecpP>(x, y) : (which == 2 ? sp_sqr_p(x) : (which == 3 ? sp_inv_n_binary(x) : (which == 4 ? sp_inv_n_safegcd(x) : sp_mont<SecpN>(x, y))));  // 3 / 4: x^-1 mod N, binary / division steps
         for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)r.v[2 * q] | ((u64)r.v[2 * q + 1] << 32);
     }
 }

@@ -97,7 +97,8 @@ def test_field_products_known_answers(hostsim):
 
 
 def test_scalar_field_inversion_known_answers(hostsim):
-    """sp_inv_n_binary (the right-shift binary inversion the verification uses for s^-1 mod N) against pow(x, -1, N)"""
+    """s^-1 mod N against pow(x, -1, N): sp_inv_n_safegcd (Bernstein-Yang division steps, what the verification uses since round 4) and
+    sp_inv_n_binary (the right-shift binary inversion of round 3, kept behind -DZK_SECP_INV_BINARY)"""
     import random
 
     from oracle import wire
@@ -109,8 +110,13 @@ def test_scalar_field_inversion_known_answers(hostsim):
     xs = [x % E.N or 1 for x in xs]
     a = wire.ints_to_cells(xs)
     out = np.zeros_like(a)
-    hostsim.sim_secp_mul(ctypes.c_int(3), vp(a), vp(a), vp(out), ctypes.c_uint64(len(xs)))
-    assert wire.cells_to_ints(out) == [pow(x, -1, E.N) for x in xs]
+    xs += [rng.randrange(1, 1 << k) for k in range(1, 257, 3) for _ in range(4)]
+    xs = [x % E.N or 1 for x in xs]
+    a = wire.ints_to_cells(xs)
+    out = np.zeros_like(a)
+    for which in (3, 4):
+        hostsim.sim_secp_mul(ctypes.c_int(which), vp(a), vp(a), vp(out), ctypes.c_uint64(len(xs)))
+        assert wire.cells_to_ints(out) == [pow(x, -1, E.N) for x in xs], which
 
 
 def _group_law_edge_cases():
