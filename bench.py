@@ -645,16 +645,64 @@ def oneshot_profile_numbers(profile):
     return (traffic / n if seen_pmc else None), (kernel_ns / n / 1e6 if kernel_ns else None)
 
 
-def oneshot_roofline(w, spans, log_rows):
+def live_pmc_traffic(log_rows):
+    """HBM-side bytes of ONE one-shot step, measured now: two short child runs of this file's own one-shot step under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE — separate passes, counters only, as the MI355X guide prescribes), the same
+    corrections as the committed profile's (oneshot_profile_numbers).  Steps are counted by the fill kernel's dispatches (one per
+    zk_evm_verify).  Returns (bytes per step or None, how it was obtained)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    kernels = {}
+    steps = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="zk_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--log-rows", str(log_rows), "--steps", "4", "--warmup", "2"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            agg = {}
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                import csv
+
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter:
+                        a = agg.setdefault(r["Kernel_Name"], [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(r["Counter_Value"])
+            for name, (n, tot) in agg.items():
+                kernels.setdefault(name, {}).setdefault("pmc", {})[counter] = {"dispatches": n, "avg_per_dispatch": tot / n}
+                if "evm_open_fill_kernel" in name:
+                    steps = n
+        except Exception as e:  # noqa: BLE001 — the committed profile stays the source then, and the line says so
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"live rocprofv3 --pmc {counter} pass failed ({type(e).__name__})"
+        shutil.rmtree(out, ignore_errors=True)
+    if not steps:
+        return None, "live rocprofv3 passes saw no one-shot steps"
+    traffic, _ = oneshot_profile_numbers({"bench_line": {"steps": steps, "warmup": 0}, "kernels": kernels})
+    return traffic, f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over {steps} one-shot steps of a child process (bench.py live_pmc_traffic)"
+
+
+def oneshot_roofline(w, spans, log_rows, live=None):
     """§8(d): algorithmic bytes of one step / the device span of one step (every kernel that reads them lies inside it)"""
     open_ms, pass_ms, span_ms = spans
     profile, profile_src = load_profile("evm_oneshot", log_rows)
     traffic, rocprof_ms = oneshot_profile_numbers(profile)
+    committed = traffic
+    if live and live[0]:
+        traffic, profile_src_traffic = live
+    else:
+        profile_src_traffic = (profile_src + (f" ({live[1]})" if live and live[1] else "")) if traffic else None
     achieved = w.algo_bytes / (span_ms / 1e3) / 1e9
     return {
         "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
         "frac_source": "SURVEY 8(d) algorithmic bytes per step / device span of one zk_evm_verify (HIP events on its first and last dispatch)",
-        "traffic": traffic, "traffic_source": profile_src if traffic else None,
+        "traffic": traffic, "traffic_source": profile_src_traffic, "traffic_committed_profile": committed,
         "traffic_over_algorithmic": None if not traffic else traffic / w.algo_bytes,
         "algorithmic_bytes": w.algo_bytes, "witness_bytes_resident": getattr(w, "witness_bytes", None),
         "kernel": "zk_evm_verify = evm_open_fill + evm_open_phase1 + evm_open_phase2 + evm_steps_kernel<hot> (+ warm / cold)",
@@ -701,11 +749,16 @@ def main():
     ap.add_argument("--no-batch-leg", action="store_true", help="EVM: skip the batch-entry (two witnesses in flight) side measurement")
     ap.add_argument("--tally", default="torch", choices=["torch", "abi"],
                     help="the tally exchange: torch.distributed all-gather (default) or the C ABI's own RCCL communicator (zk_dist_*; checked against the other)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="EVM one-shot line: take roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of live_pmc_traffic: one-shot steps only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[0], [1], [3], [4] after the headline (default: run them at N = 1, evm workload)")
     args = ap.parse_args()
+    if args.pmc_child:  # counters are collected over the one-shot steps alone
+        args.no_session_leg = args.no_batch_leg = args.no_cold_leg = args.no_fresh_leg = args.no_other_configs = args.no_cpu_baseline = True
+        args.no_live_pmc = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)
 
@@ -774,7 +827,8 @@ def main():
     if rank == 0:
         rows_total = w.total_units * args.steps
         if oneshot_mode:
-            roofline, profile, profile_src = oneshot_roofline(w, spans, log_rows)
+            live = live_pmc_traffic(log_rows) if (world == 1 and not args.no_live_pmc and not args.pmc_child) else None
+            roofline, profile, profile_src = oneshot_roofline(w, spans, log_rows, live)
         else:
             roofline, profile, profile_src = roofline_block(w, res, world, strong, cold_ms)
         out = {
