@@ -24,5 +24,17 @@ for seed in (41, 42, 43):
             bad += 1
             d = [(j, g, e) for j, (g, e) in enumerate(zip(got, exp)) if g != e][:5]
             print("MISMATCH seed", seed, sort, d)
+    # round 4: the side-stream form of the pass and the one-shot C entry (single-pass open: staging from the step rows) on the same witness
+    import torch
+    with engine.open_evm(w, side_stream=True) as s:
+        s.run(); s.run(); got = s.read_status().tolist()
+    if got != exp:
+        bad += 1; print("MISMATCH side stream, seed", seed)
+    dev = {k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v.view(np.int32) if v.dtype == np.uint32 else v).cuda() for k, v in w.items()}
+    buf = torch.full((len(exp),), 0x7fffffff, dtype=torch.int32, device="cuda")
+    res = engine.evm_verify(dev, status_dev=buf)
+    got = buf.cpu().numpy().view(np.uint32).tolist()
+    if got != exp or res.fail_count != sum(1 for e in exp if e):
+        bad += 1; print("MISMATCH one-shot, seed", seed)
     print(seed, "failing", sum(1 for e in exp if e))
 print("bad", bad)
