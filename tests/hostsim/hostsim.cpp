@@ -189,6 +189,8 @@ extern "C" int sim_keccak_table(const uint8_t* data, const u64* offsets, u64 n, 
     g.rpow = rpow.data();
     g.rows = rows;
     g.mode = mode;
+    g.long_list = nullptr;
+    g.long_count = nullptr;
     for (u64 i = 0; i < n; i++) status[i] = keccak_table_row(g, i);
     return 0;
 }

@@ -148,6 +148,42 @@ def test_gpu_alignments_and_device_buffers():
 
 
 @pytest.mark.gpu
+def test_gpu_long_messages_lane_group_form():
+    """Messages of 544 bytes and more (KeccakCircuit.add mode) are hashed and RLC'd by a 32-lane group each
+    (csrc/keccak_table.hpp keccak_table_row_group): lengths around the threshold, the rate (136), the RLC chunk (64) and the
+    per-lane run boundaries (32 runs), odd alignments, long and short messages mixed in one batch — against the oracle and,
+    bit for bit, against the one-lane-per-message form (ZK_KECCAK_NO_GROUPS=1)."""
+    from zkevm_specs_amd import engine
+
+    rng = random.Random(17)
+    r = rng.randrange(KT.P)
+    lens = [543, 544, 545, 136 * 4, 136 * 4 + 1, 136 * 5 - 1, 136 * 5, 64 * 9, 64 * 9 + 1, 64 * 32, 64 * 32 + 63, 64 * 33, 64 * 64 + 5, 2047, 2048, 2049, 2720,
+            4095, 4096, 24575, 24576, 24577, 30000]
+    lens += [rng.randrange(544, 9000) for _ in range(40)] + [rng.randrange(0, 544) for _ in range(60)]
+    for lead in (0, 3):
+        rng.shuffle(lens)
+        msgs = [bytes(rng.getrandbits(8) for _ in range(n)) for n in lens]
+        blob = bytes(lead) + b"".join(msgs)
+        data = np.frombuffer(blob, dtype=np.uint8).copy()
+        offsets = (np.cumsum([0] + [len(m) for m in msgs]) + lead).astype(np.uint64)
+        want, _ = KT.table_rows(msgs, r, 0)
+        with engine.open_keccak(data, offsets, r, 0) as s:
+            assert s.run().ok
+            got = s.rows()
+            assert s.run().ok  # a second pass over the same session (the work list is rebuilt per pass)
+            assert np.array_equal(s.rows(), got)
+        bad = [i for i in range(len(msgs)) if not np.array_equal(got[i], want[i])]
+        assert not bad, [(i, len(msgs[i])) for i in bad[:8]]
+        os.environ["ZK_KECCAK_NO_GROUPS"] = "1"
+        try:
+            with engine.open_keccak(data, offsets, r, 0) as s:
+                assert s.run().ok
+                assert np.array_equal(s.rows(), got)
+        finally:
+            del os.environ["ZK_KECCAK_NO_GROUPS"]
+
+
+@pytest.mark.gpu
 def test_gpu_full_size_properties():
     """2^16 public keys (64 B, Tx/Sig shape) + bytecode-sized inputs: size-independent checks.
     Row i depends only on message i: a shuffled batch gives the shuffled rows; sampled rows equal

@@ -582,6 +582,8 @@ extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint6
     g.rpow = s->a64[1].data();
     g.rows = s->keccak_rows.data();
     g.mode = mode;
+    g.long_list = nullptr;
+    g.long_count = nullptr;
     s->row = [s](u64 i) { return keccak_table_row(s->kgen, i); };
     *out = s;
     return 0;

@@ -210,6 +210,16 @@ ZK_NOINLINE Fr fr_mont(Fr a, Fr b) {
 ZK_HD Fr fr_mul(const Fr& a, const Fr& b) { return fr_mont(fr_mont(a, b), frm_r2()); }
 ZK_HD Fr fr_mulc(const Fr& a, const Fr& cM) { return fr_mont(a, cM); }
 ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont(a, frm_r2()); }
+// Mont(r^k) for k < 128 from rM = Mont(r), square-and-multiply: the lanes of a power-table kernel compute their own entries
+// (14 products each) instead of one lane walking the table (64 dependent products: 80-180 us per table at one wavefront's pace)
+ZK_HD Fr fr_pow_small_mont(const Fr& rM, u32 k) {
+    Fr acc = frm_one(), sq = rM;
+    for (int b = 0; b < 7; b++) {
+        if ((k >> b) & 1u) acc = fr_mont(acc, sq);
+        sq = fr_mont(sq, sq);
+    }
+    return acc;
+}
 // FQ.inv (util/arithmetic.py:59-60: py_ecc's prime_field_inv, which returns 0 for 0): Fermat, a^(p-2), a square-and-multiply
 // walk over the bits of p - 2 in Montgomery form (254 squarings + the products of its 109 one-bits below the top; a vector
 // op for callers and tests — the circuits' own inverses are all of constants, folded at build time)

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u3
     tally_commit(tally, i, code);
 }
 // Bytecode-circuit witness assignment (bytecode_assign.hpp)
-__global__ void bca_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) bca_fill_rpow(r, out);
+__global__ void bca_rpow_kernel(Fr r, u64* out) {  // entry m = Mont(r^m), one lane each (bca_fill_rpow is the host form)
+    if (blockIdx.x == 0 && threadIdx.x < BCA_RPOW_ROWS) bca_store(out + 4 * threadIdx.x, fr_pow_small_mont(fr_to_mont(r), threadIdx.x));
 }
 __global__ void bca_chunk_kernel(BcaArgs a) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,17 +135,33 @@ __global__ __launch_bounds__(256) void bca_rows_kernel(BcaArgs a, u32* status, Z
     tally_commit(tally, i, 0);
 }
 // Keccak table generation: one lane per message (keccak_table.hpp)
-__global__ void keccak_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) kt_fill_rpow(r, out);
+__global__ void keccak_rpow_kernel(Fr r, u64* out) {  // rows 0..64: r^k canonical; row 65: Mont(r^64) (kt_fill_rpow is the host form)
+    const u32 k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= KT_RPOW_ROWS) return;
+    const Fr pM = fr_pow_small_mont(fr_to_mont(r), k < 65u ? k : 64u);
+    kt_store(out + 4 * k, k < 65u ? fr_mont(pM, fr_from_u64(1)) : pM);
 }
 __global__ __launch_bounds__(256) void keccak_table_kernel(KeccakGenArgs g, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 code = 0;
     if (i < g.n) {
-        code = keccak_table_row(g, i);
+        // long messages of the KeccakCircuit.add form go to the lane-group kernel behind this one (their status is 0: only
+        // KeccakTable.add has a failing case, inputs over 64 bytes, and that verdict needs no hashing)
+        if (g.long_list && g.mode == KT_MODE_CIRCUIT && g.offsets[i + 1] - g.offsets[i] >= KT_GROUP_MIN_BYTES)
+            g.long_list[atomicAdd(g.long_count, 1u)] = (u32)i;
+        else
+            code = keccak_table_row(g, i);
         if (status) status[i] = code;
     }
     tally_commit(tally, i, code);
+}
+// two messages per wavefront; the groups walk the list of long messages grid-stride (its length is only known on the device)
+__global__ __launch_bounds__(256) void keccak_table_group_kernel(KeccakGenArgs g) {
+    const u32 gl = threadIdx.x & 31u;
+    const int base = (int)(threadIdx.x & 32u);
+    const u32 n_long = *g.long_count;
+    const u32 groups = gridDim.x * (blockDim.x >> 5);
+    for (u32 k = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); k < n_long; k += groups) keccak_table_row_group(g, g.long_list[k], gl, base);
 }
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally) {
     const u32 cap = a.mask + 1u;
@@ -156,7 +172,7 @@ void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, Zk
     hipLaunchKernelGGL(assign_rank_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
     hipLaunchKernelGGL(assign_rows_kernel, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a, status, tally);
 }
-void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(bca_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }
+void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(bca_rpow_kernel, dim3(1), dim3(128), 0, st, r, out); }
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally) {
     const u32 gc = (u32)((a.n_codes + 63) / 64), gk = (u32)((a.n_chunks + 63) / 64);
     if (a.n_codes) {
@@ -167,8 +183,8 @@ void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, Zk
     hipLaunchKernelGGL(bca_rows_kernel, dim3((u32)((a.n_out + 255) / 256)), dim3(256), 0, st, a, status, tally);
 }
 // Copy-circuit witness assignment (copy_assign.hpp)
-__global__ void cpa_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) cpa_fill_rpow(r, out);
+__global__ void cpa_rpow_kernel(Fr r, u64* out) {  // entry m = Mont(r^m), one lane each (cpa_fill_rpow is the host form)
+    if (blockIdx.x == 0 && threadIdx.x < CPA_RPOW_ROWS) cpa_store(out + 4 * threadIdx.x, fr_pow_small_mont(fr_to_mont(r), threadIdx.x));
 }
 __global__ void cpa_chunk_kernel(CpaArgs a) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,14 +206,19 @@ __global__ __launch_bounds__(256) void cpa_rows_kernel(CpaArgs a, u32* status, Z
     }
     tally_commit(tally, j, 0);
 }
-void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(cpa_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }
+void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(cpa_rpow_kernel, dim3(1), dim3(128), 0, st, r, out); }
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally) {
     if (a.n_chunks) hipLaunchKernelGGL(cpa_chunk_kernel, dim3((u32)((a.n_chunks + 63) / 64)), dim3(64), 0, st, a);
     if (a.n_events) hipLaunchKernelGGL(cpa_prefix_kernel, dim3((u32)((a.n_events + 63) / 64)), dim3(64), 0, st, a);
     if (a.n_chunks) hipLaunchKernelGGL(cpa_rlc_kernel, dim3((u32)((a.n_chunks + 63) / 64)), dim3(64), 0, st, a);
     if (a.n_rows) hipLaunchKernelGGL(cpa_rows_kernel, dim3((u32)((a.n_rows + 255) / 256)), dim3(256), 0, st, a, status, tally);
 }
-void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(64), 0, st, r, out); }
+void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(128), 0, st, r, out); }
 void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status, ZkTally* tally) {
+    if (g.long_list) (void)hipMemsetAsync(g.long_count, 0, sizeof(u32), st);
     hipLaunchKernelGGL(keccak_table_kernel, dim3((u32)((g.n + 255) / 256)), dim3(256), 0, st, g, status, tally);
+    if (g.long_list) {
+        const u64 blocks = (g.n + 7) / 8;  // eight groups per block; at most one group per message
+        hipLaunchKernelGGL(keccak_table_group_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, g);
+    }
 }

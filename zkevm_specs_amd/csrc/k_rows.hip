@@ -40,8 +40,11 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u64 lo, u64 
     tally_commit(tally, i, code);
 }
 // Tx / Sig circuits: one lane per tx slot / signature row (units are independent: no halo).
-__global__ void sign_rpow_kernel(Fr r, u64* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) sign_fill_rpow(r, out);
+__global__ void sign_rpow_kernel(Fr r, u64* out) {  // row k = r^k canonical, k < 64, one lane each (sign_fill_rpow is the host form)
+    const u32 k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= 64u) return;
+    const Fr p = fr_mont(fr_pow_small_mont(fr_to_mont(r), k), fr_from_u64(1));
+    for (int j = 0; j < 4; j++) out[4 * k + j] = (u64)p.v[2 * j] | ((u64)p.v[2 * j + 1] << 32);
 }
 __global__ __launch_bounds__(256) void sign_units_kernel(SignArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);

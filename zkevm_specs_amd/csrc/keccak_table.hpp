@@ -27,7 +27,11 @@ struct KeccakGenArgs {
     const u64* rpow;      // [KT_RPOW_ROWS][4]
     u64* rows;            // out: [n][KT_NCELLS][4]
     u32 mode;
+    // device only: messages of KT_GROUP_MIN_BYTES and more (KeccakCircuit.add mode) are left to the lane-group kernel
+    u32* long_list;       // [n] their indices, in no particular order (nullptr: the one-lane form handles every message)
+    u32* long_count;
 };
+#define KT_GROUP_MIN_BYTES 544u  // four rate blocks: below that the one-lane form's 64 messages per wavefront win
 
 ZK_HD void kt_fill_rpow(const Fr& r, u64* out) {
     Fr p = fr_from_u64(1);
@@ -204,3 +208,120 @@ ZK_HD u32 keccak_table_row(const KeccakGenArgs& g, u64 i) {
     }
     return 0;
 }
+
+
+#ifndef ZK_HOSTSIM
+// ---------------------------------------------------------------------------------------
+// Long messages: a GROUP of 32 lanes per message (round 4).  With one lane per message a contract's bytecode is a chain of
+// len / 136 permutations of ~7,000 instructions each on ONE lane (24 KiB: 180 of them, 7.8 ms for a launch of 4,096 such
+// messages on 64 wavefronts; a block's 16 contracts bound its keccak-table launch at 1.7 ms).  Here lane l = x + 5 y of the group
+// holds state word A[x][y]: theta's column parities, rho-pi's permutation and chi's row neighbours are lane shuffles (nine 64-bit
+// shuffles per round), the 17 rate words of a block are fetched by 17 lanes at once, and the input RLC is cut into per-lane runs
+// of 64-byte chunks whose partial sums are weighted with (r^64)^k and added through a shuffle tree.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 kt_shfl64(u64 v, int lane) {
+    const u32 lo = (u32)__shfl((int)(u32)v, lane), hi = (u32)__shfl((int)(u32)(v >> 32), lane);
+    return (u64)lo | ((u64)hi << 32);
+}
+__device__ __forceinline__ u64 kt_rolv(u64 x, u32 n) { return (x << (n & 63u)) | (x >> ((64u - n) & 63u)); }
+// bytes [at, at + 8) of a message as a little-endian word; bytes at or beyond `len` read as zero (never touched)
+__device__ __forceinline__ u64 kt_word_at(const uint8_t* p, u64 at, u64 len) {
+    u64 w = 0;
+#pragma unroll
+    for (u32 b = 0; b < 8; b++)
+        if (at + b < len) w |= (u64)p[at + b] << (8u * b);
+    return w;
+}
+__device__ __forceinline__ Fr kt_shfl_fr(const Fr& a, int lane) {
+    Fr o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o.v[j] = (u32)__shfl((int)a.v[j], lane);
+    return o;
+}
+// one message by the 32 lanes [base, base + 32) of the wavefront; every lane of the group calls this with the same i
+__device__ __forceinline__ void keccak_table_row_group(const KeccakGenArgs& g, u64 i, u32 gl /* lane in group */, int base) {
+    const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                        0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                        0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                        0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                        0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    const u64 o0 = g.offsets[i], o1 = g.offsets[i + 1];
+    const uint8_t* p = g.data + o0;
+    const u64 len = o1 - o0;
+    // lane geometry (lanes 25..31 shadow lane 24's sources: their values are never read by lanes 0..24)
+    const u32 l = gl < 25u ? gl : 24u;
+    const u32 x = l % 5u, y = l / 5u;
+    // rotation offsets r[x][y] of rho, indexed x + 5 y, six bits each
+    const u64 ROT0 = (0ull) | (1ull << 6) | (62ull << 12) | (28ull << 18) | (27ull << 24) | (36ull << 30) | (44ull << 36) | (6ull << 42) | (55ull << 48) | (20ull << 54);
+    const u64 ROT1 = (3ull) | (10ull << 6) | (43ull << 12) | (25ull << 18) | (39ull << 24) | (41ull << 30) | (45ull << 36) | (15ull << 42) | (21ull << 48) | (8ull << 54);
+    const u64 ROT2 = (18ull) | (2ull << 6) | (61ull << 12) | (56ull << 18) | (14ull << 24);
+    const u32 my_rot = (u32)(((l < 10u ? ROT0 : l < 20u ? ROT1 : ROT2) >> (6u * (l % 10u))) & 63u);
+    const int col1 = base + (int)((l + 5u) % 25u), col2 = base + (int)((l + 10u) % 25u), col3 = base + (int)((l + 15u) % 25u), col4 = base + (int)((l + 20u) % 25u);
+    const int xm1 = base + (int)(5u * y + (x + 4u) % 5u), xp1 = base + (int)(5u * y + (x + 1u) % 5u), xp2 = base + (int)(5u * y + (x + 2u) % 5u);
+    // pi as a gather: the word that lands at (x', y') = (x, y) comes from ((x' + 3 y') mod 5, x')
+    const int pi_src = base + (int)(((x + 3u * y) % 5u) + 5u * x);
+    u64 a = 0;
+    const u64 nblocks = len / 136 + 1;
+    for (u64 blk = 0; blk < nblocks; blk++) {
+        const u64 off = blk * 136;
+        u64 w = 0;
+        if (gl < 17u) {
+            w = kt_word_at(p, off + 8u * gl, len);
+            if (blk + 1 == nblocks) {  // pad10*1 inside the last block
+                const u32 rem = (u32)(len - off);
+                if ((rem >> 3) == gl) w ^= 1ull << (8u * (rem & 7u));
+                if (gl == 16u) w ^= 0x80ull << 56;
+            }
+        }
+        a ^= w;
+#pragma unroll 1
+        for (int round = 0; round < 24; round++) {
+            const u64 c = a ^ kt_shfl64(a, col1) ^ kt_shfl64(a, col2) ^ kt_shfl64(a, col3) ^ kt_shfl64(a, col4);  // column parity C[x]
+            a ^= kt_shfl64(c, xm1) ^ kt_rolv(kt_shfl64(c, xp1), 1);                                                  // theta
+            const u64 b = kt_shfl64(kt_rolv(a, my_rot), pi_src);                                                     // rho + pi
+            a = b ^ (~kt_shfl64(b, xp1) & kt_shfl64(b, xp2));                                                        // chi
+            if (gl == 0u) a ^= RC[round];                                                                            // iota
+        }
+    }
+    // input RLC: a leading partial chunk (lane 0), then the W whole 64-byte chunks in 32 runs of q chunks
+    const u32 m0 = (u32)(len & 63u);
+    const u64 W = (len - m0) / 64;
+    const u64 q = (W + 31) / 32;
+    const u64 c_lo = (u64)gl * q < W ? (u64)gl * q : W, c_hi = ((u64)gl + 1) * q < W ? ((u64)gl + 1) * q : W;
+    Fr acc = fr_zero();
+    if (gl == 0u && m0) {
+        KtStream lead = kt_stream(p, m0);
+        acc = kt_chunk(lead, m0, m0 - 1, g.rpow);
+    }
+    const Fr r64m = fr_load(g.rpow + 4 * 65);
+    if (c_hi > c_lo) {
+        KtStream body = kt_stream(p + m0 + 64 * c_lo, 64 * (c_hi - c_lo));
+        for (u64 c = c_lo; c < c_hi; c++) acc = fr_add(fr_mulc(acc, r64m), kt_chunk(body, 64, 63, g.rpow));
+    }
+    {   // weight: (r^64)^(W - c_hi), square-and-multiply on the Montgomery form of r^64
+        u64 e = W - c_hi;
+        Fr sq = r64m;
+        while (__any(e != 0)) {
+            if (e & 1u) acc = fr_mulc(acc, sq);
+            sq = fr_mont(sq, sq);
+            e >>= 1;
+        }
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        const Fr o = kt_shfl_fr(acc, base + (int)((gl + (u32)d) & 31u));
+        if (gl < (u32)d) acc = fr_add(acc, o);
+    }
+    // digest words sit in lanes 0..3
+    const u64 d0 = kt_shfl64(a, base + 0), d1 = kt_shfl64(a, base + 1), d2 = kt_shfl64(a, base + 2), d3 = kt_shfl64(a, base + 3);
+    if (gl == 0u) {
+        u64* out = g.rows + i * (KT_NCELLS * 4);
+        kt_store(out + 0, fr_from_u64(2));
+        kt_store(out + 4, acc);
+        kt_store(out + 8, fr_from_u64(len));
+        out[12] = kt_bswap64(d3); out[13] = kt_bswap64(d2); out[14] = 0; out[15] = 0;
+        out[16] = kt_bswap64(d1); out[17] = kt_bswap64(d0); out[18] = 0; out[19] = 0;
+    }
+}
+#endif

@@ -1288,6 +1288,14 @@ extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint6
     s->keccak_gen.offsets = (const u64*)p;
     s->keccak_gen.n = n_msgs;
     s->keccak_gen.mode = mode;
+    s->keccak_gen.long_list = nullptr;
+    s->keccak_gen.long_count = nullptr;
+    if (mode == KT_MODE_CIRCUIT && !getenv("ZK_KECCAK_NO_GROUPS")) {  // the lane-group kernel's work list (keccak_table.hpp)
+        u32* d_list = nullptr;
+        if ((rc = dev_alloc(s, (void**)&d_list, ((size_t)n_msgs + 1) * sizeof(u32)))) goto fail;
+        s->keccak_gen.long_list = d_list + 1;
+        s->keccak_gen.long_count = d_list;
+    }
     if (dev) {
         if (hipMemcpy(rh, randomness, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
