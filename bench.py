@@ -664,7 +664,7 @@ def live_pmc_traffic(log_rows):
         cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                "--log-rows", str(log_rows), "--steps", "4", "--warmup", "2"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             agg = {}
             for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 import csv
