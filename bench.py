@@ -664,7 +664,18 @@ def live_pmc_traffic(log_rows):
         cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                "--log-rows", str(log_rows), "--steps", "4", "--warmup", "2"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)  # its own process group: a pass that overruns is ended with everything it started
+            try:
+                rc = child.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                raise
+            if rc:
+                raise subprocess.CalledProcessError(rc, cmd)
             agg = {}
             for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 import csv
