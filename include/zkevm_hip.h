@@ -278,6 +278,9 @@ int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, u
  *      (the one value outside the engine's domain: eth-keys' `if not p[1]` sees it as non-zero; any other coordinate >= P is
  *      reduced mod P, as eth-keys' formulas do implicitly).  Public keys that are not on the curve are evaluated with eth-keys'
  *      Jacobian case analysis (a Y == 0 point is the point at infinity, inv(0) == 0), so their verdicts are reproducible too.
+ *      These verdicts for keys off the curve / coordinates >= P are those of eth-keys' NATIVE backend (pure Python,
+ *      eth_keys/backends/native/ecdsa.py — what the reference's pinned environment uses); an environment with `coincurve`
+ *      installed makes KeyAPI use libsecp256k1, which rejects such keys up front.  Well-formed keys verify identically either way.
  *      out_dev (DEVICE pointer, optional): out_dev[i * out_stride] = status, e.g. meta + 0 with stride 4 to fill the
  *      units' meta column in place.  zk_launch / zk_collect / zk_read_status as for the circuits (the tally counts
  *      the signatures that did not verify).
