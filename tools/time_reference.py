@@ -56,7 +56,7 @@ def time_evm():
     meta = w.pop("meta")
     w = with_defaults(w)
     pts = []
-    for log_n in (4, 6, 8):
+    for log_n in [int(x) for x in os.environ.get("ZK_TIME_EVM_LOGS", "4,6,8").split(",")]:  # bench.py's live leg uses 4,5 (~30 s)
         n = 1 << log_n
         pw = evm_prefix(w, n)
         tables, steps = unflatten(pw)
@@ -70,7 +70,7 @@ def time_evm():
     x = np.array([p["rw_rows"] + p["bytecode_rows"] for p in pts], dtype=np.float64)
     y = np.array([p["seconds"] / p["step_pairs"] for p in pts])
     A = np.stack([np.ones_like(x), x], axis=1)
-    (a, b), *_ = np.linalg.lstsq(A, y, rcond=None)
+    (a, b), *_ = np.linalg.lstsq(A, y, rcond=None) if len(pts) > 1 else ((0.0, float(y[0] / x[0])), None)
     if a < 0:  # a per-step cost cannot be negative: refit through the origin
         a, b = 0.0, float((x * y).sum() / (x * x).sum())
     full_tables = meta["n_rw"] + meta["n_bytecode"]
@@ -79,6 +79,26 @@ def time_evm():
             "fit": {"model": "seconds_per_step_pair = a + b * (rw_rows + bytecode_rows), a >= 0", "a": float(a), "b": float(b)},
             "extrapolated_2p18": {"step_pairs": (1 << 18) - 1, "table_rows": int(full_tables), "seconds": float(per_step * ((1 << 18) - 1)),
                                   "pairs_per_s": float(1.0 / per_step), "note": "EXTRAPOLATED from the fit, not measured"}}
+
+
+def time_evm_prefixes(npz_path):
+    """bench.py's live leg: prefixes of the trace cut by the caller (evm_prefix above, saved as '<log_n>/<table>' arrays), timed
+    here through the reference's own verify_steps — this process sees the reference (PYTHONPATH), bench.py's does not"""
+    from oracle.gen_golden_evm import unflatten
+    from zkevm_specs.evm_circuit.main import verify_steps
+
+    z = np.load(npz_path)
+    logs = sorted({int(k.split("/")[0]) for k in z.files})
+    pts = []
+    for log_n in logs:
+        pw = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(f"{log_n}/")}
+        tables, steps = unflatten(pw)
+        t0 = time.perf_counter()
+        verify_steps(tables, steps)
+        dt = time.perf_counter() - t0
+        n = int(pw["steps"].shape[0]) - 1
+        pts.append({"step_pairs": n, "rw_rows": int(pw["rw"].shape[0]), "bytecode_rows": int(pw["bytecode"].shape[0]), "seconds": dt, "pairs_per_s": n / dt})
+    return {"measured": pts}
 
 
 def time_state():
@@ -216,6 +236,10 @@ def main():
     out = {"what": "the unmodified reference (/root/reference, tag 2024_08_07) on oracle/refshim dependency stand-ins, pure Python, 1 process / 1 core",
            "host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
                     "cores_total": os.cpu_count(), "cores_used": 1, "python": platform.python_version()}}
+    if os.environ.get("ZK_TIME_EVM_NPZ"):  # bench.py's live reference leg
+        out["evm_live"] = time_evm_prefixes(os.environ["ZK_TIME_EVM_NPZ"])
+        print(json.dumps(out))
+        return
     only = set(os.environ.get("ZK_TIME_ONLY", "bytecode,exp,tx,state,evm").split(","))
     prev = os.environ.get("ZK_TIME_MERGE")  # an earlier result file: sections not re-timed are carried over, marked with their origin
     if prev:
