@@ -904,8 +904,10 @@ def main():
             out["roofline"]["per_circuit"] = per_circuit
         if args.workload == "tx":
             tx_extras(out["roofline"], res, profile, profile_src)
-        if not args.no_cpu_baseline and (w.env is not None or w.wire_h is not None):
+        if not args.no_cpu_baseline and world == 1 and (w.env is not None or w.wire_h is not None):
             out["cpu_baseline"] = cpu_baseline(args.workload, w)
+        elif world > 1:
+            out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "port", "sample": "timed at N = 1 only (run without --gpus)"}
     if sess is not None:
         sess.close()
     del w, sess
