@@ -838,7 +838,12 @@ def main():
     if rank == 0:
         rows_total = w.total_units * args.steps
         if oneshot_mode:
-            live = live_pmc_traffic(log_rows) if (world == 1 and not args.no_live_pmc and not args.pmc_child) else None
+            live = None
+            if world == 1 and not args.no_live_pmc and not args.pmc_child:
+                try:
+                    live = live_pmc_traffic(log_rows)
+                except Exception as e:  # noqa: BLE001 — never let the side measurement take the line down
+                    live = (None, f"live PMC measurement failed ({type(e).__name__})")
             roofline, profile, profile_src = oneshot_roofline(w, spans, log_rows, live)
         else:
             roofline, profile, profile_src = roofline_block(w, res, world, strong, cold_ms)
