@@ -437,6 +437,7 @@ def timed_passes(ctx, sess, steps, warmup):
         if n_ramp % 16 == 0:
             sess.collect()
     sess.collect()
+    timed_passes.last_ramp = n_ramp  # reported as `pre_ramp_steps`
     for _ in range(warmup):
         sess.launch()
     sess.collect()
@@ -642,7 +643,7 @@ def oneshot_profile_numbers(profile):
     calibrated on this access pattern — for the gathering evaluation kernels) and the sum of the kernels' average durations"""
     if not profile or not profile.get("bench_line"):
         return None, None
-    n = profile["bench_line"]["steps"] + profile["bench_line"]["warmup"]
+    n = profile["bench_line"]["steps"] + profile["bench_line"]["warmup"] + (profile["bench_line"].get("pre_ramp_steps") or 0)
     traffic, kernel_ns, seen_pmc = 0.0, 0.0, False
     for name, k in profile["kernels"].items():
         if name.startswith("__amd_rocclr"):
@@ -760,6 +761,110 @@ def digest_other(roof, cfg, other):
             cfg[f"{key}_backend"] = b["backend"]
 
 
+LINE_BUDGET = 3800  # bytes: the driver keeps a bounded tail of stdout; round 4's 25 KB line outgrew it and was recorded as unparsed
+
+
+def _sig(x, digits=6):
+    """floats at `digits` significant digits (the full-precision record is bench_full.json)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses: the contract's fields, a `config` naming the workload, `roofline` and `cpu_baseline` as flat
+    numbers — never prose.  Everything else the run measured (other_configs, the legs' sample texts, resident_session, batch,
+    fresh_witness, host_path) is in `out`, which main() writes to bench_full.json.  Keeps the line under LINE_BUDGET bytes by
+    construction: fixed key lists, short strings, 6 significant digits; a last-resort trim drops the other configurations' digests."""
+    cfg_full, roof_full = out.get("config") or {}, out.get("roofline") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "pre_ramp_steps", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = {"workload": str(cfg_full.get("workload", ""))[:150]}
+    for k in ("step", "sharding"):
+        if cfg_full.get(k):
+            cfg[k] = str(cfg_full[k])[:100]
+    others = tuple(out.get("other_configs") or ())
+    for k, v in cfg_full.items():
+        if k.startswith(others) and others:
+            continue  # digest_other's flat copies: the line carries them once, under roofline.other_configs
+        if k not in cfg and isinstance(v, (int, float)) and not isinstance(v, bool):
+            cfg[k] = v
+        elif k in ("rows_per_gpu", "rows_total") and isinstance(v, dict):
+            cfg[k] = v
+    roof = {}
+    for k in ("bound", "kernel"):
+        if roof_full.get(k) is not None:
+            roof[k] = str(roof_full[k])[:110]
+    for k in ("peak", "unit", "achieved", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes", "witness_bytes_resident", "kernel_ms",
+              "open_ms", "pass_kernel_ms", "rocprof_sum_kernel_ms_per_step", "rocprof_avg_kernel_ms", "host_us_in_open", "host_us_in_launch",
+              "host_us_in_collect", "host_us_in_close", "batch_ms_per_witness", "batch_rows_per_s", "resident_ms_per_pass", "resident_rows_per_s",
+              "resident_hot_kernel_ms"):
+        if k in roof_full:
+            roof[k] = roof_full[k]
+    alg = roof_full.get("algorithmic")
+    if isinstance(alg, dict):  # the pass workloads: frac = physical traffic; the §8(d) algorithmic figure beside it
+        roof["algorithmic_bytes"], roof["algorithmic_frac"] = alg.get("bytes_per_launch"), alg.get("frac")
+    cold = roof_full.get("cold_cache")
+    if isinstance(cold, dict):
+        roof["cold_kernel_ms"] = cold.get("kernel_ms")
+    if roof_full.get("traffic_source"):
+        roof["traffic_live"] = str(roof_full["traffic_source"]).startswith("measured in this run")
+    pc = roof_full.get("per_circuit")
+    if isinstance(pc, dict):
+        roof["per_circuit_kernel_ms"] = {k: v.get("kernel_ms") for k, v in pc.items()}
+    other = {}  # <= 3 scalars per other configuration: throughput, ms per step, fraction of the roof of its dominant kernel
+    for key in (out.get("other_configs") or {}):
+        unit = "txs" if key.startswith("tx") else "rows"
+        b = out["other_configs"][key]
+        other[key] = {f"{unit}_per_s": b.get("value"), "ms_per_step": b.get("ms_per_step")}
+        r = b.get("roofline") or {}
+        if r.get("frac") is not None:
+            other[key]["frac"] = r["frac"]
+    if other:
+        roof["other_configs"] = other
+    line["config"], line["roofline"] = cfg, roof
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:120]
+        legs = cb.get("legs") or {}
+        head = legs.get("reference") or {}
+        c["extrapolated"] = bool(head.get("extrapolated", False))
+        c["measured_on"] = "this box" if (head.get("timed_on") == "this box" or cb.get("kind") == "port") else "build container"
+        c["this_box_cores_total"] = cb.get("this_box_cores_total")
+        c["legs"] = {k: {"value": v.get("value"), "cores": v.get("cores")} for k, v in legs.items()}
+        line["cpu_baseline"] = c
+    if full_path:
+        line["full_record"] = full_path
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return _sig(o)
+
+    line = rnd(line)
+    for drop in ("other_configs", "per_circuit_kernel_ms"):  # last resort; never reached with the key lists above
+        if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET:
+            break
+        line["roofline"].pop(drop, None)
+    return line
+
+
+def write_full(out):
+    """the full record next to the script (and into gpurun_out/ when that exists, so that it comes back from a lease)"""
+    name = "bench_full.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    return name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -779,6 +884,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
+    ap.add_argument("--full-line", action="store_true", help="print the full nested record on stdout instead of the compact line (it is always written to bench_full.json)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[0], [1], [3], [4] after the headline (default: run them at N = 1, evm workload)")
     args = ap.parse_args()
     if args.pmc_child:  # counters are collected over the one-shot steps alone
@@ -816,6 +922,7 @@ def main():
             session_side = (dt_s, res_s)
     else:
         dt, res = timed_passes(ctx, sess, args.steps, args.warmup)
+        pre_ramp = timed_passes.last_ramp
         if args.workload == "super":
             res, per_circuit = resolve_super(w, res)
 
@@ -868,11 +975,13 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # untimed steps BEFORE the W warm-ups (clock ramp of a fresh box): the untimed work is pre_ramp_steps + warmup steps
+            "pre_ramp_steps": PRE_RAMP_STEPS if oneshot_mode else pre_ramp,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "u256 (BN254 Fr, 4xu64 canonical cells; u32-limb Montgomery multiply)",
+            "dtype": "u256 (BN254 Fr: 4xu64 canonical cells, u32-limb Montgomery)",
             "data": "synthetic",
             "config": dict({"workload": w.workload, "sharding": f"rows x{world} ({'one global witness, tables broadcast' if strong else 'independent witnesses'}), tally all-gather"},
                            **w.extra_cfg),
@@ -935,7 +1044,13 @@ def main():
         out["other_configs"] = other_configs(ctx, args)
         digest_other(out["roofline"], out["config"], out["other_configs"])
     if rank == 0:
-        print(json.dumps(out))
+        full_path = write_full(out)
+        if args.full_line:
+            print(json.dumps(out))  # everything on one line (tools that want the nested blocks on stdout); NOT what the driver should parse
+        else:
+            line = json.dumps(compact_line(out, full_path), separators=(",", ":"))
+            assert len(line) <= LINE_BUDGET, len(line)
+            print(line, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1114,6 +1229,7 @@ def live_reference_leg(ev, logs=(4, 5)):
         sys.path.pop(0)
     top = pts[-1]
     return {"value": top["pairs_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False, "timed_on": "this box",
+            "sample_short": f"unmodified reference verify_steps, first {top['step_pairs']} step pairs of this trace, {top['seconds']:.0f} s, this box",
             "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"], "seconds": p["seconds"],
                           "rows_per_s": p["pairs_per_s"]} for p in pts],
             "sample": f"verify_steps of the unmodified reference (oracle/_ref staging copy, dependency stand-ins of oracle/refshim) over the first "
@@ -1121,12 +1237,33 @@ def live_reference_leg(ev, logs=(4, 5)):
                       f"{top['seconds']:.1f} s on one core of this box; its lookups scan the table, so the full 2^18-step trace is far slower per row"}
 
 
+def effective_cores():
+    """Cores this process may actually burn: the smaller of its affinity mask and the cgroup's CFS quota.  On the round-4 GPU box
+    os.cpu_count() said 256 while all-core passes after the first took 99.8 / 139.7 / 200.1 ms — multiples of the 100 ms CFS
+    period: 256 OpenMP threads spend the quota in a burst (pass 0: 10.9 ms) and are then throttled.  Returns (cores, how)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity mask"
+    try:
+        quota = period = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):  # cgroup v2: "<quota|max> <period>"
+            q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota, period = (None if q == "max" else float(q)), float(p_)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota, period = (None if q <= 0 else q), float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota and period and quota / period < n:
+            n, how = max(1, int(quota / period)), f"cgroup CFS quota {quota / period:.1f} cores"
+    except (OSError, ValueError):
+        pass
+    return n, how
+
+
 def cpu_baseline(workload, w):
     """CPU legs on rank 0's host cores, bounded samples.  `value` is the reference's own figure when the committed
     build-container measurement exists (kind "reference"), else the oracle port's."""
     import numpy as np
 
-    cores_total = os.cpu_count()
+    cores_total, cores_how = effective_cores()
     ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")), reverse=True)
     ref = json.load(open(ref_file[0])) if ref_file else None
     legs = {}
@@ -1163,14 +1300,15 @@ def cpu_baseline(workload, w):
             tc = time.perf_counter()
             with zengine.open_evm(sub, device="cpu") as cs:
                 t_open = time.perf_counter() - tc
-                runs = [cs.run() for _ in range(3 if threads == 1 else 7)]  # the first pass pays for the OpenMP thread pool
-                r_cpu = min(runs, key=lambda r: r.kernel_ms)
-            assert r_cpu.ok
+                runs = [cs.run() for _ in range(4 if threads == 1 else 8)]  # pass 0 (thread-pool start, and a CFS burst) is not counted
+            assert all(r.ok for r in runs)
             ms_sorted = sorted(r.kernel_ms for r in runs[1:])
-            legs[key] = {"value": hs / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms, "open_s": t_open,
-                         "pass_ms_spread": {"min": ms_sorted[0], "median": ms_sorted[len(ms_sorted) // 2], "max": ms_sorted[-1], "passes": len(ms_sorted)},
+            med = ms_sorted[len(ms_sorted) // 2]
+            legs[key] = {"value": hs / (med / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": med, "pass0_ms": runs[0].kernel_ms, "open_s": t_open,
+                         "pass_ms_spread": {"min": ms_sorted[0], "median": med, "max": ms_sorted[-1], "passes": len(ms_sorted)},
                          "sample": f"{hs} step pairs through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernels' own per-step functions compiled for the "
-                                   "host, OpenMP over the pairs; csrc/cpu_backend.cpp), best of three passes with tables and indices resident — the optimised-CPU line"}
+                                   f"host, OpenMP over the pairs; csrc/cpu_backend.cpp), MEDIAN of passes 1..{len(ms_sorted)} with tables and indices "
+                                   f"resident, {threads} thread(s) = {cores_how if threads > 1 else 'one core'} — the optimised-CPU line"}
         live = live_reference_leg(ev) if workload == "evm" else None
         if live:
             legs["reference"] = live
@@ -1182,6 +1320,7 @@ def cpu_baseline(workload, w):
                                  "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"],
                                                "rows_per_s": p["pairs_per_s"]} for p in e["measured"]],
                                  "fit": e["fit"], "extrapolated": True,
+                                 "sample_short": "unmodified reference verify_steps, 2^4/2^6/2^8-pair prefixes, build container; 2^18 EXTRAPOLATED",
                                  "sample": "verify_steps of the unmodified reference on 2^4 / 2^6 / 2^8-pair prefixes of this trace, build container "
                                            f"({os.path.basename(ref_file[0])}); the 2^18 figure is EXTRAPOLATED from the fit (linear-scan lookups, table.py:864-884)"}
     elif workload == "tx":
@@ -1208,13 +1347,13 @@ def cpu_baseline(workload, w):
                 assert r_cpu.ok, (is_sig, r_cpu)
             return time.perf_counter() - tc
 
-        for threads, key, sample, reps in ((1, "cpu_backend_1core", min(n, 1 << 9), 1), (cores_total, "cpu_backend_allcores", n, 2)):
+        for threads, key, sample, reps in ((1, "cpu_backend_1core", min(n, 1 << 9), 1), (cores_total, "cpu_backend_allcores", n, 3)):
             zlib.set_cpu_threads(threads)
-            tc = min(both_circuits(sample) for _ in range(reps))  # all cores: the first repetition pays for the OpenMP thread pool
+            tc = sorted(both_circuits(sample) for _ in range(reps))[reps // 2]  # median (all cores: repetition 0 pays for the OpenMP thread pool)
             legs[key] = {"value": sample / tc, "unit": "txs/s", "cores": threads,
                          "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications through libzkevm_cpu.so (ZK_BACKEND=cpu: "
                                    "the kernels' own per-unit functions compiled for the host, OpenMP; csrc/cpu_backend.cpp), wall clock of the one-shot "
-                                   f"entries, best of {reps}"}
+                                   f"entries, median of {reps}"}
         from oracle import ecdsa_oracle, wire
 
         sample_p = min(n, 1 << 5)
@@ -1251,11 +1390,14 @@ def cpu_baseline(workload, w):
         for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
             zlib.set_cpu_threads(threads)
             with zengine.open_state(cols, flags, mpt, device="cpu") as cs:
-                r_cpu = min((cs.run() for _ in range(3)), key=lambda r: r.kernel_ms)  # the first pass pays for the OpenMP thread pool
-            assert r_cpu.ok
-            legs[key] = {"value": int(cols.shape[1]) / (r_cpu.kernel_ms / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": r_cpu.kernel_ms,
+                runs = [cs.run() for _ in range(6)]  # pass 0 (thread-pool start, and a CFS burst) is not counted
+            assert all(r.ok for r in runs)
+            ms_sorted = sorted(r.kernel_ms for r in runs[1:])
+            med = ms_sorted[len(ms_sorted) // 2]
+            legs[key] = {"value": int(cols.shape[1]) / (med / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": med, "pass0_ms": runs[0].kernel_ms,
                          "sample": f"all {int(cols.shape[1])} rows through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernel's own per-row function compiled for "
-                                   "the host, OpenMP over the rows; csrc/cpu_backend.cpp), best of three passes with the witness and the MPT index resident"}
+                                   f"the host, OpenMP over the rows; csrc/cpu_backend.cpp), MEDIAN of passes 1..5 with the witness and the MPT index resident, "
+                                   f"{threads} thread(s)"}
         if ref and "state" in ref:
             legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
                                  "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
@@ -1263,8 +1405,8 @@ def cpu_baseline(workload, w):
     head = legs.get("reference") or legs.get("port") or legs["cpu_backend_1core"]
     return {"value": head["value"], "unit": head["unit"], "cores": 1,
             "kind": "reference" if "reference" in legs else "port",
-            "sample": head["sample"], "legs": legs,
-            "this_box_cores_total": cores_total,
+            "sample": head["sample"], "sample_short": head.get("sample_short"), "legs": legs,
+            "this_box_cores_total": cores_total, "this_box_cores_source": cores_how, "this_box_cpu_count": os.cpu_count(),
             "reference_measured_on": ("this box (oracle/_ref staging copy)" if (legs.get("reference") or {}).get("timed_on") == "this box" else
                                       None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: /root/reference does not exist "
                                                                 "here, so the `reference` leg is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box")),

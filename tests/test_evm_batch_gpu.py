@@ -1,0 +1,116 @@
+"""GPU parity of the batch entry `zk_evm_verify_batch` (include/zkevm_hip.h): n independent witnesses, two in flight on the
+device's two pipeline streams sharing the buffer arena.  Reference semantics: one `verify_steps` per witness
+(evm_circuit/main.py:14-44) — so every result must equal the oracle's tally of ITS witness, whatever ran beside it."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from tests.evm_cases import fuzz_wire, golden_files, load_cases, oracle_status
+from zkevm_specs_amd import _lib, engine
+from zkevm_specs_amd.synth_evm import synth_evm_trace
+
+pytestmark = pytest.mark.gpu
+
+
+def _tally(exp):
+    fails = [j for j, c in enumerate(exp) if c]
+    return (len(fails), fails[0], exp[fails[0]]) if fails else (0, None, 0)
+
+
+def _witnesses():
+    """(wire, expected tally): traces of different sizes; valid ones, ones with their own tampered cells (steps, RW rows,
+    bytecode, type bits), and one whose tampered pair carries word cells >= 2^128 (deferred to the general build)"""
+    rng = random.Random(77)
+    out = []
+    for n, seed, n_fuzz, wide in ((1 << 12, 41, 0, False), (3000, 42, 30, False), (1 << 13, 43, 55, False), (5000, 44, 0, False),
+                                  (1 << 12, 45, 12, True), (2500, 46, 25, False)):
+        w = {k: v for k, v in synth_evm_trace(n, seed=seed).items() if k != "meta"}
+        for _ in range(n_fuzz):
+            w = fuzz_wire(w, rng)
+        if wide:
+            w = dict(w, steps=w["steps"].copy())
+            w["steps"][777, 9, 2] = np.uint64(1)    # gas_left >= 2^128
+            w["steps"][1500, 2, 1] = np.uint64(5)   # call_id >= 2^64
+        exp = oracle_status(w)
+        assert len(exp) == n - 1
+        out.append((w, _tally(exp)))
+    assert sum(1 for _, t in out if t[0] == 0) == 2 and all(t[0] >= 5 for _, t in out if t[0])
+    return out
+
+
+def _check(results, order, ws):
+    for i, k in enumerate(order):
+        r, (n_fail, first, code) = results[i], ws[k][1]
+        assert r.fail_count == n_fail, (i, k)
+        assert r.rows_evaluated == ws[k][0]["steps"].shape[0] - 1, (i, k)
+        if n_fail:
+            assert (r.first_fail_row, r.first_fail_code) == (first, code), (i, k)
+        else:
+            assert r.ok and r.first_fail_row is None, (i, k)
+
+
+# both pipeline slots (even / odd positions) see failing and clean witnesses, clean next to failing, a witness twice in flight
+# back to back (same tables read by both streams), odd and even batch lengths, a batch of one
+ORDERS = [[0, 1, 2, 3, 4, 5], [1, 0, 3, 2, 5, 4, 0], [2, 2, 0, 0, 4, 4, 1], [3], [4, 1], [5, 3, 1, 0, 2, 4, 3, 1, 5, 0, 2]]
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_batch_results_equal_oracle_tally_per_witness(on_device):
+    import torch
+
+    ws = _witnesses()
+    wires = [w for w, _ in ws]
+    if on_device:
+        def dev(x):
+            v = x.view(np.int64) if x.dtype == np.uint64 else (x.view(np.int32) if x.dtype == np.uint32 else x)
+            return torch.from_numpy(np.ascontiguousarray(v)).cuda()
+        wires = [{k: dev(v) for k, v in w.items()} for w in wires]
+    for order in ORDERS:
+        b = engine.EvmBatch(wires, order)
+        for _ in range(3):  # repeated calls reuse the arena's buffers: results must not depend on what the buffers held before
+            b()
+            _check(b.results(), order, ws)
+    # the one-shot entry on the same witnesses agrees (same sessions, one at a time)
+    for k, (w, t) in enumerate(ws):
+        r = engine.evm_verify(wires[k])
+        assert r.fail_count == t[0] and (r.first_fail_row, r.first_fail_code if t[0] else 0) == (t[1], t[2])
+
+
+def test_batch_of_golden_cases_with_their_own_flags(golden_dir):
+    """reference-labelled golden witnesses (tiny, some raising / deferring, begin / end flags of their own) through one batch call"""
+    cases = []
+    for fn in golden_files(golden_dir):
+        cs = load_cases(fn)
+        cases += cs[:: max(1, len(cs) // 3)][:3]
+    cases = cases[:120]
+    wires = [c[1] for c in cases]
+    flags = [c[2] for c in cases]
+    b = engine.EvmBatch(wires, list(range(len(wires))), flags=flags)
+    b()
+    n_fail = 0
+    for r, (name, w, opts, _) in zip(b.results(), cases):
+        exp = oracle_status(w, opts)
+        t = _tally(exp)
+        assert r.fail_count == t[0], name
+        if t[0]:
+            assert (r.first_fail_row, r.first_fail_code) == (t[1], t[2]), name
+            n_fail += 1
+    assert n_fail >= 5
+
+
+def test_batch_null_witness_is_refused_before_anything_opens():
+    """a null witness anywhere in the list: infrastructure error, nothing opened (round 4 returned from inside the pipeline with
+    the other slot's session still open); the library keeps working afterwards"""
+    w = {k: v for k, v in synth_evm_trace(1 << 10, seed=5).items() if k != "meta"}
+    b = engine.EvmBatch([w], [0, 0, 0])
+    lib = _lib.load()
+    ptrs = (ctypes.POINTER(_lib.ZkEvmTables) * 3)(b._ptrs[0], ctypes.POINTER(_lib.ZkEvmTables)(), b._ptrs[2])
+    res = (engine.ZkResult * 3)()
+    for _ in range(50):
+        assert lib.zk_evm_verify_batch(ptrs, 3, b._opts, res) < 0
+    assert b"null witness" in lib.zk_last_error()
+    b()
+    assert all(r.ok for r in b.results())
+    assert lib.zk_evm_verify_batch(None, 0, 0, None) == 0  # an empty batch is fine

@@ -1,0 +1,39 @@
+#!/bin/bash
+# ONE parameterised lease script (run on the GPU box through gpurun): `tools/gpu_run.sh <tag> <stage>...`, stages in the order given.
+#   tests      the -m gpu suite (PYTEST_ARGS narrows it)          smoke     __graft_entry__.smoke()
+#   bench      the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5; checks that the LAST stdout line parses
+#   prof-evm   rocprofv3 passes of the one-shot headline           prof-session / prof-state / prof-tx / prof-super: the other configurations
+#   rows       tools/bench_row_kernels.py                          refsuite  the reference's own tests through the HIP library
+#   cmd:<...>  any shell command (quote it)
+# Everything lands in gpurun_out/<tag>/ (merged back by gpurun); copy what is to be judged into profiles/.
+set -u
+tag=$1; shift
+out=gpurun_out/$tag; mkdir -p "$out"
+for stage in "$@"; do
+    t0=$(date +%s)
+    case "$stage" in
+    tests)    timeout 2400 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -5 $out/pytest.log ;;
+    smoke)    python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log ;;
+    bench)    timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_stdout.txt 2> $out/bench.err; echo "bench rc=$?"
+              cp -f bench_full.json $out/bench_full.json 2>/dev/null
+              python - "$out" <<'PY'
+import json, sys
+lines = open(sys.argv[1] + "/bench_stdout.txt").read().splitlines()
+d = json.loads(lines[-1])
+print("last stdout line:", len(lines[-1]), "bytes; value", d["value"], "ms/step", d["ms_per_step"], "frac", d["roofline"]["frac"],
+      "kernel_ms", d["roofline"]["kernel_ms"], "cpu_baseline", d.get("cpu_baseline", {}).get("value"))
+print(lines[-1])
+PY
+              ;;
+    prof-evm)     tools/profile_bench.sh evm_oneshot_2p18 --no-session-leg --no-batch-leg --no-other-configs --no-live-pmc --steps 20 --warmup 5 > $out/prof_evm_oneshot.log 2>&1; tail -3 $out/prof_evm_oneshot.log | cut -c1-400 ;;
+    prof-session) tools/profile_bench.sh evm_2p18 --session-pass --no-other-configs --steps 50 --warmup 5 > $out/prof_evm.log 2>&1; tail -2 $out/prof_evm.log | cut -c1-300 ;;
+    prof-state)   tools/profile_bench.sh state_2p16 --workload state --steps 50 --warmup 5 > $out/prof_state.log 2>&1; tail -2 $out/prof_state.log | cut -c1-300 ;;
+    prof-tx)      tools/profile_bench.sh tx_2p14 --workload tx --steps 6 --warmup 2 > $out/prof_tx.log 2>&1; tail -2 $out/prof_tx.log | cut -c1-300 ;;
+    prof-super)   tools/profile_bench.sh super_2p20 --workload super --steps 10 --warmup 3 > $out/prof_super.log 2>&1; tail -2 $out/prof_super.log | cut -c1-300 ;;
+    rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
+    refsuite) timeout 900 python tools/run_reference_suite.py --backend hip --ref-root oracle/_ref/reference --out $out/reference_suite_hip.json > $out/reference_suite_hip.log 2>&1; tail -1 $out/reference_suite_hip.log ;;
+    cmd:*)    bash -c "${stage#cmd:}" > $out/cmd_$(date +%s).log 2>&1; echo "cmd rc=$?"; tail -5 $out/cmd_*.log | cut -c1-400 ;;
+    *)        echo "unknown stage $stage" ;;
+    esac
+    echo "[$stage: $(( $(date +%s) - t0 )) s]"
+done

@@ -390,6 +390,7 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
 
 extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, uint32_t opts, zk_result* results) {
     ARG_TRY((t && results) || n == 0, "zk_evm_verify_batch: bad arguments");
+    for (uint64_t i = 0; i < n; i++) ARG_TRY(t[i], "zk_evm_verify_batch: null witness");
     for (uint64_t i = 0; i < n; i++) {  // nothing to pipeline on the host: one witness after the other
         const int rc = zk_evm_verify(t[i], opts, nullptr, &results[i]);
         if (rc) return rc;

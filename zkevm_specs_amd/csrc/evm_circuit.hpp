@@ -437,6 +437,10 @@ template <int NCELLS, u32 MASK>
 ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
                               int out1_cell = 0) {
 #if EVM_FAST
+    // the pair goes to the general build: the outputs are defined (zero) all the same, never left uninitialised for a caller
+    // that would one day branch or address on them
+    if (out0) *out0 = fr_zero();
+    if (out1) *out1 = fr_zero();
     I.defer = 2u;
     I.seq++;
     return 0u;

@@ -1065,6 +1065,9 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
 extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, uint32_t opts, zk_result* results) {
     ARG_TRY(t_device >= 0, "zk_evm_verify_batch: call zk_init first");
     ARG_TRY((t && results) || n == 0, "zk_evm_verify_batch: bad arguments");
+    // every witness pointer is checked before the first session opens: an early return from inside the pipeline would leave the
+    // other slot's session open with kernels in flight (arena buffers, events and the pinned block leaked)
+    for (uint64_t i = 0; i < n; i++) ARG_TRY(t[i], "zk_evm_verify_batch: null witness");
     HIP_TRY(hipSetDevice(t_device));
     {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
@@ -1084,7 +1087,6 @@ extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, ui
             pend[slot] = nullptr;
         }
         if (!rc && i < n) {
-            ARG_TRY(t[i], "zk_evm_verify_batch: null witness");
             t_stream = g_batch_stream[t_device][slot];
             rc = zk_evm_open(t[i], opts | ZK_OPT_SINGLE_PASS, &pend[slot]);
             t_stream = caller;
@@ -1990,7 +1992,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     hipStream_t side = nullptr;
     if (s->kind == SESSION_EVM && s->evm.perm && s->side_stream &&
         !(s->evm_ranges_known && s->evm_warm_empty && s->evm_cold_empty)) {
-        if (!g_side_stream[s->device]) HIP_TRY(hipStreamCreateWithFlags(&g_side_stream[s->device], hipStreamNonBlocking));
+        {   // lazily created under the device mutex (two threads launching side-stream sessions on one device)
+            std::lock_guard<std::mutex> lock(g_dev_mutex);
+            if (!g_side_stream[s->device]) HIP_TRY(hipStreamCreateWithFlags(&g_side_stream[s->device], hipStreamNonBlocking));
+        }
         if (!s->ev_fork) {
             int erc = arena_event(s->device, &s->ev_fork);
             if (!erc) erc = arena_event(s->device, &s->ev_join);

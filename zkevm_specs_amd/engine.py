@@ -266,13 +266,19 @@ class EvmBatch:
     """A prepared call of `zk_evm_verify_batch` over resident wire dicts (the witness list may name the same dict several times):
     n independent verifications, software-pipelined two deep by the library."""
 
-    def __init__(self, wires, order, device=None):
+    def __init__(self, wires, order, device=None, flags=None):
+        """`flags`: per wire, (begin_with_first_step, end_with_last_step) — carried in each witness's own argument block"""
         self._lib = _lib.init(device)
-        prepared = [_evm_tables(w, False, False) for w in wires]
+        flags = flags if flags is not None else [(False, False)] * len(wires)
+        prepared = [_evm_tables(w, bool(f[0]), bool(f[1])) for w, f in zip(wires, flags)]
         self._keep = prepared
         self._opts = prepared[0][1]
+        # one `opts` word goes to the library for the whole batch: host and device wires (ZK_OPT_DEVICE_PTRS) cannot be mixed
+        if any(p[1] != self._opts for p in prepared):
+            raise ValueError("EvmBatch: every witness must be prepared with the same options (all host arrays or all device tensors)")
         self.n = len(order)
-        self.n_pairs = prepared[0][3]
+        self.n_pairs = prepared[0][3]                    # of the first witness (kept for callers of the equal-size case)
+        self.n_pairs_each = [prepared[k][3] for k in order]  # per witness, in call order
         arr_t = ctypes.POINTER(_lib.ZkEvmTables) * self.n
         self._ptrs = arr_t(*[ctypes.pointer(prepared[k][0]) for k in order])
         self._results = (ZkResult * self.n)()
