@@ -844,7 +844,7 @@ def compact_line(out, full_path=None):
             return [rnd(v) for v in o]
         return _sig(o)
 
-    line = rnd(line)
+    line = {k: (v if k in ("value", "ms_per_step") else rnd(v)) for k, v in line.items()}  # the two contract scalars at full precision
     for drop in ("other_configs", "per_circuit_kernel_ms"):  # last resort; never reached with the key lists above
         if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET:
             break

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra, port):
-    env = dict(os.environ, ZK_BENCH_DEVICE="0", ZK_BENCH_BACKEND="gloo")
+def _run(extra, port, env_extra=None):
+    env = dict(os.environ, ZK_BENCH_DEVICE="0", ZK_BENCH_BACKEND="gloo", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-cold-leg", "--no-fresh-leg"] + extra
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -64,3 +64,21 @@ def test_weak_scaling_two_ranks_one_gpu():
     d = _run(["--workload", "evm", "--log-rows", "14"], 29761)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * ((1 << 14) - 1)) < 1e-3
+
+
+def _fake_rccl_hip():
+    d = os.path.join(ROOT, "tests", "fakerccl")
+    so, src = os.path.join(d, "libfakerccl_hip.so"), os.path.join(d, "fake_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([os.path.join(d, "build.sh")])
+    return so
+
+
+@pytest.mark.parametrize("workload,log_rows,scaling", [("evm", 14, "strong"), ("state", 13, "weak")])
+def test_abi_tally_two_ranks_one_gpu(workload, log_rows, scaling):
+    """`--tally abi` with N = 2: the HIP library's own zk_dist_init / zk_dist_tally with world 2 — ncclCommInitRank and the
+    all-gather of device buffers on the communicator's stream — through tests/fakerccl's stand-in (RCCL refuses two ranks on one
+    device); bench.py asserts that the tally equals torch.distributed's"""
+    d = _run(["--workload", workload, "--log-rows", str(log_rows), "--scaling", scaling, "--tally", "abi"], 29791 + log_rows,
+             {"ZK_RCCL_LIB": _fake_rccl_hip()})
+    assert d["n_gpus"] == 2 and d["value"] > 0

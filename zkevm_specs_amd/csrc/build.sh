@@ -25,7 +25,7 @@ for u in $UNITS; do OBJS="$OBJS $OUT/$u.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libzkevm_hip.so $OBJS
 # the CPU backend behind the same C ABI (cpu_backend.cpp: the same headers compiled for the host, OpenMP over the rows)
 if [ ! -f ../libzkevm_cpu.so ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name cpu_backend.cpp -o -name build.sh \) -newer ../libzkevm_cpu.so | head -1)" ]; then
-    g++ -O2 -std=c++17 -fopenmp -DZK_HOSTSIM -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-array-bounds -o ../libzkevm_cpu.so cpu_backend.cpp
+    g++ -O2 -std=c++17 -fopenmp -DZK_HOSTSIM -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-array-bounds -o ../libzkevm_cpu.so cpu_backend.cpp -ldl
 fi
 cat $OUT/*.log | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | paste - - - - - - | sed 's/remark: [^ ]* //g; s/\[-Rpass-analysis=kernel-resource-usage\]//g' > "$OUT/resource_usage.txt" || true
 echo "built $(ls -la ../libzkevm_hip.so)"

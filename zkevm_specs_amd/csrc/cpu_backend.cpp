@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/zkevm_hip.h"
+#include "dist_tally.hpp"
 #include "state_circuit.hpp"
 #include "evm_circuit.hpp"
 #include "host_index.hpp"
@@ -177,28 +178,72 @@ extern "C" int zk_session_timing(zk_session*, double* open_ms, double* span_ms) 
     if (span_ms) *span_ms = -1.0;
     return 0;
 }
-// Multi-GPU tally: the CPU backend is one process (world == 1: the identity with the row offset applied); ranks of a CPU job
-// exchange their tallies on the host (zkevm_specs_amd.distributed.reduce_tally over gloo)
-struct zk_comm { int world; };
+// Multi-GPU tally.  World 1 is the identity with the row offset applied.  World > 1 goes through the same collective binding as
+// the HIP library (dist_tally.hpp) with HOST buffers — which RCCL itself does not accept, so it needs ZK_RCCL_LIB to name a
+// collective library that does (tests/fakerccl: an all-gather over a shared-memory file); without one, ranks of a CPU job
+// exchange their tallies on the host (zkevm_specs_amd.distributed.reduce_tally over gloo).
+struct zk_comm {
+    int rank = 0, world = 1;
+    void* nccl = nullptr;
+    std::vector<uint64_t> buf;  // TALLY_WORDS of this rank | TALLY_WORDS * world gathered
+};
+#define RCCL_TRY(expr, what)                                                                                                                   \
+    do {                                                                                                                                       \
+        const int r_ = (expr);                                                                                                                 \
+        if (r_ != 0) {                                                                                                                         \
+            char buf_[256];                                                                                                                    \
+            snprintf(buf_, sizeof buf_, "%s: RCCL error %d (%s)", what, r_, zkdist::rccl().GetErrorString ? zkdist::rccl().GetErrorString(r_) : "?"); \
+            g_err = buf_;                                                                                                                      \
+            return -3;                                                                                                                         \
+        }                                                                                                                                      \
+    } while (0)
+static bool host_collective() { return getenv("ZK_RCCL_LIB") && zkdist::rccl().ok && zkdist::rccl().named_by_env; }
 extern "C" int zk_dist_unique_id(uint8_t* id) {
     ARG_TRY(id, "zk_dist_unique_id: id is null");
     memset(id, 0, ZK_DIST_ID_BYTES);
+    if (host_collective()) {
+        zkdist::RcclId u;
+        RCCL_TRY(zkdist::rccl().GetUniqueId(&u), "ncclGetUniqueId");
+        memcpy(id, u.internal, ZK_DIST_ID_BYTES);
+    }
+    return 0;
+}
+extern "C" int zk_dist_close(zk_comm* c) {
+    if (c && c->nccl) (void)zkdist::rccl().CommDestroy(c->nccl);
+    delete c;
     return 0;
 }
 extern "C" int zk_dist_init(const uint8_t* id, int rank, int world, zk_comm** out) {
-    ARG_TRY(id && out, "zk_dist_init: bad arguments");
-    ARG_TRY(world == 1 && rank == 0, "zk_dist_init: the CPU backend has no collective (world must be 1); reduce on the host");
-    *out = new zk_comm{1};
+    ARG_TRY(id && out && world >= 1 && rank >= 0 && rank < world, "zk_dist_init: bad arguments");
+    ARG_TRY(world == 1 || host_collective(),
+            "zk_dist_init: the CPU backend has no collective of its own (world must be 1, or ZK_RCCL_LIB must name a library that gathers host buffers); reduce on the host");
+    zk_comm* c = new zk_comm();
+    c->rank = rank;
+    c->world = world;
+    c->buf.assign((size_t)(world + 1) * zkdist::TALLY_WORDS, 0);
+    if (world > 1) {
+        zkdist::RcclId u;
+        memcpy(u.internal, id, ZK_DIST_ID_BYTES);
+        if (int r = zkdist::rccl().CommInitRank(&c->nccl, world, u, rank)) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "ncclCommInitRank: RCCL error %d", r);
+            g_err = buf;
+            c->nccl = nullptr;
+            zk_dist_close(c);
+            return -3;
+        }
+    }
+    *out = c;
     return 0;
 }
 extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_offset, zk_result* global) {
     ARG_TRY(c && local && global, "zk_dist_tally: bad arguments");
-    *global = *local;
-    if (local->first_fail_row != UINT64_MAX) global->first_fail_row = local->first_fail_row + row_offset;
-    return 0;
-}
-extern "C" int zk_dist_close(zk_comm* c) {
-    delete c;
+    uint64_t* mine = c->buf.data();
+    uint64_t* all = mine + zkdist::TALLY_WORDS;
+    zkdist::tally_pack(mine, local, row_offset);
+    if (c->world == 1) memcpy(all, mine, zkdist::TALLY_WORDS * sizeof(uint64_t));
+    else RCCL_TRY(zkdist::rccl().AllGather(mine, all, zkdist::TALLY_WORDS, zkdist::RCCL_UINT64, c->nccl, nullptr), "ncclAllGather");
+    zkdist::tally_reduce(all, c->world, local, global);
     return 0;
 }
 extern "C" int zk_last_host_phases(double* us4) {

@@ -13,6 +13,7 @@
 
 #include "../../include/zkevm_hip.h"
 #include "kernels.hpp"
+#include "dist_tally.hpp"
 #include "host_index.hpp"
 #include "code_dir_build.hpp"
 
@@ -2240,35 +2241,9 @@ extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* 
 // Multi-GPU tally through RCCL (include/zkevm_hip.h "Multi-GPU tally").  librccl is bound at first use: nothing else in the
 // library needs it, and torch — when it is in the process — has usually loaded the same SONAME already.
 // ---------------------------------------------------------------------------------------
-namespace {
-struct RcclId { char internal[ZK_DIST_ID_BYTES]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
-struct RcclApi {
-    int (*GetUniqueId)(RcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool ok = false;
-};
-const int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h ncclDataType_t)
-RcclApi& rccl() {
-    static RcclApi api = [] {
-        RcclApi a;
-        void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!h) return a;
-        a.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
-        a.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
-        a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
-        a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
-        a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-        a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy;
-        return a;
-    }();
-    return api;
-}
-}  // namespace
+using zkdist::rccl;
+using zkdist::RcclId;
+static const int RCCL_UINT64 = zkdist::RCCL_UINT64;
 #define RCCL_TRY(expr, what)                                                                                        \
     do {                                                                                                            \
         const int r_ = (expr);                                                                                      \
@@ -2287,7 +2262,7 @@ struct zk_comm {
     u64* d_buf = nullptr;  // ZK_TALLY_WORDS of this rank | ZK_TALLY_WORDS * world gathered
     u64* h_buf = nullptr;  // page-locked, same layout, gathered part first
 };
-#define ZK_TALLY_WORDS 5  // per rank: fail count | first failing GLOBAL row (UINT64_MAX: none) | its code | rows evaluated | kernel_ms (the double's bits)
+#define ZK_TALLY_WORDS zkdist::TALLY_WORDS
 
 extern "C" int zk_dist_unique_id(uint8_t* id) {
     ARG_TRY(id, "zk_dist_unique_id: id is null");
@@ -2338,31 +2313,11 @@ extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_of
     ARG_TRY(c && local && global, "zk_dist_tally: bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     u64* mine = c->h_buf + (size_t)c->world * ZK_TALLY_WORDS;
-    mine[0] = local->fail_count;
-    mine[1] = local->first_fail_row == UINT64_MAX ? UINT64_MAX : local->first_fail_row + row_offset;
-    mine[2] = local->first_fail_row == UINT64_MAX ? 0u : (u64)local->first_fail_code;
-    mine[3] = local->rows_evaluated;
-    memcpy(&mine[4], &local->kernel_ms, 8);
+    zkdist::tally_pack(mine, local, row_offset);
     HIP_TRY(hipMemcpyAsync(c->d_buf, mine, ZK_TALLY_WORDS * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(rccl().AllGather(c->d_buf, c->d_buf + ZK_TALLY_WORDS, ZK_TALLY_WORDS, RCCL_UINT64, c->nccl, c->stream), "ncclAllGather");
     HIP_TRY(hipMemcpyAsync(c->h_buf, c->d_buf + ZK_TALLY_WORDS, (size_t)c->world * ZK_TALLY_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    *global = *local;
-    u64 total = 0, rows = 0, row = UINT64_MAX, code = 0;
-    double kmax = 0.0;
-    for (int r = 0; r < c->world; r++) {
-        const u64* w = c->h_buf + (size_t)r * ZK_TALLY_WORDS;
-        total += w[0];
-        rows += w[3];
-        if (w[1] < row) { row = w[1]; code = w[2]; }  // global rows of different ranks are distinct: no tie to break
-        double k;
-        memcpy(&k, &w[4], 8);
-        if (k > kmax) kmax = k;
-    }
-    global->rows_evaluated = rows;
-    global->fail_count = total;
-    global->first_fail_row = row;
-    global->first_fail_code = row == UINT64_MAX ? 0u : (u32)code;
-    global->kernel_ms = kmax;
+    zkdist::tally_reduce(c->h_buf, c->world, local, global);
     return 0;
 }
