@@ -4,6 +4,7 @@
 #   bench      the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5; checks that the LAST stdout line parses
 #   prof-evm   rocprofv3 passes of the one-shot headline           prof-session / prof-state / prof-tx / prof-super: the other configurations
 #   rows       tools/bench_row_kernels.py                          refsuite  the reference's own tests through the HIP library
+#   ab:<A=x,B=y> A/B of environment switches on the one-shot headline (default, each switch alone, all together; twice)
 #   cmd:<...>  any shell command (quote it)
 # Everything lands in gpurun_out/<tag>/ (merged back by gpurun); copy what is to be judged into profiles/.
 set -u
@@ -32,6 +33,14 @@ PY
     prof-super)   tools/profile_bench.sh super_2p20 --workload super --steps 10 --warmup 3 > $out/prof_super.log 2>&1; tail -2 $out/prof_super.log | cut -c1-300 ;;
     rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
     refsuite) timeout 900 python tools/run_reference_suite.py --backend hip --ref-root oracle/_ref/reference --out $out/reference_suite_hip.json > $out/reference_suite_hip.log 2>&1; tail -1 $out/reference_suite_hip.log ;;
+    ab:*)     # A/B of environment switches on the one-shot headline: `ab:ZK_P1_TAIL=0,ZK_PRECLEAN=0` runs the default, each switch, and all of them
+              sw="${stage#ab:}"; IFS=',' read -ra S <<< "$sw"
+              q="--no-other-configs --no-cpu-baseline --no-live-pmc --no-session-leg --no-batch-leg --no-cold-leg --no-fresh-leg --steps 50 --warmup 5"
+              for rep in 1 2; do
+                for e in "" "${S[@]}" "${sw//,/ }"; do
+                  printf "%-40s " "[${e:-default}]"; env $e python bench.py $q 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('ms/step %.4f span %.4f open %.4f pass %.4f' % (d['ms_per_step'], r['kernel_ms'], r['open_ms'], r['pass_kernel_ms']))"
+                done
+              done | tee $out/ab_$(date +%s).txt ;;
     cmd:*)    bash -c "${stage#cmd:}" > $out/cmd_$(date +%s).log 2>&1; echo "cmd rc=$?"; tail -5 $out/cmd_*.log | cut -c1-400 ;;
     *)        echo "unknown stage $stage" ;;
     esac

@@ -52,6 +52,7 @@ struct EvmDyn {
     u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
     u32 dir_entries;    // directory build: groups counted so far (may exceed the capacity; then codes_n stays 0)
     u32 n_deferred;     // pairs the fast (hot) kernel handed to the general build this pass (reset at the start of every pass)
+    u32 open_timeout;   // a tail block of the open launch gave up waiting for its producers (never expected; zk_collect reports it)
 };
 
 struct EvmArgs {
@@ -429,31 +430,11 @@ ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u
     return kind == ZK_LOOKUP_UNSAT ? 0u : (u32)res;
 }
 
-// The same lookup for the tables the warm gadgets query on every step (copy / keccak / exp tables): cell count and query mask
-// are compile-time constants, so the query stays in registers (no private copy handed to an out-of-line probe: that copy was the
-// warm kernel's scratch) and the candidate row is compared in 4-cell groups — the loads of a group in flight together,
-// folded into one difference word — instead of one dependent round trip per cell.  Same verdicts as table_probe_generic.
+// The probe itself, without an instruction context: `kind` = 0 / ZK_LOOKUP_UNSAT / ZK_LOOKUP_AMBIGUOUS, returns the row found (0 if
+// none).  Also what the Copy circuit's bytecode / tx-table lookups use (copy_circuit.hpp).
 template <int NCELLS, u32 MASK>
-ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
-                              int out1_cell = 0) {
-#if EVM_FAST
-    // the pair goes to the general build: the outputs are defined (zero) all the same, never left uninitialised for a caller
-    // that would one day branch or address on them
-    if (out0) *out0 = fr_zero();
-    if (out1) *out1 = fr_zero();
-    I.defer = 2u;
-    I.seq++;
-    return 0u;
-#endif
-#ifdef ZK_WARM_GENERIC_LOOKUP  // tuning build: the out-of-line generic probe, for A / B timelines
-    {
-        const u32 rg = table_lookup<NCELLS>(I, t, h, q, MASK);
-        if (out0) *out0 = zk_table_cell(t, rg, out0_cell);
-        if (out1) *out1 = zk_table_cell(t, rg, out1_cell);
-        return rg;
-    }
-#endif
-    I.seq++;
+ZK_HD u32 table_probe_inline(const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32& kind, Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
+                             int out1_cell = 0) {
     u32 found = ZK_EMPTY_SLOT;
     bool ambiguous = false;
     if (out0) *out0 = fr_zero();
@@ -506,8 +487,40 @@ ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCE
             if (r != ZK_EMPTY_SLOT) r_next = t.slots[(slot + 1) & t.mask];
         }
     }
-    if (found == ZK_EMPTY_SLOT) { ev_fail(I, ZK_LOOKUP_UNSAT); return 0u; }
-    if (ambiguous) ev_fail(I, ZK_LOOKUP_AMBIGUOUS);
+    kind = found == ZK_EMPTY_SLOT ? (u32)ZK_LOOKUP_UNSAT : (ambiguous ? (u32)ZK_LOOKUP_AMBIGUOUS : 0u);
+    return found == ZK_EMPTY_SLOT ? 0u : found;
+}
+
+
+// The same lookup for the tables the warm gadgets query on every step (copy / keccak / exp tables): cell count and query mask
+// are compile-time constants, so the query stays in registers (no private copy handed to an out-of-line probe: that copy was the
+// warm kernel's scratch) and the candidate row is compared in 4-cell groups — the loads of a group in flight together,
+// folded into one difference word — instead of one dependent round trip per cell.  Same verdicts as table_probe_generic.
+template <int NCELLS, u32 MASK>
+ZK_HD u32 table_lookup_inline(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
+                              int out1_cell = 0) {
+#if EVM_FAST
+    // the pair goes to the general build: the outputs are defined (zero) all the same, never left uninitialised for a caller
+    // that would one day branch or address on them
+    if (out0) *out0 = fr_zero();
+    if (out1) *out1 = fr_zero();
+    I.defer = 2u;
+    I.seq++;
+    return 0u;
+#endif
+#ifdef ZK_WARM_GENERIC_LOOKUP  // tuning build: the out-of-line generic probe, for A / B timelines
+    {
+        const u32 rg = table_lookup<NCELLS>(I, t, h, q, MASK);
+        if (out0) *out0 = zk_table_cell(t, rg, out0_cell);
+        if (out1) *out1 = zk_table_cell(t, rg, out1_cell);
+        return rg;
+    }
+#endif
+    I.seq++;
+    u32 kind;
+    const u32 found = table_probe_inline<NCELLS, MASK>(t, h, q, kind, out0, out0_cell, out1, out1_cell);
+    if (kind == (u32)ZK_LOOKUP_UNSAT) { ev_fail(I, ZK_LOOKUP_UNSAT); return 0u; }
+    if (kind) ev_fail(I, ZK_LOOKUP_AMBIGUOUS);
     return found;
 }
 

@@ -1,4 +1,5 @@
 // Bytecode / Copy / Tx+Sig / Exp row kernels
+#include <stdlib.h>
 #include "kernels.hpp"
 
 // ---------------------------------------------------------------------------------------
@@ -29,14 +30,21 @@ __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u64 
     else if (status) status[i] = code;
     tally_commit(tally, i, code);
 }
+// Copy: a wavefront holds 64 consecutive rows, evaluates the first 62 and takes the cells of rows i + 1 / i + 2 from lanes + 1 /
+// + 2; its last two lanes are (read-only) successors.  Rows past the end wrap to the start (copy_circuit.py:92-130).
 __global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
-    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 code = 0;
-    if (i < hi) {
-        code = copy_check_row(a, i);
-        if (status) status[i] = code;
-    }
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 n = a.rows.n;
+    u64 i = lo + wave * CP_ROWS_PER_WAVE + lane;
+    const bool evaluate = lane < (u32)CP_ROWS_PER_WAVE && i < hi;
+    if (i >= n) i %= n;  // the wrap-around successors (and lanes further out, which only have to stay in bounds)
+    CpRow C;
+    copy_load_row(a.rows, i, C);
+    u32 code = copy_check_loaded(a, C, C, C);
+    if (!evaluate) code = 0;
+    else if (status) status[i] = code;
     tally_commit(tally, i, code);
 }
 // Tx / Sig circuits: one lane per tx slot / signature row (units are independent: no halo).
@@ -96,7 +104,11 @@ void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 
     hipLaunchKernelGGL(bytecode_rows_kernel, dim3((u32)((hi - lo + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, a, lo, hi, status, tally);
 }
 void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
+    // small tables: one wavefront per block (2^15 rows = 532 wavefronts reach every CU; four per block only a third of them)
+    static const u32 forced = [] { const char* e = getenv("ZK_COPY_BLOCK"); const int v = e ? atoi(e) : 0; return (u32)((v == 64 || v == 128 || v == 256) ? v : 0); }();
+    const u64 waves = (hi - lo + CP_ROWS_PER_WAVE - 1) / CP_ROWS_PER_WAVE;
+    const u32 block = forced ? forced : (waves <= 4096 ? 64u : 256u);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((u32)((waves + block / 64 - 1) / (block / 64))), dim3(block), 0, st, a, lo, hi, status, tally);
 }
 void zk_launch_sign_units(hipStream_t st, const SignArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     hipLaunchKernelGGL(sign_units_kernel, dim3(grid256(hi - lo)), dim3(256), 0, st, a, lo, hi, status, tally);
