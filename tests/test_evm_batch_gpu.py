@@ -82,7 +82,7 @@ def test_batch_of_golden_cases_with_their_own_flags(golden_dir):
     """reference-labelled golden witnesses (tiny, some raising / deferring, begin / end flags of their own) through one batch call"""
     cases = []
     for fn in golden_files(golden_dir):
-        cs = load_cases(fn)
+        cs = list(load_cases(fn))
         cases += cs[:: max(1, len(cs) // 3)][:3]
     cases = cases[:120]
     wires = [c[1] for c in cases]

@@ -302,6 +302,74 @@ ZK_HD u64 keccak_key_hash(const ZkTable& t, u32 r) { return keccak_key_hash_cell
 ZK_HD u64 zk_code_hash_key(const Fr& lo, const Fr& hi) { return zk_hash_cell(zk_hash_cell(0xc0de5u, lo), hi); }
 
 // Column-major witness: cell c of row i at cells[(c * n + i) * 4].
+ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
+    bool same = true;
+    for (u32 c = 0; c < t.ncells; c++) same = same && fr_eq(zk_table_cell(t, r0, c), zk_table_cell(t, r1, c));
+    return same;
+}
+
+// Inline "exactly one distinct matching row" probe over an open-addressing index, query cells and mask compile-time: `kind` = 0 / ZK_LOOKUP_UNSAT / ZK_LOOKUP_AMBIGUOUS, returns the row found (0 if
+// none).  Used by the EVM warm gadgets (table_lookup_inline), the Copy circuit's lookups and the keccak-table membership tests.
+template <int NCELLS, u32 MASK>
+ZK_HD u32 table_probe_inline(const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32& kind, Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
+                             int out1_cell = 0) {
+    u32 found = ZK_EMPTY_SLOT;
+    bool ambiguous = false;
+    if (out0) *out0 = fr_zero();
+    if (out1) *out1 = fr_zero();
+    if (t.n != 0) {
+        u32 slot = (u32)h & t.mask;
+        // two dependent round trips per probe: the slot and its successor together (an empty successor ends the probe sequence
+        // without a trip of its own), then the candidate's whole row in one batch — compared in registers, and the cells the
+        // caller wants back (out0 / out1) taken from the same batch
+        u32 r = t.slots[slot], r_next = t.slots[(slot + 1) & t.mask];
+        for (u32 probes = 0; probes <= t.mask; probes++) {
+            if (r == ZK_EMPTY_SLOT) break;
+            const u64* p = t.cells + (u64)r * NCELLS * 4;
+            u32 diff = 0;
+#ifndef ZK_HOSTSIM
+            zk_u32x4 x[2 * NCELLS];
+            zk_load_row<2 * NCELLS>(p, x);
+#pragma unroll
+            for (int k = 0; k < 2 * NCELLS; k++)
+                if ((MASK >> (k >> 1)) & 1u) {
+                    const u32* qq = q[k >> 1].v + (k & 1) * 4;
+                    diff |= (x[k].x ^ qq[0]) | (x[k].y ^ qq[1]) | (x[k].z ^ qq[2]) | (x[k].w ^ qq[3]);
+                }
+#else
+            for (int c = 0; c < NCELLS; c++)
+                if ((MASK >> c) & 1u) {
+                    const Fr cell = fr_load(p + 4 * c);
+                    for (int k = 0; k < 8; k++) diff |= cell.v[k] ^ q[c].v[k];
+                }
+#endif
+            if (diff == 0u) {
+                if (found == ZK_EMPTY_SLOT) {
+                    found = r;
+#ifndef ZK_HOSTSIM
+#pragma unroll
+                    for (int c = 0; c < NCELLS; c++) {  // (out*_cell are compile-time constants at every call site)
+                        if (out0 && c == out0_cell) { for (int k = 0; k < 4; k++) { out0->v[k] = x[2 * c][k]; out0->v[4 + k] = x[2 * c + 1][k]; } }
+                        if (out1 && c == out1_cell) { for (int k = 0; k < 4; k++) { out1->v[k] = x[2 * c][k]; out1->v[4 + k] = x[2 * c + 1][k]; } }
+                    }
+#else
+                    if (out0) *out0 = fr_load(p + 4 * out0_cell);
+                    if (out1) *out1 = fr_load(p + 4 * out1_cell);
+#endif
+                } else if (!rows_identical(t, found, r)) {
+                    ambiguous = true;
+                }
+            }
+            slot = (slot + 1) & t.mask;
+            r = r_next;
+            if (r != ZK_EMPTY_SLOT) r_next = t.slots[(slot + 1) & t.mask];
+        }
+    }
+    kind = found == ZK_EMPTY_SLOT ? (u32)ZK_LOOKUP_UNSAT : (ambiguous ? (u32)ZK_LOOKUP_AMBIGUOUS : 0u);
+    return found == ZK_EMPTY_SLOT ? 0u : found;
+}
+
+
 struct ZkCols {
     const u64* cells;
     const u32* flags;

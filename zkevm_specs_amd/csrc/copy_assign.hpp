@@ -82,14 +82,46 @@ ZK_HD u64 cpa_n_real(const CpaEvent& e) {
 }
 ZK_HD u32 cpa_value(const CpaArgs& a, const CpaEvent& e, u64 i, u64 n_real) { return i < n_real ? (u32)(a.data[e.data0 + i] & 0xffu) : 0u; }
 
+// sum over s < upto of value(start + s) * r^(upto - 1 - s), canonical: the Horner value of `upto` bytes WITHOUT the dependent chain of
+// `upto` Montgomery products — the bytes times the Montgomery powers of r accumulate as plain integers (each term < 2^262, 64 of
+// them < 2^268: nine 32-bit limbs, 8 multiply-adds per byte, independent loads), reduced once and taken out of Montgomery form
+// with one product.  Round 4's per-chunk loops did `acc = acc * r + byte` with a dependent byte load per step: 64 load + product
+// round trips = 49 us for a chunk launch whatever its size.
+ZK_HD Fr cpa_dot(const CpaArgs& a, const CpaEvent& e, u64 start, u32 upto, u64 n_real) {
+    u32 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[j] = 0;
+#pragma unroll 8
+    for (u32 s = 0; s < upto; s++) {
+        const u32 v = cpa_value(a, e, start + s, n_real);
+        const Fr pw = fr_load(a.rpow + 4 * (u64)(upto - 1u - s));
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)acc[j] + (u64)pw.v[j] * v;
+            acc[j] = (u32)c;
+            c >>= 32;
+        }
+        acc[8] += (u32)c;
+    }
+    Fr lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) lo.v[j] = acc[j];
+    const Fr p = fr_modulus();
+#pragma unroll
+    for (int it = 0; it < 5; it++) {  // lo < 2^256 < 6 p
+        Fr t;
+        const u32 bw = u256_sub(t, lo, p);
+        lo = bw ? lo : t;
+    }
+    // + acc[8] * 2^256 (mod p): 2^256 mod p is the Montgomery one; the sum is the Montgomery form of the Horner value
+    const Fr xM = fr_add(lo, fr_mul(fr_from_u64(acc[8]), frm_one()));
+    return fr_mont(xM, fr_from_u64(1));
+}
 ZK_HD void cpa_chunk(const CpaArgs& a, u64 c) {
     const CpaChunk ch = a.chunks[c];
     const CpaEvent& e = a.ev[ch.event];
-    const u64 n_real = cpa_n_real(e);
-    const Fr rM = fr_load(a.rpow + 4);
-    Fr acc = fr_zero();
-    for (u32 t = 0; t < ch.count; t++) acc = fr_add(fr_mont(acc, rM), fr_from_u64(cpa_value(a, e, (u64)ch.start + t, n_real)));
-    cpa_store(a.chunk_acc + 4 * c, acc);
+    cpa_store(a.chunk_acc + 4 * c, cpa_dot(a, e, (u64)ch.start, ch.count, cpa_n_real(e)));
 }
 ZK_HD void cpa_prefix_event(const CpaArgs& a, u64 j) {
     const CpaEvent& e = a.ev[j];
@@ -100,17 +132,18 @@ ZK_HD void cpa_prefix_event(const CpaArgs& a, u64 j) {
     }
     cpa_store(a.ev_rlc + 4 * j, running);
 }
-ZK_HD void cpa_rlc_chunk(const CpaArgs& a, u64 c) {
+// running value after byte t of chunk c: (value entering the chunk) * r^(t + 1) + the Horner value of bytes 0..t of the chunk — one
+// output per call, independent of the other outputs of the chunk (the device runs one lane per output)
+ZK_HD void cpa_rlc_byte(const CpaArgs& a, u64 c, u32 t) {
     const CpaChunk ch = a.chunks[c];
+    if (t >= ch.count) return;
     const CpaEvent& e = a.ev[ch.event];
-    const u64 n_real = cpa_n_real(e);
-    const Fr rM = fr_load(a.rpow + 4);
-    Fr rlc = fr_load(a.chunk_in + 4 * c);
-    for (u32 t = 0; t < ch.count; t++) {
-        const u64 i = (u64)ch.start + t;
-        rlc = fr_add(fr_mont(rlc, rM), fr_from_u64(cpa_value(a, e, i, n_real)));
-        cpa_store(a.rlc + 4 * (e.rlc0 + i), rlc);
-    }
+    const Fr head = fr_mont(fr_load(a.chunk_in + 4 * c), fr_load(a.rpow + 4 * (u64)(t + 1u)));  // canonical x Montgomery power -> canonical
+    const Fr rlc = fr_add(head, cpa_dot(a, e, (u64)ch.start, t + 1u, cpa_n_real(e)));
+    cpa_store(a.rlc + 4 * (e.rlc0 + (u64)ch.start + t), rlc);
+}
+ZK_HD void cpa_rlc_chunk(const CpaArgs& a, u64 c) {  // host builds: every output of the chunk
+    for (u32 t = 0; t < CPA_CHUNK; t++) cpa_rlc_byte(a, c, t);
 }
 // Output row j (CopyCircuitRow, table.py:472-491: q_step, is_first, is_last, id lo, hi, tag, addr, src_addr_end, bytes_left,
 // value, rlc_acc, is_code, is_pad, rw_counter, rwc_inc_left, is_memory, is_bytecode, is_tx_calldata, is_tx_log, is_rlc_acc)

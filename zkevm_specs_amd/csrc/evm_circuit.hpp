@@ -52,7 +52,6 @@ struct EvmDyn {
     u32 agg_max_txs, agg_total_txs, agg_invalid_txs, agg_bad_invalid_rows, agg_total_wds;
     u32 dir_entries;    // directory build: groups counted so far (may exceed the capacity; then codes_n stays 0)
     u32 n_deferred;     // pairs the fast (hot) kernel handed to the general build this pass (reset at the start of every pass)
-    u32 open_timeout;   // a tail block of the open launch gave up waiting for its producers (never expected; zk_collect reports it)
 };
 
 struct EvmArgs {
@@ -381,11 +380,6 @@ ZK_HD u64 ecc_key_hash(const ZkTable& t, u32 r) {
 }
 ZK_HD u64 expt_key_hash(const ZkTable& t, u32 r) { return expt_key_hash_cells(zk_table_cell(t, r, XT_ID), zk_table_cell(t, r, XT_IS_LAST), zk_table_cell(t, r, XT_EXP_LO)); }
 
-ZK_HD bool rows_identical(const ZkTable& t, u32 r0, u32 r1) {
-    bool same = true;
-    for (u32 c = 0; c < t.ncells; c++) same = same && fr_eq(zk_table_cell(t, r0, c), zk_table_cell(t, r1, c));
-    return same;
-}
 
 // Generic "exactly one distinct matching row" lookup (table.py:864-884) over the open-addressing
 // index: `q` holds the query cells, bit c of `mask` says cell c is part of the query.  Out of
@@ -429,68 +423,6 @@ ZK_HD u32 table_lookup(Ins& I, const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u
     if (kind) ev_fail(I, kind);
     return kind == ZK_LOOKUP_UNSAT ? 0u : (u32)res;
 }
-
-// The probe itself, without an instruction context: `kind` = 0 / ZK_LOOKUP_UNSAT / ZK_LOOKUP_AMBIGUOUS, returns the row found (0 if
-// none).  Also what the Copy circuit's bytecode / tx-table lookups use (copy_circuit.hpp).
-template <int NCELLS, u32 MASK>
-ZK_HD u32 table_probe_inline(const ZkTable& t, u64 h, const Fr (&q)[NCELLS], u32& kind, Fr* out0 = nullptr, int out0_cell = 0, Fr* out1 = nullptr,
-                             int out1_cell = 0) {
-    u32 found = ZK_EMPTY_SLOT;
-    bool ambiguous = false;
-    if (out0) *out0 = fr_zero();
-    if (out1) *out1 = fr_zero();
-    if (t.n != 0) {
-        u32 slot = (u32)h & t.mask;
-        // two dependent round trips per probe: the slot and its successor together (an empty successor ends the probe sequence
-        // without a trip of its own), then the candidate's whole row in one batch — compared in registers, and the cells the
-        // caller wants back (out0 / out1) taken from the same batch
-        u32 r = t.slots[slot], r_next = t.slots[(slot + 1) & t.mask];
-        for (u32 probes = 0; probes <= t.mask; probes++) {
-            if (r == ZK_EMPTY_SLOT) break;
-            const u64* p = t.cells + (u64)r * NCELLS * 4;
-            u32 diff = 0;
-#ifndef ZK_HOSTSIM
-            zk_u32x4 x[2 * NCELLS];
-            zk_load_row<2 * NCELLS>(p, x);
-#pragma unroll
-            for (int k = 0; k < 2 * NCELLS; k++)
-                if ((MASK >> (k >> 1)) & 1u) {
-                    const u32* qq = q[k >> 1].v + (k & 1) * 4;
-                    diff |= (x[k].x ^ qq[0]) | (x[k].y ^ qq[1]) | (x[k].z ^ qq[2]) | (x[k].w ^ qq[3]);
-                }
-#else
-            for (int c = 0; c < NCELLS; c++)
-                if ((MASK >> c) & 1u) {
-                    const Fr cell = fr_load(p + 4 * c);
-                    for (int k = 0; k < 8; k++) diff |= cell.v[k] ^ q[c].v[k];
-                }
-#endif
-            if (diff == 0u) {
-                if (found == ZK_EMPTY_SLOT) {
-                    found = r;
-#ifndef ZK_HOSTSIM
-#pragma unroll
-                    for (int c = 0; c < NCELLS; c++) {  // (out*_cell are compile-time constants at every call site)
-                        if (out0 && c == out0_cell) { for (int k = 0; k < 4; k++) { out0->v[k] = x[2 * c][k]; out0->v[4 + k] = x[2 * c + 1][k]; } }
-                        if (out1 && c == out1_cell) { for (int k = 0; k < 4; k++) { out1->v[k] = x[2 * c][k]; out1->v[4 + k] = x[2 * c + 1][k]; } }
-                    }
-#else
-                    if (out0) *out0 = fr_load(p + 4 * out0_cell);
-                    if (out1) *out1 = fr_load(p + 4 * out1_cell);
-#endif
-                } else if (!rows_identical(t, found, r)) {
-                    ambiguous = true;
-                }
-            }
-            slot = (slot + 1) & t.mask;
-            r = r_next;
-            if (r != ZK_EMPTY_SLOT) r_next = t.slots[(slot + 1) & t.mask];
-        }
-    }
-    kind = found == ZK_EMPTY_SLOT ? (u32)ZK_LOOKUP_UNSAT : (ambiguous ? (u32)ZK_LOOKUP_AMBIGUOUS : 0u);
-    return found == ZK_EMPTY_SLOT ? 0u : found;
-}
-
 
 // The same lookup for the tables the warm gadgets query on every step (copy / keccak / exp tables): cell count and query mask
 // are compile-time constants, so the query stays in registers (no private copy handed to an out-of-line probe: that copy was the
@@ -4669,6 +4601,15 @@ ZK_HD bool evm_stage_steps_rows_quad(const EvmArgs& a, u32 idx, bool mine, __att
 }
 #endif
 
+// Cold families (tuning builds: -DZK_COLD_MASK=<bits> keeps only some of them, to see which gadgets a build's registers / stack come
+// from): 0 error states | 1 account / block / tx readers | 2 SDIV_SMOD | 3 precompiles | 4 CREATE | 5 CALL family | 6 tx / block framing
+#ifndef ZK_COLD_MASK
+#define ZK_COLD_MASK 0x7fu
+#endif
+#define EVM_COLD_FAM(f) (G == EVM_GROUP_COLD && ((ZK_COLD_MASK >> (f)) & 1u))
+// (Measured with it, round 5: error states alone 592 B of stack per lane, readers 464, SDIV_SMOD 996, precompiles 624, CREATE 736,
+// CALL 592, tx / block framing 816 — 2,492 together; 448 of every figure is table_lookup's private query copy.  Putting each gadget
+// behind an out-of-line call made it 3,004: the callee-saved registers of a 256-VGPR gadget go to the stack too.)
 template <int G>
 ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullptr, EVM_LDS_PTR dir_lds = nullptr) {
     Ins I;
@@ -4763,46 +4704,46 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     case ES_ADDRESS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_ADDRESS) { g_ctx_word(I, T, OP_ADDRESS, CC_CalleeAddress); } break;
     case ES_CALLDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CALLDATASIZE) { g_ctx_value(I, T, OP_CALLDATASIZE, CC_CallDataLength); } break;
     case ES_RETURNDATASIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_RETURNDATASIZE) { g_ctx_value(I, T, OP_RETURNDATASIZE, CC_LastCalleeReturnDataLength); } break;
-    case ES_ORIGIN: if (G == EVM_GROUP_COLD) { g_tx_word(I, T, OP_ORIGIN, TXC_CallerAddress); } break;
-    case ES_GASPRICE: if (G == EVM_GROUP_COLD) { g_tx_word(I, T, OP_GASPRICE, TXC_GasPrice); } break;
+    case ES_ORIGIN: if (EVM_COLD_FAM(1)) { g_tx_word(I, T, OP_ORIGIN, TXC_CallerAddress); } break;
+    case ES_GASPRICE: if (EVM_COLD_FAM(1)) { g_tx_word(I, T, OP_GASPRICE, TXC_GasPrice); } break;
     case ES_SELFBALANCE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SELFBALANCE) { g_selfbalance(I, T); } break;
-    case ES_BlockCtx: if (G == EVM_GROUP_COLD) { g_blockctx(I, T); } break;
+    case ES_BlockCtx: if (EVM_COLD_FAM(1)) { g_blockctx(I, T); } break;
     case ES_GAS: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_GAS) { g_gas(I, T); } break;
     case ES_MSIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_MSIZE) { g_msize(I, T); } break;
     case ES_CODESIZE: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_CODESIZE) { g_codesize(I, T); } break;
     case ES_STOP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_STOP) { g_stop(I, T); } break;
     case ES_SAR: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SAR) { g_sar(I, T); } break;
-    case ES_ErrorOutOfGasStaticMemoryExpansion: if (G == EVM_GROUP_COLD) { g_error_oog_static_memory(I, T); } break;
-    case ES_ErrorOutOfGasDynamicMemoryExpansion: if (G == EVM_GROUP_COLD) { g_error_oog_dynamic_memory(I, T); } break;
-    case ES_ErrorOutOfGasMemoryCopy: if (G == EVM_GROUP_COLD) { g_error_oog_memory_copy(I, T); } break;
-    case ES_ErrorOutOfGasAccountAccess: if (G == EVM_GROUP_COLD) { g_error_oog_account_access(I, T); } break;
-    case ES_ErrorOutOfGasLOG: if (G == EVM_GROUP_COLD) { g_error_oog_log(I, T); } break;
-    case ES_ErrorOutOfGasEXP: if (G == EVM_GROUP_COLD) { g_error_oog_exp(I, T); } break;
-    case ES_ErrorOutOfGasSHA3: if (G == EVM_GROUP_COLD) { g_error_oog_sha3(I, T); } break;
-    case ES_ErrorReturnDataOutOfBound: if (G == EVM_GROUP_COLD) { g_error_return_data_oob(I, T); } break;
-    case ES_ErrorWriteProtection: if (G == EVM_GROUP_COLD) { g_error_write_protection(I, T); } break;
-    case ES_DATACOPY: if (G == EVM_GROUP_COLD) { g_datacopy(I, T); } break;
-    case ES_ECRECOVER: if (G == EVM_GROUP_COLD) { g_ecrecover(I, T); } break;
-    case ES_BN254_ADD: if (G == EVM_GROUP_COLD) { g_ecadd_ecmul(I, T, false); } break;
-    case ES_BN254_SCALAR_MUL: if (G == EVM_GROUP_COLD) { g_ecadd_ecmul(I, T, true); } break;
-    case ES_BN254_PAIRING: if (G == EVM_GROUP_COLD) { g_ecpairing(I, T); } break;
-    case ES_ErrorOutOfGasPrecompile: if (G == EVM_GROUP_COLD) { g_error_oog_precompile(I, T); } break;
-    case ES_ErrorOutOfGasCREATE: if (G == EVM_GROUP_COLD) { g_error_oog_create(I, T); } break;
-    case ES_ErrorGasUintOverflow: if (G == EVM_GROUP_COLD) { g_error_gas_uint_overflow(I, T); } break;
-    case ES_CREATE: case ES_CREATE2: if (G == EVM_GROUP_COLD) { g_create(I, T); } break;
-    case ES_ErrorOutOfGasSloadSstore: if (G == EVM_GROUP_COLD) { g_error_oog_sload_sstore(I, T); } break;
-    case ES_CALL_OP: if (G == EVM_GROUP_COLD) { g_callop(I, T); } break;
-    case ES_ErrorOutOfGasCall: if (G == EVM_GROUP_COLD) { g_error_oog_call(I, T); } break;
-    case ES_BeginTx: if (G == EVM_GROUP_COLD) { g_begin_tx(I, T, is_first); } break;
-    case ES_EndTx: if (G == EVM_GROUP_COLD) { g_end_tx(I, T); } break;
-    case ES_RETURN: if (G == EVM_GROUP_COLD) { g_return(I, T); } break;
-    case ES_ErrorInvalidCreationCode: if (G == EVM_GROUP_COLD) { g_error_invalid_creation_code(I, T); } break;
-    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (G == EVM_GROUP_COLD) { g_error_code_store(I, T); } break;
-    case ES_EndBlock: if (G == EVM_GROUP_COLD) { g_end_block(I, T, is_last); } break;
-    case ES_ErrorInvalidOpcode: if (G == EVM_GROUP_COLD) { g_error_invalid_opcode(I, T); } break;
-    case ES_ErrorStack: if (G == EVM_GROUP_COLD) { g_error_stack(I, T); } break;
-    case ES_ErrorOutOfGasConstant: if (G == EVM_GROUP_COLD) { g_error_oog_constant(I, T); } break;
-    case ES_ErrorInvalidJump: if (G == EVM_GROUP_COLD) { g_error_invalid_jump(I, T); } break;
+    case ES_ErrorOutOfGasStaticMemoryExpansion: if (EVM_COLD_FAM(0)) { g_error_oog_static_memory(I, T); } break;
+    case ES_ErrorOutOfGasDynamicMemoryExpansion: if (EVM_COLD_FAM(0)) { g_error_oog_dynamic_memory(I, T); } break;
+    case ES_ErrorOutOfGasMemoryCopy: if (EVM_COLD_FAM(0)) { g_error_oog_memory_copy(I, T); } break;
+    case ES_ErrorOutOfGasAccountAccess: if (EVM_COLD_FAM(0)) { g_error_oog_account_access(I, T); } break;
+    case ES_ErrorOutOfGasLOG: if (EVM_COLD_FAM(0)) { g_error_oog_log(I, T); } break;
+    case ES_ErrorOutOfGasEXP: if (EVM_COLD_FAM(0)) { g_error_oog_exp(I, T); } break;
+    case ES_ErrorOutOfGasSHA3: if (EVM_COLD_FAM(0)) { g_error_oog_sha3(I, T); } break;
+    case ES_ErrorReturnDataOutOfBound: if (EVM_COLD_FAM(0)) { g_error_return_data_oob(I, T); } break;
+    case ES_ErrorWriteProtection: if (EVM_COLD_FAM(0)) { g_error_write_protection(I, T); } break;
+    case ES_DATACOPY: if (EVM_COLD_FAM(3)) { g_datacopy(I, T); } break;
+    case ES_ECRECOVER: if (EVM_COLD_FAM(3)) { g_ecrecover(I, T); } break;
+    case ES_BN254_ADD: if (EVM_COLD_FAM(3)) { g_ecadd_ecmul(I, T, false); } break;
+    case ES_BN254_SCALAR_MUL: if (EVM_COLD_FAM(3)) { g_ecadd_ecmul(I, T, true); } break;
+    case ES_BN254_PAIRING: if (EVM_COLD_FAM(3)) { g_ecpairing(I, T); } break;
+    case ES_ErrorOutOfGasPrecompile: if (EVM_COLD_FAM(0)) { g_error_oog_precompile(I, T); } break;
+    case ES_ErrorOutOfGasCREATE: if (EVM_COLD_FAM(0)) { g_error_oog_create(I, T); } break;
+    case ES_ErrorGasUintOverflow: if (EVM_COLD_FAM(0)) { g_error_gas_uint_overflow(I, T); } break;
+    case ES_CREATE: case ES_CREATE2: if (EVM_COLD_FAM(4)) { g_create(I, T); } break;
+    case ES_ErrorOutOfGasSloadSstore: if (EVM_COLD_FAM(0)) { g_error_oog_sload_sstore(I, T); } break;
+    case ES_CALL_OP: if (EVM_COLD_FAM(5)) { g_callop(I, T); } break;
+    case ES_ErrorOutOfGasCall: if (EVM_COLD_FAM(0)) { g_error_oog_call(I, T); } break;
+    case ES_BeginTx: if (EVM_COLD_FAM(6)) { g_begin_tx(I, T, is_first); } break;
+    case ES_EndTx: if (EVM_COLD_FAM(6)) { g_end_tx(I, T); } break;
+    case ES_RETURN: if (EVM_COLD_FAM(6)) { g_return(I, T); } break;
+    case ES_ErrorInvalidCreationCode: if (EVM_COLD_FAM(0)) { g_error_invalid_creation_code(I, T); } break;
+    case ES_ErrorMaxCodeSizeExceeded: case ES_ErrorOutOfGasCodeStore: if (EVM_COLD_FAM(0)) { g_error_code_store(I, T); } break;
+    case ES_EndBlock: if (EVM_COLD_FAM(6)) { g_end_block(I, T, is_last); } break;
+    case ES_ErrorInvalidOpcode: if (EVM_COLD_FAM(0)) { g_error_invalid_opcode(I, T); } break;
+    case ES_ErrorStack: if (EVM_COLD_FAM(0)) { g_error_stack(I, T); } break;
+    case ES_ErrorOutOfGasConstant: if (EVM_COLD_FAM(0)) { g_error_oog_constant(I, T); } break;
+    case ES_ErrorInvalidJump: if (EVM_COLD_FAM(0)) { g_error_invalid_jump(I, T); } break;
     case ES_LOG: if (G == EVM_GROUP_WARM) { g_log(I, T); } break;
     case ES_SHA3: if (G == EVM_GROUP_WARM) { g_sha3(I, T); } break;
     case ES_CODECOPY: if (G == EVM_GROUP_WARM) { g_codecopy(I, T); } break;
@@ -4810,12 +4751,12 @@ ZK_HD u32 evm_check_step(const EvmArgs& a, u64 idx, EVM_LDS32_PTR stage = nullpt
     case ES_RETURNDATACOPY: if (G == EVM_GROUP_WARM) { g_returndatacopy(I, T); } break;
     case ES_EXTCODECOPY: if (G == EVM_GROUP_WARM) { g_extcodecopy(I, T); } break;
     case ES_EXP: if (G == EVM_GROUP_WARM) { g_exp(I, T); } break;
-    case ES_BALANCE: if (G == EVM_GROUP_COLD) { g_balance(I, T); } break;
-    case ES_EXTCODESIZE: if (G == EVM_GROUP_COLD) { g_extcodesize(I, T); } break;
-    case ES_EXTCODEHASH: if (G == EVM_GROUP_COLD) { g_extcodehash(I, T); } break;
-    case ES_BLOCKHASH: if (G == EVM_GROUP_COLD) { g_blockhash(I, T); } break;
-    case ES_CALLDATALOAD: if (G == EVM_GROUP_COLD) { g_calldataload(I, T); } break;
-    case ES_SDIV_SMOD: if (G == EVM_GROUP_COLD) { g_sdiv_smod(I, T); } break;
+    case ES_BALANCE: if (EVM_COLD_FAM(1)) { g_balance(I, T); } break;
+    case ES_EXTCODESIZE: if (EVM_COLD_FAM(1)) { g_extcodesize(I, T); } break;
+    case ES_EXTCODEHASH: if (EVM_COLD_FAM(1)) { g_extcodehash(I, T); } break;
+    case ES_BLOCKHASH: if (EVM_COLD_FAM(1)) { g_blockhash(I, T); } break;
+    case ES_CALLDATALOAD: if (EVM_COLD_FAM(1)) { g_calldataload(I, T); } break;
+    case ES_SDIV_SMOD: if (EVM_COLD_FAM(2)) { g_sdiv_smod(I, T); } break;
     case ES_JUMP: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMP) { g_jump(I, T); } break;
     case ES_JUMPI: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_JUMPI) { g_jumpi(I, T); } break;
     case ES_SLOAD: if (G == EVM_GROUP_ALL || G == GROUP_OF_ES_SLOAD) { g_sload(I, T); } break;

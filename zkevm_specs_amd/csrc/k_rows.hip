@@ -32,7 +32,10 @@ __global__ __launch_bounds__(256) void bytecode_rows_kernel(BytecodeArgs a, u64 
 }
 // Copy: a wavefront holds 64 consecutive rows, evaluates the first 62 and takes the cells of rows i + 1 / i + 2 from lanes + 1 /
 // + 2; its last two lanes are (read-only) successors.  Rows past the end wrap to the start (copy_circuit.py:92-130).
-__global__ __launch_bounds__(256) void copy_rows_kernel(CopyArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
+#ifndef ZK_COPY_OCC
+#define ZK_COPY_OCC 1  // blocks of 256 per CU the build is sized for (tuning builds: 2 = at most 256 registers, two wavefronts per SIMD)
+#endif
+__global__ __launch_bounds__(256, ZK_COPY_OCC) void copy_rows_kernel(CopyArgs a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     tally_clear_twin(tally);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

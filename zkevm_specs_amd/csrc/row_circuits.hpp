@@ -29,17 +29,13 @@ struct BytecodeArgs {
 };
 
 
-// `row in keccak_table` with all five cells given (set membership, bytecode_circuit.py:100)
-ZK_HD bool keccak_contains(const ZkTable& t, const Fr q[KECCAK_NCELLS]) {
-    if (t.n == 0) return false;
-    u32 slot = (u32)keccak_key_hash_cells(q[1], q[2]) & t.mask;
-    for (u32 probes = 0; probes <= t.mask; probes++) {
-        const u32 r = t.slots[slot];
-        if (r == ZK_EMPTY_SLOT) return false;
-        if (zk_row_matches(t, r, q, 0x1fu)) return true;
-        slot = (slot + 1) & t.mask;
-    }
-    return false;
+// `row in keccak_table` with all five cells given (set membership, bytecode_circuit.py:100).  The query stays in registers: the
+// candidate row comes in one batch of loads and is compared with compile-time cell indices (zk_row_matches indexes the query at
+// run time, which put it on the stack: 176 B per lane in the Bytecode kernel, 208 in the Tx / Sig one).
+ZK_HD bool keccak_contains(const ZkTable& t, const Fr (&q)[KECCAK_NCELLS]) {
+    u32 kind;
+    (void)table_probe_inline<KECCAK_NCELLS, 0x1fu>(t, keccak_key_hash_cells(q[1], q[2]), q, kind);
+    return kind != (u32)ZK_LOOKUP_UNSAT;  // one matching row or several: contained either way
 }
 
 #define RC_ASSERT(cond, site) code = (code == 0u && !(cond)) ? ZK_CODE(ZK_ASSERT, site) : code

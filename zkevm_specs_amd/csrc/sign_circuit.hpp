@@ -118,18 +118,21 @@ ZK_HD u32 sign_check_unit(const SignArgs& a, u64 i) {
     SG_ASSERT(!(bad & 0x30u) && sg_bytes_eq(msg, sg_bytes(a, i, SG_E_MSG)), 3);
     if (a.is_sig) {
         // sig_r/sig_s.int_value() == int.from_bytes(ecdsa sig bytes, "little")  (sig_circuit.py:70-71)
+#pragma unroll
         for (int which = 0; which < 2; which++) {
             const Fr lo = zk_col(a.cells, SG_SIG_R_LO + 2 * which, i), hi = zk_col(a.cells, SG_SIG_R_HI + 2 * which, i);
             const B32 b = sg_bytes(a, i, SG_E_SIG_R + which);
             // lo + (hi << 128) as a 384-bit integer vs the 256-bit byte value
             u32 sum[12];
             u64 c = 0;
-            for (int k = 0; k < 12; k++) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {  // (unrolled: a run-time index would put lo / hi / sum on the stack)
                 c += (u64)(k < 8 ? lo.v[k] : 0u) + (u64)((k >= 4) ? hi.v[k - 4] : 0u);
                 sum[k] = (u32)c;
                 c >>= 32;
             }
             bool eq = c == 0;
+#pragma unroll
             for (int k = 0; k < 12; k++) {
                 u32 want = 0;
                 if (k < 8) want = b.w[k];

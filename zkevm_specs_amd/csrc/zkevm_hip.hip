@@ -266,86 +266,6 @@ __global__ __launch_bounds__(1024) void evm_state_scatter_kernel(const uint16_t*
                                                                  u32* taken, u32* group_start, u32* perm) {
     evm_state_scatter_body(blockIdx.x, bin16, n_pairs, hist, hist_next, taken, group_start, perm);
 }
-// The same scatter for the tail of the session-open launch (evm_open_phase1_kernel): 256-thread blocks, 1,024 pairs per block
-// (four per thread: the same number of global atomics per pair as the 1,024-thread form), two bins per thread in the scan.
-#define EVM_TAIL_SCATTER_PAIRS 1024u
-__device__ __forceinline__ void evm_state_scatter_tail(u32 vblock, const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next, u32* taken,
-                                                       u32* group_start, u32* perm) {
-    __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
-    __shared__ u32 local[EVM_N_BINS];
-    __shared__ u32 base[EVM_N_BINS];
-    const u32 T = blockDim.x, tid = threadIdx.x;
-    for (u32 k = tid; k < EVM_N_BINS; k += T) {
-        const u32 c_real = hist[k];
-        sa[k] = k < (u32)EVM_GROUP_WARM * 128u ? ((c_real + 63u) & ~63u) : c_real;  // hot bins: whole wavefronts
-        local[k] = 0;
-        if (vblock == 0) hist_next[k] = 0;
-    }
-    __syncthreads();
-    u32* src = sa;
-    u32* dst = sb;
-    for (u32 off = 1; off < EVM_N_BINS; off <<= 1) {
-        for (u32 k = tid; k < EVM_N_BINS; k += T) dst[k] = src[k] + (k >= off ? src[k - off] : 0u);
-        __syncthreads();
-        u32* t = src; src = dst; dst = t;
-    }
-    // `src` = inclusive sums of the padded counts
-    for (u32 k = tid; k < EVM_N_BINS; k += T) {
-        const u32 c_real = hist[k];
-        const u32 c = k < (u32)EVM_GROUP_WARM * 128u ? ((c_real + 63u) & ~63u) : c_real;
-        const u32 excl = src[k] - c;
-        base[k] = excl;
-        if (vblock == 0) {
-            if ((k & 127u) == 0) group_start[k >> 7] = excl;
-            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
-            for (u32 j = c_real; j < c; j++) perm[excl + j] = EVM_NO_PAIR;
-        }
-    }
-    u32 bins[4], ranks[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const u32 i = vblock * EVM_TAIL_SCATTER_PAIRS + (u32)j * T + tid;
-        bins[j] = ranks[j] = 0;
-        if (i < n_pairs) {
-            bins[j] = bin16[i];
-            ranks[j] = atomicAdd(&local[bins[j]], 1u);
-        }
-    }
-    __syncthreads();
-    for (u32 k = tid; k < EVM_N_BINS; k += T)
-        if (local[k]) base[k] += atomicAdd(&taken[k], local[k]);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const u32 i = vblock * EVM_TAIL_SCATTER_PAIRS + (u32)j * T + tid;
-        if (i < n_pairs) perm[base[bins[j]] + ranks[j]] = i;
-    }
-}
-// Producer / consumer counters of the session-open launch (in the session's zero region, behind the result block).  The
-// consumers are the LAST blocks of the grid: a block is dispatched after every block with a smaller index of its XCD's share, and
-// no producer waits for anything, so a waiting consumer can only be waiting for blocks that are running or about to.  The wait is
-// bounded all the same (EvmDyn::open_timeout -> zk_collect fails) so that a wrong assumption shows up as an error, not as a hang.
-struct EvmOpenSync {
-    u32 hist_done, dir_done, rw_done, pad;
-};
-__device__ __forceinline__ void open_signal(u32* counter) {
-    __threadfence();  // this thread's stores / atomics are visible device-wide ...
-    __syncthreads();  // ... for every thread of the block, before thread 0 counts the block in
-    if (threadIdx.x == 0) atomicAdd(counter, 1u);
-}
-__device__ __forceinline__ bool open_wait(u32* counter, u32 target, EvmDyn* dyn) {
-    __shared__ u32 ok;
-    if (threadIdx.x == 0) {
-        u32 spins = 0;
-        bool got = false;
-        while (!(got = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(8);
-        ok = got ? 1u : 0u;
-        if (!got) atomicOr(&dyn->open_timeout, 1u);
-    }
-    __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // nothing this CU cached before the producers finished is read after this point
-    return ok != 0u;
-}
 // ---------------------------------------------------------------------------------------
 // EVM session open: three launches, whatever the tables (the host enqueues them and returns; nothing is read back).
 //   evm_open_fill_kernel    every slot table / "min" array of the session to 0xFF.., every counter / status array to 0
@@ -448,12 +368,6 @@ struct EvmOpenTables {
     u32 rec_block0;
     EvmSortArgs sort;    // sort.perm != nullptr: the first pass's counting sort rides on the two launches (histogram in phase 1, scatter in phase 2)
     u32 hist_block0;
-    // tail of phase 1 (ZK_P1_TAIL, default on): what used to be the second launch — scatter | directory entries | generic RW index —
-    // as the last blocks of the first one, each range waiting for its producers' counter (EvmOpenSync)
-    EvmOpenSync* sync;   // nullptr: two launches (evm_open_phase2_kernel)
-    u32 tail_block0;     // == the old grid size; tail ranges: [0, t_scatter) | [t_scatter, t_scatter + t_dir) | generic RW
-    u32 t_scatter, t_dir, t_rwgen, t_force_generic;
-    u32 n_hist_blocks, n_dir_row_blocks, n_rw_row_blocks;
     u32 lat_period;      // phase 1: every lat_period-th block of the launch's first part is one of the latency-bound ranges' (0 / 1: they all come first)
 #ifdef ZK_DIAG_P1
     u32 diag_skip;       // tuning builds only (tools/p1_ranges.py): ranges of phase 1 that return at once — results are INVALID
@@ -508,32 +422,6 @@ __device__ __forceinline__ void evm_open_small_tables(const EvmOpenTables& o, u3
     u32 s = (u32)h & t.mask;
     while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
 }
-// The tail ranges of the session-open launch (see EvmOpenSync): the first pass's scatter, the directory's entries, the generic RW
-// index (which does nothing when the rows are dense — the usual case).
-__device__ __forceinline__ void evm_open_tail(const EvmOpenTables& o, u32 tb) {
-    if (tb < o.t_scatter) {
-        if (!open_wait(&o.sync->hist_done, o.n_hist_blocks, o.dyn)) return;
-        evm_state_scatter_tail(tb, o.sort.bin16, o.sort.n_pairs, o.sort.hist, o.sort.hist_next, o.sort.taken, o.sort.group_start, o.sort.perm);
-        return;
-    }
-    tb -= o.t_scatter;
-    if (tb < o.t_dir) {
-        if (!open_wait(&o.sync->dir_done, o.n_dir_row_blocks, o.dyn)) return;
-        dirb_finalize_entry(o.dir, tb * blockDim.x + threadIdx.x);
-        return;
-    }
-    tb -= o.t_dir;
-    // generic RW index: only when the rows are not dense (or the session asked for generic indices); the verdict needs every RW block
-    if (o.rw_keys && !open_wait(&o.sync->rw_done, o.n_rw_row_blocks, o.dyn)) return;
-    if (!o.t_force_generic && o.dyn->rw_sparse == 0u) return;
-    if (o.t_force_generic && tb == 0 && threadIdx.x == 0) o.dyn->rw_sparse = 1u;  // generic-index sessions never use the dense path
-    u32* slots = const_cast<u32*>(o.rw.slots);
-    const u32 stride = o.t_rwgen * blockDim.x;
-    for (u32 r = tb * blockDim.x + threadIdx.x; r < o.rw.n; r += stride) {
-        u32 sl = (u32)rw_key_hash(o.rw, r) & o.rw.mask;
-        while (atomicCAS(&slots[sl], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) sl = (sl + 1) & o.rw.mask;
-    }
-}
 __global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
         o.tally[threadIdx.x].fail_count = 0ull;
@@ -556,17 +444,10 @@ __global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
     }
 #endif
     if (b < o.dir_block0) evm_open_small_tables(o, b);
-    else if (b < o.hist_block0) {
-        dirb_events_row(o.dir, (b - o.dir_block0) * blockDim.x + threadIdx.x);
-        if (o.sync) open_signal(&o.sync->dir_done);
-    } else if (b < o.rw_block0) {
-        evm_state_hist_body(b - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally, o.sort.defer_count);
-        if (o.sync) open_signal(&o.sync->hist_done);
-    } else if (b < o.rec_block0) {
-        rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (b - o.rw_block0) * blockDim.x + threadIdx.x);
-        if (o.sync && o.t_rwgen) open_signal(&o.sync->rw_done);
-    } else if (b < o.tail_block0) evm_step_record_quad(o.steps, o.n_steps, o.step_recs, (b - o.rec_block0) * blockDim.x + threadIdx.x);
-    else evm_open_tail(o, b - o.tail_block0);
+    else if (b < o.hist_block0) dirb_events_row(o.dir, (b - o.dir_block0) * blockDim.x + threadIdx.x);
+    else if (b < o.rw_block0) evm_state_hist_body(b - o.hist_block0, o.sort.steps, o.sort.n_pairs, o.sort.hist, o.sort.taken, o.sort.bin16, o.sort.tally, o.sort.defer_count);
+    else if (b < o.rec_block0) rw_prepare_quad(o.rw, o.rw_keys, o.dyn, (b - o.rw_block0) * blockDim.x + threadIdx.x);
+    else evm_step_record_quad(o.steps, o.n_steps, o.step_recs, (b - o.rec_block0) * blockDim.x + threadIdx.x);
 }
 // Phase 2.  The generic RW index is only needed when the rows are not dense: the blocks are always launched (the host does
 // not know the verdict), the work is conditional; grid-stride so that the idle case is 256 blocks that exit at once.
@@ -669,14 +550,6 @@ struct zk_session {
     u32* d_perm = nullptr;   // EVM: state-sorted lane -> pair permutation
     hipEvent_t ev_open0 = nullptr, ev_open1 = nullptr;  // EVM: ride on the first / last dispatch of zk_evm_open (zk_session_timing)
     bool side_stream = false;                           // EVM: ZK_OPT_SIDE_STREAM
-    // EVM: the session's 0xFF region and zero region (evm_open_fill_kernel's two ranges).  They are not in `owned`: zk_close refills
-    // them behind the session's last work and parks the pair in the arena's clean list, so that the next open of the same shape
-    // finds them filled and starts with its first build launch (ZK_PRECLEAN, default on)
-    void* fill_ff = nullptr;
-    void* fill_zero = nullptr;
-    int fill_ff_cls = 0, fill_zero_cls = 0;
-    u64 fill_n_ff16 = 0, fill_n_zero16 = 0;
-    hipEvent_t ev_clean0 = nullptr, ev_clean1 = nullptr;  // ride on the refill that cleaned THIS session's regions (its time is part of this session's device work)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // EVM: fork to / join from the device's side stream (warm + cold builds)
     // EVM: EvmDyn, the two tallies and the lane ranges sit in ONE 128-byte device block (EvmResultBlock) that zk_collect reads
     // back with ONE copy into page-locked host memory (three copies into pageable memory cost three blocking round trips)
@@ -712,16 +585,7 @@ struct DevArena {
     std::vector<hipEvent_t> events;
     std::vector<void*> pinned;  // ZK_PINNED_BYTES-byte blocks of page-locked host memory (result read-backs)
     size_t cached_bytes = 0;
-    struct CleanPair {  // an EVM session's two fill regions, refilled by the closing session on `stream` (e1 rides on that dispatch)
-        void* ff; void* zero;
-        int ff_cls, zero_cls;
-        u64 n_ff16, n_zero16;
-        hipStream_t stream;
-        hipEvent_t e0, e1;
-    };
-    std::vector<CleanPair> clean;
 };
-#define ZK_ARENA_MAX_CLEAN 8
 static DevArena g_arena[ZK_MAX_DEVICES];
 static size_t arena_limit() {
     static const size_t lim = [] { const char* e = getenv("ZK_ARENA_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30); }();
@@ -730,10 +594,6 @@ static size_t arena_limit() {
 static bool arena_off() {
     static const bool off = [] { const char* e = getenv("ZK_NO_ARENA"); return e && e[0] == '1'; }();
     return off;
-}
-static bool arena_preclean() {
-    static const bool on = [] { const char* e = getenv("ZK_PRECLEAN"); return !(e && e[0] == '0'); }();
-    return on && !arena_off();
 }
 static int arena_class(size_t bytes) {
     int c = 8;  // 256 B: hipMalloc's own granularity
@@ -799,7 +659,7 @@ static void arena_release_all() {
     for (int d = 0; d < ZK_MAX_DEVICES; d++) {
         DevArena& A = g_arena[d];
         std::lock_guard<std::mutex> lock(A.m);
-        bool any = !A.events.empty() || !A.pinned.empty() || !A.clean.empty();
+        bool any = !A.events.empty() || !A.pinned.empty();
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) any = any || !A.free_[c].empty();
         if (!any || hipSetDevice(d) != hipSuccess) continue;
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) {
@@ -810,13 +670,6 @@ static void arena_release_all() {
         A.events.clear();
         for (void* h : A.pinned) (void)hipHostFree(h);
         A.pinned.clear();
-        for (DevArena::CleanPair& c : A.clean) {
-            (void)hipFree(c.ff);
-            (void)hipFree(c.zero);
-            if (c.e0) (void)hipEventDestroy(c.e0);
-            if (c.e1) (void)hipEventDestroy(c.e1);
-        }
-        A.clean.clear();
         A.cached_bytes = 0;
     }
 }
@@ -875,63 +728,14 @@ static int session_common_init(zk_session* s) {
     return 0;
 }
 
-// zk_close of an EVM session: refill its two fill regions (asynchronously, behind everything the session enqueued: the stream was
-// just synchronised) and park them as a clean pair; the next zk_evm_open with the same region sizes takes the pair and skips its
-// evm_open_fill_kernel launch — the refill runs while the host is between two calls, the device otherwise idle.  Falls back to
-// handing the buffers to the ordinary free lists (pre-clean off, list full, a launch error).
-static void evm_park_fill_regions(zk_session* s) {
-    DevArena& A = g_arena[s->device];
-    bool parked = false;
-    if (arena_preclean()) {
-        bool room;
-        {
-            std::lock_guard<std::mutex> lock(A.m);
-            room = A.clean.size() < ZK_ARENA_MAX_CLEAN;
-        }
-        if (room && (s->ev_clean0 || arena_event(s->device, &s->ev_clean0) == 0) && (s->ev_clean1 || arena_event(s->device, &s->ev_clean1) == 0)) {
-            const u64 n16 = s->fill_n_ff16 + s->fill_n_zero16;
-            const u32 grid = (u32)(n16 / 256 < 2048 ? (n16 + 255) / 256 : 2048);
-            hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(grid ? grid : 1u), dim3(256), 0, s->stream, s->ev_clean0, s->ev_clean1, 0, (uint4*)s->fill_ff,
-                                  s->fill_n_ff16, (uint4*)s->fill_zero, s->fill_n_zero16);
-            if (hipGetLastError() == hipSuccess) {
-                std::lock_guard<std::mutex> lock(A.m);
-                A.clean.push_back({s->fill_ff, s->fill_zero, s->fill_ff_cls, s->fill_zero_cls, s->fill_n_ff16, s->fill_n_zero16, s->stream, s->ev_clean0, s->ev_clean1});
-                s->ev_clean0 = s->ev_clean1 = nullptr;  // travel with the pair
-                parked = true;
-            }
-        }
-    }
-    if (!parked) {
-        arena_give(s->device, s->fill_ff, s->fill_ff_cls);
-        arena_give(s->device, s->fill_zero, s->fill_zero_cls);
-    }
-    s->fill_ff = s->fill_zero = nullptr;
-}
-// a parked pair with exactly these region sizes (sizes in 16-byte units), or false
-static bool arena_take_clean(int device, u64 n_ff16, u64 n_zero16, DevArena::CleanPair* out) {
-    if (!arena_preclean()) return false;
-    DevArena& A = g_arena[device];
-    std::lock_guard<std::mutex> lock(A.m);
-    for (size_t k = A.clean.size(); k-- > 0;)
-        if (A.clean[k].n_ff16 == n_ff16 && A.clean[k].n_zero16 == n_zero16) {
-            *out = A.clean[k];
-            A.clean.erase(A.clean.begin() + (long)k);
-            return true;
-        }
-    return false;
-}
-
 extern "C" int zk_close(zk_session* s) {
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);  // nothing enqueued may still read the buffers that go back to the arena
     for (size_t k = 0; k < s->owned.size(); k++) arena_give(s->device, s->owned[k], s->owned_class[k]);
-    if (s->fill_ff && s->fill_zero) evm_park_fill_regions(s);
     {
         DevArena& A = g_arena[s->device];
         std::lock_guard<std::mutex> lock(A.m);
-        if (s->ev_clean0) A.events.push_back(s->ev_clean0);
-        if (s->ev_clean1) A.events.push_back(s->ev_clean1);
         for (hipEvent_t e : s->ev) A.events.push_back(e);
         if (s->ev_open0) A.events.push_back(s->ev_open0);
         if (s->ev_open1) A.events.push_back(s->ev_open1);
@@ -1038,7 +842,6 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     s->side_stream = (opts & ZK_OPT_SIDE_STREAM) != 0;
     int rc = 0;
     const void* p = nullptr;
-    bool open_first_pending = false;  // pre-cleaned regions: no fill launch, phase 1 is the open's first dispatch
     EvmArgs& E = s->evm;
     if ((rc = stage(s, t->steps, (size_t)t->n_steps * STEP_NCELLS * 32, dev, &p))) goto fail;
     E.steps = (const u64*)p;
@@ -1074,33 +877,19 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         for (int k = 0; k < EVM_OPEN_TABLES; k++) { caps[k] = index_cap(small[k]->n); n_ff += caps[k]; }
         const u32 cap_rw = index_cap(E.rw.n), cap_big = want_dir ? index_cap(t->n_bytecode) : 0u;
         n_ff += (size_t)cap_rw + 2 * (size_t)cap_big + (want_dir ? DIRB_SMALL_SLOTS : 0u);
-        // ---- one zero region: EvmDyn, the two histograms, the per-pair status, the directory's last / runs / bad -------------
-        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (((size_t)s->n * sizeof(u32)) + 15) & ~(size_t)15;
-        const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
-        // both regions come as a pair: refilled by the session that last closed with this shape (arena clean list), or fresh + one fill launch
         u32* ff = nullptr;
-        char* zero = nullptr;
-        DevArena::CleanPair cp;
-        const bool precleaned = arena_take_clean(s->device, n_ff / 4, zero_bytes / 16, &cp);
-        if (precleaned) {
-            ff = (u32*)cp.ff; zero = (char*)cp.zero;
-            s->fill_ff_cls = cp.ff_cls; s->fill_zero_cls = cp.zero_cls;
-            s->ev_clean0 = cp.e0; s->ev_clean1 = cp.e1;
-            // refilled on another stream: this session's stream starts behind that refill
-            if (cp.stream != s->stream && hipStreamWaitEvent(s->stream, cp.e1, 0) != hipSuccess) (void)hipEventSynchronize(cp.e1);
-        } else {
-            if ((rc = arena_take(s->device, n_ff * sizeof(u32), (void**)&ff, &s->fill_ff_cls))) goto fail;
-            s->fill_ff = ff;  // owned from here on (zk_close gives it back whatever happens next)
-            if ((rc = arena_take(s->device, zero_bytes, (void**)&zero, &s->fill_zero_cls))) { arena_give(s->device, ff, s->fill_ff_cls); s->fill_ff = nullptr; goto fail; }
-        }
-        s->fill_ff = ff; s->fill_zero = zero;
-        s->fill_n_ff16 = n_ff / 4; s->fill_n_zero16 = zero_bytes / 16;
+        if ((rc = dev_alloc(s, (void**)&ff, n_ff * sizeof(u32)))) goto fail;
         u32* cur = ff;
         for (int k = 0; k < EVM_OPEN_TABLES; k++) { small[k]->slots = cur; small[k]->mask = caps[k] - 1; cur += caps[k]; }
         E.rw.slots = cur; E.rw.mask = cap_rw - 1; cur += cap_rw;
         u32* const dir_rep = cur; cur += cap_big;
         u32* const dir_first = cur; cur += cap_big;
         u32* const small_slots = cur;
+        // ---- one zero region: EvmDyn, the two histograms, the per-pair status, the directory's last / runs / bad -------------
+        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (((size_t)s->n * sizeof(u32)) + 15) & ~(size_t)15;
+        const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
+        char* zero = nullptr;
+        if ((rc = dev_alloc(s, (void**)&zero, zero_bytes))) goto fail;
         EvmResultBlock* const rb = (EvmResultBlock*)zero;  // the first 128 of the region's 256 leading bytes
         EvmDyn* dyn = &rb->dyn;
         s->d_result = rb;
@@ -1122,10 +911,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             // the open's device span is measured by two events that ride on its first and last dispatch (no event packets of their
             // own between the kernels): zk_session_timing / zk_last_timing
             if (arena_event(s->device, &s->ev_open0) || arena_event(s->device, &s->ev_open1)) s->ev_open0 = s->ev_open1 = nullptr;
-            if (!precleaned)
-                hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, s->ev_open0, nullptr, 0, (uint4*)ff,
-                                      (u64)(n_ff / 4), (uint4*)zero, (u64)(zero_bytes / 16));
-            open_first_pending = precleaned;  // the first build launch carries the open's start event then
+            hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, s->ev_open0, nullptr, 0, (uint4*)ff,
+                                  (u64)(n_ff / 4), (uint4*)zero, (u64)(zero_bytes / 16));
         }
         E.rw_dense = 0;
         E.rw_base = 0;
@@ -1223,27 +1010,10 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
 #ifdef ZK_DIAG_P1
             if (o.diag_skip) phase2 = false;  // its inputs are missing
 #endif
-            // ZK_P1_TAIL (default 1): the second launch's ranges ride at the end of the first one behind producer counters
-            // (evm_open_tail) — one launch boundary and most of the scatter's 8 us come off the open; 0 = two launches
-            static const bool p1_tail = [] { const char* e = getenv("ZK_P1_TAIL"); return !(e && e[0] == '0'); }();
-            o.tail_block0 = grid1;
-            if (phase2 && p1_tail) {
-                static_assert(sizeof(EvmResultBlock) + sizeof(EvmOpenSync) <= 256, "the open's counters live behind the result block");
-                o.sync = (EvmOpenSync*)(zero + sizeof(EvmResultBlock));
-                o.t_scatter = sorted ? (E.n_pairs + EVM_TAIL_SCATTER_PAIRS - 1u) / EVM_TAIL_SCATTER_PAIRS : 0u;
-                o.t_dir = want_dir ? DIRB_MAX_ENTRIES / 256u : 0u;
-                o.t_rwgen = t->n_rw ? 256u : 0u;
-                o.t_force_generic = generic ? 1u : 0u;
-                o.n_hist_blocks = hist_blocks;
-                o.n_dir_row_blocks = dir_row_blocks;
-                o.n_rw_row_blocks = rw_row_blocks;
-                hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 + o.t_scatter + o.t_dir + o.t_rwgen), dim3(256), 0, s->stream, open_first_pending ? s->ev_open0 : nullptr, s->ev_open1, 0, o);
-            } else {
-                hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, open_first_pending ? s->ev_open0 : nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
-                if (phase2)
-                    hipExtLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, nullptr,
-                                          s->ev_open1, 0, o, scatter_blocks, dir_blocks, generic ? 1u : 0u);
-            }
+            hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
+            if (phase2)
+                hipExtLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, nullptr,
+                                      s->ev_open1, 0, o, scatter_blocks, dir_blocks, generic ? 1u : 0u);
         }
         if (hipGetLastError() != hipSuccess) { rc = -2; g_err = "zk_evm_open: a build kernel failed to launch"; goto fail; }
     }
@@ -2343,7 +2113,6 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
         HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(EvmResultBlock), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
         const EvmResultBlock* h = (const EvmResultBlock*)s->h_result;
-        ARG_TRY(h->dyn.open_timeout == 0u, "zk_collect: a tail block of the session-open launch timed out waiting for its producers (set ZK_P1_TAIL=0 and report)");
         n_def = h->dyn.n_deferred;
         for (int k = 0; k <= EVM_N_GROUPS; k++) gs[k] = h->group_start[k];
         t = h->tally[s->tally_last - s->d_tally];
@@ -2404,12 +2173,6 @@ static void session_timing(zk_session* s, double pass_ms, double* open_ms, doubl
     float f = 0;
     if (hipEventElapsedTime(&f, s->ev_open0, s->ev_open1) == hipSuccess) *open_ms = f;
     if (pass_ms > 0 && s->ev.size() >= 2 && hipEventElapsedTime(&f, s->ev_open0, s->ev[1]) == hipSuccess) *span_ms = f;
-    // pre-cleaned fill regions: the refill that prepared them ran behind the previous session of this shape — its duration is this
-    // session's device work all the same, and is added to both figures
-    if (s->ev_clean0 && s->ev_clean1 && hipEventElapsedTime(&f, s->ev_clean0, s->ev_clean1) == hipSuccess) {
-        if (*open_ms >= 0) *open_ms += f;
-        if (*span_ms >= 0) *span_ms += f;
-    }
     (void)hipGetLastError();
 }
 extern "C" int zk_session_timing(zk_session* s, double* open_ms, double* span_ms) {
