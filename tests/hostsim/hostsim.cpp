@@ -441,7 +441,6 @@ extern "C" int sim_copy_assign(const u64* events, const u32* flags, u64 n, const
     a.rlc = rlc.data(); a.rows = rows; a.row_flags = row_flags; a.table = table; a.rw = rw; a.rw_flags = rw_flags;
     for (u64 c = 0; c < chunks.size(); c++) cpa_chunk(a, c);
     for (u64 e = 0; e < n; e++) cpa_prefix_event(a, e);
-    for (u64 c = 0; c < chunks.size(); c++) cpa_rlc_chunk(a, c);
     for (u64 j = 0; j < nr; j++) cpa_write_row(a, j);
     return 0;
 }

@@ -165,10 +165,25 @@ def test_events_to_verified_copy_circuit_on_device_valid_and_tampered():
             h_rw[i, c] = np.frombuffer(((old + 1) % wire.P).to_bytes(32, "little"), dtype="<u8")
         else:
             h_rf[rng.randrange(n_rows)] ^= np.uint32(1)
+    # the tampered rows include the last row and both sides of a wavefront boundary of the kernel (a wavefront evaluates 62 rows and
+    # takes rows i + 1 / i + 2 from lanes + 1 / + 2; the table's last rows take them from rows 0 / 1)
+    for i, c in ((n_rows - 1, 6), (n_rows - 2, 13), (0, 3), (1, 6), (61, 6), (62, 13), (63, 9), (62 * 40 - 1, 10), (62 * 40, 6), (62 * 40 + 1, 8)):
+        old = int.from_bytes(h_rows[c, i].tobytes(), "little")
+        h_rows[c, i] = np.frombuffer(((old + 1) % wire.P).to_bytes(32, "little"), dtype="<u8")
+    e_st = _copy_status(wire.colmajor_to_rows(h_rows), h_rf.tolist(), w, wire.rowmajor_to_rows(h_rw), h_rwf.tolist())
     with engine.open_copy(h_rows, h_rf, w["r"], h_rw, h_rwf, w["bytecode"], w["tx"], w["tx_flags"]) as s:
         res = s.run()
         status = s.read_status().tolist()
-    e_st = _copy_status(wire.colmajor_to_rows(h_rows), h_rf.tolist(), w, wire.rowmajor_to_rows(h_rw), h_rwf.tolist())
+        # row ranges (zk_set_range: what a rank of a sharded run evaluates), cut at and off the 62-row wavefront period
+        for lo, hi in ((0, 62), (61, 125), (62 * 40 - 3, 62 * 40 + 3), (n_rows - 70, n_rows), (12345, 12346), (1000, 30000)):
+            s.set_range(lo, hi)
+            r2 = s.run()
+            part = s.read_status()[lo:hi].tolist()
+            assert part == e_st[lo:hi], (lo, hi)
+            pf = [j for j in range(lo, hi) if e_st[j]]
+            assert r2.rows_evaluated == hi - lo and r2.fail_count == len(pf), (lo, hi)
+            if pf:
+                assert r2.first_fail_row == pf[0] and r2.first_fail_code == e_st[pf[0]], (lo, hi)
     assert status == e_st
     fails = [j for j, c in enumerate(e_st) if c]
     assert res.fail_count == len(fails) >= 200 and res.first_fail_row == fails[0] and res.first_fail_code == e_st[fails[0]]

@@ -13,8 +13,9 @@
 // is computed on its own lane:
 //   * rw_counter of a row is closed-form: reads so far (only memory sources, only below src_addr_end) + writes so far (only
 //     memory / tx-log destinations), so `rwc_inc_left` needs no back-patching pass;
-//   * the Horner recurrence is cut into 64-byte chunks like the Bytecode assignment: cpa_chunk (Horner from 0 per chunk)
-//     -> cpa_prefix (one lane per event: incoming value per chunk, event total) -> cpa_rlc (per-byte running values);
+//   * the Horner recurrence is cut into 64-byte chunks: cpa_chunk (the chunk's Horner value from 0, as ONE lazy dot product with the
+//     Montgomery powers of r: cpa_dot) -> cpa_prefix (one lane per event: incoming value per chunk, event total); the per-byte
+//     running value of a row is incoming * r^(t + 1) + the dot product of the chunk's first t + 1 bytes, computed by the row's own lane;
 //   * cpa_write_row: one lane per OUTPUT row, coalesced 32 B/lane stores of the 20 cells; the lane of an event's first row
 //     also writes its copy-table row, the lanes of rows that touch the RW table write their RW row.
 #pragma once
@@ -54,7 +55,7 @@ struct CpaArgs {
     u64* chunk_acc;         // [n_chunks][4]
     u64* chunk_in;          // [n_chunks][4]
     u64* ev_rlc;            // [n_events][4] final rlc_acc of the event (0 for other destinations)
-    u64* rlc;               // per-byte running values of the RlcAcc events
+    u64* rlc;               // (unused since round 5: the row lanes compute the running values themselves)
     u64* rows;              // out [20][n_rows][4]
     u32* row_flags;         // out [n_rows]
     u64* table;             // out [n_table][14][4]
@@ -132,18 +133,14 @@ ZK_HD void cpa_prefix_event(const CpaArgs& a, u64 j) {
     }
     cpa_store(a.ev_rlc + 4 * j, running);
 }
-// running value after byte t of chunk c: (value entering the chunk) * r^(t + 1) + the Horner value of bytes 0..t of the chunk — one
-// output per call, independent of the other outputs of the chunk (the device runs one lane per output)
-ZK_HD void cpa_rlc_byte(const CpaArgs& a, u64 c, u32 t) {
-    const CpaChunk ch = a.chunks[c];
-    if (t >= ch.count) return;
-    const CpaEvent& e = a.ev[ch.event];
+// running value after byte i of an RlcAcc event: (value entering the byte's chunk) * r^(t + 1) + the Horner value of bytes 0..t of
+// the chunk — independent of every other output, so the row lanes compute it where they need it (no per-byte array, no launch
+// of its own: round 5 first had one lane per running value in a kernel between the prefix and the rows)
+ZK_HD Fr cpa_rlc_value(const CpaArgs& a, const CpaEvent& e, u64 i, u64 n_real) {
+    const u64 c = (u64)e.chunk0 + i / CPA_CHUNK;
+    const u32 t = (u32)(i % CPA_CHUNK);
     const Fr head = fr_mont(fr_load(a.chunk_in + 4 * c), fr_load(a.rpow + 4 * (u64)(t + 1u)));  // canonical x Montgomery power -> canonical
-    const Fr rlc = fr_add(head, cpa_dot(a, e, (u64)ch.start, t + 1u, cpa_n_real(e)));
-    cpa_store(a.rlc + 4 * (e.rlc0 + (u64)ch.start + t), rlc);
-}
-ZK_HD void cpa_rlc_chunk(const CpaArgs& a, u64 c) {  // host builds: every output of the chunk
-    for (u32 t = 0; t < CPA_CHUNK; t++) cpa_rlc_byte(a, c, t);
+    return fr_add(head, cpa_dot(a, e, i - t, t + 1u, n_real));
 }
 // Output row j (CopyCircuitRow, table.py:472-491: q_step, is_first, is_last, id lo, hi, tag, addr, src_addr_end, bytes_left,
 // value, rlc_acc, is_code, is_pad, rw_counter, rwc_inc_left, is_memory, is_bytecode, is_tx_calldata, is_tx_log, is_rlc_acc)
@@ -177,7 +174,7 @@ ZK_HD void cpa_write_row(const CpaArgs& a, u64 j) {
     const Fr rlc_acc = dst_rlc ? fr_load(a.ev_rlc + 4 * ei) : fr_zero();
     u64 addr = is_write ? e.dst_addr + i : e.src_addr + i;
     if (is_write && dst_log) addr += ((u64)CPA_TX_LOG_DATA << 32) + (e.log_id << 48);
-    const Fr wvalue = (is_write && dst_rlc) ? fr_load(a.rlc + 4 * (e.rlc0 + i)) : fr_from_u64(value);
+    const Fr wvalue = (is_write && dst_rlc) ? cpa_rlc_value(a, e, i, n_real) : fr_from_u64(value);
     const u64 n = a.n_rows;
 #define CPA_OUT(c) (a.rows + ((u64)(c) * n + j) * 4)
     cpa_store_u64(CPA_OUT(0), is_write ? 0 : 1);

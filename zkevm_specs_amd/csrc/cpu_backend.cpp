@@ -864,7 +864,6 @@ static void copy_assign_pass(zk_session* s) {
     CpaArgs& a = s->cpa;
     for (u64 c = 0; c < a.n_chunks; c++) cpa_chunk(a, c);
     for (u64 e = 0; e < a.n_events; e++) cpa_prefix_event(a, e);
-    for (u64 c = 0; c < a.n_chunks; c++) cpa_rlc_chunk(a, c);
     for (u64 j = 0; j < a.n_rows; j++) cpa_write_row(a, j);
 }
 extern "C" int zk_copy_assign_sizes(const zk_copy_events* t, uint32_t opts, uint64_t* n_rows, uint64_t* n_table, uint64_t* n_rw) {

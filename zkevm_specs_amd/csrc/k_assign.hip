@@ -194,9 +194,6 @@ __global__ void cpa_prefix_kernel(CpaArgs a) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < a.n_events) cpa_prefix_event(a, j);
 }
-__global__ __launch_bounds__(CPA_CHUNK) void cpa_rlc_kernel(CpaArgs a) {  // a block per chunk, a lane per running value
-    cpa_rlc_byte(a, blockIdx.x, threadIdx.x);
-}
 __global__ __launch_bounds__(256) void cpa_rows_kernel(CpaArgs a, u32* status, ZkTally* tally) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < a.n_rows) {
@@ -209,7 +206,6 @@ void zk_launch_cpa_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernel
 void zk_launch_copy_assign(hipStream_t st, const CpaArgs& a, u32* status, ZkTally* tally) {
     if (a.n_chunks) hipLaunchKernelGGL(cpa_chunk_kernel, dim3((u32)((a.n_chunks + 63) / 64)), dim3(64), 0, st, a);
     if (a.n_events) hipLaunchKernelGGL(cpa_prefix_kernel, dim3((u32)((a.n_events + 63) / 64)), dim3(64), 0, st, a);
-    if (a.n_chunks) hipLaunchKernelGGL(cpa_rlc_kernel, dim3((u32)a.n_chunks), dim3(CPA_CHUNK), 0, st, a);
     if (a.n_rows) hipLaunchKernelGGL(cpa_rows_kernel, dim3((u32)((a.n_rows + 255) / 256)), dim3(256), 0, st, a, status, tally);
 }
 void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out) { hipLaunchKernelGGL(keccak_rpow_kernel, dim3(1), dim3(128), 0, st, r, out); }

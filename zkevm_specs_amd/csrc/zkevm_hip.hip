@@ -1708,8 +1708,7 @@ extern "C" int zk_copy_assign_open(const zk_copy_events* t, uint64_t* rows_dev, 
     a.chunk_in = (u64*)d;
     if ((rc = dev_alloc(s, &d, (size_t)t->n_events * 32))) goto fail;
     a.ev_rlc = (u64*)d;
-    if ((rc = dev_alloc(s, &d, (size_t)pl.n_rlc * 32))) goto fail;
-    a.rlc = (u64*)d;
+    a.rlc = nullptr;  // the row lanes compute the running values themselves (copy_assign.hpp cpa_rlc_value)
     a.rows = rows_dev; a.row_flags = row_flags_dev; a.table = table_dev; a.rw = rw_dev; a.rw_flags = rw_flags_dev;
     if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)pl.n_rows * CPA_ROW_NCELLS * 32))) goto fail;
     if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)pl.n_rows * 4))) goto fail;
