@@ -67,6 +67,40 @@ def test_kernel_logic_on_large_random_codes(hostsim):
         assert wire.colmajor_to_rows(got) == B.assign(k, wire.rowmajor_to_rows(rows_in), offsets, lengths, r), k
 
 
+def _malformed_inputs():
+    """value cells that are not bytes — 2^32 - 1 (still on the lazy path), 2^32, 2^64 + 5, a full field element — on both sides of
+    chunk boundaries and in a bytecode's first chunk (whose Header row is skipped): value_rlc must follow the reference's
+    recurrence `value_rlc * r + value` with the value as it is (bytecode_circuit.py:117-130 never range-checks it)"""
+    rng = random.Random(77)
+    r = rng.randrange(wire.P)
+    codes = [bytes(rng.randrange(256) for _ in range(n)) for n in (200, 64, 130, 5)]
+    rows_in, offsets, lengths = _unroll(codes, lambda c: rng.getrandbits(256))
+    rows_in = rows_in.copy()
+    put = lambda row, val: rows_in.__setitem__((row, 5), np.frombuffer(int(val % wire.P).to_bytes(32, "little"), dtype="<u8"))  # noqa: E731
+    for row, val in ((3, (1 << 32) - 1), (40, 1 << 32), (63, (1 << 64) + 5), (64, wire.P - 1), (65, 0x7F), (130, rng.randrange(wire.P)),
+                     (int(offsets[1]) + 1, 1 << 200), (int(offsets[2]) + 64, (1 << 32) + 0x60), (int(offsets[3]) + 2, 1 << 40)):
+        put(row, val)
+    return rows_in, offsets, lengths, r
+
+
+def test_kernel_logic_on_values_that_are_not_bytes(hostsim):
+    rows_in, offsets, lengths, r = _malformed_inputs()
+    for k in (9, 10):
+        got = _hostsim(hostsim, k, rows_in, offsets, lengths, r)
+        assert wire.colmajor_to_rows(got) == B.assign(k, wire.rowmajor_to_rows(rows_in), offsets, lengths, r), k
+
+
+@pytest.mark.gpu
+def test_hip_on_values_that_are_not_bytes():
+    from zkevm_specs_amd import engine
+
+    rows_in, offsets, lengths, r = _malformed_inputs()
+    for k in (9, 10):
+        with engine.open_bytecode_assign(rows_in, offsets, lengths, k, r) as s:
+            assert s.run().ok
+            assert wire.colmajor_to_rows(s.rows()) == B.assign(k, wire.rowmajor_to_rows(rows_in), offsets, lengths, r), k
+
+
 @pytest.mark.gpu
 def test_hip_matches_the_reference_rows(golden_dir):
     from zkevm_specs_amd import engine

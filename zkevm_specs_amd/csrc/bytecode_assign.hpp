@@ -66,23 +66,62 @@ ZK_HD void bca_fill_rpow(const Fr& r, u64* out) {  // single lane, once per sess
         acc = fr_mont(acc, rM);
     }
 }
+// Horner value of the byte rows [j0, j1) of a chunk (indices among the chunk's BYTE rows; the Header row of a bytecode's first chunk
+// is not one), from 0: sum of value_j * r^(j1 - 1 - j).  Values below 2^32 — every well-formed row: a byte — accumulate against the
+// Montgomery powers of r as plain integers (ten 32-bit limbs, 8 multiply-adds per row, independent loads), one reduction and one
+// product to leave Montgomery form; a wider value (malformed witnesses only) sends the whole range down the reference's own
+// recurrence `acc = acc * r + value`.  Round 4 ran that recurrence always: 64 dependent load + Montgomery-product round trips per
+// chunk lane, 0.32 ms for a block's 131,072 rows whatever the occupancy.
+ZK_HD Fr bca_dot(const BcaArgs& a, const BcaChunk& ch, u32 j1) {
+    const u32 skip = ch.first ? 1u : 0u;  // chunk row t = skip + j
+    u32 acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0;
+    u32 wide = 0;
+#pragma unroll 8
+    for (u32 j = 0; j < j1; j++) {
+        const Fr v = bca_in_cell(a, (u64)ch.start + skip + j, 5);
+        wide |= v.v[1] | v.v[2] | v.v[3] | v.v[4] | v.v[5] | v.v[6] | v.v[7];
+        const Fr pw = fr_load(a.rpow + 4 * (u64)(j1 - 1u - j));
+        u64 c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c += (u64)acc[k] + (u64)pw.v[k] * v.v[0];  // <= (2^32 - 1)^2 + 2 (2^32 - 1) = 2^64 - 1
+            acc[k] = (u32)c;
+            c >>= 32;
+        }
+        c += acc[8];
+        acc[8] = (u32)c;
+        acc[9] += (u32)(c >> 32);
+    }
+    if (wide) {  // the exact recurrence over the same rows
+        const Fr rM = fr_load(a.rpow + 4);
+        Fr x = fr_zero();
+        for (u32 j = 0; j < j1; j++) x = fr_add(fr_mont(x, rM), bca_in_cell(a, (u64)ch.start + skip + j, 5));
+        return x;
+    }
+    Fr lo;
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo.v[k] = acc[k];
+    const Fr p = fr_modulus();
+#pragma unroll
+    for (int it = 0; it < 5; it++) {  // lo < 2^256 < 6 p
+        Fr t;
+        const u32 bw = u256_sub(t, lo, p);
+        lo = bw ? lo : t;
+    }
+    // + (acc[8] + acc[9] 2^32) * 2^256 (mod p): 2^256 mod p is the Montgomery one; the sum is the Montgomery form of the value
+    const Fr xM = fr_add(lo, fr_mul(fr_from_u64((u64)acc[8] | ((u64)acc[9] << 32)), frm_one()));
+    return fr_mont(xM, fr_from_u64(1));
+}
 // The push-data counter (bytecode_circuit.py:117-130): entering a byte row with `left`, the next row is entered with
 // (left == 0 ? get_push_size(value) : left - 1); the Header row (the bytecode's first row) leaves it alone.
 ZK_HD void bca_chunk(const BcaArgs& a, u64 c) {
     const BcaChunk ch = a.chunks[c];
-    const Fr rM = fr_load(a.rpow + 4);
-    Fr acc = fr_zero();
-    u32 m = 0;
+    const u32 m = ch.count - (ch.first ? 1u : 0u);
     uint8_t size[BCA_CHUNK];
-    for (u32 t = 0; t < ch.count; t++) {
-        size[t] = 0;
-        if (ch.first && t == 0) continue;
-        const Fr v = bca_in_cell(a, (u64)ch.start + t, 5);
-        size[t] = (uint8_t)bca_push_size(v);
-        acc = fr_add(fr_mont(acc, rM), v);
-        m++;
-    }
-    bca_store(a.chunk_acc + 4 * c, acc);
+    for (u32 t = 0; t < ch.count; t++) size[t] = (ch.first && t == 0) ? (uint8_t)0 : (uint8_t)bca_push_size(bca_in_cell(a, (u64)ch.start + t, 5));
+    bca_store(a.chunk_acc + 4 * c, bca_dot(a, ch, m));
     a.chunk_m[c] = m;
     // zero_out[p]: the counter after the chunk when position p is entered with 0
     uint8_t zero_out[BCA_CHUNK + 1];
@@ -106,26 +145,33 @@ ZK_HD void bca_prefix_code(const BcaArgs& a, u64 j) {
         left = a.chunk_map[(u64)c * BCA_MAP_STRIDE + left];
     }
 }
-ZK_HD void bca_rlc_chunk(const BcaArgs& a, u64 c) {
+// Row t of chunk c: value_rlc after the row = (value entering the chunk) * r^(byte rows up to and including t) + their Horner value;
+// push_data_left entering the row and the row's push_data_size by walking the counter from the chunk's entry state.  One output row
+// per call, independent of the chunk's other rows (the device runs one lane per row: a chunk is a 64-lane block).
+ZK_HD void bca_rlc_row(const BcaArgs& a, u64 c, u32 t) {
     const BcaChunk ch = a.chunks[c];
-    const Fr rM = fr_load(a.rpow + 4);
-    Fr rlc = fr_load(a.chunk_in + 4 * c);
-    u32 next = a.chunk_state[c];
-    for (u32 t = 0; t < ch.count; t++) {
-        const u64 g = (u64)ch.start + t;
-        const u32 left = next;
-        u32 size = 0;
-        if (!(ch.first && t == 0)) {
-            const Fr v = bca_in_cell(a, g, 5);
-            rlc = fr_add(fr_mont(rlc, rM), v);
-            size = bca_push_size(v);
-            next = left == 0u ? size : left - 1u;
-        }
-        bca_store(a.rlc + 4 * g, rlc);
-        a.row_code[g] = ch.code;
-        a.track[2 * g] = (uint8_t)left;
-        a.track[2 * g + 1] = (uint8_t)size;
+    if (t >= ch.count) return;
+    const u64 g = (u64)ch.start + t;
+    const u32 skip = ch.first ? 1u : 0u;
+    u32 left = a.chunk_state[c];
+    for (u32 q = skip; q < t; q++) {  // rows before this one: only their push sizes matter
+        const u32 sz = bca_push_size(bca_in_cell(a, (u64)ch.start + q, 5));
+        left = left == 0u ? sz : left - 1u;
     }
+    Fr rlc = fr_load(a.chunk_in + 4 * c);
+    u32 size = 0;
+    if (t >= skip) {
+        const u32 k = t + 1u - skip;  // byte rows 0..k-1 of the chunk end at this row
+        rlc = fr_add(fr_mont(rlc, fr_load(a.rpow + 4 * (u64)k)), bca_dot(a, ch, k));
+        size = bca_push_size(bca_in_cell(a, g, 5));
+    }
+    bca_store(a.rlc + 4 * g, rlc);
+    a.row_code[g] = ch.code;
+    a.track[2 * g] = (uint8_t)left;
+    a.track[2 * g + 1] = (uint8_t)size;
+}
+ZK_HD void bca_rlc_chunk(const BcaArgs& a, u64 c) {  // host builds: every row of the chunk
+    for (u32 t = 0; t < BCA_CHUNK; t++) bca_rlc_row(a, c, t);
 }
 // Output row i (bytecode_circuit.Row: q_first, q_last, hash lo, hi, tag, index, value, is_code, push_data_left, value_rlc,
 // length, push_data_size)

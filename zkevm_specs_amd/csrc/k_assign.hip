@@ -122,9 +122,8 @@ __global__ void bca_prefix_kernel(BcaArgs a) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < a.n_codes) bca_prefix_code(a, j);
 }
-__global__ void bca_rlc_kernel(BcaArgs a) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < a.n_chunks) bca_rlc_chunk(a, c);
+__global__ __launch_bounds__(BCA_CHUNK) void bca_rlc_kernel(BcaArgs a) {  // a block per chunk, a lane per row
+    if (blockIdx.x < a.n_chunks) bca_rlc_row(a, blockIdx.x, threadIdx.x);
 }
 __global__ __launch_bounds__(256) void bca_rows_kernel(BcaArgs a, u32* status, ZkTally* tally) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,7 +177,7 @@ void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, Zk
     if (a.n_codes) {
         hipLaunchKernelGGL(bca_chunk_kernel, dim3(gk ? gk : 1), dim3(64), 0, st, a);
         hipLaunchKernelGGL(bca_prefix_kernel, dim3(gc), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(bca_rlc_kernel, dim3(gk ? gk : 1), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(bca_rlc_kernel, dim3((u32)(a.n_chunks ? a.n_chunks : 1)), dim3(BCA_CHUNK), 0, st, a);
     }
     hipLaunchKernelGGL(bca_rows_kernel, dim3((u32)((a.n_out + 255) / 256)), dim3(256), 0, st, a, status, tally);
 }
