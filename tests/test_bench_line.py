@@ -89,5 +89,5 @@ def test_compact_line_pass_workloads(bench):
 
 
 def test_effective_cores(bench):
-    n, how = bench.effective_cores()
+    n, how = bench.legs.effective_cores()
     assert 1 <= n <= (os.cpu_count() or 1) and how

@@ -1,0 +1,476 @@
+#!/usr/bin/env python3
+"""Side measurements of bench.py — everything that is NOT the timed headline loop and its roofline block: the CPU baseline legs
+(`cpu_baseline`: pure-Python port, libzkevm_cpu.so on one core and on the cgroup's effective cores, the unmodified reference in a
+child process), the other BASELINE configurations at N = 1 (`other_configs`), the batch entry, the flushed-cache open / pass
+split, the live `rocprofv3 --pmc` traffic measurement and the marshalling sample.  bench.py imports this module and hands itself
+over as `core` where a leg needs its builders / timing loops; their results go to bench_full.json and, as a few scalars, into
+the compact line."""
+import ctypes
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBPS = 8000.0
+
+
+def timed_batch(ctx, w, steps, warmup):
+    """the same K fresh-witness verifications through ONE call of the batch entry (zk_evm_verify_batch: two witnesses in flight on
+    two streams); wall clock of the call, bracketed like the headline"""
+    from zkevm_specs_amd import engine
+
+    n_copies = len(w.shots)
+    mk = lambda n, first: engine.EvmBatch(w.copies, [(first + i) % n_copies for i in range(n)], device=ctx.local_rank)  # noqa: E731
+    mk(max(warmup, 2), 0)()
+    b = mk(steps, warmup)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    b()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    rs = b.results()
+    assert all(r.ok for r in rs), "synthetic witness must satisfy every constraint"
+    return {"ms_per_witness": dt / steps * 1e3, "rows_per_s": w.units * steps / dt, "witnesses": steps,
+            "mean_pass_kernel_ms": sum(r.kernel_ms for r in rs) / len(rs)}
+
+
+def fresh_leg(ctx, w, flush):
+    """A verifier sees each witness once.  (a) open (device-resident inputs: packed key records, density check, bytecode
+    directory, small-table indices — device kernels, no host synchronisation inside) + one pass over cold caches, wall clock
+    around both with ONE synchronisation at the end (the collect); (b) the same split into open / pass with a flush and a
+    synchronisation between them (round-2 definition, comparable); (c) the one-shot C entry (open + launch + collect + close).
+    Best of 5 each."""
+    np, torch = ctx.np, ctx.torch
+    both, opens, passes, open_dev, shots = [], [], [], [], []
+    for _ in range(5):
+        flush.sum()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        s2 = w.fresh()
+        r2 = s2.run()
+        both.append(time.perf_counter() - t)
+        assert r2.ok
+        s2.close()
+    for _ in range(5):
+        flush.sum()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = time.perf_counter()
+        e0.record()
+        s2 = w.fresh()
+        e1.record()
+        torch.cuda.synchronize()
+        t_open = time.perf_counter() - t
+        flush.sum()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r2 = s2.run()
+        t_pass = time.perf_counter() - t
+        assert r2.ok
+        s2.close()
+        opens.append(t_open)
+        passes.append(t_pass)
+        open_dev.append(e0.elapsed_time(e1))
+    if w.oneshot is not None:
+        for _ in range(5):
+            flush.sum()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r3 = w.oneshot()
+            shots.append(time.perf_counter() - t)
+            assert r3.ok
+    k = int(np.argmin([a + b for a, b in zip(opens, passes)]))
+    best = min(both)
+    return {"open_plus_pass_ms": best * 1e3, "rows_per_s": w.units / best,
+            "split": {"open_ms": opens[k] * 1e3, "open_device_span_ms": open_dev[k], "cold_pass_ms": passes[k] * 1e3,
+                      "rows_per_s": w.units / (opens[k] + passes[k])},
+            "one_shot_c_entry_ms": min(shots) * 1e3 if shots else None,
+            "one_shot_rows_per_s": w.units / min(shots) if shots else None,
+            "note": "inputs resident in HBM; caches flushed (2 GiB sweep) before every repetition; `open_plus_pass_ms` = session open (device-side "
+                    "index / packed-key / directory builds from a per-device buffer arena, no host synchronisation) + launch + collect, one wall-clock "
+                    "interval; `split` re-flushes and synchronises between open and pass (the round-2 definition); best of 5"}
+
+
+def live_pmc_traffic(core, log_rows):
+    """HBM-side bytes of ONE one-shot step, measured now: two short child runs of this file's own one-shot step under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE — separate passes, counters only, as the MI355X guide prescribes), the same
+    corrections as the committed profile's (oneshot_profile_numbers).  Steps are counted by the fill kernel's dispatches (one per
+    zk_evm_verify).  Returns (bytes per step or None, how it was obtained)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    kernels = {}
+    steps = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="zk_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child",
+               "--log-rows", str(log_rows), "--steps", "4", "--warmup", "2"]
+        try:
+            child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)  # its own process group: a pass that overruns is ended with everything it started
+            try:
+                rc = child.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(child.pid, signal.SIGKILL)
+                child.wait()
+                raise
+            if rc:
+                raise subprocess.CalledProcessError(rc, cmd)
+            agg = {}
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                import csv
+
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter:
+                        a = agg.setdefault(r["Kernel_Name"], [0, 0.0])
+                        a[0] += 1
+                        a[1] += float(r["Counter_Value"])
+            for name, (n, tot) in agg.items():
+                kernels.setdefault(name, {}).setdefault("pmc", {})[counter] = {"dispatches": n, "avg_per_dispatch": tot / n}
+                if "evm_open_fill_kernel" in name:
+                    steps = n
+        except Exception as e:  # noqa: BLE001 — the committed profile stays the source then, and the line says so
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"live rocprofv3 --pmc {counter} pass failed ({type(e).__name__})"
+        shutil.rmtree(out, ignore_errors=True)
+    if not steps:
+        return None, "live rocprofv3 passes saw no one-shot steps"
+    traffic, _ = core.oneshot_profile_numbers({"bench_line": {"steps": steps, "warmup": 0}, "kernels": kernels})
+    return traffic, f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over {steps} one-shot steps of a child process (bench.py live_pmc_traffic)"
+
+
+def config0_bytecode(args):
+    """BASELINE configs[0]: the Bytecode circuit over ONE 256-byte contract, k = 9 (512 rows, bytecode_circuit.py:37,104) — the
+    reference's own CPU-runnable case, "pure CPU path (plumbing, no GPU)": timed through the CPU backend behind the same C ABI
+    (libzkevm_cpu.so, one core), beside the reference's own figure from the build container."""
+    import numpy as np
+
+    from zkevm_specs_amd import _lib as zlib, oneshot as zoneshot
+    from zkevm_specs_amd.synth import synth_bytecode_witness
+
+    code = bytes(np.random.default_rng(1).integers(0, 256, 256, dtype=np.uint8))
+    r = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % (1 << 253)
+    cols, keccak = synth_bytecode_witness([code], 9, r)
+    zlib.set_cpu_threads(1)
+    reps = 200
+    res, _ = zoneshot.bytecode_verify(cols, keccak, r, device="cpu")
+    assert res.ok and res.rows_evaluated == 512
+    t = time.perf_counter()
+    for _ in range(reps):
+        zoneshot.bytecode_verify(cols, keccak, r, device="cpu")
+    dt = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for _ in range(20):
+        res_g, _ = zoneshot.bytecode_verify(cols, keccak, r)
+    dt_g = (time.perf_counter() - t) / 20
+    assert res_g.ok
+    blk = {"workload": "Bytecode circuit, one 256-byte contract, k = 9: 512 rows (BASELINE configs[0]: the CPU-runnable plumbing case)",
+           "value": 512 / dt, "unit": "rows/s", "steps": reps, "warmup": 1, "ms_per_step": dt * 1e3, "units_per_pass": 512,
+           "backend": "libzkevm_cpu.so, 1 core (one-shot zk_bytecode_verify incl. its keccak-table index build and the ctypes call)",
+           "hip_one_shot": {"rows_per_s": 512 / dt_g, "ms": dt_g * 1e3,
+                            "note": "the same one-shot call on the MI355X incl. H2D staging of the 200 KB witness: launch-latency bound at 512 rows"}}
+    if not args.no_cpu_baseline:
+        ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")), reverse=True)
+        ref = json.load(open(ref_file[0])) if ref_file else None
+        if ref and "bytecode" in ref:
+            blk["cpu_baseline"] = {"value": ref["bytecode"]["rows_per_s"], "unit": "rows/s", "cores": 1, "kind": "reference",
+                                   "sample": f"check_bytecode_row of the unmodified reference over the 512 rows of this configuration, build container ({os.path.basename(ref_file[0])}): a cross-box figure"}
+    return blk
+
+
+def other_configs(core, ctx, args):
+    """BASELINE configs[0], [1], [3], [4] on the driver's clock, after the headline: each one timed like the headline (barrier +
+    synchronize around K passes), a reduced K so that they add well under a minute of GPU time (witness synthesis is
+    host work outside the timed regions).  State also at 2^20 rows (past the 256 MiB Infinity Cache: the HBM figure) and, at
+    2^16, with a cold-cache leg (its 120 MB witness otherwise never leaves the Infinity Cache between passes)."""
+    out = {"bytecode_256B": config0_bytecode(args)}
+    torch = ctx.torch
+    # tx 2^11: ONE GPU's shard of BASELINE configs[3] at 8 GPUs (2^14 txs over 8 ranks) — the ECDSA launch is a dependent chain per
+    # signature, so this is what every rank of the 8-GPU run takes per pass, and why that configuration's strong scaling is flat
+    for name, log_rows, steps, warmup in (("state", 16, 50, 5), ("state", 20, 20, 3), ("tx", 14, 10, 2), ("tx", 11, 10, 2), ("super", 20, 20, 3)):
+        t_build = time.perf_counter()
+        w = core.BUILDERS[name](ctx, log_rows, False)
+        t_build = time.perf_counter() - t_build
+        dt, res = core.timed_passes(ctx, w.sess, steps, warmup)
+        per_circuit = None
+        if name == "super":
+            res, per_circuit = core.resolve_super(w, res)
+        assert res.fail_count == 0, f"{name}: synthetic witness must satisfy every constraint"
+        cold_ms = None
+        if name == "state" and not args.no_cold_leg:
+            flush = torch.zeros(1 << 29, dtype=torch.int32, device="cuda")
+            for _ in range(8):
+                flush.sum()
+                w.sess.launch()
+            cold_ms = w.sess.collect().kernel_ms
+            del flush
+        roof, profile, profile_src = core.roofline_block(w, res, 1, False, cold_ms)
+        if name == "tx":
+            core.tx_extras(roof, res, profile, profile_src)
+        if per_circuit is not None:
+            roof["per_circuit"] = per_circuit
+        blk = {"workload": w.workload, "value": w.total_units * steps / dt, "unit": "txs/s" if name == "tx" else "rows/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": dt / steps * 1e3, "units_per_pass": w.total_units, "witness_build_s": t_build,
+               "roofline": roof, "config": w.extra_cfg}
+        blk["pre_ramp_steps"] = core.timed_passes.last_ramp
+        if not args.no_cpu_baseline and not (name == "state" and log_rows == 20) and not (name == "tx" and log_rows == 11):
+            blk["cpu_baseline"] = cpu_baseline(name, w)
+        w.sess.close()
+        out[f"{name}_2p{log_rows}"] = blk
+        del w
+        torch.cuda.empty_cache()
+    return out
+
+
+def marshalling_sample(wire_h, n_steps=1 << 10):
+    """flatten_evm (reference-shaped Python objects -> wire arrays, zkevm_specs_amd/flatten.py) timed on a bounded prefix of this run's
+    trace: the objects are rebuilt from the wire first (zkevm_specs_amd/objects.py), which is not part of the figure."""
+    import numpy as np
+
+    from zkevm_specs_amd import flatten, objects
+
+    w = {k: v for k, v in wire_h.items()}
+    w["steps"] = np.ascontiguousarray(w["steps"][: n_steps + 1])
+    hi = int(w["steps"][-1, 1, 0]) + 64  # rw_counter of the last sampled step: the RW rows the prefix can look up
+    base = int(w["rw"][0, 0, 0])
+    w["rw"] = np.ascontiguousarray(w["rw"][: max(hi - base, 1)])
+    w["rw_flags"] = np.ascontiguousarray(w["rw_flags"][: len(w["rw"])])
+    tables, steps = objects.evm_from_wire(w)
+    t = time.perf_counter()
+    out = flatten.flatten_evm(tables, steps)
+    dt = time.perf_counter() - t
+    cells = sum(int(v.size) // 4 for v in out.values() if hasattr(v, "dtype") and v.dtype == np.uint64)
+    return {"steps": n_steps, "cells": cells, "seconds": dt, "steps_per_s": n_steps / dt, "cells_per_s": cells / dt, "cores": 1,
+            "note": "per-cell Python (`x.expr().n` -> 4 x u64); a caller that keeps its witness in wire arrays (device-side assignment, "
+                    "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
+
+
+def live_reference_leg(ev, logs=(4, 5)):
+    """The UNMODIFIED reference timed on THIS box: `verify_steps` (evm_circuit/main.py:14) over the first 2^4 and 2^5 step pairs of
+    the bench's own trace, each with the table rows those steps can look up (the reference scans whole tables per lookup,
+    table.py:864-884) — about 30 s of one core.  The reference lives in the git-ignored staging copy oracle/_ref/reference
+    (tools/run_reference_suite.py --stage; it travels to the GPU box, /root/reference does not) and is only ever imported by the
+    child process (tools/time_reference.py with PYTHONPATH = oracle/refshim + the staged src).  None when it is not staged."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+
+    src = os.path.join(ROOT, "oracle", "_ref", "reference", "src")
+    if not os.path.isdir(src):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from time_reference import evm_prefix
+
+        from tests.evm_cases import with_defaults
+
+        full = with_defaults({k: v for k, v in ev.items() if k != "meta"})
+        arrays = {}
+        for log_n in logs:
+            for k, v in evm_prefix(full, 1 << log_n).items():
+                arrays[f"{log_n}/{k}"] = v
+        with tempfile.TemporaryDirectory(prefix="zk_ref_", dir="/tmp") as td:
+            npz = os.path.join(td, "prefixes.npz")
+            np.savez(npz, **arrays)
+            env = dict(os.environ, ZK_TIME_EVM_NPZ=npz, PYTHONDONTWRITEBYTECODE="1",
+                       PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle", "refshim"), src]))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference.py")], env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, timeout=240, check=True).stdout
+        pts = json.loads(out)["evm_live"]["measured"]
+    except Exception:  # noqa: BLE001 — the committed build-container figure stays the reference leg then
+        return None
+    finally:
+        sys.path.pop(0)
+    top = pts[-1]
+    return {"value": top["pairs_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False, "timed_on": "this box",
+            "sample_short": f"unmodified reference verify_steps, first {top['step_pairs']} step pairs of this trace, {top['seconds']:.0f} s, this box",
+            "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"], "seconds": p["seconds"],
+                          "rows_per_s": p["pairs_per_s"]} for p in pts],
+            "sample": f"verify_steps of the unmodified reference (oracle/_ref staging copy, dependency stand-ins of oracle/refshim) over the first "
+                      f"{top['step_pairs']} step pairs of this trace with the {top['rw_rows'] + top['bytecode_rows']} table rows they can look up, "
+                      f"{top['seconds']:.1f} s on one core of this box; its lookups scan the table, so the full 2^18-step trace is far slower per row"}
+
+
+def effective_cores():
+    """Cores this process may actually burn: the smaller of its affinity mask and the cgroup's CFS quota.  On the round-4 GPU box
+    os.cpu_count() said 256 while all-core passes after the first took 99.8 / 139.7 / 200.1 ms — multiples of the 100 ms CFS
+    period: 256 OpenMP threads spend the quota in a burst (pass 0: 10.9 ms) and are then throttled.  Returns (cores, how)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity mask"
+    try:
+        quota = period = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):  # cgroup v2: "<quota|max> <period>"
+            q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota, period = (None if q == "max" else float(q)), float(p_)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota, period = (None if q <= 0 else q), float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota and period and quota / period < n:
+            n, how = max(1, int(quota / period)), f"cgroup CFS quota {quota / period:.1f} cores"
+    except (OSError, ValueError):
+        pass
+    return n, how
+
+
+def cpu_baseline(workload, w):
+    """CPU legs on rank 0's host cores, bounded samples.  `value` is the reference's own figure when the committed
+    build-container measurement exists (kind "reference"), else the oracle port's."""
+    import numpy as np
+
+    cores_total, cores_how = effective_cores()
+    ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")), reverse=True)
+    ref = json.load(open(ref_file[0])) if ref_file else None
+    legs = {}
+    if workload in ("evm", "super"):
+        from oracle import evm_oracle, wire
+
+        from tests.evm_cases import to_witness
+
+        ev = w.wire_h if workload == "evm" else dict(w.env["parts"]["evm"])
+        if workload == "super" and "copy_events" in w.env["parts"]:
+            # the block's copy table on the host (on the device it is zk_copy_assign's output): the oracle's restatement of the same
+            # assignment — test infrastructure, used here only to hand the CPU legs the witness the device evaluates
+            from oracle import copy_assign_oracle
+            from zkevm_specs_amd.wire import rows_to_rowmajor
+
+            ce = w.env["parts"]["copy_events"]
+            ev["copy"] = rows_to_rowmajor(copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"],
+                                                                     ce["offsets"], ce["r"])[2], 14)
+        sample = min(int(ev["steps"].shape[0]) - 1, 1 << 15)
+        W = to_witness(dict({k: v for k, v in ev.items() if k != "meta"}, steps=ev["steps"][: sample + 1]))
+        tc = time.perf_counter()
+        st = evm_oracle.verify_steps(W)
+        tc = time.perf_counter() - tc
+        assert not any(st)
+        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
+                        "sample": f"first {sample} step pairs of the same trace, pure-Python oracle with dict-indexed lookups (oracle/evm_oracle.py)"}
+        from zkevm_specs_amd import _lib as zlib, engine as zengine
+
+        hs = min(int(ev["steps"].shape[0]) - 1, 1 << 18)
+        sub = {k: v for k, v in ev.items() if k != "meta"}
+        sub["steps"] = ev["steps"][: hs + 1]
+        for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
+            zlib.set_cpu_threads(threads)
+            tc = time.perf_counter()
+            with zengine.open_evm(sub, device="cpu") as cs:
+                t_open = time.perf_counter() - tc
+                runs = [cs.run() for _ in range(4 if threads == 1 else 8)]  # pass 0 (thread-pool start, and a CFS burst) is not counted
+            assert all(r.ok for r in runs)
+            ms_sorted = sorted(r.kernel_ms for r in runs[1:])
+            med = ms_sorted[len(ms_sorted) // 2]
+            legs[key] = {"value": hs / (med / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": med, "pass0_ms": runs[0].kernel_ms, "open_s": t_open,
+                         "pass_ms_spread": {"min": ms_sorted[0], "median": med, "max": ms_sorted[-1], "passes": len(ms_sorted)},
+                         "sample": f"{hs} step pairs through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernels' own per-step functions compiled for the "
+                                   f"host, OpenMP over the pairs; csrc/cpu_backend.cpp), MEDIAN of passes 1..{len(ms_sorted)} with tables and indices "
+                                   f"resident, {threads} thread(s) = {cores_how if threads > 1 else 'one core'} — the optimised-CPU line"}
+        live = live_reference_leg(ev) if workload == "evm" else None
+        if live:
+            legs["reference"] = live
+            if ref and "evm" in ref:
+                live["extrapolated_2p18_rows_per_s_build_container"] = ref["evm"]["extrapolated_2p18"]["pairs_per_s"]
+        elif ref and "evm" in ref:
+            e = ref["evm"]
+            legs["reference"] = {"value": e["extrapolated_2p18"]["pairs_per_s"], "unit": "rows/s", "cores": 1,
+                                 "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"],
+                                               "rows_per_s": p["pairs_per_s"]} for p in e["measured"]],
+                                 "fit": e["fit"], "extrapolated": True,
+                                 "sample_short": "unmodified reference verify_steps, 2^4/2^6/2^8-pair prefixes, build container; 2^18 EXTRAPOLATED",
+                                 "sample": "verify_steps of the unmodified reference on 2^4 / 2^6 / 2^8-pair prefixes of this trace, build container "
+                                           f"({os.path.basename(ref_file[0])}); the 2^18 figure is EXTRAPOLATED from the fit (linear-scan lookups, table.py:864-884)"}
+    elif workload == "tx":
+        from oracle import sign_oracle
+
+        tx, sg = w.env["tx"], w.env["sig"]
+        from zkevm_specs_amd import _lib as zlib, oneshot as zoneshot
+
+        n = int(tx["bytes"].shape[0])
+        R_TX = 0x1F2E3D4C5B6A79881726354433221100FFEEDDCCBBAA99887766554433221
+        r4 = np.frombuffer(int(R_TX).to_bytes(32, "little"), dtype="<u8").copy()
+        def both_circuits(sample):
+            """Tx circuit + Sig circuit over the first `sample` txs through the one-shot entries of the CPU backend; wall clock"""
+            tc = time.perf_counter()
+            for wire_, layout, is_sig in ((tx, 1, False), (sg, 2, True)):
+                wslice = {k: (np.ascontiguousarray(v[:sample]) if k in ("bytes", "meta") else (np.ascontiguousarray(v[:, :sample]) if k == "cells" else v))
+                          for k, v in wire_.items()}
+                if not is_sig:
+                    wslice["tx_rows"], wslice["tx_flags"] = wire_["tx_rows"][: 12 * sample], wire_["tx_flags"][: 12 * sample]
+                _, est = zoneshot.ecdsa_verify(wslice["bytes"], np.ascontiguousarray(wslice["meta"][:, 3]) if is_sig else None, layout=layout, device="cpu")
+                wslice["meta"] = wslice["meta"].copy()
+                wslice["meta"][:, 0] = est
+                r_cpu, _ = zoneshot.sign_verify(wslice, R_TX, is_sig, device="cpu")
+                assert r_cpu.ok, (is_sig, r_cpu)
+            return time.perf_counter() - tc
+
+        for threads, key, sample, reps in ((1, "cpu_backend_1core", min(n, 1 << 9), 1), (cores_total, "cpu_backend_allcores", n, 3)):
+            zlib.set_cpu_threads(threads)
+            tc = sorted(both_circuits(sample) for _ in range(reps))[reps // 2]  # median (all cores: repetition 0 pays for the OpenMP thread pool)
+            legs[key] = {"value": sample / tc, "unit": "txs/s", "cores": threads,
+                         "sample": f"first {sample} txs: Tx circuit + Sig circuit incl. both ECDSA verifications through libzkevm_cpu.so (ZK_BACKEND=cpu: "
+                                   "the kernels' own per-unit functions compiled for the host, OpenMP; csrc/cpu_backend.cpp), wall clock of the one-shot "
+                                   f"entries, median of {reps}"}
+        from oracle import ecdsa_oracle, wire
+
+        sample_p = min(n, 1 << 5)
+        tc = time.perf_counter()
+        b = tx["bytes"][:sample_p]
+        packed = np.stack([b[:, 0], b[:, 1], b[:, 4, ::-1], b[:, 7], b[:, 8]], axis=1)  # Tx units carry msg_hash little-endian
+        meta = tx["meta"][:sample_p].copy()
+        meta[:, 0] = ecdsa_oracle.verify_packed(packed)
+        st = sign_oracle.verify_units(b, tx["cells"][:, :sample_p], meta, wire.rowmajor_to_rows(tx["keccak"]), int.from_bytes(r4.tobytes(), "little"), False,
+                                      wire.rowmajor_to_rows(tx["tx_rows"][: 12 * sample_p]), tx["tx_flags"][: 12 * sample_p])
+        tc = time.perf_counter() - tc
+        assert not any(st)
+        legs["port"] = {"value": sample_p / tc, "unit": "txs/s", "cores": 1,
+                        "sample": f"first {sample_p} txs, Tx circuit with ECDSA verification, pure-Python oracle (oracle/sign_oracle.py + oracle/ecdsa_oracle.py)"}
+        if ref and "tx" in ref:
+            t = ref["tx"]
+            legs["reference"] = {"value": t["txs_per_s"], "unit": "txs/s", "cores": 1, "extrapolated": False, "measured": t.get("measured"),
+                                 "sample": f"tx_circuit.verify_circuit + sig_circuit.verify_circuit of the unmodified reference over {t['txs']} of these txs "
+                                           f"(eth-keys stand-in: oracle/refshim), build container ({os.path.basename(ref_file[0])})"}
+    else:
+        from oracle import state_oracle, wire
+
+        cols, flags, mpt = w.env["cols"], w.env["flags"], w.env["mpt"]
+        sample = min(int(cols.shape[1]), 1 << 16)
+        rows_i = wire.colmajor_to_rows(cols[:, :sample])
+        mpt_i = wire.rowmajor_to_rows(mpt)
+        tc = time.perf_counter()
+        state_oracle.verify_rows(rows_i, flags[:sample], mpt_i)
+        tc = time.perf_counter() - tc
+        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
+                        "sample": f"first {sample} rows of the same witness, pure-Python oracle (oracle/state_oracle.py)"}
+        from zkevm_specs_amd import _lib as zlib, engine as zengine
+
+        for threads, key in ((1, "cpu_backend_1core"), (cores_total, "cpu_backend_allcores")):
+            zlib.set_cpu_threads(threads)
+            with zengine.open_state(cols, flags, mpt, device="cpu") as cs:
+                runs = [cs.run() for _ in range(6)]  # pass 0 (thread-pool start, and a CFS burst) is not counted
+            assert all(r.ok for r in runs)
+            ms_sorted = sorted(r.kernel_ms for r in runs[1:])
+            med = ms_sorted[len(ms_sorted) // 2]
+            legs[key] = {"value": int(cols.shape[1]) / (med / 1e3), "unit": "rows/s", "cores": threads, "pass_ms": med, "pass0_ms": runs[0].kernel_ms,
+                         "sample": f"all {int(cols.shape[1])} rows through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernel's own per-row function compiled for "
+                                   f"the host, OpenMP over the rows; csrc/cpu_backend.cpp), MEDIAN of passes 1..5 with the witness and the MPT index resident, "
+                                   f"{threads} thread(s)"}
+        if ref and "state" in ref:
+            legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
+                                 "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
+                                           f"({os.path.basename(ref_file[0])})"}
+    head = legs.get("reference") or legs.get("port") or legs["cpu_backend_1core"]
+    return {"value": head["value"], "unit": head["unit"], "cores": 1,
+            "kind": "reference" if "reference" in legs else "port",
+            "sample": head["sample"], "sample_short": head.get("sample_short"), "legs": legs,
+            "this_box_cores_total": cores_total, "this_box_cores_source": cores_how, "this_box_cpu_count": os.cpu_count(),
+            "reference_measured_on": ("this box (oracle/_ref staging copy)" if (legs.get("reference") or {}).get("timed_on") == "this box" else
+                                      None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: /root/reference does not exist "
+                                                                "here, so the `reference` leg is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box")),
+            }

@@ -13,7 +13,7 @@ out=gpurun_out/$tag; mkdir -p "$out"
 for stage in "$@"; do
     t0=$(date +%s)
     case "$stage" in
-    tests)    timeout 2400 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -5 $out/pytest.log ;;
+    tests)    eval "timeout 2400 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-}" > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log; tail -5 $out/pytest.log ;;
     smoke)    python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log ;;
     bench)    timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_stdout.txt 2> $out/bench.err; echo "bench rc=$?"
               cp -f bench_full.json $out/bench_full.json 2>/dev/null

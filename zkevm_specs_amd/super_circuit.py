@@ -20,6 +20,8 @@ Concurrency note: the sessions overlap on the device only when their streams lan
 reads GPU_MAX_HW_QUEUES (default 4) at its first call; `zkevm_specs_amd._lib.load()` defaults it to 16 — call it (or `init()`)
 before the process's first HIP call (e.g. before `torch.cuda.set_device`), or export the variable yourself.
 """
+import os
+
 import numpy as np
 
 from . import engine
@@ -282,7 +284,15 @@ class SuperCircuit:
             import torch
 
             torch.cuda.synchronize()  # witness uploads / open-time packing ran on the stream the sessions were opened on
-            self._streams = {k: torch.cuda.Stream() for k in self.sessions}
+            # ZK_SUPER_PRIO=1 (experiment, round 5): the four small circuits (Exp, Tx, Copy, Bytecode: 1 k - 131 k rows, 12 - 50 us alone) on
+            # high-priority streams, so that they are not parked behind the State launch's wavefronts until it drains
+            prio = os.environ.get("ZK_SUPER_PRIO") == "1"
+            self._streams = {k: (torch.cuda.Stream(priority=-1) if prio and k in ("exp", "tx", "copy", "bytecode") else torch.cuda.Stream())
+                             for k in self.sessions}
+            order = os.environ.get("ZK_SUPER_ORDER")  # experiment: launch order of the sessions, e.g. "exp,tx,copy,bytecode,evm,state"
+            if order:
+                keys = [k for k in order.split(",") if k in self.sessions] + [k for k in self.sessions if k not in order.split(",")]
+                self.sessions = {k: self.sessions[k] for k in keys}
             for k, s in self.sessions.items():
                 s.set_stream(self._streams[k])
 
