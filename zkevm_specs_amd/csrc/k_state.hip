@@ -116,7 +116,10 @@ void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTal
         launch_group<4>(st, a, status, tally);
         return;
     }
-    const int lds = (block / 64) * ST_DMA_WAVE_BYTES;
+    // ZK_STATE_LDS_PAD=<bytes> (experiment): extra dynamic LDS per block — 17408 makes a block 81 KB, i.e. ONE block (one wavefront per
+    // SIMD, 249 VGPRs) per CU, which leaves registers and LDS for another circuit's wavefronts beside it
+    static const int pad = [] { const char* e = getenv("ZK_STATE_LDS_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 65536 ? 65536 : v); }();
+    const int lds = (block / 64) * ST_DMA_WAVE_BYTES + pad;
     {  // > 64 KiB of dynamic LDS has to be asked for, once per device
         static std::mutex m;
         static bool asked[64] = {false};

@@ -280,25 +280,26 @@ class SuperCircuit:
         # one HIP stream per circuit: the kernels are independent and bound by different things (the State kernel streams
         # HBM, the EVM kernel is latency / issue bound), so their passes overlap on the device
         self._streams = None
+        self._launch_order = None  # results / first-failure reporting keep the sessions' own order whatever the launch order is
         if hasattr(ops, "is_cuda"):
             import torch
 
             torch.cuda.synchronize()  # witness uploads / open-time packing ran on the stream the sessions were opened on
-            # ZK_SUPER_PRIO=1 (experiment, round 5): the four small circuits (Exp, Tx, Copy, Bytecode: 1 k - 131 k rows, 12 - 50 us alone) on
-            # high-priority streams, so that they are not parked behind the State launch's wavefronts until it drains
-            prio = os.environ.get("ZK_SUPER_PRIO") == "1"
+            # The four small circuits (Exp, Tx, Copy, Bytecode: 1 k - 131 k rows, 12 - 50 us alone) run on high-priority streams and are
+            # launched first, then the EVM chain, the State launch last: parked behind the State kernel's wavefronts they used to take
+            # 100 - 240 us each and stretch the pass (round 5, four alternating runs: 0.354 -> 0.331 ms; priority alone 0.341, order alone
+            # no gain).  ZK_SUPER_PRIO=0 / ZK_SUPER_ORDER=<names> restore / change it for A/B runs.
+            prio = os.environ.get("ZK_SUPER_PRIO", "1") == "1"
             self._streams = {k: (torch.cuda.Stream(priority=-1) if prio and k in ("exp", "tx", "copy", "bytecode") else torch.cuda.Stream())
                              for k in self.sessions}
-            order = os.environ.get("ZK_SUPER_ORDER")  # experiment: launch order of the sessions, e.g. "exp,tx,copy,bytecode,evm,state"
-            if order:
-                keys = [k for k in order.split(",") if k in self.sessions] + [k for k in self.sessions if k not in order.split(",")]
-                self.sessions = {k: self.sessions[k] for k in keys}
+            order = os.environ.get("ZK_SUPER_ORDER", "exp,tx,copy,bytecode,evm,state" if prio else "").split(",")
+            self._launch_order = [k for k in order if k in self.sessions] + [k for k in self.sessions if k not in order]
             for k, s in self.sessions.items():
                 s.set_stream(self._streams[k])
 
     def launch(self):
-        for s in self.sessions.values():
-            s.launch()
+        for k in (self._launch_order or self.sessions):
+            self.sessions[k].launch()
 
     def collect(self):
         results = {k: s.collect() for k, s in self.sessions.items()}
