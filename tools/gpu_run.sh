@@ -4,6 +4,7 @@
 #   bench      the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5; checks that the LAST stdout line parses
 #   prof-evm   rocprofv3 passes of the one-shot headline           prof-session / prof-state / prof-tx / prof-super: the other configurations
 #   rows       tools/bench_row_kernels.py                          refsuite  the reference's own tests through the HIP library
+#   fuzz       differential fuzz (State, EVM pairs, EVM traces) against the oracle
 #   ab:<A=x,B=y> A/B of environment switches on the one-shot headline (default, each switch alone, all together; twice)
 #   cmd:<...>  any shell command (quote it)
 # Everything lands in gpurun_out/<tag>/ (merged back by gpurun); copy what is to be judged into profiles/.
@@ -33,6 +34,12 @@ PY
     prof-super)   tools/profile_bench.sh super_2p20 --workload super --steps 10 --warmup 3 > $out/prof_super.log 2>&1; tail -2 $out/prof_super.log | cut -c1-300 ;;
     rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
     refsuite) timeout 900 python tools/run_reference_suite.py --backend hip --ref-root oracle/_ref/reference --out $out/reference_suite_hip.json > $out/reference_suite_hip.log 2>&1; tail -1 $out/reference_suite_hip.log ;;
+    fuzz)     # differential fuzz of the HIP path against the oracle (per-row / per-pair status words bit for bit)
+              { echo "== python tests/gpu_fuzz_state.py 600 31"; timeout 900 python tests/gpu_fuzz_state.py 600 31 2>&1 | tail -2
+                echo "== ZK_STATE_DMA=0 python tests/gpu_fuzz_state.py 60 9"; ZK_STATE_DMA=0 timeout 600 python tests/gpu_fuzz_state.py 60 9 2>&1 | tail -2
+                echo "== python tests/gpu_fuzz_copy.py 150 7"; timeout 900 python tests/gpu_fuzz_copy.py 150 7 2>&1 | tail -3
+                echo "== python tests/gpu_fuzz_evm.py 40 29"; timeout 900 python tests/gpu_fuzz_evm.py 40 29 2>&1 | tail -2
+                echo "== python tests/gpu_fuzz_evm_trace.py"; timeout 900 python tests/gpu_fuzz_evm_trace.py 2>&1 | tail -3; } > $out/fuzz.txt 2>&1; grep -v amdgpu.ids $out/fuzz.txt | cut -c1-300 ;;
     ab:*)     # A/B of environment switches on the one-shot headline: `ab:ZK_P1_TAIL=0,ZK_PRECLEAN=0` runs the default, each switch, and all of them
               sw="${stage#ab:}"; IFS=',' read -ra S <<< "$sw"
               q="--no-other-configs --no-cpu-baseline --no-live-pmc --no-session-leg --no-batch-leg --no-cold-leg --no-fresh-leg --steps 50 --warmup 5"
