@@ -727,6 +727,10 @@ def compact_line(out, full_path=None):
 def write_full(out):
     """the full record next to the script (and into gpurun_out/ when that exists, so that it comes back from a lease)"""
     name = "bench_full.json"
+    if os.environ.get("ZK_BENCH_FULL"):  # a child run of another configuration (tools/bench_legs.py own_process_config): its record goes where the parent reads it
+        with open(os.environ["ZK_BENCH_FULL"], "w") as f:
+            json.dump(out, f)
+        return os.environ["ZK_BENCH_FULL"]
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         try:
             if os.path.isdir(d):

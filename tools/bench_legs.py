@@ -186,6 +186,41 @@ def config0_bytecode(args):
     return blk
 
 
+def own_process_config(name, log_rows, steps, warmup, args, with_cpu_baseline):
+    """One other configuration measured in a process of its own (`python bench.py --workload <name> ...` as a child, its full record
+    read back): the block pass and the Tx / Sig pass are several concurrent streams, and inside the default line's process — where
+    the batch entry's pipeline streams, side streams and the earlier configurations' streams exist by then — they share hardware
+    queues (round 5: block pass 0.352 ms in-process against 0.331 ms alone, Tx + Sig at 2^11 1.48 against 1.18 ms).  None on any
+    failure: the caller then measures in-process."""
+    import subprocess
+    import tempfile
+
+    fd, path = tempfile.mkstemp(prefix="zk_bench_child_", suffix=".json", dir="/tmp")
+    os.close(fd)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--log-rows", str(log_rows), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-other-configs", "--no-cold-leg", "--no-fresh-leg"] + ([] if with_cpu_baseline else ["--no-cpu-baseline"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        t0 = time.perf_counter()
+        subprocess.run(cmd, env=dict(env, ZK_BENCH_FULL=path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        wall = time.perf_counter() - t0
+        d = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    cfg = dict(d.get("config") or {})
+    blk = {"workload": cfg.pop("workload", name), "value": d["value"], "unit": "txs/s" if name == "tx" else "rows/s", "steps": d["steps"], "warmup": d["warmup"],
+           "pre_ramp_steps": d.get("pre_ramp_steps"), "ms_per_step": d["ms_per_step"], "units_per_pass": d["value"] * d["ms_per_step"] / 1e3,
+           "process": "own process: " + " ".join(cmd[1:]), "process_wall_s": wall, "roofline": d["roofline"], "config": cfg}
+    if d.get("cpu_baseline"):
+        blk["cpu_baseline"] = d["cpu_baseline"]
+    return blk
+
+
 def other_configs(core, ctx, args):
     """BASELINE configs[0], [1], [3], [4] on the driver's clock, after the headline: each one timed like the headline (barrier +
     synchronize around K passes), a reduced K so that they add well under a minute of GPU time (witness synthesis is
@@ -196,6 +231,12 @@ def other_configs(core, ctx, args):
     # tx 2^11: ONE GPU's shard of BASELINE configs[3] at 8 GPUs (2^14 txs over 8 ranks) — the ECDSA launch is a dependent chain per
     # signature, so this is what every rank of the 8-GPU run takes per pass, and why that configuration's strong scaling is flat
     for name, log_rows, steps, warmup in (("state", 16, 50, 5), ("state", 20, 20, 3), ("tx", 14, 10, 2), ("tx", 11, 10, 2), ("super", 20, 20, 3)):
+        if name in ("tx", "super") and os.environ.get("ZK_BENCH_INPROCESS") != "1":  # the multi-stream passes: a process of their own
+            want_cpu = not args.no_cpu_baseline and not (name == "tx" and log_rows == 11)
+            blk = own_process_config(name, log_rows, steps, warmup, args, want_cpu)
+            if blk is not None:
+                out[f"{name}_2p{log_rows}"] = blk
+                continue
         t_build = time.perf_counter()
         w = core.BUILDERS[name](ctx, log_rows, False)
         t_build = time.perf_counter() - t_build
