@@ -72,7 +72,7 @@ ZK_HD void bca_fill_rpow(const Fr& r, u64* out) {  // single lane, once per sess
 // product to leave Montgomery form; a wider value (malformed witnesses only) sends the whole range down the reference's own
 // recurrence `acc = acc * r + value`.  Round 4 ran that recurrence always: 64 dependent load + Montgomery-product round trips per
 // chunk lane, 0.32 ms for a block's 131,072 rows whatever the occupancy.
-ZK_HD Fr bca_dot(const BcaArgs& a, const BcaChunk& ch, u32 j1) {
+ZK_HD Fr bca_dot(const BcaArgs& a, const BcaChunk& ch, u32 j1, uint8_t* sizes = nullptr) {  // sizes: optional, push size of every byte row [skip + j]
     const u32 skip = ch.first ? 1u : 0u;  // chunk row t = skip + j
     u32 acc[10];
 #pragma unroll
@@ -82,6 +82,7 @@ ZK_HD Fr bca_dot(const BcaArgs& a, const BcaChunk& ch, u32 j1) {
     for (u32 j = 0; j < j1; j++) {
         const Fr v = bca_in_cell(a, (u64)ch.start + skip + j, 5);
         wide |= v.v[1] | v.v[2] | v.v[3] | v.v[4] | v.v[5] | v.v[6] | v.v[7];
+        if (sizes) sizes[skip + j] = (uint8_t)bca_push_size(v);  // from the same batch of loads (a loop of its own was 64 serial round trips)
         const Fr pw = fr_load(a.rpow + 4 * (u64)(j1 - 1u - j));
         u64 c = 0;
 #pragma unroll
@@ -120,8 +121,8 @@ ZK_HD void bca_chunk(const BcaArgs& a, u64 c) {
     const BcaChunk ch = a.chunks[c];
     const u32 m = ch.count - (ch.first ? 1u : 0u);
     uint8_t size[BCA_CHUNK];
-    for (u32 t = 0; t < ch.count; t++) size[t] = (ch.first && t == 0) ? (uint8_t)0 : (uint8_t)bca_push_size(bca_in_cell(a, (u64)ch.start + t, 5));
-    bca_store(a.chunk_acc + 4 * c, bca_dot(a, ch, m));
+    size[0] = 0;  // the Header row of a bytecode's first chunk; overwritten otherwise
+    bca_store(a.chunk_acc + 4 * c, bca_dot(a, ch, m, size));
     a.chunk_m[c] = m;
     // zero_out[p]: the counter after the chunk when position p is entered with 0
     uint8_t zero_out[BCA_CHUNK + 1];
