@@ -492,8 +492,8 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
     for (int k = 0; k < 4; k++) out[4 * i + k] = (u64)r.v[2 * k] | ((u64)r.v[2 * k + 1] << 32);
 }
 
-// ZK_POLL_RESULT=1 (experiment, round 5): the 128-byte result block travels to the host by a one-wavefront kernel at the end of the
-// pass — 32 lanes store its 32 words into the session's page-locked (device-mapped, coherent) block, a system-scope fence, then the
+// The 128-byte result block travels to the host by a one-wavefront kernel at the end of the pass (ZK_POLL_RESULT=0: by a copy
+// dispatch + hipStreamSynchronize, as until round 4) — 32 lanes store its 32 words into the session's page-locked (device-mapped, coherent) block, a system-scope fence, then the
 // sequence number into the word behind it — and zk_collect polls that word instead of waiting for the runtime's completion signal
 // of a copy dispatch.  (Not the in-kernel publication round 4 measured: nothing of the evaluation launches changes.)
 __global__ __launch_bounds__(64) void evm_publish_kernel(const u32* d, u32* h, u32 seq) {
@@ -2121,10 +2121,11 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     u32 gs[EVM_N_GROUPS + 1] = {0};
     const bool read_ranges = s->kind == SESSION_EVM && s->evm.perm && !s->evm_ranges_known && s->launches > 0;
     if (s->kind == SESSION_EVM && s->d_result && s->h_result) {
-        // one copy of the 128-byte result block (deferred count, both tallies, lane ranges) into page-locked memory, one wait.
-        // (Having the pass's last block write the block to the host itself — system-scope stores + fence from inside the cold
-        // launch — was measured: the launch waits for the PCIe writes, pass 76 -> 90 us, step 0.179 -> 0.187 ms.  Rejected.)
-        static const bool poll = [] { const char* e = getenv("ZK_POLL_RESULT"); return e && e[0] == '1'; }();
+        // the 128-byte result block (deferred count, both tallies, lane ranges) in page-locked memory: published by evm_publish_kernel and
+        // polled (default), or one copy dispatch + one wait.  (Having the pass's last block write the block to the host itself — system-
+        // scope stores + fence from inside the cold launch — was measured in round 4: pass 76 -> 90 us.  The separate one-wavefront
+        // kernel costs the evaluation launches nothing and saves the runtime's completion-signal path: step 0.179 -> 0.174 ms.)
+        static const bool poll = [] { const char* e = getenv("ZK_POLL_RESULT"); return !(e && e[0] == '0'); }();  // default on (round 5: step 0.179 -> 0.174 ms)
         bool polled = false;
         if (poll) {
             static_assert(sizeof(EvmResultBlock) == 128 && ZK_PINNED_BYTES >= 132, "flag word behind the result block");
