@@ -471,14 +471,14 @@ def timed_oneshots(ctx, w, steps, warmup):
     t0 = time.perf_counter()
     # the per-step read of the device spans is one C call into preallocated doubles (the timed region holds as little of the
     # measurement itself as possible: engine.last_timing allocates three ctypes objects per call, ~2 us of Python per step)
-    tm = (ctypes.c_double * 3)()
-    p_tm = [ctypes.byref(tm, 8 * k) for k in range(3)]
+    tm = [ctypes.c_double(), ctypes.c_double(), ctypes.c_double()]
+    p_tm = [ctypes.byref(x) for x in tm]
     read_timing = lib.zk_last_timing
     order = [shots[(warmup + i) % len(shots)] for i in range(steps)]
     for shot in order:
         fails += shot().fail_count
         read_timing(p_tm[0], p_tm[1], p_tm[2])
-        spans[0] += tm[0]; spans[1] += tm[1]; spans[2] += tm[2]
+        spans[0] += tm[0].value; spans[1] += tm[1].value; spans[2] += tm[2].value
     ctx.barrier()
     dt = time.perf_counter() - t0
     res = shots[(warmup + steps - 1) % len(shots)].result()
