@@ -496,29 +496,11 @@ __global__ void fr_op_kernel(int op, const u64* a, const u64* b, u64* out, u64 n
 // dispatch + hipStreamSynchronize, as until round 4) — 32 lanes store its 32 words into the session's page-locked (device-mapped, coherent) block, a system-scope fence, then the
 // sequence number into the word behind it — and zk_collect polls that word instead of waiting for the runtime's completion signal
 // of a copy dispatch.  (Not the in-kernel publication round 4 measured: nothing of the evaluation launches changes.)
-__global__ __launch_bounds__(256) void evm_publish_kernel(u32* d, u32* h, u32 seq, uint4* ff, u64 n_ff16, uint4* zero, u64 n_zero16) {
-    // Block 0, first wavefront: the result block to the host.  With refill ranges (one-shot verifications: nothing reads the session's
-    // tables after this kernel) the OTHER blocks bring the session's two fill regions back to their open-time state — 0xFF.. / 0 —
-    // unless the pass left deferred pairs (then the general build still needs the tables: the host sees the count and nothing is
-    // refilled).  Block 0 clears the zero region's first 256 bytes itself, after it has read them.
-    const bool refill = n_ff16 != 0;
-    if (blockIdx.x == 0) {
-        const u32 i = threadIdx.x;
-        if (i < 64u) {
-            const u32 mine = i < 32u ? d[i] : 0u;
-            const u32 n_def = ((const EvmDyn*)d)->n_deferred;
-            if (i < 32u) __hip_atomic_store(&h[i], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();  // one wavefront: every lane's store has left before the flag does
-            if (i == 0u) __hip_atomic_store(&h[32], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (refill && n_def == 0u) d[i] = 0u;  // the leading 256 bytes (64 words), read above by this very wavefront
-        }
-        return;
-    }
-    if (!refill || ((const EvmDyn*)d)->n_deferred != 0u) return;  // (0 here means it was 0 before block 0 cleared it, too)
-    const u64 stride = (u64)(gridDim.x - 1u) * blockDim.x;
-    const uint4 F = make_uint4(~0u, ~0u, ~0u, ~0u), Z = make_uint4(0u, 0u, 0u, 0u);
-    for (u64 k = (u64)(blockIdx.x - 1u) * blockDim.x + threadIdx.x; k < n_ff16; k += stride) ff[k] = F;
-    for (u64 k = 16u + (u64)(blockIdx.x - 1u) * blockDim.x + threadIdx.x; k < n_zero16; k += stride) zero[k] = Z;  // from byte 256 on
+__global__ __launch_bounds__(64) void evm_publish_kernel(const u32* d, u32* h, u32 seq) {
+    const u32 i = threadIdx.x;
+    if (i < 32u) __hip_atomic_store(&h[i], d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();  // one wavefront: every lane's store has left before the flag does
+    if (i == 0u) __hip_atomic_store(&h[32], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ---------------------------------------------------------------------------------------
 // sessions
@@ -583,18 +565,6 @@ struct zk_session {
     // back with ONE copy into page-locked host memory (three copies into pageable memory cost three blocking round trips)
     void* d_result = nullptr;
     void* h_result = nullptr;
-    // EVM: the session's 0xFF region and zero region (evm_open_fill_kernel's two ranges) — not in `owned`.  A one-shot verification lets
-    // its publish kernel refill them behind the result (its other blocks; ZK_REFILL, default on) and zk_close parks the pair for the
-    // next open of the same shape on the same stream, which then starts with its first build launch instead of a fill launch.
-    void* fill_ff = nullptr;
-    void* fill_zero = nullptr;
-    int fill_ff_cls = 0, fill_zero_cls = 0;
-    u64 fill_n_ff16 = 0, fill_n_zero16 = 0;
-    bool refill_at_collect = false;  // set by the one-shot entries: nothing reads the session's tables after its collect
-    bool refilled = false;           // the publish kernel's refill blocks ran (the device found no deferred pairs)
-    hipEvent_t ev_clean0 = nullptr, ev_clean1 = nullptr;  // ride on the launch that refilled THIS session's regions (its time is this session's device work)
-    hipEvent_t ev_refill0 = nullptr, ev_refill1 = nullptr;  // ride on this session's own publish + refill launch (travel with the parked pair)
-    bool refill_launched = false;
     u32 publish_seq = 0;        // ZK_POLL_RESULT: sequence number of the last evm_publish_kernel (the flag word behind the block)
     bool stream_drained = false;  // the host has seen the stream's last kernel finish without a hipStreamSynchronize (zk_close may skip its own)
 };
@@ -627,16 +597,7 @@ struct DevArena {
     std::vector<hipEvent_t> events;
     std::vector<void*> pinned;  // ZK_PINNED_BYTES-byte blocks of page-locked host memory (result read-backs)
     size_t cached_bytes = 0;
-    struct CleanPair {  // an EVM session's two fill regions, refilled on `stream` by the publish kernel of the session that used them last
-        void* ff; void* zero;
-        int ff_cls, zero_cls;
-        u64 n_ff16, n_zero16;
-        hipStream_t stream;
-        hipEvent_t e0, e1;  // ride on that launch (may be null)
-    };
-    std::vector<CleanPair> clean;
 };
-#define ZK_ARENA_MAX_CLEAN 8
 static DevArena g_arena[ZK_MAX_DEVICES];
 static size_t arena_limit() {
     static const size_t lim = [] { const char* e = getenv("ZK_ARENA_MAX_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30); }();
@@ -645,10 +606,6 @@ static size_t arena_limit() {
 static bool arena_off() {
     static const bool off = [] { const char* e = getenv("ZK_NO_ARENA"); return e && e[0] == '1'; }();
     return off;
-}
-static bool arena_refill() {
-    static const bool on = [] { const char* e = getenv("ZK_REFILL"); return !(e && e[0] == '0'); }();
-    return on && !arena_off();
 }
 static int arena_class(size_t bytes) {
     int c = 8;  // 256 B: hipMalloc's own granularity
@@ -714,7 +671,7 @@ static void arena_release_all() {
     for (int d = 0; d < ZK_MAX_DEVICES; d++) {
         DevArena& A = g_arena[d];
         std::lock_guard<std::mutex> lock(A.m);
-        bool any = !A.events.empty() || !A.pinned.empty() || !A.clean.empty();
+        bool any = !A.events.empty() || !A.pinned.empty();
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) any = any || !A.free_[c].empty();
         if (!any || hipSetDevice(d) != hipSuccess) continue;
         for (int c = 0; c < ZK_ARENA_CLASSES; c++) {
@@ -725,13 +682,6 @@ static void arena_release_all() {
         A.events.clear();
         for (void* h : A.pinned) (void)hipHostFree(h);
         A.pinned.clear();
-        for (DevArena::CleanPair& c : A.clean) {
-            (void)hipFree(c.ff);
-            (void)hipFree(c.zero);
-            if (c.e0) (void)hipEventDestroy(c.e0);
-            if (c.e1) (void)hipEventDestroy(c.e1);
-        }
-        A.clean.clear();
         A.cached_bytes = 0;
     }
 }
@@ -790,21 +740,6 @@ static int session_common_init(zk_session* s) {
     return 0;
 }
 
-// a parked pair of fill regions with exactly these sizes (16-byte units) that was refilled on THIS stream (a launch on it is ordered
-// behind the refill without an event), or false
-static bool arena_take_clean(int device, hipStream_t stream, u64 n_ff16, u64 n_zero16, DevArena::CleanPair* out) {
-    if (!arena_refill()) return false;
-    DevArena& A = g_arena[device];
-    std::lock_guard<std::mutex> lock(A.m);
-    for (size_t k = A.clean.size(); k-- > 0;)
-        if (A.clean[k].n_ff16 == n_ff16 && A.clean[k].n_zero16 == n_zero16 && A.clean[k].stream == stream) {
-            *out = A.clean[k];
-            A.clean.erase(A.clean.begin() + (long)k);
-            return true;
-        }
-    return false;
-}
-
 extern "C" int zk_close(zk_session* s) {
     if (!s) return 0;
     (void)hipSetDevice(s->device);
@@ -812,29 +747,9 @@ extern "C" int zk_close(zk_session* s) {
     // last kernel finish through the polled result block and nothing was enqueued since)
     if (!s->stream_drained) (void)hipStreamSynchronize(s->stream);
     for (size_t k = 0; k < s->owned.size(); k++) arena_give(s->device, s->owned[k], s->owned_class[k]);
-    if (s->fill_ff && s->fill_zero) {
-        DevArena& A = g_arena[s->device];
-        bool parked = false;
-        if (s->refilled) {  // this session's publish kernel is refilling them on s->stream: a clean pair for the next open on that stream
-            std::lock_guard<std::mutex> lock(A.m);
-            if (A.clean.size() < ZK_ARENA_MAX_CLEAN) {
-                A.clean.push_back({s->fill_ff, s->fill_zero, s->fill_ff_cls, s->fill_zero_cls, s->fill_n_ff16, s->fill_n_zero16, s->stream, s->ev_refill0, s->ev_refill1});
-                s->ev_refill0 = s->ev_refill1 = nullptr;  // travel with the pair
-                parked = true;
-            }
-        }
-        if (!parked) {
-            if (s->refilled) (void)hipStreamSynchronize(s->stream);  // (list full) the refill blocks must be done before anybody else gets the buffers
-            arena_give(s->device, s->fill_ff, s->fill_ff_cls);
-            arena_give(s->device, s->fill_zero, s->fill_zero_cls);
-        }
-        s->fill_ff = s->fill_zero = nullptr;
-    }
     {
         DevArena& A = g_arena[s->device];
         std::lock_guard<std::mutex> lock(A.m);
-        for (hipEvent_t e : {s->ev_clean0, s->ev_clean1, s->ev_refill0, s->ev_refill1})
-            if (e) A.events.push_back(e);
         for (hipEvent_t e : s->ev) A.events.push_back(e);
         if (s->ev_open0) A.events.push_back(s->ev_open0);
         if (s->ev_open1) A.events.push_back(s->ev_open1);
@@ -941,7 +856,6 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
     s->side_stream = (opts & ZK_OPT_SIDE_STREAM) != 0;
     int rc = 0;
     const void* p = nullptr;
-    bool open_first_pending = false;
     EvmArgs& E = s->evm;
     if ((rc = stage(s, t->steps, (size_t)t->n_steps * STEP_NCELLS * 32, dev, &p))) goto fail;
     E.steps = (const u64*)p;
@@ -977,31 +891,19 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         for (int k = 0; k < EVM_OPEN_TABLES; k++) { caps[k] = index_cap(small[k]->n); n_ff += caps[k]; }
         const u32 cap_rw = index_cap(E.rw.n), cap_big = want_dir ? index_cap(t->n_bytecode) : 0u;
         n_ff += (size_t)cap_rw + 2 * (size_t)cap_big + (want_dir ? DIRB_SMALL_SLOTS : 0u);
-        // ---- one zero region: EvmDyn, the two histograms, the per-pair status, the directory's last / runs / bad -------------
-        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (((size_t)s->n * sizeof(u32)) + 15) & ~(size_t)15;
-        const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
-        // both regions come as a pair: refilled by the publish kernel of the one-shot verification that used them last on this stream
-        // (arena clean list), or fresh + one fill launch
         u32* ff = nullptr;
-        char* zero = nullptr;
-        DevArena::CleanPair cp;
-        const bool precleaned = arena_take_clean(s->device, s->stream, n_ff / 4, zero_bytes / 16, &cp);
-        if (precleaned) {
-            ff = (u32*)cp.ff; zero = (char*)cp.zero;
-            s->fill_ff_cls = cp.ff_cls; s->fill_zero_cls = cp.zero_cls;
-            s->ev_clean0 = cp.e0; s->ev_clean1 = cp.e1;
-        } else {
-            if ((rc = arena_take(s->device, n_ff * sizeof(u32), (void**)&ff, &s->fill_ff_cls))) goto fail;
-            if ((rc = arena_take(s->device, zero_bytes, (void**)&zero, &s->fill_zero_cls))) { arena_give(s->device, ff, s->fill_ff_cls); goto fail; }
-        }
-        s->fill_ff = ff; s->fill_zero = zero;  // owned from here on (zk_close gives them back or parks them)
-        s->fill_n_ff16 = n_ff / 4; s->fill_n_zero16 = zero_bytes / 16;
+        if ((rc = dev_alloc(s, (void**)&ff, n_ff * sizeof(u32)))) goto fail;
         u32* cur = ff;
         for (int k = 0; k < EVM_OPEN_TABLES; k++) { small[k]->slots = cur; small[k]->mask = caps[k] - 1; cur += caps[k]; }
         E.rw.slots = cur; E.rw.mask = cap_rw - 1; cur += cap_rw;
         u32* const dir_rep = cur; cur += cap_big;
         u32* const dir_first = cur; cur += cap_big;
         u32* const small_slots = cur;
+        // ---- one zero region: EvmDyn, the two histograms, the per-pair status, the directory's last / runs / bad -------------
+        const size_t dyn_bytes = 256, hist_bytes = EVM_N_BINS * sizeof(u32), status_bytes = (((size_t)s->n * sizeof(u32)) + 15) & ~(size_t)15;
+        const size_t zero_bytes = dyn_bytes + 2 * hist_bytes + status_bytes + 3 * (size_t)cap_big * 4;
+        char* zero = nullptr;
+        if ((rc = dev_alloc(s, (void**)&zero, zero_bytes))) goto fail;
         EvmResultBlock* const rb = (EvmResultBlock*)zero;  // the first 128 of the region's 256 leading bytes
         EvmDyn* dyn = &rb->dyn;
         s->d_result = rb;
@@ -1023,10 +925,8 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             // the open's device span is measured by two events that ride on its first and last dispatch (no event packets of their
             // own between the kernels): zk_session_timing / zk_last_timing
             if (arena_event(s->device, &s->ev_open0) || arena_event(s->device, &s->ev_open1)) s->ev_open0 = s->ev_open1 = nullptr;
-            if (!precleaned)
-                hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, s->ev_open0, nullptr, 0, (uint4*)ff,
-                                      (u64)(n_ff / 4), (uint4*)zero, (u64)(zero_bytes / 16));
-            open_first_pending = precleaned;  // no fill launch: the first build launch carries the open's start event
+            hipExtLaunchKernelGGL(evm_open_fill_kernel, dim3(fill_grid ? fill_grid : 1u), dim3(256), 0, s->stream, s->ev_open0, nullptr, 0, (uint4*)ff,
+                                  (u64)(n_ff / 4), (uint4*)zero, (u64)(zero_bytes / 16));
         }
         E.rw_dense = 0;
         E.rw_base = 0;
@@ -1124,7 +1024,7 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
 #ifdef ZK_DIAG_P1
             if (o.diag_skip) phase2 = false;  // its inputs are missing
 #endif
-            hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, open_first_pending ? s->ev_open0 : nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
+            hipExtLaunchKernelGGL(evm_open_phase1_kernel, dim3(grid1 ? grid1 : 1u), dim3(256), 0, s->stream, nullptr, phase2 ? nullptr : s->ev_open1, 0, o);
             if (phase2)
                 hipExtLaunchKernelGGL(evm_open_phase2_kernel, dim3(scatter_blocks + dir_blocks + rw_blocks), dim3(EVM_OPEN_P2_BLOCK), 0, s->stream, nullptr,
                                       s->ev_open1, 0, o, scatter_blocks, dir_blocks, generic ? 1u : 0u);
@@ -1156,7 +1056,6 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
     rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
     const auto h2 = std::chrono::steady_clock::now();
-    s->refill_at_collect = !(status_out && !dev);  // nothing reads the session's tables after the collect (a host status read-back would)
     if (!rc) rc = zk_collect(s, result);
     const auto h3 = std::chrono::steady_clock::now();
     if (!rc) {
@@ -1198,7 +1097,6 @@ extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, ui
     for (uint64_t i = 0; i < n + 2 && !rc; i++) {
         const int slot = (int)(i & 1u);
         if (pend[slot]) {  // witness i - 2
-            pend[slot]->refill_at_collect = true;
             rc = zk_collect(pend[slot], &results[i - 2]);
             zk_close(pend[slot]);
             pend[slot] = nullptr;
@@ -2236,23 +2134,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
             if (hipHostGetDevicePointer(&hd, s->h_result, 0) == hipSuccess && hd) {
                 const u32 seq = ++s->publish_seq ? s->publish_seq : ++s->publish_seq;  // never 0
                 __atomic_store_n(&hw[32], 0u, __ATOMIC_RELEASE);
-                const bool refill = s->refill_at_collect && arena_refill() && s->fill_ff && s->fill_zero && (void*)s->d_result == s->fill_zero;
-                if (refill) {
-                    // the refill's time belongs to this verification's device work: two events ride on the launch, the session that takes
-                    // the pair adds their span to its own (zk_last_timing)
-                    hipEvent_t c0 = nullptr, c1 = nullptr;
-                    if (arena_event(s->device, &c0) || arena_event(s->device, &c1)) c0 = c1 = nullptr;
-                    const u64 n16 = s->fill_n_ff16 + s->fill_n_zero16;
-                    const u32 blocks = (u32)(n16 / 256 < 2048 ? (n16 + 255) / 256 : 2048);
-                    hipExtLaunchKernelGGL(evm_publish_kernel, dim3(1u + (blocks ? blocks : 1u)), dim3(256), 0, s->stream, c0, c1, 0, (u32*)s->d_result, (u32*)hd, seq,
-                                          (uint4*)s->fill_ff, s->fill_n_ff16, (uint4*)s->fill_zero, s->fill_n_zero16);
-                    s->ev_refill0 = c0; s->ev_refill1 = c1;
-                    s->refill_launched = true;
-                } else {
-                    s->refill_launched = false;
-                    hipLaunchKernelGGL(evm_publish_kernel, dim3(1), dim3(256), 0, s->stream, (u32*)s->d_result, (u32*)hd, seq, (uint4*)nullptr, (u64)0, (uint4*)nullptr, (u64)0);
-                }
-                s->refilled = false;
+                hipLaunchKernelGGL(evm_publish_kernel, dim3(1), dim3(64), 0, s->stream, (const u32*)s->d_result, (u32*)hd, seq);
                 if (hipGetLastError() == hipSuccess) {
                     const auto t0 = std::chrono::steady_clock::now();
                     u64 spins = 0;
@@ -2260,19 +2142,12 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
                         if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;  // never expected: fall back to the runtime's wait
                     }
                     polled = __atomic_load_n(&hw[32], __ATOMIC_ACQUIRE) == seq;
-                    if (!polled) {  // timed out: wait the runtime's way; the kernel has then either published or never ran
-                        HIP_TRY(hipStreamSynchronize(s->stream));
-                        polled = __atomic_load_n(&hw[32], __ATOMIC_ACQUIRE) == seq;
-                    }
                 }
             }
             (void)hipGetLastError();
         }
         if (polled) {
-            // the publish block is done; with refill ranges the kernel's other blocks may still be writing the session's two fill
-            // regions — nothing else, and nobody but a later launch on this stream will look at those
-            s->stream_drained = true;
-            s->refilled = s->refill_launched && ((const EvmResultBlock*)s->h_result)->dyn.n_deferred == 0u;
+            s->stream_drained = true;  // the publish kernel is the stream's last command and its stores are done
         } else {
             HIP_TRY(hipMemcpyAsync(s->h_result, s->d_result, sizeof(EvmResultBlock), hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
@@ -2344,11 +2219,6 @@ static void session_timing(zk_session* s, double pass_ms, double* open_ms, doubl
     float f = 0;
     if (hipEventElapsedTime(&f, s->ev_open0, s->ev_open1) == hipSuccess) *open_ms = f;
     if (pass_ms > 0 && s->ev.size() >= 2 && hipEventElapsedTime(&f, s->ev_open0, s->ev[1]) == hipSuccess) *span_ms = f;
-    // regions refilled by the previous verification's publish kernel: that launch's duration is this one's device work all the same
-    if (s->ev_clean0 && s->ev_clean1 && hipEventElapsedTime(&f, s->ev_clean0, s->ev_clean1) == hipSuccess) {
-        if (*open_ms >= 0) *open_ms += f;
-        if (*span_ms >= 0) *span_ms += f;
-    }
     (void)hipGetLastError();
 }
 extern "C" int zk_session_timing(zk_session* s, double* open_ms, double* span_ms) {
