@@ -290,8 +290,8 @@ class SuperCircuit:
             # 100 - 240 us each and stretch the pass (round 5, four alternating runs: 0.354 -> 0.331 ms; priority alone 0.341, order alone
             # no gain).  ZK_SUPER_PRIO=0 / ZK_SUPER_ORDER=<names> restore / change it for A/B runs.
             prio = os.environ.get("ZK_SUPER_PRIO", "1") == "1"
-            self._streams = {k: (torch.cuda.Stream(priority=-1) if prio and k in ("exp", "tx", "copy", "bytecode") else torch.cuda.Stream())
-                             for k in self.sessions}
+            hi = tuple(os.environ.get("ZK_SUPER_PRIO_SET", "exp,tx,copy,bytecode").split(","))  # which sessions get the high-priority streams
+            self._streams = {k: (torch.cuda.Stream(priority=-1) if prio and k in hi else torch.cuda.Stream()) for k in self.sessions}
             order = os.environ.get("ZK_SUPER_ORDER", "exp,tx,copy,bytecode,evm,state" if prio else "").split(",")
             self._launch_order = [k for k in order if k in self.sessions] + [k for k in self.sessions if k not in order]
             for k, s in self.sessions.items():
