@@ -35,9 +35,9 @@ PY
     rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
     refsuite) timeout 900 python tools/run_reference_suite.py --backend hip --ref-root oracle/_ref/reference --out $out/reference_suite_hip.json > $out/reference_suite_hip.log 2>&1; tail -1 $out/reference_suite_hip.log ;;
     fuzz)     # differential fuzz of the HIP path against the oracle (per-row / per-pair status words bit for bit)
-              { echo "== python tests/gpu_fuzz_state.py 600 31"; timeout 900 python tests/gpu_fuzz_state.py 600 31 2>&1 | tail -2
+              { echo "== python tests/gpu_fuzz_state.py ${FUZZ_STATE:-600} 31"; timeout 900 python tests/gpu_fuzz_state.py ${FUZZ_STATE:-600} 31 2>&1 | tail -2
                 echo "== ZK_STATE_DMA=0 python tests/gpu_fuzz_state.py 60 9"; ZK_STATE_DMA=0 timeout 600 python tests/gpu_fuzz_state.py 60 9 2>&1 | tail -2
-                echo "== python tests/gpu_fuzz_copy.py 150 7"; timeout 900 python tests/gpu_fuzz_copy.py 150 7 2>&1 | tail -3
+                echo "== python tests/gpu_fuzz_copy.py ${FUZZ_COPY:-150} 7"; timeout 900 python tests/gpu_fuzz_copy.py ${FUZZ_COPY:-150} 7 2>&1 | tail -3
                 echo "== python tests/gpu_fuzz_evm.py 40 29"; timeout 900 python tests/gpu_fuzz_evm.py 40 29 2>&1 | tail -2
                 echo "== python tests/gpu_fuzz_evm_trace.py"; timeout 900 python tests/gpu_fuzz_evm_trace.py 2>&1 | tail -3; } > $out/fuzz.txt 2>&1; grep -v amdgpu.ids $out/fuzz.txt | cut -c1-300 ;;
     ab:*)     # A/B of environment switches on the one-shot headline: `ab:ZK_P1_TAIL=0,ZK_PRECLEAN=0` runs the default, each switch, and all of them
