@@ -1,4 +1,5 @@
 // Witness assignment (State, Bytecode) and keccak-table generation kernels
+#include <stdlib.h>
 #include "kernels.hpp"
 
 
@@ -155,12 +156,14 @@ __global__ __launch_bounds__(256) void keccak_table_kernel(KeccakGenArgs g, u32*
     tally_commit(tally, i, code);
 }
 // two messages per wavefront; the groups walk the list of long messages grid-stride (its length is only known on the device)
-__global__ __launch_bounds__(256) void keccak_table_group_kernel(KeccakGenArgs g) {
+__global__ __launch_bounds__(256) void keccak_table_group_kernel(KeccakGenArgs g, u32 use_lds) {
+    __shared__ u64 s_state[8][64];  // per lane group: the state words and the rotated words of a round (keccak_table_row_group)
     const u32 gl = threadIdx.x & 31u;
     const int base = (int)(threadIdx.x & 32u);
     const u32 n_long = *g.long_count;
     const u32 groups = gridDim.x * (blockDim.x >> 5);
-    for (u32 k = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); k < n_long; k += groups) keccak_table_row_group(g, g.long_list[k], gl, base);
+    u64* lds = use_lds ? s_state[threadIdx.x >> 5] : nullptr;
+    for (u32 k = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); k < n_long; k += groups) keccak_table_row_group(g, g.long_list[k], gl, base, lds);
 }
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally) {
     const u32 cap = a.mask + 1u;
@@ -213,6 +216,7 @@ void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status,
     hipLaunchKernelGGL(keccak_table_kernel, dim3((u32)((g.n + 255) / 256)), dim3(256), 0, st, g, status, tally);
     if (g.long_list) {
         const u64 blocks = (g.n + 7) / 8;  // eight groups per block; at most one group per message
-        hipLaunchKernelGGL(keccak_table_group_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, g);
+        static const u32 use_lds = [] { const char* e = getenv("ZK_KECCAK_LDS"); return (u32)!(e && e[0] == '0'); }();  // 0: the shuffle rounds of round 4
+        hipLaunchKernelGGL(keccak_table_group_kernel, dim3((u32)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, g, use_lds);
     }
 }

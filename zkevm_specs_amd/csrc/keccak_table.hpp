@@ -239,7 +239,12 @@ __device__ __forceinline__ Fr kt_shfl_fr(const Fr& a, int lane) {
     return o;
 }
 // one message by the 32 lanes [base, base + 32) of the wavefront; every lane of the group calls this with the same i
-__device__ __forceinline__ void keccak_table_row_group(const KeccakGenArgs& g, u64 i, u32 gl /* lane in group */, int base) {
+// `lds`: 64 u64 of LDS owned by this lane group (two 32-entry arrays), or nullptr for the shuffle form of the rounds (round 4: nine
+// 64-bit shuffles = 18 ds_bpermute in four dependent stages per round).  With it a round is two stages through LDS: every lane
+// stores its word, reads the ten words of the columns x - 1 and x + 1 (theta without the separate parity exchange), stores its
+// rotated word, and reads the three rotated words chi needs — its own pi source and the pi sources of (x + 1, y), (x + 2, y):
+// 2 stores + 13 loads of 8 bytes, 11 DS instructions, two dependent round trips instead of four.
+__device__ __forceinline__ void keccak_table_row_group(const KeccakGenArgs& g, u64 i, u32 gl /* lane in group */, int base, u64* lds = nullptr) {
     const u64 RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                         0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
                         0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
@@ -263,11 +268,15 @@ __device__ __forceinline__ void keccak_table_row_group(const KeccakGenArgs& g, u
     const int pi_src = base + (int)(((x + 3u * y) % 5u) + 5u * x);
     u64 a = 0;
     const u64 nblocks = len / 136 + 1;
+    // the next block's rate word is fetched before this block's 24 rounds run (its eight byte loads land under them; fetched where
+    // it is needed, they were ~1.5 us of exposed latency per 136-byte block)
+    u64 w_next = gl < 17u ? kt_word_at(p, 8u * gl, len) : 0ull;
     for (u64 blk = 0; blk < nblocks; blk++) {
         const u64 off = blk * 136;
         u64 w = 0;
         if (gl < 17u) {
-            w = kt_word_at(p, off + 8u * gl, len);
+            w = w_next;
+            if (blk + 1 < nblocks) w_next = kt_word_at(p, off + 136u + 8u * gl, len);
             if (blk + 1 == nblocks) {  // pad10*1 inside the last block
                 const u32 rem = (u32)(len - off);
                 if ((rem >> 3) == gl) w ^= 1ull << (8u * (rem & 7u));
@@ -275,6 +284,43 @@ __device__ __forceinline__ void keccak_table_row_group(const KeccakGenArgs& g, u
             }
         }
         a ^= w;
+        if (lds) {
+            u64* A = lds;
+            u64* R = lds + 32;
+            const u32 xm = (x + 4u) % 5u, xp = (x + 1u) % 5u;  // the neighbouring columns' x
+            const u32 x1 = (x + 1u) % 5u, x2 = (x + 2u) % 5u;
+            const u32 p0 = ((x + 3u * y) % 5u) + 5u * x, p1 = ((x1 + 3u * y) % 5u) + 5u * x1, p2 = ((x2 + 3u * y) % 5u) + 5u * x2;
+            // rotate by the lane's own amount with two funnel shifts (v_alignbit_b32) on the halves, swapped first when the amount is
+            // 32 or more — full-rate instructions where a 64-bit variable shift pair is not; the 24 rounds are unrolled (round constants
+            // as immediates: the rolled loop fetched RC[round] with a scalar load and a branch for lane 0 every round)
+            const u32 rot_swap = my_rot & 32u, rot_n = (32u - (my_rot & 31u)) & 31u;
+            const bool rot_id = (my_rot & 31u) == 0u;
+            const u64 iota_mask = gl == 0u ? ~0ull : 0ull;
+#pragma unroll
+            for (int round = 0; round < 24; round++) {
+                A[gl] = a;  // (lanes 25..31 use slots 25..31: nobody reads them)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const u64 cm = A[xm] ^ A[xm + 5u] ^ A[xm + 10u] ^ A[xm + 15u] ^ A[xm + 20u];
+                const u64 cp = A[xp] ^ A[xp + 5u] ^ A[xp + 10u] ^ A[xp + 15u] ^ A[xp + 20u];
+                a ^= cm ^ kt_rolv(cp, 1);                                                                            // theta
+                {                                                                                                    // rho
+                    u32 lo = (u32)a, hi = (u32)(a >> 32);
+                    if (rot_swap) { const u32 t = lo; lo = hi; hi = t; }
+                    // rotl by m = my_rot & 31 on (hi:lo): lo' = (lo << m) | (hi >> (32 - m)) = alignbit(lo, hi, 32 - m), likewise hi'
+                    const u32 nlo = rot_id ? lo : __builtin_amdgcn_alignbit(lo, hi, rot_n);
+                    const u32 nhi = rot_id ? hi : __builtin_amdgcn_alignbit(hi, lo, rot_n);
+                    R[gl] = (u64)nlo | ((u64)nhi << 32);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const u64 b0 = R[p0], b1 = R[p1], b2 = R[p2];                                                        // pi (gathers)
+                a = b0 ^ (~b1 & b2);                                                                                 // chi
+                a ^= RC[round] & iota_mask;                                                                          // iota (lane 0)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the next round's stores stay behind this round's loads
+            }
+        } else
 #pragma unroll 1
         for (int round = 0; round < 24; round++) {
             const u64 c = a ^ kt_shfl64(a, col1) ^ kt_shfl64(a, col2) ^ kt_shfl64(a, col3) ^ kt_shfl64(a, col4);  // column parity C[x]
