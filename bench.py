@@ -33,9 +33,9 @@ below them: the driver's record keeps scalars of those two objects):
   fresh_witness   open + pass split with explicit cache flushes (the round-2/3 definition of the same thing, for comparison)
   cpu_baseline    `port` (oracle/, pure Python, dict-indexed lookups), `cpu_backend_1core` / `cpu_backend_allcores` (libzkevm_cpu.so:
                   the kernels' own sources built for the host behind the same C ABI, OpenMP: the "optimised CPU" line) — timed
-                  here on a bounded sample — and `reference`: the
+                  here on a bounded sample; the headline `value` is the `port` leg's — and `reference_build_container`: the
                   unmodified reference timed in the build container (tools/time_reference.py -> profiles/r*_cpu_reference.json;
-                  /root/reference does not exist on the GPU box, so this leg is a CROSS-BOX figure and says so).
+                  the reference is Python and does not travel to the GPU box, so this leg is a CROSS-BOX figure and says so).
   host_path       marshalling (Python objects -> wire arrays, flatten.py) and H2D staging, reported separately.
   other_configs   (default N = 1 run only) BASELINE configs[0], [1], [3], [4] measured after the headline on the same clock:
                   Bytecode 256 B (CPU backend: configs[0] is the CPU-runnable case), State 2^16 (+ cold-cache leg) and 2^20,
@@ -705,9 +705,8 @@ def compact_line(out, full_path=None):
         c = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
         c["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:120]
         legs = cb.get("legs") or {}
-        head = legs.get("reference") or {}
-        c["extrapolated"] = bool(head.get("extrapolated", False))
-        c["measured_on"] = "this box" if (head.get("timed_on") == "this box" or cb.get("kind") == "port") else "build container"
+        c["extrapolated"] = False  # the headline leg is measured
+        c["measured_on"] = "this box"  # cpu_baseline() only ever heads the line with a leg timed here (bench_legs.py)
         c["this_box_cores_total"] = cb.get("this_box_cores_total")
         c["legs"] = {k: {"value": v.get("value"), "cores": v.get("cores")} for k, v in legs.items()}
         line["cpu_baseline"] = c

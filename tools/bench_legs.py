@@ -181,7 +181,7 @@ def config0_bytecode(args):
         ref_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")), reverse=True)
         ref = json.load(open(ref_file[0])) if ref_file else None
         if ref and "bytecode" in ref:
-            blk["cpu_baseline"] = {"value": ref["bytecode"]["rows_per_s"], "unit": "rows/s", "cores": 1, "kind": "reference",
+            blk["cpu_baseline"] = {"value": ref["bytecode"]["rows_per_s"], "unit": "rows/s", "cores": 1, "kind": "reference", "measured_on": "build container",
                                    "sample": f"check_bytecode_row of the unmodified reference over the 512 rows of this configuration, build container ({os.path.basename(ref_file[0])}): a cross-box figure"}
     return blk
 
@@ -294,53 +294,6 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
                     "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
 
 
-def live_reference_leg(ev, logs=(4, 5)):
-    """The UNMODIFIED reference timed on THIS box: `verify_steps` (evm_circuit/main.py:14) over the first 2^4 and 2^5 step pairs of
-    the bench's own trace, each with the table rows those steps can look up (the reference scans whole tables per lookup,
-    table.py:864-884) — about 30 s of one core.  The reference lives in the git-ignored staging copy oracle/_ref/reference
-    (tools/run_reference_suite.py --stage; it travels to the GPU box, /root/reference does not) and is only ever imported by the
-    child process (tools/time_reference.py with PYTHONPATH = oracle/refshim + the staged src).  None when it is not staged."""
-    import subprocess
-    import tempfile
-
-    import numpy as np
-
-    src = os.path.join(ROOT, "oracle", "_ref", "reference", "src")
-    if not os.path.isdir(src):
-        return None
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    try:
-        from time_reference import evm_prefix
-
-        from tests.evm_cases import with_defaults
-
-        full = with_defaults({k: v for k, v in ev.items() if k != "meta"})
-        arrays = {}
-        for log_n in logs:
-            for k, v in evm_prefix(full, 1 << log_n).items():
-                arrays[f"{log_n}/{k}"] = v
-        with tempfile.TemporaryDirectory(prefix="zk_ref_", dir="/tmp") as td:
-            npz = os.path.join(td, "prefixes.npz")
-            np.savez(npz, **arrays)
-            env = dict(os.environ, ZK_TIME_EVM_NPZ=npz, PYTHONDONTWRITEBYTECODE="1",
-                       PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle", "refshim"), src]))
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference.py")], env=env, stdout=subprocess.PIPE,
-                                 stderr=subprocess.DEVNULL, timeout=240, check=True).stdout
-        pts = json.loads(out)["evm_live"]["measured"]
-    except Exception:  # noqa: BLE001 — the committed build-container figure stays the reference leg then
-        return None
-    finally:
-        sys.path.pop(0)
-    top = pts[-1]
-    return {"value": top["pairs_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False, "timed_on": "this box",
-            "sample_short": f"unmodified reference verify_steps, first {top['step_pairs']} step pairs of this trace, {top['seconds']:.0f} s, this box",
-            "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"], "seconds": p["seconds"],
-                          "rows_per_s": p["pairs_per_s"]} for p in pts],
-            "sample": f"verify_steps of the unmodified reference (oracle/_ref staging copy, dependency stand-ins of oracle/refshim) over the first "
-                      f"{top['step_pairs']} step pairs of this trace with the {top['rw_rows'] + top['bytecode_rows']} table rows they can look up, "
-                      f"{top['seconds']:.1f} s on one core of this box; its lookups scan the table, so the full 2^18-step trace is far slower per row"}
-
-
 def effective_cores():
     """Cores this process may actually burn: the smaller of its affinity mask and the cgroup's CFS quota.  On the round-4 GPU box
     os.cpu_count() said 256 while all-core passes after the first took 99.8 / 139.7 / 200.1 ms — multiples of the 100 ms CFS
@@ -363,8 +316,10 @@ def effective_cores():
 
 
 def cpu_baseline(workload, w):
-    """CPU legs on rank 0's host cores, bounded samples.  `value` is the reference's own figure when the committed
-    build-container measurement exists (kind "reference"), else the oracle port's."""
+    """CPU legs on rank 0's host cores, bounded samples.  `value` is the oracle port's (kind "port"), timed on this box: the
+    reference is Python and does not travel to the GPU box, and bench.py never reads /root/reference.  The committed
+    build-container measurement of the reference itself (tools/time_reference.py -> profiles/r*_cpu_reference.json) rides along as
+    the cross-box leg `reference_build_container`."""
     import numpy as np
 
     cores_total, cores_how = effective_cores()
@@ -413,12 +368,7 @@ def cpu_baseline(workload, w):
                          "sample": f"{hs} step pairs through libzkevm_cpu.so (ZK_BACKEND=cpu: the kernels' own per-step functions compiled for the "
                                    f"host, OpenMP over the pairs; csrc/cpu_backend.cpp), MEDIAN of passes 1..{len(ms_sorted)} with tables and indices "
                                    f"resident, {threads} thread(s) = {cores_how if threads > 1 else 'one core'} — the optimised-CPU line"}
-        live = live_reference_leg(ev) if workload == "evm" else None
-        if live:
-            legs["reference"] = live
-            if ref and "evm" in ref:
-                live["extrapolated_2p18_rows_per_s_build_container"] = ref["evm"]["extrapolated_2p18"]["pairs_per_s"]
-        elif ref and "evm" in ref:
+        if ref and "evm" in ref:  # the committed build-container measurement of the reference itself (tools/time_reference.py): a cross-box leg
             e = ref["evm"]
             legs["reference"] = {"value": e["extrapolated_2p18"]["pairs_per_s"], "unit": "rows/s", "cores": 1,
                                  "measured": [{"step_pairs": p["step_pairs"], "table_rows": p["rw_rows"] + p["bytecode_rows"],
@@ -506,12 +456,14 @@ def cpu_baseline(workload, w):
             legs["reference"] = {"value": ref["state"]["rows_per_s"], "unit": "rows/s", "cores": 1, "extrapolated": False,
                                  "sample": f"check_state_row of the unmodified reference over all {ref['state']['rows']} rows of this witness, build container "
                                            f"({os.path.basename(ref_file[0])})"}
+    # the headline baseline is timed on THIS box (the oracle port); the committed build-container figure of the reference stays beside it
+    if "reference" in legs:
+        legs["reference_build_container"] = legs.pop("reference")
     head = legs.get("reference") or legs.get("port") or legs["cpu_backend_1core"]
     return {"value": head["value"], "unit": head["unit"], "cores": 1,
             "kind": "reference" if "reference" in legs else "port",
             "sample": head["sample"], "sample_short": head.get("sample_short"), "legs": legs,
             "this_box_cores_total": cores_total, "this_box_cores_source": cores_how, "this_box_cpu_count": os.cpu_count(),
-            "reference_measured_on": ("this box (oracle/_ref staging copy)" if (legs.get("reference") or {}).get("timed_on") == "this box" else
-                                      None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: /root/reference does not exist "
-                                                                "here, so the `reference` leg is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box")),
+            "reference_measured_on": (None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: a Python reference does not "
+                                                                "travel, so `reference_build_container` is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box")),
             }

@@ -33,7 +33,6 @@ PY
     prof-tx)      tools/profile_bench.sh tx_2p14 --workload tx --steps 6 --warmup 2 > $out/prof_tx.log 2>&1; tail -2 $out/prof_tx.log | cut -c1-300 ;;
     prof-super)   tools/profile_bench.sh super_2p20 --workload super --steps 10 --warmup 3 > $out/prof_super.log 2>&1; tail -2 $out/prof_super.log | cut -c1-300 ;;
     rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
-    refsuite) timeout 900 python tools/run_reference_suite.py --backend hip --ref-root oracle/_ref/reference --out $out/reference_suite_hip.json > $out/reference_suite_hip.log 2>&1; tail -1 $out/reference_suite_hip.log ;;
     fuzz)     # differential fuzz of the HIP path against the oracle (per-row / per-pair status words bit for bit)
               { echo "== python tests/gpu_fuzz_state.py ${FUZZ_STATE:-600} 31"; timeout 900 python tests/gpu_fuzz_state.py ${FUZZ_STATE:-600} 31 2>&1 | tail -2
                 echo "== ZK_STATE_DMA=0 python tests/gpu_fuzz_state.py 60 9"; ZK_STATE_DMA=0 timeout 600 python tests/gpu_fuzz_state.py 60 9 2>&1 | tail -2

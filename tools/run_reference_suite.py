@@ -15,9 +15,10 @@ A pytest plugin rebinds, inside every reference test module that imported them, 
 (`--backend cpu`: libzkevm_cpu.so, runs in the GPU-less build container; `--backend hip`: libzkevm_hip.so on an MI355X).
 Everything else of the tests — witness construction with the reference's own classes, the expected outcomes — is untouched.
 
-The reference itself cannot travel to the GPU box (`/root/reference` only exists in the build container): `--stage` copies
-its `src/` and `tests/` under oracle/_ref/reference/ (git-ignored, shipped by gpurun like other built artefacts; never part
-of the repository's history) and `--ref-root oracle/_ref/reference` runs against that copy.
+The reference is Python and does not travel to the GPU box in any form (`/root/reference` only exists in the build
+container), so this tool runs where the reference is: in the build container, `--backend cpu`.  What reaches the GPU box
+instead is data: the witnesses of these very tests with the reference's recorded outcomes (tests/golden/, oracle/gen_golden*.py).
+(`--backend hip` is for an integrator's machine that has both a reference checkout and an MI355X.)
 
 Writes a JSON summary (`--out`): totals, per-file counts, every non-passing test with the reason, and how many calls went
 through each rebound entry.
@@ -25,7 +26,6 @@ through each rebound entry.
 import argparse
 import json
 import os
-import shutil
 import sys
 import time
 
@@ -93,33 +93,19 @@ class Rebind:
             self.durations[report.nodeid] = report.duration
 
 
-def stage_reference(dst):
-    src_root = "/root/reference"
-    if os.path.isdir(dst):
-        shutil.rmtree(dst)
-    os.makedirs(dst)
-    for sub in ("src", "tests"):
-        shutil.copytree(os.path.join(src_root, sub), os.path.join(dst, sub), ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
-    print(f"staged {src_root}/{{src,tests}} -> {dst} (git-ignored; travels with gpurun)")
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", choices=("cpu", "hip"), default="cpu")
     ap.add_argument("--ref-root", default="/root/reference", help="directory holding the reference's src/ and tests/")
-    ap.add_argument("--stage", action="store_true", help="copy the reference under oracle/_ref/reference and exit")
     ap.add_argument("--out", default=None, help="JSON summary path")
     ap.add_argument("--select", nargs="*", default=None, help="test files / node ids relative to <ref-root>/tests (default: all)")
     ap.add_argument("-k", dest="keyword", default=None)
     ap.add_argument("-x", dest="exitfirst", action="store_true")
     args = ap.parse_args()
-    if args.stage:
-        stage_reference(os.path.join(ROOT, "oracle", "_ref", "reference"))
-        return 0
     ref_root = os.path.abspath(args.ref_root)
     tests_dir = os.path.join(ref_root, "tests")
     if not os.path.isdir(tests_dir):
-        print(f"{tests_dir} not found (build container: /root/reference; GPU box: --stage first, then --ref-root oracle/_ref/reference)")
+        print(f"{tests_dir} not found (the reference lives in the build container: /root/reference)")
         return 2
     os.environ["ZK_BACKEND"] = args.backend  # read when zkevm_specs_amd._lib is first imported
     os.environ.setdefault("ZKEVM_SHIM_SEED", "20240807")
