@@ -264,6 +264,34 @@ int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, uint64_t n, u
                     uint32_t* row_flags_out, uint64_t* mpt_out /* capacity n rows */, uint64_t* n_mpt_out,
                     uint32_t opts, uint32_t* status_out, zk_result* result);
 
+/* ---- RW table -> State-circuit operations (the "RW-table lexicographic sort" half): from the EVM circuit's
+ *      RW table to the op list zk_state_assign_open takes, on the device.  The reference never links the two in code (SURVEY.md
+ *      Appendix A.14); its State witnesses are lists of `Operation`s (src/zkevm_specs/state_circuit.py:616-825) in the order
+ *      the circuit checks — (tag, id, address, field_tag, storage_key, rw_counter) strictly increasing (:552-570) — handed to
+ *      assign_state_circuit (:855-884), and a block's RW rows come out of `RWDictionary` (evm_circuit/typing.py:464-845) under
+ *      the EVM side's `Target` numbering (evm_circuit/table.py:184-204).  This entry re-keys every RW row (Target -> Tag; the
+ *      CallContext field tag from the address cell; Account rows without an id; the TxLog address cell unpacked into log_id /
+ *      field_tag / index; initial_value = aux0 for Account / AccountStorage rows), sorts the ops by that key — stable: equal
+ *      keys keep their table order, like Python's sorted() — and puts a StartOp in front.
+ *      rw: uint64[n][14][4] + rw_flags uint32[n] (nullable), the EVM circuit's RW table as in zk_evm_tables.
+ *      Outputs: ops COLUMN-major uint64[12][n_ops][4] + op_flags uint32[n_ops], exactly what zk_state_assign_open takes;
+ *      n_ops = 1 + the rows kept, known when zk_state_ops_from_rw_open returns (*n_ops_out; at most n + 1).  Left out:
+ *      CallContext rows whose field tag exceeds the State circuit's MAX_FIELD_TAG (24, state_circuit.py:34,334) — not an error —
+ *      and rejected rows: status (ZK_KIND_VALUE_ERROR << 24) | 1 = the target cell is not a Target, (ZK_KIND_OVERFLOW_ERROR
+ *      << 24) | 2 = storage_key hi cell >= 2^128 (lo | hi << 128 does not fit the 256-bit slot).  Status is per RW ROW (n
+ *      entries); the tally counts the rejected rows.
+ *      With ZK_OPT_DEVICE_PTRS rw / rw_flags are device pointers and ops_dev / op_flags_dev (each nullable: the session then owns
+ *      the buffer; capacity (n + 1) ops when given) receive the outputs in place, packed for n_ops.
+ *      zk_state_ops_from_rw_open runs the class scan (one streaming pass over the table) and waits for it: the sort key is
+ *      compacted to the bits that vary inside each tag class, which decides the number of radix passes.  zk_launch enqueues the
+ *      rest (key packing, the radix passes, the op list) asynchronously; zk_collect / zk_read_status as for the circuits. */
+int zk_state_ops_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_dev, uint32_t* op_flags_dev,
+                              uint32_t opts, uint64_t* n_ops_out, zk_session** out);
+/* Copy the outputs of the last pass to HOST buffers (each nullable; ops_host holds n_ops ops). */
+int zk_state_ops_from_rw_read(zk_session* s, uint64_t* ops_host, uint32_t* op_flags_host, uint64_t* n_ops_out);
+int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_out /* capacity n + 1 ops */,
+                         uint32_t* op_flags_out, uint64_t* n_ops_out, uint32_t opts, uint32_t* status_out, zk_result* result);
+
 /* ---- secp256k1 ECDSA verification: computes the `ecdsa_status` column of the Tx / Sig units
  *      on the device instead of taking it from the host.  Replaces `ECDSAVerifyChip.verify`
  *      (src/zkevm_specs/tx_circuit.py:147-158, util/ec.py:109-117), i.e. eth-keys 0.4.0's

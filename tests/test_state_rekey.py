@@ -1,0 +1,201 @@
+"""RW table -> State-circuit operations (the sort half; include/zkevm_hip.h zk_state_ops_from_rw*):
+the C-ABI entry against the checker oracle/rw_state_oracle.py — ops, op flags, order and per-row status bit for bit.
+CPU suite: through libzkevm_cpu.so (the same per-row functions and compact-key plan, std::stable_sort).  GPU suite: the HIP
+path (radix passes on the device) on the same cases, 200 fuzzed tables, and the full 2^18-step block."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import rw_state_oracle, wire
+from zkevm_specs_amd import oneshot
+from zkevm_specs_amd.wire import rows_to_rowmajor
+
+M256 = (1 << 256) - 1
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def rand_rw_table(rng, n, wide=0.0, bad=0.0, dup=0.3):
+    """n RW rows (14 ints) over every target, with repeated keys, unsorted / repeated rw_counters, CallContext field tags on both
+    sides of 24, packed TxLog address cells, and — with probability `wide` per row — cells as wide as the wire allows; `bad`: rows
+    the entry rejects (no such target, storage_key hi >= 2^128)."""
+    rows, flags = [], []
+    addrs = [rng.getrandbits(160) for _ in range(3)]
+    keys = [rng.getrandbits(256) for _ in range(4)] + [0, 1, (1 << 128), (1 << 128) - 1]
+    for i in range(n):
+        if rows and rng.random() < dup:  # an earlier row's key again (the stable order decides)
+            c = list(rng.choice(rows))
+            if rng.random() < 0.7:
+                c[0] = rng.randrange(1, 4 * n)
+            c[8] = rng.getrandbits(128)
+            rows.append(c)
+            flags.append(rng.getrandbits(2))
+            continue
+        t = rng.choice([2, 3, 4, 5, 6, 7, 7, 8, 8, 8, 9, 9, 9, 10, 11, 1])
+        c = [0] * 14
+        c[0] = rng.randrange(0, 4 * n)
+        c[1] = rng.getrandbits(1)
+        c[2] = t
+        c[3] = rng.randrange(0, 40)
+        if t in (8,):
+            c[4] = rng.randrange(900, 1024)
+        elif t == 9:
+            c[4] = rng.randrange(0, 1 << rng.choice([5, 12, 33]))
+        elif t == 7:
+            c[4] = rng.choice([1, 2, 5, 17, 20, 23, 24, 25, 26, 300])
+        elif t == 10:
+            c[4] = (rng.randrange(0, 6) << 48) | (rng.randrange(0, 5) << 32) | rng.randrange(0, 70)
+        elif t in (2, 3, 5, 6):
+            c[4] = rng.choice(addrs)
+        if t in (5, 11):
+            c[5] = rng.randrange(1, 5)
+        if t in (3, 6):
+            k = rng.choice(keys)
+            c[6], c[7] = k & ((1 << 128) - 1), k >> 128
+        c[8], c[9] = rng.getrandbits(128), rng.getrandbits(rng.choice([0, 128]))
+        c[10], c[11] = rng.getrandbits(128), rng.getrandbits(rng.choice([0, 128]))
+        c[12], c[13] = rng.getrandbits(128), rng.getrandbits(rng.choice([0, 128]))
+        if rng.random() < wide:
+            j = rng.choice([0, 3, 4, 5, 6, 7, 8, 12])
+            c[j] = rng.choice([rng.getrandbits(256), P - 1, M256, rng.getrandbits(200), (1 << 128) | rng.getrandbits(20)])
+            if j == 7 and rng.random() < 0.5:
+                c[7] &= (1 << 128) - 1
+        if rng.random() < bad:
+            if rng.random() < 0.5:
+                c[2] = rng.choice([0, 12, 13, 255, 1 << 40, P - 1])
+            else:
+                c[7] = (1 << 128) | rng.getrandbits(100)
+        rows.append(c)
+        flags.append(rng.getrandbits(2))
+    return rows, flags
+
+
+def check_against_oracle(rows, flags, device):
+    rw = rows_to_rowmajor(rows, 14)
+    fl = np.array(flags, dtype=np.uint32)
+    res, status, ops, op_flags = oneshot.state_ops_from_rw(rw, fl, device=device)
+    e_ops, e_flags, e_status = rw_state_oracle.rw_to_state_ops(rows, flags, strict=False)
+    assert status.tolist() == e_status
+    assert res.fail_count == sum(1 for s in e_status if s)
+    assert ops.shape[1] == len(e_ops)
+    got = wire.colmajor_to_rows(ops)
+    for j, (g, e) in enumerate(zip(got, e_ops)):
+        assert g == e, (j, g, e)
+    assert op_flags.tolist() == e_flags
+    return len(e_ops)
+
+
+CASES = [(1, 0.0, 0.0), (2, 0.0, 0.0), (63, 0.0, 0.0), (64, 0.0, 0.0), (65, 0.1, 0.0), (257, 0.0, 0.05), (1000, 0.02, 0.01), (4097, 0.0, 0.0),
+         (5000, 0.3, 0.1), (9000, 0.001, 0.0)]
+
+
+@pytest.mark.parametrize("n,wide,bad", CASES)
+def test_cpu_backend_matches_checker(n, wide, bad):
+    rng = random.Random(1000 * n + 7)
+    rows, flags = rand_rw_table(rng, n, wide, bad)
+    check_against_oracle(rows, flags, "cpu")
+
+
+def test_cpu_backend_without_ranks_matches(monkeypatch):
+    """the generic path (no rank compression: every varying bit of the wide fields is a key bit)"""
+    monkeypatch.setenv("ZK_REKEY_NO_RANKS", "1")
+    rng = random.Random(5)
+    rows, flags = rand_rw_table(rng, 700, 0.2, 0.02)
+    check_against_oracle(rows, flags, "cpu")
+
+
+def test_checker_matches_trace_generator():
+    """the block generator's RW table: every kept row becomes one op, the order is the State circuit's, and the derived witness is
+    one the State circuit accepts (oracle/state_oracle.py over the oracle's own assignment)"""
+    from oracle import assign_oracle, state_oracle
+    from zkevm_specs_amd.synth_block import synth_block_trace
+
+    w = synth_block_trace(600, seed=3, seg_len=96, n_contracts=2)
+    rows = wire.rowmajor_to_rows(w["rw"])
+    ops, flags, status = rw_state_oracle.rw_to_state_ops(rows, w["rw_flags"].tolist())
+    assert not any(status) and len(ops) > 1000
+    keys = [(o[2], o[3], o[4], o[5], o[6], o[0]) for o in ops[1:]]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+    st_rows, st_flags, mpt, st = assign_oracle.assign(ops, flags)
+    assert not any(st)
+    assert not any(state_oracle.verify_rows(st_rows, st_flags, mpt))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,wide,bad", CASES)
+def test_gpu_matches_checker(n, wide, bad):
+    rng = random.Random(1000 * n + 7)
+    rows, flags = rand_rw_table(rng, n, wide, bad)
+    check_against_oracle(rows, flags, None)
+
+
+@pytest.mark.gpu
+def test_gpu_200_fuzzed_tables():
+    rng = random.Random(20260101)
+    total = 0
+    for t in range(200):
+        n = rng.choice([3, 40, 130, 700, 2100, 4500])
+        rows, flags = rand_rw_table(rng, n, wide=rng.choice([0.0, 0.0, 0.05, 0.5]), bad=rng.choice([0.0, 0.02]), dup=rng.choice([0.1, 0.6]))
+        total += check_against_oracle(rows, flags, None)
+    assert total > 100000
+
+
+@pytest.mark.gpu
+def test_gpu_without_ranks(monkeypatch):
+    monkeypatch.setenv("ZK_REKEY_NO_RANKS", "1")
+    rng = random.Random(6)
+    rows, flags = rand_rw_table(rng, 3000, 0.2, 0.02)
+    check_against_oracle(rows, flags, None)
+
+
+@pytest.mark.gpu
+def test_gpu_generic_sort_path(monkeypatch):
+    """keys wider than 64 bits take the generic path (index-only passes, digits gathered from the key words): forced here for
+    tables the fast path would sort, and reached naturally by the un-ranked wide tables of test_gpu_without_ranks"""
+    monkeypatch.setenv("ZK_REKEY_NO_FAST", "1")
+    rng = random.Random(8)
+    for n in (5, 900, 4097, 9000):
+        rows, flags = rand_rw_table(rng, n, 0.01, 0.01)
+        check_against_oracle(rows, flags, None)
+
+
+@pytest.mark.gpu
+def test_gpu_full_block_2p18():
+    """BASELINE configs[4]'s block: the 2^18-step trace's RW table (about 7.6e5 rows) re-keyed and sorted on the device, device
+    pointers in and out, against the checker; then straight into the device-side State assignment and the State circuit."""
+    import torch
+
+    from zkevm_specs_amd import engine
+    from zkevm_specs_amd.synth_block import synth_block_trace
+
+    w = synth_block_trace(1 << 18, seed=5)
+    rw, fl = w["rw"], w["rw_flags"]
+    n = int(rw.shape[0])
+    dev = torch.device("cuda:0")
+    d_rw = torch.from_numpy(rw.view(np.int64)).to(dev)
+    d_fl = torch.from_numpy(fl.view(np.int32)).to(dev)
+    d_ops = torch.empty(48 * (n + 1), dtype=torch.int64, device=dev)
+    d_of = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    with engine.open_state_ops_from_rw(d_rw, d_fl, d_ops, d_of) as s:
+        res = s.run()
+        m = s.n_ops
+    assert res.ok
+    rows = wire.rowmajor_to_rows(rw)
+    e_ops, e_flags, _ = rw_state_oracle.rw_to_state_ops(rows, fl.tolist())
+    assert m == len(e_ops)
+    got = d_ops[: 48 * m].view(12, m, 4).cpu().numpy().view(np.uint64)
+    exp = np.ascontiguousarray(rows_to_rowmajor(e_ops, 12).transpose(1, 0, 2))
+    assert np.array_equal(got, exp)
+    assert d_of[:m].cpu().numpy().view(np.uint32).tolist() == e_flags
+    # ... and on into the State circuit without leaving the device
+    ops_t = d_ops[: 48 * m].view(12, m, 4)
+    st_rows = torch.empty((57, m, 4), dtype=torch.int64, device=dev)
+    st_flags = torch.empty(m, dtype=torch.int32, device=dev)
+    mpt = torch.empty((m, 12, 4), dtype=torch.int64, device=dev)
+    with engine.open_state_assign(ops_t, d_of[:m], st_rows, st_flags, mpt) as a:
+        assert a.run().ok
+        n_mpt = a.n_mpt()
+    with engine.open_state(st_rows, st_flags, mpt[:n_mpt]) as st:
+        r = st.run()
+    assert r.ok and r.rows_evaluated == m

@@ -31,6 +31,7 @@
 #include "pi_circuit.hpp"
 #include "state_assign.hpp"
 #include "bytecode_assign.hpp"
+#include "state_rekey.hpp"
 
 static thread_local std::string g_err;
 #define ARG_TRY(cond, msg) do { if (!(cond)) { g_err = msg; return -1; } } while (0)
@@ -92,7 +93,10 @@ struct zk_session {
     std::vector<u64> w64[4];              // assignment sessions: work / output buffers
     std::vector<u32> out32;
     void (*pass)(zk_session*) = nullptr;  // assignment sessions: one pass computes the outputs and fills `status`
-    int assign_kind = 0;                  // 1 state, 2 bytecode, 3 copy
+    int assign_kind = 0;                  // 1 state, 2 bytecode, 3 copy, 4 RW -> State ops
+    u64 n_ops = 0;                        // RW -> State ops: 1 + kept rows
+    std::vector<u32> rekey_plan;          // RW -> State ops: the RwkHostPlan's plan (as words) ...
+    std::vector<u32> rekey_jobs;          // ... and its rank jobs (cls, field, base, count)
     u64 n_mpt = 0;
     CpuTable tab[12];
     std::vector<u64> keccak_rows;         // keccak sessions: the table
@@ -784,6 +788,120 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
     rc = zk_launch(s, nullptr);
     if (!rc) rc = zk_collect(s, result);
     if (!rc) rc = zk_state_assign_read(s, rows_out, row_flags_out, mpt_out, n, n_mpt_out);
+    if (!rc && status_out) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
+// ---- RW table -> State-circuit operations (state_rekey.hpp): the device's per-row functions and its compact-key plan, the sort
+// itself a std::stable_sort over the compact keys (the device sorts the same keys with LSD radix passes).
+#include "state_rekey_plan.hpp"
+#include <algorithm>
+static void rekey_scan_host(const u64* rw, u64 n, std::vector<u32>& masks) {
+    masks.assign(2 * RWK_MASK_WORDS_H + RWK_NCLASSES, 0u);
+    for (u64 i = 0; i < n; i++) {
+        const RwkKey k = rwk_key(rw + i * (RWK_RW_NCELLS * 4));
+        masks[2 * RWK_MASK_WORDS_H + k.cls]++;
+        if (k.cls == RWK_CLASS_DROPPED) continue;
+        for (int f = 0; f < RWK_NFIELDS; f++)
+            for (int w = 0; w < 8; w++) {
+                const u32 slot = (k.cls * RWK_NFIELDS + f) * 8 + w;
+                masks[slot] |= k.f[f].v[w];
+                masks[RWK_MASK_WORDS_H + slot] |= ~k.f[f].v[w];
+            }
+    }
+}
+static void state_rekey_pass(zk_session* s) {
+    const u64 n = s->n;
+    const u64* rw = s->a64[0].data();
+    const u32* fl = s->a32[0].data();
+    RwkPlan plan;
+    memcpy(&plan, s->rekey_plan.data(), sizeof(plan));
+    // ranks of the plan's wide fields: rank = number of class members with a smaller value
+    std::vector<u32> ranks[RWK_NFIELDS];
+    for (size_t j = 0; j + 3 < s->rekey_jobs.size(); j += 4) {
+        const u32 cls = s->rekey_jobs[j], field = s->rekey_jobs[j + 1];
+        if (ranks[field].empty()) ranks[field].assign(n, 0u);
+        std::vector<std::pair<Fr, u32>> mem;
+        for (u64 i = 0; i < n; i++) {
+            const RwkKey k = rwk_key(rw + i * (RWK_RW_NCELLS * 4));
+            if (k.cls == cls) mem.push_back({k.f[field], (u32)i});
+        }
+        std::sort(mem.begin(), mem.end(), [](const std::pair<Fr, u32>& x, const std::pair<Fr, u32>& y) { return fr_lt(x.first, y.first); });
+        u32 r = 0;
+        for (size_t q = 0; q < mem.size(); q++) {
+            if (q && fr_lt(mem[q - 1].first, mem[q].first)) r = (u32)q;
+            ranks[field][mem[q].second] = r;
+        }
+    }
+    const u32 kw = plan.key_words;
+    std::vector<u32> keys((size_t)kw * n);
+    for (u64 i = 0; i < n; i++) {
+        const RwkKey k = rwk_key(rw + i * (RWK_RW_NCELLS * 4));
+        u32 rk[RWK_NFIELDS];
+        for (int f = 0; f < RWK_NFIELDS; f++) rk[f] = ranks[f].empty() ? 0u : ranks[f][i];
+        rwk_pack(plan, plan.cls[k.cls], k, rk, keys.data() + i, n);
+        s->status[i] = k.status;
+    }
+    std::vector<u32> order(n);
+    for (u64 i = 0; i < n; i++) order[i] = (u32)i;
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) {
+        for (u32 w = 0; w < kw; w++) {
+            const u32 a = keys[(size_t)w * n + x], b = keys[(size_t)w * n + y];
+            if (a != b) return a < b;
+        }
+        return false;
+    });
+    u64* ops = s->a64[1].data();
+    u32* of = s->out32.data();
+    rwk_emit_start(ops, of, s->n_ops);
+    for (u64 j = 1; j < s->n_ops; j++) {
+        const u64* p = rw + (u64)order[j - 1] * (RWK_RW_NCELLS * 4);
+        const RwkKey k = rwk_key(p);
+        rwk_emit(ops, of, s->n_ops, j, k, rwk_op(p, fl[order[j - 1]], k));
+    }
+}
+extern "C" int zk_state_ops_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_dev, uint32_t* op_flags_dev,
+                                         uint32_t opts, uint64_t* n_ops_out, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_state_ops_from_rw_open");
+    ARG_TRY(out && rw && n > 0 && n < (1ull << 31) && !ops_dev && !op_flags_dev, "zk_state_ops_from_rw_open: bad arguments");
+    zk_session* s = new_session(n, false);
+    s->a64[0].assign(rw, rw + n * RWK_RW_NCELLS * 4);
+    if (rw_flags) s->a32[0].assign(rw_flags, rw_flags + n);
+    else s->a32[0].assign(n, 0u);
+    std::vector<u32> masks;
+    rekey_scan_host(s->a64[0].data(), n, masks);
+    RwkHostPlan hp;
+    const char* e = getenv("ZK_REKEY_NO_RANKS");
+    rwk_build_plan(masks.data(), !(e && e[0] == '1'), hp);
+    s->rekey_plan.assign((sizeof(RwkPlan) + 3) / 4, 0u);
+    memcpy(s->rekey_plan.data(), &hp.plan, sizeof(RwkPlan));
+    for (const RwkRankJob& j : hp.jobs) { s->rekey_jobs.push_back(j.cls); s->rekey_jobs.push_back(j.field); s->rekey_jobs.push_back(j.base); s->rekey_jobs.push_back(j.count); }
+    s->n_ops = 1 + hp.n_kept;
+    s->a64[1].assign(s->n_ops * RWK_NSLOTS * 4, 0);
+    s->out32.assign(s->n_ops, 0);
+    s->pass = state_rekey_pass;
+    s->assign_kind = 4;
+    if (n_ops_out) *n_ops_out = s->n_ops;
+    *out = s;
+    return 0;
+}
+extern "C" int zk_state_ops_from_rw_read(zk_session* s, uint64_t* ops_host, uint32_t* op_flags_host, uint64_t* n_ops_out) {
+    ARG_TRY(s && s->assign_kind == 4, "zk_state_ops_from_rw_read: bad arguments");
+    if (n_ops_out) *n_ops_out = s->n_ops;
+    if (ops_host) memcpy(ops_host, s->a64[1].data(), s->a64[1].size() * 8);
+    if (op_flags_host) memcpy(op_flags_host, s->out32.data(), s->out32.size() * 4);
+    return 0;
+}
+extern "C" int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_out, uint32_t* op_flags_out,
+                                    uint64_t* n_ops_out, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && n_ops_out, "zk_state_ops_from_rw: null output");
+    zk_session* s = nullptr;
+    int rc = zk_state_ops_from_rw_open(rw, rw_flags, n, nullptr, nullptr, opts, n_ops_out, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc) rc = zk_state_ops_from_rw_read(s, ops_out, op_flags_out, n_ops_out);
     if (!rc && status_out) rc = zk_read_status(s, status_out);
     zk_close(s);
     return rc;

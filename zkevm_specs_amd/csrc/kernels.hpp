@@ -15,6 +15,7 @@
 #include "bytecode_assign.hpp"
 #include "copy_assign.hpp"
 #include "pi_circuit.hpp"
+#include "state_rekey.hpp"
 
 // The single-kernel row sessions keep two tallies and alternate between them: a pass accumulates into one and its first
 // lane clears the other for the pass after it, so that no reset kernel sits in front of every evaluation kernel (a kernel
@@ -58,6 +59,8 @@ void zk_launch_sign_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status, ZkTally* tally);
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally);
+void zk_launch_rekey_scan(hipStream_t st, const RekeyArgs& a);  // open-time class masks of the RW -> State re-keying
+void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTally* tally);
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_bytecode_assign(hipStream_t st, const BcaArgs& a, u32* status, ZkTally* tally);
 void zk_launch_pi_rows(hipStream_t st, const PiArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally);

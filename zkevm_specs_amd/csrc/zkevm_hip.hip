@@ -514,7 +514,7 @@ struct EvmResultBlock {
     u32 pad1[8 - (EVM_N_GROUPS + 1)];
 };
 static_assert(sizeof(EvmDyn) <= 64 && sizeof(EvmResultBlock) == 128, "EvmResultBlock layout");
-enum SessionKind { SESSION_PICOPY = 13, SESSION_PI = 12, SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
+enum SessionKind { SESSION_REKEY = 14, SESSION_PICOPY = 13, SESSION_PI = 12, SESSION_CPA = 11, SESSION_STATE = 1, SESSION_EVM = 2, SESSION_BYTECODE = 3, SESSION_EXP = 4, SESSION_COPY = 5, SESSION_SIGN = 6, SESSION_KECCAK = 7, SESSION_ASSIGN = 8, SESSION_ECDSA = 9, SESSION_BCA = 10 };
 
 struct zk_session {
     SessionKind kind;
@@ -544,6 +544,7 @@ struct zk_session {
     CpaArgs cpa;
     PiArgs pi;
     PiCopyArgs picopy;
+    RekeyArgs rekey;
     u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
@@ -1437,6 +1438,112 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
     return rc;
 }
 
+// ---- RW table -> State-circuit operations (state_rekey.hpp)
+#include "state_rekey_plan.hpp"
+extern "C" int zk_state_ops_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_dev, uint32_t* op_flags_dev,
+                                         uint32_t opts, uint64_t* n_ops_out, zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_state_ops_from_rw_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(out && rw && n > 0 && n < (1ull << 31), "zk_state_ops_from_rw_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || (!ops_dev && !op_flags_dev), "zk_state_ops_from_rw_open: output buffers need ZK_OPT_DEVICE_PTRS");
+    zk_session* s = new zk_session();
+    s->kind = SESSION_REKEY;
+    s->n = n;
+    RekeyArgs& a = s->rekey;
+    memset(&a, 0, sizeof(a));
+    int rc = 0;
+    const void* p = nullptr;
+    RwkHostPlan hp;
+    std::vector<u32> h_masks(2 * RWK_MASK_WORDS_H + RWK_NCLASSES);
+    const size_t mask_bytes = h_masks.size() * 4;
+    RwkPlan* d_plan = nullptr;
+    if ((rc = stage(s, rw, (size_t)n * RWK_RW_NCELLS * 32, dev, &p))) goto fail;
+    a.rw = (const u64*)p;
+    if (rw_flags) {
+        if ((rc = stage(s, rw_flags, (size_t)n * 4, dev, &p))) goto fail;
+        a.rw_flags = (const u32*)p;
+    }
+    a.n = n;
+    if ((rc = dev_alloc(s, (void**)&a.masks, mask_bytes))) goto fail;
+    if (hipMemsetAsync(a.masks, 0, mask_bytes, s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: memset failed"; goto fail; }
+    zk_launch_rekey_scan(s->stream, a);
+    if (hipMemcpyAsync(h_masks.data(), a.masks, mask_bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: the class scan failed"; goto fail; }
+    {
+        const char* e = getenv("ZK_REKEY_NO_RANKS");  // (read per open: the tests switch it inside one process)
+        rwk_build_plan(h_masks.data(), !(e && e[0] == '1'), hp);
+    }
+    a.key_words = hp.plan.key_words;
+    a.n_passes = hp.plan.n_passes;
+    a.n_ops = 1 + hp.n_kept;
+    a.ntiles = (u32)((n + 4095) / 4096);
+    if ((rc = dev_alloc(s, (void**)&d_plan, sizeof(RwkPlan)))) goto fail;
+    if (hipMemcpyAsync(d_plan, &hp.plan, sizeof(RwkPlan), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: plan upload failed"; goto fail; }
+    a.plan = d_plan;
+    {
+        const char* e = getenv("ZK_REKEY_NO_FAST");
+        const bool no_fast = e && e[0] == '1';
+        a.fast = (!no_fast && a.key_words <= 2 && a.n_passes <= 8 && n < (1ull << 30)) ? 1u : 0u;
+    }
+    a.ntiles_fast = (u32)((n + 8191) / 8192);  // k_rekey.hip RWK_SW_TILE
+    if ((rc = dev_alloc(s, (void**)&a.idx_a, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.idx_b, (size_t)n * 4))) goto fail;
+    if (a.fast) {
+        if ((rc = dev_alloc(s, (void**)&a.key64_a, (size_t)n * 8))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.key64_b, (size_t)n * 8))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.sweep, ((size_t)RWK_SWEEP_HEAD + (size_t)a.n_passes * a.ntiles_fast * 256) * 4))) goto fail;
+    } else {
+        if ((rc = dev_alloc(s, (void**)&a.keys, (size_t)a.key_words * n * 4))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.hist, (size_t)a.ntiles * 256 * 4))) goto fail;
+    }
+    a.n_jobs = (u32)hp.jobs.size();
+    if (a.n_jobs) {
+        u32 members = 0;
+        for (u32 j = 0; j < a.n_jobs; j++) { a.jobs[j] = hp.jobs[j]; members += hp.jobs[j].count; }
+        for (int f = 0; f < RWK_NFIELDS; f++)
+            if (hp.rank_field[f] && (rc = dev_alloc(s, (void**)&a.ranks[f], (size_t)n * 4))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.job_cursor, (size_t)RWK_MAX_JOBS * 4))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.job_rows, (size_t)members * 4))) goto fail;
+        if ((rc = dev_alloc(s, (void**)&a.job_vals, (size_t)members * 32))) goto fail;
+    }
+    a.ops = ops_dev;
+    a.op_flags = op_flags_dev;
+    if (!a.ops && (rc = dev_alloc(s, (void**)&a.ops, (size_t)a.n_ops * RWK_NSLOTS * 32))) goto fail;
+    if (!a.op_flags && (rc = dev_alloc(s, (void**)&a.op_flags, (size_t)a.n_ops * 4))) goto fail;
+    if ((rc = session_common_init(s))) goto fail;
+    if (n_ops_out) *n_ops_out = a.n_ops;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_state_ops_from_rw_read(zk_session* s, uint64_t* ops_host, uint32_t* op_flags_host, uint64_t* n_ops_out) {
+    ARG_TRY(s && s->kind == SESSION_REKEY, "zk_state_ops_from_rw_read: bad arguments");
+    const RekeyArgs& a = s->rekey;
+    if (n_ops_out) *n_ops_out = a.n_ops;
+    if (ops_host) HIP_TRY(hipMemcpyAsync(ops_host, a.ops, (size_t)a.n_ops * RWK_NSLOTS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (op_flags_host) HIP_TRY(hipMemcpyAsync(op_flags_host, a.op_flags, (size_t)a.n_ops * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+extern "C" int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_out, uint32_t* op_flags_out,
+                                    uint64_t* n_ops_out, uint32_t opts, uint32_t* status_out, zk_result* result) {
+    ARG_TRY(result && n_ops_out, "zk_state_ops_from_rw: null output");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_state_ops_from_rw_open(rw, rw_flags, n, dev ? ops_out : nullptr, dev ? op_flags_out : nullptr, opts, n_ops_out, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && !dev) rc = zk_state_ops_from_rw_read(s, ops_out, op_flags_out, n_ops_out);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
 // ---- secp256k1 ECDSA verification
 extern "C" int zk_ecdsa_open_batches(const zk_ecdsa_batch* bt, uint32_t n_batches, uint32_t opts, zk_session** out) {
     ARG_TRY(t_device >= 0, "zk_ecdsa_open: call zk_init first");
@@ -2034,6 +2141,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_PICOPY: zk_launch_pi_copy(s->stream, s->picopy, status, tally); break;
     case SESSION_CPA: zk_launch_copy_assign(s->stream, s->cpa, status, s->d_tally); break;
+    case SESSION_REKEY: zk_launch_state_rekey(s->stream, s->rekey, status, s->d_tally); break;
     case SESSION_EVM: {
         // the state-sorted lane mapping is derived from the step column on every pass
         if (s->evm.perm) {

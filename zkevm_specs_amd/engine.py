@@ -484,6 +484,43 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
 
 
+class RekeySession(Session):
+    """RW table -> State-circuit operations (zk_state_ops_from_rw_*): launch()/collect() like the circuits (status = one code per
+    RW row); n_ops = StartOp + the rows kept; read() -> (ops uint64[12, n_ops, 4], op_flags uint32[n_ops]) on the host."""
+
+    n_ops = 0
+
+    def read(self):
+        ops = np.empty((12, self.n_ops, 4), dtype=np.uint64)
+        flags = np.empty(self.n_ops, dtype=np.uint32)
+        check(self._lib.zk_state_ops_from_rw_read(self._h, _lib.ptr(ops), _lib.ptr(flags), None), "zk_state_ops_from_rw_read", self._lib)
+        return ops, flags
+
+
+def open_state_ops_from_rw(rw, rw_flags, ops_dev=None, op_flags_dev=None, device=None):
+    """rw uint64[n, 14, 4] + rw_flags uint32[n] (the EVM circuit's RW table) -> RekeySession.  numpy inputs are staged to HBM;
+    torch CUDA tensors are used in place, and ops_dev (a flat CUDA buffer of at least 12 * (n + 1) * 4 uint64) / op_flags_dev
+    (n + 1 uint32) then receive the op list packed for session.n_ops ops: ops_dev[: 12 * n_ops * 4].view(12, n_ops, 4) is what
+    open_state_assign takes."""
+    lib = _lib.init(device)
+    _expect(rw, "rw table", 8, (None, 14, 4))
+    n = int(rw.shape[0])
+    _expect(rw_flags, "rw_flags", 4, (n,))
+    _expect(ops_dev, "ops_dev", 8, (None,))
+    _expect(op_flags_dev, "op_flags_dev", 4, (None,))
+    if ops_dev is not None and int(ops_dev.shape[0]) < 48 * (n + 1):
+        raise ValueError("ops_dev holds fewer than 12 * (n + 1) cells")
+    if op_flags_dev is not None and int(op_flags_dev.shape[0]) < n + 1:
+        raise ValueError("op_flags_dev holds fewer than n + 1 entries")
+    (rw, rw_flags, ops_dev, op_flags_dev), opts = _prep([rw, rw_flags, ops_dev, op_flags_dev], outputs=(2, 3))
+    h, n_ops = ctypes.c_void_p(), ctypes.c_uint64()
+    check(lib.zk_state_ops_from_rw_open(_lib.ptr(rw), _lib.ptr(rw_flags), n, _lib.ptr(ops_dev), _lib.ptr(op_flags_dev), opts,
+                                        ctypes.byref(n_ops), ctypes.byref(h)), "zk_state_ops_from_rw_open")
+    s = RekeySession(h, n, (rw, rw_flags, ops_dev, op_flags_dev), lib=lib)
+    s.n_ops = int(n_ops.value)
+    return s
+
+
 class BytecodeAssignSession(Session):
     """Bytecode-witness assignment session: launch()/collect() like the circuits; rows() for the 2^k circuit rows."""
 

@@ -166,6 +166,21 @@ def state_assign(ops, op_flags, device=None):
     return Result(r), status, rows, rflags, mpt[: int(n_mpt.value)]
 
 
+def state_ops_from_rw(rw, rw_flags, device=None):
+    """zk_state_ops_from_rw -> (Result, status uint32[n] per RW row, ops uint64[12, n_ops, 4], op_flags uint32[n_ops])"""
+    lib = _lib.init(device)
+    rw, rw_flags = _c(rw), _c(rw_flags, np.uint32)
+    _expect(rw, "rw table", 8, (None, 14, 4))
+    n = int(rw.shape[0])
+    _expect(rw_flags, "rw_flags", 4, (n,))
+    ops, flags = np.zeros(12 * (n + 1) * 4, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint32)
+    status, r, n_ops = np.zeros(n, dtype=np.uint32), ZkResult(), ctypes.c_uint64()
+    check(lib.zk_state_ops_from_rw(_p(rw), _p(rw_flags), n, _p(ops), _p(flags), ctypes.byref(n_ops), 0, _p(status), ctypes.byref(r)),
+          "zk_state_ops_from_rw")
+    m = int(n_ops.value)
+    return Result(r), status, ops[: 48 * m].reshape(12, m, 4), flags[:m]
+
+
 def bytecode_assign(in_rows, offsets, lengths, k, randomness, device=None):
     """zk_bytecode_assign -> (Result, rows uint64[12, 2^k, 4])"""
     lib = _lib.init(device)
