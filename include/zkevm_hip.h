@@ -292,6 +292,16 @@ int zk_state_ops_from_rw_read(zk_session* s, uint64_t* ops_host, uint32_t* op_fl
 int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_out /* capacity n + 1 ops */,
                          uint32_t* op_flags_out, uint64_t* n_ops_out, uint32_t opts, uint32_t* status_out, zk_result* result);
 
+/* The two steps in one session — RW table in, State-circuit witness out: the re-keying and the sort as above, then
+ * assign_state_circuit / mpt_table_from_ops (zk_state_assign_open) over ops that are read straight from the RW rows through the
+ * sorted order; the op list is never written to memory.  Outputs as zk_state_assign_open's, for n_ops rows (*n_ops_out, known
+ * when this returns; buffers given with ZK_OPT_DEVICE_PTRS have capacity n_rw + 1 rows and are packed for n_ops:
+ * rows uint64[57][n_ops][4], row_flags uint32[n_ops], mpt uint64[n_mpt][12][4]).  zk_launch / zk_collect / zk_read_status
+ * (one code per OP) / zk_state_assign_read as for zk_state_assign_open; RW rows the re-keying rejects (codes above) count in
+ * the same tally, first_fail_row then being the RW row. */
+int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint64_t* rows_dev,
+                                 uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, uint64_t* n_ops_out, zk_session** out);
+
 /* ---- secp256k1 ECDSA verification: computes the `ecdsa_status` column of the Tx / Sig units
  *      on the device instead of taking it from the host.  Replaces `ECDSAVerifyChip.verify`
  *      (src/zkevm_specs/tx_circuit.py:147-158, util/ec.py:109-117), i.e. eth-keys 0.4.0's

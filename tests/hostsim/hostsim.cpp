@@ -292,7 +292,7 @@ extern "C" int sim_sign_verify(const uint8_t* bytes, const u64* cells, const u32
 #include "../../zkevm_specs_amd/csrc/state_assign.hpp"
 extern "C" int sim_state_assign(const u64* ops, const u32* op_flags, u64 n, u64* rows, u32* row_flags, u64* mpt,
                                 u64* n_mpt, u32* status) {
-    AssignArgs a;
+    AssignArgs a = {};
     a.ops = ops; a.op_flags = op_flags; a.n = n; a.rows = rows; a.row_flags = row_flags; a.mpt = mpt;
     u32 cap = 16;
     while (cap < 2 * n + 2) cap <<= 1;

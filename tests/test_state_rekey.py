@@ -122,6 +122,38 @@ def test_checker_matches_trace_generator():
     assert not any(state_oracle.verify_rows(st_rows, st_flags, mpt))
 
 
+def fused_equals_two_steps(rows, flags, device):
+    """zk_state_assign_from_rw (ops read straight from the RW rows) == zk_state_ops_from_rw followed by zk_state_assign"""
+    from zkevm_specs_amd import engine
+
+    rw = rows_to_rowmajor(rows, 14)
+    fl = np.array(flags, dtype=np.uint32)
+    _, _, ops, op_flags = oneshot.state_ops_from_rw(rw, fl, device=device)
+    r2, st2, rows2, rf2, mpt2 = oneshot.state_assign(ops, op_flags, device=device)
+    with engine.open_state_assign_from_rw(rw, fl, device=device) as a:
+        assert a.n == ops.shape[1]
+        r1 = a.run()
+        st1 = a.read_status()
+        rows1, rf1, mpt1 = a.read()
+    assert (r1.fail_count, r1.first_fail_row, r1.first_fail_code) == (r2.fail_count, r2.first_fail_row, r2.first_fail_code)
+    assert st1.tolist() == st2.tolist()
+    assert np.array_equal(rows1, rows2) and np.array_equal(rf1, rf2) and np.array_equal(mpt1, mpt2)
+
+
+def test_cpu_backend_fused_assign():
+    rng = random.Random(77)
+    rows, flags = rand_rw_table(rng, 1500, 0.0, 0.0)
+    fused_equals_two_steps(rows, flags, "cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_fused_assign():
+    rng = random.Random(78)
+    for n in (1, 70, 1500, 6000):
+        rows, flags = rand_rw_table(rng, n, 0.0, 0.0)
+        fused_equals_two_steps(rows, flags, None)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,wide,bad", CASES)
 def test_gpu_matches_checker(n, wide, bad):
@@ -199,3 +231,12 @@ def test_gpu_full_block_2p18():
     with engine.open_state(st_rows, st_flags, mpt[:n_mpt]) as st:
         r = st.run()
     assert r.ok and r.rows_evaluated == m
+    # the fused session (no op list in memory) produces the same witness
+    f_rows = torch.empty(57 * 4 * (n + 1), dtype=torch.int64, device=dev)
+    f_flags = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    f_mpt = torch.empty(48 * (n + 1), dtype=torch.int64, device=dev)
+    with engine.open_state_assign_from_rw(d_rw, d_fl, f_rows, f_flags, f_mpt) as a:
+        assert a.n == m and a.run().ok
+        assert a.n_mpt() == n_mpt
+    assert torch.equal(f_rows[: 57 * 4 * m].view(57, m, 4), st_rows) and torch.equal(f_flags[:m], st_flags)
+    assert torch.equal(f_mpt[: 48 * n_mpt].view(n_mpt, 12, 4), mpt[:n_mpt])

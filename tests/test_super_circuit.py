@@ -10,6 +10,17 @@ from tests.evm_cases import oracle_status
 from zkevm_specs_amd.super_circuit import CIRCUITS, synth_super
 
 
+
+def _block_state_ops(p):
+    """the block's State ops as the CHECKER derives them from the block's RW table (oracle/rw_state_oracle.py): what SuperCircuit
+    computes on the device (zk_state_assign_from_rw) — lists of ints, ready for assign_oracle.assign"""
+    from oracle import rw_state_oracle
+
+    ops, flags, status = rw_state_oracle.rw_to_state_ops(wire.rowmajor_to_rows(p["evm"]["rw"]), p["evm"]["rw_flags"].tolist())
+    assert not any(status)
+    return ops, flags
+
+
 def _oracle_keccak(codes, r):
     return keccak_table.table_rows(codes, r, keccak_table.MODE_CIRCUIT)[0]
 
@@ -95,9 +106,10 @@ def test_block_witness_is_one_consistent_witness():
     from zkevm_specs_amd import evm_tables as T
     assert int(T.ExecutionState.SHA3) in states and int(T.ExecutionState.CODECOPY) in states
     # State circuit over the trace's own RW rows
-    ops, flags = p["state_ops"]
-    assert ops.shape[1] == evm["rw"].shape[0] + 1 - int((evm["rw"][:, 2, 0] == 7).astype(int) @ (evm["rw"][:, 4, 0] > 24).astype(int))
-    rows, rflags, mpt, status = assign_oracle.assign(wire.colmajor_to_rows(ops), flags.tolist())
+    assert p["state_ops"] is None  # derived on the device by SuperCircuit; here by the checker
+    ops, flags = _block_state_ops(p)
+    assert len(ops) == p["rows"]["state"] == evm["rw"].shape[0] + 1 - int((evm["rw"][:, 2, 0] == 7).astype(int) @ (evm["rw"][:, 4, 0] > 24).astype(int))
+    rows, rflags, mpt, status = assign_oracle.assign(ops, flags)
     assert not any(status) and not any(state_oracle.verify_rows(rows, rflags, mpt))
     by_rwc = {r[0]: r for r in rows}
     for c in wire.rowmajor_to_rows(evm["rw"][:: 37]):
@@ -128,7 +140,6 @@ def test_block_super_circuit_on_device():
     import torch
 
     from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, SuperCircuit, synth_super_block
-    from zkevm_specs_amd.synth_block import rw_to_state_ops
 
     p = synth_super_block(16, seed=3)
     dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
@@ -148,7 +159,6 @@ def test_block_super_circuit_on_device():
     # (1) a Stack read's value: the EVM circuit (the step that looks the row up) and the State circuit (read consistency)
     i = next(j for j in range(2000, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)
     rw[i, 8, 0] ^= np.uint64(1)
-    p["state_ops"] = rw_to_state_ops(rw, p["evm"]["rw_flags"])
     res = run(p)
     assert not res["evm"].ok and not res["state"].ok and res["bytecode"].ok and res["copy"].ok and res["exp"].ok
     rw[i, 8, 0] ^= np.uint64(1)
@@ -163,11 +173,9 @@ def test_block_super_circuit_on_device():
 
     assert int(rw[j, 0, 0]) == first_rwc + 1 and int(rw[j, 2, 0]) == int(ET.Target.Memory)  # a Memory row of that event
     rw[j, 8, 0] ^= np.uint64(1)
-    p["state_ops"] = rw_to_state_ops(rw, p["evm"]["rw_flags"])
     res = run(p)
     assert not res["copy"].ok and not res["state"].ok and res["bytecode"].ok and res["exp"].ok
     rw[j, 8, 0] ^= np.uint64(1)
-    p["state_ops"] = rw_to_state_ops(rw, p["evm"]["rw_flags"])
     # (3) the exp table row an EXP step looks up: the EVM circuit only (the Exp circuit's own rows are untouched)
     p["evm"]["exp"][0, 9, 0] ^= np.uint64(1)
     res = run(p)
@@ -189,7 +197,6 @@ def test_full_size_block_every_row_of_every_circuit_vs_oracles():
     from oracle import copy_assign_oracle, copy_oracle
     from zkevm_specs_amd import evm_tables as ET
     from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, SuperCircuit, synth_super_block
-    from zkevm_specs_amd.synth_block import rw_to_state_ops
     from zkevm_specs_amd.wire import rows_to_rowmajor
 
     p = synth_super_block(20, seed=5)
@@ -229,7 +236,6 @@ def test_full_size_block_every_row_of_every_circuit_vs_oracles():
     tx, r_tx = p["tx"]
     for _ in range(30):
         tx["cells"][rng.randrange(tx["cells"].shape[0]), rng.randrange(tx["cells"].shape[1]), 0] ^= np.uint64(1)
-    p["state_ops"] = rw_to_state_ops(rw, evm["rw_flags"])
     with SuperCircuit(p) as sc:
         sc.launch()
         results, total, first = sc.collect()
@@ -237,8 +243,8 @@ def test_full_size_block_every_row_of_every_circuit_vs_oracles():
     # ---- the oracles over the same block -----------------------------------------------------------------------------
     c_rows, c_rf, c_table, c_rw, c_rwf = copy_assign_oracle.assign(wire.rowmajor_to_rows(ce["events"]), ce["flags"].tolist(), ce["data"], ce["offsets"], ce["r"])
     exp = {"evm": oracle_status(dict(evm, copy=rows_to_rowmajor(c_table, 14)))}
-    ops, flags = p["state_ops"]
-    rows, rflags, mpt, a_status = assign_oracle.assign(wire.colmajor_to_rows(ops), flags.tolist())
+    ops, flags = _block_state_ops(p)
+    rows, rflags, mpt, a_status = assign_oracle.assign(ops, flags)
     assert not any(a_status)
     exp["state"] = state_oracle.verify_rows(rows, rflags, mpt)
     ub_rows, ub_off, ub_len, k = p["bytecode_unrolled"]

@@ -907,6 +907,28 @@ extern "C" int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags
     return rc;
 }
 
+// RW table -> State rows in one session: here simply the two host passes back to back (the device reads its ops straight from
+// the RW rows; the results are the same by construction of asg_slot_rw, which tests/test_state_rekey.py checks on the device).
+extern "C" int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint64_t* rows_dev,
+                                            uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, uint64_t* n_ops_out, zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_state_assign_from_rw_open");
+    ARG_TRY(out && rw && n_rw > 0 && !rows_dev && !row_flags_dev && !mpt_dev, "zk_state_assign_from_rw_open: bad arguments");
+    zk_session* r = nullptr;
+    uint64_t n_ops = 0;
+    int rc = zk_state_ops_from_rw_open(rw, rw_flags, n_rw, nullptr, nullptr, opts, &n_ops, &r);
+    if (rc) return rc;
+    run_pass(r, nullptr);
+    if (r->fail_count) {
+        g_err = "zk_state_assign_from_rw_open: the RW table has rows the re-keying rejects (zk_state_ops_from_rw reports them)";
+        zk_close(r);
+        return -1;
+    }
+    rc = zk_state_assign_open(r->a64[1].data(), r->out32.data(), n_ops, nullptr, nullptr, nullptr, opts, out);
+    zk_close(r);
+    if (!rc && n_ops_out) *n_ops_out = n_ops;
+    return rc;
+}
+
 static void bytecode_assign_pass(zk_session* s) {
     BcaArgs& a = s->bca;
     for (u64 c = 0; c < a.n_chunks; c++) bca_chunk(a, c);

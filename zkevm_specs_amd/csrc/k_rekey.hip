@@ -423,7 +423,7 @@ void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTa
             kin = kbufs[p & 1u];
             iin = ibufs[p & 1u];
         }
-        hipLaunchKernelGGL(rwk_emit_kernel, dim3((u32)((a.n_ops + RWK_BLOCK - 1) / RWK_BLOCK)), dim3(RWK_BLOCK), 0, st, a, iin);
+        if (a.ops) hipLaunchKernelGGL(rwk_emit_kernel, dim3((u32)((a.n_ops + RWK_BLOCK - 1) / RWK_BLOCK)), dim3(RWK_BLOCK), 0, st, a, iin);
         return;
     }
     hipLaunchKernelGGL(rwk_pack_kernel, dim3(grid), dim3(RWK_BLOCK), 0, st, a, status, tally);
@@ -436,5 +436,5 @@ void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTa
         hipLaunchKernelGGL(rwk_scatter_kernel, dim3(a.ntiles), dim3(RWK_BLOCK), 0, st, a, in, out, word, shift);
         in = out;
     }
-    hipLaunchKernelGGL(rwk_emit_kernel, dim3((u32)((a.n_ops + RWK_BLOCK - 1) / RWK_BLOCK)), dim3(RWK_BLOCK), 0, st, a, in);
+    if (a.ops) hipLaunchKernelGGL(rwk_emit_kernel, dim3((u32)((a.n_ops + RWK_BLOCK - 1) / RWK_BLOCK)), dim3(RWK_BLOCK), 0, st, a, in);
 }

@@ -17,6 +17,7 @@
 // computed with wave ballots + one small single-block scan over per-block partials (zkevm_hip.hip).
 #pragma once
 #include "common.hpp"
+#include "state_rekey.hpp"
 
 enum { ASG_NSLOTS = 12, ASG_ROW_NCELLS = 57, ASG_MPT_NCELLS = 12 };
 enum { ASG_RWC = 0, ASG_RW, ASG_TAG, ASG_ID, ASG_ADDR, ASG_FT, ASG_KEY, ASG_VLO, ASG_VHI, ASG_ILO, ASG_IHI, ASG_LEX };
@@ -28,6 +29,11 @@ struct AssignArgs {
     const u64* ops;      // [12][n][4] column-major
     const u32* op_flags; // [n] bit0 value.is_word, bit1 initial_value.is_word, bit2 field_tag is an AccountFieldTag
     u64 n;
+    // The ops may also be read straight from an EVM-circuit RW table through the sorted order of its rows (state_rekey.hpp:
+    // zk_state_assign_from_rw): op 0 = StartOp, op i = the re-keyed RW row order[i - 1]; `ops` / `op_flags` are then unused.
+    const u64* rw;       // [n_rw][14][4] or nullptr
+    const u32* rw_flags; // [n_rw] or nullptr
+    const u32* order;    // [n - 1]
     u64* rows;           // out [57][n][4]
     u32* row_flags;      // out [n]
     u64* mpt;            // out [n_mpt][12][4] (capacity n rows), first-occurrence order
@@ -40,7 +46,44 @@ struct AssignArgs {
     u32* blk_next;       // [nb + 1] smallest keyed op index per block -> min over the blocks AFTER b
 };
 
-ZK_HD Fr asg_slot(const AssignArgs& a, u32 s, u64 i) { return fr_load(a.ops + ((u64)s * a.n + i) * 4); }
+// Slot s of op i when the ops are the re-keyed rows of an RW table (the mapping of rwk_key / rwk_op, one slot at a time: `s` is a
+// compile-time constant at every call site, so only that slot's cells are loaded).
+ZK_HD Fr asg_slot_rw(const AssignArgs& a, u32 s, u64 i) {
+    if (i == 0) return s == ASG_TAG ? fr_from_u64(1) : fr_zero();  // StartOp (rwk_emit_start)
+    const u64* p = a.rw + (u64)a.order[i - 1] * (RWK_RW_NCELLS * 4);
+    if (s == ASG_RWC) return rwk_cell(p, 0);
+    if (s == ASG_RW) return rwk_cell(p, 1);
+    if (s == ASG_VLO) return rwk_cell(p, 8);
+    if (s == ASG_VHI) return rwk_cell(p, 9);
+    if (s == ASG_LEX) return fr_from_u64(1);
+    const u32 tag = rwk_tag_of_target(rwk_cell(p, 2).v[0]);  // (rows in `order` hold one of Target's values)
+    if (s == ASG_TAG) return fr_from_u64(tag);
+    if (s == ASG_ID) return tag == 6u ? fr_zero() : rwk_cell(p, 3);
+    if (s == ASG_ILO) return (tag == 4u || tag == 6u) ? rwk_cell(p, 12) : fr_zero();
+    if (s == ASG_IHI) return (tag == 4u || tag == 6u) ? rwk_cell(p, 13) : fr_zero();
+    if (s == ASG_KEY && tag != 10u) {
+        Fr key = rwk_cell(p, 6);
+        const Fr khi = rwk_cell(p, 7);
+        key.v[4] |= khi.v[0]; key.v[5] |= khi.v[1]; key.v[6] |= khi.v[2]; key.v[7] |= khi.v[3];
+        return key;
+    }
+    if (s == ASG_FT && tag != 5u && tag != 10u) return rwk_cell(p, 5);
+    const Fr c4 = rwk_cell(p, 4);
+    if (s == ASG_ADDR) return tag == 5u ? fr_zero() : (tag == 10u ? rwk_shr(c4, 48) : c4);
+    if (s == ASG_FT) return tag == 5u ? c4 : fr_from_u64((u64)(c4.v[1] & 0xffffu));
+    return fr_from_u64((u64)c4.v[0]);  // ASG_KEY of a TxLog row
+}
+ZK_HD Fr asg_slot(const AssignArgs& a, u32 s, u64 i) {
+    if (a.rw) return asg_slot_rw(a, s, i);
+    return fr_load(a.ops + ((u64)s * a.n + i) * 4);
+}
+ZK_HD u32 asg_flags(const AssignArgs& a, u64 i) {
+    if (!a.rw) return a.op_flags[i];
+    if (i == 0) return 0u;
+    const u32 r = a.order[i - 1];
+    const u32 tag = rwk_tag_of_target(rwk_cell(a.rw + (u64)r * (RWK_RW_NCELLS * 4), 2).v[0]);
+    return ((a.rw_flags ? a.rw_flags[r] : 0u) & 1u) | ((tag == 4u || tag == 6u) ? 2u : 0u) | (tag == 6u ? 4u : 0u);
+}
 // FQ(int) of a 256-bit Python int: x < 2^256 < 6p
 ZK_HD Fr asg_reduce(Fr x) {
     const Fr p = fr_modulus();
@@ -148,9 +191,11 @@ ZK_HD u32 asg_mock_status(u32 flags, const Fr& ft, const Fr& vlo, const Fr& vhi,
 // root lo/hi, root_prev lo/hi, value lo/hi, value_prev lo/hi.
 ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
     u64* out = a.mpt + (u64)r * (ASG_MPT_NCELLS * 4);
-    const u32 flags = a.op_flags[i];
+    const u32 flags = asg_flags(a, i);
     const Fr ft = asg_slot(a, ASG_FT, i);
     const Fr key = asg_slot(a, ASG_KEY, i);
+    const Fr vlo = asg_slot(a, ASG_VLO, i), vhi = asg_slot(a, ASG_VHI, i);
+    const Fr ilo = asg_slot(a, ASG_ILO, i), ihi = asg_slot(a, ASG_IHI, i);
     asg_store(out + 0, asg_reduce(asg_slot(a, ASG_ADDR, i)));
     // isinstance(field_tag, AccountFieldTag) -> from_account_field_tag (table.py:341-350: Nonce..NonExisting -> 1..4), else StorageMod
     asg_store_u64(out + 4, (flags & 4u) ? fr_lo64(ft) : 6ull);
@@ -162,10 +207,10 @@ ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
     asg_store_u64(out + 24, root_prev);
     asg_store_u64(out + 28, 0);
     Fr lo, hi;
-    asg_word_of(asg_slot(a, ASG_VLO, i), asg_slot(a, ASG_VHI, i), lo, hi);
+    asg_word_of(vlo, vhi, lo, hi);
     asg_store(out + 32, lo);
     asg_store(out + 36, hi);
-    asg_word_of(asg_slot(a, ASG_ILO, i), asg_slot(a, ASG_IHI, i), lo, hi);
+    asg_word_of(ilo, ihi, lo, hi);
     asg_store(out + 40, lo);
     asg_store(out + 44, hi);
 }
@@ -175,16 +220,18 @@ ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     const u64 n = a.n;
     u64* rows = a.rows;
 #define ASG_OUT(c) (rows + ((u64)(c) * n + i) * 4)
-    const u32 flags = a.op_flags[i];
+    const u32 flags = asg_flags(a, i);
     const Fr addr = asg_slot(a, ASG_ADDR, i);
     const Fr key = asg_slot(a, ASG_KEY, i);
     const Fr ft = asg_slot(a, ASG_FT, i);
     const Fr vlo = asg_slot(a, ASG_VLO, i), vhi = asg_slot(a, ASG_VHI, i);
     const Fr ilo = asg_slot(a, ASG_ILO, i), ihi = asg_slot(a, ASG_IHI, i);
-    asg_store(ASG_OUT(0), asg_reduce(asg_slot(a, ASG_RWC, i)));
-    asg_store_u64(ASG_OUT(1), fr_is_zero(asg_slot(a, ASG_RW, i)) ? 0 : 1);  // `op.rw == RW.Read` :829
-    asg_store(ASG_OUT(2), asg_reduce(asg_slot(a, ASG_TAG, i)));
-    asg_store(ASG_OUT(3), asg_reduce(asg_slot(a, ASG_ID, i)));
+    const Fr rwc = asg_slot(a, ASG_RWC, i), rw = asg_slot(a, ASG_RW, i), tag = asg_slot(a, ASG_TAG, i), id = asg_slot(a, ASG_ID, i);
+    const Fr lex = asg_slot(a, ASG_LEX, i);  // (every slot is read before the first store: the stores may alias the loads for the compiler)
+    asg_store(ASG_OUT(0), asg_reduce(rwc));
+    asg_store_u64(ASG_OUT(1), fr_is_zero(rw) ? 0 : 1);  // `op.rw == RW.Read` :829
+    asg_store(ASG_OUT(2), asg_reduce(tag));
+    asg_store(ASG_OUT(3), asg_reduce(id));
     asg_store(ASG_OUT(4), asg_reduce(addr));
     asg_store(ASG_OUT(5), asg_reduce(ft));
     asg_store(ASG_OUT(6), u256_lo(key));
@@ -199,7 +246,7 @@ ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     asg_store(ASG_OUT(53), ihi);
     asg_store_u64(ASG_OUT(54), root);
     asg_store_u64(ASG_OUT(55), 0);
-    asg_store(ASG_OUT(56), asg_slot(a, ASG_LEX, i));
+    asg_store(ASG_OUT(56), lex);
 #undef ASG_OUT
     a.row_flags[i] = flags & 3u;
     u32 code = is_first ? asg_mock_status(flags, ft, vlo, vhi, ilo, ihi) : 0u;

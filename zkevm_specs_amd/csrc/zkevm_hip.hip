@@ -545,6 +545,8 @@ struct zk_session {
     PiArgs pi;
     PiCopyArgs picopy;
     RekeyArgs rekey;
+    bool assign_from_rw = false;  // SESSION_ASSIGN over an RW table: every pass starts with the re-keying and the sort (rekey)
+    u32* rekey_status = nullptr;  // ... whose per-RW-row codes go here (the session's statuses are per op)
     u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
     u32* d_cursor = nullptr; // EVM: per-bin scatter cursors (cleared by every histogram pass)
@@ -1440,6 +1442,79 @@ extern "C" int zk_state_assign(const uint64_t* ops, const uint32_t* op_flags, ui
 
 // ---- RW table -> State-circuit operations (state_rekey.hpp)
 #include "state_rekey_plan.hpp"
+// Stage the RW table, run the class scan, build the plan and allocate the sort's buffers (s->rekey); with want_ops the op list's
+// buffers too (ops_dev / op_flags_dev: the caller's, or session-owned when null).  s->n is left to the caller.
+static int rekey_setup(zk_session* s, const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, bool dev, bool want_ops,
+                       uint64_t* ops_dev, uint32_t* op_flags_dev) {
+    RekeyArgs& a = s->rekey;
+    memset(&a, 0, sizeof(a));
+    int rc = 0;
+    const void* p = nullptr;
+    RwkHostPlan hp;
+    std::vector<u32> h_masks(2 * RWK_MASK_WORDS_H + RWK_NCLASSES);
+    const size_t mask_bytes = h_masks.size() * 4;
+    RwkPlan* d_plan = nullptr;
+    if ((rc = stage(s, rw, (size_t)n * RWK_RW_NCELLS * 32, dev, &p))) return rc;
+    a.rw = (const u64*)p;
+    if (rw_flags) {
+        if ((rc = stage(s, rw_flags, (size_t)n * 4, dev, &p))) return rc;
+        a.rw_flags = (const u32*)p;
+    }
+    a.n = n;
+    if ((rc = dev_alloc(s, (void**)&a.masks, mask_bytes))) return rc;
+    HIP_TRY(hipMemsetAsync(a.masks, 0, mask_bytes, s->stream));
+    zk_launch_rekey_scan(s->stream, a);
+    HIP_TRY(hipMemcpyAsync(h_masks.data(), a.masks, mask_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    {
+        const char* e = getenv("ZK_REKEY_NO_RANKS");  // (read per open: the tests switch it inside one process)
+        rwk_build_plan(h_masks.data(), !(e && e[0] == '1'), hp);
+    }
+    a.key_words = hp.plan.key_words;
+    a.n_passes = hp.plan.n_passes;
+    a.n_ops = 1 + hp.n_kept;
+    a.ntiles = (u32)((n + 4095) / 4096);
+    if ((rc = dev_alloc(s, (void**)&d_plan, sizeof(RwkPlan)))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_plan, &hp.plan, sizeof(RwkPlan), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));  // (hp lives on this stack frame)
+    a.plan = d_plan;
+    {
+        const char* e = getenv("ZK_REKEY_NO_FAST");
+        const bool no_fast = e && e[0] == '1';
+        a.fast = (!no_fast && a.key_words <= 2 && a.n_passes <= 8 && n < (1ull << 30)) ? 1u : 0u;
+    }
+    a.ntiles_fast = (u32)((n + 8191) / 8192);  // k_rekey.hip RWK_SW_TILE
+    if ((rc = dev_alloc(s, (void**)&a.idx_a, (size_t)n * 4))) return rc;
+    if ((rc = dev_alloc(s, (void**)&a.idx_b, (size_t)n * 4))) return rc;
+    if (a.fast) {
+        if ((rc = dev_alloc(s, (void**)&a.key64_a, (size_t)n * 8))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.key64_b, (size_t)n * 8))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.sweep, ((size_t)RWK_SWEEP_HEAD + (size_t)a.n_passes * a.ntiles_fast * 256) * 4))) return rc;
+    } else {
+        if ((rc = dev_alloc(s, (void**)&a.keys, (size_t)a.key_words * n * 4))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.hist, (size_t)a.ntiles * 256 * 4))) return rc;
+    }
+    a.n_jobs = (u32)hp.jobs.size();
+    if (a.n_jobs) {
+        u32 members = 0;
+        for (u32 j = 0; j < a.n_jobs; j++) { a.jobs[j] = hp.jobs[j]; members += hp.jobs[j].count; }
+        for (int f = 0; f < RWK_NFIELDS; f++)
+            if (hp.rank_field[f] && (rc = dev_alloc(s, (void**)&a.ranks[f], (size_t)n * 4))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.job_cursor, (size_t)RWK_MAX_JOBS * 4))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.job_rows, (size_t)members * 4))) return rc;
+        if ((rc = dev_alloc(s, (void**)&a.job_vals, (size_t)members * 32))) return rc;
+    }
+    if (want_ops) {
+        a.ops = ops_dev;
+        a.op_flags = op_flags_dev;
+        if (!a.ops && (rc = dev_alloc(s, (void**)&a.ops, (size_t)a.n_ops * RWK_NSLOTS * 32))) return rc;
+        if (!a.op_flags && (rc = dev_alloc(s, (void**)&a.op_flags, (size_t)a.n_ops * 4))) return rc;
+    }
+    return 0;
+}
+// the index buffer the last radix pass of a rekey session writes: the sorted order of the kept rows (then the left-out ones)
+static const u32* rekey_order(const RekeyArgs& a) { return ((a.n_passes - 1u) & 1u) ? a.idx_b : a.idx_a; }
+
 extern "C" int zk_state_ops_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint64_t* ops_dev, uint32_t* op_flags_dev,
                                          uint32_t opts, uint64_t* n_ops_out, zk_session** out) {
     ARG_TRY(t_device >= 0, "zk_state_ops_from_rw_open: call zk_init first");
@@ -1450,70 +1525,52 @@ extern "C" int zk_state_ops_from_rw_open(const uint64_t* rw, const uint32_t* rw_
     zk_session* s = new zk_session();
     s->kind = SESSION_REKEY;
     s->n = n;
-    RekeyArgs& a = s->rekey;
-    memset(&a, 0, sizeof(a));
-    int rc = 0;
-    const void* p = nullptr;
-    RwkHostPlan hp;
-    std::vector<u32> h_masks(2 * RWK_MASK_WORDS_H + RWK_NCLASSES);
-    const size_t mask_bytes = h_masks.size() * 4;
-    RwkPlan* d_plan = nullptr;
-    if ((rc = stage(s, rw, (size_t)n * RWK_RW_NCELLS * 32, dev, &p))) goto fail;
-    a.rw = (const u64*)p;
-    if (rw_flags) {
-        if ((rc = stage(s, rw_flags, (size_t)n * 4, dev, &p))) goto fail;
-        a.rw_flags = (const u32*)p;
-    }
+    int rc = rekey_setup(s, rw, rw_flags, n, dev, true, ops_dev, op_flags_dev);
+    if (!rc) rc = session_common_init(s);
+    if (rc) { zk_close(s); return rc; }
+    if (n_ops_out) *n_ops_out = s->rekey.n_ops;
+    *out = s;
+    return 0;
+}
+// RW table -> State-circuit rows in one session: the re-keying and the sort as above, then the witness assignment reads its ops
+// straight from the RW rows through the sorted order (state_assign.hpp asg_slot_rw): the op list is never materialised.
+extern "C" int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint64_t* rows_dev,
+                                            uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, uint64_t* n_ops_out, zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_state_assign_from_rw_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(out && rw && n_rw > 0 && n_rw < (1ull << 31) - 1, "zk_state_assign_from_rw_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    ARG_TRY(dev || (!rows_dev && !row_flags_dev && !mpt_dev), "zk_state_assign_from_rw_open: output buffers need ZK_OPT_DEVICE_PTRS");
+    zk_session* s = new zk_session();
+    s->kind = SESSION_ASSIGN;
+    int rc = rekey_setup(s, rw, rw_flags, n_rw, dev, false, nullptr, nullptr);
+    if (rc) { zk_close(s); return rc; }
+    const u64 n = s->rekey.n_ops;
+    s->n = n;
+    s->assign_from_rw = true;
+    AssignArgs& a = s->assign;
+    u32 cap = 16;
     a.n = n;
-    if ((rc = dev_alloc(s, (void**)&a.masks, mask_bytes))) goto fail;
-    if (hipMemsetAsync(a.masks, 0, mask_bytes, s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: memset failed"; goto fail; }
-    zk_launch_rekey_scan(s->stream, a);
-    if (hipMemcpyAsync(h_masks.data(), a.masks, mask_bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-        hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: the class scan failed"; goto fail; }
-    {
-        const char* e = getenv("ZK_REKEY_NO_RANKS");  // (read per open: the tests switch it inside one process)
-        rwk_build_plan(h_masks.data(), !(e && e[0] == '1'), hp);
-    }
-    a.key_words = hp.plan.key_words;
-    a.n_passes = hp.plan.n_passes;
-    a.n_ops = 1 + hp.n_kept;
-    a.ntiles = (u32)((n + 4095) / 4096);
-    if ((rc = dev_alloc(s, (void**)&d_plan, sizeof(RwkPlan)))) goto fail;
-    if (hipMemcpyAsync(d_plan, &hp.plan, sizeof(RwkPlan), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
-        hipStreamSynchronize(s->stream) != hipSuccess) { rc = -2; g_err = "zk_state_ops_from_rw_open: plan upload failed"; goto fail; }
-    a.plan = d_plan;
-    {
-        const char* e = getenv("ZK_REKEY_NO_FAST");
-        const bool no_fast = e && e[0] == '1';
-        a.fast = (!no_fast && a.key_words <= 2 && a.n_passes <= 8 && n < (1ull << 30)) ? 1u : 0u;
-    }
-    a.ntiles_fast = (u32)((n + 8191) / 8192);  // k_rekey.hip RWK_SW_TILE
-    if ((rc = dev_alloc(s, (void**)&a.idx_a, (size_t)n * 4))) goto fail;
-    if ((rc = dev_alloc(s, (void**)&a.idx_b, (size_t)n * 4))) goto fail;
-    if (a.fast) {
-        if ((rc = dev_alloc(s, (void**)&a.key64_a, (size_t)n * 8))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.key64_b, (size_t)n * 8))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.sweep, ((size_t)RWK_SWEEP_HEAD + (size_t)a.n_passes * a.ntiles_fast * 256) * 4))) goto fail;
-    } else {
-        if ((rc = dev_alloc(s, (void**)&a.keys, (size_t)a.key_words * n * 4))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.hist, (size_t)a.ntiles * 256 * 4))) goto fail;
-    }
-    a.n_jobs = (u32)hp.jobs.size();
-    if (a.n_jobs) {
-        u32 members = 0;
-        for (u32 j = 0; j < a.n_jobs; j++) { a.jobs[j] = hp.jobs[j]; members += hp.jobs[j].count; }
-        for (int f = 0; f < RWK_NFIELDS; f++)
-            if (hp.rank_field[f] && (rc = dev_alloc(s, (void**)&a.ranks[f], (size_t)n * 4))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.job_cursor, (size_t)RWK_MAX_JOBS * 4))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.job_rows, (size_t)members * 4))) goto fail;
-        if ((rc = dev_alloc(s, (void**)&a.job_vals, (size_t)members * 32))) goto fail;
-    }
-    a.ops = ops_dev;
-    a.op_flags = op_flags_dev;
-    if (!a.ops && (rc = dev_alloc(s, (void**)&a.ops, (size_t)a.n_ops * RWK_NSLOTS * 32))) goto fail;
-    if (!a.op_flags && (rc = dev_alloc(s, (void**)&a.op_flags, (size_t)a.n_ops * 4))) goto fail;
+    a.rw = s->rekey.rw;
+    a.rw_flags = s->rekey.rw_flags;
+    a.order = rekey_order(s->rekey);
+    a.nb = (u32)((n + ASG_BLOCK - 1) / ASG_BLOCK);
+    a.rows = rows_dev;
+    a.row_flags = row_flags_dev;
+    a.mpt = mpt_dev;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * ASG_ROW_NCELLS * 32))) goto fail;
+    if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)n * 4))) goto fail;
+    if (!a.mpt && (rc = dev_alloc(s, (void**)&a.mpt, (size_t)n * ASG_MPT_NCELLS * 32))) goto fail;
+    while (cap < 2 * n + 2) cap <<= 1;
+    a.mask = cap - 1;
+    if ((rc = dev_alloc(s, (void**)&a.slots, (size_t)cap * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.first, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.rank, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_cnt, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_next, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->rekey_status, (size_t)n_rw * 4))) goto fail;
     if ((rc = session_common_init(s))) goto fail;
-    if (n_ops_out) *n_ops_out = a.n_ops;
+    if (n_ops_out) *n_ops_out = n;
     *out = s;
     return 0;
 fail:
@@ -2135,7 +2192,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_SIGN: zk_launch_sign_units(s->stream, s->sign, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_EXP: zk_launch_exp_rows(s->stream, s->exp, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_KECCAK: zk_launch_keccak_table(s->stream, s->keccak_gen, status, s->d_tally); break;
-    case SESSION_ASSIGN: zk_launch_state_assign(s->stream, s->assign, status, s->d_tally); break;
+    case SESSION_ASSIGN:
+        if (s->assign_from_rw) zk_launch_state_rekey(s->stream, s->rekey, s->rekey_status, s->d_tally);  // rejected RW rows count in the same tally
+        zk_launch_state_assign(s->stream, s->assign, status, s->d_tally);
+        break;
     case SESSION_ECDSA: zk_launch_ecdsa(s->stream, s->ecdsa, status, s->d_tally); break;
     case SESSION_BCA: zk_launch_bytecode_assign(s->stream, s->bca, status, s->d_tally); break;
     case SESSION_PI: zk_launch_pi_rows(s->stream, s->pi, range_lo(s), range_hi(s), status, tally); break;

@@ -484,6 +484,27 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
 
 
+def open_state_assign_from_rw(rw, rw_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None):
+    """rw uint64[n, 14, 4] + rw_flags uint32[n] (the EVM circuit's RW table) -> AssignSession over the n_ops = 1 + kept rows State
+    rows (session.n): re-keying + sort + witness assignment in one session, the op list never materialised
+    (zk_state_assign_from_rw_open).  With CUDA tensors, rows_dev / row_flags_dev / mpt_dev are FLAT buffers of capacity
+    57 * (n + 1) * 4 / n + 1 / (n + 1) * 12 * 4 receiving the outputs packed for n_ops: rows_dev[: 57 * n_ops * 4].view(57, n_ops, 4)
+    etc. are what open_state takes."""
+    lib = _lib.init(device)
+    _expect(rw, "rw table", 8, (None, 14, 4))
+    n = int(rw.shape[0])
+    _expect(rw_flags, "rw_flags", 4, (n,))
+    for buf, name, size, cap in ((rows_dev, "rows_dev", 8, 57 * 4 * (n + 1)), (row_flags_dev, "row_flags_dev", 4, n + 1), (mpt_dev, "mpt_dev", 8, 48 * (n + 1))):
+        _expect(buf, name, size, (None,))
+        if buf is not None and int(buf.shape[0]) < cap:
+            raise ValueError(f"{name} holds fewer than {cap} entries")
+    (rw, rw_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([rw, rw_flags, rows_dev, row_flags_dev, mpt_dev], outputs=(2, 3, 4))
+    h, n_ops = ctypes.c_void_p(), ctypes.c_uint64()
+    check(lib.zk_state_assign_from_rw_open(_lib.ptr(rw), _lib.ptr(rw_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev), _lib.ptr(mpt_dev),
+                                           opts, ctypes.byref(n_ops), ctypes.byref(h)), "zk_state_assign_from_rw_open")
+    return AssignSession(h, int(n_ops.value), (rw, rw_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
+
+
 class RekeySession(Session):
     """RW table -> State-circuit operations (zk_state_ops_from_rw_*): launch()/collect() like the circuits (status = one code per
     RW row); n_ops = StartOp + the rows kept; read() -> (ops uint64[12, n_ops, 4], op_flags uint32[n_ops]) on the host."""

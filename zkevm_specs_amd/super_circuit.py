@@ -86,12 +86,13 @@ def synth_super(log_total=20, seed=5, keccak_rows_of=None):
 
 def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None, n_steps=None):
     """BASELINE config 5 over ONE consistent witness (synth_block.py): the State circuit's rows ARE the EVM trace's RW table
-    (re-keyed with the explicit Target -> Tag / key-slot mapping of synth_block.rw_to_state_ops and re-sorted), the Bytecode
+    (re-keyed with the explicit Target -> Tag / key-slot mapping of csrc/state_rekey.hpp and re-sorted ON THE DEVICE by SuperCircuit:
+    `state_ops` is None here), the Bytecode
     circuit's rows are the contracts the trace executes (their code hashes the keccak digests of the device-built keccak
     table), plus a Copy circuit (copy events expanded on the device, zk_copy_assign) and an Exp circuit — about 2^log_total
     rows in total: the EVM share is sized so that its RW table (about 2.9 rows per step) fits.  Returns the dict
     SuperCircuit takes; `rows` has the six circuits."""
-    from .synth_block import rw_to_state_ops, synth_block_codes, synth_block_trace
+    from .synth_block import synth_block_codes, synth_block_trace
 
     assert log_total >= 12
     total = 1 << log_total
@@ -130,7 +131,9 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None,
     evm["keccak"] = sha3_rows  # the EVM circuit's keccak table: the SHA3 steps' rows (execution/sha3.py:31)
     # evm["exp"] (the exp table of the EXP steps) came with the trace; evm["copy"] is produced by the copy assignment (SuperCircuit)
     copy_ev["from_trace"] = True  # the Copy circuit looks up the BLOCK's RW / bytecode tables, not tables of its own
-    ops, op_flags = rw_to_state_ops(evm["rw"], evm["rw_flags"])
+    # State rows: 1 StartOp + one per RW row the State circuit can carry (CallContext field tags above its MAX_FIELD_TAG are left out,
+    # csrc/state_rekey.hpp); the ops themselves are derived on the device from evm["rw"] (zk_state_assign_from_rw), not here
+    n_state = 1 + int(evm["rw"].shape[0]) - int(np.count_nonzero((evm["rw"][:, 2, 0] == 7) & (evm["rw"][:, 4, 0] > 24)))
     digest = dict(zip(codes, hashes))
     bc_rows, bc_keccak = synth_bytecode_witness(codes, k, r, digest=lambda c: digest[c])
     tx = synth_tx_witness(n_tx, r, seed=seed + 1)
@@ -140,8 +143,8 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None,
     offsets = np.array(starts, dtype=np.uint64)
     lengths = (offsets[1:] - offsets[:-1] - np.uint64(1)).astype(np.uint64)
     n_exp = int(exp_rows.shape[1])
-    rows = {"evm": n_steps - 1, "state": int(ops.shape[1]), "bytecode": 1 << k, "tx": n_tx, "copy": int(copy_ev["n_rows"]), "exp": n_exp}
-    return {"codes": codes, "evm": evm, "state_ops": (ops, op_flags), "bytecode": (bc_rows, keccak, r), "bytecode_unrolled": (bt, offsets, lengths, k),
+    rows = {"evm": n_steps - 1, "state": n_state, "bytecode": 1 << k, "tx": n_tx, "copy": int(copy_ev["n_rows"]), "exp": n_exp}
+    return {"codes": codes, "evm": evm, "state_ops": None, "bytecode": (bc_rows, keccak, r), "bytecode_unrolled": (bt, offsets, lengths, k),
             "tx": (tx, r), "copy_events": copy_ev, "exp_rows": exp_rows, "rows": rows,
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True, copy_exp_rows_from_trace=True)}
 
@@ -167,15 +170,41 @@ class SuperCircuit:
         dev = lambda x: x if (_on_device(x) or x is None) else to_dev_fn(x)  # noqa: E731  (replicated tensors arrive on the device)
         rank, world = shard if shard is not None else (0, 1)
         self._keep = []
-        ops, op_flags = (dev(a) for a in parts["state_ops"])
+        evm_w = {k: dev(v) for k, v in parts["evm"].items()}
+        on_dev = hasattr(evm_w["steps"], "is_cuda")
+        odev = evm_w["steps"].device if on_dev else None
+        self.state_from_rw = parts.get("state_ops") is None
+        if self.state_from_rw:
+            # State rows: the block's own RW table re-keyed, sorted and assigned on the device in one session (zk_state_assign_from_rw:
+            # Target -> Tag / key slots, LSD radix sort on (tag, id, address, field_tag, storage_key, rw_counter), op2row) — no host step
+            ops = op_flags = None
+            if on_dev:
+                import torch
+
+                n_rw = int(evm_w["rw"].shape[0])
+                rows_b = torch.empty(57 * 4 * (n_rw + 1), dtype=torch.int64, device=evm_w["rw"].device)
+                flags_b = torch.empty(n_rw + 1, dtype=torch.int32, device=evm_w["rw"].device)
+                mpt_b = torch.empty(48 * (n_rw + 1), dtype=torch.int64, device=evm_w["rw"].device)
+                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], rows_b, flags_b, mpt_b, device=device) as a:
+                    res = a.run()
+                    n, m = a.n, a.n_mpt()
+                rows, flags, mpt = rows_b[: 57 * 4 * n].view(57, n, 4), flags_b[:n], mpt_b[: 48 * m].view(m, 12, 4)
+            else:
+                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], device=device) as a:
+                    res = a.run()
+                    rows, flags, mpt = a.read()
+        else:
+            ops, op_flags = (dev(a) for a in parts["state_ops"])
         # State rows: assigned on the device from the op list, then evaluated from the same HBM buffers
-        if hasattr(ops, "is_cuda"):
+        if self.state_from_rw:
+            pass
+        elif on_dev:
             import torch
 
             n = int(ops.shape[1])
-            rows = torch.empty((57, n, 4), dtype=torch.int64, device=ops.device)
-            flags = torch.empty(n, dtype=torch.int32, device=ops.device)
-            mpt = torch.empty((n, 12, 4), dtype=torch.int64, device=ops.device)
+            rows = torch.empty((57, n, 4), dtype=torch.int64, device=odev)
+            flags = torch.empty(n, dtype=torch.int32, device=odev)
+            mpt = torch.empty((n, 12, 4), dtype=torch.int64, device=odev)
             with engine.open_state_assign(ops, op_flags, rows, flags, mpt, device=device) as a:
                 res = a.run()
                 m = a.n_mpt()
@@ -191,7 +220,7 @@ class SuperCircuit:
         # Bytecode circuit rows: assigned on the device from the EVM circuit's own bytecode table
         ub_rows, ub_off, ub_len, k = parts["bytecode_unrolled"]
         d_ub = dev(ub_rows)
-        if hasattr(d_ub, "is_cuda"):
+        if on_dev:
             import torch
 
             bc_rows = torch.empty((12, 1 << k, 4), dtype=torch.int64, device=d_ub.device)
@@ -209,17 +238,17 @@ class SuperCircuit:
         copy_open = None
         if "copy_events" in parts and int(parts["copy_events"]["events"].shape[0]) > 0:  # (a block without copy events has no Copy circuit rows)
             ce = parts["copy_events"]
-            ev, fl, da, of = dev(ce["events"]), dev(ce["flags"]), (dev(ce["data"].view(np.int16)) if hasattr(ops, "is_cuda") else ce["data"]), dev(ce["offsets"])
-            if hasattr(ops, "is_cuda"):
+            ev, fl, da, of = dev(ce["events"]), dev(ce["flags"]), (dev(ce["data"].view(np.int16)) if on_dev else ce["data"]), dev(ce["offsets"])
+            if on_dev:
                 import torch
 
                 h_ev, h_fl, h_da, h_of = (x.cpu().numpy() if hasattr(x, "is_cuda") else x for x in (ce["events"], ce["flags"], ce["data"], ce["offsets"]))
                 n_rows, n_table, n_rw = engine.copy_assign_sizes(h_ev.view(np.uint64), h_fl.view(np.uint32), h_da.view(np.uint16), h_of.view(np.uint64), device)
-                c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device=ops.device)
-                c_rf = torch.empty(n_rows, dtype=torch.int32, device=ops.device)
-                c_table = torch.empty((n_table, 14, 4), dtype=torch.int64, device=ops.device)
-                c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=ops.device)
-                c_rwf = torch.empty(n_rw, dtype=torch.int32, device=ops.device)
+                c_rows = torch.empty((20, n_rows, 4), dtype=torch.int64, device=odev)
+                c_rf = torch.empty(n_rows, dtype=torch.int32, device=odev)
+                c_table = torch.empty((n_table, 14, 4), dtype=torch.int64, device=odev)
+                c_rw = torch.empty((n_rw, 14, 4), dtype=torch.int64, device=odev)
+                c_rwf = torch.empty(n_rw, dtype=torch.int32, device=odev)
                 with engine.open_copy_assign(ev, fl, da, of, ce["r"], c_rows, c_rf, c_table, c_rw, c_rwf, device=device) as a:
                     res = a.run()
                 if not res.ok:
@@ -232,7 +261,6 @@ class SuperCircuit:
                     c_rows, c_rf, c_table, c_rw, c_rwf = a.read()
             copy_open = (c_rows, c_rf, c_table, c_rw, c_rwf, ce)
         tx, r_tx = parts["tx"]
-        evm_w = {k: dev(v) for k, v in parts["evm"].items()}
         if copy_open is not None and copy_open[5].get("from_trace"):
             evm_w["copy"] = copy_open[2]  # the copy table the SHA3 / CODECOPY steps look up = the table of the very events the Copy circuit checks
 
@@ -281,7 +309,7 @@ class SuperCircuit:
         # HBM, the EVM kernel is latency / issue bound), so their passes overlap on the device
         self._streams = None
         self._launch_order = None  # results / first-failure reporting keep the sessions' own order whatever the launch order is
-        if hasattr(ops, "is_cuda"):
+        if on_dev:
             import torch
 
             torch.cuda.synchronize()  # witness uploads / open-time packing ran on the stream the sessions were opened on

@@ -40,9 +40,6 @@ _POPS = {"ADDSUB": 2, "MULDIVMOD": 2, "CMP": 2, "SCMP": 2, "BITWISE": 2, "NOT": 
          "SLOAD": 1, "SSTORE": 2, "READER": 0, "PUSH": 0}
 _READERS = ["ADDRESS", "CALLER", "CALLVALUE", "CALLDATASIZE", "CODESIZE"]
 # State-circuit tags (state_circuit.py:42-60) of the RW-table targets (evm_circuit/table.py:184-216)
-STATE_TAG_OF_TARGET = {int(TG.Start): 1, int(TG.Memory): 2, int(TG.Stack): 3, int(TG.AccountStorage): 4, int(TG.CallContext): 5, int(TG.Account): 6,
-                       int(TG.TxRefund): 7, int(TG.TxAccessListAccount): 8, int(TG.TxAccessListAccountStorage): 9, int(TG.TxLog): 10,
-                       int(TG.TxReceipt): 11}
 
 
 class _Program:
@@ -488,54 +485,3 @@ def synth_block_trace(n_steps, seed=5, seg_len=640, n_contracts=16, code_hashes=
         out["exp"] = rows_to_rowmajor(exp_table, 11)
         out["sha3_inputs"] = [m for c in contracts for m in c.sha3_inputs]
     return out
-
-
-MAX_STATE_FIELD_TAG = 24  # state_circuit.py:34
-
-
-def rw_to_state_ops(rw, rw_flags):
-    """RW-table rows (uint64[n, 14, 4] + flags) -> the State circuit's operations in the wire form of zk_state_assign
-    (ops uint64[12, n + 1, 4] column-major, flags uint32[n + 1]): a StartOp in front, then one op per RW row sorted by
-    (tag, id, address, field_tag, storage_key, rw_counter), the order assign_state_circuit's callers hand ops over in
-    (state_circuit.py:617-852: the Operation subclasses).  Key slots per target (RWDictionary, evm_circuit/typing.py:430-845):
-      Stack / Memory           id = call_id, address = stack pointer / memory address
-      CallContext              id = call_id, field_tag = the RW row's address cell (the CallContextFieldTag travels there)
-      AccountStorage           id = tx_id, address, storage_key; initial_value = the committed value (the RW row's aux0)
-      Account                  address, field_tag; initial_value = aux0
-      TxAccessListAccount(Storage), TxRefund   id = tx_id (+ address, storage_key)
-      TxLog                    id = tx_id, address = log_id, field_tag, storage_key = index (unpacked from the RW address cell)
-      TxReceipt                id = tx_id, field_tag
-    CallContext rows whose field tag exceeds the State circuit's MAX_FIELD_TAG (24, state_circuit.py:34,334) are left out:
-    CallContextFieldTag.ReversibleWriteCounter is 25 (evm_circuit/table.py), so the reference's State circuit rejects a row its
-    own STOP / RETURN gadgets look up (instruction.py:292-363) — no State witness of a trace with an internal call can carry it.
-    """
-    from .wire import cells_to_ints
-
-    n = int(rw.shape[0])
-    flat = cells_to_ints(rw)
-    ops, flags = [], []
-    for i in range(n):
-        c = flat[i * 14:(i + 1) * 14]
-        target, tag = c[2], STATE_TAG_OF_TARGET[c[2]]
-        id_, address, ft, key = c[3], c[4], c[5], c[6] | (c[7] << 128)
-        vlo, vhi, ilo, ihi = c[8], c[9], 0, 0
-        vw, iw, acc = int(rw_flags[i]) & 1, 0, 0
-        if target == int(TG.CallContext):
-            address, ft = 0, c[4]
-            if ft > MAX_STATE_FIELD_TAG:
-                continue
-        elif target in (int(TG.AccountStorage), int(TG.Account)):
-            ilo, ihi, iw = c[12], c[13], 1
-            acc = 4 if target == int(TG.Account) else 0
-            if target == int(TG.Account):
-                id_ = 0
-        elif target == int(TG.TxLog):
-            address, ft, key = (c[4] >> 48), (c[4] >> 32) & 0xFFFF, c[4] & 0xFFFFFFFF
-        ops.append([c[0], c[1], tag, id_, address, ft, key, vlo, vhi, ilo, ihi, 1])
-        flags.append(vw | (iw << 1) | acc)
-    n = len(ops)
-    order = sorted(range(n), key=lambda j: (ops[j][2], ops[j][3], ops[j][4], ops[j][5], ops[j][6], ops[j][0]))
-    rows = [[0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]] + [ops[j] for j in order]   # StartOp(rw_counter 0, lexicographic_ordering_selector 0)
-    fl = [0] + [flags[j] for j in order]
-    # slot 6 (storage_key) is a 256-bit integer: it does not fit one field cell's canonical range check, but the wire slot is 256 bits
-    return rows_to_colmajor(rows, 12), np.array(fl, dtype=np.uint32)
