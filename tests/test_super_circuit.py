@@ -265,3 +265,31 @@ def test_full_size_block_every_row_of_every_circuit_vs_oracles():
         assert results[k].fail_count == n_fail[k], k
     assert all(n_fail[k] >= 5 for k in BLOCK_CIRCUITS), n_fail
     assert total == sum(n_fail.values())
+
+
+@pytest.mark.gpu
+def test_block_one_shot_from_raw_inputs():
+    """block.BlockVerifier: keccak table, Bytecode / Copy / State assignments (State from the RW table) and the six circuits derived and
+    evaluated from the block's raw device-resident inputs in one call — clean block, then a tampered RW value: the same circuits notice
+    as with the resident SuperCircuit"""
+    import torch
+
+    from zkevm_specs_amd.block import BlockVerifier, stage_block
+    from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, synth_super_block
+
+    p = synth_super_block(16, seed=3)
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    bv = BlockVerifier(0)
+    try:
+        for _ in range(3):
+            results, total = bv.verify(stage_block(p, dev))
+            assert total == 0 and set(results) == set(BLOCK_CIRCUITS)
+            assert {k: r.rows_evaluated for k, r in results.items()} == p["rows"]
+        rw = p["evm"]["rw"]
+        i = next(j for j in range(2000, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)
+        rw[i, 8, 0] ^= np.uint64(1)  # a Stack read's value: the EVM circuit and the State circuit
+        results, total = bv.verify(stage_block(p, dev))
+        assert not results["evm"].ok and not results["state"].ok and results["bytecode"].ok and results["copy"].ok and results["exp"].ok and results["tx"].ok
+        rw[i, 8, 0] ^= np.uint64(1)
+    finally:
+        bv.close()

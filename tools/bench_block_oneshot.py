@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Wall clock of block.BlockVerifier.verify on BASELINE config 5's block: everything derived on the device (keccak table, the
+Bytecode / Copy / State assignments incl. the RW -> State sort, six opens), one pass of each circuit, collects, closes.
+Rotates over `copies` device-resident copies of the inputs so that no call finds its block in the caches."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zkevm_specs_amd import _lib  # noqa: E402
+
+_lib.load()
+from zkevm_specs_amd.block import BlockVerifier, stage_block  # noqa: E402
+from zkevm_specs_amd.super_circuit import synth_super_block  # noqa: E402
+
+log_total = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+copies = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+parts = synth_super_block(log_total, seed=5)
+dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+blocks = [stage_block(parts, dev) for _ in range(copies)]
+bv = BlockVerifier(0)
+times = []
+for r in range(reps + 3):
+    b = blocks[r % copies]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results, total = bv.verify(b)
+    t1 = time.perf_counter()
+    assert total == 0, {k: (v.fail_count, v.first_fail_row, v.first_fail_code) for k, v in results.items()}
+    if r >= 3:
+        times.append((t1 - t0) * 1e3)
+        last_trace = sorted(bv.trace, key=lambda e: e[2])
+times.sort()
+rows = {k: v.rows_evaluated for k, v in results.items()}
+print(json.dumps({"block_rows": rows, "total_rows": sum(rows.values()), "reps": reps, "copies": copies,
+                  "oneshot_ms": {"median": times[len(times) // 2], "min": times[0], "max": times[-1]},
+                  "kernel_ms": {k: v.kernel_ms for k, v in results.items()}}))
+for c, what, t in last_trace:
+    print(f"{t:8.3f} ms  {c:7s} {what}")
+bv.close()

@@ -208,7 +208,7 @@ def _evm_tables(wire, begin_with_first_step, end_with_last_step):
 
 
 def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device=None, state_sort=True,
-             generic_index=False, side_stream=False):
+             generic_index=False, side_stream=False, single_pass=False):
     """wire: dict with steps uint64[n, 13, 4] (row-major), rw/rw_flags, bytecode, tx/tx_flags, block/block_flags
     and optionally copy uint64[m, 14, 4], keccak uint64[m, 5, 4], exp uint64[m, 11, 4], sig uint64[m, 9, 4], ecc uint64[m, 13, 4],
     aux uint64[n, 2 or 12, 4] + aux_kind, withdrawals uint64[m, 4, 4]
@@ -219,6 +219,8 @@ def open_evm(wire, begin_with_first_step=False, end_with_last_step=False, device
         opts |= _lib.OPT_NO_STATE_SORT
     if generic_index:
         opts |= _lib.OPT_GENERIC_INDEX
+    if single_pass:  # the session will evaluate ONE pass: skip the packed step records (ZK_OPT_SINGLE_PASS, include/zkevm_hip.h)
+        opts |= _lib.OPT_SINGLE_PASS
     if side_stream:  # warm / cold launches beside the hot one: pays when other sessions' passes share the device (include/zkevm_hip.h)
         opts |= _lib.OPT_SIDE_STREAM
     h = ctypes.c_void_p()

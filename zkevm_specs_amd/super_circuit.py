@@ -111,6 +111,7 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None,
     sha3_inputs = synth_block_sha3_inputs(seed, seg_len=seg_len, n_contracts=n_contracts, block_ops=bw)
     sha3_unique = sorted(set(sha3_inputs))
     all_rows = keccak_rows_of(list(codes) + sha3_unique, r)
+    k_data, k_offsets = engine.pack_messages(list(codes) + sha3_unique)  # the same messages in wire form (block.verify_block re-derives the table)
     keccak = np.ascontiguousarray(all_rows[: len(codes)])
     sha3_rows = np.ascontiguousarray(all_rows[len(codes):])
     hashes = [_digest_of_row(keccak[i]) for i in range(len(codes))]
@@ -145,7 +146,7 @@ def synth_super_block(log_total=20, seed=5, keccak_rows_of=None, block_ops=None,
     n_exp = int(exp_rows.shape[1])
     rows = {"evm": n_steps - 1, "state": n_state, "bytecode": 1 << k, "tx": n_tx, "copy": int(copy_ev["n_rows"]), "exp": n_exp}
     return {"codes": codes, "evm": evm, "state_ops": None, "bytecode": (bc_rows, keccak, r), "bytecode_unrolled": (bt, offsets, lengths, k),
-            "tx": (tx, r), "copy_events": copy_ev, "exp_rows": exp_rows, "rows": rows,
+            "tx": (tx, r), "copy_events": copy_ev, "exp_rows": exp_rows, "rows": rows, "keccak_messages": (k_data, k_offsets, len(codes)),
             "meta": dict(meta, n_contracts=n_contracts, code_rows=n_code_rows, state_rows_from_rw_table=True, copy_exp_rows_from_trace=True)}
 
 
