@@ -697,8 +697,16 @@ def compact_line(out, full_path=None):
         r = b.get("roofline") or {}
         if r.get("frac") is not None:
             other[key]["frac"] = r["frac"]
+            # what the fraction is OF (the enclosing object's bound / unit describe the headline only): "hbm-physical" = PMC traffic of the
+            # dominant kernel / its time / 8 TB/s, "hbm-algorithmic" = SURVEY 8(d) bytes, "valu" = VALU-active cycles / issue peak
+            src, bnd = str(r.get("frac_source", "")), str(r.get("bound", ""))
+            other[key]["bound"] = "valu" if bnd.startswith("valu") else ("hbm-physical" if src.startswith("pmc traffic") else "hbm-algorithmic")
     if other:
         roof["other_configs"] = other
+    # the headline `frac` is ALGORITHMIC (SURVEY 8(d) bytes / device span); the physical figure beside it: measured HBM-side traffic / span
+    roof["frac_bound"] = "hbm-algorithmic"
+    if roof_full.get("traffic") and roof_full.get("kernel_ms") and roof_full.get("peak"):
+        roof["physical_frac"] = _sig(roof_full["traffic"] / (roof_full["kernel_ms"] * 1e-3) / 1e9 / roof_full["peak"])
     line["config"], line["roofline"] = cfg, roof
     cb = out.get("cpu_baseline")
     if cb:
@@ -708,6 +716,8 @@ def compact_line(out, full_path=None):
         c["extrapolated"] = False  # the headline leg is measured
         c["measured_on"] = "this box"  # cpu_baseline() only ever heads the line with a leg timed here (bench_legs.py)
         c["this_box_cores_total"] = cb.get("this_box_cores_total")
+        if cb.get("sample_pairs") is not None:
+            c["sample_pairs"] = cb["sample_pairs"]  # units of the timed sample, as a number (the `sample` text says what they were)
         c["legs"] = {k: {"value": v.get("value"), "cores": v.get("cores")} for k, v in legs.items()}
         line["cpu_baseline"] = c
     if full_path:

@@ -50,7 +50,15 @@ def test_compact_line_fits_and_round_trips(bench):
     assert abs(d["value"] - full["value"]) / full["value"] < 1e-5
     # <= 3 scalars per other configuration
     assert set(r["other_configs"]) == set(full["other_configs"])
-    assert all(len(v) <= 3 and all(isinstance(x, (int, float)) for x in v.values()) for v in r["other_configs"].values())
+    assert all(len(v) <= 4 and all(isinstance(x, (int, float)) for k, x in v.items() if k != "bound") for v in r["other_configs"].values())
+    # every fraction says what it is a fraction OF: the headline's is algorithmic, the physical one sits beside it
+    assert r["frac_bound"] == "hbm-algorithmic" and 0 < r["physical_frac"] < 1
+    assert abs(r["physical_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-4
+    for k, v in r["other_configs"].items():
+        assert ("frac" in v) == ("bound" in v), k
+        if "bound" in v:
+            assert v["bound"] in ("hbm-physical", "hbm-algorithmic", "valu"), (k, v)
+    assert r["other_configs"]["tx_2p14"]["bound"] == "valu" and r["other_configs"]["state_2p20"]["bound"] == "hbm-physical"
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and isinstance(c["value"], float) and c["cores"] == 1 and len(c["sample"]) <= 120
     assert set(c["legs"]) == set(full["cpu_baseline"]["legs"])

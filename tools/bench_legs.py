@@ -347,7 +347,7 @@ def cpu_baseline(workload, w):
         st = evm_oracle.verify_steps(W)
         tc = time.perf_counter() - tc
         assert not any(st)
-        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
+        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1, "units": sample,
                         "sample": f"first {sample} step pairs of the same trace, pure-Python oracle with dict-indexed lookups (oracle/evm_oracle.py)"}
         from zkevm_specs_amd import _lib as zlib, engine as zengine
 
@@ -420,7 +420,7 @@ def cpu_baseline(workload, w):
                                       wire.rowmajor_to_rows(tx["tx_rows"][: 12 * sample_p]), tx["tx_flags"][: 12 * sample_p])
         tc = time.perf_counter() - tc
         assert not any(st)
-        legs["port"] = {"value": sample_p / tc, "unit": "txs/s", "cores": 1,
+        legs["port"] = {"value": sample_p / tc, "unit": "txs/s", "cores": 1, "units": sample_p,
                         "sample": f"first {sample_p} txs, Tx circuit with ECDSA verification, pure-Python oracle (oracle/sign_oracle.py + oracle/ecdsa_oracle.py)"}
         if ref and "tx" in ref:
             t = ref["tx"]
@@ -437,7 +437,7 @@ def cpu_baseline(workload, w):
         tc = time.perf_counter()
         state_oracle.verify_rows(rows_i, flags[:sample], mpt_i)
         tc = time.perf_counter() - tc
-        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1,
+        legs["port"] = {"value": sample / tc, "unit": "rows/s", "cores": 1, "units": sample,
                         "sample": f"first {sample} rows of the same witness, pure-Python oracle (oracle/state_oracle.py)"}
         from zkevm_specs_amd import _lib as zlib, engine as zengine
 
@@ -462,7 +462,7 @@ def cpu_baseline(workload, w):
     head = legs.get("reference") or legs.get("port") or legs["cpu_backend_1core"]
     return {"value": head["value"], "unit": head["unit"], "cores": 1,
             "kind": "reference" if "reference" in legs else "port",
-            "sample": head["sample"], "sample_short": head.get("sample_short"), "legs": legs,
+            "sample": head["sample"], "sample_short": head.get("sample_short"), "sample_pairs": head.get("units"), "legs": legs,
             "this_box_cores_total": cores_total, "this_box_cores_source": cores_how, "this_box_cpu_count": os.cpu_count(),
             "reference_measured_on": (None if not ref else dict(ref.get("host", {}), note="the BUILD CONTAINER, not this GPU box: a Python reference does not "
                                                                 "travel, so `reference_build_container` is a cross-box figure; `port` and the `cpu_backend_*` legs are timed on this box")),

@@ -81,6 +81,41 @@ for kk in sorted({16, k}):
     d_rflags = torch.empty(1 << kk, dtype=torch.int32, device="cuda")
     d_mpt = torch.empty((1 << kk, 12, 4), dtype=torch.int64, device="cuda")
     run(f"state_assign_2p{kk}", engine.open_state_assign(d_ops, d_oflags, d_rows, d_rflags, d_mpt), 1 << kk, (12 + 57) * 32 + 8)
+# Bytecode witness assignment: the unrolled bytecode table of 2^17 / 24,576-byte contracts -> the circuit's 2^17 rows (HBM: 6 cells read, 12 written)
+from zkevm_specs_amd.wire import rows_to_rowmajor  # noqa: E402
+
+
+def unrolled_bytecode_table(codes_):
+    """BytecodeTableRows of Bytecode.table_assignments() in wire form (Header row, then a Byte row per byte with is_code)"""
+    rows_, offs_, lens_ = [], [0], []
+    for ci, code in enumerate(codes_):
+        lo, hi = 0x1000 + ci, 0x77
+        rows_.append([lo, hi, 1, 0, 0, len(code)])
+        left = 0
+        for idx, b in enumerate(code):
+            is_code = left == 0
+            rows_.append([lo, hi, 2, idx, int(is_code), b])
+            left = (b - 0x5F if 0x60 <= b <= 0x7F else 0) if is_code else left - 1
+        offs_.append(len(rows_))
+        lens_.append(len(code))
+    return rows_to_rowmajor(rows_, 6), np.array(offs_, dtype=np.uint64), np.array(lens_, dtype=np.uint64)
+
+
+kb = 17
+b_codes = [bytes(rng.getrandbits(8) for _ in range(24000)) for _ in range(((1 << kb) // 24576))]
+ub_rows, ub_off, ub_len = unrolled_bytecode_table(b_codes)
+d_bc = torch.empty((12, 1 << kb, 4), dtype=torch.int64, device="cuda")
+run(f"bytecode_assign_2p{kb}", engine.open_bytecode_assign(to_dev(ub_rows), to_dev(ub_off), to_dev(ub_len), kb, r, rows_dev=d_bc), 1 << kb, (6 + 12) * 32)
+# RW table -> State witness in one session (re-keying + radix sort + assignment): the 2^18-step block trace's RW table
+from zkevm_specs_amd.synth_block import synth_block_trace  # noqa: E402
+wb = synth_block_trace(1 << 18, seed=5)
+n_rw = int(wb["rw"].shape[0])
+f_rows, f_fl = torch.empty(57 * 4 * (n_rw + 1), dtype=torch.int64, device="cuda"), torch.empty(n_rw + 1, dtype=torch.int32, device="cuda")
+f_mpt = torch.empty(48 * (n_rw + 1), dtype=torch.int64, device="cuda")
+d_rw, d_rwf = to_dev(wb["rw"]), to_dev(wb["rw_flags"])
+run("state_assign_from_rw_2p18", engine.open_state_assign_from_rw(d_rw, d_rwf, f_rows, f_fl, f_mpt), n_rw, (14 + 57) * 32 + 8)
+d_ops_b, d_of_b = torch.empty(48 * (n_rw + 1), dtype=torch.int64, device="cuda"), torch.empty(n_rw + 1, dtype=torch.int32, device="cuda")
+run("state_ops_from_rw_2p18", engine.open_state_ops_from_rw(d_rw, d_rwf, d_ops_b, d_of_b), n_rw, (14 + 12) * 32 + 8)
 # secp256k1 ECDSA verification (integer-ALU bound: ~8.6 k 256-bit Montgomery products per signature)
 from zkevm_specs_amd.synth import synth_signatures
 n_sig = 1 << 14

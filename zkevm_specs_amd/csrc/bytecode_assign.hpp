@@ -24,6 +24,8 @@
 
 enum { BCA_IN_NCELLS = 6, BCA_OUT_NCELLS = 12, BCA_CHUNK = 64, BCA_RPOW_ROWS = BCA_CHUNK + 1, BCA_MAP_STRIDE = 36 /* 33 states, padded */ };
 
+static_assert(BCA_CHUNK == 64, "a chunk is one wavefront (k_assign.hip) and bca_dot's ten-limb accumulator holds at most 64 byte terms");
+
 struct BcaChunk {
     u32 code;   // bytecode index
     u32 start;  // first global input row of the chunk
@@ -48,6 +50,7 @@ struct BcaArgs {
     u64* chunk_in;          // [n_chunks][4] incoming value_rlc
     u64* rlc;               // [n_in][4] value_rlc per input row
     u32* row_code;          // [n_in] bytecode of every input row (written by bca_rlc_chunk)
+    u32* row_chunk;         // [n_in] chunk of every input row (device kernels: k_assign.hip bca_chunk_wave_kernel)
     u64* rows;              // out [12][n_out][4]
 };
 

@@ -22,6 +22,7 @@
 #include "common.hpp"
 
 enum { CPA_EV_NCELLS = 12, CPA_ROW_NCELLS = 20, CPA_TABLE_NCELLS = 14, CPA_RW_NCELLS = 14, CPA_CHUNK = 64, CPA_RPOW_ROWS = CPA_CHUNK + 1 };
+static_assert(CPA_CHUNK <= 64, "the per-chunk integer accumulators (nine 32-bit limbs + carries) are sized for at most 64 byte terms");
 enum { CPA_BYTECODE = 1, CPA_MEMORY = 2, CPA_TX_CALLDATA = 3, CPA_TX_LOG = 4, CPA_RLC_ACC = 5 };  // CopyDataTypeTag (table.py:308-315)
 enum { CPA_TARGET_MEMORY = 9, CPA_TARGET_TX_LOG = 10, CPA_TX_LOG_DATA = 3 };                     // Target, TxLogFieldTag.Data
 #define CPA_NONE 0xffffffffu

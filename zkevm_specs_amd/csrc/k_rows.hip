@@ -108,6 +108,7 @@ void zk_launch_bytecode_rows(hipStream_t st, const BytecodeArgs& a, u64 lo, u64 
 }
 void zk_launch_copy_rows(hipStream_t st, const CopyArgs& a, u64 lo, u64 hi, u32* status, ZkTally* tally) {
     // small tables: one wavefront per block (2^15 rows = 532 wavefronts reach every CU; four per block only a third of them)
+    if (hi <= lo) return;  // nothing to evaluate (and the kernel's wrap-around `i %= n` must never see an empty table)
     static const u32 forced = [] { const char* e = getenv("ZK_COPY_BLOCK"); const int v = e ? atoi(e) : 0; return (u32)((v == 64 || v == 128 || v == 256) ? v : 0); }();
     const u64 waves = (hi - lo + CP_ROWS_PER_WAVE - 1) / CP_ROWS_PER_WAVE;
     const u32 block = forced ? forced : (waves <= 4096 ? 64u : 256u);

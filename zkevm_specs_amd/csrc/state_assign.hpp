@@ -73,12 +73,16 @@ ZK_HD Fr asg_slot_rw(const AssignArgs& a, u32 s, u64 i) {
     if (s == ASG_FT) return tag == 5u ? c4 : fr_from_u64((u64)(c4.v[1] & 0xffffu));
     return fr_from_u64((u64)c4.v[0]);  // ASG_KEY of a TxLog row
 }
+// RW: the ops are the re-keyed rows of an RW table (a compile-time switch: the device has one instantiation of every assignment
+// kernel per source, so the op-list form pays nothing for the other one — a run-time branch cost assign_rows_kernel 14 VGPRs, +13 %)
+template <bool RW = false>
 ZK_HD Fr asg_slot(const AssignArgs& a, u32 s, u64 i) {
-    if (a.rw) return asg_slot_rw(a, s, i);
+    if (RW) return asg_slot_rw(a, s, i);
     return fr_load(a.ops + ((u64)s * a.n + i) * 4);
 }
+template <bool RW = false>
 ZK_HD u32 asg_flags(const AssignArgs& a, u64 i) {
-    if (!a.rw) return a.op_flags[i];
+    if (!RW) return a.op_flags[i];
     if (i == 0) return 0u;
     const u32 r = a.order[i - 1];
     const u32 tag = rwk_tag_of_target(rwk_cell(a.rw + (u64)r * (RWK_RW_NCELLS * 4), 2).v[0]);
@@ -102,19 +106,21 @@ ZK_HD bool asg_has_key(const Fr& tag) { return fr_eq_u64(tag, 4) || fr_eq_u64(ta
 struct AsgKey {
     Fr addr, ft, key;  // FQ(address), FQ(field_tag), storage_key (lo/hi halves compared together)
 };
+template <bool RW = false>
 ZK_HD AsgKey asg_key_of(const AssignArgs& a, u64 i) {
     AsgKey k;
-    k.addr = asg_reduce(asg_slot(a, ASG_ADDR, i));
-    k.ft = asg_reduce(asg_slot(a, ASG_FT, i));
-    k.key = asg_slot(a, ASG_KEY, i);
+    k.addr = asg_reduce(asg_slot<RW>(a, ASG_ADDR, i));
+    k.ft = asg_reduce(asg_slot<RW>(a, ASG_FT, i));
+    k.key = asg_slot<RW>(a, ASG_KEY, i);
     return k;
 }
 ZK_HD bool asg_key_eq(const AsgKey& x, const AsgKey& y) { return fr_eq(x.addr, y.addr) && fr_eq(x.ft, y.ft) && fr_eq(x.key, y.key); }
 ZK_HD u64 asg_key_hash(const AsgKey& k) { return zk_hash_cell(zk_hash_cell(zk_hash_cell(0x6d7074u, k.addr), k.ft), k.key); }
 
 // Claim / join the slot of op i's key; afterwards the slot holds the smallest op index with that key.
+template <bool RW = false>
 ZK_HD void asg_insert(const AssignArgs& a, u32 i) {
-    const AsgKey k = asg_key_of(a, i);
+    const AsgKey k = asg_key_of<RW>(a, i);
     u32 s = (u32)asg_key_hash(k) & a.mask;
     for (;;) {
 #if defined(ZK_HOSTSIM)
@@ -128,7 +134,7 @@ ZK_HD void asg_insert(const AssignArgs& a, u32 i) {
         }
 #endif
         // `cur` is some op with the slot's key (the occupant only ever changes to an op with the same key)
-        if (asg_key_eq(asg_key_of(a, cur), k)) {
+        if (asg_key_eq(asg_key_of<RW>(a, cur), k)) {
 #if defined(ZK_HOSTSIM)
             if (i < a.slots[s]) a.slots[s] = i;
 #else
@@ -139,13 +145,14 @@ ZK_HD void asg_insert(const AssignArgs& a, u32 i) {
         s = (s + 1) & a.mask;
     }
 }
+template <bool RW = false>
 ZK_HD u32 asg_find_first(const AssignArgs& a, u32 i) {
-    const AsgKey k = asg_key_of(a, i);
+    const AsgKey k = asg_key_of<RW>(a, i);
     u32 s = (u32)asg_key_hash(k) & a.mask;
     for (;;) {
         const u32 cur = a.slots[s];
         if (cur == ZK_EMPTY_SLOT) return ASG_NONE;  // unreachable after asg_insert
-        if (cur == i || asg_key_eq(asg_key_of(a, cur), k)) return cur;
+        if (cur == i || asg_key_eq(asg_key_of<RW>(a, cur), k)) return cur;
         s = (s + 1) & a.mask;
     }
 }
@@ -155,7 +162,7 @@ ZK_HD void asg_store(u64* out, const Fr& x) {
     uint4 lo, hi;
     lo.x = x.v[0]; lo.y = x.v[1]; lo.z = x.v[2]; lo.w = x.v[3];
     hi.x = x.v[4]; hi.y = x.v[5]; hi.z = x.v[6]; hi.w = x.v[7];
-    q[0] = lo;
+    q[0] = lo;  // (plain stores: the two halves of a cell merge in L2; non-temporal stores were measured at 2.1x the kernel time, round 6)
     q[1] = hi;
 }
 ZK_HD void asg_store_u64(u64* out, u64 x) { asg_store(out, fr_from_u64(x)); }
@@ -189,14 +196,15 @@ ZK_HD u32 asg_mock_status(u32 flags, const Fr& ft, const Fr& vlo, const Fr& vhi,
 
 // MPTTableRow of first-occurrence op i with rank r (:921-929): address, proof_type, storage_key lo/hi,
 // root lo/hi, root_prev lo/hi, value lo/hi, value_prev lo/hi.
+template <bool RW = false>
 ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
     u64* out = a.mpt + (u64)r * (ASG_MPT_NCELLS * 4);
-    const u32 flags = asg_flags(a, i);
-    const Fr ft = asg_slot(a, ASG_FT, i);
-    const Fr key = asg_slot(a, ASG_KEY, i);
-    const Fr vlo = asg_slot(a, ASG_VLO, i), vhi = asg_slot(a, ASG_VHI, i);
-    const Fr ilo = asg_slot(a, ASG_ILO, i), ihi = asg_slot(a, ASG_IHI, i);
-    asg_store(out + 0, asg_reduce(asg_slot(a, ASG_ADDR, i)));
+    const u32 flags = asg_flags<RW>(a, i);
+    const Fr ft = asg_slot<RW>(a, ASG_FT, i);
+    const Fr key = asg_slot<RW>(a, ASG_KEY, i);
+    const Fr vlo = asg_slot<RW>(a, ASG_VLO, i), vhi = asg_slot<RW>(a, ASG_VHI, i);
+    const Fr ilo = asg_slot<RW>(a, ASG_ILO, i), ihi = asg_slot<RW>(a, ASG_IHI, i);
+    asg_store(out + 0, asg_reduce(asg_slot<RW>(a, ASG_ADDR, i)));
     // isinstance(field_tag, AccountFieldTag) -> from_account_field_tag (table.py:341-350: Nonce..NonExisting -> 1..4), else StorageMod
     asg_store_u64(out + 4, (flags & 4u) ? fr_lo64(ft) : 6ull);
     asg_store(out + 8, u256_lo(key));
@@ -216,22 +224,26 @@ ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
 }
 
 // op2row (:827-852) with the back-filled root; returns the op's status code.
+template <bool RW = false>
 ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     const u64 n = a.n;
     u64* rows = a.rows;
 #define ASG_OUT(c) (rows + ((u64)(c) * n + i) * 4)
-    const u32 flags = asg_flags(a, i);
-    const Fr addr = asg_slot(a, ASG_ADDR, i);
-    const Fr key = asg_slot(a, ASG_KEY, i);
-    const Fr ft = asg_slot(a, ASG_FT, i);
-    const Fr vlo = asg_slot(a, ASG_VLO, i), vhi = asg_slot(a, ASG_VHI, i);
-    const Fr ilo = asg_slot(a, ASG_ILO, i), ihi = asg_slot(a, ASG_IHI, i);
-    const Fr rwc = asg_slot(a, ASG_RWC, i), rw = asg_slot(a, ASG_RW, i), tag = asg_slot(a, ASG_TAG, i), id = asg_slot(a, ASG_ID, i);
-    const Fr lex = asg_slot(a, ASG_LEX, i);  // (every slot is read before the first store: the stores may alias the loads for the compiler)
-    asg_store(ASG_OUT(0), asg_reduce(rwc));
-    asg_store_u64(ASG_OUT(1), fr_is_zero(rw) ? 0 : 1);  // `op.rw == RW.Read` :829
-    asg_store(ASG_OUT(2), asg_reduce(tag));
-    asg_store(ASG_OUT(3), asg_reduce(id));
+    const u32 flags = asg_flags<RW>(a, i);
+    const Fr addr = asg_slot<RW>(a, ASG_ADDR, i);
+    const Fr key = asg_slot<RW>(a, ASG_KEY, i);
+    const Fr ft = asg_slot<RW>(a, ASG_FT, i);
+    const Fr vlo = asg_slot<RW>(a, ASG_VLO, i), vhi = asg_slot<RW>(a, ASG_VHI, i);
+    const Fr ilo = asg_slot<RW>(a, ASG_ILO, i), ihi = asg_slot<RW>(a, ASG_IHI, i);
+    // RW source: every slot is read before the first store (the stores may alias the loads for the compiler: each later slot would
+    // re-read the row's target cell); op-list source: the four slots are loaded where they are stored (8 fewer live registers each)
+    const Fr rwc = RW ? asg_slot<RW>(a, ASG_RWC, i) : fr_zero(), rw = RW ? asg_slot<RW>(a, ASG_RW, i) : fr_zero();
+    const Fr tag = RW ? asg_slot<RW>(a, ASG_TAG, i) : fr_zero(), id = RW ? asg_slot<RW>(a, ASG_ID, i) : fr_zero();
+    const Fr lex = RW ? asg_slot<RW>(a, ASG_LEX, i) : fr_zero();
+    asg_store(ASG_OUT(0), asg_reduce(RW ? rwc : asg_slot<RW>(a, ASG_RWC, i)));
+    asg_store_u64(ASG_OUT(1), fr_is_zero(RW ? rw : asg_slot<RW>(a, ASG_RW, i)) ? 0 : 1);  // `op.rw == RW.Read` :829
+    asg_store(ASG_OUT(2), asg_reduce(RW ? tag : asg_slot<RW>(a, ASG_TAG, i)));
+    asg_store(ASG_OUT(3), asg_reduce(RW ? id : asg_slot<RW>(a, ASG_ID, i)));
     asg_store(ASG_OUT(4), asg_reduce(addr));
     asg_store(ASG_OUT(5), asg_reduce(ft));
     asg_store(ASG_OUT(6), u256_lo(key));
@@ -246,7 +258,7 @@ ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     asg_store(ASG_OUT(53), ihi);
     asg_store_u64(ASG_OUT(54), root);
     asg_store_u64(ASG_OUT(55), 0);
-    asg_store(ASG_OUT(56), lex);
+    asg_store(ASG_OUT(56), RW ? lex : asg_slot<RW>(a, ASG_LEX, i));
 #undef ASG_OUT
     a.row_flags[i] = flags & 3u;
     u32 code = is_first ? asg_mock_status(flags, ft, vlo, vhi, ilo, ihi) : 0u;

@@ -1779,6 +1779,8 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
         a.rlc = (u64*)d;
         if ((rc = dev_alloc(s, &d, (size_t)n_rows * 4))) goto fail;
         a.row_code = (u32*)d;
+        if ((rc = dev_alloc(s, &d, (size_t)n_rows * 4))) goto fail;
+        a.row_chunk = (u32*)d;
     }
     a.rows = rows_dev;
     if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)a.n_out * BCA_OUT_NCELLS * 32))) goto fail;
@@ -2285,6 +2287,7 @@ static int evm_finish_deferred(zk_session* s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->deferred_pending = false;
     if (n_def) {
+        s->stream_drained = false;  // (something is enqueued behind the polled result: zk_close must wait again)
         zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
         HIP_TRY(hipGetLastError());
     }
@@ -2318,6 +2321,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
                     const auto t0 = std::chrono::steady_clock::now();
                     u64 spins = 0;
                     while (__atomic_load_n(&hw[32], __ATOMIC_ACQUIRE) != seq) {
+                        __builtin_ia32_pause();  // (the host side of this file is x86-64: a polite spin)
                         if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;  // never expected: fall back to the runtime's wait
                     }
                     polled = __atomic_load_n(&hw[32], __ATOMIC_ACQUIRE) == seq;
@@ -2350,7 +2354,8 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     if (check_deferred) {
         s->deferred_pending = false;
         if (n_def) {  // the general build decides the pairs the fast kernel left (see evm_finish_deferred), then the tally is final
-            zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
+            s->stream_drained = false;  // (something is enqueued behind the polled result: zk_close must wait again)
+        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
