@@ -675,7 +675,7 @@ def compact_line(out, full_path=None):
     for k in ("peak", "unit", "achieved", "frac", "traffic", "traffic_over_algorithmic", "algorithmic_bytes", "witness_bytes_resident", "kernel_ms",
               "open_ms", "pass_kernel_ms", "rocprof_sum_kernel_ms_per_step", "rocprof_avg_kernel_ms", "host_us_in_open", "host_us_in_launch",
               "host_us_in_collect", "host_us_in_close", "batch_ms_per_witness", "batch_rows_per_s", "resident_ms_per_pass", "resident_rows_per_s",
-              "resident_hot_kernel_ms"):
+              "resident_hot_kernel_ms", "oneshot_ms"):
         if k in roof_full:
             roof[k] = roof_full[k]
     alg = roof_full.get("algorithmic")
@@ -695,6 +695,8 @@ def compact_line(out, full_path=None):
         b = out["other_configs"][key]
         other[key] = {f"{unit}_per_s": b.get("value"), "ms_per_step": b.get("ms_per_step")}
         r = b.get("roofline") or {}
+        if (b.get("block_oneshot") or {}).get("ms") is not None:
+            other[key]["oneshot_ms"] = b["block_oneshot"]["ms"]  # the block verified from raw inputs, everything derived on the device (block.py)
         if r.get("frac") is not None:
             other[key]["frac"] = r["frac"]
             # what the fraction is OF (the enclosing object's bound / unit describe the headline only): "hbm-physical" = PMC traffic of the
@@ -772,6 +774,7 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="EVM one-shot line: take roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of live_pmc_traffic: one-shot steps only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oneshot-leg", action="store_true", help="super: skip the block one-shot side measurement (block.BlockVerifier)")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
     ap.add_argument("--full-line", action="store_true", help="print the full nested record on stdout instead of the compact line (it is always written to bench_full.json)")
@@ -782,7 +785,7 @@ def main():
                                  tx_extras=tx_extras, oneshot_profile_numbers=oneshot_profile_numbers)
     if args.pmc_child:  # counters are collected over the one-shot steps alone
         args.no_session_leg = args.no_batch_leg = args.no_cold_leg = args.no_fresh_leg = args.no_other_configs = args.no_cpu_baseline = True
-        args.no_live_pmc = True
+        args.no_live_pmc = args.no_oneshot_leg = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)
 
@@ -923,6 +926,12 @@ def main():
                     v["traffic_bytes"] = kc2["pmc"]["FETCH_SIZE"]["avg_per_dispatch"] * 1024.0 * corr + kc2["pmc"].get("WRITE_SIZE", {}).get("avg_per_dispatch", 0) * 1024.0
                     v["traffic_GBps"] = v["traffic_bytes"] / (v["kernel_ms"] / 1e3) / 1e9
             out["roofline"]["per_circuit"] = per_circuit
+        if args.workload == "super" and world == 1 and w.env is not None and not args.no_oneshot_leg:
+            try:
+                out["block_oneshot"] = legs.block_oneshot(w.env["parts"], ctx.to_dev, device=ctx.local_rank)
+                out["roofline"]["oneshot_ms"] = out["block_oneshot"]["ms"]
+            except Exception as e:  # noqa: BLE001 — a side leg: the line says so instead of losing the resident figures
+                out["block_oneshot"] = {"ms": None, "error": f"{type(e).__name__}: {e}"[:300]}
         if args.workload == "tx":
             tx_extras(out["roofline"], res, profile, profile_src)
         if not args.no_cpu_baseline and world == 1 and (w.env is not None or w.wire_h is not None):

@@ -60,6 +60,9 @@ class BlockVerifier:
         # table, copy table) are short, latency-bound kernels: they run on high-priority streams
         self.streams = {c: torch.cuda.Stream(device=device, priority=0 if c == "state" else -1) for c in self.CHAINS}
         self.keccak_ready = torch.cuda.Event()
+        import os
+
+        self.gate_state = os.environ.get("ZK_BLOCK_GATE_STATE", "0") == "1"
         self._bound = threading.local()
         self._bufs = {}
 
@@ -105,6 +108,9 @@ class BlockVerifier:
             rows_b, flags_b, mpt_b = self._buf("st_rows", 57 * 4 * (n_rw + 1), i64), self._buf("st_flags", n_rw + 1, i32), self._buf("st_mpt", 48 * (n_rw + 1), i64)
             with engine.open_state_assign_from_rw(evm_in["rw"], evm_in["rw_flags"], rows_b, flags_b, mpt_b, device=self.device) as a:
                 mark("state", "assign opened (class scan + plan)")
+                if self.gate_state:  # the keccak pass (latency-bound, a handful of wavefronts) runs 4x slower beside the State chain's
+                    done_keccak.wait()  # HBM-bound kernels: let it finish first (the EVM chain waits for its table)
+                    mark("state", "keccak done: go")
                 res = a.run()
                 mark("state", "assign done (sort + rows)")
                 n, m = a.n, a.n_mpt()
@@ -205,6 +211,7 @@ class BlockVerifier:
             except Exception as e:  # noqa: BLE001 — the first failure is re-raised once every chain has ended (no thread is left waiting)
                 err = err or e
                 keccak_enqueued.set()
+                done_keccak.set()
         if err is not None:
             raise err
         return results, sum(r.fail_count for r in results.values())
