@@ -5,6 +5,7 @@
 //            rwk_hist / rwk_scatter   LSD radix sort of the row indices, 8 bits per pass, stable (wave match-any ranking)
 //            rwk_emit_kernel      ops[12][n_ops] + flags in sorted order, StartOp in front
 #include "kernels.hpp"
+#include <mutex>
 
 #define RWK_BLOCK 256
 #define RWK_TILE_ITEMS 16
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(1024) void rwk_pack64_kernel(RekeyArgs a, u32* stat
 #define RWK_SW_TILE (RWK_SW_BLOCK * RWK_SW_ITEMS)
 __global__ __launch_bounds__(RWK_SW_BLOCK) void rwk_sweep_kernel(RekeyArgs a, const u64* in_key, const u32* in_idx, u64* out_key, u32* out_idx, u32 pass) {
     __shared__ u32 s_cnt[RWK_SW_BLOCK / 64][256];
-    __shared__ u32 s_scan[256];
+    __shared__ u32 s_scan[256], s_texcl[256], s_gbase[256];
     __shared__ u32 s_tile;
     const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     u32* ticket = a.sweep + 8 * 256;
@@ -261,38 +262,80 @@ __global__ __launch_bounds__(RWK_SW_BLOCK) void rwk_sweep_kernel(RekeyArgs a, co
         meta[j] = valid ? (dg | (r << 8)) : 0xffffffffu;
     }
     __syncthreads();
+    // the tile's own histogram, published at once (the later tiles' look-backs can proceed), and its exclusive scan over the digits
+    u32 wave_tot[RWK_SW_BLOCK / 64], tile_tot = 0;
+    u32* mine = desc + (u64)tile * 256 + (threadIdx.x & 255u);
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < RWK_SW_BLOCK / 64; w++) { wave_tot[w] = s_cnt[w][threadIdx.x]; tile_tot += wave_tot[w]; }
+        __hip_atomic_store(mine, tile_tot | (tile == 0 ? RWK_DESC_INCL : RWK_DESC_LOCAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_texcl[threadIdx.x] = tile_tot;
+    }
+    __syncthreads();
+    {
+        const u32 d = threadIdx.x & 255u;
+        for (u32 s = 1; s < 256; s <<= 1) {
+            const u32 x = (threadIdx.x < 256 && d >= s) ? s_texcl[d - s] : 0u;
+            __syncthreads();
+            if (threadIdx.x < 256) s_texcl[d] += x;
+            __syncthreads();
+        }
+    }
     if (threadIdx.x < 256) {
         const u32 d = threadIdx.x;
-        u32 wave_tot[RWK_SW_BLOCK / 64], tile_tot = 0;
-#pragma unroll
-        for (int w = 0; w < RWK_SW_BLOCK / 64; w++) { wave_tot[w] = s_cnt[w][d]; tile_tot += wave_tot[w]; }
-        u32* mine = desc + (u64)tile * 256 + d;
-        __hip_atomic_store(mine, tile_tot | (tile == 0 ? RWK_DESC_INCL : RWK_DESC_LOCAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 g = a.sweep[pass * 256 + d];
+        const u32 texcl = s_texcl[d] - tile_tot;
+        // look-back, eight predecessors per round trip: their descriptors are independent loads; the walk ends at the first
+        // inclusive one.  (One predecessor per round trip made the pass a chain of ntiles dependent agent-scope loads: 19 of its 20 us.)
         u32 excl = 0;
-        for (int p = (int)tile - 1; p >= 0; p--) {
-            u32 v = 0, spins = 0;
-            do {
-                v = __hip_atomic_load(desc + (u64)p * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((v >> 30) == 0u && ++spins < (1u << 24));
-            if ((v >> 30) == 0u) { atomicOr(err, 1u); break; }  // (never seen: a predecessor did not publish within ~seconds)
-            excl += v & RWK_DESC_VAL;
-            if ((v >> 30) == 2u) break;
+        int p = (int)tile - 1;
+        u32 spins = 0;
+        while (p >= 0) {
+            u32 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = p - q >= 0 ? __hip_atomic_load(desc + (u64)(p - q) * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RWK_DESC_INCL;
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (done || p < 0) continue;
+                if ((v[q] >> 30) == 0u) { done = true; continue; }  // not published yet: re-read from here
+                excl += v[q] & RWK_DESC_VAL;
+                p = (v[q] >> 30) == 2u ? -1 : p - 1;
+            }
+            if (done && ++spins >= (1u << 22)) { atomicOr(err, 1u); break; }  // (never seen: a predecessor did not publish within ~seconds)
         }
         if (tile) __hip_atomic_store(mine, (excl + tile_tot) | RWK_DESC_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u32 run = s_scan[d] + excl;  // s_scan: the digit's base (exclusive scan of the pass's global histogram, below)
-        (void)g;
+        // where digit d's run of this tile starts in the output, minus where it starts in the tile-local order
+        s_gbase[d] = s_scan[d] + excl - texcl;  // (s_scan: the digit's base = exclusive scan of the pass's global histogram; wraps mod 2^32, added back below)
+        u32 run = texcl;
 #pragma unroll
         for (int w = 0; w < RWK_SW_BLOCK / 64; w++) { s_cnt[w][d] = run; run += wave_tot[w]; }
     }
     __syncthreads();
+    // tile-local reorder through LDS: the elements of one digit become one contiguous run, so that the global stores of a wavefront
+    // cover whole runs (scattered 8 + 4-byte stores of an 8-bit digit pass cost 26 us of a 2^20-key pass, the rest of the kernel 16)
+    extern __shared__ u64 s_dyn[];
+    u64* s_key = s_dyn;
+    u32* s_row = (u32*)(s_dyn + RWK_SW_TILE);
 #pragma unroll
     for (int j = 0; j < RWK_SW_ITEMS; j++)
         if (meta[j] != 0xffffffffu) {
-            const u32 pos = s_cnt[wv][meta[j] & 0xffu] + (meta[j] >> 8);
-            out_idx[pos] = rows[j];
-            if (out_key) out_key[pos] = keys[j];
+            const u32 q = s_cnt[wv][meta[j] & 0xffu] + (meta[j] >> 8);
+            s_key[q] = keys[j];
+            s_row[q] = rows[j];
         }
+    __syncthreads();
+    const u64 left = a.n - tile0;
+    const u32 n_here = left < (u64)RWK_SW_TILE ? (u32)left : (u32)RWK_SW_TILE;
+#pragma unroll
+    for (int j = 0; j < RWK_SW_ITEMS; j++) {
+        const u32 q = (u32)j * RWK_SW_BLOCK + threadIdx.x;
+        if (q < n_here) {
+            const u64 k = s_key[q];
+            const u32 pos = s_gbase[(u32)((k >> shift) & 0xffull)] + q;
+            out_idx[pos] = s_row[q];
+            if (out_key) out_key[pos] = k;
+        }
+    }
 }
 
 // ---- LSD radix sort of the row indices, 8 bits per pass ---------------------------------------------------------------------
@@ -410,6 +453,17 @@ void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTa
             hipLaunchKernelGGL(rwk_rank_kernel, dim3((a.jobs[j].count + RWK_BLOCK - 1) / RWK_BLOCK), dim3(RWK_BLOCK), 0, st, a, j);
     }
     if (a.fast) {
+        {   // > 64 KiB of dynamic LDS has to be asked for, once per device
+            static std::mutex m;
+            static bool asked[64] = {false};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lock(m);
+            if (dev >= 0 && dev < 64 && !asked[dev]) {
+                (void)hipFuncSetAttribute((const void*)rwk_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RWK_SW_TILE * 12);
+                asked[dev] = true;
+            }
+        }
         hipMemsetAsync(a.sweep, 0, ((size_t)RWK_SWEEP_HEAD + (size_t)a.n_passes * a.ntiles_fast * 256) * 4, st);
         u32 g64 = (u32)((a.n + 1023) / 1024);
         hipLaunchKernelGGL(rwk_pack64_kernel, dim3(g64 > 256u ? 256u : g64), dim3(1024), 0, st, a, status, tally);
@@ -419,7 +473,7 @@ void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTa
         u32* ibufs[2] = {a.idx_a, a.idx_b};
         for (u32 p = 0; p < a.n_passes; p++) {
             const bool last = p + 1 == a.n_passes;
-            hipLaunchKernelGGL(rwk_sweep_kernel, dim3(a.ntiles_fast), dim3(RWK_SW_BLOCK), 0, st, a, kin, iin, last ? (u64*)nullptr : kbufs[p & 1u], ibufs[p & 1u], p);
+            hipLaunchKernelGGL(rwk_sweep_kernel, dim3(a.ntiles_fast), dim3(RWK_SW_BLOCK), RWK_SW_TILE * 12, st, a, kin, iin, last ? (u64*)nullptr : kbufs[p & 1u], ibufs[p & 1u], p);
             kin = kbufs[p & 1u];
             iin = ibufs[p & 1u];
         }
