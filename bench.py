@@ -391,6 +391,9 @@ def build_tx(ctx, log_rows, strong):
     return w
 
 
+STATE_COMPACT = False  # --state-compact: the super workload's State rows without their limb / byte columns (ZK_OPT_STATE_COMPACT)
+
+
 def build_super(ctx, log_rows, strong):
     from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
 
@@ -401,18 +404,18 @@ def build_super(ctx, log_rows, strong):
         if ctx.rank == 0:
             w.env = {"parts": parts}
         parts = ctx.replicate_tree(parts, big=1 << 20)
-        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, shard=(ctx.rank, ctx.world))
+        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, shard=(ctx.rank, ctx.world), state_compact=STATE_COMPACT)
         w.total_units = sum(w.sess.global_rows.values())
     else:
         parts = synth_super_block(log_rows, seed=5 + ctx.rank)
         w.env = {"parts": parts}
-        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev)
+        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, state_compact=STATE_COMPACT)
     sess = w.sess
     w.units = sum(sess.rows.values())
     if not strong:
         w.row_offset, w.total_units = ctx.rank * w.units, w.units * ctx.world
     frac = {k: sess.rows[k] / max(sess.global_rows[k], 1) for k in sess.rows}
-    w.super_bytes = {"evm": parts["meta"]["algorithmic_bytes"] * frac["evm"], "state": sess.rows["state"] * 57 * 32,
+    w.super_bytes = {"evm": parts["meta"]["algorithmic_bytes"] * frac["evm"], "state": sess.rows["state"] * (15 if STATE_COMPACT else 57) * 32,
                      "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * TX_UNIT_BYTES,
                      "copy": sess.rows.get("copy", 0) * (20 + 14) * 32, "exp": sess.rows.get("exp", 0) * 21 * 32}
     w.workload = (f"Super circuit, ~2^{log_rows} rows {'in total' if strong else 'per GPU'} over ONE consistent witness (BASELINE configs[4]; State rows = "
@@ -422,6 +425,11 @@ def build_super(ctx, log_rows, strong):
     if strong:
         w.extra_cfg["rows_total"] = dict(sess.global_rows)
     w.profile_key = ("super", log_rows)
+    if STATE_COMPACT:
+        w.workload += ("; STATE ROWS COMPACT (ZK_OPT_STATE_COMPACT): 15 of the State row's 57 cells are stored — the ten address limbs and 32 key "
+                       "bytes are derived from the address / key cells where the checks use them, not assigned and read back")
+        w.extra_cfg["state_compact"] = 1
+        w.profile_key = ("super_compact", log_rows)
     return w
 
 
@@ -774,12 +782,15 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="EVM one-shot line: take roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of live_pmc_traffic: one-shot steps only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--state-compact", action="store_true", help="super: State rows without their limb / byte columns (ZK_OPT_STATE_COMPACT)")
     ap.add_argument("--no-oneshot-leg", action="store_true", help="super: skip the block one-shot side measurement (block.BlockVerifier)")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the open / pass split with explicit cache flushes")
     ap.add_argument("--full-line", action="store_true", help="print the full nested record on stdout instead of the compact line (it is always written to bench_full.json)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs[0], [1], [3], [4] after the headline (default: run them at N = 1, evm workload)")
     args = ap.parse_args()
+    global STATE_COMPACT
+    STATE_COMPACT = bool(args.state_compact)
     # what the side legs (tools/bench_legs.py) need from this file: the builders, the timing loop and the roofline blocks
     CORE = types.SimpleNamespace(BUILDERS=BUILDERS, timed_passes=timed_passes, resolve_super=resolve_super, roofline_block=roofline_block,
                                  tx_extras=tx_extras, oneshot_profile_numbers=oneshot_profile_numbers)
@@ -928,7 +939,7 @@ def main():
             out["roofline"]["per_circuit"] = per_circuit
         if args.workload == "super" and world == 1 and w.env is not None and not args.no_oneshot_leg:
             try:
-                out["block_oneshot"] = legs.block_oneshot(w.env["parts"], ctx.to_dev, device=ctx.local_rank)
+                out["block_oneshot"] = legs.block_oneshot(w.env["parts"], ctx.to_dev, device=ctx.local_rank, state_compact=STATE_COMPACT)
                 out["roofline"]["oneshot_ms"] = out["block_oneshot"]["ms"]
             except Exception as e:  # noqa: BLE001 — a side leg: the line says so instead of losing the resident figures
                 out["block_oneshot"] = {"ms": None, "error": f"{type(e).__name__}: {e}"[:300]}

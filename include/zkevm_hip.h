@@ -67,6 +67,16 @@ typedef struct zk_result {
 } zk_result;
 
 #define ZK_OPT_DEVICE_PTRS 1u  /* every data pointer is a device (HBM) pointer */
+/* State rows without the limb / byte columns (zk_state_open, zk_state_assign_open, zk_state_assign_from_rw_open): the witness is
+ * uint64[15][n][4] — rw_counter, is_write, tag, id, address, field_tag, storage_key lo / hi, then value lo / hi, initial_value lo / hi,
+ * root lo / hi, lexicographic_ordering_selector (columns 0..7 and 50..56 of the 57-cell row) — and the ten 16-bit address limbs and 32
+ * storage-key bytes (columns 8..49; Row.key2_limbs / key45_bytes, state_circuit.py:63-96) are DERIVED from the address and storage-key
+ * cells where the circuit's checks use them, as assign_state_circuit's op2row derives them (:834-842).  For witnesses assigned on the
+ * device: the assignment does not write, and the circuit does not read back, 1,344 of a row's 1,824 bytes.  What it gives up: the limb /
+ * byte cells are no independent inputs, so their range and recomposition checks (state_circuit.py:505-517) reduce to "address < 2^160,
+ * key halves < 2^128" (sites 5 and 7).  Every other check, the ordering, the lookups and the per-tag rules are evaluated as always.
+ * Not for witnesses from outside (a tampered limb cell cannot be expressed): those use the 57-cell form. */
+#define ZK_OPT_STATE_COMPACT 32u
 
 /* Select the GPU (HIP ordinal) for the calling thread; creates that device's engine stream on first use.  Idempotent.
  * Selecting another device drops a stream set with zk_set_stream (it belongs to the previous device). */

@@ -28,7 +28,7 @@ extern "C" int sim_state_verify(const u64* cells, const u32* flags, u64 n, const
 }
 extern "C" int sim_state_verify_range(const u64* cells, const u32* flags, u64 n, const u64* mpt, u64 n_mpt,
                                       u64 lo, u64 hi, u32* status) {
-    StateArgs a;
+    StateArgs a = {};
     a.rows.cells = cells;
     a.rows.flags = flags;
     a.rows.n = n;
@@ -91,7 +91,7 @@ extern "C" int sim_evm_verify(const u64* steps, u64 n_steps, const u64* rw, cons
                               const u64* keccak, u64 n_keccak, const u64* exp, u64 n_exp, const u64* aux, const u32* aux_kind,
                               const u64* wds, u64 n_wds, const u64* sig, u64 n_sig, const u64* ecc, u64 n_ecc, u32 aux_cells,
                               u32 opts, u32* status) {
-    EvmArgs a;
+    EvmArgs a = {};
     a.dyn = nullptr;
     a.step_recs = nullptr;
     a.defer_list = nullptr;
@@ -217,7 +217,7 @@ extern "C" void sim_divmod(int wide, const u64* n, const u64* d, u64* q, u64* r,
 #include "../../zkevm_specs_amd/csrc/row_circuits.hpp"
 
 extern "C" int sim_bytecode_verify(const u64* cells, u64 n, const u64* keccak, u64 n_keccak, const u64* r, u32* status) {
-    BytecodeArgs a;
+    BytecodeArgs a = {};
     a.r_mont = nullptr;
     a.rows.cells = cells;
     a.rows.flags = nullptr;
@@ -230,7 +230,7 @@ extern "C" int sim_bytecode_verify(const u64* cells, u64 n, const u64* keccak, u
     return 0;
 }
 extern "C" int sim_exp_verify(const u64* cells, u64 n, u32* status) {
-    ExpArgs a;
+    ExpArgs a = {};
     a.rows.cells = cells;
     a.rows.flags = nullptr;
     a.rows.n = n;
@@ -244,7 +244,7 @@ extern "C" int sim_exp_verify(const u64* cells, u64 n, u32* status) {
 extern "C" int sim_copy_verify(const u64* cells, const u32* flags, u64 n, const u64* r, const u64* rw, const u32* rw_flags,
                                u64 n_rw, const u64* bytecode, u64 n_bc, const u64* tx, const u32* tx_flags, u64 n_tx,
                                u32 generic_index, u32* status) {
-    CopyArgs a;
+    CopyArgs a = {};
     a.rows.cells = cells;
     a.rows.flags = flags;
     a.rows.n = n;
@@ -267,7 +267,7 @@ extern "C" int sim_copy_verify(const u64* cells, const u32* flags, u64 n, const 
 
 extern "C" int sim_sign_verify(const uint8_t* bytes, const u64* cells, const u32* meta, u64 n, const u64* keccak, u64 n_keccak,
                                const u64* tx_rows, const u32* tx_flags, u64 n_tx_rows, const u64* r, u32 is_sig, u32* status) {
-    SignArgs a;
+    SignArgs a = {};
     a.bytes = bytes;
     a.cells.cells = cells;
     a.cells.flags = nullptr;
@@ -322,7 +322,7 @@ extern "C" int sim_state_assign(const u64* ops, const u32* op_flags, u64 n, u64*
 #include "../../zkevm_specs_amd/csrc/secp256k1.hpp"
 extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
-    EcdsaArgs a;
+    EcdsaArgs a = {};
     a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
     ecdsa_single_batch(a);
     a.msg_be = layout != 1u;
@@ -335,7 +335,7 @@ extern "C" int sim_ecdsa_verify(const uint8_t* bytes, u32 layout, const u32* v, 
 // the lane-pair form of the kernel (k_ecdsa.hip, L = 2) in a plain loop: two partial sums, added at the end
 extern "C" int sim_ecdsa_verify_pairs(const uint8_t* bytes, u32 layout, const u32* v, u32 v_stride, u64 n, u32* status) {
     static const u32 OFF[2][5] = {{0, 32, 64, 96, 128}, {64, 96, 160, 224, 256}};
-    EcdsaArgs a;
+    EcdsaArgs a = {};
     a.bytes = bytes; a.stride = layout ? 288 : 160; a.v = v; a.v_stride = v_stride; a.n = n; a.first = 0; a.out = nullptr; a.out_stride = 0;
     ecdsa_single_batch(a);
     a.msg_be = layout != 1u;
@@ -359,7 +359,7 @@ extern "C" int sim_ecdsa_verify_pairs(const uint8_t* bytes, u32 layout, const u3
 #include "../../zkevm_specs_amd/csrc/bytecode_assign.hpp"
 extern "C" int sim_bytecode_assign(const u64* in_rows, u64 n_rows, const u64* offsets, const u64* lengths, u64 n_codes, u32 k,
                                    const u64* r4, u64* rows_out) {
-    BcaArgs a;
+    BcaArgs a = {};
     a.in_rows = in_rows; a.offsets = offsets; a.lengths = lengths; a.n_in = n_rows; a.n_codes = n_codes; a.n_out = 1ull << k;
     std::vector<BcaChunk> chunks;
     std::vector<u32> c0(n_codes + 1, 0);
@@ -435,7 +435,7 @@ extern "C" int sim_copy_assign(const u64* events, const u32* flags, u64 n, const
     Fr r;
     for (int q = 0; q < 4; q++) { r.v[2 * q] = (u32)r4[q]; r.v[2 * q + 1] = (u32)(r4[q] >> 32); }
     cpa_fill_rpow(r, rpow.data());
-    CpaArgs a;
+    CpaArgs a = {};
     a.events = events; a.ev = ev.data(); a.row0 = row0.data(); a.n_events = n; a.n_rows = nr; a.data = data; a.rpow = rpow.data();
     a.chunks = chunks.data(); a.n_chunks = chunks.size(); a.chunk_acc = chunk_acc.data(); a.chunk_in = chunk_in.data(); a.ev_rlc = ev_rlc.data();
     a.rlc = rlc.data(); a.rows = rows; a.row_flags = row_flags; a.table = table; a.rw = rw; a.rw_flags = rw_flags;
@@ -449,7 +449,7 @@ extern "C" int sim_copy_assign(const u64* events, const u32* flags, u64 n, const
 #include "../../zkevm_specs_amd/csrc/pi_circuit.hpp"
 extern "C" int sim_pi_verify(const u64* rows, u64 n, const u64* keccak, u64 n_keccak, const u64* gas, u64 n_gas, u64 circuit_len,
                              const u64* keccak_rand, const u64* byte_pow_base, u32* status) {
-    PiArgs a;
+    PiArgs a = {};
     a.rows.cells = rows; a.rows.flags = nullptr; a.rows.n = n;
     HostTable tk, tg;
     host_table(tk, keccak, nullptr, n_keccak, KECCAK_NCELLS, keccak_key_hash);
@@ -483,7 +483,7 @@ extern "C" void sim_wide_witness(u32 op, const u64* x, u64* out, u32* flags, u64
 
 // PI circuit copy constraints (csrc/pi_circuit.hpp pi_copy_check)
 extern "C" int sim_pi_copy_verify(const u64* cells, const uint8_t* bytes, const u32* lens, u64 n, u32* status) {
-    PiCopyArgs a;
+    PiCopyArgs a = {};
     a.cells = cells; a.bytes = bytes; a.lens = lens; a.n = n;
     for (u64 i = 0; i < n; i++) status[i] = pi_copy_check(a, i);
     return 0;

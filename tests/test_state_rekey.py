@@ -240,3 +240,83 @@ def test_gpu_full_block_2p18():
         assert a.n_mpt() == n_mpt
     assert torch.equal(f_rows[: 57 * 4 * m].view(57, m, 4), st_rows) and torch.equal(f_flags[:m], st_flags)
     assert torch.equal(f_mpt[: 48 * n_mpt].view(n_mpt, 12, 4), mpt[:n_mpt])
+
+
+def compact_equals_full(rows, flags, device, tamper=0):
+    """ZK_OPT_STATE_COMPACT: the 15-cell witness of the assignment is columns 0..7 and 50..56 of the 57-cell one, and the State circuit
+    gives every row the status it gives the 57-cell row — also after damage to cells both forms carry"""
+    from zkevm_specs_amd import engine
+
+    rw = rows_to_rowmajor(rows, 14)
+    fl = np.array(flags, dtype=np.uint32)
+    with engine.open_state_assign_from_rw(rw, fl, device=device) as a:
+        assert a.run().ok
+        full, rf, mpt = a.read()
+    with engine.open_state_assign_from_rw(rw, fl, device=device, compact=True) as a:
+        assert a.run().ok
+        comp, rf_c, mpt_c = a.read()
+    assert comp.shape == (15, full.shape[1], 4) and np.array_equal(comp, np.concatenate([full[:8], full[50:]])) and np.array_equal(rf, rf_c)
+    assert np.array_equal(mpt, mpt_c)
+    rng = random.Random(len(rows) + tamper)
+    decomposed = set()  # rows whose address / storage-key cells were damaged: the cells the limb / byte columns decompose
+    for _ in range(tamper):
+        c, i = rng.randrange(15), rng.randrange(full.shape[1])
+        v = rng.choice([np.uint64(1), np.uint64(1) << np.uint64(40)])
+        w = rng.randrange(4)  # (words 1..3: also values the derived limbs cannot express — address >= 2^160, key halves >= 2^128)
+        comp[c, i, w] ^= v
+        full[c if c < 8 else c + 42, i, w] ^= v
+        if c in (4, 6, 7):
+            decomposed.add(i)
+    # the 57-cell form of the damaged witness: its limb / byte cells are the ones assigned from the UNDAMAGED address and key, so rows whose
+    # address / key cells were hit fail a recomposition check there (sites 5 / 7) exactly where the compact form reports them
+    with engine.open_state(full, rf, mpt, device=device) as s:
+        r_full = s.run()
+        st_full = s.read_status()
+    with engine.open_state(comp, rf, mpt, device=device, compact=True) as s:
+        r_comp = s.run()
+        st_comp = s.read_status()
+    bad = [j for j in range(len(st_full)) if st_full[j] != st_comp[j]]
+    # only damage to the address / key cells may be reported differently, and only at the damaged row and its two neighbours (the
+    # ordering checks compare a row's packed key with the previous row's, the last-access check looks at the next row's): the 57-cell
+    # row's stored limbs / bytes still spell the UNDAMAGED address / key — it fails 0.1 / 0.2 (sites 5 / 7) and packs the old bytes —,
+    # the compact row derives them from the damaged cell.  Damage to any other cell is reported identically.
+    n_rows = len(st_full)
+    for j in bad:
+        assert any(((j + d) % n_rows) in decomposed for d in (-1, 0, 1)), (j, hex(st_full[j]), hex(st_comp[j]))
+    for j in decomposed:  # (the compact row with another address / key may well be a row the State circuit accepts: it is another witness)
+        assert st_full[j] != 0, (j, hex(st_full[j]), hex(st_comp[j]))
+    if not tamper:
+        assert not bad and r_full.fail_count == r_comp.fail_count  # (the fuzz tables are no valid State witnesses: equal verdicts, not clean ones)
+    return len(bad), int(r_full.fail_count), int(r_comp.fail_count)
+
+
+def _valid_block_rw(n_steps):
+    from zkevm_specs_amd.synth_block import synth_block_trace
+
+    w = synth_block_trace(n_steps, seed=4, seg_len=96, n_contracts=2)
+    return wire.rowmajor_to_rows(w["rw"]), w["rw_flags"].tolist()
+
+
+def test_cpu_backend_compact_state_rows():
+    rng = random.Random(91)
+    rows, flags = rand_rw_table(rng, 1200, 0.0, 0.0)
+    compact_equals_full(rows, flags, "cpu")
+    rows, flags = _valid_block_rw(500)  # a consistent trace: the derived witness satisfies the State circuit in both forms
+    _, f_full, f_comp = compact_equals_full(rows, flags, "cpu")
+    assert f_full == 0 and f_comp == 0
+    _, f_full, f_comp = compact_equals_full(rows, flags, "cpu", tamper=60)
+    assert f_full >= 20 and f_comp >= 20
+
+
+@pytest.mark.gpu
+def test_gpu_compact_state_rows():
+    rng = random.Random(92)
+    for n in (3, 200, 5000):
+        rows, flags = rand_rw_table(rng, n, 0.0, 0.0)
+        compact_equals_full(rows, flags, None)
+        compact_equals_full(rows, flags, None, tamper=max(3, n // 25))
+    rows, flags = _valid_block_rw(3000)
+    _, f_full, f_comp = compact_equals_full(rows, flags, None)
+    assert f_full == 0 and f_comp == 0
+    _, f_full, f_comp = compact_equals_full(rows, flags, None, tamper=300)
+    assert f_full >= 100 and f_comp >= 100

@@ -23,7 +23,7 @@ copies = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 parts = synth_super_block(log_total, seed=5)
 dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
 blocks = [stage_block(parts, dev) for _ in range(copies)]
-bv = BlockVerifier(0)
+bv = BlockVerifier(0, state_compact=os.environ.get("ZK_STATE_COMPACT", "0") == "1")
 times = []
 for r in range(reps + 3):
     b = blocks[r % copies]

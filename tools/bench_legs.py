@@ -186,7 +186,7 @@ def config0_bytecode(args):
     return blk
 
 
-def own_process_config(name, log_rows, steps, warmup, args, with_cpu_baseline):
+def own_process_config(name, log_rows, steps, warmup, args, with_cpu_baseline, extra=()):
     """One other configuration measured in a process of its own (`python bench.py --workload <name> ...` as a child, its full record
     read back): the block pass and the Tx / Sig pass are several concurrent streams, and inside the default line's process — where
     the batch entry's pipeline streams, side streams and the earlier configurations' streams exist by then — they share hardware
@@ -198,7 +198,7 @@ def own_process_config(name, log_rows, steps, warmup, args, with_cpu_baseline):
     fd, path = tempfile.mkstemp(prefix="zk_bench_child_", suffix=".json", dir="/tmp")
     os.close(fd)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--log-rows", str(log_rows), "--steps", str(steps), "--warmup", str(warmup),
-           "--no-other-configs", "--no-cold-leg", "--no-fresh-leg"] + ([] if with_cpu_baseline else ["--no-cpu-baseline"])
+           "--no-other-configs", "--no-cold-leg", "--no-fresh-leg"] + ([] if with_cpu_baseline else ["--no-cpu-baseline"]) + list(extra)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
         t0 = time.perf_counter()
@@ -238,6 +238,10 @@ def other_configs(core, ctx, args):
             blk = own_process_config(name, log_rows, steps, warmup, args, want_cpu)
             if blk is not None:
                 out[f"{name}_2p{log_rows}"] = blk
+                if name == "super":  # the same block with the State rows in their compact form (ZK_OPT_STATE_COMPACT): a labelled second figure
+                    blk_c = own_process_config(name, log_rows, steps, warmup, args, False, extra=("--state-compact",))
+                    if blk_c is not None:
+                        out[f"{name}_2p{log_rows}_compact"] = blk_c
                 continue
         t_build = time.perf_counter()
         w = core.BUILDERS[name](ctx, log_rows, False)
@@ -296,7 +300,7 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
                     "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
 
 
-def block_oneshot(parts, to_dev, device=0, reps=8, copies=3):
+def block_oneshot(parts, to_dev, device=0, reps=8, copies=3, state_compact=False):
     """BASELINE config 5 as a ONE-SHOT: block.BlockVerifier.verify on a block not touched before (rotating over `copies` device-resident
     copies of the raw inputs) — the keccak table, the Bytecode / Copy / State assignments (State = the RW table re-keyed and radix-sorted
     on the device), the six opens, one pass of every circuit, collects, closes.  Wall clock per block, median of `reps` (3 untimed first)."""
@@ -305,7 +309,7 @@ def block_oneshot(parts, to_dev, device=0, reps=8, copies=3):
     from zkevm_specs_amd.block import BlockVerifier, stage_block
 
     blocks = [stage_block(parts, to_dev) for _ in range(copies)]
-    bv = BlockVerifier(device)
+    bv = BlockVerifier(device, state_compact=state_compact)
     times = []
     try:
         for r in range(reps + 3):

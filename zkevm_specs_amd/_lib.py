@@ -95,6 +95,7 @@ OPT_NO_STATE_SORT = 2
 OPT_GENERIC_INDEX = 4
 OPT_SINGLE_PASS = 8
 OPT_SIDE_STREAM = 16
+OPT_STATE_COMPACT = 32  # State rows without the limb / byte columns (include/zkevm_hip.h ZK_OPT_STATE_COMPACT)
 
 
 class EngineError(RuntimeError):

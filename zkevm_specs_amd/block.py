@@ -50,9 +50,10 @@ class BlockVerifier:
 
     CHAINS = ("state", "keccak", "copy", "rest")
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, state_compact=False):
         import torch
 
+        self.state_compact = bool(state_compact)  # ZK_OPT_STATE_COMPACT for the State chain (include/zkevm_hip.h)
         self.device = device
         self.lib = _lib.init(device)
         self.pool = ThreadPoolExecutor(max_workers=len(self.CHAINS))
@@ -105,8 +106,9 @@ class BlockVerifier:
             self._bind("state")
             mark("state", "start")
             n_rw = int(evm_in["rw"].shape[0])
-            rows_b, flags_b, mpt_b = self._buf("st_rows", 57 * 4 * (n_rw + 1), i64), self._buf("st_flags", n_rw + 1, i32), self._buf("st_mpt", 48 * (n_rw + 1), i64)
-            with engine.open_state_assign_from_rw(evm_in["rw"], evm_in["rw_flags"], rows_b, flags_b, mpt_b, device=self.device) as a:
+            nc = 15 if self.state_compact else 57
+            rows_b, flags_b, mpt_b = self._buf("st_rows", nc * 4 * (n_rw + 1), i64), self._buf("st_flags", n_rw + 1, i32), self._buf("st_mpt", 48 * (n_rw + 1), i64)
+            with engine.open_state_assign_from_rw(evm_in["rw"], evm_in["rw_flags"], rows_b, flags_b, mpt_b, device=self.device, compact=self.state_compact) as a:
                 mark("state", "assign opened (class scan + plan)")
                 if self.gate_state:  # the keccak pass (latency-bound, a handful of wavefronts) runs 4x slower beside the State chain's
                     done_keccak.wait()  # HBM-bound kernels: let it finish first (the EVM chain waits for its table)
@@ -117,7 +119,7 @@ class BlockVerifier:
             if not res.ok:
                 raise exception_for_code(res.first_fail_code, f"state witness assignment: {res.first_fail_row}")
             mark("state", "assign closed")
-            with engine.open_state(rows_b[: 57 * 4 * n].view(57, n, 4), flags_b[:n], mpt_b[: 48 * m].view(m, 12, 4), device=self.device) as s:
+            with engine.open_state(rows_b[: nc * 4 * n].view(nc, n, 4), flags_b[:n], mpt_b[: 48 * m].view(m, 12, 4), device=self.device, compact=self.state_compact) as s:
                 mark("state", "state opened")
                 results["state"] = s.run()
                 mark("state", "state pass done")

@@ -374,6 +374,8 @@ struct ZkCols {
     const u64* cells;
     const u32* flags;
     u64 n;
+    u32 skip;  // State rows only (ZK_OPT_STATE_COMPACT): 42 = the limb / byte columns 8..49 are absent, columns 50.. follow column 7; else 0
+    u32 pad_;
 };
 ZK_HD Fr zk_col(const ZkCols& w, u32 c, u64 i) { return fr_load(w.cells + ((u64)c * w.n + i) * 4); }
 

@@ -287,6 +287,9 @@ static int one_shot(zk_session* s, uint32_t* status_out, zk_result* result) {
     return rc;
 }
 #define NO_DEVICE_PTRS(opts, name) ARG_TRY(!((opts) & ZK_OPT_DEVICE_PTRS), name ": ZK_OPT_DEVICE_PTRS has no meaning on the CPU backend")
+#ifndef ZK_OPT_STATE_COMPACT
+#define ZK_OPT_STATE_COMPACT 32u
+#endif
 
 // ---- Fr vector ops ------------------------------------------------------------------------------------------------------
 extern "C" int zk_fr_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n, uint32_t opts) {
@@ -317,7 +320,9 @@ extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64
     NO_DEVICE_PTRS(opts, "zk_state_open");
     ARG_TRY(out && rows && n > 0 && n < (1ull << 32) && n_mpt < (1ull << 31), "zk_state_open: bad arguments");
     zk_session* s = new_session(n, true);
-    s->a64[0].assign(rows, rows + n * ST_NCELLS * 4);
+    const bool compact = opts & ZK_OPT_STATE_COMPACT;  // 15-cell rows, limb / byte decompositions derived (include/zkevm_hip.h)
+    s->a64[0].assign(rows, rows + n * (compact ? 15 : ST_NCELLS) * 4);
+    s->state.rows.skip = compact ? 42u : 0u;
     if (flags) s->a32[0].assign(flags, flags + n);
     else s->a32[0].assign(n, 0u);
     cpu_table(s->tab[0], mpt, nullptr, n_mpt, MPT_NCELLS, nullptr);
@@ -749,7 +754,8 @@ extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flag
     zk_session* s = new_session(n, false);
     s->a64[0].assign(ops, ops + n * ASG_NSLOTS * 4);
     s->a32[0].assign(op_flags, op_flags + n);
-    s->a64[1].assign(n * ASG_ROW_NCELLS * 4, 0);  // rows
+    const bool compact = opts & ZK_OPT_STATE_COMPACT;
+    s->a64[1].assign(n * (compact ? 15 : ASG_ROW_NCELLS) * 4, 0);  // rows
     s->a64[2].assign(n * ASG_MPT_NCELLS * 4, 0);  // mpt
     s->out32.assign(n, 0);                        // row flags
     u32 cap = 16;
@@ -762,6 +768,7 @@ extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flag
     a.rows = s->a64[1].data(); a.row_flags = s->out32.data(); a.mpt = s->a64[2].data();
     a.slots = s->a32[1].data(); a.mask = cap - 1; a.first = s->a32[2].data(); a.rank = s->a32[3].data();
     a.nb = 0; a.blk_cnt = nullptr; a.blk_next = nullptr;
+    a.compact = compact ? 1u : 0u;
     s->pass = state_assign_pass;
     s->assign_kind = 1;
     *out = s;

@@ -66,6 +66,29 @@ __global__ __launch_bounds__(256, ZK_STATE_DMA_OCC) void state_rows_dma_kernel(S
     tally_commit(tally, i, code);
 }
 
+// ZK_OPT_STATE_COMPACT: the 15-cell rows of a device-assigned witness (st_col / state_load_row derive the limb and byte
+// decompositions from the address and storage-key cells): fourteen wide cells per lane, no LDS ring.
+#ifndef ZK_STATE_COMPACT_OCC
+#define ZK_STATE_COMPACT_OCC 2
+#endif
+__global__ __launch_bounds__(256, ZK_STATE_COMPACT_OCC) void state_rows_compact_kernel(StateArgs a, u32* status, ZkTally* tally) {
+    tally_clear_twin(tally);
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 first = a.eval_lo + wave * ST_ROWS_PER_WAVE;
+    const u64 n = a.rows.n;
+    const u64 i_raw = lane == 0 ? (first == 0 ? n - 1 : first - 1) : first + lane - 1;
+    const bool evaluate = lane != 0 && i_raw < a.eval_hi;
+    const u64 i = i_raw >= n ? n - 1 : i_raw;
+    StRow C;
+    u32 code = 0;
+    state_load_row_compact(a.rows, i, C, code);
+    code = state_check_loaded<1>(a, i, C, C, code);
+    if (!evaluate) code = 0;
+    else if (status) status[i] = code;
+    tally_commit(tally, i, code);
+}
+
 // The lane-group forms (state_load_row_group<L>): L = 4 lanes per row = 16 rows per wavefront, L = 2 = 32 rows; the first
 // row of a wavefront is the halo row in front of the evaluated ones.
 #ifndef ZK_STATE_QUAD_OCC
@@ -112,6 +135,12 @@ static void launch_group(hipStream_t st, const StateArgs& a, u32* status, ZkTall
 }
 void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
     const int block = 256;
+    if (a.rows.skip) {
+        const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;
+        const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(state_rows_compact_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);
+        return;
+    }
     if (!state_use_dma()) {
         launch_group<4>(st, a, status, tally);
         return;

@@ -31,6 +31,8 @@ struct AssignArgs {
     u64 n;
     // The ops may also be read straight from an EVM-circuit RW table through the sorted order of its rows (state_rekey.hpp:
     // zk_state_assign_from_rw): op 0 = StartOp, op i = the re-keyed RW row order[i - 1]; `ops` / `op_flags` are then unused.
+    u32 compact;         // 1: rows out are the 15 cells of ZK_OPT_STATE_COMPACT ([15][n][4]: no limb / byte columns)
+    u32 pad_;
     const u64* rw;       // [n_rw][14][4] or nullptr
     const u32* rw_flags; // [n_rw] or nullptr
     const u32* order;    // [n - 1]
@@ -228,7 +230,7 @@ template <bool RW = false>
 ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     const u64 n = a.n;
     u64* rows = a.rows;
-#define ASG_OUT(c) (rows + ((u64)(c) * n + i) * 4)
+#define ASG_OUT(c) (rows + ((u64)(((c) >= 50 && a.compact) ? (c) - 42 : (c)) * n + i) * 4)
     const u32 flags = asg_flags<RW>(a, i);
     const Fr addr = asg_slot<RW>(a, ASG_ADDR, i);
     const Fr key = asg_slot<RW>(a, ASG_KEY, i);
@@ -248,10 +250,12 @@ ZK_HD u32 asg_write_row(const AssignArgs& a, u64 i, u64 root, bool is_first) {
     asg_store(ASG_OUT(5), asg_reduce(ft));
     asg_store(ASG_OUT(6), u256_lo(key));
     asg_store(ASG_OUT(7), u256_hi(key));
+    if (!a.compact) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) asg_store_u64(ASG_OUT(8 + k), (addr.v[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        for (int k = 0; k < 10; k++) asg_store_u64(ASG_OUT(8 + k), (addr.v[k >> 1] >> (16 * (k & 1))) & 0xffffu);
 #pragma unroll
-    for (int k = 0; k < 32; k++) asg_store_u64(ASG_OUT(18 + k), fr_byte(key, k));
+        for (int k = 0; k < 32; k++) asg_store_u64(ASG_OUT(18 + k), fr_byte(key, k));
+    }
     asg_store(ASG_OUT(50), vlo);
     asg_store(ASG_OUT(51), vhi);
     asg_store(ASG_OUT(52), ilo);

@@ -33,6 +33,13 @@ enum {
 };
 enum { MPT_NCELLS = 12 };
 
+// Column c of a State row.  With ZK_OPT_STATE_COMPACT (w.skip == 42) the witness is the 15 cells that are not limb / byte
+// decompositions — rw_counter .. storage_key hi, then value .. lexicographic selector — and the decompositions are DERIVED from the
+// address and storage-key cells where the checks need them (state_load_row): what assign_state_circuit's op2row computes
+// (state_circuit.py:834-842) is not stored and read back.  For witnesses assigned on the device (zk_state_assign*): 480 B per row
+// instead of 1,824.
+ZK_HD Fr st_col(const ZkCols& w, u32 c, u64 i) { return fr_load(w.cells + ((u64)(c >= 50u ? c - w.skip : c) * w.n + i) * 4); }
+
 struct StateArgs {
     ZkCols rows;
     ZkTable mpt;
@@ -69,17 +76,17 @@ ZK_HD bool state_pack_keys(const ZkCols& w, u64 i, Big18& out) {
     U256 key = fr_zero();
     bool ok = true;
     for (int b = 0; b < 32; b++) {
-        Fr c = zk_col(w, ST_BYTE0 + b, i);
+        Fr c = st_col(w, ST_BYTE0 + b, i);
         if (!fr_le_u64(c, 255)) ok = false;
         key.v[b >> 2] |= (c.v[0] & 0xff) << (8 * (b & 3));
     }
     if (!ok) return false;
-    big_shl_add(out, 0, 0, zk_col(w, ST_TAG, i));
-    big_shl_add(out, 0, 28, zk_col(w, ST_ID, i));         // v * 2^ID_BITS + id
-    big_shl_add(out, 5, 0, zk_col(w, ST_ADDR, i));        // v * 2^160 + address
-    big_shl_add(out, 0, 16, zk_col(w, ST_FIELD_TAG, i));  // v * 2^16 + field_tag
+    big_shl_add(out, 0, 0, st_col(w, ST_TAG, i));
+    big_shl_add(out, 0, 28, st_col(w, ST_ID, i));         // v * 2^ID_BITS + id
+    big_shl_add(out, 5, 0, st_col(w, ST_ADDR, i));        // v * 2^160 + address
+    big_shl_add(out, 0, 16, st_col(w, ST_FIELD_TAG, i));  // v * 2^16 + field_tag
     big_shl_add(out, 1, 0, key);                          // v * 2^32 + storage key (256-bit)
-    big_shl_add(out, 1, 0, zk_col(w, ST_RWC, i));         // v * 2^32 + rw_counter
+    big_shl_add(out, 1, 0, st_col(w, ST_RWC, i));         // v * 2^32 + rw_counter
     // keep 31 limbs of 16 bits = 496 bits
     out.v[15] &= 0xffffu;
     out.v[16] = 0;
@@ -94,14 +101,14 @@ ZK_HD bool big_lt(const Big18& a, const Big18& b) {
 
 ZK_HD bool state_keys_eq(const ZkCols& w, u64 i, u64 j) {
     bool eq = true;
-    for (int c = ST_TAG; c <= ST_KEY_HI; c++) eq = eq && fr_eq(zk_col(w, c, i), zk_col(w, c, j));
+    for (int c = ST_TAG; c <= ST_KEY_HI; c++) eq = eq && fr_eq(st_col(w, c, i), st_col(w, c, j));
     return eq;
 }
 ZK_HD bool state_pair_eq(const ZkCols& w, int c, u64 i, u64 j) {
-    return fr_eq(zk_col(w, c, i), zk_col(w, c, j)) && fr_eq(zk_col(w, c + 1, i), zk_col(w, c + 1, j));
+    return fr_eq(st_col(w, c, i), st_col(w, c, j)) && fr_eq(st_col(w, c + 1, i), st_col(w, c + 1, j));
 }
 ZK_HD bool state_pair_zero(const ZkCols& w, int c, u64 i) {
-    return fr_is_zero(zk_col(w, c, i)) && fr_is_zero(zk_col(w, c + 1, i));
+    return fr_is_zero(st_col(w, c, i)) && fr_is_zero(st_col(w, c + 1, i));
 }
 
 // MPT lookup with every field given (state_circuit.py:165-184 -> table.py:864-884): since the query covers all 12 cells and the
@@ -255,25 +262,38 @@ struct StRow {
 // of check_state_row :498-520); `code` is the row's running first-failure code.
 ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
     R.flags = w.flags ? w.flags[i] : 0u;
-    R.rwc = zk_col(w, ST_RWC, i);
-    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
-    R.tag = zk_col(w, ST_TAG, i);
-    R.id = zk_col(w, ST_ID, i);
-    R.addr = zk_col(w, ST_ADDR, i);
-    R.ftag = zk_col(w, ST_FIELD_TAG, i);
-    R.key_lo = zk_col(w, ST_KEY_LO, i);
-    R.key_hi = zk_col(w, ST_KEY_HI, i);
+    R.rwc = st_col(w, ST_RWC, i);
+    const Fr is_write = st_col(w, ST_IS_WRITE, i);
+    R.tag = st_col(w, ST_TAG, i);
+    R.id = st_col(w, ST_ID, i);
+    R.addr = st_col(w, ST_ADDR, i);
+    R.ftag = st_col(w, ST_FIELD_TAG, i);
+    R.key_lo = st_col(w, ST_KEY_LO, i);
+    R.key_hi = st_col(w, ST_KEY_HI, i);
     // 0.0 tag, id, field_tag ranges (:498-502)
     ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
     ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
     ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
     // 0.1 address limbs are 16-bit and recompose to address in Fr (:505-509)
+    U256 key = fr_zero();
+    if (w.skip) {
+        // derived decompositions (ZK_OPT_STATE_COMPACT): the ten limbs are the address's low 160 bits, the 32 bytes the key halves' low
+        // 128 bits each — in range by construction; what remains of 0.1 / 0.2 is that they recompose, i.e. that the cells are that narrow
+        U256 lc = fr_zero();
+#pragma unroll
+        for (int k = 0; k < 5; k++) lc.v[k] = R.addr.v[k];
+        ST_ASSERT(fr_eq(R.addr, lc), 5);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { key.v[k] = R.key_lo.v[k]; key.v[4 + k] = R.key_hi.v[k]; }
+        R.pack_ok = 1u;
+        ST_ASSERT(fr_eq(R.key_lo, u256_lo(key)) && fr_eq(R.key_hi, u256_hi(key)), 7);
+    } else {
     {
         U256 lc = fr_zero();
         bool limbs_ok = true;
 #pragma unroll
         for (int k = 0; k < 10; k++) {
-            const Fr limb = zk_col(w, ST_LIMB0 + k, i);
+            const Fr limb = st_col(w, ST_LIMB0 + k, i);
             limbs_ok = limbs_ok && fr_le_u64(limb, 65535);
             lc.v[k >> 1] |= (limb.v[0] & 0xffffu) << (16 * (k & 1));
         }
@@ -281,18 +301,18 @@ ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
         ST_ASSERT(fr_eq(R.addr, lc), 5);  // sum < 2^160 < p: integer value == field value
     }
     // 0.2 storage-key bytes are bytes and recompose to (lo, hi) (:512-517)
-    U256 key = fr_zero();
     {
         bool bytes_ok = true;
 #pragma unroll
         for (int b = 0; b < 32; b++) {
-            const Fr c = zk_col(w, ST_BYTE0 + b, i);
+            const Fr c = st_col(w, ST_BYTE0 + b, i);
             bytes_ok = bytes_ok && fr_le_u64(c, 255);
             key.v[b >> 2] |= (c.v[0] & 0xffu) << (8 * (b & 3));
         }
         R.pack_ok = bytes_ok ? 1u : 0u;
         ST_ASSERT(bytes_ok, 6);
         ST_ASSERT(fr_eq(R.key_lo, u256_lo(key)) && fr_eq(R.key_hi, u256_hi(key)), 7);
+    }
     }
     // 0.3 is_write boolean (:520)
     ST_ASSERT(fr_le_u64(is_write, 1), 8);
@@ -311,12 +331,55 @@ ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
 #pragma unroll
         for (int k = 0; k < 16; k++) R.pack[k] = out.v[k];
     }
-    R.val_lo = zk_col(w, ST_VAL_LO, i);
-    R.val_hi = zk_col(w, ST_VAL_HI, i);
-    R.init_lo = zk_col(w, ST_INIT_LO, i);
-    R.init_hi = zk_col(w, ST_INIT_HI, i);
-    R.root_lo = zk_col(w, ST_ROOT_LO, i);
-    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+    R.val_lo = st_col(w, ST_VAL_LO, i);
+    R.val_hi = st_col(w, ST_VAL_HI, i);
+    R.init_lo = st_col(w, ST_INIT_LO, i);
+    R.init_hi = st_col(w, ST_INIT_HI, i);
+    R.root_lo = st_col(w, ST_ROOT_LO, i);
+    R.root_hi = st_col(w, ST_ROOT_HI, i);
+}
+
+// state_load_row for the 15-cell rows alone (ZK_OPT_STATE_COMPACT): the device kernel's loader — none of the 42-column code.
+ZK_HD void state_load_row_compact(const ZkCols& w, u64 i, StRow& R, u32& code) {
+    R.flags = w.flags ? w.flags[i] : 0u;
+    R.rwc = st_col(w, ST_RWC, i);
+    const Fr is_write = st_col(w, ST_IS_WRITE, i);
+    R.tag = st_col(w, ST_TAG, i);
+    R.id = st_col(w, ST_ID, i);
+    R.addr = st_col(w, ST_ADDR, i);
+    R.ftag = st_col(w, ST_FIELD_TAG, i);
+    R.key_lo = st_col(w, ST_KEY_LO, i);
+    R.key_hi = st_col(w, ST_KEY_HI, i);
+    R.val_lo = st_col(w, ST_VAL_LO, i);
+    R.val_hi = st_col(w, ST_VAL_HI, i);
+    R.init_lo = st_col(w, ST_INIT_LO, i);
+    R.init_hi = st_col(w, ST_INIT_HI, i);
+    R.root_lo = st_col(w, ST_ROOT_LO, i);
+    R.root_hi = st_col(w, ST_ROOT_HI, i);
+    ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
+    ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
+    ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
+    ST_ASSERT((R.addr.v[5] | R.addr.v[6] | R.addr.v[7]) == 0u, 5);   // the derived limbs recompose iff address < 2^160
+    R.pack_ok = 1u;
+    ST_ASSERT(fr_fits128(R.key_lo) && fr_fits128(R.key_hi), 7);       // the derived bytes recompose iff both halves < 2^128
+    U256 keyv;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { keyv.v[k] = R.key_lo.v[k]; keyv.v[4 + k] = R.key_hi.v[k]; }
+    ST_ASSERT(fr_le_u64(is_write, 1), 8);
+    R.is_write01 = fr_is_zero(is_write) ? 0u : (fr_eq_u64(is_write, 1) ? 1u : 2u);
+    {
+        Big18 out;
+        for (int k = 0; k < 18; k++) out.v[k] = 0;
+        big_shl_add(out, 0, 0, R.tag);
+        big_shl_add(out, 0, 28, R.id);
+        big_shl_add(out, 5, 0, R.addr);
+        big_shl_add(out, 0, 16, R.ftag);
+        big_shl_add(out, 1, 0, keyv);
+        big_shl_add(out, 1, 0, R.rwc);
+        out.v[15] &= 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 16; k++) R.pack[k] = out.v[k];
+    }
 }
 
 #ifdef ZK_HOSTSIM
@@ -410,7 +473,7 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
         ST_ASSERT(fr_is_zero(val_hi), 24);
         ST_ASSERT(fr_is_zero(init_hi), 25);
         {
-            Fr lex = zk_col(w, ST_LEX, i);
+            Fr lex = st_col(w, ST_LEX, i);
             Fr d = fr_sub_u64(fr_sub(rwc, p_rwc), 1);
             ST_ASSERT(fr_is_zero(lex) || fr_is_zero(d), 26);  // p prime: product zero iff a factor is
             ST_ASSERT(!val_is_word, 27);
@@ -482,7 +545,7 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
 #else
             next_diff = 0;
             for (int c = 0; c < 6; c++) {
-                const Fr x = zk_col(w, ST_TAG + c, in);
+                const Fr x = st_col(w, ST_TAG + c, in);
                 for (int k = 0; k < 8; k++) next_diff |= x.v[k] ^ mine[c]->v[k];
             }
 #endif
@@ -635,7 +698,7 @@ ZK_HD void state_load_row_group(const ZkCols& w, u64 i, u32 q, StRow& R, u32& co
     constexpr int NS = 56 / L;
     Fr mine[NS];  // cell q + L k
 #pragma unroll
-    for (int k = 0; k < NS; k++) mine[k] = zk_col(w, q + (u32)L * (u32)k, i);
+    for (int k = 0; k < NS; k++) mine[k] = st_col(w, q + (u32)L * (u32)k, i);
     // limb cells 8..17 and key-byte cells 18..49 held by this lane: range flags + their bits of the packed values
     u32 lc[5] = {0, 0, 0, 0, 0}, key[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bad_limb = 0, bad_byte = 0;
 #pragma unroll
@@ -807,20 +870,20 @@ __device__ __forceinline__ void st_dma_steps(const ZkCols& w, uint4* ring, u32 l
 __device__ __forceinline__ void state_load_row_dma(const ZkCols& w, u64 i, const u64 off[2], uint4* ring, u32 lane, StRow& R, u32& code) {
     R.flags = w.flags ? w.flags[i] : 0u;
 #ifndef ST_DMA_BIG_LATE
-    R.rwc = zk_col(w, ST_RWC, i);
-    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
-    R.tag = zk_col(w, ST_TAG, i);
-    R.id = zk_col(w, ST_ID, i);
-    R.addr = zk_col(w, ST_ADDR, i);
-    R.ftag = zk_col(w, ST_FIELD_TAG, i);
-    R.key_lo = zk_col(w, ST_KEY_LO, i);
-    R.key_hi = zk_col(w, ST_KEY_HI, i);
-    R.val_lo = zk_col(w, ST_VAL_LO, i);
-    R.val_hi = zk_col(w, ST_VAL_HI, i);
-    R.init_lo = zk_col(w, ST_INIT_LO, i);
-    R.init_hi = zk_col(w, ST_INIT_HI, i);
-    R.root_lo = zk_col(w, ST_ROOT_LO, i);
-    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+    R.rwc = st_col(w, ST_RWC, i);
+    const Fr is_write = st_col(w, ST_IS_WRITE, i);
+    R.tag = st_col(w, ST_TAG, i);
+    R.id = st_col(w, ST_ID, i);
+    R.addr = st_col(w, ST_ADDR, i);
+    R.ftag = st_col(w, ST_FIELD_TAG, i);
+    R.key_lo = st_col(w, ST_KEY_LO, i);
+    R.key_hi = st_col(w, ST_KEY_HI, i);
+    R.val_lo = st_col(w, ST_VAL_LO, i);
+    R.val_hi = st_col(w, ST_VAL_HI, i);
+    R.init_lo = st_col(w, ST_INIT_LO, i);
+    R.init_hi = st_col(w, ST_INIT_HI, i);
+    R.root_lo = st_col(w, ST_ROOT_LO, i);
+    R.root_hi = st_col(w, ST_ROOT_HI, i);
 #endif
 #pragma unroll
     for (int k = 0; k < ST_DMA_RING; k++) st_dma_issue(w, k, ring, off);
@@ -829,20 +892,20 @@ __device__ __forceinline__ void state_load_row_dma(const ZkCols& w, u64 i, const
     const u32 lds_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)ring + lane * 32u;
     st_dma_steps<0>(w, ring, lds_lane, off, lc, key, bad_limb, bad_byte);
 #ifdef ST_DMA_BIG_LATE
-    R.rwc = zk_col(w, ST_RWC, i);
-    const Fr is_write = zk_col(w, ST_IS_WRITE, i);
-    R.tag = zk_col(w, ST_TAG, i);
-    R.id = zk_col(w, ST_ID, i);
-    R.addr = zk_col(w, ST_ADDR, i);
-    R.ftag = zk_col(w, ST_FIELD_TAG, i);
-    R.key_lo = zk_col(w, ST_KEY_LO, i);
-    R.key_hi = zk_col(w, ST_KEY_HI, i);
-    R.val_lo = zk_col(w, ST_VAL_LO, i);
-    R.val_hi = zk_col(w, ST_VAL_HI, i);
-    R.init_lo = zk_col(w, ST_INIT_LO, i);
-    R.init_hi = zk_col(w, ST_INIT_HI, i);
-    R.root_lo = zk_col(w, ST_ROOT_LO, i);
-    R.root_hi = zk_col(w, ST_ROOT_HI, i);
+    R.rwc = st_col(w, ST_RWC, i);
+    const Fr is_write = st_col(w, ST_IS_WRITE, i);
+    R.tag = st_col(w, ST_TAG, i);
+    R.id = st_col(w, ST_ID, i);
+    R.addr = st_col(w, ST_ADDR, i);
+    R.ftag = st_col(w, ST_FIELD_TAG, i);
+    R.key_lo = st_col(w, ST_KEY_LO, i);
+    R.key_hi = st_col(w, ST_KEY_HI, i);
+    R.val_lo = st_col(w, ST_VAL_LO, i);
+    R.val_hi = st_col(w, ST_VAL_HI, i);
+    R.init_lo = st_col(w, ST_INIT_LO, i);
+    R.init_hi = st_col(w, ST_INIT_HI, i);
+    R.root_lo = st_col(w, ST_ROOT_LO, i);
+    R.root_hi = st_col(w, ST_ROOT_HI, i);
 #endif
     U256 lcv = fr_zero(), keyv;
 #pragma unroll

@@ -780,13 +780,15 @@ extern "C" int zk_state_open(const uint64_t* rows, const uint32_t* flags, uint64
     ARG_TRY(out && rows && n > 0 && n < (1ull << 32), "zk_state_open: bad arguments");
     ARG_TRY(n_mpt < (1ull << 31), "zk_state_open: MPT table too large");
     const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    const bool compact = opts & ZK_OPT_STATE_COMPACT;
     zk_session* s = new zk_session();
     s->kind = SESSION_STATE;
     s->n = n;
     int rc = 0;
     const void* p = nullptr;
-    if ((rc = stage(s, rows, (size_t)n * ST_NCELLS * 32, dev, &p))) goto fail;
+    if ((rc = stage(s, rows, (size_t)n * (compact ? 15 : ST_NCELLS) * 32, dev, &p))) goto fail;
     s->state.rows.cells = (const u64*)p;
+    s->state.rows.skip = compact ? 42u : 0u;
     if ((rc = stage(s, flags, (size_t)n * 4, dev, &p))) goto fail;
     s->state.rows.flags = (const u32*)p;
     s->state.rows.n = n;
@@ -1397,7 +1399,8 @@ extern "C" int zk_state_assign_open(const uint64_t* ops, const uint32_t* op_flag
     a.rows = rows_dev;
     a.row_flags = row_flags_dev;
     a.mpt = mpt_dev;
-    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * ASG_ROW_NCELLS * 32))) goto fail;
+    a.compact = (opts & ZK_OPT_STATE_COMPACT) ? 1u : 0u;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * (a.compact ? 15 : ASG_ROW_NCELLS) * 32))) goto fail;
     if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)n * 4))) goto fail;
     if (!a.mpt && (rc = dev_alloc(s, (void**)&a.mpt, (size_t)n * ASG_MPT_NCELLS * 32))) goto fail;
     while (cap < 2 * n + 2) cap <<= 1;
@@ -1422,7 +1425,7 @@ extern "C" int zk_state_assign_read(zk_session* s, uint64_t* rows_host, uint32_t
     HIP_TRY(hipMemcpyAsync(&n_mpt, a.blk_cnt + a.nb, 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (n_mpt_out) *n_mpt_out = n_mpt;
-    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n * ASG_ROW_NCELLS * 32, hipMemcpyDeviceToHost, s->stream));
+    if (rows_host) HIP_TRY(hipMemcpyAsync(rows_host, a.rows, (size_t)a.n * (a.compact ? 15 : ASG_ROW_NCELLS) * 32, hipMemcpyDeviceToHost, s->stream));
     if (row_flags_host) HIP_TRY(hipMemcpyAsync(row_flags_host, a.row_flags, (size_t)a.n * 4, hipMemcpyDeviceToHost, s->stream));
     if (mpt_host) {
         ARG_TRY(mpt_capacity_rows >= n_mpt, "zk_state_assign_read: mpt buffer too small");
@@ -1567,7 +1570,8 @@ extern "C" int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* 
     a.rows = rows_dev;
     a.row_flags = row_flags_dev;
     a.mpt = mpt_dev;
-    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * ASG_ROW_NCELLS * 32))) goto fail;
+    a.compact = (opts & ZK_OPT_STATE_COMPACT) ? 1u : 0u;
+    if (!a.rows && (rc = dev_alloc(s, (void**)&a.rows, (size_t)n * (a.compact ? 15 : ASG_ROW_NCELLS) * 32))) goto fail;
     if (!a.row_flags && (rc = dev_alloc(s, (void**)&a.row_flags, (size_t)n * 4))) goto fail;
     if (!a.mpt && (rc = dev_alloc(s, (void**)&a.mpt, (size_t)n * ASG_MPT_NCELLS * 32))) goto fail;
     while (cap < 2 * n + 2) cap <<= 1;

@@ -153,13 +153,16 @@ def _randomness_cells(randomness, like):
     return cells
 
 
-def open_state(rows, flags, mpt, device=None):
-    """rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4] -> Session"""
+def open_state(rows, flags, mpt, device=None, compact=False):
+    """rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4] -> Session.  compact: rows uint64[15, n, 4], a device-assigned
+    witness without the limb / byte columns (ZK_OPT_STATE_COMPACT, include/zkevm_hip.h)"""
     lib = _lib.init(device)
-    _expect(rows, "state rows", 8, (57, None, 4))
+    _expect(rows, "state rows", 8, (15 if compact else 57, None, 4))
     _expect(flags, "state flags", 4, (rows.shape[1],))
     _expect(mpt, "mpt", 8, (None, 12, 4))
     (rows, flags, mpt), opts = _prep([rows, flags, mpt])
+    if compact:
+        opts |= _lib.OPT_STATE_COMPACT
     n = rows.shape[1]
     m = mpt.shape[0] if mpt is not None else 0
     h = ctypes.c_void_p()
@@ -454,10 +457,12 @@ class AssignSession(Session):
         check(self._lib.zk_state_assign_read(self._h, None, None, None, 0, ctypes.byref(m)), "zk_state_assign_read", self._lib)
         return int(m.value)
 
+    compact = False
+
     def read(self):
-        """-> (rows uint64[57, n, 4], flags uint32[n], mpt uint64[m, 12, 4]) on the host"""
+        """-> (rows uint64[57, n, 4] (15 with compact), flags uint32[n], mpt uint64[m, 12, 4]) on the host"""
         m = self.n_mpt()
-        rows = np.empty((57, self.n, 4), dtype=np.uint64)
+        rows = np.empty((15 if self.compact else 57, self.n, 4), dtype=np.uint64)
         flags = np.empty(self.n, dtype=np.uint32)
         mpt = np.empty((m, 12, 4), dtype=np.uint64)
         got = ctypes.c_uint64()
@@ -466,7 +471,7 @@ class AssignSession(Session):
         return rows, flags, mpt
 
 
-def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None):
+def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None, compact=False):
     """ops uint64[12, n, 4] (column-major Operation slots, include/zkevm_hip.h), op_flags uint32[n] -> AssignSession.
     numpy inputs are staged to HBM; torch CUDA tensors are used in place, and rows_dev uint64[57, n, 4] /
     row_flags_dev uint32[n] / mpt_dev uint64[n, 12, 4] (optional CUDA tensors) then receive the outputs, ready
@@ -475,18 +480,22 @@ def open_state_assign(ops, op_flags, rows_dev=None, row_flags_dev=None, mpt_dev=
     _expect(ops, "state ops", 8, (12, None, 4))
     n = int(ops.shape[1])
     _expect(op_flags, "op_flags", 4, (n,))
-    _expect(rows_dev, "rows_dev", 8, (57, n, 4))
+    _expect(rows_dev, "rows_dev", 8, (15 if compact else 57, n, 4))
     _expect(row_flags_dev, "row_flags_dev", 4, (n,))
     _expect(mpt_dev, "mpt_dev", 8, (n, 12, 4))
     (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([ops, op_flags, rows_dev, row_flags_dev, mpt_dev],
                                                                     outputs=(2, 3, 4))
+    if compact:
+        opts |= _lib.OPT_STATE_COMPACT
     h = ctypes.c_void_p()
     check(lib.zk_state_assign_open(_lib.ptr(ops), _lib.ptr(op_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev),
                                    _lib.ptr(mpt_dev), opts, ctypes.byref(h)), "zk_state_assign_open")
-    return AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
+    s = AssignSession(h, n, (ops, op_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
+    s.compact = bool(compact)
+    return s
 
 
-def open_state_assign_from_rw(rw, rw_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None):
+def open_state_assign_from_rw(rw, rw_flags, rows_dev=None, row_flags_dev=None, mpt_dev=None, device=None, compact=False):
     """rw uint64[n, 14, 4] + rw_flags uint32[n] (the EVM circuit's RW table) -> AssignSession over the n_ops = 1 + kept rows State
     rows (session.n): re-keying + sort + witness assignment in one session, the op list never materialised
     (zk_state_assign_from_rw_open).  With CUDA tensors, rows_dev / row_flags_dev / mpt_dev are FLAT buffers of capacity
@@ -496,15 +505,19 @@ def open_state_assign_from_rw(rw, rw_flags, rows_dev=None, row_flags_dev=None, m
     _expect(rw, "rw table", 8, (None, 14, 4))
     n = int(rw.shape[0])
     _expect(rw_flags, "rw_flags", 4, (n,))
-    for buf, name, size, cap in ((rows_dev, "rows_dev", 8, 57 * 4 * (n + 1)), (row_flags_dev, "row_flags_dev", 4, n + 1), (mpt_dev, "mpt_dev", 8, 48 * (n + 1))):
+    for buf, name, size, cap in ((rows_dev, "rows_dev", 8, (15 if compact else 57) * 4 * (n + 1)), (row_flags_dev, "row_flags_dev", 4, n + 1), (mpt_dev, "mpt_dev", 8, 48 * (n + 1))):
         _expect(buf, name, size, (None,))
         if buf is not None and int(buf.shape[0]) < cap:
             raise ValueError(f"{name} holds fewer than {cap} entries")
     (rw, rw_flags, rows_dev, row_flags_dev, mpt_dev), opts = _prep([rw, rw_flags, rows_dev, row_flags_dev, mpt_dev], outputs=(2, 3, 4))
+    if compact:
+        opts |= _lib.OPT_STATE_COMPACT
     h, n_ops = ctypes.c_void_p(), ctypes.c_uint64()
     check(lib.zk_state_assign_from_rw_open(_lib.ptr(rw), _lib.ptr(rw_flags), n, _lib.ptr(rows_dev), _lib.ptr(row_flags_dev), _lib.ptr(mpt_dev),
                                            opts, ctypes.byref(n_ops), ctypes.byref(h)), "zk_state_assign_from_rw_open")
-    return AssignSession(h, int(n_ops.value), (rw, rw_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
+    s = AssignSession(h, int(n_ops.value), (rw, rw_flags, rows_dev, row_flags_dev, mpt_dev), lib=lib)
+    s.compact = bool(compact)
+    return s
 
 
 class RekeySession(Session):

@@ -158,7 +158,7 @@ class SuperCircuit:
     """Sessions of the four circuits over one witness set; launch() enqueues one pass of each, collect() returns
     ({circuit: Result}, total fail_count, first failing (circuit, row, code))."""
 
-    def __init__(self, parts, device=None, to_device=None, shard=None):
+    def __init__(self, parts, device=None, to_device=None, shard=None, state_compact=False):
         """shard = (rank, world): ONE global block, every circuit's rows cut into `world` contiguous ranges with that
         circuit's halo (distributed.HALO), all tables whole on every rank (BASELINE configs[4]).  The
         witness assignment (State / Bytecode / Copy rows from ops / unrolled codes / copy events) runs over the whole
@@ -175,6 +175,10 @@ class SuperCircuit:
         on_dev = hasattr(evm_w["steps"], "is_cuda")
         odev = evm_w["steps"].device if on_dev else None
         self.state_from_rw = parts.get("state_ops") is None
+        # state_compact: the State rows are assigned and evaluated without their limb / byte columns (ZK_OPT_STATE_COMPACT: 15 of the 57
+        # cells; the decompositions are derived where the checks use them).  Only for rows derived on the device from the RW table.
+        self.state_compact = bool(state_compact) and self.state_from_rw
+        nc = 15 if self.state_compact else 57
         if self.state_from_rw:
             # State rows: the block's own RW table re-keyed, sorted and assigned on the device in one session (zk_state_assign_from_rw:
             # Target -> Tag / key slots, LSD radix sort on (tag, id, address, field_tag, storage_key, rw_counter), op2row) — no host step
@@ -183,15 +187,15 @@ class SuperCircuit:
                 import torch
 
                 n_rw = int(evm_w["rw"].shape[0])
-                rows_b = torch.empty(57 * 4 * (n_rw + 1), dtype=torch.int64, device=evm_w["rw"].device)
+                rows_b = torch.empty(nc * 4 * (n_rw + 1), dtype=torch.int64, device=evm_w["rw"].device)
                 flags_b = torch.empty(n_rw + 1, dtype=torch.int32, device=evm_w["rw"].device)
                 mpt_b = torch.empty(48 * (n_rw + 1), dtype=torch.int64, device=evm_w["rw"].device)
-                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], rows_b, flags_b, mpt_b, device=device) as a:
+                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], rows_b, flags_b, mpt_b, device=device, compact=self.state_compact) as a:
                     res = a.run()
                     n, m = a.n, a.n_mpt()
-                rows, flags, mpt = rows_b[: 57 * 4 * n].view(57, n, 4), flags_b[:n], mpt_b[: 48 * m].view(m, 12, 4)
+                rows, flags, mpt = rows_b[: nc * 4 * n].view(nc, n, 4), flags_b[:n], mpt_b[: 48 * m].view(m, 12, 4)
             else:
-                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], device=device) as a:
+                with engine.open_state_assign_from_rw(evm_w["rw"], evm_w["rw_flags"], device=device, compact=self.state_compact) as a:
                     res = a.run()
                     rows, flags, mpt = a.read()
         else:
@@ -279,7 +283,7 @@ class SuperCircuit:
             tx_w, self.row_lo["tx"] = distributed.shard_units(tx_w, rank, world)
         self.sessions = {
             "evm": engine.open_evm(evm_w, device=device, side_stream=True),
-            "state": engine.open_state(rows, flags, mpt, device=device),
+            "state": engine.open_state(rows, flags, mpt, device=device, compact=self.state_compact),
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign(tx_w, r_tx, False, device=device),
         }
