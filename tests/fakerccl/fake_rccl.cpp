@@ -52,6 +52,15 @@ int barrier(Comm* c) {
 }
 }  // namespace
 
+// What kind of buffers this library's ncclAllGather takes (csrc/dist_tally.hpp reads it: a real RCCL has no such symbol and takes device
+// memory): 0 = host pointers (the CPU backend's ranks), 1 = device pointers (the HIP library's).  A mismatch is refused at zk_dist_init.
+extern "C" int zk_collective_buffers(void) {
+#ifdef FAKE_RCCL_HIP
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int ncclGetUniqueId(UniqueId* id) {
     memset(id->internal, 0, sizeof id->internal);
     unsigned char rnd[12] = {0};

@@ -201,7 +201,9 @@ struct zk_comm {
             return -3;                                                                                                                         \
         }                                                                                                                                      \
     } while (0)
-static bool host_collective() { return getenv("ZK_RCCL_LIB") && zkdist::rccl().ok && zkdist::rccl().named_by_env; }
+// a collective library that takes HOST buffers: it has to say so itself (`zk_collective_buffers() == 0`, dist_tally.hpp) — ZK_RCCL_LIB
+// may just as well name the integrator's own build of RCCL, whose ncclAllGather must never see host pointers
+static bool host_collective() { return getenv("ZK_RCCL_LIB") && zkdist::rccl().ok && zkdist::rccl().named_by_env && zkdist::rccl().buffers == 0; }
 extern "C" int zk_dist_unique_id(uint8_t* id) {
     ARG_TRY(id, "zk_dist_unique_id: id is null");
     memset(id, 0, ZK_DIST_ID_BYTES);

@@ -20,6 +20,8 @@ struct RcclApi {
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     bool named_by_env = false;  // ZK_RCCL_LIB chose the library (the integrator's own build of RCCL, or a host-buffer stand-in)
+    int buffers = 1;            // what its ncclAllGather takes: 1 device memory (RCCL; any library without the marker), 0 host memory
+                                // (a stand-in that exports `int zk_collective_buffers(void)` returning 0: tests/fakerccl)
 };
 static const int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h ncclDataType_t)
 // librccl is bound at first use: nothing else in the library needs it, and torch — when it is in the process — has usually
@@ -41,6 +43,7 @@ inline RcclApi& rccl() {
         a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
         a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy;
+        if (auto marker = (int (*)(void))dlsym(h, "zk_collective_buffers")) a.buffers = marker() ? 1 : 0;
         return a;
     }();
     return api;

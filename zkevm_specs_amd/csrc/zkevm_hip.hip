@@ -2521,6 +2521,8 @@ extern "C" int zk_dist_init(const uint8_t* id, int rank, int world, zk_comm** ou
     ARG_TRY(t_device >= 0, "zk_dist_init: call zk_init first");
     ARG_TRY(id && out && world >= 1 && rank >= 0 && rank < world, "zk_dist_init: bad arguments");
     ARG_TRY(rccl().ok, "zk_dist_init: librccl.so.1 could not be loaded");
+    ARG_TRY(rccl().buffers == 1, "zk_dist_init: ZK_RCCL_LIB names a collective library that takes HOST buffers (zk_collective_buffers() == 0): the "
+                                 "HIP library hands it device memory");
     HIP_TRY(hipSetDevice(t_device));
     zk_comm* c = new zk_comm();
     c->rank = rank; c->world = world; c->device = t_device;
