@@ -420,6 +420,33 @@ int zk_copy_assign_read(zk_session* s, uint64_t* rows_host, uint32_t* row_flags_
 int zk_copy_assign(const zk_copy_events* ev, uint64_t* rows_out, uint32_t* row_flags_out, uint64_t* table_out,
                    uint64_t* rw_out, uint32_t* rw_flags_out, uint32_t opts, zk_result* result);
 
+/* ---- A block as a ONE-SHOT (BASELINE config 5; round 6): everything the Super circuit derives on the device and one evaluation pass of
+ *      its six circuits, from the block's raw device-resident inputs, in one call.  The reference has no super-circuit driver (SURVEY.md
+ *      Appendix A.14); the inputs are what its own constructors take: the EVM circuit's tables and steps (`Tables`, evm_circuit/table.py:
+ *      583-625), the byte strings the block hashes (`KeccakCircuit.add`, evm_circuit/typing.py:854-865: the contracts first, then the
+ *      SHA3 inputs), the copy events (`CopyCircuit.copy`, :1010-1091), the Exp circuit's rows, the Tx units.  Derived inside: the keccak
+ *      table (zk_keccak_*: rows [0, n_codes) are the Bytecode circuit's table, the rest the EVM circuit's), the Bytecode circuit's rows
+ *      (zk_bytecode_assign_*: the unrolled bytecodes ARE evm.bytecode, cut by code_offsets / code_lengths), the Copy circuit's rows and
+ *      the EVM circuit's copy table (zk_copy_assign_*; the Copy circuit looks up evm.rw / evm.bytecode / evm.tx), the State circuit's
+ *      rows from evm.rw (zk_state_assign_from_rw_open).  evm.copy / evm.keccak are ignored.  Four host threads drive four chains on
+ *      four streams of the calling thread's device: State | keccak -> Bytecode | copy assignment -> Copy + EVM | Exp + Tx.
+ *      Every pointer is a device pointer (opts must carry ZK_OPT_DEVICE_PTRS; ZK_OPT_STATE_COMPACT is honoured).  results[c]: the
+ *      tally of circuit c (enum below; rows_evaluated == 0 for a circuit without rows); a failing witness ASSIGNMENT (keccak input,
+ *      State op, ...) is an error return with the text in zk_last_error.  chain_end_ms (nullable): host milliseconds from the call
+ *      to the end of each chain (measurement aid). */
+typedef struct zk_block {
+    zk_evm_tables evm;
+    const uint8_t* hashed_data; uint64_t hashed_bytes; const uint64_t* hashed_offsets;  /* n_hashed + 1 offsets */
+    uint64_t n_codes, n_hashed;
+    const uint64_t* randomness;                                                          /* one cell: the block's keccak randomness */
+    const uint64_t* code_offsets; const uint64_t* code_lengths; uint64_t n_bytecodes; uint32_t k; uint32_t reserved;
+    zk_copy_events copy_events;                                                          /* n_events == 0: no Copy circuit rows */
+    const uint64_t* exp_rows; uint64_t n_exp_rows;                                       /* column-major uint64[21][n][4] */
+    zk_sign_units tx;                                                                    /* n_units == 0: no Tx circuit */
+} zk_block;
+enum { ZK_BLOCK_EVM = 0, ZK_BLOCK_STATE = 1, ZK_BLOCK_BYTECODE = 2, ZK_BLOCK_TX = 3, ZK_BLOCK_COPY = 4, ZK_BLOCK_EXP = 5, ZK_BLOCK_NCIRCUITS = 6 };
+int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results /* [ZK_BLOCK_NCIRCUITS] */, double* chain_end_ms /* [4], nullable */);
+
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous) on the session's stream.  status_dev: optional DEVICE buffer of
  *         n uint32 receiving the per-row status codes.  A caller-provided status_dev is final in stream order: once the

@@ -293,3 +293,35 @@ def test_block_one_shot_from_raw_inputs():
         rw[i, 8, 0] ^= np.uint64(1)
     finally:
         bv.close()
+
+
+@pytest.mark.gpu
+def test_block_one_shot_native_entry():
+    """zk_block_verify (the chains on threads inside the library) == block.BlockVerifier (the same chains from Python), full and compact
+    State rows, clean and tampered block"""
+    import torch
+
+    from zkevm_specs_amd.block import BlockVerifier, stage_block, verify_block_native
+    from zkevm_specs_amd.super_circuit import BLOCK_CIRCUITS, synth_super_block
+
+    p = synth_super_block(16, seed=3)
+    dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
+    bv = BlockVerifier(0)
+    try:
+        for compact in (False, True):
+            for _ in range(2):
+                results, total, ends = verify_block_native(stage_block(p, dev), 0, compact)
+                assert total == 0 and set(results) == set(BLOCK_CIRCUITS) and {k: r.rows_evaluated for k, r in results.items()} == p["rows"]
+                assert all(e > 0 for e in ends)
+        rw = p["evm"]["rw"]
+        i = next(j for j in range(2000, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)
+        rw[i, 8, 0] ^= np.uint64(1)
+        b = stage_block(p, dev)
+        want, _ = bv.verify(b)
+        got, total, _ = verify_block_native(stage_block(p, dev), 0, False)
+        assert total == sum(r.fail_count for r in want.values()) > 0
+        for k in BLOCK_CIRCUITS:
+            assert (got[k].fail_count, got[k].first_fail_row, got[k].first_fail_code) == (want[k].fail_count, want[k].first_fail_row, want[k].first_fail_code), k
+        rw[i, 8, 0] ^= np.uint64(1)
+    finally:
+        bv.close()

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zkevm_specs_amd import _lib  # noqa: E402
 
 _lib.load()
-from zkevm_specs_amd.block import BlockVerifier, stage_block  # noqa: E402
+from zkevm_specs_amd.block import BlockVerifier, stage_block, verify_block_native  # noqa: E402
 from zkevm_specs_amd.super_circuit import synth_super_block  # noqa: E402
 
 log_total = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -23,18 +23,24 @@ copies = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 parts = synth_super_block(log_total, seed=5)
 dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
 blocks = [stage_block(parts, dev) for _ in range(copies)]
-bv = BlockVerifier(0, state_compact=os.environ.get("ZK_STATE_COMPACT", "0") == "1")
+compact = os.environ.get("ZK_STATE_COMPACT", "0") == "1"
+native = os.environ.get("ZK_BLOCK_NATIVE", "0") == "1"  # zk_block_verify (the chains on threads inside the library) instead of block.py's Python threads
+bv = BlockVerifier(0, state_compact=compact)
+last_trace = []
 times = []
 for r in range(reps + 3):
     b = blocks[r % copies]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results, total = bv.verify(b)
+    if native:
+        results, total, ends = verify_block_native(b, 0, compact)
+    else:
+        results, total = bv.verify(b)
     t1 = time.perf_counter()
     assert total == 0, {k: (v.fail_count, v.first_fail_row, v.first_fail_code) for k, v in results.items()}
     if r >= 3:
         times.append((t1 - t0) * 1e3)
-        last_trace = sorted(bv.trace, key=lambda e: e[2])
+        last_trace = [("native", f"chain {c} end", t) for c, t in zip(("state", "keccak", "copy", "rest"), ends)] if native else sorted(bv.trace, key=lambda e: e[2])
 times.sort()
 rows = {k: v.rows_evaluated for k, v in results.items()}
 print(json.dumps({"block_rows": rows, "total_rows": sum(rows.values()), "reps": reps, "copies": copies,

@@ -301,34 +301,29 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
 
 
 def block_oneshot(parts, to_dev, device=0, reps=8, copies=3, state_compact=False):
-    """BASELINE config 5 as a ONE-SHOT: block.BlockVerifier.verify on a block not touched before (rotating over `copies` device-resident
+    """BASELINE config 5 as a ONE-SHOT: zk_block_verify on a block not touched before (rotating over `copies` device-resident
     copies of the raw inputs) — the keccak table, the Bytecode / Copy / State assignments (State = the RW table re-keyed and radix-sorted
     on the device), the six opens, one pass of every circuit, collects, closes.  Wall clock per block, median of `reps` (3 untimed first)."""
     import torch
 
-    from zkevm_specs_amd.block import BlockVerifier, stage_block
+    from zkevm_specs_amd.block import stage_block, verify_block_native
 
     blocks = [stage_block(parts, to_dev) for _ in range(copies)]
-    bv = BlockVerifier(device, state_compact=state_compact)
     times = []
-    try:
-        for r in range(reps + 3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            results, total = bv.verify(blocks[r % copies])
-            t1 = time.perf_counter()
-            assert total == 0, {k: (v.fail_count, v.first_fail_row, v.first_fail_code) for k, v in results.items()}
-            if r >= 3:
-                times.append((t1 - t0) * 1e3)
-        trace = sorted(bv.trace, key=lambda e: e[2])
-    finally:
-        bv.close()
+    for r in range(reps + 3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        results, total, ends = verify_block_native(blocks[r % copies], device, state_compact)
+        t1 = time.perf_counter()
+        assert total == 0, {k: (v.fail_count, v.first_fail_row, v.first_fail_code) for k, v in results.items()}
+        if r >= 3:
+            times.append((t1 - t0) * 1e3)
     times.sort()
     rows = sum(v.rows_evaluated for v in results.values())
     ms = times[len(times) // 2]
     return {"ms": ms, "min_ms": times[0], "max_ms": times[-1], "rows": rows, "rows_per_s": rows / (ms / 1e3), "reps": reps, "copies": copies,
-            "chain_end_ms": {c: max(t for cc, _, t in trace if cc == c) for c in ("state", "keccak", "copy", "rest")},
-            "note": "wall clock of block.BlockVerifier.verify: four host threads / HIP streams (State chain: class scan + radix sort + assignment + "
+            "chain_end_ms": dict(zip(("state", "keccak", "copy", "rest"), ends)),
+            "note": "wall clock of zk_block_verify (block.verify_block_native): four host threads / HIP streams inside the library (State chain: class scan + radix sort + assignment + "
                     "State circuit; keccak table -> Bytecode assignment + circuit; copy assignment -> Copy circuit + EVM open + pass; Exp + Tx); "
                     "every derived table and witness is rebuilt on the device for every block"}
 

@@ -45,6 +45,52 @@ def stage_block(parts, to_device):
     return b
 
 
+def native_block(b):
+    """the zk_block struct of a staged block (stage_block): built once, every pointer is a device pointer of a tensor `b` keeps alive"""
+    def p(x, n=1):
+        return ctypes.c_void_p(x.data_ptr()).value if (x is not None and n) else None
+
+    def rows(x):
+        return 0 if x is None else int(x.shape[0])
+
+    e = b["evm"]
+    evm = _lib.ZkEvmTables(
+        p(e["steps"]), rows(e["steps"]), p(e.get("rw"), rows(e.get("rw"))), p(e.get("rw_flags"), rows(e.get("rw"))), rows(e.get("rw")),
+        p(e.get("bytecode"), rows(e.get("bytecode"))), rows(e.get("bytecode")),
+        p(e.get("tx"), rows(e.get("tx"))), p(e.get("tx_flags"), rows(e.get("tx"))), rows(e.get("tx")),
+        p(e.get("block"), rows(e.get("block"))), p(e.get("block_flags"), rows(e.get("block"))), rows(e.get("block")),
+        0, 0, None, 0, None, 0, p(e.get("exp"), rows(e.get("exp"))), rows(e.get("exp")),
+        None, None, None, 0, None, 0, None, 0, 0, 0)
+    data, offsets, n_codes, n_msgs = b["keccak"]
+    ub_rows, ub_off, ub_len, k = b["bytecode"]
+    ev, fl, da, of, r_copy = b["copy_events"]
+    ce = _lib.ZkCopyEvents(p(ev), p(fl), rows(ev), p(da, rows(da)), p(of), p(r_copy))
+    tx_w, r_tx = b["tx"]
+    n_tx = rows(tx_w.get("bytes"))
+    tx = _lib.ZkSignUnits(p(tx_w.get("bytes"), n_tx), p(tx_w.get("cells"), n_tx), p(tx_w.get("meta"), n_tx), n_tx, p(r_tx),
+                          p(tx_w.get("keccak"), rows(tx_w.get("keccak"))), rows(tx_w.get("keccak")),
+                          p(tx_w.get("tx_rows"), rows(tx_w.get("tx_rows"))), p(tx_w.get("tx_flags"), rows(tx_w.get("tx_rows"))), rows(tx_w.get("tx_rows")), 0)
+    ex = b["exp_rows"]
+    n_exp = 0 if ex is None else int(ex.shape[1])
+    return _lib.ZkBlock(evm, p(data, int(data.shape[0])), int(data.shape[0]), p(offsets), int(n_codes), int(n_msgs), p(b["r"]),
+                        p(ub_off), p(ub_len), int(ub_len.shape[0]), int(k), 0, ce, p(ex, n_exp), n_exp, tx)
+
+
+def verify_block_native(b, device=0, state_compact=False):
+    """zk_block_verify (include/zkevm_hip.h): the same chains as BlockVerifier.verify, driven by four threads inside the library —
+    -> ({circuit: Result}, total fail count, chain_end_ms[4])"""
+    lib = _lib.init(device)
+    blk = b.get("_native")
+    if blk is None:
+        blk = b["_native"] = native_block(b)
+    res = (_lib.ZkResult * 6)()
+    ends = (ctypes.c_double * 4)()
+    opts = _lib.OPT_DEVICE_PTRS | (_lib.OPT_STATE_COMPACT if state_compact else 0)
+    _lib.check(lib.zk_block_verify(ctypes.byref(blk), opts, res, ends), "zk_block_verify", lib)
+    results = {name: engine.Result(res[i]) for i, name in enumerate(_lib.BLOCK_CIRCUITS) if res[i].rows_evaluated or res[i].launches}
+    return results, sum(r.fail_count for r in results.values()), list(ends)
+
+
 class BlockVerifier:
     """Persistent worker threads + streams + output buffers for verify(): nothing is allocated or created per block."""
 

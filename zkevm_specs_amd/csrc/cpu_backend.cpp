@@ -938,6 +938,13 @@ extern "C" int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* 
     return rc;
 }
 
+// the block one-shot is four chains on four device streams: there is nothing to overlap on the host — callers of the CPU backend use the
+// per-circuit entries (zkevm_specs_amd/super_circuit.py does, on host arrays)
+extern "C" int zk_block_verify(const zk_block*, uint32_t, zk_result*, double*) {
+    g_err = "zk_block_verify: not available on the CPU backend (it needs ZK_OPT_DEVICE_PTRS); use the per-circuit entries";
+    return -1;
+}
+
 static void bytecode_assign_pass(zk_session* s) {
     BcaArgs& a = s->bca;
     for (u64 c = 0; c < a.n_chunks; c++) bca_chunk(a, c);

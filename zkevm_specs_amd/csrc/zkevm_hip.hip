@@ -2557,3 +2557,187 @@ extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_of
     zkdist::tally_reduce(c->h_buf, c->world, local, global);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// zk_block_verify: a block as a one-shot (include/zkevm_hip.h).  The chains are the C entries above, driven by four host threads:
+// every open has its own small host round trip (class scan, offsets, event plan), so the overlap has to come from threads.
+// ---------------------------------------------------------------------------------------
+#include <condition_variable>
+#include <thread>
+static hipStream_t g_block_stream[ZK_MAX_DEVICES][4] = {{nullptr}};
+struct BlockShared {
+    std::mutex m;
+    std::condition_variable cv;
+    bool keccak_enqueued = false, keccak_failed = false;
+    const u64* keccak_rows = nullptr;
+    hipEvent_t ev_keccak = nullptr;
+    int rc[4] = {0, 0, 0, 0};
+    std::string err[4];
+    double end_ms[4] = {0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t0;
+};
+#define BLK_TRY(expr) do { if ((rc = (expr))) goto done; } while (0)
+static int block_run_pass(zk_session* s, zk_result* r) {
+    int rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, r);
+    return rc;
+}
+extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results, double* chain_end_ms) {
+    ARG_TRY(t_device >= 0, "zk_block_verify: call zk_init first");
+    ARG_TRY(b && results && (opts & ZK_OPT_DEVICE_PTRS), "zk_block_verify: needs a block, a result array and ZK_OPT_DEVICE_PTRS");
+    ARG_TRY(b->evm.steps && b->evm.n_steps >= 2 && b->evm.rw && b->evm.n_rw && b->randomness && b->hashed_offsets && b->n_hashed >= b->n_codes &&
+            b->code_offsets && b->code_lengths && b->n_bytecodes, "zk_block_verify: bad arguments");
+    HIP_TRY(hipSetDevice(t_device));
+    const int device = t_device;
+    const uint32_t dev_opts = ZK_OPT_DEVICE_PTRS, st_opts = ZK_OPT_DEVICE_PTRS | (opts & ZK_OPT_STATE_COMPACT);
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        for (int c = 0; c < 4; c++)
+            if (!g_block_stream[device][c]) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                // the State chain floods the device with HBM-bound kernels; the chains the EVM circuit waits for are short: high priority
+                // (a CU-mask split between the State chain and the others was measured: no gain at 4 / 8 / 16 of every 32 CUs — the chains
+                // slow each other through the memory system, not through shared CUs; profiles/r06_experiments.txt)
+                HIP_TRY(hipStreamCreateWithPriority(&g_block_stream[device][c], hipStreamNonBlocking, c == 0 ? lo : hi));
+            }
+    }
+    for (int c = 0; c < ZK_BLOCK_NCIRCUITS; c++) { memset(&results[c], 0, sizeof(zk_result)); results[c].first_fail_row = UINT64_MAX; }
+    BlockShared sh;
+    sh.t0 = std::chrono::steady_clock::now();
+    { int erc = arena_event(device, &sh.ev_keccak); if (erc) return erc; }
+    zk_session* keccak_s = nullptr;  // stays open until the EVM chain is done with its rows
+    auto enter = [&](int chain) {
+        (void)zk_init(device);
+        (void)zk_set_stream(g_block_stream[device][chain]);
+    };
+    auto leave = [&](int chain, int rc) {
+        sh.rc[chain] = rc;
+        if (rc) sh.err[chain] = g_err;
+        sh.end_ms[chain] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
+    };
+    std::thread th_state([&] {
+        enter(0);
+        int rc = 0;
+        zk_session *a = nullptr, *s = nullptr;
+        uint64_t n_ops = 0, n_mpt = 0;
+        zk_result ra;
+        BLK_TRY(zk_state_assign_from_rw_open(b->evm.rw, b->evm.rw_flags, b->evm.n_rw, nullptr, nullptr, nullptr, st_opts, &n_ops, &a));
+        BLK_TRY(block_run_pass(a, &ra));
+        if (ra.fail_count) { rc = -1; g_err = "zk_block_verify: the State witness assignment failed (zk_state_assign_from_rw reports the op)"; goto done; }
+        BLK_TRY(zk_state_assign_read(a, nullptr, nullptr, nullptr, 0, &n_mpt));
+        BLK_TRY(zk_state_open(a->assign.rows, a->assign.row_flags, n_ops, a->assign.mpt, n_mpt, st_opts, &s));
+        BLK_TRY(block_run_pass(s, &results[ZK_BLOCK_STATE]));
+    done:
+        if (s) zk_close(s);
+        if (a) zk_close(a);
+        leave(0, rc);
+    });
+    std::thread th_keccak([&] {
+        enter(1);
+        int rc = 0;
+        zk_session *ba = nullptr, *bs = nullptr;
+        zk_result rk, rb;
+        bool signalled = false;
+        // the Bytecode assignment does not depend on the digests: opened first (its open reads the offsets back), enqueued behind the keccak pass
+        BLK_TRY(zk_bytecode_assign_open(b->evm.bytecode, b->evm.n_bytecode, b->code_offsets, b->code_lengths, b->n_bytecodes, b->k, b->randomness, nullptr, dev_opts, &ba));
+        BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets, b->n_hashed, b->randomness, 0, nullptr, dev_opts, &keccak_s));
+        BLK_TRY(zk_launch(keccak_s, nullptr));
+        if (hipEventRecord(sh.ev_keccak, keccak_s->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
+        {
+            std::lock_guard<std::mutex> lock(sh.m);
+            sh.keccak_rows = keccak_s->keccak_gen.rows;
+            sh.keccak_enqueued = true;
+        }
+        sh.cv.notify_all();
+        signalled = true;
+        BLK_TRY(zk_launch(ba, nullptr));
+        BLK_TRY(zk_collect(keccak_s, &rk));
+        if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a hashed message was rejected by the keccak table generation"; goto done; }
+        BLK_TRY(zk_collect(ba, &rb));
+        BLK_TRY(zk_bytecode_open(ba->bca.rows, (uint64_t)1 << b->k, keccak_s->keccak_gen.rows, b->n_codes, b->randomness, dev_opts, &bs));
+        BLK_TRY(block_run_pass(bs, &results[ZK_BLOCK_BYTECODE]));
+    done:
+        if (!signalled) {
+            { std::lock_guard<std::mutex> lock(sh.m); sh.keccak_failed = true; sh.keccak_enqueued = true; }
+            sh.cv.notify_all();
+        }
+        if (bs) zk_close(bs);
+        if (ba) zk_close(ba);
+        leave(1, rc);
+    });
+    std::thread th_copy([&] {
+        enter(2);
+        int rc = 0;
+        zk_session *ca = nullptr, *cs = nullptr, *es = nullptr;
+        zk_result rc_assign;
+        zk_evm_tables t = b->evm;
+        t.copy = nullptr; t.n_copy = 0; t.keccak = nullptr; t.n_keccak = 0;
+        if (b->copy_events.n_events) {
+            BLK_TRY(zk_copy_assign_open(&b->copy_events, nullptr, nullptr, nullptr, nullptr, nullptr, dev_opts, &ca));
+            BLK_TRY(block_run_pass(ca, &rc_assign));
+            zk_copy_tables ct;
+            memset(&ct, 0, sizeof ct);
+            ct.rows = ca->cpa.rows; ct.row_flags = ca->cpa.row_flags; ct.n_rows = ca->cpa.n_rows; ct.randomness = b->copy_events.randomness;
+            ct.rw = b->evm.rw; ct.rw_flags = b->evm.rw_flags; ct.n_rw = b->evm.n_rw;
+            ct.bytecode = b->evm.bytecode; ct.n_bytecode = b->evm.n_bytecode;
+            ct.tx = b->evm.tx; ct.tx_flags = b->evm.tx_flags; ct.n_tx = b->evm.n_tx;
+            if (ct.n_rows) {
+                BLK_TRY(zk_copy_open(&ct, dev_opts, &cs));
+                BLK_TRY(zk_launch(cs, nullptr));
+            }
+            t.copy = ca->cpa.table;
+            t.n_copy = ca->cpa_n_table;
+        }
+        {
+            std::unique_lock<std::mutex> lock(sh.m);
+            sh.cv.wait(lock, [&] { return sh.keccak_enqueued; });
+            if (sh.keccak_failed) { rc = -1; g_err = "zk_block_verify: the keccak chain failed before its table was enqueued"; goto done; }
+        }
+        if (hipStreamWaitEvent(g_block_stream[device][2], sh.ev_keccak, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+        if (b->n_hashed > b->n_codes) {
+            t.keccak = sh.keccak_rows + b->n_codes * (KT_NCELLS * 4);
+            t.n_keccak = b->n_hashed - b->n_codes;
+        }
+        BLK_TRY(zk_evm_open(&t, dev_opts | ZK_OPT_SINGLE_PASS, &es));
+        BLK_TRY(block_run_pass(es, &results[ZK_BLOCK_EVM]));
+        if (cs) BLK_TRY(zk_collect(cs, &results[ZK_BLOCK_COPY]));
+    done:
+        if (es) zk_close(es);
+        if (cs) zk_close(cs);
+        if (ca) zk_close(ca);
+        leave(2, rc);
+    });
+    std::thread th_rest([&] {
+        enter(3);
+        int rc = 0;
+        zk_session *ex = nullptr, *tx = nullptr;
+        if (b->n_exp_rows) {
+            BLK_TRY(zk_exp_open(b->exp_rows, b->n_exp_rows, dev_opts, &ex));
+            BLK_TRY(zk_launch(ex, nullptr));
+        }
+        if (b->tx.n_units) {
+            BLK_TRY(zk_sign_open(&b->tx, dev_opts, &tx));
+            BLK_TRY(block_run_pass(tx, &results[ZK_BLOCK_TX]));
+        }
+        if (ex) BLK_TRY(zk_collect(ex, &results[ZK_BLOCK_EXP]));
+    done:
+        if (tx) zk_close(tx);
+        if (ex) zk_close(ex);
+        leave(3, rc);
+    });
+    th_state.join();
+    th_keccak.join();
+    th_copy.join();
+    th_rest.join();
+    if (keccak_s) zk_close(keccak_s);
+    {
+        DevArena& A = g_arena[device];
+        std::lock_guard<std::mutex> lock(A.m);
+        A.events.push_back(sh.ev_keccak);
+    }
+    if (chain_end_ms) for (int c = 0; c < 4; c++) chain_end_ms[c] = sh.end_ms[c];
+    for (int c = 0; c < 4; c++)
+        if (sh.rc[c]) { g_err = sh.err[c]; return sh.rc[c]; }
+    return 0;
+}
