@@ -429,7 +429,9 @@ int zk_copy_assign(const zk_copy_events* ev, uint64_t* rows_out, uint32_t* row_f
  *      (zk_bytecode_assign_*: the unrolled bytecodes ARE evm.bytecode, cut by code_offsets / code_lengths), the Copy circuit's rows and
  *      the EVM circuit's copy table (zk_copy_assign_*; the Copy circuit looks up evm.rw / evm.bytecode / evm.tx), the State circuit's
  *      rows from evm.rw (zk_state_assign_from_rw_open).  evm.copy / evm.keccak are ignored.  Four host threads drive four chains on
- *      four streams of the calling thread's device: State | keccak -> Bytecode | copy assignment -> Copy + EVM | Exp + Tx.
+ *      four streams of the calling thread's device: State | keccak of the contracts -> Bytecode circuit | copy assignment -> Copy
+ *      circuit, keccak of the SHA3 inputs -> EVM open + pass | Bytecode assignment, Exp, Tx (the EVM circuit's keccak table holds the
+ *      SHA3 rows only, so its chain never waits for the long pass over the contracts).
  *      Every pointer is a device pointer (opts must carry ZK_OPT_DEVICE_PTRS; ZK_OPT_STATE_COMPACT is honoured).  results[c]: the
  *      tally of circuit c (enum below; rows_evaluated == 0 for a circuit without rows); a failing witness ASSIGNMENT (keccak input,
  *      State op, ...) is an error return with the text in zk_last_error.  chain_end_ms (nullable): host milliseconds from the call

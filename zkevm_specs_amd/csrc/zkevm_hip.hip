@@ -545,6 +545,7 @@ struct zk_session {
     PiArgs pi;
     PiCopyArgs picopy;
     RekeyArgs rekey;
+    RwkPlan rekey_plan_host;      // the compact-key plan as uploaded (host copy owned by the session: the upload needs no synchronisation of its own)
     bool assign_from_rw = false;  // SESSION_ASSIGN over an RW table: every pass starts with the re-keying and the sort (rekey)
     u32* rekey_status = nullptr;  // ... whose per-RW-row codes go here (the session's statuses are per op)
     u64 cpa_n_table = 0, cpa_n_rw = 0;
@@ -1487,8 +1488,8 @@ static int rekey_setup(zk_session* s, const uint64_t* rw, const uint32_t* rw_fla
     a.n_ops = 1 + hp.n_kept;
     a.ntiles = (u32)((n + 4095) / 4096);
     if ((rc = dev_alloc(s, (void**)&d_plan, sizeof(RwkPlan)))) return rc;
-    HIP_TRY(hipMemcpyAsync(d_plan, &hp.plan, sizeof(RwkPlan), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));  // (hp lives on this stack frame)
+    s->rekey_plan_host = hp.plan;  // (lives as long as the session: no wait for the copy here — one host round trip less per open)
+    HIP_TRY(hipMemcpyAsync(d_plan, &s->rekey_plan_host, sizeof(RwkPlan), hipMemcpyHostToDevice, s->stream));
     a.plan = d_plan;
     {
         const char* e = getenv("ZK_REKEY_NO_FAST");
@@ -2569,8 +2570,11 @@ struct BlockShared {
     std::mutex m;
     std::condition_variable cv;
     bool keccak_enqueued = false, keccak_failed = false;
-    const u64* keccak_rows = nullptr;
-    hipEvent_t ev_keccak = nullptr;
+    zk_session* keep = nullptr;  // the Bytecode assignment session (its rows are another chain's input)
+    zk_session* keep_cpa = nullptr;  // the copy assignment session (the Copy circuit on chain 3 reads its rows)
+    bool cpa_enqueued = false, cpa_failed = false;
+    hipEvent_t ev_cpa = nullptr;
+    hipEvent_t ev_keccak = nullptr;  // here: "the Bytecode assignment's rows are written"
     int rc[4] = {0, 0, 0, 0};
     std::string err[4];
     double end_ms[4] = {0, 0, 0, 0};
@@ -2606,7 +2610,13 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
     BlockShared sh;
     sh.t0 = std::chrono::steady_clock::now();
     { int erc = arena_event(device, &sh.ev_keccak); if (erc) return erc; }
-    zk_session* keccak_s = nullptr;  // stays open until the EVM chain is done with its rows
+    { int erc = arena_event(device, &sh.ev_cpa); if (erc) return erc; }
+    // Chains (each a host thread on its own stream):
+    //   0  State:     RW table -> State witness -> State circuit
+    //   1  Bytecode:  keccak of the contracts (long messages: the slow pass) -> [Bytecode rows ready: event from chain 3] -> Bytecode circuit
+    //   2  EVM:       copy assignment -> Copy circuit launched -> keccak of the SHA3 inputs (its own short pass: the EVM circuit's keccak
+    //                 table does not hold the contracts' hashes, so this chain never waits for chain 1) -> EVM open + pass -> Copy collect
+    //   3  rest:      Bytecode assignment launched (+ event) -> Exp launched -> Tx pass -> collects
     auto enter = [&](int chain) {
         (void)zk_init(device);
         (void)zk_set_stream(g_block_stream[device][chain]);
@@ -2616,16 +2626,21 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         if (rc) sh.err[chain] = g_err;
         sh.end_ms[chain] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
     };
+    const u64* bca_rows = nullptr;  // (written by chain 3 before it sets keccak_enqueued — here: "bytecode rows enqueued")
     std::thread th_state([&] {
         enter(0);
         int rc = 0;
         zk_session *a = nullptr, *s = nullptr;
         uint64_t n_ops = 0, n_mpt = 0;
         zk_result ra;
+        u32 n_mpt32 = 0;
         BLK_TRY(zk_state_assign_from_rw_open(b->evm.rw, b->evm.rw_flags, b->evm.n_rw, nullptr, nullptr, nullptr, st_opts, &n_ops, &a));
-        BLK_TRY(block_run_pass(a, &ra));
+        BLK_TRY(zk_launch(a, nullptr));
+        // the MPT row count rides on the collect's synchronisation (zk_state_assign_read would be two more round trips)
+        if (hipMemcpyAsync(&n_mpt32, a->assign.blk_cnt + a->assign.nb, 4, hipMemcpyDeviceToHost, a->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: copy failed"; goto done; }
+        BLK_TRY(zk_collect(a, &ra));
         if (ra.fail_count) { rc = -1; g_err = "zk_block_verify: the State witness assignment failed (zk_state_assign_from_rw reports the op)"; goto done; }
-        BLK_TRY(zk_state_assign_read(a, nullptr, nullptr, nullptr, 0, &n_mpt));
+        n_mpt = n_mpt32;
         BLK_TRY(zk_state_open(a->assign.rows, a->assign.row_flags, n_ops, a->assign.mpt, n_mpt, st_opts, &s));
         BLK_TRY(block_run_pass(s, &results[ZK_BLOCK_STATE]));
     done:
@@ -2633,85 +2648,85 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         if (a) zk_close(a);
         leave(0, rc);
     });
-    std::thread th_keccak([&] {
+    std::thread th_bytecode([&] {
         enter(1);
         int rc = 0;
-        zk_session *ba = nullptr, *bs = nullptr;
-        zk_result rk, rb;
-        bool signalled = false;
-        // the Bytecode assignment does not depend on the digests: opened first (its open reads the offsets back), enqueued behind the keccak pass
-        BLK_TRY(zk_bytecode_assign_open(b->evm.bytecode, b->evm.n_bytecode, b->code_offsets, b->code_lengths, b->n_bytecodes, b->k, b->randomness, nullptr, dev_opts, &ba));
-        BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets, b->n_hashed, b->randomness, 0, nullptr, dev_opts, &keccak_s));
-        BLK_TRY(zk_launch(keccak_s, nullptr));
-        if (hipEventRecord(sh.ev_keccak, keccak_s->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
-        {
-            std::lock_guard<std::mutex> lock(sh.m);
-            sh.keccak_rows = keccak_s->keccak_gen.rows;
-            sh.keccak_enqueued = true;
-        }
-        sh.cv.notify_all();
-        signalled = true;
-        BLK_TRY(zk_launch(ba, nullptr));
-        BLK_TRY(zk_collect(keccak_s, &rk));
-        if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a hashed message was rejected by the keccak table generation"; goto done; }
-        BLK_TRY(zk_collect(ba, &rb));
-        BLK_TRY(zk_bytecode_open(ba->bca.rows, (uint64_t)1 << b->k, keccak_s->keccak_gen.rows, b->n_codes, b->randomness, dev_opts, &bs));
-        BLK_TRY(block_run_pass(bs, &results[ZK_BLOCK_BYTECODE]));
-    done:
-        if (!signalled) {
-            { std::lock_guard<std::mutex> lock(sh.m); sh.keccak_failed = true; sh.keccak_enqueued = true; }
-            sh.cv.notify_all();
-        }
-        if (bs) zk_close(bs);
-        if (ba) zk_close(ba);
-        leave(1, rc);
-    });
-    std::thread th_copy([&] {
-        enter(2);
-        int rc = 0;
-        zk_session *ca = nullptr, *cs = nullptr, *es = nullptr;
-        zk_result rc_assign;
-        zk_evm_tables t = b->evm;
-        t.copy = nullptr; t.n_copy = 0; t.keccak = nullptr; t.n_keccak = 0;
-        if (b->copy_events.n_events) {
-            BLK_TRY(zk_copy_assign_open(&b->copy_events, nullptr, nullptr, nullptr, nullptr, nullptr, dev_opts, &ca));
-            BLK_TRY(block_run_pass(ca, &rc_assign));
-            zk_copy_tables ct;
-            memset(&ct, 0, sizeof ct);
-            ct.rows = ca->cpa.rows; ct.row_flags = ca->cpa.row_flags; ct.n_rows = ca->cpa.n_rows; ct.randomness = b->copy_events.randomness;
-            ct.rw = b->evm.rw; ct.rw_flags = b->evm.rw_flags; ct.n_rw = b->evm.n_rw;
-            ct.bytecode = b->evm.bytecode; ct.n_bytecode = b->evm.n_bytecode;
-            ct.tx = b->evm.tx; ct.tx_flags = b->evm.tx_flags; ct.n_tx = b->evm.n_tx;
-            if (ct.n_rows) {
-                BLK_TRY(zk_copy_open(&ct, dev_opts, &cs));
-                BLK_TRY(zk_launch(cs, nullptr));
-            }
-            t.copy = ca->cpa.table;
-            t.n_copy = ca->cpa_n_table;
+        zk_session *ks = nullptr, *bs = nullptr;
+        zk_result rk;
+        if (b->n_codes) {
+            BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets, b->n_codes, b->randomness, 0, nullptr, dev_opts, &ks));
+            BLK_TRY(block_run_pass(ks, &rk));
+            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a contract was rejected by the keccak table generation"; goto done; }
         }
         {
             std::unique_lock<std::mutex> lock(sh.m);
-            sh.cv.wait(lock, [&] { return sh.keccak_enqueued; });
-            if (sh.keccak_failed) { rc = -1; g_err = "zk_block_verify: the keccak chain failed before its table was enqueued"; goto done; }
+            sh.cv.wait(lock, [&] { return sh.keccak_enqueued; });  // chain 3 has enqueued the Bytecode assignment (or failed)
+            if (sh.keccak_failed) { rc = -1; g_err = "zk_block_verify: the Bytecode assignment failed before it was enqueued"; goto done; }
         }
-        if (hipStreamWaitEvent(g_block_stream[device][2], sh.ev_keccak, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
-        if (b->n_hashed > b->n_codes) {
-            t.keccak = sh.keccak_rows + b->n_codes * (KT_NCELLS * 4);
+        if (hipStreamWaitEvent(g_block_stream[device][1], sh.ev_keccak, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+        BLK_TRY(zk_bytecode_open(bca_rows, (uint64_t)1 << b->k, ks ? ks->keccak_gen.rows : nullptr, b->n_codes, b->randomness, dev_opts, &bs));
+        BLK_TRY(block_run_pass(bs, &results[ZK_BLOCK_BYTECODE]));
+    done:
+        if (bs) zk_close(bs);
+        if (ks) zk_close(ks);
+        leave(1, rc);
+    });
+    std::thread th_evm([&] {
+        enter(2);
+        int rc = 0;
+        zk_session *ca = nullptr, *es = nullptr, *ks = nullptr;
+        zk_result rc_assign, rk;
+        zk_evm_tables t = b->evm;
+        t.copy = nullptr; t.n_copy = 0; t.keccak = nullptr; t.n_keccak = 0;
+        bool cpa_signalled = false;
+        if (b->copy_events.n_events) {
+            BLK_TRY(zk_copy_assign_open(&b->copy_events, nullptr, nullptr, nullptr, nullptr, nullptr, dev_opts, &ca));
+            BLK_TRY(zk_launch(ca, nullptr));
+            if (hipEventRecord(sh.ev_cpa, ca->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
+            sh.keep_cpa = ca;
+            { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_enqueued = true; }
+            sh.cv.notify_all();
+            cpa_signalled = true;
+            BLK_TRY(zk_collect(ca, &rc_assign));
+            t.copy = ca->cpa.table;
+            t.n_copy = ca->cpa_n_table;
+        } else {
+            { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_enqueued = true; }
+            sh.cv.notify_all();
+            cpa_signalled = true;
+        }
+        if (b->n_hashed > b->n_codes) {  // the SHA3 steps' inputs: the EVM circuit's keccak table (execution/sha3.py:31), on this chain's own stream
+            BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets + b->n_codes, b->n_hashed - b->n_codes, b->randomness, 0, nullptr, dev_opts, &ks));
+            BLK_TRY(block_run_pass(ks, &rk));
+            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a SHA3 input was rejected by the keccak table generation"; goto done; }
+            t.keccak = ks->keccak_gen.rows;
             t.n_keccak = b->n_hashed - b->n_codes;
         }
-        BLK_TRY(zk_evm_open(&t, dev_opts | ZK_OPT_SINGLE_PASS, &es));
+        BLK_TRY(zk_evm_open(&t, dev_opts | ZK_OPT_SINGLE_PASS | ZK_OPT_SIDE_STREAM, &es));
         BLK_TRY(block_run_pass(es, &results[ZK_BLOCK_EVM]));
-        if (cs) BLK_TRY(zk_collect(cs, &results[ZK_BLOCK_COPY]));
     done:
+        if (!cpa_signalled) {
+            { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_failed = true; sh.cpa_enqueued = true; }
+            sh.cv.notify_all();
+        }
         if (es) zk_close(es);
-        if (cs) zk_close(cs);
-        if (ca) zk_close(ca);
+        if (ks) zk_close(ks);
+        // (the copy assignment's rows are read by chain 3's Copy circuit: closed after the joins)
         leave(2, rc);
     });
     std::thread th_rest([&] {
         enter(3);
         int rc = 0;
-        zk_session *ex = nullptr, *tx = nullptr;
+        zk_session *ex = nullptr, *tx = nullptr, *ba = nullptr, *cs = nullptr;
+        zk_result rb;
+        bool signalled = false;
+        BLK_TRY(zk_bytecode_assign_open(b->evm.bytecode, b->evm.n_bytecode, b->code_offsets, b->code_lengths, b->n_bytecodes, b->k, b->randomness, nullptr, dev_opts, &ba));
+        BLK_TRY(zk_launch(ba, nullptr));
+        if (hipEventRecord(sh.ev_keccak, ba->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
+        bca_rows = ba->bca.rows;
+        { std::lock_guard<std::mutex> lock(sh.m); sh.keccak_enqueued = true; }
+        sh.cv.notify_all();
+        signalled = true;
         if (b->n_exp_rows) {
             BLK_TRY(zk_exp_open(b->exp_rows, b->n_exp_rows, dev_opts, &ex));
             BLK_TRY(zk_launch(ex, nullptr));
@@ -2721,20 +2736,47 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
             BLK_TRY(block_run_pass(tx, &results[ZK_BLOCK_TX]));
         }
         if (ex) BLK_TRY(zk_collect(ex, &results[ZK_BLOCK_EXP]));
+        BLK_TRY(zk_collect(ba, &rb));
+        {   // the Copy circuit over the rows chain 2's copy assignment writes (ordered behind it on the device)
+            std::unique_lock<std::mutex> lock(sh.m);
+            sh.cv.wait(lock, [&] { return sh.cpa_enqueued; });
+            if (sh.cpa_failed) { rc = -1; g_err = "zk_block_verify: the copy assignment failed before it was enqueued"; goto done; }
+        }
+        if (sh.keep_cpa && sh.keep_cpa->cpa.n_rows) {
+            zk_session* ca = sh.keep_cpa;
+            if (hipStreamWaitEvent(g_block_stream[device][3], sh.ev_cpa, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+            zk_copy_tables ct;
+            memset(&ct, 0, sizeof ct);
+            ct.rows = ca->cpa.rows; ct.row_flags = ca->cpa.row_flags; ct.n_rows = ca->cpa.n_rows; ct.randomness = b->copy_events.randomness;
+            ct.rw = b->evm.rw; ct.rw_flags = b->evm.rw_flags; ct.n_rw = b->evm.n_rw;
+            ct.bytecode = b->evm.bytecode; ct.n_bytecode = b->evm.n_bytecode;
+            ct.tx = b->evm.tx; ct.tx_flags = b->evm.tx_flags; ct.n_tx = b->evm.n_tx;
+            BLK_TRY(zk_copy_open(&ct, dev_opts, &cs));
+            BLK_TRY(block_run_pass(cs, &results[ZK_BLOCK_COPY]));
+        }
     done:
+        if (cs) zk_close(cs);
+        if (!signalled) {
+            { std::lock_guard<std::mutex> lock(sh.m); sh.keccak_failed = true; sh.keccak_enqueued = true; }
+            sh.cv.notify_all();
+        }
         if (tx) zk_close(tx);
         if (ex) zk_close(ex);
+        // (the Bytecode assignment's rows are read by chain 1's Bytecode circuit: closed after the joins)
+        sh.keep = ba;
         leave(3, rc);
     });
     th_state.join();
-    th_keccak.join();
-    th_copy.join();
+    th_bytecode.join();
+    th_evm.join();
     th_rest.join();
-    if (keccak_s) zk_close(keccak_s);
+    if (sh.keep) zk_close(sh.keep);
+    if (sh.keep_cpa) zk_close(sh.keep_cpa);
     {
         DevArena& A = g_arena[device];
         std::lock_guard<std::mutex> lock(A.m);
         A.events.push_back(sh.ev_keccak);
+        A.events.push_back(sh.ev_cpa);
     }
     if (chain_end_ms) for (int c = 0; c < 4; c++) chain_end_ms[c] = sh.end_ms[c];
     for (int c = 0; c < 4; c++)
