@@ -323,5 +323,16 @@ def test_block_one_shot_native_entry():
         for k in BLOCK_CIRCUITS:
             assert (got[k].fail_count, got[k].first_fail_row, got[k].first_fail_code) == (want[k].fail_count, want[k].first_fail_row, want[k].first_fail_code), k
         rw[i, 8, 0] ^= np.uint64(1)
+        # a block whose State witness cannot be assigned (an RW row with no Target in its tag cell): an error return with its text, every
+        # chain ended (no thread left waiting on another), and the next block verifies again
+        from zkevm_specs_amd._lib import EngineError
+
+        old = int(rw[3000, 2, 0])
+        rw[3000, 2, 0] = np.uint64(99)
+        with pytest.raises(EngineError, match="State witness assignment"):
+            verify_block_native(stage_block(p, dev), 0, False)
+        rw[3000, 2, 0] = np.uint64(old)
+        _, total, _ = verify_block_native(stage_block(p, dev), 0, False)
+        assert total == 0
     finally:
         bv.close()

@@ -93,6 +93,8 @@ ZK_HD u32 asg_flags(const AssignArgs& a, u64 i) {
 // FQ(int) of a 256-bit Python int: x < 2^256 < 6p
 ZK_HD Fr asg_reduce(Fr x) {
     const Fr p = fr_modulus();
+    if (x.v[7] < p.v[7]) return x;  // below 2^224 * (top limb of p): already reduced — every well-formed slot (the subtraction ladder below
+                                     // is 5 x 16 limb operations for each of the six reduced slots of a row)
 #pragma unroll
     for (int it = 0; it < 5; it++) {
         Fr t;
