@@ -77,6 +77,7 @@ typedef struct zk_result {
  * key halves < 2^128" (sites 5 and 7).  Every other check, the ordering, the lookups and the per-tag rules are evaluated as always.
  * Not for witnesses from outside (a tampered limb cell cannot be expressed): those use the 57-cell form. */
 #define ZK_OPT_STATE_COMPACT 32u
+#define ZK_OPT_BLOCK_STATE_ROWS 64u /* zk_block_verify: materialise the State witness (57-cell rows) instead of the fused form */
 
 /* Select the GPU (HIP ordinal) for the calling thread; creates that device's engine stream on first use.  Idempotent.
  * Selecting another device drops a stream set with zk_set_stream (it belongs to the previous device). */
@@ -312,6 +313,19 @@ int zk_state_ops_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t 
 int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint64_t* rows_dev,
                                  uint32_t* row_flags_dev, uint64_t* mpt_dev, uint32_t opts, uint64_t* n_ops_out, zk_session** out);
 
+/* RW table in, State-circuit VERDICT out — `check_state_circuit(assign_state_circuit(ops, r), ...)` over the ops of an EVM-circuit RW
+ * table without the witness in between (state_circuit.py:827-889 then :492-613; tests/test_state_circuit.py's `verify(ops, tables,
+ * randomness)` is this composition): the re-keying, the sort and the mock MPT updates as zk_state_assign_from_rw_open, but op2row's
+ * rows are evaluated in the registers they are computed in and never stored (1,824 B per row that the two-step form writes and reads
+ * back).  zk_launch (status_dev: uint32[n_ops], the State circuit's code per row) / zk_collect (the State circuit's zk_result) /
+ * zk_read_status as for zk_state_open; results identical to zk_state_assign_from_rw_open + zk_state_open on its outputs.  An RW row
+ * the re-keying rejects or an op assign_state_circuit raises on (codes of zk_state_assign_*) means there is no witness: zk_collect
+ * then returns -1 with the count, the first row and its code in zk_last_error() (libzkevm_cpu.so: the open does). */
+int zk_state_verify_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint32_t opts, uint64_t* n_ops_out,
+                                 zk_session** out);
+int zk_state_verify_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint32_t opts, uint32_t* status_out /* n_ops <= n + 1 codes */,
+                            uint64_t* n_ops_out, zk_result* result);
+
 /* ---- secp256k1 ECDSA verification: computes the `ecdsa_status` column of the Tx / Sig units
  *      on the device instead of taking it from the host.  Replaces `ECDSAVerifyChip.verify`
  *      (src/zkevm_specs/tx_circuit.py:147-158, util/ec.py:109-117), i.e. eth-keys 0.4.0's
@@ -428,14 +442,17 @@ int zk_copy_assign(const zk_copy_events* ev, uint64_t* rows_out, uint32_t* row_f
  *      table (zk_keccak_*: rows [0, n_codes) are the Bytecode circuit's table, the rest the EVM circuit's), the Bytecode circuit's rows
  *      (zk_bytecode_assign_*: the unrolled bytecodes ARE evm.bytecode, cut by code_offsets / code_lengths), the Copy circuit's rows and
  *      the EVM circuit's copy table (zk_copy_assign_*; the Copy circuit looks up evm.rw / evm.bytecode / evm.tx), the State circuit's
- *      rows from evm.rw (zk_state_assign_from_rw_open).  evm.copy / evm.keccak are ignored.  Four host threads drive four chains on
+ *      verdict from evm.rw (zk_state_verify_from_rw_open: the State rows are evaluated where they are computed; with
+ *      ZK_OPT_BLOCK_STATE_ROWS or ZK_OPT_STATE_COMPACT the witness is written and read back as zk_state_assign_from_rw_open +
+ *      zk_state_open do — the same results, for comparison).  evm.copy / evm.keccak are ignored.  Four host threads drive four chains on
  *      four streams of the calling thread's device: State | keccak of the contracts -> Bytecode circuit | copy assignment -> Copy
  *      circuit, keccak of the SHA3 inputs -> EVM open + pass | Bytecode assignment, Exp, Tx (the EVM circuit's keccak table holds the
  *      SHA3 rows only, so its chain never waits for the long pass over the contracts).
  *      Every pointer is a device pointer (opts must carry ZK_OPT_DEVICE_PTRS; ZK_OPT_STATE_COMPACT is honoured).  results[c]: the
  *      tally of circuit c (enum below; rows_evaluated == 0 for a circuit without rows); a failing witness ASSIGNMENT (keccak input,
- *      State op, ...) is an error return with the text in zk_last_error.  chain_end_ms (nullable): host milliseconds from the call
- *      to the end of each chain (measurement aid). */
+ *      State op, ...) is an error return with the text in zk_last_error.  chain_ms (nullable, ten doubles; a measurement aid): host
+ *      milliseconds from the call to the end of each chain [0..3], to its start [4..7], to the end of the last one [8] and to the
+ *      return [9]. */
 typedef struct zk_block {
     zk_evm_tables evm;
     const uint8_t* hashed_data; uint64_t hashed_bytes; const uint64_t* hashed_offsets;  /* n_hashed + 1 offsets */
@@ -447,7 +464,7 @@ typedef struct zk_block {
     zk_sign_units tx;                                                                    /* n_units == 0: no Tx circuit */
 } zk_block;
 enum { ZK_BLOCK_EVM = 0, ZK_BLOCK_STATE = 1, ZK_BLOCK_BYTECODE = 2, ZK_BLOCK_TX = 3, ZK_BLOCK_COPY = 4, ZK_BLOCK_EXP = 5, ZK_BLOCK_NCIRCUITS = 6 };
-int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results /* [ZK_BLOCK_NCIRCUITS] */, double* chain_end_ms /* [4], nullable */);
+int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results /* [ZK_BLOCK_NCIRCUITS] */, double* chain_ms /* [10], nullable */);
 
 /* ---- Session protocol shared by every circuit.
  * launch: enqueue one evaluation pass (asynchronous) on the session's stream.  status_dev: optional DEVICE buffer of

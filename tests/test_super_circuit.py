@@ -308,9 +308,9 @@ def test_block_one_shot_native_entry():
     dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32) if x.dtype == np.uint32 else x).cuda()  # noqa: E731
     bv = BlockVerifier(0)
     try:
-        for compact in (False, True):
+        for compact, rows in ((False, False), (False, True), (True, False)):  # State rows fused (default) / 57-cell witness / 15-cell witness
             for _ in range(2):
-                results, total, ends = verify_block_native(stage_block(p, dev), 0, compact)
+                results, total, ends = verify_block_native(stage_block(p, dev), 0, compact, rows)
                 assert total == 0 and set(results) == set(BLOCK_CIRCUITS) and {k: r.rows_evaluated for k, r in results.items()} == p["rows"]
                 assert all(e > 0 for e in ends)
         rw = p["evm"]["rw"]
@@ -318,10 +318,11 @@ def test_block_one_shot_native_entry():
         rw[i, 8, 0] ^= np.uint64(1)
         b = stage_block(p, dev)
         want, _ = bv.verify(b)
-        got, total, _ = verify_block_native(stage_block(p, dev), 0, False)
-        assert total == sum(r.fail_count for r in want.values()) > 0
-        for k in BLOCK_CIRCUITS:
-            assert (got[k].fail_count, got[k].first_fail_row, got[k].first_fail_code) == (want[k].fail_count, want[k].first_fail_row, want[k].first_fail_code), k
+        for rows in (False, True):
+            got, total, _ = verify_block_native(stage_block(p, dev), 0, False, rows)
+            assert total == sum(r.fail_count for r in want.values()) > 0
+            for k in BLOCK_CIRCUITS:
+                assert (got[k].fail_count, got[k].first_fail_row, got[k].first_fail_code) == (want[k].fail_count, want[k].first_fail_row, want[k].first_fail_code), k
         rw[i, 8, 0] ^= np.uint64(1)
         # a block whose State witness cannot be assigned (an RW row with no Target in its tag cell): an error return with its text, every
         # chain ended (no thread left waiting on another), and the next block verifies again

@@ -322,9 +322,10 @@ def block_oneshot(parts, to_dev, device=0, reps=8, copies=3, state_compact=False
     rows = sum(v.rows_evaluated for v in results.values())
     ms = times[len(times) // 2]
     return {"ms": ms, "min_ms": times[0], "max_ms": times[-1], "rows": rows, "rows_per_s": rows / (ms / 1e3), "reps": reps, "copies": copies,
-            "chain_end_ms": dict(zip(("state", "keccak", "copy", "rest"), ends)),
-            "note": "wall clock of zk_block_verify (block.verify_block_native): four host threads / HIP streams inside the library (State chain: class scan + radix sort + assignment + "
-                    "State circuit; keccak table -> Bytecode assignment + circuit; copy assignment -> Copy circuit + EVM open + pass; Exp + Tx); "
+            "chain_end_ms": dict(zip(("state", "keccak", "copy", "rest"), ends[:4])),
+            "note": "wall clock of zk_block_verify (block.verify_block_native): four persistent host threads / HIP streams inside the library (State chain: class scan + radix sort + mock MPT + "
+                    "the State circuit on rows evaluated where op2row computes them (zk_state_verify_from_rw; with state_compact the 15-cell witness is written and read back); "
+                    "contracts' keccak -> Bytecode circuit; copy assignment + SHA3 keccak -> EVM open + pass; Bytecode assignment, Exp, Tx, Copy circuit); "
                     "every derived table and witness is rebuilt on the device for every block"}
 
 

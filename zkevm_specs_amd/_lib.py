@@ -22,7 +22,7 @@ LIB_PATH = CPU_LIB_PATH if BACKEND == "cpu" else (os.environ.get("ZK_HIP_LIB") o
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
     "zk_state_open", "zk_state_set_range", "zk_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_evm_verify_batch", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
-    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_state_ops_from_rw_open", "zk_state_ops_from_rw_read", "zk_state_ops_from_rw", "zk_state_assign_from_rw_open", "zk_block_verify", "zk_ecdsa_open", "zk_ecdsa_open_batches", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_pi_copy_open", "zk_pi_copy_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing", "zk_last_host_phases", "zk_dist_unique_id", "zk_dist_init", "zk_dist_tally", "zk_dist_close",
+    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_state_ops_from_rw_open", "zk_state_ops_from_rw_read", "zk_state_ops_from_rw", "zk_state_assign_from_rw_open", "zk_state_verify_from_rw_open", "zk_state_verify_from_rw", "zk_block_verify", "zk_ecdsa_open", "zk_ecdsa_open_batches", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_pi_copy_open", "zk_pi_copy_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing", "zk_last_host_phases", "zk_dist_unique_id", "zk_dist_init", "zk_dist_tally", "zk_dist_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -111,6 +111,7 @@ OPT_GENERIC_INDEX = 4
 OPT_SINGLE_PASS = 8
 OPT_SIDE_STREAM = 16
 OPT_STATE_COMPACT = 32  # State rows without the limb / byte columns (include/zkevm_hip.h ZK_OPT_STATE_COMPACT)
+OPT_BLOCK_STATE_ROWS = 64  # zk_block_verify: materialise the State witness instead of the fused form
 
 
 class EngineError(RuntimeError):
@@ -196,6 +197,8 @@ def _bind(lib):
     lib.zk_state_ops_from_rw_open.argtypes = [vp, vp, u64, vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(vp)]
     lib.zk_state_ops_from_rw_read.argtypes = [vp, vp, vp, ctypes.POINTER(u64)]
     lib.zk_state_assign_from_rw_open.argtypes = [vp, vp, u64, vp, vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(vp)]
+    lib.zk_state_verify_from_rw_open.argtypes = [vp, vp, u64, u32, ctypes.POINTER(u64), ctypes.POINTER(vp)]
+    lib.zk_state_verify_from_rw.argtypes = [vp, vp, u64, u32, vp, ctypes.POINTER(u64), ctypes.POINTER(ZkResult)]
     lib.zk_block_verify.argtypes = [vp, u32, vp, vp]
     lib.zk_state_ops_from_rw.argtypes = [vp, vp, u64, vp, vp, ctypes.POINTER(u64), u32, vp, ctypes.POINTER(ZkResult)]
     lib.zk_ecdsa_open.argtypes = [vp, u32, vp, u32, u64, vp, u32, u32, ctypes.POINTER(vp)]

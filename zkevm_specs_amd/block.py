@@ -76,16 +76,17 @@ def native_block(b):
                         p(ub_off), p(ub_len), int(ub_len.shape[0]), int(k), 0, ce, p(ex, n_exp), n_exp, tx)
 
 
-def verify_block_native(b, device=0, state_compact=False):
+def verify_block_native(b, device=0, state_compact=False, state_rows=False):
     """zk_block_verify (include/zkevm_hip.h): the same chains as BlockVerifier.verify, driven by four threads inside the library —
-    -> ({circuit: Result}, total fail count, chain_end_ms[4])"""
+    -> ({circuit: Result}, total fail count, chain_ms[10]: ends, starts, all ended, return).  The State rows are evaluated where they are computed
+    (zk_state_verify_from_rw_open) unless state_rows (57-cell witness written and read back) or state_compact (15-cell) asks for them."""
     lib = _lib.init(device)
     blk = b.get("_native")
     if blk is None:
         blk = b["_native"] = native_block(b)
     res = (_lib.ZkResult * 6)()
-    ends = (ctypes.c_double * 4)()
-    opts = _lib.OPT_DEVICE_PTRS | (_lib.OPT_STATE_COMPACT if state_compact else 0)
+    ends = (ctypes.c_double * 10)()  # chain ends [4], chain starts [4], all chains ended, return (host ms from the call)
+    opts = _lib.OPT_DEVICE_PTRS | (_lib.OPT_STATE_COMPACT if state_compact else 0) | (_lib.OPT_BLOCK_STATE_ROWS if state_rows else 0)
     _lib.check(lib.zk_block_verify(ctypes.byref(blk), opts, res, ends), "zk_block_verify", lib)
     results = {name: engine.Result(res[i]) for i, name in enumerate(_lib.BLOCK_CIRCUITS) if res[i].rows_evaluated or res[i].launches}
     return results, sum(r.fail_count for r in results.values()), list(ends)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${ZK_BUILD_DIR:-build}
 mkdir -p "$OUT"
-UNITS="zkevm_hip k_state k_evm_hot k_evm_cold k_evm_warm k_evm_slow k_rows k_assign k_ecdsa k_rekey"
+UNITS="zkevm_hip k_state k_evm_hot k_evm_cold k_evm_warm k_evm_slow k_rows k_assign k_ecdsa k_rekey k_state_fused"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage $ZK_EXTRA_FLAGS"
 pids=()
 for u in $UNITS; do

@@ -938,6 +938,43 @@ extern "C" int zk_state_assign_from_rw_open(const uint64_t* rw, const uint32_t* 
     return rc;
 }
 
+// RW table -> State verdict: the device evaluates the rows where it computes them (state_fused.hpp); here the three host passes back
+// to back — re-keying, assignment (15-cell rows), State circuit — with the errors of the first two reported by the open.
+extern "C" int zk_state_verify_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint32_t opts, uint64_t* n_ops_out,
+                                            zk_session** out) {
+    NO_DEVICE_PTRS(opts, "zk_state_verify_from_rw_open");
+    ARG_TRY(out && rw && n_rw > 0, "zk_state_verify_from_rw_open: bad arguments");
+    zk_session* a = nullptr;
+    uint64_t n_ops = 0;
+    int rc = zk_state_assign_from_rw_open(rw, rw_flags, n_rw, nullptr, nullptr, nullptr, opts | ZK_OPT_STATE_COMPACT, &n_ops, &a);
+    if (rc) return rc;
+    run_pass(a, nullptr);
+    if (a->fail_count) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "zk_state_verify_from_rw: the State witness assignment failed for %llu ops (first: %llu, code 0x%08x; zk_state_assign_from_rw reports each)",
+                 (unsigned long long)a->fail_count, (unsigned long long)a->first_row, (unsigned)a->first_code);
+        g_err = msg;
+        zk_close(a);
+        return -1;
+    }
+    rc = zk_state_open(a->a64[1].data(), a->out32.data(), n_ops, a->a64[2].data(), a->n_mpt, opts | ZK_OPT_STATE_COMPACT, out);
+    zk_close(a);
+    if (!rc && n_ops_out) *n_ops_out = n_ops;
+    return rc;
+}
+extern "C" int zk_state_verify_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint32_t opts, uint32_t* status_out,
+                                       uint64_t* n_ops_out, zk_result* result) {
+    ARG_TRY(result, "zk_state_verify_from_rw: result is null");
+    zk_session* s = nullptr;
+    int rc = zk_state_verify_from_rw_open(rw, rw_flags, n, opts, n_ops_out, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
+
 // the block one-shot is four chains on four device streams: there is nothing to overlap on the host — callers of the CPU backend use the
 // per-circuit entries (zkevm_specs_amd/super_circuit.py does, on host arrays)
 extern "C" int zk_block_verify(const zk_block*, uint32_t, zk_result*, double*) {

@@ -87,10 +87,24 @@ __global__ __launch_bounds__(ASG_BLOCK) void assign_rank_kernel(AssignArgs a) {
         u32 r = a.blk_cnt[blockIdx.x] + (u32)__popcll(bf & ((1ull << lane) - 1ull));
         for (u32 k = 0; k < w; k++) r += s_cnt[k];
         a.rank[i] = r;
-        asg_write_mpt<RW>(a, i, r);
+        Fr q[ASG_MPT_NCELLS];
+        asg_mpt_cells<RW>(a, i, r, q);
+        u64* out = a.mpt + (u64)r * (ASG_MPT_NCELLS * 4);
+#pragma unroll
+        for (int c = 0; c < ASG_MPT_NCELLS; c++) asg_store(out + 4 * c, q[c]);
+        if (a.mpt_slots) {  // the State circuit's MPT index, entered as the row is written (build_index + mpt_index_build_kernel otherwise)
+            ZkTable t;
+            t.n = (u32)a.n;
+            const u64 h = state_mpt_hash_cells(q);
+            const u32 v = state_mpt_slot_value(t, r, h);
+            u32 s = (u32)h & a.mpt_mask;
+            while (atomicCAS(&a.mpt_slots[s], ZK_EMPTY_SLOT, v) != ZK_EMPTY_SLOT) s = (s + 1) & a.mpt_mask;
+        }
     }
 }
-template <bool RW>
+// ROWS = false: only every op's root (as the rank it is made of) comes out — the rows are computed again where they are evaluated
+// (state_rows_fused_kernel)
+template <bool RW, bool ROWS = true>
 __global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u32* status, ZkTally* tally) {
     __shared__ u32 s_min[ASG_BLOCK / 64];
     const u64 i = (u64)blockIdx.x * ASG_BLOCK + threadIdx.x;
@@ -109,11 +123,15 @@ __global__ __launch_bounds__(ASG_BLOCK) void assign_rows_kernel(AssignArgs a, u3
     if (nxt == ASG_NONE) nxt = a.blk_next[blockIdx.x];
     u32 code = 0;
     if (in) {
-        const u64 root = 3ull + 5ull * (nxt == ASG_NONE ? a.blk_cnt[a.nb] : a.rank[a.first[nxt]]);
-        code = asg_write_row<RW>(a, i, root, f == (u32)i);
+        const u32 rk = nxt == ASG_NONE ? a.blk_cnt[a.nb] : a.rank[a.first[nxt]];
+        if (!ROWS) {
+            a.root_rank[i] = rk;
+            return;
+        }
+        code = asg_write_row<RW>(a, i, 3ull + 5ull * rk, f == (u32)i);
         if (status) status[i] = code;
     }
-    tally_commit(tally, i, code);
+    if (ROWS) tally_commit(tally, i, code);
 }
 // Bytecode-circuit witness assignment (bytecode_assign.hpp)
 __global__ void bca_rpow_kernel(Fr r, u64* out) {  // entry m = Mont(r^m), one lane each (bca_fill_rpow is the host form)
@@ -326,8 +344,25 @@ __global__ __launch_bounds__(256) void keccak_table_group_kernel(KeccakGenArgs g
     for (u32 k = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5); k < n_long; k += groups) keccak_table_row_group(g, g.long_list[k], gl, base, lds);
 }
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally) {
-    const u32 cap = a.mask + 1u;
+    // (the fused form's MPT index sits behind the key slots in one buffer: one fill)
+    const u32 cap = a.mask + 1u + (a.mpt_slots ? a.mpt_mask + 1u : 0u);
     hipLaunchKernelGGL(slots_fill_kernel_asg, dim3((cap + 255) / 256), dim3(256), 0, st, a.slots, cap);
+    if (a.root_rank) {  // rows evaluated where they are computed: no row pass, the roots alone
+        if (a.rw) {
+            hipLaunchKernelGGL(assign_insert_kernel<true>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(assign_mark_kernel<true>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(assign_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL(assign_rank_kernel<true>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(assign_rows_kernel<true, false>), dim3(a.nb), dim3(ASG_BLOCK), 0, st, a, status, tally);
+        } else {
+            hipLaunchKernelGGL(assign_insert_kernel<false>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(assign_mark_kernel<false>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(assign_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL(assign_rank_kernel<false>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(assign_rows_kernel<false, false>), dim3(a.nb), dim3(ASG_BLOCK), 0, st, a, status, tally);
+        }
+        return;
+    }
     if (a.rw) {  // ops read straight from the RW rows through the sorted order (zk_state_assign_from_rw)
         hipLaunchKernelGGL(assign_insert_kernel<true>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);
         hipLaunchKernelGGL(assign_mark_kernel<true>, dim3(a.nb), dim3(ASG_BLOCK), 0, st, a);

@@ -59,6 +59,8 @@ void zk_launch_sign_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_keccak_rpow(hipStream_t st, const Fr& r, u64* out);
 void zk_launch_keccak_table(hipStream_t st, const KeccakGenArgs& g, u32* status, ZkTally* tally);
 void zk_launch_state_assign(hipStream_t st, const AssignArgs& a, u32* status, ZkTally* tally);
+// state_fused.hpp: the State circuit on rows computed from the ops (after zk_launch_state_assign with a.root_rank set)
+void zk_launch_state_rows_fused(hipStream_t st, const StateArgs& sa, const AssignArgs& g, u32* status, ZkTally* tally, ZkTally* asg_tally);
 void zk_launch_rekey_scan(hipStream_t st, const RekeyArgs& a);  // open-time class masks of the RW -> State re-keying
 void zk_launch_state_rekey(hipStream_t st, const RekeyArgs& a, u32* status, ZkTally* tally);
 void zk_launch_bca_rpow(hipStream_t st, const Fr& r, u64* out);

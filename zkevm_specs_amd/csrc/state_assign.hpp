@@ -46,6 +46,12 @@ struct AssignArgs {
     u32* rank;           // [n] rank of a first-occurrence op among the first occurrences
     u32* blk_cnt;        // [nb + 1] first occurrences per block -> exclusive prefix; [nb] = n_mpt
     u32* blk_next;       // [nb + 1] smallest keyed op index per block -> min over the blocks AFTER b
+    // Rows evaluated where they are computed (zk_state_verify_from_rw, state_fused.hpp): `rows` is null, every op's root comes out as
+    // the rank it is made of, and the rank pass enters every MPT row into the State circuit's MPT index as it writes it.
+    u32* root_rank;      // out [n] or nullptr: the row's root = 3 + 5 * root_rank[i]
+    u32* mpt_slots;      // [mpt_mask + 1] or nullptr: the MPT index (slot value = row | hash fingerprint << 24; n < 2^24 - 1)
+    u32 mpt_mask;
+    u32 pad2_;
 };
 
 // Slot s of op i when the ops are the re-keyed rows of an RW table (the mapping of rwk_key / rwk_op, one slot at a time: `s` is a
@@ -201,30 +207,32 @@ ZK_HD u32 asg_mock_status(u32 flags, const Fr& ft, const Fr& vlo, const Fr& vhi,
 // MPTTableRow of first-occurrence op i with rank r (:921-929): address, proof_type, storage_key lo/hi,
 // root lo/hi, root_prev lo/hi, value lo/hi, value_prev lo/hi.
 template <bool RW = false>
-ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
-    u64* out = a.mpt + (u64)r * (ASG_MPT_NCELLS * 4);
+ZK_HD void asg_mpt_cells(const AssignArgs& a, u64 i, u32 r, Fr q[ASG_MPT_NCELLS]) {
     const u32 flags = asg_flags<RW>(a, i);
     const Fr ft = asg_slot<RW>(a, ASG_FT, i);
     const Fr key = asg_slot<RW>(a, ASG_KEY, i);
     const Fr vlo = asg_slot<RW>(a, ASG_VLO, i), vhi = asg_slot<RW>(a, ASG_VHI, i);
     const Fr ilo = asg_slot<RW>(a, ASG_ILO, i), ihi = asg_slot<RW>(a, ASG_IHI, i);
-    asg_store(out + 0, asg_reduce(asg_slot<RW>(a, ASG_ADDR, i)));
+    q[0] = asg_reduce(asg_slot<RW>(a, ASG_ADDR, i));
     // isinstance(field_tag, AccountFieldTag) -> from_account_field_tag (table.py:341-350: Nonce..NonExisting -> 1..4), else StorageMod
-    asg_store_u64(out + 4, (flags & 4u) ? fr_lo64(ft) : 6ull);
-    asg_store(out + 8, u256_lo(key));
-    asg_store(out + 12, u256_hi(key));
+    q[1] = fr_from_u64((flags & 4u) ? fr_lo64(ft) : 6ull);
+    q[2] = u256_lo(key);
+    q[3] = u256_hi(key);
     const u64 root_prev = 3ull + 5ull * r;
-    asg_store_u64(out + 16, root_prev + 5);
-    asg_store_u64(out + 20, 0);
-    asg_store_u64(out + 24, root_prev);
-    asg_store_u64(out + 28, 0);
-    Fr lo, hi;
-    asg_word_of(vlo, vhi, lo, hi);
-    asg_store(out + 32, lo);
-    asg_store(out + 36, hi);
-    asg_word_of(ilo, ihi, lo, hi);
-    asg_store(out + 40, lo);
-    asg_store(out + 44, hi);
+    q[4] = fr_from_u64(root_prev + 5);
+    q[5] = fr_zero();
+    q[6] = fr_from_u64(root_prev);
+    q[7] = fr_zero();
+    asg_word_of(vlo, vhi, q[8], q[9]);
+    asg_word_of(ilo, ihi, q[10], q[11]);
+}
+template <bool RW = false>
+ZK_HD void asg_write_mpt(const AssignArgs& a, u64 i, u32 r) {
+    u64* out = a.mpt + (u64)r * (ASG_MPT_NCELLS * 4);
+    Fr q[ASG_MPT_NCELLS];
+    asg_mpt_cells<RW>(a, i, r, q);
+#pragma unroll
+    for (int c = 0; c < ASG_MPT_NCELLS; c++) asg_store(out + 4 * c, q[c]);
 }
 
 // op2row (:827-852) with the back-filled root; returns the op's status code.

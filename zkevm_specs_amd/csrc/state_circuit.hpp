@@ -340,6 +340,7 @@ ZK_HD void state_load_row(const ZkCols& w, u64 i, StRow& R, u32& code) {
 }
 
 // state_load_row for the 15-cell rows alone (ZK_OPT_STATE_COMPACT): the device kernel's loader — none of the 42-column code.
+ZK_HD void state_finish_row_compact(StRow& R, const Fr& is_write, u32& code);
 ZK_HD void state_load_row_compact(const ZkCols& w, u64 i, StRow& R, u32& code) {
     R.flags = w.flags ? w.flags[i] : 0u;
     R.rwc = st_col(w, ST_RWC, i);
@@ -356,6 +357,11 @@ ZK_HD void state_load_row_compact(const ZkCols& w, u64 i, StRow& R, u32& code) {
     R.init_hi = st_col(w, ST_INIT_HI, i);
     R.root_lo = st_col(w, ST_ROOT_LO, i);
     R.root_hi = st_col(w, ST_ROOT_HI, i);
+    state_finish_row_compact(R, is_write, code);
+}
+// The row's own checks (sites 1..8) and its key packing from the fifteen cells alone; also the tail of the loader that computes a row
+// from its State op instead of reading it (state_fused.hpp).
+ZK_HD void state_finish_row_compact(StRow& R, const Fr& is_write, u32& code) {
     ST_ASSERT(fr_fits64(R.tag) && fr_lo64(R.tag) >= 1 && fr_lo64(R.tag) <= 12, 1);
     ST_ASSERT(fr_le_u64(R.id, (1ull << 28) - 1), 2);
     ST_ASSERT(fr_le_u64(R.ftag, 24), 3);
@@ -408,8 +414,15 @@ ZK_HD Fr st_shr_fr(const Fr& x) {
 // Checks of row i that involve the previous row (sites 9..13) and the per-tag rules; C = this
 // row, P = previous row (host build only; the device takes it from the neighbouring lane).
 // Must be called by every lane of the wavefront (the DPP moves read the neighbour's registers).
-template <int SHIFT = 1>
-ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const StRow& P, u32 code) {
+// Where the two reads of state_check_loaded that are not in a StRow come from — the Start row's lexicographic-ordering cell and the key
+// cells of row i + 1 for the last row of a wavefront: the witness (StateArgs), or the State ops themselves (StateFusedArgs,
+// state_fused.hpp: overloads on the argument type).
+ZK_HD Fr st_src_lex(const StateArgs& a, u64 i) { return st_col(a.rows, ST_LEX, i); }
+#ifndef ZK_HOSTSIM
+__device__ __forceinline__ u32 st_src_next_keys_diff(const StateArgs& a, u64 j, const Fr* const mine[6]) { return st_next_keys_diff(a.rows, j, mine); }
+#endif
+template <int SHIFT = 1, class ARGS = StateArgs>
+ZK_HD u32 state_check_loaded(const ARGS& a, u64 i, const StRow& C, const StRow& P, u32 code) {
     (void)P;
     ST_STAMP(0);
 #if defined(ZK_STATE_PROF) && ZK_STATE_PROF == 2
@@ -473,7 +486,7 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
         ST_ASSERT(fr_is_zero(val_hi), 24);
         ST_ASSERT(fr_is_zero(init_hi), 25);
         {
-            Fr lex = st_col(w, ST_LEX, i);
+            Fr lex = st_src_lex(a, i);
             Fr d = fr_sub_u64(fr_sub(rwc, p_rwc), 1);
             ST_ASSERT(fr_is_zero(lex) || fr_is_zero(d), 26);  // p prime: product zero iff a factor is
             ST_ASSERT(!val_is_word, 27);
@@ -541,7 +554,7 @@ ZK_HD u32 state_check_loaded(const StateArgs& a, u64 i, const StRow& C, const St
             // The last rows of the wavefront, and the row in front of the wrap-around, read the next row instead.
             const u32 lane = threadIdx.x & 63u;
             if (lane + SHIFT < 64u && i + 1 < n) next_diff = ((eq_prev_mask >> (lane + SHIFT)) & 1ull) ? 0u : 1u;
-            else next_diff = st_next_keys_diff(w, in, mine);
+            else next_diff = st_src_next_keys_diff(a, in, mine);
 #else
             next_diff = 0;
             for (int c = 0; c < 6; c++) {

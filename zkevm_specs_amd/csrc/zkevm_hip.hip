@@ -145,12 +145,18 @@ __global__ void slots_fill_kernel(u32* slots, u32 n) {
     if (i < n) slots[i] = ZK_EMPTY_SLOT;
 }
 
+// unless_dense: the verdict of rw_dense_check_kernel (earlier on the stream) — a dense RW table is looked up by position and its
+// open-addressing index is never read (copy_rw_lookup): neither filled nor built then
 template <u64 (*HASH)(const ZkTable&, u32)>
-__global__ void index_build_kernel(ZkTable t, u32* slots) {
+__global__ void index_build_kernel(ZkTable t, u32* slots, const ZkRwMeta* unless_dense = nullptr) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= t.n) return;
+    if (r >= t.n || (unless_dense && unless_dense->dense)) return;
     u32 s = (u32)HASH(t, r) & t.mask;
     while (atomicCAS(&slots[s], ZK_EMPTY_SLOT, r) != ZK_EMPTY_SLOT) s = (s + 1) & t.mask;
+}
+__global__ void slots_fill_unless_dense_kernel(u32* slots, u32 n, const ZkRwMeta* unless_dense) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !unless_dense->dense) slots[i] = ZK_EMPTY_SLOT;
 }
 // MPT index: slot value = row | hash fingerprint (state_mpt_slot_value)
 __global__ void mpt_index_build_kernel(ZkTable t, u32* slots) {
@@ -547,6 +553,8 @@ struct zk_session {
     RekeyArgs rekey;
     RwkPlan rekey_plan_host;      // the compact-key plan as uploaded (host copy owned by the session: the upload needs no synchronisation of its own)
     bool assign_from_rw = false;  // SESSION_ASSIGN over an RW table: every pass starts with the re-keying and the sort (rekey)
+    bool fused_verify = false;    // SESSION_ASSIGN whose rows are evaluated where they are computed (zk_state_verify_from_rw_open):
+                                  // d_tally[0] = the State circuit's tally, d_tally[1] = rejected RW rows + failed assignments
     u32* rekey_status = nullptr;  // ... whose per-RW-row codes go here (the session's statuses are per op)
     u64 cpa_n_table = 0, cpa_n_rw = 0;
     u32* d_hist = nullptr;   // EVM: (group, state) bins (histogram -> cursors)
@@ -725,9 +733,20 @@ static int d2h_now(hipStream_t st, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
+// Host copies of small device inputs that a caller already holds (zk_block_verify reads the block's randomness cells and offsets once
+// and opens a dozen sessions over them): an open that needs such a value on the host takes it from here instead of waiting for its
+// stream — which, once a chain has work queued, is a wait for that work.
+struct HostView { const void* dev; const void* host; size_t bytes; };
+static thread_local HostView t_host_view[4];
+static thread_local int t_n_host_view = 0;
+static int fetch_small(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    for (int k = 0; k < t_n_host_view; k++)
+        if (t_host_view[k].dev == src && t_host_view[k].bytes >= bytes) { memcpy(dst, t_host_view[k].host, bytes); return 0; }
+    return d2h_now(st, dst, src, bytes);
+}
 
 template <u64 (*HASH)(const ZkTable&, u32)>
-static int build_index(zk_session* s, ZkTable& t, bool mpt_fingerprints = false) {
+static int build_index(zk_session* s, ZkTable& t, bool mpt_fingerprints = false, const ZkRwMeta* unless_dense = nullptr) {
     u32 cap = 16;
     while (cap < 2 * t.n + 2) cap <<= 1;
     u32* slots = nullptr;
@@ -735,9 +754,10 @@ static int build_index(zk_session* s, ZkTable& t, bool mpt_fingerprints = false)
     if (rc) return rc;
     t.mask = cap - 1;
     t.slots = slots;
-    hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, s->stream, slots, cap);
+    if (unless_dense) hipLaunchKernelGGL(slots_fill_unless_dense_kernel, dim3((cap + 255) / 256), dim3(256), 0, s->stream, slots, cap, unless_dense);
+    else hipLaunchKernelGGL(slots_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, s->stream, slots, cap);
     if (t.n && mpt_fingerprints) hipLaunchKernelGGL(mpt_index_build_kernel, dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
-    else if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots);
+    else if (t.n) hipLaunchKernelGGL(HIP_KERNEL_NAME(index_build_kernel<HASH>), dim3((t.n + 255) / 256), dim3(256), 0, s->stream, t, slots, unless_dense);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1147,7 +1167,7 @@ extern "C" int zk_bytecode_open(const uint64_t* rows, uint64_t n, const uint64_t
     if ((rc = table_stage(s, s->bytecode.keccak, keccak, nullptr, n_keccak, KECCAK_NCELLS, dev))) goto fail;
     if ((rc = build_index<keccak_key_hash>(s, s->bytecode.keccak))) goto fail;
     if (dev) {
-        if (d2h_now(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, randomness, 32);
     }
@@ -1220,13 +1240,13 @@ extern "C" int zk_copy_open(const zk_copy_tables* t, uint32_t opts, zk_session**
     if ((rc = table_stage(s, s->copy.rw, t->rw, t->rw_flags, t->n_rw, RW_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->copy.bytecode, t->bytecode, nullptr, t->n_bytecode, BYTECODE_NCELLS, dev))) goto fail;
     if ((rc = table_stage(s, s->copy.tx, t->tx, t->tx_flags, t->n_tx, TX_NCELLS, dev))) goto fail;
-    if ((rc = build_index<rw_key_hash>(s, s->copy.rw))) goto fail;
-    if ((rc = build_index<bc_key_hash>(s, s->copy.bytecode))) goto fail;
-    if ((rc = build_index<tx_key_hash>(s, s->copy.tx))) goto fail;
     s->copy.rw_meta = nullptr;
     if (!(opts & ZK_OPT_GENERIC_INDEX) && (rc = build_rw_meta(s, s->copy.rw, &s->copy.rw_meta))) goto fail;
+    if ((rc = build_index<rw_key_hash>(s, s->copy.rw, false, s->copy.rw_meta))) goto fail;  // (neither filled nor built when the rows are dense)
+    if ((rc = build_index<bc_key_hash>(s, s->copy.bytecode))) goto fail;
+    if ((rc = build_index<tx_key_hash>(s, s->copy.tx))) goto fail;
     if (dev) {
-        if (d2h_now(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, t->randomness, 32);
     }
@@ -1268,7 +1288,7 @@ extern "C" int zk_sign_open(const zk_sign_units* t, uint32_t opts, zk_session** 
     s->sign.tx_rows.mask = 0;
     s->sign.is_sig = t->is_sig ? 1u : 0u;
     if (dev) {
-        if (d2h_now(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, t->randomness, 32);
     }
@@ -1329,7 +1349,7 @@ extern "C" int zk_keccak_open(const uint8_t* data, uint64_t n_bytes, const uint6
         s->keccak_gen.long_count = d_list;
     }
     if (dev) {
-        if (d2h_now(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, randomness, 32);
     }
@@ -1591,6 +1611,75 @@ fail:
     zk_close(s);
     return rc;
 }
+// RW table -> State circuit verdict in one session: the re-keying, the sort and the mock MPT as above; op2row's rows are evaluated in
+// the registers they are computed in (state_fused.hpp) and never stored.
+extern "C" int zk_state_verify_from_rw_open(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n_rw, uint32_t opts, uint64_t* n_ops_out,
+                                            zk_session** out) {
+    ARG_TRY(t_device >= 0, "zk_state_verify_from_rw_open: call zk_init first");
+    HIP_TRY(hipSetDevice(t_device));
+    ARG_TRY(out && rw && n_rw > 0 && n_rw < (1ull << 31) - 1, "zk_state_verify_from_rw_open: bad arguments");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = new zk_session();
+    s->kind = SESSION_ASSIGN;
+    int rc = rekey_setup(s, rw, rw_flags, n_rw, dev, false, nullptr, nullptr);
+    if (rc) { zk_close(s); return rc; }
+    const u64 n = s->rekey.n_ops;
+    s->n = n;
+    s->assign_from_rw = true;
+    s->fused_verify = true;
+    AssignArgs& a = s->assign;
+    StateArgs& v = s->state;
+    u32 cap = 16, mcap = 16;
+    a.n = n;
+    a.rw = s->rekey.rw;
+    a.rw_flags = s->rekey.rw_flags;
+    a.order = rekey_order(s->rekey);
+    a.nb = (u32)((n + ASG_BLOCK - 1) / ASG_BLOCK);
+    if ((rc = dev_alloc(s, (void**)&a.mpt, (size_t)n * ASG_MPT_NCELLS * 32))) goto fail;
+    while (cap < 2 * n + 2) cap <<= 1;
+    mcap = cap;  // (as many MPT rows as ops at most)
+    a.mask = cap - 1;
+    a.mpt_mask = mcap - 1;
+    if ((rc = dev_alloc(s, (void**)&a.slots, ((size_t)cap + mcap) * 4))) goto fail;  // key slots, then the MPT index: one fill
+    a.mpt_slots = a.slots + cap;
+    if ((rc = dev_alloc(s, (void**)&a.first, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.rank, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.root_rank, (size_t)n * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_cnt, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&a.blk_next, (size_t)(a.nb + 1) * 4))) goto fail;
+    if ((rc = dev_alloc(s, (void**)&s->rekey_status, (size_t)n_rw * 4))) goto fail;
+    v.rows.cells = nullptr;
+    v.rows.flags = nullptr;
+    v.rows.n = n;
+    v.eval_lo = 0;
+    v.eval_hi = n;
+    v.mpt.cells = a.mpt;
+    v.mpt.flags = nullptr;
+    v.mpt.n = (u32)n;  // a capacity: see StateFusedArgs
+    v.mpt.ncells = MPT_NCELLS;
+    v.mpt.slots = a.mpt_slots;
+    v.mpt.mask = a.mpt_mask;
+    if ((rc = session_common_init(s))) goto fail;
+    if (n_ops_out) *n_ops_out = n;
+    *out = s;
+    return 0;
+fail:
+    zk_close(s);
+    return rc;
+}
+extern "C" int zk_state_verify_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64_t n, uint32_t opts, uint32_t* status_out,
+                                       uint64_t* n_ops_out, zk_result* result) {
+    ARG_TRY(result, "zk_state_verify_from_rw: result is null");
+    const bool dev = opts & ZK_OPT_DEVICE_PTRS;
+    zk_session* s = nullptr;
+    int rc = zk_state_verify_from_rw_open(rw, rw_flags, n, opts, n_ops_out, &s);
+    if (rc) return rc;
+    rc = zk_launch(s, (dev && status_out) ? status_out : nullptr);
+    if (!rc) rc = zk_collect(s, result);
+    if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
+    zk_close(s);
+    return rc;
+}
 extern "C" int zk_state_ops_from_rw_read(zk_session* s, uint64_t* ops_host, uint32_t* op_flags_host, uint64_t* n_ops_out) {
     ARG_TRY(s && s->kind == SESSION_REKEY, "zk_state_ops_from_rw_read: bad arguments");
     const RekeyArgs& a = s->rekey;
@@ -1725,7 +1814,7 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
     // the chunk table is index plumbing over the row offsets (not witness data): built on the host
     if (n_codes) {
         if (dev) {
-            if (d2h_now(s->stream, h_off.data(), offsets, (n_codes + 1) * 8)) { rc = -2; g_err = "offsets download failed"; goto fail; }
+            if (fetch_small(s->stream, h_off.data(), offsets, (n_codes + 1) * 8)) { rc = -2; g_err = "offsets download failed"; goto fail; }
         } else {
             memcpy(h_off.data(), offsets, (n_codes + 1) * 8);
         }
@@ -1751,7 +1840,7 @@ extern "C" int zk_bytecode_assign_open(const uint64_t* in_rows, uint64_t n_rows,
     a.lengths = (const u64*)p;
     a.n_in = n_rows; a.n_codes = n_codes; a.n_out = 1ull << k; a.n_chunks = chunks.size();
     if (dev) {
-        if (d2h_now(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, randomness, 32);
     }
@@ -1888,7 +1977,7 @@ extern "C" int zk_copy_assign_open(const zk_copy_events* t, uint64_t* rows_dev, 
     a.chunks = (const CpaChunk*)p;
     a.n_events = t->n_events; a.n_rows = pl.n_rows; a.n_chunks = pl.chunks.size();
     if (dev) {
-        if (d2h_now(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
+        if (fetch_small(s->stream, rh, t->randomness, 32)) { rc = -2; g_err = "randomness download failed"; goto fail; }
     } else {
         memcpy(rh, t->randomness, 32);
     }
@@ -2181,7 +2270,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
-        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, s->stream, s->d_tally, s->kind == SESSION_EVM ? s->evm.defer_count : (u32*)nullptr);
+        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(s->fused_verify ? 2 : 1), 0, s->stream, s->d_tally, s->kind == SESSION_EVM ? s->evm.defer_count : (u32*)nullptr);
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
     // no separate event packets between the sort passes and the evaluation kernels
@@ -2211,6 +2300,12 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_EXP: zk_launch_exp_rows(s->stream, s->exp, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_KECCAK: zk_launch_keccak_table(s->stream, s->keccak_gen, status, s->d_tally); break;
     case SESSION_ASSIGN:
+        if (s->fused_verify) {
+            zk_launch_state_rekey(s->stream, s->rekey, s->rekey_status, s->d_tally + 1);
+            zk_launch_state_assign(s->stream, s->assign, nullptr, nullptr);  // (the roots alone: root_rank is set)
+            zk_launch_state_rows_fused(s->stream, s->state, s->assign, status, s->d_tally, s->d_tally + 1);
+            break;
+        }
         if (s->assign_from_rw) zk_launch_state_rekey(s->stream, s->rekey, s->rekey_status, s->d_tally);  // rejected RW rows count in the same tally
         zk_launch_state_assign(s->stream, s->assign, status, s->d_tally);
         break;
@@ -2347,8 +2442,19 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
     } else {
         if (check_deferred) HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));  // rides on the tally's synchronisation
         if (read_ranges) HIP_TRY(hipMemcpyAsync(gs, s->d_group_start, sizeof gs, hipMemcpyDeviceToHost, s->stream));
+        ZkTally t_asg = {0ull, ~0ull};
+        if (s->fused_verify) HIP_TRY(hipMemcpyAsync(&t_asg, s->d_tally + 1, sizeof t_asg, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
+        if (t_asg.fail_count) {  // no witness: what assign_state_circuit raises in the reference is an error here, not a verdict
+            char msg[240];
+            snprintf(msg, sizeof msg, "zk_state_verify_from_rw: the State witness assignment failed for %llu RW rows / ops (first: %llu, code 0x%08x; "
+                     "zk_state_assign_from_rw reports each)", (unsigned long long)t_asg.fail_count, (unsigned long long)(t_asg.first_fail >> 32),
+                     (unsigned)(t_asg.first_fail & 0xffffffffull));
+            g_err = msg;
+            s->launches = 0;
+            return -1;
+        }
     }
     if (read_ranges) {
         s->evm_ranges_known = 1;
@@ -2561,11 +2667,41 @@ extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_of
 
 // ---------------------------------------------------------------------------------------
 // zk_block_verify: a block as a one-shot (include/zkevm_hip.h).  The chains are the C entries above, driven by four host threads:
-// every open has its own small host round trip (class scan, offsets, event plan), so the overlap has to come from threads.
+// every open has its own small host work (class scan + plan, chunk tables, event plan), so the overlap has to come from threads.
+// The threads are persistent (four per device, parked on a condition variable); within a chain every session is opened and launched
+// before the first one is collected, so the host's opens overlap the device's kernels and a chain waits once, at its end.
 // ---------------------------------------------------------------------------------------
 #include <condition_variable>
+#include <functional>
 #include <thread>
 static hipStream_t g_block_stream[ZK_MAX_DEVICES][4] = {{nullptr}};
+struct BlockWorkers {  // (never destroyed: the threads are parked, not joined, when the process ends)
+    std::mutex call;   // one block at a time per device
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<void()> job[4];
+    bool has_job[4] = {false, false, false, false};
+    int pending = 0;
+    bool started = false;
+    void run(int c) {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv_job.wait(lock, [&] { return has_job[c]; });
+                f = std::move(job[c]);
+                has_job[c] = false;
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lock(m);
+                pending--;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+static BlockWorkers* g_block_workers[ZK_MAX_DEVICES] = {nullptr};
 struct BlockShared {
     std::mutex m;
     std::condition_variable cv;
@@ -2577,7 +2713,7 @@ struct BlockShared {
     hipEvent_t ev_keccak = nullptr;  // here: "the Bytecode assignment's rows are written"
     int rc[4] = {0, 0, 0, 0};
     std::string err[4];
-    double end_ms[4] = {0, 0, 0, 0};
+    double end_ms[4] = {0, 0, 0, 0}, start_ms[4] = {0, 0, 0, 0};
     std::chrono::steady_clock::time_point t0;
 };
 #define BLK_TRY(expr) do { if ((rc = (expr))) goto done; } while (0)
@@ -2586,7 +2722,7 @@ static int block_run_pass(zk_session* s, zk_result* r) {
     if (!rc) rc = zk_collect(s, r);
     return rc;
 }
-extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results, double* chain_end_ms) {
+extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* results, double* chain_ms) {
     ARG_TRY(t_device >= 0, "zk_block_verify: call zk_init first");
     ARG_TRY(b && results && (opts & ZK_OPT_DEVICE_PTRS), "zk_block_verify: needs a block, a result array and ZK_OPT_DEVICE_PTRS");
     ARG_TRY(b->evm.steps && b->evm.n_steps >= 2 && b->evm.rw && b->evm.n_rw && b->randomness && b->hashed_offsets && b->n_hashed >= b->n_codes &&
@@ -2594,6 +2730,9 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
     HIP_TRY(hipSetDevice(t_device));
     const int device = t_device;
     const uint32_t dev_opts = ZK_OPT_DEVICE_PTRS, st_opts = ZK_OPT_DEVICE_PTRS | (opts & ZK_OPT_STATE_COMPACT);
+    BlockShared sh;
+    sh.t0 = std::chrono::steady_clock::now();
+    BlockWorkers* W = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
         for (int c = 0; c < 4; c++)
@@ -2603,37 +2742,76 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
                 // the State chain floods the device with HBM-bound kernels; the chains the EVM circuit waits for are short: high priority
                 // (a CU-mask split between the State chain and the others was measured: no gain at 4 / 8 / 16 of every 32 CUs — the chains
                 // slow each other through the memory system, not through shared CUs; profiles/r06_experiments.txt)
-                HIP_TRY(hipStreamCreateWithPriority(&g_block_stream[device][c], hipStreamNonBlocking, c == 0 ? lo : hi));
+                // (the State chain on the low priority: with its rows evaluated in registers it no longer floods HBM, but it is still the
+                // chain with the most device work — on the high priority the block is 1.02 ms, like this 0.96; ZK_BLOCK_STATE_PRIO=hi)
+                static const bool state_low = [] { const char* e = getenv("ZK_BLOCK_STATE_PRIO"); return !(e && e[0] == 'h'); }();
+                HIP_TRY(hipStreamCreateWithPriority(&g_block_stream[device][c], hipStreamNonBlocking, (c == 0) == state_low ? lo : hi));
             }
+        if (!g_block_workers[device]) g_block_workers[device] = new BlockWorkers();
+        W = g_block_workers[device];
+    }
+    std::lock_guard<std::mutex> one_block(W->call);
+    if (!W->started) {
+        for (int c = 0; c < 4; c++) std::thread([W, c] { W->run(c); }).detach();
+        W->started = true;
     }
     for (int c = 0; c < ZK_BLOCK_NCIRCUITS; c++) { memset(&results[c], 0, sizeof(zk_result)); results[c].first_fail_row = UINT64_MAX; }
-    BlockShared sh;
-    sh.t0 = std::chrono::steady_clock::now();
+    // the small inputs every open wants on the host (HostView): the randomness cells and the bytecode offsets, fetched once by this
+    // thread while the chains start — the State chain needs none of them and does not wait
+    u64 h_cells[3][4];
+    std::vector<u64> h_code_off((size_t)b->n_bytecodes + 1);
+    HostView views[4];
+    int n_views = 0;
+    bool views_ready = false, views_failed = false;
     { int erc = arena_event(device, &sh.ev_keccak); if (erc) return erc; }
     { int erc = arena_event(device, &sh.ev_cpa); if (erc) return erc; }
     // Chains (each a host thread on its own stream):
-    //   0  State:     RW table -> State witness -> State circuit
+    //   0  State:     RW table -> State verdict (rows evaluated where they are computed; or -> State witness -> State circuit)
     //   1  Bytecode:  keccak of the contracts (long messages: the slow pass) -> [Bytecode rows ready: event from chain 3] -> Bytecode circuit
-    //   2  EVM:       copy assignment -> Copy circuit launched -> keccak of the SHA3 inputs (its own short pass: the EVM circuit's keccak
-    //                 table does not hold the contracts' hashes, so this chain never waits for chain 1) -> EVM open + pass -> Copy collect
-    //   3  rest:      Bytecode assignment launched (+ event) -> Exp launched -> Tx pass -> collects
+    //   2  EVM:       copy assignment (+ event) -> keccak of the SHA3 inputs (its own short pass: the EVM circuit's keccak table does not
+    //                 hold the contracts' hashes, so this chain never waits for chain 1) -> EVM open + pass
+    //   3  rest:      Bytecode assignment (+ event) -> Exp -> Tx -> [copy rows ready: event from chain 2] -> Copy circuit
     auto enter = [&](int chain) {
         (void)zk_init(device);
         (void)zk_set_stream(g_block_stream[device][chain]);
+        sh.start_ms[chain] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
+        if (chain == 0) return true;
+        std::unique_lock<std::mutex> lock(sh.m);
+        sh.cv.wait(lock, [&] { return views_ready; });
+        for (int k = 0; k < n_views; k++) t_host_view[k] = views[k];
+        t_n_host_view = n_views;
+        return !views_failed;
     };
     auto leave = [&](int chain, int rc) {
+        t_n_host_view = 0;
         sh.rc[chain] = rc;
         if (rc) sh.err[chain] = g_err;
         sh.end_ms[chain] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
     };
+    // ZK_BLOCK_TRACE=1: host-side marks of every chain to stderr (where a chain's host thread is when)
+    static const bool trace = [] { const char* e = getenv("ZK_BLOCK_TRACE"); return e && e[0] == '1'; }();
+    struct Mark { int chain; const char* what; double ms; };
+    std::vector<Mark> marks[4];
+    auto mark = [&](int chain, const char* what) {
+        if (trace) marks[chain].push_back(Mark{chain, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count()});
+    };
     const u64* bca_rows = nullptr;  // (written by chain 3 before it sets keccak_enqueued — here: "bytecode rows enqueued")
-    std::thread th_state([&] {
+    auto chain_state = [&] {
         enter(0);
         int rc = 0;
         zk_session *a = nullptr, *s = nullptr;
         uint64_t n_ops = 0, n_mpt = 0;
         zk_result ra;
         u32 n_mpt32 = 0;
+        if (!(opts & (ZK_OPT_BLOCK_STATE_ROWS | ZK_OPT_STATE_COMPACT))) {  // rows evaluated where they are computed: one session, no witness
+            BLK_TRY(zk_state_verify_from_rw_open(b->evm.rw, b->evm.rw_flags, b->evm.n_rw, dev_opts, &n_ops, &a));
+            mark(0, "state opened (class scan + plan)");
+            BLK_TRY(zk_launch(a, nullptr));
+            mark(0, "state launched");
+            BLK_TRY(zk_collect(a, &results[ZK_BLOCK_STATE]));
+            mark(0, "state collected");
+            goto done;
+        }
         BLK_TRY(zk_state_assign_from_rw_open(b->evm.rw, b->evm.rw_flags, b->evm.n_rw, nullptr, nullptr, nullptr, st_opts, &n_ops, &a));
         BLK_TRY(zk_launch(a, nullptr));
         // the MPT row count rides on the collect's synchronisation (zk_state_assign_read would be two more round trips)
@@ -2647,63 +2825,83 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         if (s) zk_close(s);
         if (a) zk_close(a);
         leave(0, rc);
-    });
-    std::thread th_bytecode([&] {
-        enter(1);
+    };
+    auto chain_bytecode = [&] {
+        const bool entered = enter(1);
         int rc = 0;
         zk_session *ks = nullptr, *bs = nullptr;
         zk_result rk;
+        if (!entered) { rc = -2; g_err = "zk_block_verify: reading the block's randomness / offsets failed"; goto done; }
         if (b->n_codes) {
             BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets, b->n_codes, b->randomness, 0, nullptr, dev_opts, &ks));
-            BLK_TRY(block_run_pass(ks, &rk));
-            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a contract was rejected by the keccak table generation"; goto done; }
+            BLK_TRY(zk_launch(ks, nullptr));
+            mark(1, "contracts' keccak launched");
         }
         {
             std::unique_lock<std::mutex> lock(sh.m);
             sh.cv.wait(lock, [&] { return sh.keccak_enqueued; });  // chain 3 has enqueued the Bytecode assignment (or failed)
             if (sh.keccak_failed) { rc = -1; g_err = "zk_block_verify: the Bytecode assignment failed before it was enqueued"; goto done; }
         }
-        if (hipStreamWaitEvent(g_block_stream[device][1], sh.ev_keccak, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+        // the Bytecode circuit's session is opened behind the keccak pass on this stream (its index over the keccak rows is a kernel in
+        // stream order); its evaluation pass also waits for the Bytecode rows of chain 3
         BLK_TRY(zk_bytecode_open(bca_rows, (uint64_t)1 << b->k, ks ? ks->keccak_gen.rows : nullptr, b->n_codes, b->randomness, dev_opts, &bs));
-        BLK_TRY(block_run_pass(bs, &results[ZK_BLOCK_BYTECODE]));
+        if (hipStreamWaitEvent(g_block_stream[device][1], sh.ev_keccak, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+        BLK_TRY(zk_launch(bs, nullptr));
+        mark(1, "bytecode circuit launched");
+        if (ks) {
+            BLK_TRY(zk_collect(ks, &rk));
+            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a contract was rejected by the keccak table generation"; goto done; }
+        }
+        BLK_TRY(zk_collect(bs, &results[ZK_BLOCK_BYTECODE]));
     done:
         if (bs) zk_close(bs);
         if (ks) zk_close(ks);
         leave(1, rc);
-    });
-    std::thread th_evm([&] {
-        enter(2);
+    };
+    auto chain_evm = [&] {
+        const bool entered = enter(2);
         int rc = 0;
         zk_session *ca = nullptr, *es = nullptr, *ks = nullptr;
         zk_result rc_assign, rk;
         zk_evm_tables t = b->evm;
         t.copy = nullptr; t.n_copy = 0; t.keccak = nullptr; t.n_keccak = 0;
         bool cpa_signalled = false;
+        if (!entered) { rc = -2; g_err = "zk_block_verify: reading the block's randomness / offsets failed"; goto done; }
         if (b->copy_events.n_events) {
             BLK_TRY(zk_copy_assign_open(&b->copy_events, nullptr, nullptr, nullptr, nullptr, nullptr, dev_opts, &ca));
             BLK_TRY(zk_launch(ca, nullptr));
             if (hipEventRecord(sh.ev_cpa, ca->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
             sh.keep_cpa = ca;
-            { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_enqueued = true; }
-            sh.cv.notify_all();
-            cpa_signalled = true;
-            BLK_TRY(zk_collect(ca, &rc_assign));
+            mark(2, "copy assignment launched");
             t.copy = ca->cpa.table;
             t.n_copy = ca->cpa_n_table;
-        } else {
-            { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_enqueued = true; }
-            sh.cv.notify_all();
-            cpa_signalled = true;
         }
+        { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_enqueued = true; }
+        sh.cv.notify_all();
+        cpa_signalled = true;
         if (b->n_hashed > b->n_codes) {  // the SHA3 steps' inputs: the EVM circuit's keccak table (execution/sha3.py:31), on this chain's own stream
             BLK_TRY(zk_keccak_open(b->hashed_data, b->hashed_bytes, b->hashed_offsets + b->n_codes, b->n_hashed - b->n_codes, b->randomness, 0, nullptr, dev_opts, &ks));
-            BLK_TRY(block_run_pass(ks, &rk));
-            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a SHA3 input was rejected by the keccak table generation"; goto done; }
+            BLK_TRY(zk_launch(ks, nullptr));
             t.keccak = ks->keccak_gen.rows;
             t.n_keccak = b->n_hashed - b->n_codes;
+            mark(2, "SHA3 keccak launched");
         }
+        // the EVM session's build kernels and its pass queue up behind the two table generations: nothing is collected before everything
+        // of this chain is enqueued
         BLK_TRY(zk_evm_open(&t, dev_opts | ZK_OPT_SINGLE_PASS | ZK_OPT_SIDE_STREAM, &es));
-        BLK_TRY(block_run_pass(es, &results[ZK_BLOCK_EVM]));
+        mark(2, "evm opened");
+        BLK_TRY(zk_launch(es, nullptr));
+        mark(2, "evm launched");
+        BLK_TRY(zk_collect(es, &results[ZK_BLOCK_EVM]));
+        mark(2, "evm collected");
+        if (ca) {
+            BLK_TRY(zk_collect(ca, &rc_assign));
+            if (rc_assign.fail_count) { rc = -1; g_err = "zk_block_verify: a copy event was rejected by the copy assignment"; goto done; }
+        }
+        if (ks) {
+            BLK_TRY(zk_collect(ks, &rk));
+            if (rk.fail_count) { rc = -1; g_err = "zk_block_verify: a SHA3 input was rejected by the keccak table generation"; goto done; }
+        }
     done:
         if (!cpa_signalled) {
             { std::lock_guard<std::mutex> lock(sh.m); sh.cpa_failed = true; sh.cpa_enqueued = true; }
@@ -2711,15 +2909,16 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         }
         if (es) zk_close(es);
         if (ks) zk_close(ks);
-        // (the copy assignment's rows are read by chain 3's Copy circuit: closed after the joins)
+        // (the copy assignment's rows are read by chain 3's Copy circuit: closed after the chains have ended)
         leave(2, rc);
-    });
-    std::thread th_rest([&] {
-        enter(3);
+    };
+    auto chain_rest = [&] {
+        const bool entered = enter(3);
         int rc = 0;
         zk_session *ex = nullptr, *tx = nullptr, *ba = nullptr, *cs = nullptr;
         zk_result rb;
         bool signalled = false;
+        if (!entered) { rc = -2; g_err = "zk_block_verify: reading the block's randomness / offsets failed"; goto done; }
         BLK_TRY(zk_bytecode_assign_open(b->evm.bytecode, b->evm.n_bytecode, b->code_offsets, b->code_lengths, b->n_bytecodes, b->k, b->randomness, nullptr, dev_opts, &ba));
         BLK_TRY(zk_launch(ba, nullptr));
         if (hipEventRecord(sh.ev_keccak, ba->stream) != hipSuccess) { rc = -2; g_err = "zk_block_verify: event record failed"; goto done; }
@@ -2727,24 +2926,24 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         { std::lock_guard<std::mutex> lock(sh.m); sh.keccak_enqueued = true; }
         sh.cv.notify_all();
         signalled = true;
+        mark(3, "bytecode assignment launched");
         if (b->n_exp_rows) {
             BLK_TRY(zk_exp_open(b->exp_rows, b->n_exp_rows, dev_opts, &ex));
             BLK_TRY(zk_launch(ex, nullptr));
         }
         if (b->tx.n_units) {
             BLK_TRY(zk_sign_open(&b->tx, dev_opts, &tx));
-            BLK_TRY(block_run_pass(tx, &results[ZK_BLOCK_TX]));
+            BLK_TRY(zk_launch(tx, nullptr));
         }
-        if (ex) BLK_TRY(zk_collect(ex, &results[ZK_BLOCK_EXP]));
-        BLK_TRY(zk_collect(ba, &rb));
-        {   // the Copy circuit over the rows chain 2's copy assignment writes (ordered behind it on the device)
+        mark(3, "exp + tx launched");
+        {   // the Copy circuit over the rows chain 2's copy assignment writes: its lookup indices are built right away, its pass is ordered
+            // behind the assignment on the device
             std::unique_lock<std::mutex> lock(sh.m);
             sh.cv.wait(lock, [&] { return sh.cpa_enqueued; });
             if (sh.cpa_failed) { rc = -1; g_err = "zk_block_verify: the copy assignment failed before it was enqueued"; goto done; }
         }
         if (sh.keep_cpa && sh.keep_cpa->cpa.n_rows) {
             zk_session* ca = sh.keep_cpa;
-            if (hipStreamWaitEvent(g_block_stream[device][3], sh.ev_cpa, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
             zk_copy_tables ct;
             memset(&ct, 0, sizeof ct);
             ct.rows = ca->cpa.rows; ct.row_flags = ca->cpa.row_flags; ct.n_rows = ca->cpa.n_rows; ct.randomness = b->copy_events.randomness;
@@ -2752,8 +2951,15 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
             ct.bytecode = b->evm.bytecode; ct.n_bytecode = b->evm.n_bytecode;
             ct.tx = b->evm.tx; ct.tx_flags = b->evm.tx_flags; ct.n_tx = b->evm.n_tx;
             BLK_TRY(zk_copy_open(&ct, dev_opts, &cs));
-            BLK_TRY(block_run_pass(cs, &results[ZK_BLOCK_COPY]));
+            if (hipStreamWaitEvent(g_block_stream[device][3], sh.ev_cpa, 0) != hipSuccess) { rc = -2; g_err = "zk_block_verify: stream wait failed"; goto done; }
+            BLK_TRY(zk_launch(cs, nullptr));
+            mark(3, "copy circuit launched");
         }
+        if (tx) BLK_TRY(zk_collect(tx, &results[ZK_BLOCK_TX]));
+        if (ex) BLK_TRY(zk_collect(ex, &results[ZK_BLOCK_EXP]));
+        BLK_TRY(zk_collect(ba, &rb));
+        if (rb.fail_count) { rc = -1; g_err = "zk_block_verify: the Bytecode assignment rejected its input"; goto done; }
+        if (cs) BLK_TRY(zk_collect(cs, &results[ZK_BLOCK_COPY]));
     done:
         if (cs) zk_close(cs);
         if (!signalled) {
@@ -2762,14 +2968,40 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         }
         if (tx) zk_close(tx);
         if (ex) zk_close(ex);
-        // (the Bytecode assignment's rows are read by chain 1's Bytecode circuit: closed after the joins)
+        // (the Bytecode assignment's rows are read by chain 1's Bytecode circuit: closed after the chains have ended)
         sh.keep = ba;
         leave(3, rc);
-    });
-    th_state.join();
-    th_bytecode.join();
-    th_evm.join();
-    th_rest.join();
+    };
+    {
+        std::unique_lock<std::mutex> lock(W->m);
+        W->job[0] = chain_state; W->job[1] = chain_bytecode; W->job[2] = chain_evm; W->job[3] = chain_rest;
+        for (int c = 0; c < 4; c++) W->has_job[c] = true;
+        W->pending = 4;
+        W->cv_job.notify_all();
+    }
+    {
+        const hipStream_t st = t_stream ? t_stream : g_own_stream[device];
+        const uint64_t* cells[3] = {b->randomness, b->copy_events.n_events ? b->copy_events.randomness : nullptr, b->tx.n_units ? b->tx.randomness : nullptr};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; k++) {
+            if (!cells[k]) continue;
+            bool seen = false;
+            for (int j = 0; j < n_views; j++) seen = seen || views[j].dev == cells[k];
+            if (seen) continue;
+            ok = hipMemcpyAsync(h_cells[k], cells[k], 32, hipMemcpyDeviceToHost, st) == hipSuccess;
+            views[n_views++] = HostView{cells[k], h_cells[k], 32};
+        }
+        ok = ok && hipMemcpyAsync(h_code_off.data(), b->code_offsets, h_code_off.size() * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+        views[n_views++] = HostView{b->code_offsets, h_code_off.data(), h_code_off.size() * 8};
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        { std::lock_guard<std::mutex> lock(sh.m); views_failed = !ok; views_ready = true; }
+        sh.cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lock(W->m);
+        W->cv_done.wait(lock, [&] { return W->pending == 0; });
+    }
+    const double joined_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
     if (sh.keep) zk_close(sh.keep);
     if (sh.keep_cpa) zk_close(sh.keep_cpa);
     {
@@ -2778,7 +3010,17 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
         A.events.push_back(sh.ev_keccak);
         A.events.push_back(sh.ev_cpa);
     }
-    if (chain_end_ms) for (int c = 0; c < 4; c++) chain_end_ms[c] = sh.end_ms[c];
+    if (trace)
+        for (int c = 0; c < 4; c++) {
+            fprintf(stderr, "[zk_block_verify] chain %d: start %.3f", c, sh.start_ms[c]);
+            for (const Mark& k : marks[c]) fprintf(stderr, " | %s %.3f", k.what, k.ms);
+            fprintf(stderr, " | end %.3f\n", sh.end_ms[c]);
+        }
+    if (chain_ms) {
+        for (int c = 0; c < 4; c++) { chain_ms[c] = sh.end_ms[c]; chain_ms[4 + c] = sh.start_ms[c]; }
+        chain_ms[8] = joined_ms;
+        chain_ms[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sh.t0).count();
+    }
     for (int c = 0; c < 4; c++)
         if (sh.rc[c]) { g_err = sh.err[c]; return sh.rc[c]; }
     return 0;

@@ -520,6 +520,20 @@ def open_state_assign_from_rw(rw, rw_flags, rows_dev=None, row_flags_dev=None, m
     return s
 
 
+def open_state_verify_from_rw(rw, rw_flags, device=None):
+    """rw uint64[n, 14, 4] + rw_flags uint32[n] (the EVM circuit's RW table) -> Session over the n_ops = 1 + kept rows State rows
+    (session.n), which are evaluated where they are computed and never stored (zk_state_verify_from_rw_open): collect() is the State
+    circuit's Result; an RW row the re-keying rejects or an op the assignment raises on makes collect() raise EngineError."""
+    lib = _lib.init(device)
+    _expect(rw, "rw table", 8, (None, 14, 4))
+    n = int(rw.shape[0])
+    _expect(rw_flags, "rw_flags", 4, (n,))
+    (rw, rw_flags), opts = _prep([rw, rw_flags])
+    h, n_ops = ctypes.c_void_p(), ctypes.c_uint64()
+    check(lib.zk_state_verify_from_rw_open(_lib.ptr(rw), _lib.ptr(rw_flags), n, opts, ctypes.byref(n_ops), ctypes.byref(h)), "zk_state_verify_from_rw_open", lib)
+    return Session(h, int(n_ops.value), (rw, rw_flags), lib=lib)
+
+
 class RekeySession(Session):
     """RW table -> State-circuit operations (zk_state_ops_from_rw_*): launch()/collect() like the circuits (status = one code per
     RW row); n_ops = StartOp + the rows kept; read() -> (ops uint64[12, n_ops, 4], op_flags uint32[n_ops]) on the host."""

@@ -181,6 +181,18 @@ def state_ops_from_rw(rw, rw_flags, device=None):
     return Result(r), status, ops[: 48 * m].reshape(12, m, 4), flags[:m]
 
 
+def state_verify_from_rw(rw, rw_flags, device=None):
+    """zk_state_verify_from_rw -> (Result of the State circuit, status uint32[n_ops] per State row)"""
+    lib = _lib.init(device)
+    rw, rw_flags = _c(rw), _c(rw_flags, np.uint32)
+    _expect(rw, "rw table", 8, (None, 14, 4))
+    n = int(rw.shape[0])
+    _expect(rw_flags, "rw_flags", 4, (n,))
+    status, r, n_ops = np.zeros(n + 1, dtype=np.uint32), ZkResult(), ctypes.c_uint64()
+    check(lib.zk_state_verify_from_rw(_p(rw), _p(rw_flags), n, 0, _p(status), ctypes.byref(n_ops), ctypes.byref(r)), "zk_state_verify_from_rw", lib)
+    return Result(r), status[: int(n_ops.value)]
+
+
 def bytecode_assign(in_rows, offsets, lengths, k, randomness, device=None):
     """zk_bytecode_assign -> (Result, rows uint64[12, 2^k, 4])"""
     lib = _lib.init(device)
