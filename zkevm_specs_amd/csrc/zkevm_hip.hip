@@ -73,6 +73,27 @@ extern "C" const char* zk_last_error(void) { return g_err.c_str(); }
 __attribute__((constructor)) static void zk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 static void arena_release_all();
 
+// The four streams of zk_block_verify's chains.  Created when the device is first selected, not when the first block arrives: the
+// runtime multiplexes streams onto a fixed number of hardware queues in creation order, and a process that has made many streams by
+// then (PyTorch creates its pools of 32 per priority at once) leaves late-comers on shared queues — two chains of a block behind
+// each other: 1.08-1.11 ms per block instead of 0.94 (profiles/r06_block_oneshot_v3.txt).
+static hipStream_t g_block_stream[ZK_MAX_DEVICES][4] = {{nullptr}};
+static int block_streams_ensure(int device) {  // g_dev_mutex held
+    for (int c = 0; c < 4; c++)
+        if (!g_block_stream[device][c]) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            // the State chain on the low priority, the three chains of short kernels on the high one: 0.96 ms per block against 1.02 the other
+            // way round (ZK_BLOCK_STATE_PRIO=hi) and 1.00 without priorities (ZK_BLOCK_PRIO=none).  (A CU-mask split between the State chain
+            // and the others was measured: no gain at 4 / 8 / 16 of every 32 CUs — the chains slow each other through the memory system,
+            // not through shared CUs; profiles/r06_experiments.txt)
+            static const bool state_low = [] { const char* e = getenv("ZK_BLOCK_STATE_PRIO"); return !(e && e[0] == 'h'); }();
+            static const bool flat = [] { const char* e = getenv("ZK_BLOCK_PRIO"); return e && e[0] == 'n'; }();
+            if (flat) HIP_TRY(hipStreamCreateWithFlags(&g_block_stream[device][c], hipStreamNonBlocking));
+            else HIP_TRY(hipStreamCreateWithPriority(&g_block_stream[device][c], hipStreamNonBlocking, (c == 0) == state_low ? lo : hi));
+        }
+    return 0;
+}
 extern "C" int zk_init(int device) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -81,7 +102,10 @@ extern "C" int zk_init(int device) {
     hipStream_t own;
     {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
-        if (!g_own_stream[device]) HIP_TRY(hipStreamCreateWithFlags(&g_own_stream[device], hipStreamNonBlocking));
+        if (!g_own_stream[device]) {
+            HIP_TRY(hipStreamCreateWithFlags(&g_own_stream[device], hipStreamNonBlocking));
+            { int brc = block_streams_ensure(device); if (brc) return brc; }
+        }
         own = g_own_stream[device];
         if (!g_zero_row[device]) {
             HIP_TRY(hipMalloc(&g_zero_row[device], 512));
@@ -112,6 +136,10 @@ extern "C" void zk_shutdown(void) {
             }
             if (g_side_stream[d]) (void)hipStreamDestroy(g_side_stream[d]);
             g_side_stream[d] = nullptr;
+            for (int k = 0; k < 4; k++) {
+                if (g_block_stream[d][k]) (void)hipStreamDestroy(g_block_stream[d][k]);
+                g_block_stream[d][k] = nullptr;
+            }
             g_own_stream[d] = nullptr;
             g_zero_row[d] = nullptr;
         }
@@ -2674,7 +2702,6 @@ extern "C" int zk_dist_tally(zk_comm* c, const zk_result* local, uint64_t row_of
 #include <condition_variable>
 #include <functional>
 #include <thread>
-static hipStream_t g_block_stream[ZK_MAX_DEVICES][4] = {{nullptr}};
 struct BlockWorkers {  // (never destroyed: the threads are parked, not joined, when the process ends)
     std::mutex call;   // one block at a time per device
     std::mutex m;
@@ -2735,18 +2762,7 @@ extern "C" int zk_block_verify(const zk_block* b, uint32_t opts, zk_result* resu
     BlockWorkers* W = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
-        for (int c = 0; c < 4; c++)
-            if (!g_block_stream[device][c]) {
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                // the State chain floods the device with HBM-bound kernels; the chains the EVM circuit waits for are short: high priority
-                // (a CU-mask split between the State chain and the others was measured: no gain at 4 / 8 / 16 of every 32 CUs — the chains
-                // slow each other through the memory system, not through shared CUs; profiles/r06_experiments.txt)
-                // (the State chain on the low priority: with its rows evaluated in registers it no longer floods HBM, but it is still the
-                // chain with the most device work — on the high priority the block is 1.02 ms, like this 0.96; ZK_BLOCK_STATE_PRIO=hi)
-                static const bool state_low = [] { const char* e = getenv("ZK_BLOCK_STATE_PRIO"); return !(e && e[0] == 'h'); }();
-                HIP_TRY(hipStreamCreateWithPriority(&g_block_stream[device][c], hipStreamNonBlocking, (c == 0) == state_low ? lo : hi));
-            }
+        { int brc = block_streams_ensure(device); if (brc) return brc; }
         if (!g_block_workers[device]) g_block_workers[device] = new BlockWorkers();
         W = g_block_workers[device];
     }
