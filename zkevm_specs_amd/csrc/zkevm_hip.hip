@@ -104,7 +104,8 @@ extern "C" int zk_init(int device) {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
         if (!g_own_stream[device]) {
             HIP_TRY(hipStreamCreateWithFlags(&g_own_stream[device], hipStreamNonBlocking));
-            { int brc = block_streams_ensure(device); if (brc) return brc; }
+            static const bool lazy = [] { const char* e = getenv("ZK_BLOCK_STREAMS_LAZY"); return e && e[0] == '1'; }();  // A/B aid
+            if (!lazy) { int brc = block_streams_ensure(device); if (brc) return brc; }
         }
         own = g_own_stream[device];
         if (!g_zero_row[device]) {
