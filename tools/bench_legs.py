@@ -277,9 +277,10 @@ def other_configs(core, ctx, args):
     return out
 
 
-def marshalling_sample(wire_h, n_steps=1 << 10):
+def marshalling_sample(wire_h, n_steps=1 << 14):
     """flatten_evm (reference-shaped Python objects -> wire arrays, zkevm_specs_amd/flatten.py) timed on a bounded prefix of this run's
-    trace: the objects are rebuilt from the wire first (zkevm_specs_amd/objects.py), which is not part of the figure."""
+    trace: the objects are rebuilt from the wire first (zkevm_specs_amd/objects.py), which is not part of the figure.  The prefix carries
+    the WHOLE bytecode table (43,913 rows whatever the prefix): rounds 4-5 sampled 2^10 steps, where that table is most of the work."""
     import numpy as np
 
     from zkevm_specs_amd import flatten, objects
@@ -291,13 +292,25 @@ def marshalling_sample(wire_h, n_steps=1 << 10):
     w["rw"] = np.ascontiguousarray(w["rw"][: max(hi - base, 1)])
     w["rw_flags"] = np.ascontiguousarray(w["rw_flags"][: len(w["rw"])])
     tables, steps = objects.evm_from_wire(w)
-    t = time.perf_counter()
-    out = flatten.flatten_evm(tables, steps)
-    dt = time.perf_counter() - t
-    cells = sum(int(v.size) // 4 for v in out.values() if hasattr(v, "dtype") and v.dtype == np.uint64)
-    return {"steps": n_steps, "cells": cells, "seconds": dt, "steps_per_s": n_steps / dt, "cells_per_s": cells / dt, "cores": 1,
-            "note": "per-cell Python (`x.expr().n` -> 4 x u64); a caller that keeps its witness in wire arrays (device-side assignment, "
-                    "zk_state_assign / zk_bytecode_assign / zk_copy_assign) never pays it"}
+    was, legs = flatten.USE_EXT, {}
+    try:
+        for name, use in (("extension", True), ("python_loops", False)):
+            if use and flatten._ext is None:
+                continue
+            flatten.USE_EXT = use
+            t = time.perf_counter()
+            out = flatten.flatten_evm(tables, steps)
+            dt = time.perf_counter() - t
+            cells = sum(int(v.size) // 4 for v in out.values() if hasattr(v, "dtype") and v.dtype == np.uint64)
+            legs[name] = {"seconds": dt, "steps_per_s": n_steps / dt, "cells_per_s": cells / dt}
+    finally:
+        flatten.USE_EXT = was
+    best = legs.get("extension") or legs["python_loops"]
+    return {"steps": n_steps, "cells": cells, "seconds": best["seconds"], "steps_per_s": best["steps_per_s"], "cells_per_s": best["cells_per_s"], "cores": 1,
+            "legs": legs,
+            "note": "the walk over the objects' attributes in C (zkevm_specs_amd/_flatten_ext, csrc/flatten_ext.c) + de-duplication / ordering on the "
+                    "packed rows in numpy; `python_loops` = the per-cell Python that defines the result (`x.expr().n` -> 4 x u64).  A caller that keeps "
+                    "its witness in wire arrays (device-side assignment, zk_state_assign / zk_bytecode_assign / zk_copy_assign) pays neither"}
 
 
 def block_oneshot(parts, to_dev, device=0, reps=8, copies=3, state_compact=False):

@@ -27,5 +27,9 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libzkevm_hip.so $OBJS
 if [ ! -f ../libzkevm_cpu.so ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name cpu_backend.cpp -o -name build.sh \) -newer ../libzkevm_cpu.so | head -1)" ]; then
     g++ -O2 -std=c++17 -fopenmp -DZK_HOSTSIM -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-array-bounds -o ../libzkevm_cpu.so cpu_backend.cpp -ldl
 fi
+# the marshalling helper of zkevm_specs_amd/flatten.py (CPython extension, host side only)
+if [ ! -f ../_flatten_ext.so ] || [ flatten_ext.c -nt ../_flatten_ext.so ]; then
+    gcc -O2 -shared -fPIC -Wall -I"$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')" -o ../_flatten_ext.so flatten_ext.c
+fi
 cat $OUT/*.log | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | paste - - - - - - | sed 's/remark: [^ ]* //g; s/\[-Rpass-analysis=kernel-resource-usage\]//g' > "$OUT/resource_usage.txt" || true
 echo "built $(ls -la ../libzkevm_hip.so)"

@@ -4,8 +4,74 @@ Duck-typed: works on the reference's own objects (`zkevm_specs.state_circuit.Row
 `MPTTableRow`, `StepState`, `RWTableRow`, ...) or on this package's mirrors — only attribute
 names are used, nothing is imported from the reference.
 """
+import os
+
 from .wire import FR_MODULUS, rows_to_colmajor, rows_to_rowmajor
 import numpy as np
+
+# The per-cell loops below define the results.  Where _flatten_ext.so is built (csrc/flatten_ext.c, by csrc/build.sh) the big
+# tables and the steps take the same walk in C — ~0.09 us per cell against ~1.2 us — and the de-duplication / ordering runs on the
+# packed rows in numpy; tests/test_flatten_ext.py holds the two paths equal, array for array.  ZK_FLATTEN_PY=1 keeps the loops.
+try:
+    from . import _flatten_ext as _ext
+except ImportError:  # not built (a source checkout before build()): the Python loops
+    _ext = None
+USE_EXT = _ext is not None and os.environ.get("ZK_FLATTEN_PY") != "1"
+_N, _LO, _HI, _INT, _BOOL = 0, 1, 2, 3, 4  # cell modes of _flatten_ext.pack
+
+
+def _spec(*cells):
+    """'a.b' -> FQ(int) of row.a.b; ('lo', 'a') / ('hi', 'a') -> the halves of a Word / WordOrValue / bare value; ('int', 'a'); ('bool', 'a')"""
+    out = []
+    for c in cells:
+        mode, path = (_N, c) if isinstance(c, str) else ({"lo": _LO, "hi": _HI, "int": _INT, "bool": _BOOL}[c[0]], c[1])
+        out.append((mode, tuple(int(t) if t.isdigit() else t for t in path.split("."))))
+    return tuple(out)
+
+
+def _pack(objs, cells, flags=()):
+    """-> (uint64[n, ncells, 4] row-major, uint32[n] flags) through _flatten_ext"""
+    objs = objs if isinstance(objs, (list, tuple)) else list(objs)
+    cb, fb = _ext.pack(objs, cells, flags)
+    return np.frombuffer(cb, dtype="<u8").reshape(len(objs), len(cells), 4), np.frombuffer(fb, dtype="<u4")
+
+
+def _dedup_rows(rows, flags=None):
+    """_dedup on packed rows: set semantics on the cells, the first occurrence's flags, ascending order of the cells as integers (the
+    order of sorted() over tuples of ints).  Rows are ranked by refining groups one 64-bit limb at a time, most significant first,
+    skipping limbs that are the same in every row, until every row stands alone (an RW table: after its rw_counter limb) or the limbs
+    run out (what still shares a group then is one row several times)."""
+    n, nc = rows.shape[:2]
+    if flags is None:
+        flags = np.zeros(n, dtype=np.uint32)
+    if n == 0:
+        return np.zeros((0, nc, 4), dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+    words = np.ascontiguousarray(rows).reshape(n, nc * 4)
+    varies = words.min(axis=0) != words.max(axis=0)
+    group, n_groups = np.zeros(n, dtype=np.int64), 1
+    for col in (4 * c + limb for c in range(nc) for limb in (3, 2, 1, 0)):
+        if n_groups == n:
+            break
+        if not varies[col]:
+            continue
+        v = np.ascontiguousarray(words[:, col])
+        idx = np.lexsort((v, group))  # by group, then by this limb
+        gs, vs = group[idx], v[idx]
+        starts = np.empty(n, dtype=bool)
+        starts[0] = True
+        np.not_equal(gs[1:], gs[:-1], out=starts[1:])
+        starts[1:] |= vs[1:] != vs[:-1]
+        ranks = np.cumsum(starts) - 1
+        group = np.empty(n, dtype=np.int64)
+        group[idx] = ranks
+        n_groups = int(ranks[-1]) + 1
+    idx = np.argsort(group, kind="stable")  # ascending rank; inside a group (duplicates) the original order: its first row is kept
+    gs = group[idx]
+    keep = np.empty(n, dtype=bool)
+    keep[0] = True
+    np.not_equal(gs[1:], gs[:-1], out=keep[1:])
+    first = idx[keep]
+    return rows[first].view(np.uint64), flags[first].astype(np.uint32, copy=False)  # (fancy indexing: fresh, contiguous arrays)
 
 
 def _n(x):
@@ -39,7 +105,16 @@ def state_row_cells(row):
     return cells, flags
 
 
+_STATE_SPEC = _spec("rw_counter", "is_write", "keys.0", "keys.1", "keys.2", "keys.3", "keys.4.lo", "keys.4.hi", *[f"key2_limbs.{k}" for k in range(10)],
+                    *[f"key45_bytes.{k}" for k in range(32)], "value.lo", "value.hi", "initial_value.lo", "initial_value.hi", "root.lo", "root.hi",
+                    "lexicographic_ordering_selector")
+_STATE_FLAGS = ((1, 0, ("value",)), (2, 0, ("initial_value",)))
+
+
 def flatten_state_rows(rows):
+    if USE_EXT:
+        cells, flags = _pack(rows, _STATE_SPEC, _STATE_FLAGS)
+        return np.ascontiguousarray(cells.transpose(1, 0, 2)), flags.astype(np.uint32)
     cf = [state_row_cells(r) for r in rows]
     cols = rows_to_colmajor([c for c, _ in cf], STATE_NCELLS)
     flags = np.array([f for _, f in cf], dtype=np.uint32)
@@ -80,8 +155,14 @@ def step_cells(s):
             _n(s.memory_word_size), _n(s.reversible_write_counter), _n(s.log_id)]
 
 
+_STEP_SPEC = _spec(("int", "execution_state"), "rw_counter", "call_id", ("bool", "is_root"), ("bool", "is_create"), "code_hash.lo", "code_hash.hi",
+                   "program_counter", "stack_pointer", "gas_left", "memory_word_size", "reversible_write_counter", "log_id")
+
+
 def flatten_steps(steps):
     """row-major uint64[n_steps, 13, 4] (see include/zkevm_hip.h: the EVM kernel gathers steps)"""
+    if USE_EXT:
+        return _pack(steps, _STEP_SPEC)[0].copy()
     return rows_to_rowmajor([step_cells(s) for s in steps], STEP_NCELLS)
 
 
@@ -113,18 +194,37 @@ def _iter_table(t):
     return list(t)
 
 
+_RW_SPEC = _spec("rw_counter", "rw", "key0", "id", "address", "field_tag", "storage_key.lo", "storage_key.hi", ("lo", "value"), ("hi", "value"),
+                 ("lo", "value_prev"), ("hi", "value_prev"), "aux0.lo", "aux0.hi")
+_RW_FLAGS = ((1, 1, ("value",)), (2, 1, ("value_prev",)))
+
+
 def flatten_rw_table(rw_table):
+    if USE_EXT:
+        return _dedup_rows(*_pack(_iter_table(rw_table), _RW_SPEC, _RW_FLAGS))
     rows, flags = _dedup([rw_row_cells(r) for r in _iter_table(rw_table)])
     return rows_to_rowmajor(rows, RW_NCELLS), np.array(flags, dtype=np.uint32)
 
 
+_BYTECODE_SPEC = _spec("bytecode_hash.lo", "bytecode_hash.hi", "field_tag", "index", "is_code", "value")
+
+
 def flatten_bytecode_table(bytecode_table):
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(bytecode_table), _BYTECODE_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.bytecode_hash.lo), _n(r.bytecode_hash.hi), _n(r.field_tag), _n(r.index),
                         _n(r.is_code), _n(r.value)], 0) for r in _iter_table(bytecode_table)])
     return rows_to_rowmajor(rows, BYTECODE_NCELLS)
 
 
+_TX_SPEC = _spec("tx_id", "field_tag", "call_data_index_or_zero", ("lo", "value"), ("hi", "value"))
+_BLOCK_SPEC = _spec("field_tag", "block_number_or_zero", ("lo", "value"), ("hi", "value"))
+_VALUE_FLAG = ((1, 1, ("value",)),)
+
+
 def flatten_tx_table(tx_table):
+    if USE_EXT:
+        return _dedup_rows(*_pack(_iter_table(tx_table), _TX_SPEC, _VALUE_FLAG))
     pairs = []
     for r in _iter_table(tx_table):
         lo, hi, w = _word_cells(r.value)
@@ -134,6 +234,8 @@ def flatten_tx_table(tx_table):
 
 
 def flatten_block_table(block_table):
+    if USE_EXT:
+        return _dedup_rows(*_pack(_iter_table(block_table), _BLOCK_SPEC, _VALUE_FLAG))
     pairs = []
     for r in _iter_table(block_table):
         lo, hi, w = _word_cells(r.value)
@@ -145,9 +247,17 @@ def flatten_block_table(block_table):
 COPY_T_NCELLS, KECCAK_T_NCELLS, EXP_T_NCELLS = 14, 5, 11
 
 
+_COPY_T_SPEC = _spec("is_first", "src_id.lo", "src_id.hi", "src_tag", "dst_id.lo", "dst_id.hi", "dst_tag", "src_addr", "src_addr_end", "dst_addr",
+                     "length", "rlc_acc", "rw_counter", "rwc_inc")
+_EXP_T_SPEC = _spec("is_step", "identifier", "is_last", "base_limb0", "base_limb1", "base_limb2", "base_limb3", "exponent.lo", "exponent.hi",
+                    "exponentiation.lo", "exponentiation.hi")
+
+
 def flatten_copy_table(copy_table):
     """set of CopyTableRow (evm_circuit/table.py:494-507) -> uint64[m, 14, 4]; ids match on their
     lo/hi cells only (TableRow.match, table.py:389-401), so no type bits travel"""
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(copy_table), _COPY_T_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.is_first), _n(r.src_id.lo), _n(r.src_id.hi), _n(r.src_tag), _n(r.dst_id.lo), _n(r.dst_id.hi),
                         _n(r.dst_tag), _n(r.src_addr), _n(r.src_addr_end), _n(r.dst_addr), _n(r.length), _n(r.rlc_acc),
                         _n(r.rw_counter), _n(r.rwc_inc)], 0) for r in _iter_table(copy_table)])
@@ -156,6 +266,8 @@ def flatten_copy_table(copy_table):
 
 def flatten_exp_table(exp_table):
     """set of ExpTableRow (evm_circuit/table.py:538-548) -> uint64[m, 11, 4]"""
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(exp_table), _EXP_T_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.is_step), _n(r.identifier), _n(r.is_last), _n(r.base_limb0), _n(r.base_limb1),
                         _n(r.base_limb2), _n(r.base_limb3), _n(r.exponent.lo), _n(r.exponent.hi),
                         _n(r.exponentiation.lo), _n(r.exponentiation.hi)], 0) for r in _iter_table(exp_table)])
@@ -233,9 +345,16 @@ SIG_NCELLS = 9
 ECC_NCELLS = 13
 
 
+_SIG_T_SPEC = _spec("msg_hash.lo", "msg_hash.hi", "sig_v", "sig_r.lo", "sig_r.hi", "sig_s.lo", "sig_s.hi", "recovered_addr", "is_valid")
+_ECC_T_SPEC = _spec("op_type", "px.lo", "px.hi", "py.lo", "py.hi", "qx.lo", "qx.hi", "qy.lo", "qy.hi", "input_rlc", "out_x", "out_y", "is_valid")
+_WITHDRAWAL_SPEC = _spec("id", "validator_id", "address", "amount")
+
+
 def flatten_sig_table(sig_table):
     """set of SigTableRow (evm_circuit/table.py:552-558) -> uint64[m, 9, 4]: msg_hash lo/hi, sig_v, sig_r lo/hi, sig_s lo/hi,
     recovered_addr, is_valid"""
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(sig_table), _SIG_T_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.msg_hash.lo), _n(r.msg_hash.hi), _n(r.sig_v), _n(r.sig_r.lo), _n(r.sig_r.hi), _n(r.sig_s.lo),
                         _n(r.sig_s.hi), _n(r.recovered_addr), _n(r.is_valid)], 0) for r in _iter_table(sig_table)])
     return rows_to_rowmajor(rows, SIG_NCELLS)
@@ -244,6 +363,8 @@ def flatten_sig_table(sig_table):
 def flatten_ecc_table(ecc_table):
     """set of EccTableRow (evm_circuit/table.py:562-575) -> uint64[m, 13, 4]: op_type, px lo/hi, py lo/hi, qx lo/hi, qy lo/hi,
     input_rlc, out_x, out_y, is_valid"""
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(ecc_table), _ECC_T_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.op_type), _n(r.px.lo), _n(r.px.hi), _n(r.py.lo), _n(r.py.hi), _n(r.qx.lo), _n(r.qx.hi),
                         _n(r.qy.lo), _n(r.qy.hi), _n(r.input_rlc), _n(r.out_x), _n(r.out_y), _n(r.is_valid)], 0)
                       for r in _iter_table(ecc_table)])
@@ -253,6 +374,8 @@ def flatten_ecc_table(ecc_table):
 def flatten_withdrawal_table(withdrawal_table):
     """set of WithdrawalTableRow (evm_circuit/table.py:430-434: id, validator_id, address, amount) -> uint64[m, 4, 4],
     sorted by the cells (id first), which is the order end_block.py:152 walks them in"""
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(withdrawal_table), _WITHDRAWAL_SPEC)[0])[0]
     rows, _ = _dedup([([_n(r.id), _n(r.validator_id), _n(r.address), _n(r.amount)], 0) for r in _iter_table(withdrawal_table)])
     return rows_to_rowmajor(rows, 4)
 
@@ -293,11 +416,16 @@ def flatten_bytecode_rows(rows):
     return rows_to_colmajor(cells, BYTECODE_ROW_NCELLS)
 
 
+_KECCAK_T_SPEC = _spec("state_tag", "input_rlc", "input_len", "output.lo", "output.hi")
+
+
 def flatten_keccak_table(keccak_table):
     """set of KeccakTableRow (evm_circuit/table.py:511-515) -> uint64[m, 5, 4]; rows already in wire
     form (e.g. from engine.keccak_table) pass through"""
     if isinstance(keccak_table, np.ndarray):
         return np.ascontiguousarray(keccak_table, dtype=np.uint64).reshape(-1, KECCAK_NCELLS, 4)
+    if USE_EXT:
+        return _dedup_rows(_pack(_iter_table(keccak_table), _KECCAK_T_SPEC)[0])[0]
     rows = sorted(set((_n(k.state_tag), _n(k.input_rlc), _n(k.input_len), _n(k.output.lo), _n(k.output.hi))
                       for k in _iter_table(keccak_table)))
     return rows_to_rowmajor([list(r) for r in rows], KECCAK_NCELLS)
