@@ -203,9 +203,6 @@ __global__ __launch_bounds__(1024) void rwk_pack64_kernel(RekeyArgs a, u32* stat
 #define RWK_DESC_LOCAL (1u << 30)
 #define RWK_DESC_INCL (2u << 30)
 #define RWK_DESC_VAL 0x3fffffffu
-#define RWK_SW_BLOCK 1024
-#define RWK_SW_ITEMS 8
-#define RWK_SW_TILE (RWK_SW_BLOCK * RWK_SW_ITEMS)
 __global__ __launch_bounds__(RWK_SW_BLOCK) void rwk_sweep_kernel(RekeyArgs a, const u64* in_key, const u32* in_idx, u64* out_key, u32* out_idx, u32 pass) {
     __shared__ u32 s_cnt[RWK_SW_BLOCK / 64][256];
     __shared__ u32 s_scan[256], s_texcl[256], s_gbase[256];

@@ -176,6 +176,12 @@ struct RekeyArgs {
     u32* sweep;           // zeroed per launch: ghist [8][256], ticket [8], error flag [8], then desc [n_passes][ntiles_fast][256]
 };
 #define RWK_SWEEP_HEAD (8 * 256 + 16)
+// one sweep tile = one 1024-thread block over RWK_SW_ITEMS keys per thread
+#define RWK_SW_BLOCK 1024
+#ifndef RWK_SW_ITEMS
+#define RWK_SW_ITEMS 8
+#endif
+#define RWK_SW_TILE (RWK_SW_BLOCK * RWK_SW_ITEMS)
 
 // Append `nbits` (<= 32) to the MSB-first bit stream (acc: pending bits right-aligned, cnt of them); full 32-bit words go to
 // out[w * stride] (w counts up).

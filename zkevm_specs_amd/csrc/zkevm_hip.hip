@@ -1545,7 +1545,7 @@ static int rekey_setup(zk_session* s, const uint64_t* rw, const uint32_t* rw_fla
         const bool no_fast = e && e[0] == '1';
         a.fast = (!no_fast && a.key_words <= 2 && a.n_passes <= 8 && n < (1ull << 30)) ? 1u : 0u;
     }
-    a.ntiles_fast = (u32)((n + 8191) / 8192);  // k_rekey.hip RWK_SW_TILE
+    a.ntiles_fast = (u32)((n + RWK_SW_TILE - 1) / RWK_SW_TILE);
     if ((rc = dev_alloc(s, (void**)&a.idx_a, (size_t)n * 4))) return rc;
     if ((rc = dev_alloc(s, (void**)&a.idx_b, (size_t)n * 4))) return rc;
     if (a.fast) {
