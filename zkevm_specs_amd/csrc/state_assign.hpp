@@ -56,30 +56,36 @@ struct AssignArgs {
 
 // Slot s of op i when the ops are the re-keyed rows of an RW table (the mapping of rwk_key / rwk_op, one slot at a time: `s` is a
 // compile-time constant at every call site, so only that slot's cells are loaded).
-ZK_HD Fr asg_slot_rw(const AssignArgs& a, u32 s, u64 i) {
-    if (i == 0) return s == ASG_TAG ? fr_from_u64(1) : fr_zero();  // StartOp (rwk_emit_start)
-    const u64* p = a.rw + (u64)a.order[i - 1] * (RWK_RW_NCELLS * 4);
-    if (s == ASG_RWC) return rwk_cell(p, 0);
-    if (s == ASG_RW) return rwk_cell(p, 1);
-    if (s == ASG_VLO) return rwk_cell(p, 8);
-    if (s == ASG_VHI) return rwk_cell(p, 9);
+// (`cell(k)`: cell k of the RW row — read from memory one at a time here, from registers where a whole row was loaded in one batch,
+// state_fused.hpp)
+template <class CELL>
+ZK_HD Fr asg_slot_of_rw_row(CELL cell, u32 s) {
+    if (s == ASG_RWC) return cell(0);
+    if (s == ASG_RW) return cell(1);
+    if (s == ASG_VLO) return cell(8);
+    if (s == ASG_VHI) return cell(9);
     if (s == ASG_LEX) return fr_from_u64(1);
-    const u32 tag = rwk_tag_of_target(rwk_cell(p, 2).v[0]);  // (rows in `order` hold one of Target's values)
+    const u32 tag = rwk_tag_of_target(cell(2).v[0]);  // (rows in `order` hold one of Target's values)
     if (s == ASG_TAG) return fr_from_u64(tag);
-    if (s == ASG_ID) return tag == 6u ? fr_zero() : rwk_cell(p, 3);
-    if (s == ASG_ILO) return (tag == 4u || tag == 6u) ? rwk_cell(p, 12) : fr_zero();
-    if (s == ASG_IHI) return (tag == 4u || tag == 6u) ? rwk_cell(p, 13) : fr_zero();
+    if (s == ASG_ID) return tag == 6u ? fr_zero() : cell(3);
+    if (s == ASG_ILO) return (tag == 4u || tag == 6u) ? cell(12) : fr_zero();
+    if (s == ASG_IHI) return (tag == 4u || tag == 6u) ? cell(13) : fr_zero();
     if (s == ASG_KEY && tag != 10u) {
-        Fr key = rwk_cell(p, 6);
-        const Fr khi = rwk_cell(p, 7);
+        Fr key = cell(6);
+        const Fr khi = cell(7);
         key.v[4] |= khi.v[0]; key.v[5] |= khi.v[1]; key.v[6] |= khi.v[2]; key.v[7] |= khi.v[3];
         return key;
     }
-    if (s == ASG_FT && tag != 5u && tag != 10u) return rwk_cell(p, 5);
-    const Fr c4 = rwk_cell(p, 4);
+    if (s == ASG_FT && tag != 5u && tag != 10u) return cell(5);
+    const Fr c4 = cell(4);
     if (s == ASG_ADDR) return tag == 5u ? fr_zero() : (tag == 10u ? rwk_shr(c4, 48) : c4);
     if (s == ASG_FT) return tag == 5u ? c4 : fr_from_u64((u64)(c4.v[1] & 0xffffu));
     return fr_from_u64((u64)c4.v[0]);  // ASG_KEY of a TxLog row
+}
+ZK_HD Fr asg_slot_rw(const AssignArgs& a, u32 s, u64 i) {
+    if (i == 0) return s == ASG_TAG ? fr_from_u64(1) : fr_zero();  // StartOp (rwk_emit_start)
+    const u64* p = a.rw + (u64)a.order[i - 1] * (RWK_RW_NCELLS * 4);
+    return asg_slot_of_rw_row([p](int k) { return rwk_cell(p, k); }, s);
 }
 // RW: the ops are the re-keyed rows of an RW table (a compile-time switch: the device has one instantiation of every assignment
 // kernel per source, so the op-list form pays nothing for the other one — a run-time branch cost assign_rows_kernel 14 VGPRs, +13 %)
