@@ -232,6 +232,14 @@ def test_warm_gadget_trace_all_pairs_vs_oracle():
         res, status = _run(w, state_sort=sort)
         assert status == exp, sort
         _check_tally(res, exp)
+    # the one-shot C entry with the session's own status buffer: the lazy tail (round 6) — zk_launch enqueues the hot build alone, the warm /
+    # cold builds follow once the open's scatter has told the host that their lane ranges are not empty (both are not, in this trace)
+    from zkevm_specs_amd import oneshot
+
+    for _ in range(3):
+        res, status = oneshot.evm_verify(w)
+        assert status.tolist() == exp
+        _check_tally(res, exp)
     # ZK_OPT_SIDE_STREAM (what SuperCircuit opens its EVM session with): warm / cold launches forked to the device's side stream,
     # joined before anything later on the session's stream; three passes, the third into a caller buffer read after a plain sync
     with engine.open_evm(dict(w), side_stream=True) as s:
@@ -244,6 +252,28 @@ def test_warm_gadget_trace_all_pairs_vs_oracle():
         torch.cuda.synchronize()
         assert buf.cpu().numpy().view(np.uint32).tolist() == exp
         _check_tally(s.collect(), exp)
+
+
+def test_oneshot_lazy_tail_with_empty_warm_and_cold_ranges():
+    """BASELINE config 3's opcode mix has no warm / cold states: the one-shot entry then launches neither build (zk_launch's lazy tail).
+    Statuses and tally against the oracle on a tampered 2^12-step trace, and against the resident session, which launches both."""
+    from zkevm_specs_amd import oneshot
+
+    n = 1 << 12
+    w = synth_evm_trace(n, seed=11)
+    w = {k: v for k, v in w.items() if k != "meta"}
+    rng = random.Random(5)
+    for _ in range(40):
+        w = fuzz_wire(w, rng, copy=False)
+    exp = oracle_status(w)
+    assert sum(1 for c in exp if c) >= 20
+    res0, status0 = _run(w)
+    assert status0 == exp
+    for _ in range(3):
+        res, status = oneshot.evm_verify(w)
+        assert status.tolist() == exp
+        _check_tally(res, exp)
+        assert (res.fail_count, res.first_fail_row, res.first_fail_code) == (res0.fail_count, res0.first_fail_row, res0.first_fail_code)
 
 
 def test_caller_status_buffer_is_final_after_a_stream_sync():

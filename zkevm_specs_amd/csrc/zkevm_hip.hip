@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include <mutex>
 #include <dlfcn.h>
 
@@ -220,7 +221,10 @@ struct EvmSortArgs {  // one pass of the counting sort (evm_build_perm); also ri
     u32* perm;
     ZkTally* tally;
     u32* defer_count;  // reset with the tally
+    u32* early_host;   // the session's page-locked block (device alias), words EVM_EARLY_WORD..: warm lanes, cold lanes, sequence number
+    u32 early_seq;     // (nullptr / 0: nobody is waiting for the lane ranges)
 };
+#define EVM_EARLY_WORD 36u  // behind the result block (32 words) and its flag word
 __device__ __forceinline__ void evm_state_hist_body(u32 vblock, const u64* steps, u32 n_pairs, u32* hist, u32* taken, uint16_t* bin16, ZkTally* tally,
                                                     u32* defer_count) {
     __shared__ u32 local[EVM_N_BINS];
@@ -256,10 +260,11 @@ __global__ void evm_state_hist_kernel(const u64* steps, u32 n_pairs, u32* hist, 
 // boundary wavefronts (STOP + ADDMOD, MEMORY + SSTORE: 190k cycles against a 118k median) were the last to leave the kernel.
 // (block size: at least EVM_N_BINS threads)
 __device__ __forceinline__ void evm_state_scatter_body(u32 vblock, const uint16_t* bin16, u32 n_pairs, const u32* hist, u32* hist_next,
-                                                       u32* taken, u32* group_start, u32* perm) {
+                                                       u32* taken, u32* group_start, u32* perm, u32* early_host = nullptr, u32 early_seq = 0u) {
     __shared__ u32 sa[EVM_N_BINS], sb[EVM_N_BINS];
     __shared__ u32 local[EVM_N_BINS];
     __shared__ u32 base[EVM_N_BINS];
+    __shared__ u32 gsh[EVM_N_GROUPS + 1];
     const u32 k = threadIdx.x;
     u32 c = 0, c_real = 0;
     if (k < EVM_N_BINS) {
@@ -281,8 +286,8 @@ __device__ __forceinline__ void evm_state_scatter_body(u32 vblock, const uint16_
     if (k < EVM_N_BINS) {
         excl = src[k] - c;
         if (vblock == 0) {
-            if ((k & 127u) == 0) group_start[k >> 7] = excl;
-            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = src[k];
+            if ((k & 127u) == 0) group_start[k >> 7] = gsh[k >> 7] = excl;
+            if (k == EVM_N_BINS - 1) group_start[EVM_N_GROUPS] = gsh[EVM_N_GROUPS] = src[k];
             for (u32 j = c_real; j < c; j++) perm[excl + j] = EVM_NO_PAIR;
         }
     }
@@ -293,6 +298,15 @@ __device__ __forceinline__ void evm_state_scatter_body(u32 vblock, const uint16_
         rank = atomicAdd(&local[bin], 1u);
     }
     __syncthreads();
+    if (vblock == 0 && k == 0 && early_host) {
+        // The host learns how many warm / cold lanes this witness has while the evaluation kernels are still queued behind this launch
+        // (zk_launch's lazy tail: an empty range is then never launched).  Two words + a sequence number into the session's page-locked
+        // block, from the first block of a short launch: nothing waits for it but the end of this kernel.
+        __hip_atomic_store(&early_host[EVM_EARLY_WORD], gsh[EVM_GROUP_WARM + 1] - gsh[EVM_GROUP_WARM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&early_host[EVM_EARLY_WORD + 1], gsh[EVM_GROUP_COLD + 1] - gsh[EVM_GROUP_COLD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&early_host[EVM_EARLY_WORD + 2], early_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (k < EVM_N_BINS && local[k]) base[k] = excl + atomicAdd(&taken[k], local[k]);
     __syncthreads();
     if (i < n_pairs) perm[base[bin] + rank] = i;
@@ -490,7 +504,8 @@ __global__ __launch_bounds__(256) void evm_open_phase1_kernel(EvmOpenTables o) {
 #define EVM_OPEN_P2_BLOCK 1024u  // the scatter scans EVM_N_BINS bins with one thread each
 __global__ __launch_bounds__(1024) void evm_open_phase2_kernel(EvmOpenTables o, u32 scatter_blocks, u32 dir_blocks, u32 force_generic) {
     if (blockIdx.x < scatter_blocks) {  // the first pass's state-sorted permutation
-        evm_state_scatter_body(blockIdx.x, o.sort.bin16, o.sort.n_pairs, o.sort.hist, o.sort.hist_next, o.sort.taken, o.sort.group_start, o.sort.perm);
+        evm_state_scatter_body(blockIdx.x, o.sort.bin16, o.sort.n_pairs, o.sort.hist, o.sort.hist_next, o.sort.taken, o.sort.group_start, o.sort.perm,
+                               o.sort.early_host, o.sort.early_seq);
         return;
     }
     const u32 b = blockIdx.x - scatter_blocks;
@@ -607,6 +622,15 @@ struct zk_session {
     void* d_result = nullptr;
     void* h_result = nullptr;
     u32 publish_seq = 0;        // ZK_POLL_RESULT: sequence number of the last evm_publish_kernel (the flag word behind the block)
+    u32* h_result_dev = nullptr;  // the device alias of h_result (queried once, at open)
+    // Lazy tail (one-shot sessions): the open's scatter writes the warm / cold lane counts into the page-locked block (sequence number
+    // early_seq); zk_launch enqueues the hot build only, and whoever consumes the pass first (evm_enqueue_tail) enqueues the builds whose
+    // range is not empty — the host has the counts long before the hot kernel ends, so nothing waits and an empty build is never launched.
+    u32 early_seq = 0;          // 0 = the open did not arm it
+    bool tail_pending = false;
+    u32 tail_cold_grid = 0;
+    u32* tail_status = nullptr;
+    hipEvent_t tail_e1 = nullptr;  // the pass's stop event (rides on the hot dispatch; moved to the last tail dispatch if there is one)
     bool stream_drained = false;  // the host has seen the stream's last kernel finish without a hipStreamSynchronize (zk_close may skip its own)
 };
 
@@ -682,6 +706,14 @@ static void arena_give(int device, void* p, int cls) {
     (void)hipFree(p);
 }
 #define ZK_PINNED_BYTES 256
+static bool evm_poll_enabled() {
+    static const bool poll = [] { const char* e = getenv("ZK_POLL_RESULT"); return !(e && e[0] == '0'); }();  // default on (round 5: step 0.179 -> 0.174 ms)
+    return poll;
+}
+static bool evm_lazy_tail_enabled() {  // ZK_LAZY_TAIL=0: every one-shot pass launches the warm and cold builds, empty or not (as until round 6)
+    static const bool lazy = [] { const char* e = getenv("ZK_LAZY_TAIL"); return !(e && e[0] == '0'); }();
+    return lazy && evm_poll_enabled();
+}
 static int arena_pinned(int device, void** p) {
     {
         DevArena& A = g_arena[device];
@@ -972,6 +1004,11 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
         EvmDyn* dyn = &rb->dyn;
         s->d_result = rb;
         if ((rc = arena_pinned(s->device, &s->h_result))) goto fail;
+        {
+            void* hd = nullptr;
+            if (hipHostGetDevicePointer(&hd, s->h_result, 0) == hipSuccess) s->h_result_dev = (u32*)hd;
+            (void)hipGetLastError();
+        }
         static_assert(sizeof(EvmResultBlock) <= 256, "the result block outgrew its slot");
         static_assert((EVM_N_BINS * sizeof(u32)) % 16 == 0, "zero region pieces are 16-byte multiples");
         s->d_hist = (u32*)(zero + dyn_bytes);
@@ -1056,6 +1093,15 @@ extern "C" int zk_evm_open(const zk_evm_tables* t, uint32_t opts, zk_session** o
             o.sort.taken = s->d_cursor; o.sort.bin16 = s->d_bin16; o.sort.group_start = s->d_group_start; o.sort.perm = s->d_perm;
             o.sort.tally = s->d_tally;
             o.sort.defer_count = E.defer_count;
+            if ((opts & ZK_OPT_SINGLE_PASS) && s->h_result_dev && evm_lazy_tail_enabled() && !(opts & ZK_OPT_SIDE_STREAM)) {
+                static std::atomic<u32> g_early_seq{0};
+                u32 q = ++g_early_seq;
+                if (!q) q = ++g_early_seq;  // never 0
+                __atomic_store_n(&((u32*)s->h_result)[EVM_EARLY_WORD + 2], 0u, __ATOMIC_RELEASE);
+                s->early_seq = q;
+                o.sort.early_host = s->h_result_dev;
+                o.sort.early_seq = q;
+            }
             hist_blocks = (E.n_pairs + 255u) / 256u;
             scatter_blocks = (E.n_pairs + EVM_OPEN_P2_BLOCK - 1u) / EVM_OPEN_P2_BLOCK;
             s->evm_pass = 1;        // the next pass's histogram is d_hist2 (cleared by this scatter)
@@ -2276,10 +2322,45 @@ extern "C" int zk_debug_calib_gather(uint64_t nbytes, uint32_t lane_bytes, float
     return 0;
 }
 
+// The lazy tail of a one-shot EVM pass (zk_session::early_seq): wait for the lane counts the open's scatter published — they arrive
+// while the hot kernel is still queued or running —, then enqueue the warm / cold builds whose range is not empty, the warm one sized
+// to its range.  Called by everything that consumes or follows a pass (zk_collect, zk_read_status, the next zk_launch).
+static int evm_enqueue_tail(zk_session* s) {
+    if (s->kind != SESSION_EVM || !s->tail_pending) return 0;
+    s->tail_pending = false;
+    s->stream_drained = false;
+    const u32* hw = (const u32*)s->h_result;
+    const auto t0 = std::chrono::steady_clock::now();
+    u64 spins = 0;
+    bool seen = true;
+    while (__atomic_load_n(&hw[EVM_EARLY_WORD + 2], __ATOMIC_ACQUIRE) != s->early_seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { seen = false; break; }  // never expected
+    }
+    u32 warm_lanes = 0;
+    bool run_warm = true, run_cold = true;
+    if (seen) {
+        warm_lanes = hw[EVM_EARLY_WORD];
+        const u32 cold_lanes = hw[EVM_EARLY_WORD + 1];
+        run_warm = warm_lanes != 0;
+        run_cold = cold_lanes != 0;
+        s->evm_ranges_known = 1;  // what a collect's read of group_start would have said
+        s->evm_warm_empty = !run_warm;
+        s->evm_warm_lanes = warm_lanes;
+        s->evm_cold_empty = !run_cold;
+    }
+    s->early_seq = 0;
+    if (run_warm) zk_launch_evm_warm(s->stream, s->tail_cold_grid, warm_lanes, s->evm, s->d_group_start, s->tail_status, s->d_tally, run_cold ? nullptr : s->tail_e1);
+    if (run_cold) zk_launch_evm_cold(s->stream, s->tail_cold_grid, s->evm, s->d_group_start, s->tail_status, s->d_tally, s->tail_e1);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ARG_TRY(s, "zk_launch: null session");
     s->stream_drained = false;
     HIP_TRY(hipSetDevice(s->device));
+    { int trc = evm_enqueue_tail(s); if (trc) return trc; }  // (a pass launched twice without a collect in between)
     s->status_external = status_dev != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = s->launches < (u32)MAX_EVENT_PAIRS;
@@ -2382,6 +2463,16 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
             }
             break;
         }
+        if (sorted && !s->evm_ranges_known && s->early_seq && !status_dev && evm_ext_events) {
+            // lazy tail: the hot build alone (it carries both events); the warm / cold builds follow from evm_enqueue_tail once the
+            // open's scatter has told the host which of their ranges are not empty
+            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, e0, e1);
+            s->tail_pending = true;
+            s->tail_cold_grid = cold_grid;
+            s->tail_status = status;
+            s->tail_e1 = e1;
+            break;
+        }
         hipEvent_t e_hot1 = (evm_ext_events && !run_warm && !run_cold) ? e1 : nullptr;  // the hot dispatch carries both events then
         zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr, e_hot1);
         if (run_warm)
@@ -2410,6 +2501,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
 // first (zk_collect, zk_read_status) looks at the count and, if there are such pairs, runs the general build over them before
 // answering.  A well-formed witness costs one extra 4-byte read, in the same synchronisation as the tally.
 static int evm_finish_deferred(zk_session* s) {
+    { int trc = evm_enqueue_tail(s); if (trc) return trc; }
     if (s->kind != SESSION_EVM || !s->deferred_pending || !s->evm.defer_count) return 0;
     u32 n_def = 0;
     HIP_TRY(hipMemcpyAsync(&n_def, s->evm.defer_count, 4, hipMemcpyDeviceToHost, s->stream));
@@ -2426,6 +2518,7 @@ static int evm_finish_deferred(zk_session* s) {
 extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ARG_TRY(s && r, "zk_collect: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
+    { int trc = evm_enqueue_tail(s); if (trc) return trc; }
     ZkTally t;
     u32 n_def = 0;
     const bool check_deferred = s->kind == SESSION_EVM && s->deferred_pending && s->evm.defer_count;
@@ -2436,13 +2529,13 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
         // polled (default), or one copy dispatch + one wait.  (Having the pass's last block write the block to the host itself — system-
         // scope stores + fence from inside the cold launch — was measured in round 4: pass 76 -> 90 us.  The separate one-wavefront
         // kernel costs the evaluation launches nothing and saves the runtime's completion-signal path: step 0.179 -> 0.174 ms.)
-        static const bool poll = [] { const char* e = getenv("ZK_POLL_RESULT"); return !(e && e[0] == '0'); }();  // default on (round 5: step 0.179 -> 0.174 ms)
+        const bool poll = evm_poll_enabled();
         bool polled = false;
         if (poll) {
-            static_assert(sizeof(EvmResultBlock) == 128 && ZK_PINNED_BYTES >= 132, "flag word behind the result block");
+            static_assert(sizeof(EvmResultBlock) == 128 && ZK_PINNED_BYTES >= 4 * (EVM_EARLY_WORD + 3), "flag word behind the result block, early words behind that");
             u32* hw = (u32*)s->h_result;
-            void* hd = nullptr;
-            if (hipHostGetDevicePointer(&hd, s->h_result, 0) == hipSuccess && hd) {
+            void* const hd = s->h_result_dev;
+            if (hd) {
                 const u32 seq = ++s->publish_seq ? s->publish_seq : ++s->publish_seq;  // never 0
                 __atomic_store_n(&hw[32], 0u, __ATOMIC_RELEASE);
                 hipLaunchKernelGGL(evm_publish_kernel, dim3(1), dim3(64), 0, s->stream, (const u32*)s->d_result, (u32*)hd, seq);
