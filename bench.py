@@ -391,6 +391,7 @@ def build_tx(ctx, log_rows, strong):
     return w
 
 
+STATE_FUSED = False  # --state-fused: the super workload's State rows evaluated where they are computed, from the block's RW table (no State witness in HBM)
 STATE_COMPACT = False  # --state-compact: the super workload's State rows without their limb / byte columns (ZK_OPT_STATE_COMPACT)
 
 
@@ -409,13 +410,15 @@ def build_super(ctx, log_rows, strong):
     else:
         parts = synth_super_block(log_rows, seed=5 + ctx.rank)
         w.env = {"parts": parts}
-        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, state_compact=STATE_COMPACT)
+        w.sess = SuperCircuit(parts, device=ctx.local_rank, to_device=ctx.to_dev, state_compact=STATE_COMPACT, state_fused=STATE_FUSED)
     sess = w.sess
     w.units = sum(sess.rows.values())
     if not strong:
         w.row_offset, w.total_units = ctx.rank * w.units, w.units * ctx.world
     frac = {k: sess.rows[k] / max(sess.global_rows[k], 1) for k in sess.rows}
-    w.super_bytes = {"evm": parts["meta"]["algorithmic_bytes"] * frac["evm"], "state": sess.rows["state"] * (15 if STATE_COMPACT else 57) * 32,
+    fused = bool(getattr(sess, "state_fused", False))
+    # (fused: what the State pass reads is the op's 14-cell RW row, through the sorted order)
+    w.super_bytes = {"evm": parts["meta"]["algorithmic_bytes"] * frac["evm"], "state": sess.rows["state"] * (14 if fused else 15 if STATE_COMPACT else 57) * 32,
                      "bytecode": sess.rows["bytecode"] * 12 * 32, "tx": sess.rows["tx"] * TX_UNIT_BYTES,
                      "copy": sess.rows.get("copy", 0) * (20 + 14) * 32, "exp": sess.rows.get("exp", 0) * 21 * 32}
     w.workload = (f"Super circuit, ~2^{log_rows} rows {'in total' if strong else 'per GPU'} over ONE consistent witness (BASELINE configs[4]; State rows = "
@@ -425,6 +428,11 @@ def build_super(ctx, log_rows, strong):
     if strong:
         w.extra_cfg["rows_total"] = dict(sess.global_rows)
     w.profile_key = ("super", log_rows)
+    if fused:
+        w.workload += ("; STATE ROWS FUSED (zk_state_verify_from_rw_open): no State witness in HBM — the State session evaluates op2row's rows in the "
+                       "registers it computes them in, from the block's RW table through the sorted order it keeps after its first pass")
+        w.extra_cfg["state_fused"] = 1
+        w.profile_key = ("super_fused", log_rows)
     if STATE_COMPACT:
         w.workload += ("; STATE ROWS COMPACT (ZK_OPT_STATE_COMPACT): 15 of the State row's 57 cells are stored — the ten address limbs and 32 key "
                        "bytes are derived from the address / key cells where the checks use them, not assigned and read back")
@@ -782,6 +790,7 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="EVM one-shot line: take roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of live_pmc_traffic: one-shot steps only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--state-fused", action="store_true", help="super: State rows evaluated from the RW table where they are computed (zk_state_verify_from_rw_open), no 57-cell witness")
     ap.add_argument("--state-compact", action="store_true", help="super: State rows without their limb / byte columns (ZK_OPT_STATE_COMPACT)")
     ap.add_argument("--no-oneshot-leg", action="store_true", help="super: skip the block one-shot side measurement (block.BlockVerifier)")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the cold-cache kernel timing after the timed region")
@@ -791,6 +800,8 @@ def main():
     args = ap.parse_args()
     global STATE_COMPACT
     STATE_COMPACT = bool(args.state_compact)
+    global STATE_FUSED
+    STATE_FUSED = bool(args.state_fused)
     # what the side legs (tools/bench_legs.py) need from this file: the builders, the timing loop and the roofline blocks
     CORE = types.SimpleNamespace(BUILDERS=BUILDERS, timed_passes=timed_passes, resolve_super=resolve_super, roofline_block=roofline_block,
                                  tx_extras=tx_extras, oneshot_profile_numbers=oneshot_profile_numbers)
@@ -945,7 +956,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "port", "sample": "timed at N = 1 only (run without --gpus)"}
     if sess is not None:
         sess.close()
-    if rank == 0 and args.workload == "super" and world == 1 and w.env is not None and not args.no_oneshot_leg:
+    if rank == 0 and args.workload == "super" and world == 1 and w.env is not None and not args.no_oneshot_leg and not STATE_FUSED:
         # (after the resident sessions are closed: the block's four chains want hardware queues of their own, and the six resident
         # sessions' streams would share them — measured 1.12 ms with them open against 0.94 ms alone)
         try:

@@ -47,6 +47,10 @@ def fused(rows, flags, device):
         r = s.run()
         st = s.read_status()
         assert r.rows_evaluated == s.n == len(st)
+        for _ in range(2):  # resident passes: the session keeps the sorted order / root ranks, the HIP library launches the evaluation kernel alone
+            rb = s.run()
+            assert (rb.fail_count, rb.first_fail_row, rb.first_fail_code) == (r.fail_count, r.first_fail_row, r.first_fail_code)
+            assert np.array_equal(s.read_status(), st)
     r1, st1 = oneshot.state_verify_from_rw(rw, fl, device=device)
     assert np.array_equal(st, st1) and (r1.fail_count, r1.first_fail_row, r1.first_fail_code) == (r.fail_count, r.first_fail_row, r.first_fail_code)
     return r, st

@@ -154,7 +154,17 @@ def test_block_super_circuit_on_device():
     def run(pp):
         with SuperCircuit(pp) as sc:
             sc.launch()
-            return sc.collect()[0]
+            res = sc.collect()[0]
+        # the same block with no State witness in HBM (state_fused: rows evaluated from the RW table where they are computed; two resident
+        # passes): every circuit's verdict — count, first failing row, code — is the 57-cell form's
+        with SuperCircuit(pp, to_device=dev, state_fused=True) as sf:
+            assert sf.state_fused and sf.rows == sc.rows
+            for _ in range(2):
+                sf.launch()
+                rf = sf.collect()[0]
+                assert {k: (r.fail_count, r.first_fail_row, r.first_fail_code) for k, r in rf.items()} == \
+                       {k: (r.fail_count, r.first_fail_row, r.first_fail_code) for k, r in res.items()}
+        return res
 
     # (1) a Stack read's value: the EVM circuit (the step that looks the row up) and the State circuit (read consistency)
     i = next(j for j in range(2000, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)

@@ -242,6 +242,11 @@ def other_configs(core, ctx, args):
                     blk_c = own_process_config(name, log_rows, steps, warmup, args, False, extra=("--state-compact",))
                     if blk_c is not None:
                         out[f"{name}_2p{log_rows}_compact"] = blk_c
+                    # ... and with no State witness at all: the rows evaluated from the RW table where they are computed (a labelled third figure)
+                    blk_f = own_process_config(name, log_rows, steps, warmup, args, False, extra=("--state-fused",))
+                    if blk_f is not None:
+                        blk_f.pop("block_oneshot", None)  # (the block one-shot is the same call whatever the resident form)
+                        out[f"{name}_2p{log_rows}_fused"] = blk_f
                 continue
         t_build = time.perf_counter()
         w = core.BUILDERS[name](ctx, log_rows, False)

@@ -15,8 +15,9 @@ to_dev = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 els
 lib = _lib.init(0)
 w = synth_evm_trace(n, seed=3)
 w.pop("meta")
-with engine.open_evm({k: to_dev(v) for k, v in w.items()}) as s:
-    for _ in range(5):
+single = os.environ.get("SINGLE_PASS", "0") == "1"  # the one-shot form: staged from the 416-byte step rows (no packed step records)
+with engine.open_evm({k: to_dev(v) for k, v in w.items()}, single_pass=single) as s:
+    for _ in range(1 if single else 5):
         s.launch()
     r = s.collect()
     buf = np.zeros(1024 * 4 * 8, dtype=np.uint64)

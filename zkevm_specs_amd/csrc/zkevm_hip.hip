@@ -597,6 +597,9 @@ struct zk_session {
     RekeyArgs rekey;
     RwkPlan rekey_plan_host;      // the compact-key plan as uploaded (host copy owned by the session: the upload needs no synchronisation of its own)
     bool assign_from_rw = false;  // SESSION_ASSIGN over an RW table: every pass starts with the re-keying and the sort (rekey)
+    bool fused_order_ready = false;  // fused_verify: a collect has seen a pass without rejected RW rows / failed ops — the sorted order, the
+                                     // first-access links and the MPT root ranks stay with the session (they are to this form what the
+                                     // assigned rows are to the 57-cell form) and later passes launch the evaluation kernel alone
     bool fused_verify = false;    // SESSION_ASSIGN whose rows are evaluated where they are computed (zk_state_verify_from_rw_open):
                                   // d_tally[0] = the State circuit's tally, d_tally[1] = rejected RW rows + failed assignments
     u32* rekey_status = nullptr;  // ... whose per-RW-row codes go here (the session's statuses are per op)
@@ -2380,7 +2383,8 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     ZkTally* const tally = twin_tally ? s->d_tally + (s->tally_pass++ & 1u) : s->d_tally;
     s->tally_last = tally;
     if (!twin_tally && !(s->kind == SESSION_EVM && s->evm.perm))
-        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(s->fused_verify ? 2 : 1), 0, s->stream, s->d_tally, s->kind == SESSION_EVM ? s->evm.defer_count : (u32*)nullptr);
+        hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3((s->fused_verify && !s->fused_order_ready) ? 2 : 1), 0, s->stream, s->d_tally,
+                           s->kind == SESSION_EVM ? s->evm.defer_count : (u32*)nullptr);
     u32* status = status_dev ? status_dev : s->d_status;
     // the state-sorted EVM pass attaches its two timing events to the kernel dispatches themselves (hipExtLaunchKernelGGL):
     // no separate event packets between the sort passes and the evaluation kernels
@@ -2411,8 +2415,10 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     case SESSION_KECCAK: zk_launch_keccak_table(s->stream, s->keccak_gen, status, s->d_tally); break;
     case SESSION_ASSIGN:
         if (s->fused_verify) {
-            zk_launch_state_rekey(s->stream, s->rekey, s->rekey_status, s->d_tally + 1);
-            zk_launch_state_assign(s->stream, s->assign, nullptr, nullptr);  // (the roots alone: root_rank is set)
+            if (!s->fused_order_ready) {  // (a session's RW table does not change between passes)
+                zk_launch_state_rekey(s->stream, s->rekey, s->rekey_status, s->d_tally + 1);
+                zk_launch_state_assign(s->stream, s->assign, nullptr, nullptr);  // (the roots alone: root_rank is set)
+            }
             zk_launch_state_rows_fused(s->stream, s->state, s->assign, status, s->d_tally, s->d_tally + 1);
             break;
         }
@@ -2577,6 +2583,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
             s->launches = 0;
             return -1;
         }
+        if (s->fused_verify && s->launches > 0) s->fused_order_ready = true;
     }
     if (read_ranges) {
         s->evm_ranges_known = 1;

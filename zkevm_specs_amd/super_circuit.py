@@ -158,7 +158,7 @@ class SuperCircuit:
     """Sessions of the four circuits over one witness set; launch() enqueues one pass of each, collect() returns
     ({circuit: Result}, total fail_count, first failing (circuit, row, code))."""
 
-    def __init__(self, parts, device=None, to_device=None, shard=None, state_compact=False):
+    def __init__(self, parts, device=None, to_device=None, shard=None, state_compact=False, state_fused=False):
         """shard = (rank, world): ONE global block, every circuit's rows cut into `world` contiguous ranges with that
         circuit's halo (distributed.HALO), all tables whole on every rank (BASELINE configs[4]).  The
         witness assignment (State / Bytecode / Copy rows from ops / unrolled codes / copy events) runs over the whole
@@ -179,7 +179,20 @@ class SuperCircuit:
         # cells; the decompositions are derived where the checks use them).  Only for rows derived on the device from the RW table.
         self.state_compact = bool(state_compact) and self.state_from_rw
         nc = 15 if self.state_compact else 57
-        if self.state_from_rw:
+        # state_fused: no State witness in HBM at all — the State session evaluates op2row's rows where it computes them, from the block's RW
+        # table through the sorted order (zk_state_verify_from_rw_open; what zk_block_verify does for a block seen once).  The session keeps
+        # the order, the first-access links and the MPT root ranks after its first pass, so a resident pass is the evaluation kernel alone.
+        # Whole blocks only (a sharded State range needs the 57-cell rows' halo handling).
+        self.state_fused = bool(state_fused) and self.state_from_rw and world == 1 and not self.state_compact
+        st_fused = None
+        if self.state_fused:
+            st_fused = engine.open_state_verify_from_rw(evm_w["rw"], evm_w["rw_flags"], device=device)
+            self._keep.append(st_fused)
+            res0 = st_fused.run()  # re-keying + sort + MPT roots + first evaluation; raises if the assignment itself fails
+            self.assign_ms = res0.kernel_ms
+            rows = flags = mpt = None
+            res = None
+        elif self.state_from_rw:
             # State rows: the block's own RW table re-keyed, sorted and assigned on the device in one session (zk_state_assign_from_rw:
             # Target -> Tag / key slots, LSD radix sort on (tag, id, address, field_tag, storage_key, rw_counter), op2row) — no host step
             ops = op_flags = None
@@ -201,7 +214,7 @@ class SuperCircuit:
         else:
             ops, op_flags = (dev(a) for a in parts["state_ops"])
         # State rows: assigned on the device from the op list, then evaluated from the same HBM buffers
-        if self.state_from_rw:
+        if self.state_from_rw or self.state_fused:
             pass
         elif on_dev:
             import torch
@@ -218,9 +231,10 @@ class SuperCircuit:
             with engine.open_state_assign(ops, op_flags, device=device) as a:
                 res = a.run()
                 rows, flags, mpt = a.read()
-        if not res.ok:
-            raise exception_for_code(res.first_fail_code, f"state witness assignment: op {res.first_fail_row}")
-        self.assign_ms = res.kernel_ms
+        if res is not None:
+            if not res.ok:
+                raise exception_for_code(res.first_fail_code, f"state witness assignment: op {res.first_fail_row}")
+            self.assign_ms = res.kernel_ms
         _, bc_keccak, r = parts["bytecode"]
         # Bytecode circuit rows: assigned on the device from the EVM circuit's own bytecode table
         ub_rows, ub_off, ub_len, k = parts["bytecode_unrolled"]
@@ -270,7 +284,7 @@ class SuperCircuit:
             evm_w["copy"] = copy_open[2]  # the copy table the SHA3 / CODECOPY steps look up = the table of the very events the Copy circuit checks
 
         tx_w = {k: dev(v) for k, v in tx.items()}
-        self.global_rows = {"evm": int(evm_w["steps"].shape[0]) - 1, "state": int(rows.shape[1]), "bytecode": int(dev_rows.shape[1]),
+        self.global_rows = {"evm": int(evm_w["steps"].shape[0]) - 1, "state": st_fused.n if st_fused is not None else int(rows.shape[1]), "bytecode": int(dev_rows.shape[1]),
                             "tx": int(tx_w["bytes"].shape[0])}
         self.row_lo = {k: 0 for k in self.global_rows}
         ranges = {}
@@ -283,7 +297,7 @@ class SuperCircuit:
             tx_w, self.row_lo["tx"] = distributed.shard_units(tx_w, rank, world)
         self.sessions = {
             "evm": engine.open_evm(evm_w, device=device, side_stream=True),
-            "state": engine.open_state(rows, flags, mpt, device=device, compact=self.state_compact),
+            "state": st_fused if st_fused is not None else engine.open_state(rows, flags, mpt, device=device, compact=self.state_compact),
             "bytecode": engine.open_bytecode(dev_rows, dev(bc_keccak), r, device=device),
             "tx": engine.open_sign(tx_w, r_tx, False, device=device),
         }
