@@ -32,6 +32,7 @@ PY
     prof-state)   tools/profile_bench.sh state_2p16 --workload state --steps 50 --warmup 5 > $out/prof_state.log 2>&1; tail -2 $out/prof_state.log | cut -c1-300 ;;
     prof-tx)      tools/profile_bench.sh tx_2p14 --workload tx --steps 6 --warmup 2 > $out/prof_tx.log 2>&1; tail -2 $out/prof_tx.log | cut -c1-300 ;;
     prof-super)   tools/profile_bench.sh super_2p20 --workload super --steps 10 --warmup 3 > $out/prof_super.log 2>&1; tail -2 $out/prof_super.log | cut -c1-300 ;;
+    prof-super-fused) tools/profile_bench.sh super_fused_2p20 --workload super --state-fused --steps 10 --warmup 3 > $out/prof_super_fused.log 2>&1; tail -2 $out/prof_super_fused.log | cut -c1-300 ;;
     prof-rows)    PROFILE_CMD="python $PWD/tools/bench_row_kernels.py" LOGN=${LOGN:-20} tools/profile_bench.sh row_kernels > $out/prof_rows.log 2>&1; tail -2 $out/prof_rows.log | cut -c1-300 ;;
     prof-rekey)   PROFILE_CMD="python $PWD/tools/bench_rekey.py 18 8" tools/profile_bench.sh rekey_2p18 > $out/prof_rekey.log 2>&1; tail -2 $out/prof_rekey.log | cut -c1-300 ;;
     rows)     python tools/bench_row_kernels.py > $out/row_kernels.txt 2>&1; tail -1 $out/row_kernels.txt > $out/row_kernels.json; cut -c1-600 $out/row_kernels.json ;;
