@@ -133,6 +133,28 @@ lib = _lib.load()
 h = ctypes.c_void_p()
 assert lib.zk_dist_init((ctypes.c_uint8 * 128)(), 1, 2, ctypes.byref(h)) != 0 and b"world must be 1" in lib.zk_last_error()
 out["dist"] = "ok"
+
+# the block's six circuits over one consistent witness, with the 57-cell State witness and with none (state_fused: the State rows evaluated from
+# the RW table where they are computed, two passes over the same session): equal verdicts, clean and with a damaged RW value
+from zkevm_specs_amd.super_circuit import SuperCircuit, synth_super_block
+p = synth_super_block(13, seed=3)
+rw = p["evm"]["rw"]
+i = next(j for j in range(500, rw.shape[0]) if int(rw[j, 2, 0]) == 8 and int(rw[j, 1, 0]) == 0)  # a Stack read
+tallies = {}
+for damaged in (False, True):
+    if damaged:
+        rw[i, 8, 0] ^= np.uint64(1)
+    for fused in (False, True):
+        with SuperCircuit(p, state_fused=fused) as sc:
+            assert sc.state_fused == fused
+            for _ in range(2):
+                sc.launch()
+                res, total, first = sc.collect()
+                tallies[(damaged, fused, _)] = {k: (r.fail_count, r.first_fail_row, r.first_fail_code) for k, r in res.items()}
+    assert tallies[(damaged, True, 0)] == tallies[(damaged, True, 1)] == tallies[(damaged, False, 0)], damaged
+assert all(v == (0, None, 0) for v in tallies[(False, True, 0)].values())
+assert tallies[(True, True, 0)]["state"][0] >= 1 and tallies[(True, True, 0)]["evm"][0] >= 1
+out["super_fused"] = "ok"
 print("RESULT " + json.dumps(out))
 '''
 
