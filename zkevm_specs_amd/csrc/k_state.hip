@@ -133,12 +133,14 @@ static void launch_group(hipStream_t st, const StateArgs& a, u32* status, ZkTall
     const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(state_rows_group_kernel<L>), dim3(grid), dim3(ZK_STATE_QUAD_BLOCK), 0, st, a, status, tally);
 }
-void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally) {
+bool zk_state_rows_events_ride(const StateArgs& a) { return a.rows.skip || state_use_dma(); }
+void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally, hipEvent_t e0, hipEvent_t e1) {
     const int block = 256;
     if (a.rows.skip) {
         const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;
         const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
-        hipLaunchKernelGGL(state_rows_compact_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);
+        if (e0 || e1) hipExtLaunchKernelGGL(state_rows_compact_kernel, dim3(grid), dim3(block), 0, st, e0, e1, 0, a, status, tally);
+        else hipLaunchKernelGGL(state_rows_compact_kernel, dim3(grid), dim3(block), 0, st, a, status, tally);
         return;
     }
     if (!state_use_dma()) {
@@ -162,5 +164,6 @@ void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTal
     }
     const u64 rows_per_block = (u64)(block / 64) * ST_ROWS_PER_WAVE;  // 63 evaluated rows per wavefront
     const u32 grid = (u32)((a.eval_hi - a.eval_lo + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(state_rows_dma_kernel, dim3(grid), dim3(block), lds, st, a, status, tally);
+    if (e0 || e1) hipExtLaunchKernelGGL(state_rows_dma_kernel, dim3(grid), dim3(block), lds, st, e0, e1, 0, a, status, tally);
+    else hipLaunchKernelGGL(state_rows_dma_kernel, dim3(grid), dim3(block), lds, st, a, status, tally);
 }

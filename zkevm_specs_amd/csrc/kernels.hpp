@@ -43,7 +43,10 @@ __device__ __forceinline__ void tally_commit(ZkTally* tally, u64 row, u32 code) 
 #define ST_ROWS_PER_WAVE 63
 
 // ---- launchers (defined in the k_*.hip units) ------------------------------------------------------------------------
-void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally);
+// e0 / e1 (optional): the pass's start / stop events ride on the dispatch itself (no event packets between back-to-back passes) when
+// zk_state_rows_events_ride(a) says the launch is one kernel of a form that takes them; otherwise the caller records them around the call
+void zk_launch_state_rows(hipStream_t st, const StateArgs& a, u32* status, ZkTally* tally, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+bool zk_state_rows_events_ride(const StateArgs& a);
 // hot: e0 rides on the dispatch as its start event; cold: e1 as its stop event (either may be null)
 void zk_launch_evm_hot(hipStream_t st, u32 grid, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e0, hipEvent_t e1 = nullptr);
 void zk_launch_evm_warm(hipStream_t st, u32 grid, u32 warm_lanes, const EvmArgs& a, const u32* group_start, u32* status, ZkTally* tally, hipEvent_t e1);

@@ -2405,9 +2405,13 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         if (side == s->stream) side = nullptr;
     }
     if (side) evm_ext_events = false;  // the pass's events are the fork / join records themselves
+    // State sessions: one kernel per pass — its two events ride on the dispatch too (back-to-back passes of 2^16 rows were 28.6 us of
+    // kernel in 35.5 us per pass: two event packets between consecutive launches)
+    const bool state_ext_events = timed && s->kind == SESSION_STATE && zk_state_rows_events_ride(s->state);
+    if (state_ext_events) evm_ext_events = true;  // (same handling below: nothing is recorded around the launch)
     if (timed && !evm_ext_events && !side) HIP_TRY(hipEventRecord(e0, s->stream));
     switch (s->kind) {
-    case SESSION_STATE: zk_launch_state_rows(s->stream, s->state, status, tally); break;
+    case SESSION_STATE: zk_launch_state_rows(s->stream, s->state, status, tally, state_ext_events ? e0 : nullptr, state_ext_events ? e1 : nullptr); break;
     case SESSION_BYTECODE: zk_launch_bytecode_rows(s->stream, s->bytecode, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_COPY: zk_launch_copy_rows(s->stream, s->copy, range_lo(s), range_hi(s), status, tally); break;
     case SESSION_SIGN: zk_launch_sign_units(s->stream, s->sign, range_lo(s), range_hi(s), status, tally); break;
