@@ -485,18 +485,18 @@ def timed_oneshots(ctx, w, steps, warmup):
     fails = 0
     ctx.barrier()
     t0 = time.perf_counter()
-    # the per-step read of the device spans is one C call into preallocated doubles (the timed region holds as little of the
-    # measurement itself as possible: engine.last_timing allocates three ctypes objects per call, ~2 us of Python per step)
-    tm = [ctypes.c_double(), ctypes.c_double(), ctypes.c_double()]
-    p_tm = [ctypes.byref(x) for x in tm]
-    read_timing = lib.zk_last_timing
+    # the device spans of the K timed steps (HIP events riding on each step's first and last dispatch) are summed inside the library and
+    # read ONCE behind the loop (zk_timing_sums): the timed region holds one foreign call per step and nothing of the measurement itself
+    sums, cnt = (ctypes.c_double * 3)(), ctypes.c_uint64()
+    lib.zk_timing_sums(sums, ctypes.byref(cnt), 1)  # reset (the warm-up steps' spans)
     order = [shots[(warmup + i) % len(shots)] for i in range(steps)]
     for shot in order:
         fails += shot().fail_count
-        read_timing(p_tm[0], p_tm[1], p_tm[2])
-        spans[0] += tm[0].value; spans[1] += tm[1].value; spans[2] += tm[2].value
     ctx.barrier()
     dt = time.perf_counter() - t0
+    lib.zk_timing_sums(sums, ctypes.byref(cnt), 1)
+    assert cnt.value == steps, (cnt.value, steps)
+    spans = [sums[0], sums[1], sums[2]]
     res = shots[(warmup + steps - 1) % len(shots)].result()
     res.fail_count = fails
     hp = (ctypes.c_double * 4)()

@@ -494,6 +494,10 @@ int zk_read_status(zk_session* s, uint32_t* status_host);
  * zk_last_timing: the same for the calling thread's last one-shot zk_evm_verify, plus its pass span (== zk_result.kernel_ms). */
 int zk_session_timing(zk_session* s, double* open_ms, double* span_ms);
 int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms);
+/* The same three spans SUMMED over the calling thread's one-shot zk_evm_verify calls since the last reset (sums_ms[3]: open, pass,
+ * span; *count = calls summed; reset != 0 clears them after reading): a caller that wants the mean span of K timed calls reads once
+ * behind the loop instead of once per call (bench.py's timed region: one foreign call per step instead of two). */
+int zk_timing_sums(double* sums_ms, uint64_t* count, int reset);
 /* Host microseconds the calling thread's last one-shot zk_evm_verify spent inside its open / launch / collect / close calls
  * (tuning aid: where the wall time beyond the device span goes). */
 int zk_last_host_phases(double* us4);

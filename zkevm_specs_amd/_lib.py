@@ -22,7 +22,7 @@ LIB_PATH = CPU_LIB_PATH if BACKEND == "cpu" else (os.environ.get("ZK_HIP_LIB") o
 EXPORTED_SYMBOLS = [
     "zk_init", "zk_shutdown", "zk_set_stream", "zk_session_set_stream", "zk_last_error", "zk_fr_op",
     "zk_state_open", "zk_state_set_range", "zk_set_range", "zk_state_verify", "zk_evm_open", "zk_evm_verify", "zk_evm_verify_batch", "zk_bytecode_open", "zk_bytecode_verify", "zk_exp_open", "zk_exp_verify", "zk_copy_open", "zk_copy_verify", "zk_sign_open", "zk_sign_verify",
-    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_state_ops_from_rw_open", "zk_state_ops_from_rw_read", "zk_state_ops_from_rw", "zk_state_assign_from_rw_open", "zk_state_verify_from_rw_open", "zk_state_verify_from_rw", "zk_block_verify", "zk_ecdsa_open", "zk_ecdsa_open_batches", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_pi_copy_open", "zk_pi_copy_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing", "zk_last_host_phases", "zk_dist_unique_id", "zk_dist_init", "zk_dist_tally", "zk_dist_close",
+    "zk_keccak_open", "zk_keccak_read_rows", "zk_keccak_table", "zk_state_assign_open", "zk_state_assign_read", "zk_state_assign", "zk_state_ops_from_rw_open", "zk_state_ops_from_rw_read", "zk_state_ops_from_rw", "zk_state_assign_from_rw_open", "zk_state_verify_from_rw_open", "zk_state_verify_from_rw", "zk_block_verify", "zk_ecdsa_open", "zk_ecdsa_open_batches", "zk_ecdsa_verify", "zk_bytecode_assign_open", "zk_bytecode_assign_read", "zk_bytecode_assign", "zk_pi_open", "zk_pi_verify", "zk_pi_copy_open", "zk_pi_copy_verify", "zk_copy_assign_sizes", "zk_copy_assign_open", "zk_copy_assign_read", "zk_copy_assign", "zk_launch", "zk_collect", "zk_read_status", "zk_close", "zk_session_timing", "zk_last_timing", "zk_timing_sums", "zk_last_host_phases", "zk_dist_unique_id", "zk_dist_init", "zk_dist_tally", "zk_dist_close",
 ]
 
 OPT_DEVICE_PTRS = 1
@@ -223,6 +223,7 @@ def _bind(lib):
     lib.zk_session_timing.argtypes = [vp, dp, dp]
     lib.zk_last_timing.argtypes = [dp, dp, dp]
     lib.zk_last_host_phases.argtypes = [dp]
+    lib.zk_timing_sums.argtypes = [dp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.zk_dist_unique_id.argtypes = [ctypes.c_void_p]
     lib.zk_dist_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.zk_dist_tally.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]

@@ -256,6 +256,11 @@ extern "C" int zk_last_host_phases(double* us4) {
     if (us4) for (int k = 0; k < 4; k++) us4[k] = -1.0;
     return 0;
 }
+extern "C" int zk_timing_sums(double* sums_ms, uint64_t* count, int) {  // (no device spans on this backend)
+    if (sums_ms) for (int k = 0; k < 3; k++) sums_ms[k] = -1.0;
+    if (count) *count = 0;
+    return 0;
+}
 extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {
     if (open_ms) *open_ms = -1.0;
     if (pass_ms) *pass_ms = -1.0;

@@ -41,6 +41,8 @@ static thread_local int t_device = -1;              // device selected by this t
 static thread_local hipStream_t t_stream = nullptr;  // stream new sessions of this thread are bound to
 static thread_local std::string g_err;
 static thread_local double t_host_phase[4] = {0, 0, 0, 0};  // zk_last_host_phases: host microseconds inside open / launch / collect / close of the last one-shot
+static thread_local double t_timing_sum[3] = {0, 0, 0};  // zk_timing_sums
+static thread_local uint64_t t_timing_count = 0;
 static thread_local double t_timing[3] = {0, 0, 0};  // zk_last_timing: open span, pass span, first open dispatch -> last pass dispatch (ms)
 
 #define HIP_TRY(expr)                                                                         \
@@ -1174,6 +1176,8 @@ extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* st
     if (!rc) {
         t_timing[1] = result->kernel_ms;
         session_timing(s, result->kernel_ms, &t_timing[0], &t_timing[2]);
+        for (int k = 0; k < 3; k++) t_timing_sum[k] += t_timing[k];
+        t_timing_count++;
     }
     if (!rc && status_out && !dev) rc = zk_read_status(s, status_out);
     zk_close(s);
@@ -2657,6 +2661,12 @@ extern "C" int zk_session_timing(zk_session* s, double* open_ms, double* span_ms
 }
 extern "C" int zk_last_host_phases(double* us4) {
     if (us4) for (int k = 0; k < 4; k++) us4[k] = t_host_phase[k];
+    return 0;
+}
+extern "C" int zk_timing_sums(double* sums_ms, uint64_t* count, int reset) {
+    if (sums_ms) for (int k = 0; k < 3; k++) sums_ms[k] = t_timing_sum[k];
+    if (count) *count = t_timing_count;
+    if (reset) { t_timing_sum[0] = t_timing_sum[1] = t_timing_sum[2] = 0; t_timing_count = 0; }
     return 0;
 }
 extern "C" int zk_last_timing(double* open_ms, double* pass_ms, double* span_ms) {
