@@ -276,6 +276,39 @@ def test_oneshot_lazy_tail_with_empty_warm_and_cold_ranges():
         assert (res.fail_count, res.first_fail_row, res.first_fail_code) == (res0.fail_count, res0.first_fail_row, res0.first_fail_code)
 
 
+def test_resident_session_passes_alternate_tallies_and_deferred_counters():
+    """Round 6: a resident session sorts once and needs no reset kernel per pass — the passes alternate between the result block's two
+    tallies / deferred-pair counters, each hot launch clearing the pair of the pass after it.  Five passes per session, collected one by
+    one and in groups (launch, launch, collect), over traces with failing rows AND pairs the fast kernel defers (wide word cells): every
+    collect reports the oracle's tally, every status array the oracle's codes."""
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "evm_wide_cells.npz")
+    cases = [c for c in load_cases(fn) if "#fuzz" in c[0]]
+    n = 0
+    for name, w, opts, _ in cases[::11]:
+        exp = oracle_status(w, opts)
+        if not any(exp):
+            continue
+        with engine.open_evm({k: v for k, v in w.items()}, bool(opts[0]), bool(opts[1])) as s:
+            for k in range(5):
+                if k == 3:
+                    s.launch()  # two passes behind one collect: the report is the last one's
+                res = s.run()
+                _check_tally(res, exp)
+                assert s.read_status().tolist() == exp, (name, k)
+        n += 1
+    assert n >= 15
+    # and a larger mixed trace (no deferred pairs, ~40 failing rows) through seven passes
+    w = {k: v for k, v in synth_evm_trace(1 << 13, seed=21).items() if k != "meta"}
+    rng = random.Random(9)
+    for _ in range(40):
+        w = fuzz_wire(w, rng, copy=False)
+    exp = oracle_status(w)
+    with engine.open_evm(w) as s:
+        for k in range(7):
+            _check_tally(s.run(), exp)
+        assert s.read_status().tolist() == exp
+
+
 def test_caller_status_buffer_is_final_after_a_stream_sync():
     """a pair the fast kernel defers (here: wide word cells, >= 2^128) must have its verdict in a caller-provided
     status_dev once the stream has drained — no zk_collect in between (include/zkevm_hip.h, zk_launch)."""

@@ -78,6 +78,8 @@ struct EvmArgs {
     const u32* perm;  // optional: lane t evaluates pair perm[t] (state-sorted order); nullptr = identity
     u32 n_pairs;      // n_steps - 1
     u32 opts;         // bit0 begin_with_first_step, bit1 end_with_last_step
+    u32* defer_count_twin;  // optional (resident device sessions): the NEXT pass's deferred-pair counter — the hot launch clears it, and the twin of its
+                            // tally, for the pass after it (kernels.hpp tally_clear_twin), so that no reset kernel sits in front of every pass
 };
 
 ZK_HD void evm_args_resolve(EvmArgs& a) {

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void evm_steps_kernel(EvmArgs a, const 
     // of three dependent round trips of 2-3 us each under load.
     u32 perm_t = 0;
     if (G == EVM_GROUP_ALL && a.perm) perm_t = a.perm[(u64)blockIdx.x * blockDim.x + threadIdx.x];
+    if (G == EVM_GROUP_ALL && a.defer_count_twin != nullptr) {  // resident sessions: this launch readies the next pass's tally and counter
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_twin = 0u;
+        tally_clear_twin(tally);
+    }
     __shared__ u64 s_dir[G == EVM_GROUP_ALL ? EVM_DIR_LDS_U64 : 1];
     const bool have_dir = G == EVM_GROUP_ALL && a.dyn != nullptr && a.codes.slots != nullptr && a.codes.entries != nullptr;
     if (have_dir) {

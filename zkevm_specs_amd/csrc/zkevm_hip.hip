@@ -560,7 +560,8 @@ __global__ __launch_bounds__(64) void evm_publish_kernel(const u32* d, u32* h, u
 // What zk_collect reads back from an EVM session, contiguous at the start of the session's zero-filled region.
 struct EvmResultBlock {
     EvmDyn dyn;                      // n_deferred
-    u32 pad0[(64 - sizeof(EvmDyn)) / 4];
+    u32 n_deferred_twin;             // the deferred-pair counter of the odd passes of a resident session (EvmArgs::defer_count_twin)
+    u32 pad0[(64 - sizeof(EvmDyn)) / 4 - 1];
     ZkTally tally[2];                // offset 64
     u32 group_start[EVM_N_GROUPS + 1];  // offset 96
     u32 pad1[8 - (EVM_N_GROUPS + 1)];
@@ -612,6 +613,7 @@ struct zk_session {
     uint16_t* d_bin16 = nullptr;  // EVM: sort bin of every pair, written by the histogram pass
     u32 evm_pass = 0;
     bool perm_ready = false; // EVM: zk_evm_open already enqueued the counting sort of the first pass
+    u32 evm_tally_idx = 0;   // EVM: which of the result block's two tallies / deferred counters the current pass uses (resident sessions alternate)
     bool perm_valid = false; // EVM: the state-sorted mapping of this session's (fixed) step table exists: later passes evaluate through it
     int evm_ranges_known = 0;       // EVM: 1 once a collect has read the warm / cold lane ranges of this session's (fixed) step table ...
     bool evm_warm_empty = false, evm_cold_empty = false;  // ... empty ranges are not launched again
@@ -2358,8 +2360,8 @@ static int evm_enqueue_tail(zk_session* s) {
         s->evm_cold_empty = !run_cold;
     }
     s->early_seq = 0;
-    if (run_warm) zk_launch_evm_warm(s->stream, s->tail_cold_grid, warm_lanes, s->evm, s->d_group_start, s->tail_status, s->d_tally, run_cold ? nullptr : s->tail_e1);
-    if (run_cold) zk_launch_evm_cold(s->stream, s->tail_cold_grid, s->evm, s->d_group_start, s->tail_status, s->d_tally, s->tail_e1);
+    if (run_warm) zk_launch_evm_warm(s->stream, s->tail_cold_grid, warm_lanes, s->evm, s->d_group_start, s->tail_status, s->tally_last, run_cold ? nullptr : s->tail_e1);
+    if (run_cold) zk_launch_evm_cold(s->stream, s->tail_cold_grid, s->evm, s->d_group_start, s->tail_status, s->tally_last, s->tail_e1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2448,9 +2450,18 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
             // them — and every later pass only resets its tally.  (Until round 6 every pass re-derived it: histogram 10.5 + scatter 7.5 us
             // of a 74-us resident pass, 26 + 19 us beside the other circuits of a block pass.  ZK_EVM_RESORT=1 restores that.)
             static const bool resort = [] { const char* e = getenv("ZK_EVM_RESORT"); return e && e[0] == '1'; }();
-            if (s->perm_ready) { s->perm_ready = false; s->perm_valid = true; }  // the open's launches carried this pass's sort (and reset the tally)
-            else if (s->perm_valid && !resort) hipLaunchKernelGGL(tally_reset_kernel, dim3(1), dim3(1), 0, s->stream, s->d_tally, s->evm.defer_count);
-            else { int prc = evm_build_perm(s); if (prc) return prc; s->perm_valid = true; }
+            // ... and needs no reset kernel either: the passes alternate between the result block's two tallies / deferred-pair counters, and
+            // every hot launch clears the pair the NEXT pass will use (EvmArgs::defer_count_twin), as the single-kernel row sessions do
+            if (s->perm_ready) { s->perm_ready = false; s->perm_valid = true; s->evm_tally_idx = 0; }  // the open's launches carried this pass's sort (and reset tally 0)
+            else if (s->perm_valid && !resort) s->evm_tally_idx ^= 1u;
+            else { int prc = evm_build_perm(s); if (prc) return prc; s->perm_valid = true; s->evm_tally_idx = 0; }
+            {
+                EvmResultBlock* const rb = (EvmResultBlock*)s->d_result;
+                u32* const dc[2] = {&rb->dyn.n_deferred, &rb->n_deferred_twin};
+                s->evm.defer_count = dc[s->evm_tally_idx];
+                s->evm.defer_count_twin = resort ? nullptr : dc[s->evm_tally_idx ^ 1u];
+                s->tally_last = s->d_tally + s->evm_tally_idx;
+            }
         }
         // with the sorted mapping the hot lane range is padded per state (EVM_PERM_PAD bounds the padding); blocks past its end exit
         const u32 grid = (u32)((s->n + (s->evm.perm ? EVM_PERM_PAD : 0) + EVM_HOT_BLOCK - 1) / EVM_HOT_BLOCK);
@@ -2473,13 +2484,13 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
             HIP_TRY(hipEventRecord(fork, s->stream));
             HIP_TRY(hipStreamWaitEvent(side, fork, 0));
             if (run_warm)
-                zk_launch_evm_warm(side, cold_grid, s->evm_ranges_known ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->d_tally, nullptr);
-            if (run_cold) zk_launch_evm_cold(side, cold_grid, s->evm, s->d_group_start, status, s->d_tally, nullptr);
+                zk_launch_evm_warm(side, cold_grid, s->evm_ranges_known ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->tally_last, nullptr);
+            if (run_cold) zk_launch_evm_cold(side, cold_grid, s->evm, s->d_group_start, status, s->tally_last, nullptr);
             HIP_TRY(hipEventRecord(s->ev_join, side));
-            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, nullptr, nullptr);
+            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->tally_last, nullptr, nullptr);
             HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
             if (status_dev && s->evm.defer_count) {
-                zk_launch_evm_deferred(s->stream, s->evm, status, s->d_tally);
+                zk_launch_evm_deferred(s->stream, s->evm, status, s->tally_last);
                 s->deferred_pending = false;
             }
             break;
@@ -2487,7 +2498,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
         if (sorted && !s->evm_ranges_known && s->early_seq && !status_dev && evm_ext_events) {
             // lazy tail: the hot build alone (it carries both events); the warm / cold builds follow from evm_enqueue_tail once the
             // open's scatter has told the host which of their ranges are not empty
-            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, e0, e1);
+            zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->tally_last, e0, e1);
             s->tail_pending = true;
             s->tail_cold_grid = cold_grid;
             s->tail_status = status;
@@ -2495,17 +2506,17 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
             break;
         }
         hipEvent_t e_hot1 = (evm_ext_events && !run_warm && !run_cold) ? e1 : nullptr;  // the hot dispatch carries both events then
-        zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e0 : nullptr, e_hot1);
+        zk_launch_evm_hot(s->stream, grid, s->evm, s->d_group_start, status, s->tally_last, evm_ext_events ? e0 : nullptr, e_hot1);
         if (run_warm)
-            zk_launch_evm_warm(s->stream, cold_grid, (sorted && s->evm_ranges_known) ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->d_tally,
+            zk_launch_evm_warm(s->stream, cold_grid, (sorted && s->evm_ranges_known) ? s->evm_warm_lanes : 0u, s->evm, s->d_group_start, status, s->tally_last,
                                (evm_ext_events && !run_cold) ? e1 : nullptr);
-        if (run_cold) zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->d_tally, evm_ext_events ? e1 : nullptr);
+        if (run_cold) zk_launch_evm_cold(s->stream, cold_grid, s->evm, s->d_group_start, status, s->tally_last, evm_ext_events ? e1 : nullptr);
         // A caller who hands over its own status buffer may read it after its own stream synchronisation, without zk_collect:
         // the general build is enqueued right behind the pass (it reads the deferred count on the device and returns at once
         // when it is zero), so that buffer — and the tally — are final in stream order.  Passes into the session's own buffer
         // keep the lazy form (zk_collect / zk_read_status look at the count in the synchronisation they need anyway).
         if (status_dev && s->evm.defer_count) {
-            zk_launch_evm_deferred(s->stream, s->evm, status, s->d_tally);
+            zk_launch_evm_deferred(s->stream, s->evm, status, s->tally_last);
             s->deferred_pending = false;
         }
         break;
@@ -2530,7 +2541,7 @@ static int evm_finish_deferred(zk_session* s) {
     s->deferred_pending = false;
     if (n_def) {
         s->stream_drained = false;  // (something is enqueued behind the polled result: zk_close must wait again)
-        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
+        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->tally_last);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -2579,7 +2590,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
             HIP_TRY(hipStreamSynchronize(s->stream));
         }
         const EvmResultBlock* h = (const EvmResultBlock*)s->h_result;
-        n_def = h->dyn.n_deferred;
+        n_def = s->evm_tally_idx ? h->n_deferred_twin : h->dyn.n_deferred;
         for (int k = 0; k <= EVM_N_GROUPS; k++) gs[k] = h->group_start[k];
         t = h->tally[s->tally_last - s->d_tally];
     } else {
@@ -2610,7 +2621,7 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
         s->deferred_pending = false;
         if (n_def) {  // the general build decides the pairs the fast kernel left (see evm_finish_deferred), then the tally is final
             s->stream_drained = false;  // (something is enqueued behind the polled result: zk_close must wait again)
-        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->d_tally);
+        zk_launch_evm_deferred(s->stream, s->evm, s->last_status, s->tally_last);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&t, s->tally_last, sizeof t, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
