@@ -630,6 +630,7 @@ struct zk_session {
     void* d_result = nullptr;
     void* h_result = nullptr;
     u32 publish_seq = 0;        // ZK_POLL_RESULT: sequence number of the last evm_publish_kernel (the flag word behind the block)
+    bool publish_enqueued = false;  // ... which is already in the stream behind the pass (evm_publish_enqueue: the batch entry enqueues it a witness ahead of the collect)
     u32* h_result_dev = nullptr;  // the device alias of h_result (queried once, at open)
     // Lazy tail (one-shot sessions): the open's scatter writes the warm / cold lane counts into the page-locked block (sequence number
     // early_seq); zk_launch enqueues the hot build only, and whoever consumes the pass first (evm_enqueue_tail) enqueues the builds whose
@@ -1164,6 +1165,8 @@ fail:
 }
 
 static void session_timing(zk_session* s, double pass_ms, double* open_ms, double* span_ms);
+static int evm_enqueue_tail(zk_session* s);
+static bool evm_publish_enqueue(zk_session* s);
 extern "C" int zk_evm_verify(const zk_evm_tables* t, uint32_t opts, uint32_t* status_out, zk_result* result) {
     ARG_TRY(result, "zk_evm_verify: result is null");
     zk_session* s = nullptr;
@@ -1226,6 +1229,13 @@ extern "C" int zk_evm_verify_batch(const zk_evm_tables* const* t, uint64_t n, ui
             rc = zk_evm_open(t[i], opts | ZK_OPT_SINGLE_PASS, &pend[slot]);
             t_stream = caller;
             if (!rc) rc = zk_launch(pend[slot], nullptr);
+        }
+        // the witness launched one iteration ago (the other slot): the open's sort has long told the host its lane ranges — enqueue what is
+        // left of its pass and its publish kernel now, behind its hot kernel, instead of when the next iteration comes to collect it
+        zk_session* const o = pend[slot ^ 1];
+        if (!rc && o && !o->publish_enqueued) {
+            rc = evm_enqueue_tail(o);
+            if (!rc) o->publish_enqueued = evm_publish_enqueue(o);
         }
     }
     for (int k = 0; k < 2; k++)
@@ -2371,6 +2381,7 @@ extern "C" int zk_launch(zk_session* s, uint32_t* status_dev) {
     s->stream_drained = false;
     HIP_TRY(hipSetDevice(s->device));
     { int trc = evm_enqueue_tail(s); if (trc) return trc; }  // (a pass launched twice without a collect in between)
+    s->publish_enqueued = false;  // (a publish kernel already behind the previous pass says nothing about this one)
     s->status_external = status_dev != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = s->launches < (u32)MAX_EVENT_PAIRS;
@@ -2547,6 +2558,17 @@ static int evm_finish_deferred(zk_session* s) {
     return 0;
 }
 
+// The publish kernel of a pass (zk_collect's polled result block), enqueued behind whatever the pass has in the stream.  zk_collect calls it;
+// zk_evm_verify_batch calls it a witness ahead, so that the block is on its way to the host when the collect comes to poll for it.
+static bool evm_publish_enqueue(zk_session* s) {
+    if (s->kind != SESSION_EVM || !s->d_result || !s->h_result || !s->h_result_dev || !evm_poll_enabled()) return false;
+    u32* hw = (u32*)s->h_result;
+    const u32 seq = ++s->publish_seq ? s->publish_seq : ++s->publish_seq;  // never 0
+    __atomic_store_n(&hw[32], 0u, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(evm_publish_kernel, dim3(1), dim3(64), 0, s->stream, (const u32*)s->d_result, s->h_result_dev, seq);
+    return hipGetLastError() == hipSuccess;
+}
+
 extern "C" int zk_collect(zk_session* s, zk_result* r) {
     ARG_TRY(s && r, "zk_collect: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
@@ -2568,10 +2590,10 @@ extern "C" int zk_collect(zk_session* s, zk_result* r) {
             u32* hw = (u32*)s->h_result;
             void* const hd = s->h_result_dev;
             if (hd) {
-                const u32 seq = ++s->publish_seq ? s->publish_seq : ++s->publish_seq;  // never 0
-                __atomic_store_n(&hw[32], 0u, __ATOMIC_RELEASE);
-                hipLaunchKernelGGL(evm_publish_kernel, dim3(1), dim3(64), 0, s->stream, (const u32*)s->d_result, (u32*)hd, seq);
-                if (hipGetLastError() == hipSuccess) {
+                const bool launched = s->publish_enqueued || evm_publish_enqueue(s);
+                s->publish_enqueued = false;
+                const u32 seq = s->publish_seq;
+                if (launched) {
                     const auto t0 = std::chrono::steady_clock::now();
                     u64 spins = 0;
                     while (__atomic_load_n(&hw[32], __ATOMIC_ACQUIRE) != seq) {
