@@ -279,7 +279,7 @@ def test_hip_matches_openssl_vectors(golden_dir):
     off = _offcurve_cases()
     assert engine.ecdsa_status(off).tolist() == E.verify_packed(off, None)
     edge = _group_law_edge_cases()
-    for lanes in ("1", "2"):  # one lane per signature / lane pairs (the library picks by batch size; both forms on every vector here)
+    for lanes in ("1", "2", "4"):  # one lane per signature / lane pairs / lane quads (the library picks by batch size; every form on every vector here)
         os.environ["ZK_ECDSA_LANES"] = lanes
         try:
             assert engine.ecdsa_status(edge).tolist() == E.verify_packed(edge, None)

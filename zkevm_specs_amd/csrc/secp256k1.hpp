@@ -654,7 +654,7 @@ struct EcdsaArgs {
     u32 out_stride;
     u32* qtab;             // per-lane tables of the key's multiples, word w of entry e of lane l at qtab[(e * 24 + w) * qtab_lanes + l]
     u64 qtab_lanes;
-    u32 lanes_per_sig;     // 1: one lane runs both halves of the GLV split; 2: a lane pair, one half each
+    u32 lanes_per_sig;     // 1: one lane runs both halves of the GLV split; 2: a lane pair, one half each; 4: two more lanes for the halves of u1 G (ecdsa_partial4)
     const u32* gcomb;      // optional: the 8-bit fixed-base table of G built on the device (ecdsa_comb_entry), nullptr: 4-bit constant table
     // A second batch in the same launch (zk_ecdsa_open_batches): signatures [n0, n) come from these arrays (the Tx circuit's and
     // the Sig circuit's chips of one block: two launches of 2^14 signatures each ran 1.9 ms side by side where one launch of
@@ -1069,6 +1069,50 @@ ZK_HD SpPoint ecdsa_partial(const EcdsaPrep& pr, int h_lo, int h_hi, u32* tab, u
         }
     }
     for (int h = h_lo; h <= h_hi; h++) ecdsa_add_g_half(acc, pr.kg[h], h, gcomb);
+    return acc;
+}
+// Four lanes per signature (small batches: the chip is far from full, the chain is what counts): roles 0 / 1 ride the two GLV halves of
+// u2 Q through the windowed ladder as above WITHOUT their half of u1 G; roles 2 / 3 carry that half — sixteen comb additions each —
+// and make them in the ladder's own addition slots (one sp_add_ip call site for the whole wavefront: the comb lanes sit out the
+// doublings and hand their point to the add the ladder lanes execute anyway).  The sixteen mixed additions a lane pair made behind its
+// ladder (176 of ~1,700 dependent products) disappear from the chain; the price is one more addition when the four partial sums meet.
+ZK_HD SpPoint ecdsa_partial4(const EcdsaPrep& pr, int role, u32* tab, u64 stride, const u32* gcomb) {
+    if (role < 2) {  // the table of this half's base, as in ecdsa_partial
+        const Fr beta = secp_beta();
+        Fr bx = role == 1 ? spf_mul(pr.qx, beta) : pr.qx;
+        Fr by = pr.neg[role] ? spf_sub(fr_zero(), pr.qy) : pr.qy;
+        SpPoint b;
+        b.X = bx; b.Y = by; b.Z = SecpP::one();
+        sp_tab_store(tab, stride, 0, b);
+        for (int k = 1; k <= 7; k++) {
+            SpPoint d = sp_tab_load(tab, stride, k - 1);
+            sp_dbl_ip(d);
+            sp_tab_store(tab, stride, 2 * k - 1, d);
+            sp_add_affine_ip(d, bx, by);
+            sp_tab_store(tab, stride, 2 * k, d);
+        }
+    }
+    SpPoint acc = sp_infinity();
+    for (int w = 31; w >= 0; w--) {
+        if (role < 2 && w != 31) {
+            for (int k = 0; k < 4; k++) sp_dbl_ip(acc);
+        }
+        SpPoint t = sp_infinity();
+        bool have = false;
+        if (role < 2) {
+            const u32 d = sp_digit4(pr.kq[role], w);
+            if (d) { t = sp_tab_load(tab, stride, (int)d - 1); have = true; }
+        } else if (w < 16) {
+            const Fr& kg = pr.kg[role - 2];
+            const u32 d = (kg.v[w >> 2] >> (8 * (w & 3))) & 0xffu;
+            if (d) {
+                sp_load_affine(gcomb + ((u64)(16 * (role - 2) + w) * 255u + (d - 1u)) * 16u, t.X, t.Y);
+                t.Z = SecpP::one();
+                have = true;
+            }
+        }
+        if (have) sp_add_ip(acc, t);
+    }
     return acc;
 }
 ZK_HD u32 ecdsa_verdict(const EcdsaPrep& pr, const SpPoint& C) {

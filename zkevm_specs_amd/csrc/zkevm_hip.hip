@@ -1856,9 +1856,12 @@ extern "C" int zk_ecdsa_open_batches(const zk_ecdsa_batch* bt, uint32_t n_batche
         }
     }
     // lane pairs while the batch cannot fill the chip anyway (the pass is then bound by one lane's dependent chain: halve it);
-    // one lane per signature beyond that (less total work).  ZK_ECDSA_LANES=1|2 overrides (tuning / tests).
-    a.lanes_per_sig = n <= (1ull << 16) ? 2u : 1u;
-    if (const char* e = getenv("ZK_ECDSA_LANES")) a.lanes_per_sig = atoi(e) == 2 ? 2u : 1u;
+    // one lane per signature beyond that (less total work); lane quads up to 2^14 signatures — one wavefront per SIMD at most —, where the
+    // two extra lanes take u1 G off the pair's chain (secp256k1.hpp ecdsa_partial4: 1.09-1.11 -> 0.99-1.02 ms; 2^15 signatures as quads
+    // are two wavefronts per SIMD: 1.67 ms against 1.13).  ZK_ECDSA_LANES=1|2|4 overrides (tuning / tests).
+    a.lanes_per_sig = n <= (1ull << 14) ? 4u : n <= (1ull << 16) ? 2u : 1u;
+    if (const char* e = getenv("ZK_ECDSA_LANES")) { const int v = atoi(e); a.lanes_per_sig = v == 4 ? 4u : v == 2 ? 2u : 1u; }
+    if (a.lanes_per_sig == 4u && !a.gcomb) a.lanes_per_sig = 2u;  // (the four-lane form takes u1 G from the comb table)
     a.first = 0;
     a.qtab_lanes = ((n * a.lanes_per_sig + 63) / 64) * 64;
     if (a.qtab_lanes > ZK_ECDSA_CHUNK_LANES) a.qtab_lanes = ZK_ECDSA_CHUNK_LANES;  // larger batches: chunked launches over one set of tables
