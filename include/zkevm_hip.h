@@ -350,7 +350,7 @@ int zk_state_verify_from_rw(const uint64_t* rw, const uint32_t* rw_flags, uint64
  *      units' meta column in place.  zk_launch / zk_collect / zk_read_status as for the circuits (the tally counts
  *      the signatures that did not verify).
  *      Device memory: the kernel keeps a 1,440-byte table of the key's multiples per lane (one lane per signature above 2^16
- *      signatures, a lane pair below): at most 2^17 lanes' worth (189 MB) is allocated per session; larger batches run as
+ *      signatures, a lane pair below, four lanes up to 2^14): at most 2^17 lanes' worth (189 MB) is allocated per session; larger batches run as
  *      consecutive launches over the same tables. */
 int zk_ecdsa_open(const uint8_t* bytes, uint32_t layout, const uint32_t* v, uint32_t v_stride, uint64_t n,
                   uint32_t* out_dev, uint32_t out_stride, uint32_t opts, zk_session** out);
